@@ -1,0 +1,54 @@
+"""Build libbpp_hip.so (gfx950) in-tree with hipcc.  Called by __graft_entry__.build() and by tests."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libbpp_hip.so")
+HOSTTEST_LIB = os.path.join(HERE, "libbpp_hosttest.so")
+SOURCES = ["engine.hip"]
+HEADERS = ["field.h", "scalar.h", "point.h", "merlin.h", "blake2b.h", "kernels_verify.h", "msm.h",
+           "field_consts.inc", "scalar_consts.inc", os.path.join("..", "..", "include", "bpp.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into libbpp_hip.so (cross-compiles without a GPU)."""
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+def build_hosttest(force=False):
+    """Host-compiled probes of the shared host/device arithmetic headers (CPU test suite only)."""
+    src = os.path.join(CSRC, "hosttest.cpp")
+    deps = [src] + [os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _stale(HOSTTEST_LIB, deps):
+        return HOSTTEST_LIB
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", HOSTTEST_LIB, src], check=True, cwd=CSRC)
+    return HOSTTEST_LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    build_hosttest(force="--force" in sys.argv)

@@ -1,0 +1,75 @@
+"""ctypes binding of include/bpp.h.  There is no fallback: a missing or unloadable libbpp_hip.so raises."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbpp_hip.so")
+
+u8p = POINTER(c_uint8)
+
+
+class VerifyItem(Structure):
+    _fields_ = [("proof", c_void_p), ("proof_len", c_size_t), ("commitments32", c_void_p), ("m", c_uint32),
+                ("min_values", c_void_p), ("min_present", c_void_p), ("seed_nonce32", c_void_p),
+                ("transcript_state", c_void_p), ("transcript_label", c_void_p), ("label_len", c_size_t)]
+
+
+class Profile(Structure):
+    _fields_ = [(n, c_float) for n in ("transcripts_ms", "decompress_ms", "chain_host_ms", "scalars_ms", "reduce_ms",
+                                       "msm_digits_ms", "msm_sort_ms", "msm_accumulate_ms", "msm_bucket_reduce_ms",
+                                       "msm_final_ms", "total_ms")] + \
+               [(n, c_uint32) for n in ("msm_terms", "msm_window_bits", "msm_windows", "msm_groups")]
+
+
+# every symbol include/bpp.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("bpp_ctx_create", c_int, [POINTER(c_void_p), c_int]),
+    ("bpp_ctx_create_on_stream", c_int, [POINTER(c_void_p), c_int, c_void_p]),
+    ("bpp_ctx_destroy", None, [c_void_p]),
+    ("bpp_ctx_last_error", c_char_p, [c_void_p]),
+    ("bpp_precomp_create", c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_uint64)]),
+    ("bpp_precomp_destroy", c_int, [c_void_p, c_uint64]),
+    ("bpp_msm_mixed", c_int, [c_void_p, c_uint64, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("bpp_msm_vartime", c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("bpp_msm_vartime_batched", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("bpp_params_create", c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, POINTER(c_uint64)]),
+    ("bpp_params_destroy", c_int, [c_void_p, c_uint64]),
+    ("bpp_params_export", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("bpp_pedersen_commit", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_uint32, c_size_t, c_void_p]),
+    ("bpp_verify_batch", c_int, [c_void_p, c_uint64, POINTER(VerifyItem), c_size_t, c_int, c_size_t, c_void_p,
+                                 c_void_p, c_void_p, c_size_t]),
+    ("bpp_batch_upload", c_int, [c_void_p, c_uint64, POINTER(VerifyItem), c_size_t, POINTER(c_uint64), c_void_p,
+                                 c_size_t]),
+    ("bpp_batch_destroy", c_int, [c_void_p, c_uint64]),
+    ("bpp_verify_resident", c_int, [c_void_p, c_uint64, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t]),
+    ("bpp_verify_phase1", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_size_t]),
+    ("bpp_weights_from_chain", c_int, [c_void_p, c_size_t, c_void_p]),
+    ("bpp_verify_phase2", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t]),
+    ("bpp_accumulators_sum_is_identity", c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_int)]),
+    ("bpp_batch_trace", c_int, [c_void_p, c_uint64, c_int, c_void_p, c_size_t, POINTER(c_size_t)]),
+    ("bpp_batch_shape", c_int, [c_void_p, c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32),
+                                POINTER(c_uint32), POINTER(c_uint32)]),
+    ("bpp_profile_enable", c_int, [c_void_p, c_int]),
+    ("bpp_profile_get", c_int, [c_void_p, POINTER(Profile)]),
+    ("bpp_transcript_new", c_int, [c_void_p, c_size_t, c_void_p]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libbpp_hip.so and bind every declared symbol; raises if the extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libbpp_hip.so is missing (%s): run __graft_entry__.build(); there is no CPU fallback"
+                           % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

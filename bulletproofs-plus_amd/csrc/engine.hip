@@ -1,0 +1,1192 @@
+// libbpp_hip.so -- host side of the C ABI in include/bpp.h.  No CPU fallback: every entry point needs a gfx950 device.
+//
+// Host responsibilities (mirroring what the reference does around its hot loops):
+//   * argument / wire-format checks with the reference's error kinds and precedence
+//     (src/range_proof.rs:719-734, :610-709, :875-888, :1155-1257; src/range_statement.rs:36-73)
+//   * packing a batch into the HBM layout documented in kernels_verify.h
+//   * the batch-weight transcript (src/range_proof.rs:811,849,853,894): a sequential sponge, run on the host
+//   * SHAKE256 / SHA3-512 byte streams for generator derivation (src/generators/generators_chain.rs:23-33,
+//     src/protocols/curve_point_protocol.rs:31-35); the hash-to-group map itself runs on the device
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bpp.h"
+#include "kernels_verify.h"
+#include "msm.h"
+
+using namespace bpp;
+
+namespace {
+
+// ------------------------------------------------------------------ utilities
+struct EngineError {
+  int code;
+  std::string msg;
+};
+
+#define HIP_CHECK(expr)                                                                          \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      char _b[256];                                                                              \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      throw EngineError{BPP_ERR_ENGINE, _b};                                                     \
+    }                                                                                            \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    if (count <= n && p) return;
+    release();
+    if (count == 0) count = 1;
+    HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+    n = count;
+  }
+};
+
+struct ProofErr {
+  int code;
+  std::string msg;
+};
+
+void set_err(char *errbuf, size_t len, const std::string &m) {
+  if (errbuf && len) {
+    snprintf(errbuf, len, "%s", m.c_str());
+  }
+}
+
+// ------------------------------------------------------------------ host hashing helpers (keccak from merlin.h)
+void keccak_sponge(const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen, uint32_t rate, uint8_t pad) {
+  uint64_t st[25];
+  memset(st, 0, sizeof(st));
+  uint8_t *sb = (uint8_t *)st;  // little-endian host
+  size_t off = 0;
+  while (inlen - off >= rate) {
+    for (uint32_t i = 0; i < rate; i++) sb[i] ^= in[off + i];
+    keccak_f1600(st);
+    off += rate;
+  }
+  for (size_t i = 0; i < inlen - off; i++) sb[i] ^= in[off + i];
+  sb[inlen - off] ^= pad;
+  sb[rate - 1] ^= 0x80;
+  keccak_f1600(st);
+  size_t o = 0;
+  while (o < outlen) {
+    size_t take = (outlen - o < rate) ? outlen - o : rate;
+    memcpy(out + o, sb, take);
+    o += take;
+    if (o < outlen) keccak_f1600(st);
+  }
+}
+void shake256(const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen) { keccak_sponge(in, inlen, out, outlen, 136, 0x1f); }
+void sha3_512(const uint8_t *in, size_t inlen, uint8_t out[64]) { keccak_sponge(in, inlen, out, 64, 72, 0x06); }
+
+// weight transcript (src/range_proof.rs:811,849,853,894)
+void weights_from_chain_host(const uint8_t *rng32, size_t n, uint8_t *weights32) {
+  Strobe wt;
+  const char *lbl = "Bulletproofs+ verifier weights";
+  merlin_new(wt, (const uint8_t *)lbl, (uint32_t)strlen(lbl));
+  for (size_t i = 0; i < n; i++) merlin_append_message(wt, (const uint8_t *)"proof", 5, rng32 + 32 * i, 32);
+  uint8_t zero32[32] = {0};
+  merlin_rng_finalize(wt, zero32);  // build_rng().finalize(&mut NullRng)
+  for (size_t i = 0; i < n; i++) {
+    sc w;
+    do {  // Scalar::random_not_zero (src/protocols/scalar_protocol.rs:23-30)
+      uint8_t wide[64];
+      merlin_rng_fill(wt, wide, 64);
+      sc_mont_from_wide(w, wide);
+    } while (sc_iszero(w));
+    sc_from_mont(w, w);
+    sc_store_words(weights32 + 32 * i, w);
+  }
+}
+
+// ------------------------------------------------------------------ objects
+struct Params {
+  uint32_t n_bits, m_max, t;
+  DevBuf<niels> table;  // [2*n*m_max interleaved G,H | t g_bases | h_base]
+  uint32_t table_len;
+  DevBuf<uint8_t> d_hg32;           // compressed H, G_0..G_{t-1}
+  std::vector<uint8_t> hg32;        // host copy
+  std::vector<uint8_t> gi32, hi32;  // compressed generators, party-major
+};
+
+struct Precomp {
+  DevBuf<niels> table;
+  uint32_t count;
+};
+
+struct MsmWork {
+  DevBuf<int16_t> digits;
+  DevBuf<uint32_t> counts, starts, cursor, sorted;
+  DevBuf<ge> buckets, Q, W, R;
+  DevBuf<uint8_t> comp32;
+  DevBuf<uint32_t> is_identity;
+  DevBuf<uint32_t> term_sidx, term_pidx, group_off;
+  MsmPlan plan{};
+  uint32_t max_group_terms = 0;
+};
+
+struct Batch {
+  Params *params = nullptr;
+  uint64_t params_handle = 0;
+  uint32_t B = 0, rmax = 0, cs = 0, max_mn = 0, total_dyn = 0, sum_m = 0, cols = 0;
+  std::vector<ProofDesc> desc;
+  std::vector<uint8_t> rounds_bad;  // 0 ok, 3 InvalidLength, 5 SizeOverflow  (src/range_proof.rs:875-888)
+  bool any_seed = false;
+  // device-resident inputs
+  DevBuf<uint8_t> bytes, states, seeds;
+  DevBuf<ProofDesc> d_desc;
+  DevBuf<uint64_t> minvals;
+  DevBuf<uint32_t> src_off, owner;
+  // device work buffers
+  DevBuf<sc> chal, rows, scal;
+  DevBuf<uint8_t> rng_out, weights, masks, chal_bytes;
+  DevBuf<uint32_t> status, group_first;
+  DevBuf<niels> dynpts;
+  MsmWork msm;
+  // layout of the last verify
+  size_t last_chunk = (size_t)-1;
+  uint32_t G = 0;
+  std::vector<uint32_t> h_group_first;
+  std::vector<uint8_t> h_rng, h_weights;
+  std::vector<uint32_t> h_status;
+  bool have_trace = false;
+};
+
+}  // namespace
+
+struct bpp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  std::mutex mu;
+  uint64_t next_handle = 1;
+  std::map<uint64_t, std::unique_ptr<Params>> params;
+  std::map<uint64_t, std::unique_ptr<Precomp>> precomps;
+  std::map<uint64_t, std::unique_ptr<Batch>> batches;
+  bool profile = false;
+  bpp_profile prof{};
+  hipEvent_t ev[16];
+  bool ev_ready = false;
+};
+
+namespace {
+
+int fail(bpp_ctx *ctx, int code, const std::string &m, char *errbuf = nullptr, size_t len = 0) {
+  if (ctx) ctx->err = m;
+  set_err(errbuf, len, m);
+  return code;
+}
+
+struct StageTimer {
+  bpp_ctx *ctx;
+  int idx = 0;
+  explicit StageTimer(bpp_ctx *c) : ctx(c) {
+    if (ctx->profile && !ctx->ev_ready) {
+      for (auto &e : ctx->ev) HIP_CHECK(hipEventCreate(&e));
+      ctx->ev_ready = true;
+    }
+  }
+  void mark() {
+    if (ctx->profile && idx < 16) HIP_CHECK(hipEventRecord(ctx->ev[idx++], ctx->stream));
+  }
+  float between(int a, int b) {
+    float ms = 0;
+    if (ctx->profile && b < idx) HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]));
+    return ms;
+  }
+};
+
+inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------ MSM driver
+uint32_t choose_window(uint32_t group_terms) {
+  // buckets per window ~ terms / 12  (bucket lists of ~12 points keep the per-lane chains short)
+  uint32_t c = 4;
+  while (c < 14 && (1u << c) * 12u <= group_terms) c++;  // nb = 2^(c-1)
+  return c;
+}
+
+void msm_prepare(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &sidx, const std::vector<uint32_t> &pidx,
+                 const std::vector<uint32_t> &goff) {
+  const uint32_t G = (uint32_t)goff.size() - 1, n = (uint32_t)sidx.size();
+  uint32_t maxg = 0;
+  for (uint32_t g = 0; g < G; g++) maxg = std::max(maxg, goff[g + 1] - goff[g]);
+  MsmPlan plan;
+  plan.c = choose_window(maxg);
+  plan.K = (254 + plan.c - 1) / plan.c;
+  plan.nb = 1u << (plan.c - 1);
+  plan.G = G;
+  plan.n_terms = n;
+  w.plan = plan;
+  w.max_group_terms = maxg;
+  const size_t nbk = (size_t)G * plan.K * plan.nb;
+  w.digits.alloc((size_t)n * plan.K);
+  w.counts.alloc(nbk);
+  w.starts.alloc(nbk);
+  w.cursor.alloc(nbk);
+  w.sorted.alloc((size_t)n * plan.K);
+  w.buckets.alloc(nbk);
+  w.Q.alloc((size_t)G * plan.K * plan.c);
+  w.W.alloc((size_t)G * plan.K);
+  w.R.alloc(G);
+  w.comp32.alloc((size_t)G * 32);
+  w.is_identity.alloc(G);
+  w.term_sidx.alloc(n);
+  w.term_pidx.alloc(n);
+  w.group_off.alloc(G + 1);
+  HIP_CHECK(hipMemcpyAsync(w.term_sidx.p, sidx.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(w.term_pidx.p, pidx.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(w.group_off.p, goff.data(), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));  // host vectors may go away
+}
+
+void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, StageTimer *tm) {
+  const MsmPlan plan = w.plan;
+  const size_t nbk = (size_t)plan.G * plan.K * plan.nb;
+  hipStream_t s = ctx->stream;
+  HIP_CHECK(hipMemsetAsync(w.counts.p, 0, nbk * 4, s));
+  HIP_CHECK(hipMemsetAsync(w.cursor.p, 0, nbk * 4, s));
+  dim3 gt(cdiv(w.max_group_terms, 256), plan.G);
+  hipLaunchKernelGGL(k_msm_digits, gt, dim3(256), 0, s, scalars, w.term_sidx.p, w.group_off.p, plan, w.digits.p,
+                     w.counts.p);
+  if (tm) tm->mark();
+  hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, w.counts.p, w.starts.p, (uint32_t)nbk);
+  hipLaunchKernelGGL(k_msm_scatter, gt, dim3(256), 0, s, w.digits.p, w.group_off.p, plan, w.starts.p, w.cursor.p,
+                     w.sorted.p);
+  if (tm) tm->mark();
+  hipLaunchKernelGGL(k_msm_accumulate, dim3(cdiv((uint32_t)nbk, 64)), dim3(64), 0, s, w.sorted.p, w.starts.p,
+                     w.counts.p, w.term_pidx.p, tabs, (uint32_t)nbk, w.buckets.p);
+  if (tm) tm->mark();
+  hipLaunchKernelGGL(k_msm_bitsum, dim3(plan.c, plan.K, plan.G), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.Q.p);
+  hipLaunchKernelGGL(k_msm_window, dim3(cdiv(plan.G * plan.K, 64)), dim3(64), 0, s, w.Q.p, plan, w.W.p);
+  if (tm) tm->mark();
+  hipLaunchKernelGGL(k_msm_final, dim3(cdiv(plan.G, 64)), dim3(64), 0, s, w.W.p, plan, w.R.p, w.comp32.p,
+                     w.is_identity.p);
+  if (tm) tm->mark();
+  HIP_CHECK(hipGetLastError());
+}
+
+// decompress `n` host points into a device niels table; returns number of bad encodings
+uint32_t decompress_to_device(bpp_ctx *ctx, const uint8_t *pts32, size_t n, niels *out) {
+  DevBuf<uint8_t> d_in;
+  DevBuf<uint32_t> d_bad;
+  d_in.alloc(n * 32);
+  d_bad.alloc(1);
+  HIP_CHECK(hipMemcpyAsync(d_in.p, pts32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIP_CHECK(hipMemsetAsync(d_bad.p, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(k_decompress_plain, dim3(cdiv((uint32_t)n, 64)), dim3(64), 0, ctx->stream, d_in.p, (uint32_t)n, out,
+                     d_bad.p);
+  uint32_t bad = 0;
+  HIP_CHECK(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return bad;
+}
+
+// generic MSM over host scalars with a prepared device point table layout
+int msm_host_entry(bpp_ctx *ctx, const niels *tab_a, uint32_t n_a, const uint8_t *static_scalars32, size_t n_static,
+                   const uint8_t *dyn_scalars32, const uint8_t *dyn_points32, size_t n_dyn,
+                   const uint32_t *group_off_in, size_t n_groups, uint8_t *out32) {
+  // scalars: [static | dynamic], canonical check
+  const size_t n = n_static + n_dyn;
+  std::vector<uint8_t> sb(n * 32 + 32);
+  if (n_static) memcpy(sb.data(), static_scalars32, n_static * 32);
+  if (n_dyn) memcpy(sb.data() + n_static * 32, dyn_scalars32, n_dyn * 32);
+  for (size_t i = 0; i < n; i++)
+    if (!sc_is_canonical(sb.data() + 32 * i)) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "scalar is not canonical");
+  if (n == 0 || n_groups == 0) {  // empty sum = identity
+    for (size_t g = 0; g < (n_groups ? n_groups : 1); g++) memset(out32 + 32 * g, 0, 32);
+    return BPP_OK;
+  }
+  DevBuf<sc> d_sc;
+  DevBuf<niels> d_dyn;
+  d_sc.alloc(n);
+  d_dyn.alloc(n_dyn);
+  HIP_CHECK(hipMemcpyAsync(d_sc.p, sb.data(), n * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (n_dyn) {
+    uint32_t bad = decompress_to_device(ctx, dyn_points32, n_dyn, d_dyn.p);
+    if (bad) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "point is not a canonical ristretto255 encoding");
+  }
+  std::vector<uint32_t> sidx(n), pidx(n), goff;
+  for (size_t i = 0; i < n; i++) {
+    sidx[i] = (uint32_t)i;
+    pidx[i] = (i < n_static) ? (uint32_t)i : (uint32_t)(n_a + (i - n_static));
+  }
+  if (group_off_in) {
+    goff.assign(group_off_in, group_off_in + n_groups + 1);
+  } else {
+    goff = {0u, (uint32_t)n};
+  }
+  MsmWork w;
+  msm_prepare(ctx, w, sidx, pidx, goff);
+  PointTables tabs{tab_a, d_dyn.p, n_a};
+  msm_run(ctx, w, d_sc.p, tabs, nullptr);
+  HIP_CHECK(hipMemcpyAsync(out32, w.comp32.p, 32 * (goff.size() - 1), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return BPP_OK;
+}
+
+// ------------------------------------------------------------------ batch upload (host parsing + packing)
+struct ParsedItem {
+  uint32_t t, rounds;
+};
+
+// RangeProof::from_bytes (src/range_proof.rs:1155-1257): structure + canonical scalars; points are not validated here
+void parse_proof(const uint8_t *p, size_t len, ParsedItem &out) {
+  if (len < 1) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Serialized proof is too short"};
+  uint32_t t = p[0];
+  if (t < 1 || t > 6) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Extension degree not valid"};
+  size_t body = len - 1, nchunks = body / 32, rem = body % 32;
+  auto need = [&](size_t idx) {
+    if (idx >= nchunks) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Serialized proof is too short"};
+  };
+  auto scalar_at = [&](size_t idx) {
+    need(idx);
+    if (!sc_is_canonical(p + 1 + 32 * idx)) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Invalid parsing"};
+  };
+  for (size_t k = 0; k < t; k++) scalar_at(k);
+  need(t);
+  need(t + 1);
+  need(t + 2);
+  scalar_at(t + 3);
+  scalar_at(t + 4);
+  size_t rest = nchunks - (t + 5);
+  if (rest / 2 == 0) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Serialized proof is too short"};
+  if ((rest % 2) || rem) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Unused data after deserialization"};
+  out.t = t;
+  out.rounds = (uint32_t)(rest / 2);
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int bpp_ctx_create_on_stream(bpp_ctx **out, int device_id, void *hip_stream) {
+  if (!out) return BPP_ERR_BAD_HANDLE;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return BPP_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return BPP_ERR_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BPP_ERR_NO_DEVICE;  // code object is gfx950 only
+  if (hipSetDevice(device_id) != hipSuccess) return BPP_ERR_NO_DEVICE;
+  bpp_ctx *c = new bpp_ctx();
+  c->device = device_id;
+  if (hip_stream) {
+    c->stream = (hipStream_t)hip_stream;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return BPP_ERR_ENGINE;
+    }
+    c->own_stream = true;
+  }
+  *out = c;
+  return BPP_OK;
+}
+
+int bpp_ctx_create(bpp_ctx **out, int device_id) { return bpp_ctx_create_on_stream(out, device_id, nullptr); }
+
+void bpp_ctx_destroy(bpp_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->batches.clear();
+  ctx->precomps.clear();
+  ctx->params.clear();
+  if (ctx->ev_ready)
+    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *bpp_ctx_last_error(bpp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+#define BPP_ENTRY(ctx)                         \
+  if (!(ctx)) return BPP_ERR_BAD_HANDLE;       \
+  std::lock_guard<std::mutex> _lk((ctx)->mu);  \
+  if (hipSetDevice((ctx)->device) != hipSuccess) return BPP_ERR_NO_DEVICE;
+#define BPP_CATCH(ctx, errbuf, len)                                \
+  catch (const EngineError &e) { return fail(ctx, e.code, e.msg, errbuf, len); } \
+  catch (const ProofErr &e) { return fail(ctx, e.code, e.msg, errbuf, len); }    \
+  catch (const std::exception &e) { return fail(ctx, BPP_ERR_ENGINE, e.what(), errbuf, len); }
+
+// ---------------------------------------------------------------- B1
+int bpp_precomp_create(bpp_ctx *ctx, const uint8_t *points32, size_t count, uint64_t *handle) {
+  BPP_ENTRY(ctx);
+  try {
+    if (!handle || (!points32 && count)) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument");
+    auto pc = std::make_unique<Precomp>();
+    pc->count = (uint32_t)count;
+    pc->table.alloc(count);
+    if (count) {
+      uint32_t bad = decompress_to_device(ctx, points32, count, pc->table.p);
+      if (bad) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "point is not a canonical ristretto255 encoding");
+    }
+    uint64_t h = ctx->next_handle++;
+    ctx->precomps[h] = std::move(pc);
+    *handle = h;
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, nullptr, 0)
+}
+
+int bpp_precomp_destroy(bpp_ctx *ctx, uint64_t handle) {
+  BPP_ENTRY(ctx);
+  return ctx->precomps.erase(handle) ? BPP_OK : BPP_ERR_BAD_HANDLE;
+}
+
+int bpp_msm_mixed(bpp_ctx *ctx, uint64_t handle, const uint8_t *static_scalars32, size_t n_static,
+                  const uint8_t *dyn_scalars32, const uint8_t *dyn_points32, size_t n_dyn, uint8_t out_point32[32]) {
+  BPP_ENTRY(ctx);
+  try {
+    auto it = ctx->precomps.find(handle);
+    if (it == ctx->precomps.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown precomputation handle");
+    Precomp &pc = *it->second;
+    if (n_static > pc.count) return fail(ctx, BPP_ERR_INVALID_LENGTH, "more static scalars than precomputed points");
+    return msm_host_entry(ctx, pc.table.p, pc.count, static_scalars32, n_static, dyn_scalars32, dyn_points32, n_dyn,
+                          nullptr, 1, out_point32);
+  }
+  BPP_CATCH(ctx, nullptr, 0)
+}
+
+int bpp_msm_vartime(bpp_ctx *ctx, const uint8_t *scalars32, const uint8_t *points32, size_t n, uint8_t out_point32[32]) {
+  BPP_ENTRY(ctx);
+  try {
+    return msm_host_entry(ctx, nullptr, 0, nullptr, 0, scalars32, points32, n, nullptr, 1, out_point32);
+  }
+  BPP_CATCH(ctx, nullptr, 0)
+}
+
+int bpp_msm_vartime_batched(bpp_ctx *ctx, const uint8_t *scalars32, const uint8_t *points32, const uint32_t *group_off,
+                            size_t n_groups, uint8_t *out_points32) {
+  BPP_ENTRY(ctx);
+  try {
+    if (!group_off || n_groups == 0) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "no groups");
+    for (size_t g = 0; g < n_groups; g++)
+      if (group_off[g + 1] < group_off[g]) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "group offsets not monotone");
+    if (group_off[0] != 0) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "group offsets must start at 0");
+    return msm_host_entry(ctx, nullptr, 0, nullptr, 0, scalars32, points32, group_off[n_groups], group_off, n_groups,
+                          out_points32);
+  }
+  BPP_CATCH(ctx, nullptr, 0)
+}
+
+// ---------------------------------------------------------------- B2: parameters
+int bpp_params_create(bpp_ctx *ctx, uint32_t bit_length, uint32_t max_aggregation, uint32_t extension_degree,
+                      const uint8_t *h_base32, const uint8_t *g_bases32, uint64_t *params) {
+  BPP_ENTRY(ctx);
+  try {
+    // RangeParameters::init checks (src/range_parameters.rs:37-51), ExtensionDegree::try_from (pedersen_gens.rs:68-82)
+    if (!params) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument");
+    if (max_aggregation == 0 || (max_aggregation & (max_aggregation - 1)))
+      return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "Aggregation factor size must be a power of two");
+    if (bit_length == 0 || (bit_length & (bit_length - 1)))
+      return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "Bit length must be a power of two");
+    if (bit_length > 64) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "Bit length must be <= 64");
+    if (extension_degree < 1 || extension_degree > 6)
+      return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "Extension degree not valid");
+    if ((uint64_t)bit_length * max_aggregation > 2048)
+      return fail(ctx, BPP_ERR_SIZE_OVERFLOW, "bit_length * max_aggregation > 2048 is not supported by this engine");
+    auto P = std::make_unique<Params>();
+    P->n_bits = bit_length;
+    P->m_max = max_aggregation;
+    P->t = extension_degree;
+    const uint32_t n = bit_length, m = max_aggregation, t = extension_degree;
+    const uint32_t n_gen = 2 * n * m;
+    P->table_len = n_gen + t + 1;
+    P->table.alloc(P->table_len);
+
+    // uniform bytes for every derived point: interleaved G,H (party-major), then default masking points
+    const uint32_t n_uni = n_gen + 6;
+    std::vector<uint8_t> uni((size_t)n_uni * 64);
+    for (uint32_t party = 0; party < m; party++) {
+      for (int which = 0; which < 2; which++) {
+        uint8_t seed[15 + 5];
+        memcpy(seed, "GeneratorsChain", 15);
+        seed[15] = which ? 'H' : 'G';
+        seed[16] = (uint8_t)party;
+        seed[17] = (uint8_t)(party >> 8);
+        seed[18] = (uint8_t)(party >> 16);
+        seed[19] = (uint8_t)(party >> 24);
+        std::vector<uint8_t> stream((size_t)n * 64);
+        shake256(seed, sizeof(seed), stream.data(), stream.size());
+        for (uint32_t i = 0; i < n; i++) memcpy(&uni[(size_t)(2 * (party * n + i) + which) * 64], &stream[(size_t)i * 64], 64);
+      }
+    }
+    for (int k = 1; k <= 6; k++) {
+      char label[64];
+      int ll = snprintf(label, sizeof(label), "RISTRETTO_MASKING_BASEPOINT_%d", k);
+      sha3_512((const uint8_t *)label, (size_t)ll, &uni[(size_t)(n_gen + k - 1) * 64]);
+    }
+    DevBuf<uint8_t> d_uni, d_comp;
+    DevBuf<niels> d_pts;
+    d_uni.alloc(uni.size());
+    d_comp.alloc((size_t)n_uni * 32);
+    d_pts.alloc(n_uni);
+    HIP_CHECK(hipMemcpyAsync(d_uni.p, uni.data(), uni.size(), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_from_uniform, dim3(cdiv(n_uni, 64)), dim3(64), 0, ctx->stream, d_uni.p, n_uni, d_pts.p, d_comp.p);
+    std::vector<uint8_t> comp((size_t)n_uni * 32);
+    HIP_CHECK(hipMemcpyAsync(comp.data(), d_comp.p, comp.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(P->table.p, d_pts.p, (size_t)n_gen * sizeof(niels), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    P->gi32.resize((size_t)n * m * 32);
+    P->hi32.resize((size_t)n * m * 32);
+    for (uint32_t i = 0; i < n * m; i++) {
+      memcpy(&P->gi32[(size_t)i * 32], &comp[(size_t)(2 * i) * 32], 32);
+      memcpy(&P->hi32[(size_t)i * 32], &comp[(size_t)(2 * i + 1) * 32], 32);
+    }
+    // Pedersen bases: H then G_k (src/ristretto.rs:67-76)
+    P->hg32.resize((size_t)(1 + t) * 32);
+    static const uint8_t BASEPOINT32[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9,
+                                            0x61, 0xc5, 0x00, 0x51, 0x5f, 0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82,
+                                            0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+    memcpy(&P->hg32[0], h_base32 ? h_base32 : BASEPOINT32, 32);
+    for (uint32_t k = 0; k < t; k++)
+      memcpy(&P->hg32[(size_t)(1 + k) * 32], g_bases32 ? g_bases32 + 32 * k : &comp[(size_t)(n_gen + k) * 32], 32);
+    // table tail = [G_0..G_{t-1}, H]
+    std::vector<uint8_t> tail((size_t)(t + 1) * 32);
+    memcpy(&tail[0], &P->hg32[32], (size_t)t * 32);
+    memcpy(&tail[(size_t)t * 32], &P->hg32[0], 32);
+    uint32_t bad = decompress_to_device(ctx, tail.data(), t + 1, P->table.p + n_gen);
+    if (bad) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "Pedersen base point is not a canonical ristretto255 encoding");
+    // validate_and_append_point(H / G) (src/transcripts.rs:72-75): identity encodings are rejected once, here
+    for (uint32_t k = 0; k < 1 + t; k++) {
+      bool z = true;
+      for (int i = 0; i < 32; i++) z = z && P->hg32[(size_t)k * 32 + i] == 0;
+      if (z) return fail(ctx, BPP_ERR_VERIFICATION_FAILED, "Identity element cannot be added to the transcript");
+    }
+    P->d_hg32.alloc(P->hg32.size());
+    HIP_CHECK(hipMemcpy(P->d_hg32.p, P->hg32.data(), P->hg32.size(), hipMemcpyHostToDevice));
+    uint64_t h = ctx->next_handle++;
+    ctx->params[h] = std::move(P);
+    *params = h;
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, nullptr, 0)
+}
+
+int bpp_params_destroy(bpp_ctx *ctx, uint64_t params) {
+  BPP_ENTRY(ctx);
+  return ctx->params.erase(params) ? BPP_OK : BPP_ERR_BAD_HANDLE;
+}
+
+int bpp_params_export(bpp_ctx *ctx, uint64_t params, uint8_t *gi_out32, uint8_t *hi_out32, uint8_t *h_out32,
+                      uint8_t *g_out32) {
+  BPP_ENTRY(ctx);
+  auto it = ctx->params.find(params);
+  if (it == ctx->params.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle");
+  Params &P = *it->second;
+  if (gi_out32) memcpy(gi_out32, P.gi32.data(), P.gi32.size());
+  if (hi_out32) memcpy(hi_out32, P.hi32.data(), P.hi32.size());
+  if (h_out32) memcpy(h_out32, P.hg32.data(), 32);
+  if (g_out32) memcpy(g_out32, P.hg32.data() + 32, (size_t)P.t * 32);
+  return BPP_OK;
+}
+
+int bpp_pedersen_commit(bpp_ctx *ctx, uint64_t params, const uint64_t *values, const uint8_t *blindings32,
+                        uint32_t n_blind, size_t count, uint8_t *commitments32) {
+  BPP_ENTRY(ctx);
+  try {
+    auto it = ctx->params.find(params);
+    if (it == ctx->params.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle");
+    Params &P = *it->second;
+    if (n_blind == 0 || n_blind > P.t) return fail(ctx, BPP_ERR_INVALID_LENGTH, "blinding vector");
+    if (count == 0) return BPP_OK;
+    // group j: value*H + sum_k r_k G_k  -> scalars [v, r_0..], points [H, G_0..] out of the params table
+    const uint32_t per = 1 + n_blind, n_gen = 2 * P.n_bits * P.m_max;
+    std::vector<uint8_t> sb(count * per * 32, 0);
+    std::vector<uint32_t> sidx(count * per), pidx(count * per), goff(count + 1);
+    for (size_t j = 0; j < count; j++) {
+      uint8_t *v = &sb[(j * per) * 32];
+      for (int k = 0; k < 8; k++) v[k] = (uint8_t)(values[j] >> (8 * k));
+      memcpy(v + 32, blindings32 + j * n_blind * 32, (size_t)n_blind * 32);
+      for (uint32_t k = 0; k < n_blind; k++)
+        if (!sc_is_canonical(v + 32 + 32 * k)) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "scalar is not canonical");
+      goff[j] = (uint32_t)(j * per);
+      for (uint32_t k = 0; k < per; k++) {
+        sidx[j * per + k] = (uint32_t)(j * per + k);
+        pidx[j * per + k] = (k == 0) ? (n_gen + P.t) : (n_gen + k - 1);
+      }
+    }
+    goff[count] = (uint32_t)(count * per);
+    DevBuf<sc> d_sc;
+    d_sc.alloc(count * per);
+    HIP_CHECK(hipMemcpyAsync(d_sc.p, sb.data(), sb.size(), hipMemcpyHostToDevice, ctx->stream));
+    MsmWork w;
+    msm_prepare(ctx, w, sidx, pidx, goff);
+    PointTables tabs{P.table.p, nullptr, P.table_len};
+    msm_run(ctx, w, d_sc.p, tabs, nullptr);
+    HIP_CHECK(hipMemcpyAsync(commitments32, w.comp32.p, count * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, nullptr, 0)
+}
+
+int bpp_transcript_new(const uint8_t *label, size_t label_len, uint8_t state203[203]) {
+  if (!state203 || (!label && label_len)) return BPP_ERR_INVALID_ARGUMENT;
+  Strobe s;
+  merlin_new(s, label, (uint32_t)label_len);
+  strobe_to_bytes(state203, s);
+  return BPP_OK;
+}
+
+int bpp_weights_from_chain(const uint8_t *rng32_all, size_t n_total, uint8_t *weights32_out) {
+  if ((!rng32_all || !weights32_out) && n_total) return BPP_ERR_INVALID_ARGUMENT;
+  weights_from_chain_host(rng32_all, n_total, weights32_out);
+  return BPP_OK;
+}
+
+// ---------------------------------------------------------------- B2: batches
+int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, uint64_t *batch,
+                     char *errbuf, size_t errbuf_len) {
+  BPP_ENTRY(ctx);
+  try {
+    auto pit = ctx->params.find(params);
+    if (pit == ctx->params.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle", errbuf, errbuf_len);
+    Params &P = *pit->second;
+    // verify_batch: by definition an empty batch fails (src/range_proof.rs:719-723)
+    if (!items || n_items == 0 || !batch)
+      return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "Range statements or proofs length empty", errbuf, errbuf_len);
+    if (n_items > (1u << 24)) return fail(ctx, BPP_ERR_SIZE_OVERFLOW, "batch too large", errbuf, errbuf_len);
+    auto B = std::make_unique<Batch>();
+    B->params = &P;
+    B->params_handle = params;
+    B->B = (uint32_t)n_items;
+    B->desc.resize(n_items);
+    B->rounds_bad.assign(n_items, 0);
+    std::vector<uint8_t> bytes, seeds(n_items * 32, 0), states;
+    std::vector<uint64_t> minvals;
+    std::map<std::string, uint32_t> state_ids;
+    size_t proof_bytes = 0, sum_m = 0;
+    for (size_t i = 0; i < n_items; i++) {
+      proof_bytes += items[i].proof_len;
+      sum_m += items[i].m;
+    }
+    bytes.reserve(proof_bytes + sum_m * 32);
+    std::vector<uint32_t> commit_rel(n_items);
+    uint32_t dyn = 0;
+    for (size_t i = 0; i < n_items; i++) {
+      const bpp_verify_item &it = items[i];
+      ProofDesc &d = B->desc[i];
+      // RangeStatement::init (src/range_statement.rs:36-73)
+      if (it.m == 0 || (it.m & (it.m - 1)))
+        throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Number of commitments must be a power of two"};
+      if (!it.commitments32 || (!it.min_values && it.min_present))
+        throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Incorrect number of minimum value promises"};
+      if (P.m_max < it.m) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Not enough generators for this statement"};
+      if (it.seed_nonce32 && it.m > 1)
+        throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Mask recovery is not supported with an aggregated statement"};
+      if (!it.proof) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Serialized proof is too short"};
+      ParsedItem pi;
+      parse_proof(it.proof, it.proof_len, pi);
+      // verify_statements_and_generators_consistency (src/range_proof.rs:637-659): extension degree of every proof
+      if (pi.t != P.t) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Inconsistent extension degree"};
+      d.proof_off = (uint32_t)bytes.size();
+      bytes.insert(bytes.end(), it.proof, it.proof + it.proof_len);
+      d.rounds = pi.rounds;
+      d.m = it.m;
+      d.minval_idx = (uint32_t)minvals.size();
+      for (uint32_t j = 0; j < it.m; j++) {
+        bool present = it.min_present ? it.min_present[j] != 0 : false;
+        uint64_t v = (present && it.min_values) ? it.min_values[j] : 0;
+        // :675-681
+        if (present && P.n_bits < 64 && (v >> P.n_bits) > 0)
+          throw ProofErr{BPP_ERR_INVALID_LENGTH, "Minimum value promise exceeds bit vector capacity"};
+        minvals.push_back(v);
+      }
+      d.dyn_off = dyn;
+      dyn += it.m + 3 + 2 * pi.rounds;
+      d.flags = it.seed_nonce32 ? 1u : 0u;
+      if (it.seed_nonce32) {
+        memcpy(&seeds[i * 32], it.seed_nonce32, 32);
+        B->any_seed = true;
+      }
+      // transcript: explicit state wins, else Transcript::new(label)
+      std::string key;
+      if (it.transcript_state) {
+        key.assign((const char *)it.transcript_state, 203);
+        key.push_back('S');
+      } else {
+        key.assign((const char *)it.transcript_label, it.transcript_label ? it.label_len : 0);
+        key.push_back('L');
+      }
+      auto sit = state_ids.find(key);
+      if (sit == state_ids.end()) {
+        uint32_t id = (uint32_t)(states.size() / 203);
+        states.resize(states.size() + 203);
+        if (it.transcript_state) {
+          memcpy(&states[(size_t)id * 203], it.transcript_state, 203);
+          if (states[(size_t)id * 203 + 200] >= BPP_STROBE_R)
+            throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "transcript state has pos >= rate"};
+        } else {
+          Strobe s;
+          merlin_new(s, it.transcript_label, (uint32_t)(it.transcript_label ? it.label_len : 0));
+          strobe_to_bytes(&states[(size_t)id * 203], s);
+        }
+        sit = state_ids.emplace(key, id).first;
+      }
+      d.state_idx = sit->second;
+      // structural checks evaluated with PASS-2 precedence at verify time (:875-888)
+      const uint64_t mn = (uint64_t)it.m * P.n_bits;
+      if (pi.rounds >= 32)
+        B->rounds_bad[i] = BPP_ERR_SIZE_OVERFLOW;
+      else if ((1ull << pi.rounds) != mn)
+        B->rounds_bad[i] = BPP_ERR_INVALID_LENGTH;
+      B->rmax = std::max(B->rmax, pi.rounds);
+      B->max_mn = std::max(B->max_mn, (uint32_t)mn);
+    }
+    // commitments after all proofs
+    for (size_t i = 0; i < n_items; i++) {
+      B->desc[i].commit_off = (uint32_t)bytes.size();
+      bytes.insert(bytes.end(), items[i].commitments32, items[i].commitments32 + (size_t)items[i].m * 32);
+    }
+    B->total_dyn = dyn;
+    B->sum_m = (uint32_t)sum_m;
+    B->cs = B->rmax + 3;
+    B->cols = 2 * B->max_mn + P.t + 1;
+    // point sources in dynamic-slot order: C_j.., A1, B, A, L.., R..
+    std::vector<uint32_t> src_off(dyn), owner(dyn);
+    for (size_t i = 0; i < n_items; i++) {
+      const ProofDesc &d = B->desc[i];
+      uint32_t q = d.dyn_off;
+      const uint32_t pA = d.proof_off + 1 + 32 * P.t;
+      for (uint32_t j = 0; j < d.m; j++) {
+        src_off[q] = d.commit_off + 32 * j;
+        owner[q++] = (uint32_t)i | 0x80000000u;
+      }
+      src_off[q] = pA + 32;  // A1
+      owner[q++] = (uint32_t)i;
+      src_off[q] = pA + 64;  // B
+      owner[q++] = (uint32_t)i;
+      src_off[q] = pA;  // A
+      owner[q++] = (uint32_t)i;
+      for (uint32_t j = 0; j < d.rounds; j++) {
+        src_off[q] = pA + 160 + 64 * j;
+        owner[q++] = (uint32_t)i;
+      }
+      for (uint32_t j = 0; j < d.rounds; j++) {
+        src_off[q] = pA + 160 + 64 * j + 32;
+        owner[q++] = (uint32_t)i;
+      }
+    }
+    // device copies
+    hipStream_t s = ctx->stream;
+    B->bytes.alloc(bytes.size());
+    B->states.alloc(states.size());
+    B->seeds.alloc(seeds.size());
+    B->d_desc.alloc(n_items);
+    B->minvals.alloc(minvals.size());
+    B->src_off.alloc(dyn);
+    B->owner.alloc(dyn);
+    HIP_CHECK(hipMemcpyAsync(B->bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(B->states.p, states.data(), states.size(), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(B->seeds.p, seeds.data(), seeds.size(), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(B->d_desc.p, B->desc.data(), n_items * sizeof(ProofDesc), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(B->minvals.p, minvals.data(), minvals.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(B->src_off.p, src_off.data(), (size_t)dyn * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(B->owner.p, owner.data(), (size_t)dyn * 4, hipMemcpyHostToDevice, s));
+    // work buffers
+    B->chal.alloc((size_t)n_items * B->cs);
+    B->rng_out.alloc(n_items * 32);
+    B->weights.alloc(n_items * 32);
+    B->status.alloc(n_items);
+    B->dynpts.alloc(dyn);
+    B->rows.alloc((size_t)n_items * B->cols);
+    B->masks.alloc(n_items * P.t * 32);
+    B->h_rng.resize(n_items * 32);
+    B->h_weights.resize(n_items * 32);
+    B->h_status.resize(n_items);
+    HIP_CHECK(hipStreamSynchronize(s));
+    uint64_t h = ctx->next_handle++;
+    ctx->batches[h] = std::move(B);
+    *batch = h;
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, errbuf, errbuf_len)
+}
+
+int bpp_batch_destroy(bpp_ctx *ctx, uint64_t batch) {
+  BPP_ENTRY(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  return ctx->batches.erase(batch) ? BPP_OK : BPP_ERR_BAD_HANDLE;
+}
+
+}  // extern "C"
+
+namespace {
+
+// PASS 1 + decompression for the whole resident batch; fills h_rng / h_status
+void run_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
+  Params &P = *b.params;
+  hipStream_t s = ctx->stream;
+  HIP_CHECK(hipMemsetAsync(b.status.p, 0, (size_t)b.B * 4, s));
+  HIP_CHECK(hipMemsetAsync(b.chal.p, 0, (size_t)b.B * b.cs * sizeof(sc), s));
+  tm.mark();  // 0
+  hipLaunchKernelGGL(k_transcripts, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.states.p,
+                     P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p);
+  tm.mark();  // 1
+  hipLaunchKernelGGL(k_decompress, dim3(cdiv(b.total_dyn, 64)), dim3(64), 0, s, b.bytes.p, b.src_off.p, b.owner.p,
+                     b.total_dyn, b.dynpts.p, b.status.p);
+  tm.mark();  // 2
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipMemcpyAsync(b.h_status.data(), b.status.p, (size_t)b.B * 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// reference error precedence for proofs [p0, p1) treated as one verify() call
+void check_chunk_errors(const Batch &b, uint32_t p0, uint32_t p1) {
+  // a statement whose commitment does not decode could never have been constructed (RangeStatement holds points)
+  for (uint32_t p = p0; p < p1; p++)
+    if (b.h_status[p] & BPP_ST_COMMIT_FAIL)
+      throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Statement commitment is not the canonical encoding of a point"};
+  // PASS 1 over all proofs of the chunk first (src/range_proof.rs:816-850)
+  for (uint32_t p = p0; p < p1; p++)
+    if (b.h_status[p] & BPP_ST_TRANSCRIPT_FAIL)
+      throw ProofErr{BPP_ERR_VERIFICATION_FAILED,
+                     "Identity element cannot be added to the transcript / transcript challenge cannot be zero"};
+  // PASS 2 in proof order (:859-888)
+  for (uint32_t p = p0; p < p1; p++) {
+    if (b.h_status[p] & BPP_ST_DECOMPRESS_FAIL)
+      throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "A proof member was not the canonical encoding of a point"};
+    if (b.rounds_bad[p] == BPP_ERR_SIZE_OVERFLOW) throw ProofErr{BPP_ERR_SIZE_OVERFLOW, "Internal size overflow"};
+    if (b.rounds_bad[p] == BPP_ERR_INVALID_LENGTH)
+      throw ProofErr{BPP_ERR_INVALID_LENGTH, "Vector L/R length not adequate"};
+  }
+}
+
+// (re)build the group layout + MSM term lists for `chunk`
+void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk) {
+  if (b.last_chunk == chunk && b.G) return;
+  Params &P = *b.params;
+  const uint32_t cz = (chunk == 0 || chunk >= b.B) ? b.B : (uint32_t)chunk;
+  const uint32_t G = cdiv(b.B, cz);
+  b.G = G;
+  b.h_group_first.resize(G + 1);
+  for (uint32_t g = 0; g <= G; g++) b.h_group_first[g] = std::min(g * cz, b.B);
+  b.group_first.alloc(G + 1);
+  HIP_CHECK(hipMemcpyAsync(b.group_first.p, b.h_group_first.data(), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  b.scal.alloc((size_t)G * b.cols + b.total_dyn);
+  // terms of group g: static columns (first 2*max_mn generators, then g bases, then h) + its proofs' dynamic slots
+  const uint32_t n_gen = 2 * P.n_bits * P.m_max;
+  std::vector<uint32_t> sidx, pidx, goff(G + 1);
+  sidx.reserve((size_t)G * b.cols + b.total_dyn);
+  pidx.reserve((size_t)G * b.cols + b.total_dyn);
+  for (uint32_t g = 0; g < G; g++) {
+    goff[g] = (uint32_t)sidx.size();
+    for (uint32_t cidx = 0; cidx < b.cols; cidx++) {
+      sidx.push_back(g * b.cols + cidx);
+      pidx.push_back(cidx < 2 * b.max_mn ? cidx : n_gen + (cidx - 2 * b.max_mn));
+    }
+    const uint32_t p0 = b.h_group_first[g], p1 = b.h_group_first[g + 1];
+    const uint32_t d0 = b.desc[p0].dyn_off, d1 = (p1 < b.B) ? b.desc[p1].dyn_off : b.total_dyn;
+    for (uint32_t q = d0; q < d1; q++) {
+      sidx.push_back(G * b.cols + q);
+      pidx.push_back(P.table_len + q);
+    }
+  }
+  goff[G] = (uint32_t)sidx.size();
+  msm_prepare(ctx, b.msm, sidx, pidx, goff);
+  b.last_chunk = chunk;
+}
+
+// PASS 2 + MSM for the whole batch with the given weights (device buffer b.weights already filled)
+void run_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
+  Params &P = *b.params;
+  hipStream_t s = ctx->stream;
+  sc *dyn_scal = b.scal.p + (size_t)b.G * b.cols;
+  hipLaunchKernelGGL(k_scalars, dim3(b.B), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.chal.p, b.weights.p,
+                     P.n_bits, P.t, b.cs, b.max_mn, b.cols, b.B, b.rows.p, dyn_scal);
+  tm.mark();  // 4
+  hipLaunchKernelGGL(k_reduce_static, dim3(b.cols, b.G), dim3(64), 0, s, b.rows.p, b.group_first.p, b.cols, b.scal.p);
+  tm.mark();  // 5
+  PointTables tabs{P.table.p, b.dynpts.p, P.table_len};
+  msm_run(ctx, b.msm, b.scal.p, tabs, &tm);  // marks 6..10
+  HIP_CHECK(hipGetLastError());
+}
+
+void collect_profile(bpp_ctx *ctx, Batch &b, StageTimer &tm, float chain_ms, float total_host_ms) {
+  if (!ctx->profile) return;
+  bpp_profile &pf = ctx->prof;
+  memset(&pf, 0, sizeof(pf));
+  pf.transcripts_ms = tm.between(0, 1);
+  pf.decompress_ms = tm.between(1, 2);
+  pf.chain_host_ms = chain_ms;
+  pf.scalars_ms = tm.between(3, 4);
+  pf.reduce_ms = tm.between(4, 5);
+  pf.msm_digits_ms = tm.between(5, 6);
+  pf.msm_sort_ms = tm.between(6, 7);
+  pf.msm_accumulate_ms = tm.between(7, 8);
+  pf.msm_bucket_reduce_ms = tm.between(8, 9);
+  pf.msm_final_ms = tm.between(9, 10);
+  pf.total_ms = total_host_ms;
+  pf.msm_terms = b.msm.plan.n_terms;
+  pf.msm_window_bits = b.msm.plan.c;
+  pf.msm_windows = b.msm.plan.K;
+  pf.msm_groups = b.msm.plan.G;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, uint8_t *masks_out, uint8_t *mask_present,
+                        char *errbuf, size_t errbuf_len) {
+  BPP_ENTRY(ctx);
+  try {
+    auto it = ctx->batches.find(batch);
+    if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle", errbuf, errbuf_len);
+    if (action < 0 || action > 2) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "unknown verify action", errbuf, errbuf_len);
+    Batch &b = *it->second;
+    Params &P = *b.params;
+    auto t_begin = std::chrono::steady_clock::now();
+    StageTimer tm(ctx);
+    hipStream_t s = ctx->stream;
+    layout_groups(ctx, b, chunk);
+    run_phase1(ctx, b, tm);
+
+    // which chunks are structurally sound?  errors surface chunk by chunk, in order
+    uint32_t first_bad_group = b.G;
+    ProofErr pending{0, ""};
+    for (uint32_t g = 0; g < b.G; g++) {
+      try {
+        check_chunk_errors(b, b.h_group_first[g], b.h_group_first[g + 1]);
+      } catch (const ProofErr &e) {
+        first_bad_group = g;
+        pending = e;
+        break;
+      }
+    }
+    if (first_bad_group == 0) throw pending;
+
+    // weight chains: one per chunk (src/range_proof.rs:811,849,853,894)
+    auto c0 = std::chrono::steady_clock::now();
+    for (uint32_t g = 0; g < b.G; g++) {
+      const uint32_t p0 = b.h_group_first[g], p1 = b.h_group_first[g + 1];
+      weights_from_chain_host(&b.h_rng[(size_t)p0 * 32], p1 - p0, &b.h_weights[(size_t)p0 * 32]);
+    }
+    auto c1 = std::chrono::steady_clock::now();
+    float chain_ms = std::chrono::duration<float, std::milli>(c1 - c0).count();
+    HIP_CHECK(hipMemcpyAsync(b.weights.p, b.h_weights.data(), (size_t)b.B * 32, hipMemcpyHostToDevice, s));
+    tm.mark();  // 3
+
+    // masks (:941-969)
+    std::vector<uint8_t> h_masks;
+    if (action != BPP_VERIFY_ONLY) {
+      if (b.any_seed) {
+        hipLaunchKernelGGL(k_masks, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.chal.p, b.seeds.p,
+                           P.n_bits, P.t, b.cs, b.B, b.masks.p);
+        h_masks.resize((size_t)b.B * P.t * 32);
+        HIP_CHECK(hipMemcpyAsync(h_masks.data(), b.masks.p, h_masks.size(), hipMemcpyDeviceToHost, s));
+      }
+    }
+    std::vector<uint32_t> h_ident(b.G, 1);
+    if (action != BPP_RECOVER_ONLY) {
+      run_phase2(ctx, b, tm);
+      HIP_CHECK(hipMemcpyAsync(h_ident.data(), b.msm.is_identity.p, (size_t)b.G * 4, hipMemcpyDeviceToHost, s));
+      b.have_trace = true;
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    auto t_end = std::chrono::steady_clock::now();
+    collect_profile(ctx, b, tm, chain_ms, std::chrono::duration<float, std::milli>(t_end - t_begin).count());
+
+    // outputs: Vec<Option<ExtendedMask>>
+    for (uint32_t p = 0; p < b.B; p++) {
+      bool present = (action != BPP_VERIFY_ONLY) && (b.desc[p].flags & 1u);
+      if (mask_present) mask_present[p] = present ? 1 : 0;
+      if (masks_out) {
+        if (present)
+          memcpy(masks_out + (size_t)p * P.t * 32, &h_masks[(size_t)p * P.t * 32], (size_t)P.t * 32);
+        else
+          memset(masks_out + (size_t)p * P.t * 32, 0, (size_t)P.t * 32);
+      }
+    }
+    for (uint32_t g = 0; g < first_bad_group; g++)
+      if (!h_ident[g]) throw ProofErr{BPP_ERR_VERIFICATION_FAILED, "Range proof batch not valid"};
+    if (first_bad_group < b.G) throw pending;
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, errbuf, errbuf_len)
+}
+
+int bpp_verify_batch(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, int action,
+                     size_t chunk, uint8_t *masks_out, uint8_t *mask_present, char *errbuf, size_t errbuf_len) {
+  uint64_t h = 0;
+  int rc = bpp_batch_upload(ctx, params, items, n_items, &h, errbuf, errbuf_len);
+  if (rc != BPP_OK) return rc;
+  rc = bpp_verify_resident(ctx, h, action, chunk, masks_out, mask_present, errbuf, errbuf_len);
+  (void)bpp_batch_destroy(ctx, h);
+  return rc;
+}
+
+// ---------------------------------------------------------------- phased form
+int bpp_verify_phase1(bpp_ctx *ctx, uint64_t batch, uint8_t *rng_out32, char *errbuf, size_t errbuf_len) {
+  BPP_ENTRY(ctx);
+  try {
+    auto it = ctx->batches.find(batch);
+    if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle", errbuf, errbuf_len);
+    Batch &b = *it->second;
+    StageTimer tm(ctx);
+    layout_groups(ctx, b, 0);
+    run_phase1(ctx, b, tm);
+    if (rng_out32) memcpy(rng_out32, b.h_rng.data(), (size_t)b.B * 32);
+    check_chunk_errors(b, 0, b.B);
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, errbuf, errbuf_len)
+}
+
+int bpp_verify_phase2(bpp_ctx *ctx, uint64_t batch, const uint8_t *weights32, uint8_t accumulator128[128], char *errbuf,
+                      size_t errbuf_len) {
+  BPP_ENTRY(ctx);
+  try {
+    auto it = ctx->batches.find(batch);
+    if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle", errbuf, errbuf_len);
+    if (!weights32 || !accumulator128) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument", errbuf, errbuf_len);
+    Batch &b = *it->second;
+    for (uint32_t p = 0; p < b.B; p++)
+      if (!sc_is_canonical(weights32 + 32 * (size_t)p))
+        return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "weight is not canonical", errbuf, errbuf_len);
+    StageTimer tm(ctx);
+    hipStream_t s = ctx->stream;
+    layout_groups(ctx, b, 0);
+    memcpy(b.h_weights.data(), weights32, (size_t)b.B * 32);
+    HIP_CHECK(hipMemcpyAsync(b.weights.p, b.h_weights.data(), (size_t)b.B * 32, hipMemcpyHostToDevice, s));
+    for (int i = 0; i < 4; i++) tm.mark();
+    run_phase2(ctx, b, tm);
+    DevBuf<uint8_t> d_out;
+    d_out.alloc(128);
+    hipLaunchKernelGGL(k_ge_to_bytes, dim3(1), dim3(64), 0, s, b.msm.R.p, 1u, d_out.p);
+    HIP_CHECK(hipMemcpyAsync(accumulator128, d_out.p, 128, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    b.have_trace = true;
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, errbuf, errbuf_len)
+}
+
+int bpp_accumulators_sum_is_identity(bpp_ctx *ctx, const uint8_t *accumulators128, size_t n, int *is_identity) {
+  BPP_ENTRY(ctx);
+  try {
+    if (!accumulators128 || !is_identity || n == 0) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument");
+    DevBuf<uint8_t> d_in, d_comp;
+    DevBuf<uint32_t> d_flag;
+    d_in.alloc(n * 128);
+    d_comp.alloc(32);
+    d_flag.alloc(1);
+    HIP_CHECK(hipMemcpyAsync(d_in.p, accumulators128, n * 128, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_sum_accumulators, dim3(1), dim3(64), 0, ctx->stream, d_in.p, (uint32_t)n, d_comp.p, d_flag.p);
+    uint32_t flag = 0;
+    HIP_CHECK(hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *is_identity = flag ? 1 : 0;
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, nullptr, 0)
+}
+
+// ---------------------------------------------------------------- trace / shape / profile
+int bpp_batch_shape(bpp_ctx *ctx, uint64_t batch, uint32_t *n_items, uint32_t *max_rounds, uint32_t *max_mn,
+                    uint32_t *total_dyn, uint32_t *groups) {
+  BPP_ENTRY(ctx);
+  auto it = ctx->batches.find(batch);
+  if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle");
+  Batch &b = *it->second;
+  if (n_items) *n_items = b.B;
+  if (max_rounds) *max_rounds = b.rmax;
+  if (max_mn) *max_mn = b.max_mn;
+  if (total_dyn) *total_dyn = b.total_dyn;
+  if (groups) *groups = b.G;
+  return BPP_OK;
+}
+
+int bpp_batch_trace(bpp_ctx *ctx, uint64_t batch, int what, uint8_t *out, size_t out_len, size_t *written) {
+  BPP_ENTRY(ctx);
+  try {
+    auto it = ctx->batches.find(batch);
+    if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle");
+    Batch &b = *it->second;
+    hipStream_t s = ctx->stream;
+    size_t need = 0;
+    const void *src = nullptr;
+    DevBuf<uint8_t> tmp;
+    switch (what) {
+      case BPP_TRACE_CHALLENGES: {
+        const uint32_t n = b.B * b.cs;
+        need = (size_t)n * 32;
+        tmp.alloc(need);
+        hipLaunchKernelGGL(k_chal_canonical, dim3(cdiv(n, 64)), dim3(64), 0, s, b.chal.p, n, tmp.p);
+        src = tmp.p;
+        break;
+      }
+      case BPP_TRACE_RNG_OUT:
+        need = (size_t)b.B * 32;
+        src = b.rng_out.p;
+        break;
+      case BPP_TRACE_WEIGHTS:
+        need = (size_t)b.B * 32;
+        src = b.weights.p;
+        break;
+      case BPP_TRACE_STATIC_SCALARS:
+        need = (size_t)b.G * b.cols * 32;
+        src = b.scal.p;
+        break;
+      case BPP_TRACE_DYNAMIC_SCALARS:
+        need = (size_t)b.total_dyn * 32;
+        src = b.scal.p + (size_t)b.G * b.cols;
+        break;
+      case BPP_TRACE_MSM_RESULT:
+        need = (size_t)b.G * 32;
+        src = b.msm.comp32.p;
+        break;
+      default:
+        return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "unknown trace selector");
+    }
+    if (written) *written = need;
+    if (!out || out_len < need) return fail(ctx, BPP_ERR_INVALID_LENGTH, "trace buffer too small");
+    HIP_CHECK(hipMemcpyAsync(out, src, need, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, nullptr, 0)
+}
+
+int bpp_profile_enable(bpp_ctx *ctx, int on) {
+  if (!ctx) return BPP_ERR_BAD_HANDLE;
+  ctx->profile = on != 0;
+  return BPP_OK;
+}
+
+int bpp_profile_get(bpp_ctx *ctx, bpp_profile *out) {
+  if (!ctx || !out) return BPP_ERR_BAD_HANDLE;
+  *out = ctx->prof;
+  return BPP_OK;
+}
+
+}  // extern "C"

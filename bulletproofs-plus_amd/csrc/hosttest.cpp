@@ -1,0 +1,40 @@
+// Host-compiled probes of the shared host/device arithmetic headers (used only by tests/, CPU suite).
+#include <string.h>
+#include "point.h"
+#include "scalar.h"
+#include "merlin.h"
+#include "blake2b.h"
+using namespace bpp;
+extern "C" {
+void ht_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe x, y, z; fe_frombytes(x, a); fe_frombytes(y, b); fe_mul(z, x, y); fe_tobytes(out, z); }
+void ht_fe_sq(const uint8_t a[32], uint8_t out[32]) { fe x, z; fe_frombytes(x, a); fe_sq(z, x); fe_tobytes(out, z); }
+void ht_fe_addsubmul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {  // (a+b)*(a-b) with lazy limbs
+  fe x, y, s, d, z; fe_frombytes(x, a); fe_frombytes(y, b); fe_add(s, x, y); fe_sub(d, x, y); fe_mul(z, s, d); fe_tobytes(out, z); }
+void ht_fe_invert(const uint8_t a[32], uint8_t out[32]) { fe x, z; fe_frombytes(x, a); fe_invert(z, x); fe_tobytes(out, z); }
+void ht_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {
+  sc x, y, z; sc_load_words(x, a); sc_load_words(y, b); sc_to_mont(x, x); sc_to_mont(y, y); sc_montmul(z, x, y); sc_from_mont(z, z); sc_store_words(out, z); }
+void ht_sc_addsub(const uint8_t a[32], const uint8_t b[32], uint8_t sum[32], uint8_t dif[32]) {
+  sc x, y, z; sc_load_words(x, a); sc_load_words(y, b); sc_add(z, x, y); sc_store_words(sum, z); sc_sub(z, x, y); sc_store_words(dif, z); }
+void ht_sc_wide(const uint8_t a[64], uint8_t out[32]) { sc z; sc_mont_from_wide(z, a); sc_from_mont(z, z); sc_store_words(out, z); }
+void ht_sc_invert(const uint8_t a[32], uint8_t out[32]) { sc x; sc_load_words(x, a); sc_to_mont(x, x); sc_mont_invert(x, x); sc_from_mont(x, x); sc_store_words(out, x); }
+int ht_sc_canonical(const uint8_t a[32]) { return sc_is_canonical(a) ? 1 : 0; }
+int ht_decompress_compress(const uint8_t in[32], uint8_t out[32]) {
+  niels n; bool ok = ristretto_decompress(n, in); if (!ok) return 0;
+  ge p; ge_identity(p); ge_madd(p, p, n); ristretto_compress(out, p); return 1; }
+void ht_from_uniform(const uint8_t in[64], uint8_t out[32]) { ge p; ristretto_from_uniform(p, in); ristretto_compress(out, p); }
+// out = compress(k*P) by double-and-add using dbl/madd/add; also exercises msub and ge_to_niels
+int ht_scalarmult(const uint8_t k[32], const uint8_t pin[32], uint8_t out[32]) {
+  niels n; if (!ristretto_decompress(n, pin)) return 0;
+  ge acc; ge_identity(acc);
+  for (int i = 255; i >= 0; i--) { ge_dbl(acc, acc); if ((k[i >> 3] >> (i & 7)) & 1) ge_madd(acc, acc, n); }
+  // acc = acc + P - P through ge_add / msub paths
+  ge q; ge_identity(q); ge_madd(q, q, n); ge t; ge_add(t, acc, q); ge_msub(t, t, n);
+  niels tn; ge_to_niels(tn, t); ge r; ge_identity(r); ge_madd(r, r, tn);
+  ristretto_compress(out, r); return 1; }
+int ht_is_identity(const uint8_t pin[32]) { niels n; if (!ristretto_decompress(n, pin)) return -1; ge p; ge_identity(p); ge_madd(p, p, n); return ge_is_ristretto_identity(p) ? 1 : 0; }
+void ht_merlin_kat(const uint8_t *label, uint32_t llen, const uint8_t *ml, uint32_t mll, const uint8_t *msg, uint32_t mlen, const uint8_t *cl, uint32_t cll, uint8_t *out, uint32_t n, uint8_t state_out[203]) {
+  Strobe s; merlin_new(s, label, llen); merlin_append_message(s, ml, mll, msg, mlen); merlin_challenge_bytes(s, cl, cll, out, n); strobe_to_bytes(state_out, s); }
+void ht_merlin_rng(const uint8_t state[203], const uint8_t *wit, uint32_t wlen, const uint8_t rnd[32], uint8_t *out, uint32_t n) {
+  Strobe s; strobe_from_bytes(s, state); if (wlen) merlin_rng_rekey(s, (const uint8_t *)"witness", 7, wit, wlen); merlin_rng_finalize(s, rnd); merlin_rng_fill(s, out, n); }
+void ht_blake2b(const uint8_t *key, uint32_t klen, const uint8_t *persona, uint32_t plen, uint8_t out[64]) { blake2b512_keyed_personal_empty(out, key, klen, persona, plen); }
+}

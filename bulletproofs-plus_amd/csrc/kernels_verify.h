@@ -1,0 +1,518 @@
+// Device kernels of the batch verifier (everything except the MSM, which lives in msm.h).
+//
+// Data layout in HBM (one resident batch):
+//   bytes[]        all proof wire bytes back to back, then all compressed commitments
+//   desc[B]        ProofDesc: where each proof's pieces are
+//   minvals[sumM]  u64 minimum-value promises (0 for None; indistinguishable in the protocol)
+//   chal[B][CS]    Montgomery-form challenges per proof: y, z, e_0..e_{r-1}, e_final   (CS = rmax + 3)
+//   rng_out[B][32] transcript-RNG bytes that feed the weight transcript
+//   dynpts[total]  affine-niels points, proof order: C_0..C_{m-1}, A1, B, A, L_0.., R_0..
+//   rows[B][cols]  per-proof contributions to the shared generator scalars (Montgomery form)
+//   scal[...]      canonical scalars the MSM consumes: [G x cols static | total dynamic]
+#pragma once
+#include "blake2b.h"
+#include "merlin.h"
+#include "point.h"
+#include "scalar.h"
+
+namespace bpp {
+
+struct ProofDesc {
+  uint32_t proof_off;   // byte offset of the proof in bytes[]
+  uint32_t rounds;      // number of (L,R) pairs present in the proof
+  uint32_t m;           // aggregation factor of the statement
+  uint32_t commit_off;  // byte offset of the m compressed commitments in bytes[]
+  uint32_t minval_idx;  // index of the first minimum value
+  uint32_t dyn_off;     // index of the first dynamic (scalar, point) slot
+  uint32_t state_idx;   // which initial transcript state
+  uint32_t flags;       // bit0: seed nonce present
+};
+
+// status bits written by the kernels
+#define BPP_ST_TRANSCRIPT_FAIL 1u  // identity encoding appended or zero challenge -> VerificationFailed
+#define BPP_ST_DECOMPRESS_FAIL 2u  // proof point not a canonical encoding          -> InvalidArgument
+#define BPP_ST_COMMIT_FAIL 4u      // statement commitment does not decode           -> InvalidArgument
+
+__device__ __forceinline__ bool bytes32_all_zero(const uint8_t *p) {
+  uint32_t r = 0;
+  for (int i = 0; i < 32; i++) r |= p[i];
+  return r == 0;
+}
+
+// challenge_scalar (src/protocols/transcript_protocol.rs:67-78): returns false on a zero challenge
+__device__ __forceinline__ bool dev_challenge(Strobe &s, const uint8_t *label, uint32_t llen, sc &out) {
+  uint8_t buf[64];
+  merlin_challenge_bytes(s, label, llen, buf, 64);
+  sc_mont_from_wide(out, buf);
+  return !sc_iszero(out);
+}
+
+// PASS 1 of RangeProof::verify (src/range_proof.rs:816-850), one lane per proof.
+// RangeProofTranscript::new / challenges_y_z / challenge_round_e / challenge_final_e / to_verifier_rng
+// (src/transcripts.rs:59-179); the intermediate build_rng() clones are dead for a verifier and skipped.
+__global__ void __launch_bounds__(64) k_transcripts(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
+                                                    const uint64_t *__restrict__ minvals,
+                                                    const uint8_t *__restrict__ states, const uint8_t *__restrict__ hg32,
+                                                    uint32_t n_bits, uint32_t t, uint32_t B, uint32_t cs,
+                                                    sc *__restrict__ chal, uint8_t *__restrict__ rng_out,
+                                                    uint32_t *__restrict__ status) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  const ProofDesc d = desc[p];
+  Strobe s;
+  strobe_from_bytes(s, states + 203u * d.state_idx);
+  bool ok = true;
+  const uint8_t *pr = bytes + d.proof_off;
+  const uint8_t *pd1 = pr + 1;
+  const uint8_t *pA = pr + 1 + 32 * t;
+  const uint8_t *pA1 = pA + 32, *pB = pA + 64, *pr1 = pA + 96, *ps1 = pA + 128, *pLR = pA + 160;
+
+  merlin_append_message(s, (const uint8_t *)"dom-sep", 7, (const uint8_t *)"Bulletproofs+ Range Proof", 25);
+  merlin_append_message(s, (const uint8_t *)"H", 1, hg32, 32);  // validated at params creation
+  for (uint32_t k = 0; k < t; k++) merlin_append_message(s, (const uint8_t *)"G", 1, hg32 + 32 * (k + 1), 32);
+  merlin_append_u64(s, (const uint8_t *)"N", 1, n_bits);
+  merlin_append_u64(s, (const uint8_t *)"T", 1, t);
+  merlin_append_u64(s, (const uint8_t *)"M", 1, d.m);
+  for (uint32_t j = 0; j < d.m; j++)
+    merlin_append_message(s, (const uint8_t *)"Ci", 2, bytes + d.commit_off + 32 * j, 32);  // identity allowed (q3)
+  for (uint32_t j = 0; j < d.m; j++)
+    merlin_append_u64(s, (const uint8_t *)"vi - minimum_value", 18, minvals[d.minval_idx + j]);
+
+  sc *c = chal + (size_t)p * cs;
+  sc v;
+  ok = ok && !bytes32_all_zero(pA);
+  merlin_append_message(s, (const uint8_t *)"A", 1, pA, 32);
+  ok = dev_challenge(s, (const uint8_t *)"y", 1, v) && ok;
+  c[0] = v;
+  ok = dev_challenge(s, (const uint8_t *)"z", 1, v) && ok;
+  c[1] = v;
+  for (uint32_t j = 0; j < d.rounds; j++) {
+    ok = ok && !bytes32_all_zero(pLR + 64 * j) && !bytes32_all_zero(pLR + 64 * j + 32);
+    merlin_append_message(s, (const uint8_t *)"L", 1, pLR + 64 * j, 32);
+    merlin_append_message(s, (const uint8_t *)"R", 1, pLR + 64 * j + 32, 32);
+    ok = dev_challenge(s, (const uint8_t *)"e", 1, v) && ok;
+    c[2 + j] = v;
+  }
+  ok = ok && !bytes32_all_zero(pA1) && !bytes32_all_zero(pB);
+  merlin_append_message(s, (const uint8_t *)"A1", 2, pA1, 32);
+  merlin_append_message(s, (const uint8_t *)"B", 1, pB, 32);
+  ok = dev_challenge(s, (const uint8_t *)"e", 1, v) && ok;
+  c[2 + d.rounds] = v;
+  // to_verifier_rng (src/transcripts.rs:166-179) + NullRng finalize + 32 bytes (src/range_proof.rs:845-848)
+  merlin_append_message(s, (const uint8_t *)"r1", 2, pr1, 32);
+  merlin_append_message(s, (const uint8_t *)"s1", 2, ps1, 32);
+  for (uint32_t k = 0; k < t; k++) merlin_append_message(s, (const uint8_t *)"d1", 2, pd1 + 32 * k, 32);
+  uint8_t zero32[32];
+  for (int i = 0; i < 32; i++) zero32[i] = 0;
+  merlin_rng_finalize(s, zero32);
+  uint8_t out[32];
+  merlin_rng_fill(s, out, 32);
+  for (int i = 0; i < 32; i++) rng_out[(size_t)p * 32 + i] = out[i];
+  if (!ok) atomicOr(&status[p], BPP_ST_TRANSCRIPT_FAIL);
+}
+
+// CompressedRistretto::decompress for every proof point and commitment (src/range_proof.rs:859-866,1067-1109),
+// one lane per point.  src_off[i] = byte offset in bytes[]; owner[i] = proof index | (is_commitment << 31).
+__global__ void __launch_bounds__(64) k_decompress(const uint8_t *__restrict__ bytes, const uint32_t *__restrict__ src_off,
+                                                   const uint32_t *__restrict__ owner, uint32_t n,
+                                                   niels *__restrict__ out, uint32_t *__restrict__ status) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t s[32];
+  const uint8_t *src = bytes + src_off[i];
+  for (int k = 0; k < 32; k++) s[k] = src[k];
+  niels q;
+  bool ok = ristretto_decompress(q, s);
+  if (!ok) {
+    niels_identity(q);
+    uint32_t o = owner[i];
+    atomicOr(&status[o & 0x7fffffffu], (o >> 31) ? BPP_ST_COMMIT_FAIL : BPP_ST_DECOMPRESS_FAIL);
+  }
+  out[i] = q;
+}
+
+// Plain batch decompression for the B1 entry points (bpp_precomp_create / bpp_msm_*).
+__global__ void __launch_bounds__(64) k_decompress_plain(const uint8_t *__restrict__ pts32, uint32_t n,
+                                                         niels *__restrict__ out, uint32_t *__restrict__ bad) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t s[32];
+  for (int k = 0; k < 32; k++) s[k] = pts32[(size_t)i * 32 + k];
+  niels q;
+  if (!ristretto_decompress(q, s)) {
+    niels_identity(q);
+    atomicAdd(bad, 1u);
+  }
+  out[i] = q;
+}
+
+// RistrettoPoint::from_uniform_bytes for generator derivation (src/generators/generators_chain.rs:43-49,
+// src/ristretto.rs:88-95): 64 uniform bytes -> affine niels + canonical encoding.
+__global__ void __launch_bounds__(64) k_from_uniform(const uint8_t *__restrict__ uni64, uint32_t n, niels *__restrict__ out,
+                                                     uint8_t *__restrict__ comp32) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t b[64];
+  for (int k = 0; k < 64; k++) b[k] = uni64[(size_t)i * 64 + k];
+  ge p;
+  ristretto_from_uniform(p, b);
+  niels q;
+  ge_to_niels(q, p);
+  out[i] = q;
+  uint8_t c[32];
+  ristretto_compress(c, p);
+  for (int k = 0; k < 32; k++) comp32[(size_t)i * 32 + k] = c[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// PASS 2 scalar block (src/range_proof.rs:894-1033), one wavefront per proof, lanes over the mn generator
+// indices.  Everything is Montgomery form until the final store.
+// ---------------------------------------------------------------------------------------------
+#define BPP_MAX_ROUNDS 12  // mn <= 64 * 32 = 2048 -> 11 rounds
+
+struct ScalarShared {
+  sc e[BPP_MAX_ROUNDS], einv[BPP_MAX_ROUNDS], esq[BPP_MAX_ROUNDS], esqinv[BPP_MAX_ROUNDS];
+  sc yinvpow[BPP_MAX_ROUNDS];  // y^{-2^b}
+  sc pre[BPP_MAX_ROUNDS + 3];
+};
+
+__device__ __forceinline__ void sc_load_mont(sc &r, const uint8_t *p) {
+  sc a;
+  sc_load_words(a, p);
+  sc_to_mont(r, a);
+}
+
+__global__ void __launch_bounds__(64) k_scalars(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
+                                                const uint64_t *__restrict__ minvals, const sc *__restrict__ chal,
+                                                const uint8_t *__restrict__ weights32, uint32_t n_bits, uint32_t t,
+                                                uint32_t cs, uint32_t max_mn, uint32_t cols, uint32_t B,
+                                                sc *__restrict__ rows, sc *__restrict__ dyn_scalars) {
+  const uint32_t p = blockIdx.x;
+  if (p >= B) return;
+  const uint32_t lane = threadIdx.x;
+  __shared__ ScalarShared sh;
+  const ProofDesc d = desc[p];
+  const uint32_t r = d.rounds, m = d.m, mn = m * n_bits;
+  const sc *c = chal + (size_t)p * cs;
+  const uint8_t *pr = bytes + d.proof_off;
+  const uint8_t *pd1 = pr + 1;
+  const uint8_t *pr1 = pr + 1 + 32 * t + 96, *ps1 = pr1 + 32;
+
+  sc one, y = c[0], z = c[1], ef = c[2 + r], w, r1, s1;
+  sc_mont_one(one);
+  sc_load_mont(w, weights32 + (size_t)p * 32);
+  sc_load_mont(r1, pr1);
+  sc_load_mont(s1, ps1);
+
+  // ---- batch inversion of [e_0..e_{r-1}, y, y-1] (src/range_proof.rs:897-905), all lanes redundantly ----
+  sc ym1;
+  sc_sub(ym1, y, one);
+  sc acc = one;
+  for (uint32_t j = 0; j < r + 2; j++) {
+    sc x = (j < r) ? c[2 + j] : (j == r ? y : ym1);
+    if (lane == 0) sh.pre[j] = acc;  // product of x_0..x_{j-1}
+    sc_montmul(acc, acc, x);
+  }
+  sc inv_all;
+  sc_mont_invert(inv_all, acc);
+  __syncthreads();
+  sc y_1_inverse, y_inverse, run = inv_all;
+  for (int j = (int)r + 1; j >= 0; j--) {
+    sc x = ((uint32_t)j < r) ? c[2 + j] : ((uint32_t)j == r ? y : ym1);
+    sc inv_j, pre = sh.pre[j];
+    sc_montmul(inv_j, run, pre);
+    sc_montmul(run, run, x);
+    if ((uint32_t)j == r + 1) y_1_inverse = inv_j;
+    else if ((uint32_t)j == r) y_inverse = inv_j;
+    else if (lane == 0) {
+      sh.e[j] = x;
+      sh.einv[j] = inv_j;
+      sc sq;
+      sc_montsq(sq, x);
+      sh.esq[j] = sq;
+      sc_montsq(sq, inv_j);
+      sh.esqinv[j] = sq;
+    }
+  }
+  // y^{-2^b}
+  {
+    sc pw = y_inverse;
+    for (uint32_t b = 0; b < r; b++) {
+      if (lane == 0) sh.yinvpow[b] = pw;
+      sc_montsq(pw, pw);
+    }
+  }
+  __syncthreads();
+  // s[0] = prod e_j^{-1}  (challenges_inv_prod, :899)
+  sc s0 = one;
+  for (uint32_t j = 0; j < r; j++) {
+    sc t0 = sh.einv[j];
+    sc_montmul(s0, s0, t0);
+  }
+  (void)s0;
+
+  sc z_square, e_square, y_nm, y_nm_1, y_sum, tmp;
+  sc_montsq(z_square, z);
+  sc_montsq(e_square, ef);
+  sc_mont_pow_u32(y_nm, y, mn);
+  sc_montmul(y_nm_1, y_nm, y);
+  sc_sub(tmp, y_nm, one);
+  sc_montmul(tmp, tmp, y);
+  sc_montmul(y_sum, tmp, y_1_inverse);  // :916
+
+  // d_sum (:932-938)
+  sc d_sum = z_square, d_tmp = z_square;
+  for (uint32_t mm = m; mm > 1; mm >>= 1) {
+    sc_montmul(tmp, d_sum, d_tmp);
+    sc_add(d_sum, d_sum, tmp);
+    sc_montsq(d_tmp, d_tmp);
+  }
+  {
+    sc tn;  // 2^n - 1
+    uint64_t v = (n_bits >= 64) ? ~0ULL : ((1ULL << n_bits) - 1ULL);
+    sc_mont_from_u64(tn, v);
+    sc_montmul(d_sum, d_sum, tn);
+  }
+
+  sc r1_e, s1_e, e_square_z, neg_e_square;
+  sc_montmul(r1_e, r1, ef);
+  sc_montmul(s1_e, s1, ef);
+  sc_montmul(e_square_z, e_square, z);
+  sc_neg(neg_e_square, e_square);
+
+  // ---- generator scalars (:972-1003): lane i handles i, i+64, ... ----
+  sc *row = rows + (size_t)p * cols;
+  for (uint32_t i = lane; i < max_mn; i += 64) {
+    sc gi, hi;
+    if (i < mn) {
+      sc s_i = one, s_rev = one, yinv_i = one;
+      for (uint32_t b = 0; b < r; b++) {
+        const uint32_t j = r - 1 - b;
+        const bool bit = (i >> b) & 1u;
+        sc a = bit ? sh.e[j] : sh.einv[j];
+        sc a_rev = bit ? sh.einv[j] : sh.e[j];
+        sc_montmul(s_i, s_i, a);
+        sc_montmul(s_rev, s_rev, a_rev);
+        if (bit) {
+          sc yp = sh.yinvpow[b];
+          sc_montmul(yinv_i, yinv_i, yp);
+        }
+      }
+      sc y_nm_i;
+      sc_montmul(y_nm_i, y_nm, yinv_i);  // y^{mn-i}
+      // d[i] = z^{2(j+1)} * 2^k, i = j*n + k  (:919-929)
+      const uint32_t party = i / n_bits, k = i % n_bits;
+      sc d_i = z_square;
+      for (uint32_t q = 0; q < party; q++) sc_montmul(d_i, d_i, z_square);
+      sc two_k;
+      sc_mont_from_u64(two_k, 1ULL << k);
+      sc_montmul(d_i, d_i, two_k);
+      sc g, h, u;
+      sc_montmul(g, r1_e, yinv_i);
+      sc_montmul(g, g, s_i);
+      sc_add(g, g, e_square_z);
+      sc_montmul(gi, w, g);
+      sc_montmul(h, s1_e, s_rev);
+      sc_montmul(u, d_i, y_nm_i);
+      sc_add(u, u, z);
+      sc_montmul(u, u, e_square);
+      sc_sub(h, h, u);
+      sc_montmul(hi, w, h);
+    } else {
+      sc_0(gi);
+      sc_0(hi);
+    }
+    row[2 * i] = gi;
+    row[2 * i + 1] = hi;
+  }
+
+  // ---- dynamic scalars (:1006-1015, :1022-1032), canonical form for the MSM ----
+  const uint32_t ndyn = m + 3 + 2 * r;
+  sc w_neg_e2;
+  sc_montmul(w_neg_e2, w, neg_e_square);
+  for (uint32_t q = lane; q < ndyn; q += 64) {
+    sc v;
+    if (q < m) {
+      sc zp = z_square;
+      for (uint32_t jj = 0; jj < q; jj++) sc_montmul(zp, zp, z_square);
+      sc_montmul(v, w_neg_e2, zp);
+      sc_montmul(v, v, y_nm_1);
+    } else if (q == m) {
+      sc ne;
+      sc_neg(ne, ef);
+      sc_montmul(v, w, ne);
+    } else if (q == m + 1) {
+      sc_neg(v, w);
+    } else if (q == m + 2) {
+      v = w_neg_e2;
+    } else if (q < m + 3 + r) {
+      sc x = sh.esq[q - (m + 3)];
+      sc_montmul(v, w_neg_e2, x);
+    } else {
+      sc x = sh.esqinv[q - (m + 3 + r)];
+      sc_montmul(v, w_neg_e2, x);
+    }
+    sc_from_mont(v, v);
+    dyn_scalars[d.dyn_off + q] = v;
+  }
+
+  // ---- Pedersen base scalars (:1011-1020) ----
+  if (lane == 0) {
+    sc hs;
+    sc_0(hs);
+    sc zp = z_square;
+    for (uint32_t j = 0; j < m; j++) {
+      sc weighted, vm;
+      sc_montmul(weighted, w_neg_e2, zp);
+      sc_montmul(weighted, weighted, y_nm_1);
+      sc_mont_from_u64(vm, minvals[d.minval_idx + j]);
+      sc_montmul(weighted, weighted, vm);
+      sc_sub(hs, hs, weighted);
+      sc_montmul(zp, zp, z_square);
+    }
+    sc a, b2, u;
+    sc_montmul(a, r1, y);
+    sc_montmul(a, a, s1);
+    sc_montmul(b2, y_nm_1, z);
+    sc_montmul(b2, b2, d_sum);
+    sc_sub(u, z_square, z);
+    sc_montmul(u, u, y_sum);
+    sc_add(b2, b2, u);
+    sc_montmul(b2, b2, e_square);
+    sc_add(a, a, b2);
+    sc_montmul(a, a, w);
+    sc_add(hs, hs, a);
+    row[2 * max_mn + t] = hs;
+  }
+  if (lane >= 1 && lane <= t) {
+    sc d1;
+    sc_load_mont(d1, pd1 + 32 * (lane - 1));
+    sc_montmul(d1, d1, w);
+    row[2 * max_mn + (lane - 1)] = d1;
+  }
+}
+
+// Column sums of rows[] per group (the `+=` into gi/hi/g/h_base_scalars of src/range_proof.rs:785-788,999-1020):
+// one wavefront per (column, group); limb-wise u64 sums, wave shuffle reduction, one Montgomery exit.
+__global__ void __launch_bounds__(64) k_reduce_static(const sc *__restrict__ rows, const uint32_t *__restrict__ group_first,
+                                                      uint32_t cols, sc *__restrict__ out /* [G][cols] canonical */) {
+  const uint32_t col = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+  const uint32_t p0 = group_first[g], p1 = group_first[g + 1];
+  uint64_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc[i] = 0;
+  for (uint32_t p = p0 + lane; p < p1; p += 64) {
+    const sc v = rows[(size_t)p * cols + col];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] += v.v[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    for (int off = 32; off >= 1; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
+  }
+  if (lane == 0) {
+    // S = sum of < 2^32 values < l: carry-normalise into 8 words + overflow word
+    uint32_t wds[8];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      carry += acc[i];
+      wds[i] = (uint32_t)carry;
+      carry >>= 32;
+    }
+    // value = lo + carry * 2^256 (Montgomery form of the true sum).  from_mont(lo) + carry  (2^256 * R^-1 = 1)
+    sc lo, res, hi;
+    sc_const(lo, wds);
+    sc_from_mont(res, lo);
+    sc_0(hi);
+    hi.v[0] = (uint32_t)carry;
+    hi.v[1] = (uint32_t)(carry >> 32);
+    sc_add(res, res, hi);
+    out[(size_t)g * cols + col] = res;
+  }
+}
+
+// Mask recovery (src/range_proof.rs:941-969) with nonce() (src/utils/generic.rs:30-60), one lane per proof.
+__device__ __forceinline__ void dev_nonce(sc &out, const uint8_t seed32[32], const char *label, uint32_t llen, int j, int k) {
+  uint8_t key[43];
+  uint32_t n = 0;
+  key[n++] = 0;
+  for (int i = 0; i < 32; i++) key[n++] = seed32[i];
+  if (j >= 0) {
+    key[n++] = 'j';
+    u32le(key + n, (uint32_t)j);
+    n += 4;
+  }
+  if (k >= 0) {
+    key[n++] = 'k';
+    u32le(key + n, (uint32_t)k);
+    n += 4;
+  }
+  uint8_t h[64];
+  blake2b512_keyed_personal_empty(h, key, n, (const uint8_t *)label, llen);
+  sc_mont_from_wide(out, h);
+}
+
+__global__ void __launch_bounds__(64) k_masks(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
+                                              const sc *__restrict__ chal, const uint8_t *__restrict__ seeds32,
+                                              uint32_t n_bits, uint32_t t, uint32_t cs, uint32_t B,
+                                              uint8_t *__restrict__ masks_out /* [B][t][32] */) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  const ProofDesc d = desc[p];
+  if (!(d.flags & 1u)) return;
+  const sc *c = chal + (size_t)p * cs;
+  const uint8_t *seed = seeds32 + (size_t)p * 32;
+  const uint8_t *pd1 = bytes + d.proof_off + 1;
+  const uint32_t r = d.rounds, mn = d.m * n_bits;
+  sc y = c[0], z = c[1], ef = c[2 + r];
+  sc e_square, e_square_inv, z_square, y_nm_1, zy_inv, tmp;
+  sc_montsq(e_square, ef);
+  sc_mont_invert(e_square_inv, e_square);
+  sc_montsq(z_square, z);
+  sc_mont_pow_u32(y_nm_1, y, mn + 1);
+  sc_montmul(tmp, z_square, y_nm_1);
+  sc_mont_invert(zy_inv, tmp);
+  for (uint32_t k = 0; k < t; k++) {
+    sc mask, n1, n2;
+    sc_load_mont(mask, pd1 + 32 * k);
+    dev_nonce(n1, seed, "eta", 3, -1, (int)k);
+    sc_sub(mask, mask, n1);
+    dev_nonce(n2, seed, "d", 1, -1, (int)k);
+    sc_montmul(n2, n2, ef);
+    sc_sub(mask, mask, n2);
+    sc_montmul(mask, mask, e_square_inv);
+    dev_nonce(n1, seed, "alpha", 5, -1, (int)k);
+    sc_sub(mask, mask, n1);
+    for (uint32_t j = 0; j < r; j++) {
+      sc ej = c[2 + j], ej2, ej2inv, ejinv;
+      sc_montsq(ej2, ej);
+      sc_mont_invert(ejinv, ej);
+      sc_montsq(ej2inv, ejinv);
+      dev_nonce(n1, seed, "dL", 2, (int)j, (int)k);
+      sc_montmul(n1, n1, ej2);
+      sc_sub(mask, mask, n1);
+      dev_nonce(n2, seed, "dR", 2, (int)j, (int)k);
+      sc_montmul(n2, n2, ej2inv);
+      sc_sub(mask, mask, n2);
+    }
+    sc_montmul(mask, mask, zy_inv);
+    sc_from_mont(mask, mask);
+    uint8_t o[32];
+    sc_store_words(o, mask);
+    for (int i = 0; i < 32; i++) masks_out[((size_t)p * t + k) * 32 + i] = o[i];
+  }
+}
+
+// challenges to canonical bytes for the parity trace
+__global__ void k_chal_canonical(const sc *__restrict__ chal, uint32_t n, uint8_t *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sc v;
+  sc_from_mont(v, chal[i]);
+  uint8_t o[32];
+  sc_store_words(o, v);
+  for (int k = 0; k < 32; k++) out[(size_t)i * 32 + k] = o[k];
+}
+
+}  // namespace bpp

@@ -1,0 +1,311 @@
+// ristretto255 group operations for gfx950 (twisted Edwards a = -1, extended coordinates).
+//
+//   ge      (X:Y:Z:T)            accumulator form, 160 B
+//   niels   (y+x, y-x, 2dxy)     affine operand form, 120 B -- every MSM input point is stored like this
+//
+// Replaces (reference boundary): RistrettoPoint / CompressedRistretto of curve25519-dalek as used at
+// src/range_proof.rs:1050-1057 (final MSM), :1067-1109 (decompress), :348,:499-504 (compress),
+// src/generators/generators_chain.rs:43-49 (from_uniform_bytes).  Algorithms: RFC 9496 4.3.1-4.3.4.
+#pragma once
+#include "field.h"
+
+namespace bpp {
+
+#define BPP_CONST static constexpr
+#include "field_consts.inc"
+
+BPP_HD void fe_const(fe &h, const uint32_t c[10]) {
+#pragma unroll
+  for (int i = 0; i < 10; i++) h.v[i] = c[i];
+}
+
+struct ge {
+  fe X, Y, Z, T;
+};
+struct niels {
+  fe yplusx, yminusx, xy2d;
+};
+
+BPP_HD void ge_identity(ge &r) {
+  fe_0(r.X);
+  fe_1(r.Y);
+  fe_1(r.Z);
+  fe_0(r.T);
+}
+
+BPP_HD void niels_identity(niels &r) {
+  fe_1(r.yplusx);
+  fe_1(r.yminusx);
+  fe_0(r.xy2d);
+}
+
+// affine (x, y) -> niels
+BPP_HD void niels_from_affine(niels &r, const fe &x, const fe &y) {
+  fe t, d2;
+  fe_add(r.yplusx, y, x);
+  fe_carry(r.yplusx);
+  fe_sub(r.yminusx, y, x);
+  fe_mul(t, x, y);
+  fe_const(d2, FE_D2);
+  fe_mul(r.xy2d, t, d2);
+}
+
+// r = p + q (q affine niels): 7 mul
+BPP_HD void ge_madd(ge &r, const ge &p, const niels &q) {
+  fe a, b, c, d, e, f, g, h;
+  fe_add(a, p.Y, p.X);
+  fe_sub(b, p.Y, p.X);
+  fe_mul(a, a, q.yplusx);
+  fe_mul(b, b, q.yminusx);
+  fe_mul(c, q.xy2d, p.T);
+  fe_add(d, p.Z, p.Z);
+  fe_sub(e, a, b);
+  fe_add(h, a, b);
+  fe_add(g, d, c);
+  fe_sub(f, d, c);
+  fe_mul(r.X, e, f);
+  fe_mul(r.Y, h, g);
+  fe_carry(g);
+  fe_mul(r.Z, g, f);
+  fe_mul(r.T, e, h);
+}
+
+// r = p - q (q affine niels)
+BPP_HD void ge_msub(ge &r, const ge &p, const niels &q) {
+  fe a, b, c, d, e, f, g, h;
+  fe_add(a, p.Y, p.X);
+  fe_sub(b, p.Y, p.X);
+  fe_mul(a, a, q.yminusx);
+  fe_mul(b, b, q.yplusx);
+  fe_mul(c, q.xy2d, p.T);
+  fe_add(d, p.Z, p.Z);
+  fe_sub(e, a, b);
+  fe_add(h, a, b);
+  fe_sub(g, d, c);
+  fe_add(f, d, c);
+  fe_mul(r.X, e, f);
+  fe_mul(r.Y, h, g);
+  fe_carry(f);
+  fe_mul(r.Z, g, f);
+  fe_mul(r.T, e, h);
+}
+
+// r = p + q, both extended: 9 mul
+BPP_HD void ge_add(ge &r, const ge &p, const ge &q) {
+  fe a, b, c, d, e, f, g, h, t, d2;
+  fe_sub(a, p.Y, p.X);
+  fe_sub(t, q.Y, q.X);
+  fe_mul(a, a, t);
+  fe_add(b, p.Y, p.X);
+  fe_add(t, q.Y, q.X);
+  fe_mul(b, b, t);
+  fe_const(d2, FE_D2);
+  fe_mul(c, p.T, q.T);
+  fe_mul(c, c, d2);
+  fe_mul(d, p.Z, q.Z);
+  fe_add(d, d, d);
+  fe_sub(e, b, a);
+  fe_sub(f, d, c);
+  fe_add(g, d, c);
+  fe_add(h, b, a);
+  fe_mul(r.X, e, f);
+  fe_carry(g);
+  fe_mul(r.Y, g, h);
+  fe_mul(r.Z, f, g);
+  fe_mul(r.T, e, h);
+}
+
+// r = 2p: 4 sq + 4 mul
+BPP_HD void ge_dbl(ge &r, const ge &p) {
+  fe a, b, c, e, f, g, h, t;
+  fe_sq(a, p.X);
+  fe_sq(b, p.Y);
+  fe_sq(c, p.Z);
+  fe_add(c, c, c);
+  fe_add(h, a, b);
+  fe_add(t, p.X, p.Y);
+  fe_sq(t, t);
+  fe_sub(e, h, t);
+  fe_sub(g, a, b);
+  fe_add(f, c, g);
+  fe_carry(f);
+  fe_carry(h);
+  fe_mul(r.X, e, f);
+  fe_mul(r.Y, g, h);
+  fe_mul(r.Z, f, g);
+  fe_mul(r.T, e, h);
+}
+
+BPP_HD void ge_neg(ge &r, const ge &p) {
+  fe_neg(r.X, p.X);
+  fe_copy(r.Y, p.Y);
+  fe_copy(r.Z, p.Z);
+  fe_neg(r.T, p.T);
+}
+
+// RFC 9496 4.2 SQRT_RATIO_M1
+BPP_HD bool fe_sqrt_ratio_m1(fe &r_out, const fe &u, const fe &v) {
+  fe v3, v7, r, check, t, neg_u, neg_u_i, sqrt_m1, rp;
+  fe_sq(v3, v);
+  fe_mul(v3, v3, v);
+  fe_sq(v7, v3);
+  fe_mul(v7, v7, v);
+  fe_mul(t, u, v7);
+  fe_pow22523(r, t);
+  fe_mul(t, u, v3);
+  fe_mul(r, r, t);
+  fe_sq(check, r);
+  fe_mul(check, check, v);
+  fe_const(sqrt_m1, FE_SQRT_M1);
+  fe_neg(neg_u, u);
+  fe_mul(neg_u_i, neg_u, sqrt_m1);
+  bool correct_sign = fe_eq(check, u);
+  bool flipped_sign = fe_eq(check, neg_u);
+  bool flipped_sign_i = fe_eq(check, neg_u_i);
+  fe_mul(rp, r, sqrt_m1);
+  fe_cmov(r, rp, flipped_sign || flipped_sign_i);
+  fe_abs(r_out, r);
+  return correct_sign || flipped_sign;
+}
+
+// RFC 9496 4.3.1 Decode -> affine niels.  false = not a canonical encoding of a point.
+BPP_HD bool ristretto_decompress(niels &out, const uint8_t s_bytes[32]) {
+  fe s, ss, u1, u2, u2_sqr, v, t, one, d, invsqrt, den_x, den_y, x, y;
+  fe_frombytes(s, s_bytes);
+  // canonical: re-encoding must reproduce the input (rejects >= p and bit 255); non-negative: low bit 0
+  uint8_t chk[32];
+  fe_tobytes(chk, s);
+  uint32_t diff = 0;
+#pragma unroll
+  for (int i = 0; i < 32; i++) diff |= (uint32_t)(chk[i] ^ s_bytes[i]);
+  bool ok = (diff == 0) && ((s_bytes[0] & 1) == 0);
+  fe_1(one);
+  fe_sq(ss, s);
+  fe_sub(u1, one, ss);
+  fe_add(u2, one, ss);
+  fe_carry(u2);
+  fe_sq(u2_sqr, u2);
+  fe_const(d, FE_D);
+  fe_sq(t, u1);
+  fe_mul(t, t, d);
+  fe_neg(t, t);
+  fe_sub(v, t, u2_sqr);
+  fe_mul(t, v, u2_sqr);
+  bool was_square = fe_sqrt_ratio_m1(invsqrt, one, t);
+  fe_mul(den_x, invsqrt, u2);
+  fe_mul(den_y, invsqrt, den_x);
+  fe_mul(den_y, den_y, v);
+  fe_mul(x, s, den_x);
+  fe_add(x, x, x);
+  fe_abs(x, x);
+  fe_mul(y, u1, den_y);
+  fe_mul(t, x, y);
+  ok = ok && was_square && !fe_isnegative(t) && !fe_iszero(y);
+  niels_from_affine(out, x, y);
+  return ok;
+}
+
+// RFC 9496 4.3.2 Encode
+BPP_HD void ristretto_compress(uint8_t out[32], const ge &p) {
+  fe u1, u2, t, one, invsqrt, den1, den2, z_inv, ix0, iy0, ench, x, y, den_inv, sqrt_m1, c, s;
+  fe_add(u1, p.Z, p.Y);
+  fe_sub(t, p.Z, p.Y);
+  fe_mul(u1, u1, t);
+  fe_mul(u2, p.X, p.Y);
+  fe_sq(t, u2);
+  fe_mul(t, t, u1);
+  fe_1(one);
+  fe_sqrt_ratio_m1(invsqrt, one, t);
+  fe_mul(den1, invsqrt, u1);
+  fe_mul(den2, invsqrt, u2);
+  fe_mul(z_inv, den1, den2);
+  fe_mul(z_inv, z_inv, p.T);
+  fe_const(sqrt_m1, FE_SQRT_M1);
+  fe_mul(ix0, p.X, sqrt_m1);
+  fe_mul(iy0, p.Y, sqrt_m1);
+  fe_const(c, FE_INVSQRT_A_MINUS_D);
+  fe_mul(ench, den1, c);
+  fe_mul(t, p.T, z_inv);
+  bool rotate = fe_isnegative(t);
+  fe_copy(x, p.X);
+  fe_copy(y, p.Y);
+  fe_copy(den_inv, den2);
+  fe_cmov(x, iy0, rotate);
+  fe_cmov(y, ix0, rotate);
+  fe_cmov(den_inv, ench, rotate);
+  fe_mul(t, x, z_inv);
+  fe ny;
+  fe_neg(ny, y);
+  fe_cmov(y, ny, fe_isnegative(t));
+  fe_sub(t, p.Z, y);
+  fe_mul(s, den_inv, t);
+  fe_abs(s, s);
+  fe_tobytes(out, s);
+}
+
+// RFC 9496 4.3.4 MAP (Elligator 2 to the Jacobi quartic, then to Edwards)
+BPP_HD void ristretto_elligator(ge &out, const fe &t_in) {
+  fe r, u, v, c, s, s_prime, n, w0, w1, w2, w3, one, d, t, k;
+  fe_1(one);
+  fe_const(k, FE_SQRT_M1);
+  fe_sq(r, t_in);
+  fe_mul(r, r, k);  // r = i t^2
+  fe_add(u, r, one);
+  fe_const(k, FE_ONE_MINUS_D_SQ);
+  fe_mul(u, u, k);
+  fe_const(d, FE_D);
+  fe_mul(t, r, d);
+  fe_add(t, t, one);
+  fe_neg(t, t);  // -1 - r d
+  fe_add(v, r, d);
+  fe_mul(v, v, t);
+  bool was_square = fe_sqrt_ratio_m1(s, u, v);
+  fe_mul(s_prime, s, t_in);
+  fe_abs(s_prime, s_prime);
+  fe_neg(s_prime, s_prime);
+  fe_cmov(s, s_prime, !was_square);
+  fe_neg(c, one);
+  fe_cmov(c, r, !was_square);
+  fe_sub(t, r, one);
+  fe_mul(n, c, t);
+  fe_const(k, FE_D_MINUS_ONE_SQ);
+  fe_mul(n, n, k);
+  fe_sub(n, n, v);
+  fe_mul(w0, s, v);
+  fe_add(w0, w0, w0);
+  fe_const(k, FE_SQRT_AD_MINUS_ONE);
+  fe_mul(w1, n, k);
+  fe_sq(t, s);
+  fe_sub(w2, one, t);
+  fe_add(w3, one, t);
+  fe_carry(w3);
+  fe_mul(out.X, w0, w3);
+  fe_mul(out.Y, w2, w1);
+  fe_mul(out.Z, w1, w3);
+  fe_mul(out.T, w0, w2);
+}
+
+// RistrettoPoint::from_uniform_bytes
+BPP_HD void ristretto_from_uniform(ge &out, const uint8_t b[64]) {
+  fe r0, r1;
+  ge p0, p1;
+  fe_frombytes(r0, b);
+  fe_frombytes(r1, b + 32);
+  ristretto_elligator(p0, r0);
+  ristretto_elligator(p1, r1);
+  ge_add(out, p0, p1);
+}
+
+// extended -> affine niels (one inversion)
+BPP_HD void ge_to_niels(niels &out, const ge &p) {
+  fe zi, x, y;
+  fe_invert(zi, p.Z);
+  fe_mul(x, p.X, zi);
+  fe_mul(y, p.Y, zi);
+  niels_from_affine(out, x, y);
+}
+
+// ristretto identity test: X == 0 or Y == 0 (dalek ct_eq against (0,1,1,0))
+BPP_HD bool ge_is_ristretto_identity(const ge &p) { return fe_iszero(p.X) || fe_iszero(p.Y); }
+
+}  // namespace bpp

@@ -1,0 +1,164 @@
+/* bpp.h -- C ABI of libbpp_hip.so, the MI355X (gfx950) engine for the Bulletproofs+ range-proof hot path.
+ *
+ * Drop-in boundary for tari_bulletproofs_plus 0.4.1 (reference = /root/reference, Rust).  Two seams:
+ *
+ *  B1 (trait level)   the three curve25519-dalek multiscalar traits the reference is generic over
+ *                     (src/traits.rs:40-43, src/protocols/curve_point_protocol.rs:18-36, impl src/ristretto.rs:28-64)
+ *  B2 (protocol level) the bodies of RangeProof::verify (src/range_proof.rs:756-1065, entered through
+ *                     verify_batch :712-752) and RangeParameters::init (src/range_parameters.rs:32-58).
+ *
+ * Conventions
+ *  - points cross the boundary as 32-byte canonical ristretto255 encodings, scalars as 32-byte canonical
+ *    little-endian integers mod l; no C++ or torch types; caller owns every buffer; nothing is retained.
+ *  - return value: 0 = Ok; 1..5 = the reference's ProofError variants (src/errors.rs:11-28); negative = engine fault.
+ *  - a ctx is bound to one HIP device and one stream; params/precomp/batch handles belong to their ctx.
+ *  - every entry point fails (negative code) if no gfx950 device is usable: there is NO CPU fallback.
+ */
+#ifndef BPP_H
+#define BPP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ProofError mapping (src/errors.rs:11-28) */
+#define BPP_OK 0
+#define BPP_ERR_VERIFICATION_FAILED 1
+#define BPP_ERR_INVALID_ARGUMENT 2
+#define BPP_ERR_INVALID_LENGTH 3
+#define BPP_ERR_INVALID_BLAKE2B 4
+#define BPP_ERR_SIZE_OVERFLOW 5
+/* engine faults (no reference analogue) */
+#define BPP_ERR_ENGINE (-1)    /* HIP runtime error, see bpp_ctx_last_error */
+#define BPP_ERR_NO_DEVICE (-2) /* no usable gfx950 device */
+#define BPP_ERR_BAD_HANDLE (-3)
+
+/* VerifyAction (src/range_proof.rs:46-54) */
+#define BPP_VERIFY_ONLY 0
+#define BPP_RECOVER_AND_VERIFY 1
+#define BPP_RECOVER_ONLY 2
+
+/* MAX_RANGE_PROOF_BATCH_SIZE (src/range_proof.rs:76): pass as `chunk` for reference-sized batches */
+#define BPP_REFERENCE_CHUNK 256
+
+typedef struct bpp_ctx bpp_ctx;
+
+/* ---- context ---- */
+int bpp_ctx_create(bpp_ctx **out, int device_id);
+/* same, but all work is enqueued on the caller's hipStream_t (e.g. torch's current stream) */
+int bpp_ctx_create_on_stream(bpp_ctx **out, int device_id, void *hip_stream);
+void bpp_ctx_destroy(bpp_ctx *ctx);
+const char *bpp_ctx_last_error(bpp_ctx *ctx);
+
+/* ---- B1: multiscalar traits ----
+ * bpp_precomp_create  = VartimePrecomputedMultiscalarMul::new(static_points)   (src/generators/bulletproof_gens.rs:103)
+ * bpp_msm_mixed       = ::vartime_mixed_multiscalar_mul(static_scalars, dyn_scalars, dyn_points)
+ *                        (src/range_proof.rs:339-345, :1050-1057); n_static <= table size, rest = zero padding
+ * bpp_msm_vartime     = VartimeMultiscalarMul::vartime_multiscalar_mul          (src/range_proof.rs:482-495, :512-521)
+ *                        also serves MultiscalarMul::multiscalar_mul            (src/generators/pedersen_gens.rs:120)
+ * A point that does not decode makes the call return BPP_ERR_INVALID_ARGUMENT. */
+int bpp_precomp_create(bpp_ctx *ctx, const uint8_t *points32, size_t count, uint64_t *handle);
+int bpp_precomp_destroy(bpp_ctx *ctx, uint64_t handle);
+int bpp_msm_mixed(bpp_ctx *ctx, uint64_t handle, const uint8_t *static_scalars32, size_t n_static,
+                  const uint8_t *dyn_scalars32, const uint8_t *dyn_points32, size_t n_dyn, uint8_t out_point32[32]);
+int bpp_msm_vartime(bpp_ctx *ctx, const uint8_t *scalars32, const uint8_t *points32, size_t n,
+                    uint8_t out_point32[32]);
+/* many independent MSMs in one launch: group g covers terms [group_off[g], group_off[g+1]) */
+int bpp_msm_vartime_batched(bpp_ctx *ctx, const uint8_t *scalars32, const uint8_t *points32,
+                            const uint32_t *group_off, size_t n_groups, uint8_t *out_points32 /* n_groups x 32 */);
+
+/* ---- B2: parameters = RangeParameters::init + BulletproofGens::new + PedersenGens ----
+ * (src/range_parameters.rs:32-58, src/generators/bulletproof_gens.rs:83-112, src/ristretto.rs:67-112)
+ * h_base32 / g_bases32 may be NULL: the reference's defaults (Ristretto basepoint; SHA3-512 hash-to-group of
+ * "RISTRETTO_MASKING_BASEPOINT_k") are derived on the device. */
+int bpp_params_create(bpp_ctx *ctx, uint32_t bit_length, uint32_t max_aggregation, uint32_t extension_degree,
+                      const uint8_t *h_base32, const uint8_t *g_bases32, uint64_t *params);
+int bpp_params_destroy(bpp_ctx *ctx, uint64_t params);
+/* compressed generators, party-major like gi_base_iter()/hi_base_iter() (src/range_parameters.rs:99-106):
+ * gi_out32, hi_out32: bit_length*max_aggregation x 32; h_out32: 32; g_out32: extension_degree x 32. Any may be NULL. */
+int bpp_params_export(bpp_ctx *ctx, uint64_t params, uint8_t *gi_out32, uint8_t *hi_out32, uint8_t *h_out32,
+                      uint8_t *g_out32);
+/* PedersenGens::commit for `count` openings (src/generators/pedersen_gens.rs:112-122):
+ * values[count], blindings32[count][n_blind][32] -> commitments32[count][32]; 1 <= n_blind <= extension degree */
+int bpp_pedersen_commit(bpp_ctx *ctx, uint64_t params, const uint64_t *values, const uint8_t *blindings32,
+                        uint32_t n_blind, size_t count, uint8_t *commitments32);
+
+/* ---- B2: batch verification = RangeProof::verify_batch / verify ---- */
+typedef struct {
+  const uint8_t *proof;         /* RangeProof::to_bytes() (src/range_proof.rs:1120-1150) */
+  size_t proof_len;
+  const uint8_t *commitments32; /* statement.commitments_compressed, m x 32 (src/range_statement.rs:27) */
+  uint32_t m;                   /* aggregation factor of this statement */
+  const uint64_t *min_values;   /* m entries; value ignored where min_present[j] == 0 */
+  const uint8_t *min_present;   /* m entries, Option<u64>::is_some; NULL = all None */
+  const uint8_t *seed_nonce32;  /* NULL = None (src/range_statement.rs:31) */
+  /* the caller's merlin::Transcript: EITHER its 203-byte STROBE state (200 state bytes, pos, pos_begin, cur_flags)
+   * OR, for a fresh Transcript::new(label), the label */
+  const uint8_t *transcript_state;
+  const uint8_t *transcript_label;
+  size_t label_len;
+} bpp_verify_item;
+
+/* One call = RangeProof::verify over every `chunk` consecutive proofs (chunk == 0: the whole batch is ONE
+ * reference batch; chunk == 256 reproduces verify_batch's chunking but -- unlike src/range_proof.rs:740-751 --
+ * verifies EVERY chunk, first failing chunk's error wins).
+ * masks_out: n_items x extension_degree x 32 (may be NULL for BPP_VERIFY_ONLY); mask_present: n_items (may be NULL).
+ * errbuf receives the reference's informational message text. */
+int bpp_verify_batch(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, int action,
+                     size_t chunk, uint8_t *masks_out, uint8_t *mask_present, char *errbuf, size_t errbuf_len);
+
+/* Same in two steps so a batch can stay resident in HBM: upload parses/validates/packs and copies to the device;
+ * verify_resident runs only device work plus the (inherently sequential) weight chain. */
+int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, uint64_t *batch,
+                     char *errbuf, size_t errbuf_len);
+int bpp_batch_destroy(bpp_ctx *ctx, uint64_t batch);
+int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, uint8_t *masks_out,
+                        uint8_t *mask_present, char *errbuf, size_t errbuf_len);
+
+/* ---- phased form of the same verification, for sharding one reference batch across GPUs ----
+ * phase1: PASS 1 of verify (src/range_proof.rs:816-850) for this rank's proofs -> the 32 transcript-RNG bytes per
+ *         proof that feed the weight transcript (:845-849).
+ * weights_from_chain: the weight transcript itself (:811,:849,:853,:894) over the WHOLE batch in global proof order
+ *         (pure host function: the chain is a sequential sponge).
+ * phase2: PASS 2 (:856-1033) + this rank's share of the final MSM (:1050) -> partial accumulator as 128 bytes
+ *         (X,Y,Z,T canonical field elements).  Only rank 0 (include_pedersen != 0 on exactly one rank is NOT needed:
+ *         every rank adds its own share of the g/h base scalars).
+ * accumulators_sum_is_identity: sum of all ranks' accumulators == identity  (:1057). */
+int bpp_verify_phase1(bpp_ctx *ctx, uint64_t batch, uint8_t *rng_out32 /* n_items x 32 */, char *errbuf,
+                      size_t errbuf_len);
+int bpp_weights_from_chain(const uint8_t *rng32_all, size_t n_total, uint8_t *weights32_out /* n_total x 32 */);
+int bpp_verify_phase2(bpp_ctx *ctx, uint64_t batch, const uint8_t *weights32 /* n_items x 32 */,
+                      uint8_t accumulator128[128], char *errbuf, size_t errbuf_len);
+int bpp_accumulators_sum_is_identity(bpp_ctx *ctx, const uint8_t *accumulators128, size_t n, int *is_identity);
+
+/* ---- parity / diagnostics: intermediates of the last verify on `batch`, for differential tests ---- */
+#define BPP_TRACE_CHALLENGES 1     /* per proof (rmax+3) x 32: y, z, e_0.., e_final (canonical), rmax = max rounds */
+#define BPP_TRACE_RNG_OUT 2        /* n x 32 */
+#define BPP_TRACE_WEIGHTS 3        /* n x 32 */
+#define BPP_TRACE_STATIC_SCALARS 4 /* groups x (2*max_mn + t + 1) x 32: gi0,hi0,gi1,hi1,...,g_0..g_{t-1},h */
+#define BPP_TRACE_DYNAMIC_SCALARS 5 /* total_dyn x 32, proof order: C_j.., A1, B, A, L.., R.. */
+#define BPP_TRACE_MSM_RESULT 6     /* groups x 32 compressed */
+int bpp_batch_trace(bpp_ctx *ctx, uint64_t batch, int what, uint8_t *out, size_t out_len, size_t *written);
+/* shape helpers for the above */
+int bpp_batch_shape(bpp_ctx *ctx, uint64_t batch, uint32_t *n_items, uint32_t *max_rounds, uint32_t *max_mn,
+                    uint32_t *total_dyn, uint32_t *groups);
+
+/* ---- per-stage device timing of the last verify (hipEvents on the ctx stream) ---- */
+typedef struct {
+  float transcripts_ms, decompress_ms, chain_host_ms, scalars_ms, reduce_ms;
+  float msm_digits_ms, msm_sort_ms, msm_accumulate_ms, msm_bucket_reduce_ms, msm_final_ms;
+  float total_ms;
+  uint32_t msm_terms, msm_window_bits, msm_windows, msm_groups;
+} bpp_profile;
+int bpp_profile_enable(bpp_ctx *ctx, int on);
+int bpp_profile_get(bpp_ctx *ctx, bpp_profile *out);
+
+/* Transcript::new(label) -> 203-byte STROBE state (host helper for callers that keep merlin on their side) */
+int bpp_transcript_new(const uint8_t *label, size_t label_len, uint8_t state203[203]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPP_H */
