@@ -1,0 +1,66 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/bpp.h declares; no compute without a GPU."""
+import ctypes
+import importlib
+import os
+import re
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "bpp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bpp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    pkg = importlib.import_module("bulletproofs-plus_amd")
+    pkg._build.build()
+    lib = pkg._lib.load()
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libbpp_hip.so does not export %s" % n
+    assert sorted(n for n, _, _ in pkg._lib.SYMBOLS) == names
+
+
+def test_host_only_entry_points():
+    pkg = importlib.import_module("bulletproofs-plus_amd")
+    from oracle.pyref import merlin as M
+    assert pkg.Transcript.new(b"BatchedRangeProofTest").strobe_state() == M.Transcript(b"BatchedRangeProofTest").strobe.to_bytes()
+
+
+def test_fails_loudly_without_a_gpu():
+    if torch.cuda.is_available():
+        return
+    pkg = importlib.import_module("bulletproofs-plus_amd")
+    lib = pkg._lib.load()
+    ctx = ctypes.c_void_p()
+    assert lib.bpp_ctx_create(ctypes.byref(ctx), 0) < 0  # BPP_ERR_NO_DEVICE: there is no CPU fallback
+    try:
+        pkg.Engine(0)
+    except pkg.EngineError:
+        pass
+    else:
+        raise AssertionError("Engine() must not succeed without a gfx950 device")
+
+
+def test_from_bytes_mirror_matches_reference_rules():
+    """RangeProof::from_bytes host mirror (src/range_proof.rs:1339-1435)"""
+    pkg = importlib.import_module("bulletproofs-plus_amd")
+    from tests.helpers import make_oracle_batch
+    raw = make_oracle_batch(4, [1], 1, seed=b"ser").o_proofs[0].to_bytes()
+    K = pkg.ProofErrorKind
+    assert pkg.RangeProof.from_bytes(raw).to_bytes() == raw
+    for bad, kind in [(b"", K.InvalidLength), (raw[:-1], K.InvalidLength), (raw + b"\0", K.InvalidLength),
+                      (raw + bytes(32), K.InvalidLength), (b"\x07" + raw[1:], K.InvalidArgument),
+                      (raw[:1 + 32 * 6], K.InvalidLength), (raw[:1] + b"\xff" * 32 + raw[33:], K.InvalidArgument)]:
+        try:
+            pkg.RangeProof.from_bytes(bad)
+        except pkg.ProofError as e:
+            assert e.kind == kind
+        else:
+            raise AssertionError("expected ProofError")
+    assert pkg.RangeProof.extension_degree_from_proof_bytes(raw) == pkg.ExtensionDegree.DefaultPedersen

@@ -1,0 +1,25 @@
+"""CPU suite: csrc/*_consts.inc are reproducible from first principles (tools/gen_constants.py)."""
+import importlib.util
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_generated_constants_are_current(tmp_path):
+    spec = importlib.util.spec_from_file_location("gen_constants", os.path.join(ROOT, "tools", "gen_constants.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    csrc = os.path.join(ROOT, "bulletproofs-plus_amd", "csrc")
+    fld = open(os.path.join(csrc, "field_consts.inc")).read()
+    scl = open(os.path.join(csrc, "scalar_consts.inc")).read()
+
+    def arr(src, name):
+        m = re.search(name + r"\[\d+\] = \{([^}]*)\}", src)
+        return [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")]
+    assert arr(fld, "FE_D") == g.limbs10(g.D)
+    assert arr(fld, "FE_SQRT_M1") == g.limbs10(g.SQRT_M1)
+    assert arr(fld, "FE_INVSQRT_A_MINUS_D") == g.limbs10(g.INVSQRT_A_MINUS_D)
+    assert arr(scl, "SC_R2") == g.words8(pow(2, 512, g.L))
+    assert arr(scl, "SC_R3") == g.words8(pow(2, 768, g.L))
+    assert (-pow(g.L, -1, 2**32)) % 2**32 == 0x12547E1B

@@ -1,0 +1,125 @@
+"""CPU suite: the product's shared host/device arithmetic headers (csrc/*.h), host-compiled, vs the oracle.
+The same headers are what hipcc compiles for gfx950; the -m gpu tests then cover the device build."""
+import ctypes
+import hashlib
+import importlib
+
+import pytest
+
+from oracle.pyref import curve as C
+from oracle.pyref import merlin as M
+from oracle.pyref import protocol as O
+
+P, L = C.P, C.L
+
+
+@pytest.fixture(scope="module")
+def ht():
+    pkg = importlib.import_module("bulletproofs-plus_amd")
+    return ctypes.CDLL(pkg._build.build_hosttest())
+
+
+def _r(tag, i, n=32):
+    return hashlib.shake_256(b"%s%d" % (tag, i)).digest(n)
+
+
+def _buf(n=32):
+    return ctypes.create_string_buffer(n)
+
+
+EDGE_FE = [0, 1, 2, P - 1, P - 2, P, P + 1, 2**255 - 1, 2**255 - 20, 2**254, 19, 2**26 - 1, 2**51]
+EDGE_SC = [0, 1, L - 1, L - 2, 2, L, L + 1, 2**256 - 1, 2**252, 2**253 - 1]
+
+
+def test_field(ht):
+    vals = [int.from_bytes(_r(b"f", i), "little") & ((1 << 255) - 1) for i in range(60)] + EDGE_FE
+    for a in vals:
+        ab = a.to_bytes(32, "little")
+        for b in vals[:5] + EDGE_FE:
+            o = _buf()
+            ht.ht_fe_mul(ab, b.to_bytes(32, "little"), o)
+            assert int.from_bytes(o.raw, "little") == a * b % P
+            ht.ht_fe_addsubmul(ab, b.to_bytes(32, "little"), o)
+            assert int.from_bytes(o.raw, "little") == (a + b) * (a - b) % P
+        o = _buf()
+        ht.ht_fe_sq(ab, o)
+        assert int.from_bytes(o.raw, "little") == a * a % P
+        ht.ht_fe_invert(ab, o)
+        assert int.from_bytes(o.raw, "little") == pow(a, P - 2, P)
+
+
+def test_scalar(ht):
+    vals = [int.from_bytes(_r(b"s", i), "little") for i in range(60)] + EDGE_SC
+    for a in vals:
+        ab = a.to_bytes(32, "little")
+        for b in vals[:4] + EDGE_SC:
+            o = _buf()
+            ht.ht_sc_mul(ab, b.to_bytes(32, "little"), o)
+            assert int.from_bytes(o.raw, "little") == a * b % L
+            if a < L and b < L:
+                s, d = _buf(), _buf()
+                ht.ht_sc_addsub(ab, b.to_bytes(32, "little"), s, d)
+                assert int.from_bytes(s.raw, "little") == (a + b) % L and int.from_bytes(d.raw, "little") == (a - b) % L
+        assert ht.ht_sc_canonical(ab) == (1 if a < L else 0)
+        o = _buf()
+        ht.ht_sc_invert((a % L).to_bytes(32, "little"), o)
+        assert int.from_bytes(o.raw, "little") == pow(a % L, L - 2, L)
+    for w in [_r(b"w", i, 64) for i in range(50)] + [b"\xff" * 64, bytes(64), L.to_bytes(64, "little"),
+                                                      (L * L - 1).to_bytes(64, "little")]:
+        o = _buf()
+        ht.ht_sc_wide(w, o)
+        assert int.from_bytes(o.raw, "little") == int.from_bytes(w, "little") % L
+
+
+def test_ristretto(ht):
+    for i in range(24):
+        u = _r(b"u", i, 64)
+        o = _buf()
+        ht.ht_from_uniform(u, o)
+        pt = C.from_uniform_bytes(u)
+        assert o.raw == pt.compress()
+        o2 = _buf()
+        assert ht.ht_decompress_compress(o.raw, o2) == 1 and o2.raw == o.raw
+        k = int.from_bytes(_r(b"k", i), "little") % L
+        o3 = _buf()
+        assert ht.ht_scalarmult(k.to_bytes(32, "little"), o.raw, o3) == 1 and o3.raw == (pt * k).compress()
+    for i in range(120):  # random strings: accept/reject must agree with the oracle
+        s = _r(b"bad", i)
+        assert (ht.ht_decompress_compress(s, _buf()) == 1) == (C.decompress(s) is not None)
+    for s in [P.to_bytes(32, "little"), (1).to_bytes(32, "little"), b"\xff" * 32, (2**255).to_bytes(32, "little")]:
+        assert ht.ht_decompress_compress(s, _buf()) == 0
+    assert ht.ht_is_identity(bytes(32)) == 1 and ht.ht_is_identity(C.BASEPOINT.compress()) == 0
+
+
+def test_merlin_and_blake2b(ht):
+    o, st = _buf(32), _buf(203)
+    ht.ht_merlin_kat(b"test protocol", 13, b"some label", 10, b"some data", 9, b"challenge", 9, o, 32, st)
+    assert o.raw.hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    t = M.Transcript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    t.challenge_bytes(b"challenge", 32)
+    assert st.raw == t.strobe.to_bytes()
+
+    class R:
+        def fill_bytes(self, n):
+            return b"\x07" * n
+    for wit in [b"", b"w" * 40, b"z" * 200]:
+        out = _buf(100)
+        ht.ht_merlin_rng(st.raw, wit, len(wit), b"\x07" * 32, out, 100)
+        b = t.build_rng()
+        if wit:
+            b.rekey_with_witness_bytes(b"witness", wit)
+        assert b.finalize(R()).fill_bytes(100) == out.raw
+    for n in [165, 166, 167, 400]:  # absorbs that straddle the STROBE rate
+        msg = (bytes(range(256)) * 2)[:n]
+        out = _buf(70)
+        ht.ht_merlin_kat(b"x", 1, b"lbl", 3, msg, n, b"c", 1, out, 70, st)
+        t2 = M.Transcript(b"x")
+        t2.append_message(b"lbl", msg)
+        assert t2.challenge_bytes(b"c", 70) == out.raw
+    for (sn, lab, j, k) in [(1, "alpha", None, 0), (1, "dL", 3, 2), (1, "eta", None, None), (L - 1, "dR", 7, 5)]:
+        key = b"\x00" + sn.to_bytes(32, "little") + (b"j" + j.to_bytes(4, "little") if j is not None else b"") + \
+            (b"k" + k.to_bytes(4, "little") if k is not None else b"")
+        out = _buf(64)
+        ht.ht_blake2b(key, len(key), lab.encode(), len(lab), out)
+        assert int.from_bytes(out.raw, "little") % L == O.nonce(sn, lab, j, k)
