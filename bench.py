@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: 64-bit range proofs verified / second (batch).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode wide|shard] [--config cfg2|cfg3] [--no-cpu-baseline]
+
+A step = one pass of the hot path (RangeProof::verify: transcript replay, decompression, scalar block, weight chain,
+final MSM) over one resident batch.  Workload at N=1 = BASELINE.json configs[1]: 1024 non-aggregated 64-bit proofs,
+extension degree 1, inputs already resident in HBM (tests/golden/bench_cfg2.bin, produced by tests/golden/make_golden.py
+with the recipe of benches/range_proof.rs:206-262).  N>1 (launched by torch.distributed.run, one rank per GPU):
+every rank holds its own 1024-proof shard (weak scaling); mode "wide" verifies the union as ONE reference batch
+(all_gather of transcript-RNG bytes + all_gather of accumulator points over RCCL), mode "shard" treats each shard as
+an independent reference batch.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="wide", choices=["wide", "shard"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"])
+    ap.add_argument("--chunk", type=int, default=0, help="proofs per reference batch at N=1 (0 = whole batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    bpp = importlib.import_module("bulletproofs-plus_amd")
+    from tests.golden.loader import load_bench
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    data = load_bench("bench_%s.bin" % args.config)
+    items = data["items"]
+    if world > 1:  # each rank verifies a different rotation of the fixture, so shards are not byte-identical
+        k = (rank * 131) % len(items)
+        items = items[k:] + items[:k]
+    n_local = len(items)
+
+    stream = torch.cuda.Stream(device=device)
+    eng = bpp.Engine(local_rank, stream=stream.cuda_stream)
+    eng.profile(True)
+    params = bpp.RangeParameters.init(data["bit_length"], data["m"], bpp.create_pedersen_gens_with_extension_degree(data["t"]),
+                                      engine=eng)
+    sts = [bpp.RangeStatement.init(params, it["commitments"], it["min_values"], None) for it in items]
+    proofs = [bpp.RangeProof.from_bytes(it["proof"]) for it in items]
+    trs = [bpp.Transcript.new(data["label"]) for _ in items]
+    t_up0 = time.perf_counter()
+    rb = bpp.ResidentBatch(trs, sts, proofs)
+    t_upload = time.perf_counter() - t_up0
+
+    if world > 1:
+        from importlib import import_module
+        dmod = import_module("bulletproofs-plus_amd.dist")
+        ops = dmod.LocalEngineOps(rb)
+
+        def step():
+            dmod.verify_sharded(ops, n_local, device, mode=args.mode)
+    else:
+        def step():
+            rb.verify(bpp.VerifyAction.VerifyOnly, chunk=args.chunk)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    prof_sum = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if world == 1:
+            for k, v in eng.last_profile().items():
+                prof_sum[k] = prof_sum.get(k, 0.0) + v
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        total = n_local * world * args.steps
+        out = {
+            "metric": "64-bit range proofs verified/sec (batch)", "value": total / elapsed, "unit": "proofs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[%d]: %d x aggregation-%d 64-bit proofs per GPU, extension degree %d, "
+                                   "VerifyOnly, resident in HBM" % (1 if args.config == "cfg2" else 2, n_local, data["m"], data["t"]),
+                       "batch_per_gpu": n_local, "mode": (args.mode if world > 1 else ("chunk-%d" % args.chunk if args.chunk else "wide")),
+                       "parallelism": "proof-sharded x%d" % world},
+        }
+        if world == 1 and prof_sum:
+            k = args.steps
+            avg = {n: v / k for n, v in prof_sum.items()}
+            msm_ms = avg["msm_digits_ms"] + avg["msm_sort_ms"] + avg["msm_accumulate_ms"] + avg["msm_bucket_reduce_ms"] + avg["msm_final_ms"]
+            terms = int(avg["msm_terms"])
+            msm_bytes = 64 * terms  # 32 B scalar + 32 B compressed point per MSM term
+            achieved = msm_bytes / (msm_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                               "kernel": "final MSM (k_msm_digits .. k_msm_final)", "kernel_ms": msm_ms,
+                               "algorithmic_bytes": msm_bytes, "msm_terms": terms,
+                               "note": "integer-VALU bound, not HBM bound (SURVEY 8d); fraction is expected to be small"}
+            out["stages_ms"] = {n: round(v, 4) for n, v in avg.items() if n.endswith("_ms")}
+            out["pcie_inclusive_upload_ms"] = 1e3 * t_upload
+        if not args.no_cpu_baseline:
+            from oracle import cport  # cpu_baseline leg only
+            cp = cport.Params(data["bit_length"], data["m"], data["t"])
+            sample = data["items"][:256]  # one reference-sized batch (MAX_RANGE_PROOF_BATCH_SIZE)
+            rc, sec1 = cp.verify_timed(sample, 256, 1)
+            iters = max(1, int(args.cpu_seconds / max(sec1, 1e-3)))
+            rc, sec = cp.verify_timed(sample, 256, iters)
+            assert rc == 0
+            out["cpu_baseline"] = {"value": len(sample) * iters / sec, "unit": "proofs/s", "cores": 1, "kind": "port",
+                                   "sample": "%d x verify of one 256-proof reference batch (first 256 proofs of the workload), "
+                                             "single thread, oracle/c port with dalek's algorithms" % iters}
+            cp.close()
+        print(json.dumps(out))
+    rb.close()
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
