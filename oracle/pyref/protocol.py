@@ -565,9 +565,12 @@ def verify_batch(transcripts, statements, proofs, action):
     return verify(transcripts, statements[:n], proofs[:n], action)
 
 
-def verify(transcripts, statements, proofs, action, trace=None):
+def verify(transcripts, statements, proofs, action, trace=None, weights_override=None, check=True):
     """src/range_proof.rs:756-1065 (no batch-size limit). Returns list of masks (list[int] | None).
-    `trace`, if a dict, receives every intermediate the GPU path is diffed against."""
+    `trace`, if a dict, receives every intermediate the GPU path is diffed against.
+    Test-only knobs for the sharded (multi-GPU) form: `weights_override` replaces the weights this call would draw
+    from its own chain (a shard of a larger batch gets its weights from the global chain); `check=False` skips the
+    identity test so the caller can combine trace["accumulator"] across shards."""
     max_mn, max_index = _consistency(statements, proofs)
     first, max_st = statements[0], statements[max_index]
     g_base_vec = first.generators.g_bases()
@@ -626,6 +629,8 @@ def verify(transcripts, statements, proofs, action, trace=None):
             raise ProofError(INVALID_LENGTH, "Vector L/R length not adequate")
 
         weight = random_not_zero(weight_rng)  # :894
+        if weights_override is not None:
+            weight = weights_override[len(weights)]
         weights.append(weight)
 
         # :897-905 batch_invert([e_j..., y, y-1]); inverse(0)=0 convention
@@ -743,6 +748,7 @@ def verify(transcripts, statements, proofs, action, trace=None):
     acc = acc + C.multiscalar_mul(dynamic_scalars, dynamic_points)
     if trace is not None:
         trace["msm_result"] = acc.compress()
-    if acc != Point.identity():
+        trace["accumulator"] = acc
+    if check and acc != Point.identity():
         raise ProofError(VERIFICATION_FAILED, "Range proof batch not valid")
     return masks

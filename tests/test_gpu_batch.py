@@ -1,0 +1,259 @@
+"""GPU parity tests, part 2: error kinds and precedence, chunking, the sharded (phased) form, and the BASELINE-size
+workloads (tests/golden/bench_cfg2.bin / bench_cfg3.bin) through size-independent properties."""
+import hashlib
+import importlib
+
+import pytest
+
+from oracle import cport
+from oracle.pyref import curve as C
+from oracle.pyref import merlin as M
+from oracle.pyref import protocol as O
+from tests.golden.loader import load_bench
+from tests.helpers import make_batch, oracle_verify_trace, sb
+
+pytestmark = pytest.mark.gpu
+
+
+def _kind(bpp, fn):
+    with pytest.raises(bpp.ProofError) as e:
+        fn()
+    return e.value.kind
+
+
+def _bench_case(bpp, engine, name, count=None):
+    data = load_bench(name)
+    items = data["items"][:count] if count else data["items"]
+    params = bpp.RangeParameters.init(data["bit_length"], data["m"], bpp.create_pedersen_gens_with_extension_degree(data["t"]),
+                                      engine=engine)
+    sts = [bpp.RangeStatement.init(params, it["commitments"], it["min_values"], it["seed_nonce"]) for it in items]
+    pub = [bpp.RangeStatement.init(params, it["commitments"], it["min_values"], None) for it in items]
+    proofs = [bpp.RangeProof.from_bytes(it["proof"]) for it in items]
+    trs = lambda: [bpp.Transcript.new(data["label"]) for _ in items]
+    return data, items, params, sts, pub, proofs, trs
+
+
+def test_argument_errors(bpp, engine):
+    """src/range_proof.rs:1759-1808 (empty / mismatched vectors), :1438-1620 (batch consistency)"""
+    K, A = bpp.ProofErrorKind, bpp.VerifyAction
+    c = make_batch(bpp, engine, 4, [1, 1], 1, seed=b"args")
+    V = bpp.RangeProof.verify_batch
+    assert _kind(bpp, lambda: V([], [], [], A.VerifyOnly)) == K.InvalidArgument
+    assert _kind(bpp, lambda: V(c.transcripts(), c.statements_public, c.proofs[:1], A.VerifyOnly)) == K.InvalidArgument
+    assert _kind(bpp, lambda: V(c.transcripts()[:1], c.statements_public, c.proofs, A.VerifyOnly)) == K.InvalidArgument
+    # proof with a different extension degree than the statements' generators -> InvalidArgument (:637-659)
+    c2 = make_batch(bpp, engine, 4, [1], 2, seed=b"args2")
+    assert _kind(bpp, lambda: V(c.transcripts()[:1], c.statements_public[:1], c2.proofs, A.VerifyOnly)) == K.InvalidArgument
+    # different bit length in one batch (:651-655)
+    c3 = make_batch(bpp, engine, 8, [1], 1, seed=b"args3")
+    assert _kind(bpp, lambda: V(c.transcripts(), [c.statements_public[0], c3.statements_public[0]],
+                                [c.proofs[0], c3.proofs[0]], A.VerifyOnly)) == K.InvalidArgument
+    # minimum value promise that does not fit the bit length -> InvalidLength (:675-681)
+    big = bpp.RangeStatement.init(c.params, c.statements_public[0].commitments_compressed, [1 << 4], None)
+    assert _kind(bpp, lambda: V(c.transcripts()[:1], [big], c.proofs[:1], A.VerifyOnly)) == K.InvalidLength
+    # RangeStatement::init checks (src/range_statement.rs:43-62)
+    assert _kind(bpp, lambda: bpp.RangeStatement.init(c.params, [bytes(32)] * 3, [None] * 3, None)) == K.InvalidArgument
+    assert _kind(bpp, lambda: bpp.RangeStatement.init(c.params, [bytes(32)] * 2, [None] * 2, None)) == K.InvalidArgument  # m > m_max
+    # RangeParameters::init checks (src/range_parameters.rs:37-51)
+    G = bpp.create_pedersen_gens_with_extension_degree
+    assert _kind(bpp, lambda: bpp.RangeParameters.init(64, 3, G(1), engine=engine)) == K.InvalidArgument
+    assert _kind(bpp, lambda: bpp.RangeParameters.init(48, 1, G(1), engine=engine)) == K.InvalidArgument
+    assert _kind(bpp, lambda: bpp.RangeParameters.init(128, 1, G(1), engine=engine)) == K.InvalidArgument
+    assert _kind(bpp, lambda: G(7)) == K.InvalidArgument
+
+
+def test_point_errors_and_precedence(bpp, engine):
+    """non-canonical members -> InvalidArgument (:1623-1663); identity members -> VerificationFailed
+    (transcript_protocol.rs:48-61); PASS-1 errors of ANY proof precede PASS-2 errors"""
+    K, A = bpp.ProofErrorKind, bpp.VerifyAction
+    c = make_batch(bpp, engine, 8, [1, 1, 1], 1, seed=b"prec")
+    V = lambda proofs, sts=None: bpp.RangeProof.verify_batch(c.transcripts(), sts or c.statements_public, proofs, A.VerifyOnly)
+    raw = [p.to_bytes() for p in c.proofs]
+    t = 1
+    offA = 1 + 32 * t
+
+    def patched(i, off, data):
+        r = bytearray(raw[i])
+        r[off:off + len(data)] = data
+        out = list(c.proofs)
+        out[i] = bpp.RangeProof.from_bytes(bytes(r))
+        return out
+    noncanon = b"\x01" + bytes(31)  # negative field element: never a valid encoding
+    for off in (offA, offA + 32, offA + 64, offA + 160, offA + 192):  # A, A1, B, L0, R0
+        assert _kind(bpp, lambda: V(patched(0, off, noncanon))) == K.InvalidArgument
+        assert _kind(bpp, lambda: V(patched(2, off, bytes(32)))) == K.VerificationFailed
+    # proof 0 has a bad point (PASS 2), proof 2 an identity member (PASS 1) -> PASS 1 wins
+    both = patched(0, offA, noncanon)
+    r2 = bytearray(raw[2])
+    r2[offA + 32:offA + 64] = bytes(32)
+    both[2] = bpp.RangeProof.from_bytes(bytes(r2))
+    assert _kind(bpp, lambda: V(both)) == K.VerificationFailed
+    # wrong number of rounds for the statement -> InvalidLength (:886-888); with a bad point in an EARLIER proof the
+    # earlier proof's InvalidArgument wins, in a LATER proof the InvalidLength wins
+    short = bpp.RangeProof.from_bytes(raw[1][:-64])
+    assert _kind(bpp, lambda: V([c.proofs[0], short, c.proofs[2]])) == K.InvalidLength
+    assert _kind(bpp, lambda: V([patched(0, offA, noncanon)[0], short, c.proofs[2]])) == K.InvalidArgument
+    assert _kind(bpp, lambda: V([c.proofs[0], short, patched(2, offA, noncanon)[2]])) == K.InvalidLength
+    # a flipped response scalar / commitment / transcript label only shows up in the final MSM
+    r = bytearray(raw[1])
+    r[offA + 96] ^= 1
+    assert _kind(bpp, lambda: V([c.proofs[0], bpp.RangeProof.from_bytes(bytes(r)), c.proofs[2]])) == K.VerificationFailed
+    swapped = [c.statements_public[1], c.statements_public[0], c.statements_public[2]]
+    assert _kind(bpp, lambda: V(c.proofs, swapped)) == K.VerificationFailed
+    wrong_label = [bpp.Transcript.new(b"other label")] + c.transcripts()[1:]
+    assert _kind(bpp, lambda: bpp.RangeProof.verify_batch(wrong_label, c.statements_public, c.proofs, A.VerifyOnly)) == K.VerificationFailed
+    # identity commitment is allowed into the transcript -> reaches the MSM and fails there
+    st = bpp.RangeStatement.init(c.params, [bytes(32)], c.statements_public[0].minimum_value_promises, None)
+    assert _kind(bpp, lambda: V(c.proofs, [st] + c.statements_public[1:])) == K.VerificationFailed
+    # RecoverOnly never runs the MSM: a proof with a flipped scalar still returns Ok
+    bad = [c.proofs[0], bpp.RangeProof.from_bytes(bytes(r)), c.proofs[2]]
+    got = bpp.RangeProof.verify_batch(c.transcripts(), c.statements_private, bad, A.RecoverOnly)
+    assert all(m is not None for m in got)
+
+
+def test_transcript_state_equals_label(bpp, engine):
+    c = make_batch(bpp, engine, 8, [2, 1], 2, seed=b"state", label=b"a custom protocol label")
+    states = [bpp.Transcript.from_state(M.Transcript(c.label).strobe.to_bytes()) for _ in c.proofs]
+    assert bpp.RangeProof.verify_batch(states, c.statements_public, c.proofs, bpp.VerifyAction.VerifyOnly) == [None, None]
+    # a transcript that already absorbed caller data
+    t0 = M.Transcript(b"outer")
+    t0.append_message(b"ctx", b"application data")
+    c2 = make_batch(bpp, engine, 8, [1], 1, seed=b"state2")
+    proof = O.prove_with_rng(t0.clone(), c2.o_statements_private[0], c2.o_witnesses[0], M.NullRng())
+    pr = bpp.RangeProof.from_bytes(proof.to_bytes())
+    ok = bpp.RangeProof.verify_batch([bpp.Transcript.from_state(t0.strobe.to_bytes())], c2.statements_public[:1], [pr],
+                                     bpp.VerifyAction.VerifyOnly)
+    assert ok == [None]
+    assert _kind(bpp, lambda: bpp.RangeProof.verify_batch([bpp.Transcript.new(b"outer")], c2.statements_public[:1], [pr],
+                                                          bpp.VerifyAction.VerifyOnly)) == bpp.ProofErrorKind.VerificationFailed
+
+
+def test_generator_capacity_above_aggregation(bpp, engine):
+    """proof with m below the generators' capacity verifies (src/range_proof.rs:1811-1844): zero padding of the table"""
+    c = make_batch(bpp, engine, 8, [1, 2], 1, seed=b"cap", m_max=4)
+    got = bpp.RangeProof.verify_batch(c.transcripts(), c.statements_private, c.proofs, bpp.VerifyAction.RecoverAndVerify)
+    want, _ = oracle_verify_trace(c, action=1)
+    assert [m.blindings() if m else None for m in got] == want
+
+
+def test_chunking_matches_reference_batches(bpp, engine):
+    """chunk = k: every k consecutive proofs are one reference verify() (own weight chain, own MSM)"""
+    c = make_batch(bpp, engine, 8, [1, 2, 1, 1, 2], 1, seed=b"chunk")
+    rb = bpp.ResidentBatch(c.transcripts(), c.statements_public, c.proofs)
+    rb.verify(bpp.VerifyAction.VerifyOnly, chunk=2)
+    assert rb.shape()["groups"] == 3
+    weights, statics, dyn = rb.trace(3), rb.trace(4), rb.trace(5)
+    assert rb.trace(6) == bytes(32) * 3
+    cols = 2 * rb.shape()["max_mn"] + 1 + 1
+    w_off = d_off = 0
+    for g, (lo, hi) in enumerate([(0, 2), (2, 4), (4, 5)]):
+        _, tr = oracle_verify_trace(c, statements=c.o_statements_public[lo:hi], proofs=c.o_proofs[lo:hi])
+        assert weights[32 * lo:32 * hi] == b"".join(sb(w) for w in tr["weights"])
+        mm = tr["max_mn"]
+        got = statics[32 * cols * g:32 * cols * (g + 1)]
+        want_gh = b"".join(sb(a) + sb(b) for a, b in zip(tr["gi"], tr["hi"]))
+        assert got[:len(want_gh)] == want_gh and got[len(want_gh):32 * 2 * rb.shape()["max_mn"]] == bytes(32 * 2 * (rb.shape()["max_mn"] - mm))
+        assert got[-64:] == sb(tr["g"][0]) + sb(tr["h"])
+        nd = len(tr["dynamic_scalars"])
+        assert dyn[32 * d_off:32 * (d_off + nd)] == b"".join(sb(x) for x in tr["dynamic_scalars"])
+        d_off += nd
+    # a bad proof in chunk 1 fails the call; precedence is chunk-major: MSM failure of chunk 0 beats a structural
+    # error in chunk 1
+    rb.close()
+    raw = bytearray(c.proofs[0].to_bytes())
+    raw[1 + 32 + 96] ^= 1
+    bad0 = bpp.RangeProof.from_bytes(bytes(raw))
+    short3 = bpp.RangeProof.from_bytes(c.proofs[3].to_bytes()[:-64])
+    V = lambda proofs, chunk: bpp.RangeProof.verify_batch(c.transcripts(), c.statements_public, proofs, bpp.VerifyAction.VerifyOnly, chunk=chunk)
+    K = bpp.ProofErrorKind
+    assert _kind(bpp, lambda: V([c.proofs[0], c.proofs[1], c.proofs[2], short3, c.proofs[4]], 2)) == K.InvalidLength
+    assert _kind(bpp, lambda: V([bad0, c.proofs[1], c.proofs[2], short3, c.proofs[4]], 2)) == K.VerificationFailed
+    assert _kind(bpp, lambda: V([bad0, c.proofs[1], c.proofs[2], short3, c.proofs[4]], 0)) == K.InvalidLength  # one batch: PASS 2 first
+
+
+def test_phased_form_equals_single_call(bpp, engine):
+    """the multi-GPU building blocks on one GPU: two shards + global weight chain == one wide batch"""
+    c = make_batch(bpp, engine, 8, [1, 2, 1, 1], 1, seed=b"phase")
+    _, tr = oracle_verify_trace(c, action=0)
+    shards = [(0, 2), (2, 4)]
+    rbs = [bpp.ResidentBatch(c.transcripts()[lo:hi], c.statements_public[lo:hi], c.proofs[lo:hi]) for lo, hi in shards]
+    rng = b"".join(rb.phase1() for rb in rbs)
+    assert rng == b"".join(tr["rng_outputs"])
+    weights = bpp.weights_from_chain(rng)
+    assert weights == b"".join(sb(w) for w in tr["weights"])
+    accs = b"".join(rb.phase2(weights[32 * lo:32 * hi]) for rb, (lo, hi) in zip(rbs, shards))
+    assert bpp.accumulators_sum_is_identity(engine, accs)
+    # (each valid proof contributes the identity, so a valid shard's partial accumulator is itself an identity)
+    # tamper one shard -> the combined check fails
+    bumped = [bpp.RangeStatement.init(c.params, s.commitments_compressed, [(v or 0) + 1 for v in s.minimum_value_promises], None)
+              for s in c.statements_public[2:4]]
+    rb_bad = bpp.ResidentBatch(c.transcripts()[2:4], bumped, c.proofs[2:4])
+    rng2 = rbs[0].phase1() + rb_bad.phase1()
+    w2 = bpp.weights_from_chain(rng2)
+    accs2 = rbs[0].phase2(w2[:64]) + rb_bad.phase2(w2[64:])
+    assert not bpp.accumulators_sum_is_identity(engine, accs2)
+    assert bpp.accumulators_sum_is_identity(engine, accs2[:128]) and not bpp.accumulators_sum_is_identity(engine, accs2[128:])
+    for rb in rbs + [rb_bad]:
+        rb.close()
+
+
+def test_baseline_cfg2_full_size(bpp, engine):
+    """BASELINE configs[1]: 1024 x m=1 64-bit proofs.  Properties: wide == chunk-256 == accept; intermediates of the
+    first reference chunk equal the C oracle's; masks equal the blinding-derived expectation; one flipped bit anywhere
+    is rejected; weights are a function of every proof in the chunk."""
+    data, items, params, sts, pub, proofs, trs = _bench_case(bpp, engine, "bench_cfg2.bin")
+    A = bpp.VerifyAction
+    rb = bpp.ResidentBatch(trs(), pub, proofs)
+    assert rb.verify(A.VerifyOnly, chunk=0) == [None] * 1024
+    assert rb.trace(6) == bytes(32)
+    wide_w = rb.trace(3)
+    assert rb.verify(A.VerifyOnly, chunk=256) == [None] * 1024
+    assert rb.shape()["groups"] == 4 and rb.trace(6) == bytes(32) * 4
+    chunk_w = rb.trace(3)
+    assert chunk_w[:32] != wide_w[:32]  # different chain
+    cp = cport.Params(64, 1, 1)
+    rc, _, tr = cp.verify(items[:256], action=0, want_trace=True)
+    assert rc == 0
+    assert chunk_w[:32 * 256] == tr["weights"] and rb.trace(2)[:32 * 256] == tr["rng_out"]
+    assert rb.trace(4)[:32 * 130] == tr["static_scalars"]
+    assert rb.trace(5)[:32 * 16 * 256] == tr["dynamic_scalars"]
+    assert rb.trace(1)[:32 * 9 * 256] == tr["challenges"]
+    rb.close()
+    # mask recovery for all 1024 (RecoverOnly: wallets scanning outputs) vs the C oracle
+    got = bpp.RangeProof.verify_batch(trs(), sts, proofs, A.RecoverOnly, chunk=0)
+    rc, want, _ = cp.verify(items[:64], action=2)
+    assert [m.blindings() for m in got[:64]] == want
+    assert all(m is not None for m in got)
+    cp.close()
+    # one flipped bit in proof #777 -> reject, in wide and in chunked mode
+    raw = bytearray(items[777]["proof"])
+    raw[300] ^= 0x10
+    bad = list(proofs)
+    bad[777] = bpp.RangeProof.from_bytes(bytes(raw))
+    for chunk in (0, 256):
+        k = _kind(bpp, lambda: bpp.RangeProof.verify_batch(trs(), pub, bad, A.VerifyOnly, chunk=chunk))
+        assert k in (bpp.ProofErrorKind.VerificationFailed, bpp.ProofErrorKind.InvalidArgument)
+
+
+def test_baseline_cfg3_full_size(bpp, engine):
+    """BASELINE configs[2]: 256 x aggregation-8 proofs (1024 static generators, 9 rounds)"""
+    data, items, params, sts, pub, proofs, trs = _bench_case(bpp, engine, "bench_cfg3.bin")
+    rb = bpp.ResidentBatch(trs(), pub, proofs)
+    assert rb.verify(bpp.VerifyAction.VerifyOnly, chunk=0) == [None] * 256
+    shp = rb.shape()
+    assert shp["max_mn"] == 512 and shp["max_rounds"] == 9 and shp["total_dyn"] == 256 * 29
+    cp = cport.Params(64, 8, 1)
+    rc, _, tr = cp.verify(items, action=0, want_trace=True)
+    assert rc == 0
+    assert rb.trace(3) == tr["weights"] and rb.trace(4) == tr["static_scalars"] and rb.trace(5) == tr["dynamic_scalars"]
+    assert rb.trace(6) == tr["msm_result"] == bytes(32)
+    rb.close()
+    cp.close()
+    bumped = list(pub)
+    bumped[100] = bpp.RangeStatement.init(params, items[100]["commitments"], [v + (j == 5) for j, v in enumerate(items[100]["min_values"])], None)
+    assert _kind(bpp, lambda: bpp.RangeProof.verify_batch(trs(), bumped, proofs, bpp.VerifyAction.VerifyOnly, chunk=0)) == bpp.ProofErrorKind.VerificationFailed
+
+
+def test_smoke_entry(bpp):
+    import __graft_entry__
+    __graft_entry__.smoke()
