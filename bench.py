@@ -32,6 +32,12 @@ def main():
     ap.add_argument("--mode", default="wide", choices=["wide", "shard"])
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--chunk", type=int, default=0, help="proofs per reference batch at N=1 (0 = whole batch)")
+    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "8")),
+                    help="resident batches in flight per GPU (one engine/stream + one host thread each); a step is still "
+                         "one complete verify of one batch")
+    ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "16")),
+                    help="resident 1024-proof batches handled by one engine call; each stays its own reference batch "
+                         "(own weight chain, own final MSM): one call = that many steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -60,52 +66,93 @@ def main():
         items = items[k:] + items[:k]
     n_local = len(items)
 
-    stream = torch.cuda.Stream(device=device)
-    eng = bpp.Engine(local_rank, stream=stream.cuda_stream)
-    eng.profile(True)
-    params = bpp.RangeParameters.init(data["bit_length"], data["m"], bpp.create_pedersen_gens_with_extension_degree(data["t"]),
-                                      engine=eng)
-    sts = [bpp.RangeStatement.init(params, it["commitments"], it["min_values"], None) for it in items]
-    proofs = [bpp.RangeProof.from_bytes(it["proof"]) for it in items]
-    trs = [bpp.Transcript.new(data["label"]) for _ in items]
-    t_up0 = time.perf_counter()
-    rb = bpp.ResidentBatch(trs, sts, proofs)
-    t_upload = time.perf_counter() - t_up0
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
 
-    if world > 1:
-        from importlib import import_module
-        dmod = import_module("bulletproofs-plus_amd.dist")
-        ops = dmod.LocalEngineOps(rb)
+    wide = world > 1 and args.mode == "wide"
+    S = 1 if wide else max(1, args.concurrency)  # cross-rank collectives must stay in program order -> no threads
+    R = 1 if (wide or args.chunk) else max(1, args.batches_per_launch)
+    while args.steps % R:
+        R -= 1  # EXACTLY `steps` steps: one engine call = R steps
+    S = max(1, min(S, args.steps // R))
+    lanes = []  # one engine + stream + resident copy of the batch per in-flight slot
+    t_upload = 0.0
+    for i in range(S):
+        stream = torch.cuda.Stream(device=device)
+        eng = bpp.Engine(local_rank, stream=stream.cuda_stream)
+        eng.profile(True)
+        params = bpp.RangeParameters.init(data["bit_length"], data["m"],
+                                          bpp.create_pedersen_gens_with_extension_degree(data["t"]), engine=eng)
+        its = []
+        for r in range(R):  # R distinct rotations of the fixture = R different 1024-proof batches
+            k = ((i * R + r) * 37) % len(items)
+            its += items[k:] + items[:k]
+        sts = [bpp.RangeStatement.init(params, it["commitments"], it["min_values"], None) for it in its]
+        proofs = [bpp.RangeProof.from_bytes(it["proof"]) for it in its]
+        trs = [bpp.Transcript.new(data["label"]) for _ in its]
+        t_up0 = time.perf_counter()
+        rb = bpp.ResidentBatch(trs, sts, proofs)
+        t_upload = time.perf_counter() - t_up0
+        lanes.append((stream, eng, rb))
 
-        def step():
-            dmod.verify_sharded(ops, n_local, device, mode=args.mode)
-    else:
-        def step():
-            rb.verify(bpp.VerifyAction.VerifyOnly, chunk=args.chunk)
+    if wide:
+        dmod = importlib.import_module("bulletproofs-plus_amd.dist")
+        ops = dmod.LocalEngineOps(lanes[0][2])
+
+    def one_step(slot):
+        _, eng, rb = lanes[slot]
+        t0 = time.perf_counter()
+        if wide:
+            dmod.verify_sharded(ops, n_local, device, mode="wide")
+        else:
+            rb.verify(bpp.VerifyAction.VerifyOnly, chunk=(args.chunk or n_local))  # raises on an invalid batch
+        return time.perf_counter() - t0, eng.last_profile()
+
+    def run_steps(count):
+        """`count` complete steps, at most S in flight; returns (per-step latencies, per-step stage profiles)"""
+        if S == 1:
+            res = [one_step(0) for _ in range(count)]
+        else:
+            nxt = [0]
+            lock = threading.Lock()
+
+            def worker(slot):
+                out = []
+                while True:
+                    with lock:
+                        if nxt[0] >= count:
+                            return out
+                        nxt[0] += 1
+                    out.append(one_step(slot))
+            with ThreadPoolExecutor(S) as ex:
+                res = [r for part in ex.map(worker, range(S)) for r in part]
+        return [r[0] for r in res], [r[1] for r in res]
 
     def sync():
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    prof_sum = {}
+    run_steps(max(-(-args.warmup // R), S if args.warmup else 0))
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        if world == 1:
-            for k, v in eng.last_profile().items():
-                prof_sum[k] = prof_sum.get(k, 0.0) + v
+    lat, profs = run_steps(args.steps // R)
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ok_all = 1
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        flag = torch.tensor([ok_all], dtype=torch.int32, device=device)  # verdicts of independent shards
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        assert int(flag.item()) == 1
+    prof_sum = {}
+    for pf in profs:
+        for k, v in pf.items():
+            prof_sum[k] = prof_sum.get(k, 0.0) + v
 
     if rank == 0:
         total = n_local * world * args.steps
@@ -116,14 +163,19 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: %d x aggregation-%d 64-bit proofs per GPU, extension degree %d, "
                                    "VerifyOnly, resident in HBM" % (1 if args.config == "cfg2" else 2, n_local, data["m"], data["t"]),
-                       "batch_per_gpu": n_local, "mode": (args.mode if world > 1 else ("chunk-%d" % args.chunk if args.chunk else "wide")),
+                       "batch_per_gpu": n_local,
+                       "mode": ("one reference batch over all ranks (all_gather rng bytes + accumulators)" if wide else
+                                ("each %d-proof chunk is a reference batch" % args.chunk if args.chunk else
+                                 "each 1024-proof resident batch is one reference batch (private verify())")),
+                       "batches_per_launch": R, "launches_in_flight_per_gpu": S,
                        "parallelism": "proof-sharded x%d" % world},
+            "launch_latency_ms": 1e3 * sum(lat) / len(lat),
         }
-        if world == 1 and prof_sum:
-            k = args.steps
+        if prof_sum and prof_sum.get("msm_final_ms", 0) > 0:
+            k = len(profs)
             avg = {n: v / k for n, v in prof_sum.items()}
             msm_ms = avg["msm_digits_ms"] + avg["msm_sort_ms"] + avg["msm_accumulate_ms"] + avg["msm_bucket_reduce_ms"] + avg["msm_final_ms"]
-            terms = int(avg["msm_terms"])
+            terms = int(avg["msm_terms"])  # all R groups of one launch
             msm_bytes = 64 * terms  # 32 B scalar + 32 B compressed point per MSM term
             achieved = msm_bytes / (msm_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -146,8 +198,9 @@ def main():
                                              "single thread, oracle/c port with dalek's algorithms" % iters}
             cp.close()
         print(json.dumps(out))
-    rb.close()
-    eng.close()
+    for _, eng, rb in lanes:
+        rb.close()
+        eng.close()
     if world > 1:
         dist.destroy_process_group()
 

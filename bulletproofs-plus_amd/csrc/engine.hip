@@ -17,6 +17,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bpp.h"
@@ -63,6 +64,31 @@ struct DevBuf {
     HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
     n = count;
   }
+};
+
+// page-locked host memory: asynchronous copies to/from it do not stall other streams or host threads
+template <typename T>
+struct PinnedBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  PinnedBuf() {}
+  PinnedBuf(const PinnedBuf &) = delete;
+  PinnedBuf &operator=(const PinnedBuf &) = delete;
+  ~PinnedBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  void resize(size_t count) {
+    if (count <= n && p) return;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    if (count == 0) count = 1;
+    HIP_CHECK(hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault));
+    n = count;
+  }
+  T *data() { return p; }
+  const T *data() const { return p; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
 };
 
 struct ProofErr {
@@ -154,14 +180,14 @@ struct Batch {
   uint32_t B = 0, rmax = 0, cs = 0, max_mn = 0, total_dyn = 0, sum_m = 0, cols = 0;
   std::vector<ProofDesc> desc;
   std::vector<uint8_t> rounds_bad;  // 0 ok, 3 InvalidLength, 5 SizeOverflow  (src/range_proof.rs:875-888)
-  bool any_seed = false;
+  bool any_seed = false, any_rounds_bad = false;
   // device-resident inputs
   DevBuf<uint8_t> bytes, states, seeds;
   DevBuf<ProofDesc> d_desc;
   DevBuf<uint64_t> minvals;
   DevBuf<uint32_t> src_off, owner;
   // device work buffers
-  DevBuf<sc> chal, rows, scal;
+  DevBuf<sc> chal, rows, scal, shr, dyn_unw, wm;
   DevBuf<uint8_t> rng_out, weights, masks, chal_bytes;
   DevBuf<uint32_t> status, group_first;
   DevBuf<niels> dynpts;
@@ -170,9 +196,9 @@ struct Batch {
   size_t last_chunk = (size_t)-1;
   uint32_t G = 0;
   std::vector<uint32_t> h_group_first;
-  std::vector<uint8_t> h_rng, h_weights;
-  std::vector<uint32_t> h_status;
-  bool have_trace = false;
+  PinnedBuf<uint8_t> h_rng, h_weights;
+  PinnedBuf<uint32_t> h_status, h_ident;
+  bool have_trace = false, phase1_done = false;
 };
 
 }  // namespace
@@ -191,6 +217,9 @@ struct bpp_ctx {
   bpp_profile prof{};
   hipEvent_t ev[16];
   bool ev_ready = false;
+  hipEvent_t ev_rng;
+  bool ev_rng_ready = false;
+  DevBuf<uint8_t> scratch128;
 };
 
 namespace {
@@ -201,21 +230,27 @@ int fail(bpp_ctx *ctx, int code, const std::string &m, char *errbuf = nullptr, s
   return code;
 }
 
+enum Mark { M_START = 0, M_TRANSCRIPTS, M_DECOMPRESS, M_SCALARS, M_WEIGHTS_IN, M_REDUCE, M_DIGITS, M_SORT, M_ACC, M_BUCKET,
+            M_FINAL, M_COUNT };
+
 struct StageTimer {
   bpp_ctx *ctx;
-  int idx = 0;
+  bool have[16] = {false};
   explicit StageTimer(bpp_ctx *c) : ctx(c) {
     if (ctx->profile && !ctx->ev_ready) {
       for (auto &e : ctx->ev) HIP_CHECK(hipEventCreate(&e));
       ctx->ev_ready = true;
     }
   }
-  void mark() {
-    if (ctx->profile && idx < 16) HIP_CHECK(hipEventRecord(ctx->ev[idx++], ctx->stream));
+  void mark(int idx) {
+    if (ctx->profile && idx < 16) {
+      HIP_CHECK(hipEventRecord(ctx->ev[idx], ctx->stream));
+      have[idx] = true;
+    }
   }
   float between(int a, int b) {
     float ms = 0;
-    if (ctx->profile && b < idx) HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]));
+    if (ctx->profile && have[a] && have[b]) HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]));
     return ms;
   }
 };
@@ -273,20 +308,20 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
   dim3 gt(cdiv(w.max_group_terms, 256), plan.G);
   hipLaunchKernelGGL(k_msm_digits, gt, dim3(256), 0, s, scalars, w.term_sidx.p, w.group_off.p, plan, w.digits.p,
                      w.counts.p);
-  if (tm) tm->mark();
-  hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, w.counts.p, w.starts.p, (uint32_t)nbk);
+  if (tm) tm->mark(M_DIGITS);
+  hipLaunchKernelGGL(k_scan_exclusive, dim3(plan.G), dim3(1024), 0, s, w.counts.p, w.starts.p, w.group_off.p, plan);
   hipLaunchKernelGGL(k_msm_scatter, gt, dim3(256), 0, s, w.digits.p, w.group_off.p, plan, w.starts.p, w.cursor.p,
                      w.sorted.p);
-  if (tm) tm->mark();
+  if (tm) tm->mark(M_SORT);
   hipLaunchKernelGGL(k_msm_accumulate, dim3(cdiv((uint32_t)nbk, 64)), dim3(64), 0, s, w.sorted.p, w.starts.p,
                      w.counts.p, w.term_pidx.p, tabs, (uint32_t)nbk, w.buckets.p);
-  if (tm) tm->mark();
+  if (tm) tm->mark(M_ACC);
   hipLaunchKernelGGL(k_msm_bitsum, dim3(plan.c, plan.K, plan.G), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.Q.p);
   hipLaunchKernelGGL(k_msm_window, dim3(cdiv(plan.G * plan.K, 64)), dim3(64), 0, s, w.Q.p, plan, w.W.p);
-  if (tm) tm->mark();
+  if (tm) tm->mark(M_BUCKET);
   hipLaunchKernelGGL(k_msm_final, dim3(cdiv(plan.G, 64)), dim3(64), 0, s, w.W.p, plan, w.R.p, w.comp32.p,
                      w.is_identity.p);
-  if (tm) tm->mark();
+  if (tm) tm->mark(M_FINAL);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -420,6 +455,8 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
   ctx->params.clear();
   if (ctx->ev_ready)
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+  if (ctx->ev_rng_ready) (void)hipEventDestroy(ctx->ev_rng);
+  ctx->scratch128.release();
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -758,6 +795,7 @@ int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items
         B->rounds_bad[i] = BPP_ERR_SIZE_OVERFLOW;
       else if ((1ull << pi.rounds) != mn)
         B->rounds_bad[i] = BPP_ERR_INVALID_LENGTH;
+      if (B->rounds_bad[i]) B->any_rounds_bad = true;
       B->rmax = std::max(B->rmax, pi.rounds);
       B->max_mn = std::max(B->max_mn, (uint32_t)mn);
     }
@@ -818,6 +856,9 @@ int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items
     B->status.alloc(n_items);
     B->dynpts.alloc(dyn);
     B->rows.alloc((size_t)n_items * B->cols);
+    B->shr.alloc((size_t)n_items * SH_STRIDE);
+    B->dyn_unw.alloc(dyn);
+    B->wm.alloc(n_items);
     B->masks.alloc(n_items * P.t * 32);
     B->h_rng.resize(n_items * 32);
     B->h_weights.resize(n_items * 32);
@@ -841,23 +882,40 @@ int bpp_batch_destroy(bpp_ctx *ctx, uint64_t batch) {
 
 namespace {
 
-// PASS 1 + decompression for the whole resident batch; fills h_rng / h_status
-void run_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
+// Weight-independent device work for the whole resident batch: PASS 1, decompression and -- unless `pass1_only` --
+// the unweighted PASS-2 scalars.  Returns after the transcript-RNG bytes have reached the host (h_rng); the rest is
+// still running on the stream (it overlaps the host weight chain).
+void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
   Params &P = *b.params;
   hipStream_t s = ctx->stream;
+  if (!ctx->ev_rng_ready) {
+    HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_rng, hipEventDisableTiming));
+    ctx->ev_rng_ready = true;
+  }
   HIP_CHECK(hipMemsetAsync(b.status.p, 0, (size_t)b.B * 4, s));
   HIP_CHECK(hipMemsetAsync(b.chal.p, 0, (size_t)b.B * b.cs * sizeof(sc), s));
-  tm.mark();  // 0
+  tm.mark(M_START);
   hipLaunchKernelGGL(k_transcripts, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.states.p,
                      P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p);
-  tm.mark();  // 1
+  tm.mark(M_TRANSCRIPTS);
+  HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
   hipLaunchKernelGGL(k_decompress, dim3(cdiv(b.total_dyn, 64)), dim3(64), 0, s, b.bytes.p, b.src_off.p, b.owner.p,
                      b.total_dyn, b.dynpts.p, b.status.p);
-  tm.mark();  // 2
+  tm.mark(M_DECOMPRESS);
+  if (!pass1_only) {
+    hipLaunchKernelGGL(k_scalars_shared, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.chal.p,
+                       P.n_bits, P.t, b.cs, b.B, b.shr.p);
+    hipLaunchKernelGGL(k_scalars_lanes, dim3(b.B), dim3(64), 0, s, b.d_desc.p, b.shr.p, P.n_bits, P.t, b.max_mn, b.cols,
+                       b.B, b.rows.p, b.dyn_unw.p);
+    tm.mark(M_SCALARS);
+  }
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipMemcpyAsync(b.h_status.data(), b.status.p, (size_t)b.B * 4, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
+  HIP_CHECK(hipEventSynchronize(ctx->ev_rng));
+}
+
+void fetch_status(bpp_ctx *ctx, Batch &b) {
+  HIP_CHECK(hipMemcpyAsync(b.h_status.data(), b.status.p, (size_t)b.B * 4, hipMemcpyDeviceToHost, ctx->stream));
 }
 
 // reference error precedence for proofs [p0, p1) treated as one verify() call
@@ -916,18 +974,21 @@ void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk) {
   b.last_chunk = chunk;
 }
 
-// PASS 2 + MSM for the whole batch with the given weights (device buffer b.weights already filled)
-void run_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
+// Weight-dependent tail: h_weights -> device, weighted reduction of the generator scalars, weighting of the dynamic
+// scalars, final MSM.
+void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
   Params &P = *b.params;
   hipStream_t s = ctx->stream;
+  HIP_CHECK(hipMemcpyAsync(b.weights.p, b.h_weights.data(), (size_t)b.B * 32, hipMemcpyHostToDevice, s));
+  tm.mark(M_WEIGHTS_IN);
   sc *dyn_scal = b.scal.p + (size_t)b.G * b.cols;
-  hipLaunchKernelGGL(k_scalars, dim3(b.B), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.chal.p, b.weights.p,
-                     P.n_bits, P.t, b.cs, b.max_mn, b.cols, b.B, b.rows.p, dyn_scal);
-  tm.mark();  // 4
-  hipLaunchKernelGGL(k_reduce_static, dim3(b.cols, b.G), dim3(64), 0, s, b.rows.p, b.group_first.p, b.cols, b.scal.p);
-  tm.mark();  // 5
+  hipLaunchKernelGGL(k_weights_to_mont, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.weights.p, b.B, b.wm.p);
+  hipLaunchKernelGGL(k_reduce_static, dim3(b.cols, b.G), dim3(64), 0, s, b.rows.p, b.wm.p, b.group_first.p, b.cols, b.scal.p);
+  hipLaunchKernelGGL(k_weight_dyn, dim3(cdiv(b.total_dyn, 64)), dim3(64), 0, s, b.dyn_unw.p, b.owner.p, b.wm.p, b.total_dyn,
+                     dyn_scal);
+  tm.mark(M_REDUCE);
   PointTables tabs{P.table.p, b.dynpts.p, P.table_len};
-  msm_run(ctx, b.msm, b.scal.p, tabs, &tm);  // marks 6..10
+  msm_run(ctx, b.msm, b.scal.p, tabs, &tm);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -935,16 +996,16 @@ void collect_profile(bpp_ctx *ctx, Batch &b, StageTimer &tm, float chain_ms, flo
   if (!ctx->profile) return;
   bpp_profile &pf = ctx->prof;
   memset(&pf, 0, sizeof(pf));
-  pf.transcripts_ms = tm.between(0, 1);
-  pf.decompress_ms = tm.between(1, 2);
+  pf.transcripts_ms = tm.between(M_START, M_TRANSCRIPTS);
+  pf.decompress_ms = tm.between(M_TRANSCRIPTS, M_DECOMPRESS);  // includes the 32 B/proof device-to-host copy
+  pf.scalars_ms = tm.between(M_DECOMPRESS, M_SCALARS);
   pf.chain_host_ms = chain_ms;
-  pf.scalars_ms = tm.between(3, 4);
-  pf.reduce_ms = tm.between(4, 5);
-  pf.msm_digits_ms = tm.between(5, 6);
-  pf.msm_sort_ms = tm.between(6, 7);
-  pf.msm_accumulate_ms = tm.between(7, 8);
-  pf.msm_bucket_reduce_ms = tm.between(8, 9);
-  pf.msm_final_ms = tm.between(9, 10);
+  pf.reduce_ms = tm.between(M_WEIGHTS_IN, M_REDUCE);
+  pf.msm_digits_ms = tm.between(M_REDUCE, M_DIGITS);
+  pf.msm_sort_ms = tm.between(M_DIGITS, M_SORT);
+  pf.msm_accumulate_ms = tm.between(M_SORT, M_ACC);
+  pf.msm_bucket_reduce_ms = tm.between(M_ACC, M_BUCKET);
+  pf.msm_final_ms = tm.between(M_BUCKET, M_FINAL);
   pf.total_ms = total_host_ms;
   pf.msm_terms = b.msm.plan.n_terms;
   pf.msm_window_bits = b.msm.plan.c;
@@ -969,53 +1030,63 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
     StageTimer tm(ctx);
     hipStream_t s = ctx->stream;
     layout_groups(ctx, b, chunk);
-    run_phase1(ctx, b, tm);
+    // a proof whose L/R count does not fit its statement makes the call fail (src/range_proof.rs:875-888).  With a
+    // single group only the precedence against PASS-1 / decompression errors is still open, so PASS 2 is skipped;
+    // with several groups the earlier groups' MSM verdicts still matter (the kernels tolerate the odd shapes).
+    const bool pass1_only = b.any_rounds_bad && b.G == 1;
+    const bool want_msm = !pass1_only && action != BPP_RECOVER_ONLY;
+    enqueue_phase1(ctx, b, tm, pass1_only || action == BPP_RECOVER_ONLY);
 
-    // which chunks are structurally sound?  errors surface chunk by chunk, in order
-    uint32_t first_bad_group = b.G;
-    ProofErr pending{0, ""};
-    for (uint32_t g = 0; g < b.G; g++) {
-      try {
-        check_chunk_errors(b, b.h_group_first[g], b.h_group_first[g + 1]);
-      } catch (const ProofErr &e) {
-        first_bad_group = g;
-        pending = e;
-        break;
-      }
-    }
-    if (first_bad_group == 0) throw pending;
-
-    // weight chains: one per chunk (src/range_proof.rs:811,849,853,894)
-    auto c0 = std::chrono::steady_clock::now();
-    for (uint32_t g = 0; g < b.G; g++) {
-      const uint32_t p0 = b.h_group_first[g], p1 = b.h_group_first[g + 1];
-      weights_from_chain_host(&b.h_rng[(size_t)p0 * 32], p1 - p0, &b.h_weights[(size_t)p0 * 32]);
-    }
-    auto c1 = std::chrono::steady_clock::now();
-    float chain_ms = std::chrono::duration<float, std::milli>(c1 - c0).count();
-    HIP_CHECK(hipMemcpyAsync(b.weights.p, b.h_weights.data(), (size_t)b.B * 32, hipMemcpyHostToDevice, s));
-    tm.mark();  // 3
-
-    // masks (:941-969)
+    float chain_ms = 0;
     std::vector<uint8_t> h_masks;
-    if (action != BPP_VERIFY_ONLY) {
-      if (b.any_seed) {
+    b.h_ident.resize(b.G);
+    for (uint32_t g = 0; g < b.G; g++) b.h_ident[g] = 1;
+    auto &h_ident = b.h_ident;
+    if (!pass1_only) {
+      // weight chains: one per chunk (src/range_proof.rs:811,849,853,894); the device keeps working meanwhile
+      auto c0 = std::chrono::steady_clock::now();
+      if (want_msm) {
+        // chunks are independent reference batches -> their (sequential) chains run on separate host threads
+        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+        const uint32_t nthreads = std::min(std::min(b.G, hw), 64u);
+        auto run = [&](uint32_t tid) {
+          for (uint32_t g = tid; g < b.G; g += nthreads) {
+            const uint32_t p0 = b.h_group_first[g], p1 = b.h_group_first[g + 1];
+            weights_from_chain_host(&b.h_rng[(size_t)p0 * 32], p1 - p0, &b.h_weights[(size_t)p0 * 32]);
+          }
+        };
+        if (nthreads <= 1) {
+          run(0);
+        } else {
+          std::vector<std::thread> pool;
+          for (uint32_t tid = 1; tid < nthreads; tid++) pool.emplace_back(run, tid);
+          run(0);
+          for (auto &th : pool) th.join();
+        }
+      }
+      chain_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c0).count();
+      if (action != BPP_VERIFY_ONLY && b.any_seed) {  // masks (:941-969)
         hipLaunchKernelGGL(k_masks, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.chal.p, b.seeds.p,
                            P.n_bits, P.t, b.cs, b.B, b.masks.p);
         h_masks.resize((size_t)b.B * P.t * 32);
         HIP_CHECK(hipMemcpyAsync(h_masks.data(), b.masks.p, h_masks.size(), hipMemcpyDeviceToHost, s));
       }
+      if (want_msm) {
+        enqueue_phase2(ctx, b, tm);
+        HIP_CHECK(hipMemcpyAsync(h_ident.data(), b.msm.is_identity.p, (size_t)b.G * 4, hipMemcpyDeviceToHost, s));
+        b.have_trace = true;
+      }
     }
-    std::vector<uint32_t> h_ident(b.G, 1);
-    if (action != BPP_RECOVER_ONLY) {
-      run_phase2(ctx, b, tm);
-      HIP_CHECK(hipMemcpyAsync(h_ident.data(), b.msm.is_identity.p, (size_t)b.G * 4, hipMemcpyDeviceToHost, s));
-      b.have_trace = true;
-    }
+    fetch_status(ctx, b);
     HIP_CHECK(hipStreamSynchronize(s));
     auto t_end = std::chrono::steady_clock::now();
     collect_profile(ctx, b, tm, chain_ms, std::chrono::duration<float, std::milli>(t_end - t_begin).count());
 
+    // errors surface chunk by chunk, in the reference's order; a chunk's MSM verdict precedes later chunks' errors
+    for (uint32_t g = 0; g < b.G; g++) {
+      check_chunk_errors(b, b.h_group_first[g], b.h_group_first[g + 1]);
+      if (want_msm && !h_ident[g]) throw ProofErr{BPP_ERR_VERIFICATION_FAILED, "Range proof batch not valid"};
+    }
     // outputs: Vec<Option<ExtendedMask>>
     for (uint32_t p = 0; p < b.B; p++) {
       bool present = (action != BPP_VERIFY_ONLY) && (b.desc[p].flags & 1u);
@@ -1027,9 +1098,6 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
           memset(masks_out + (size_t)p * P.t * 32, 0, (size_t)P.t * 32);
       }
     }
-    for (uint32_t g = 0; g < first_bad_group; g++)
-      if (!h_ident[g]) throw ProofErr{BPP_ERR_VERIFICATION_FAILED, "Range proof batch not valid"};
-    if (first_bad_group < b.G) throw pending;
     return BPP_OK;
   }
   BPP_CATCH(ctx, errbuf, errbuf_len)
@@ -1054,9 +1122,12 @@ int bpp_verify_phase1(bpp_ctx *ctx, uint64_t batch, uint8_t *rng_out32, char *er
     Batch &b = *it->second;
     StageTimer tm(ctx);
     layout_groups(ctx, b, 0);
-    run_phase1(ctx, b, tm);
+    enqueue_phase1(ctx, b, tm, b.any_rounds_bad);
+    fetch_status(ctx, b);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (rng_out32) memcpy(rng_out32, b.h_rng.data(), (size_t)b.B * 32);
     check_chunk_errors(b, 0, b.B);
+    b.phase1_done = true;
     return BPP_OK;
   }
   BPP_CATCH(ctx, errbuf, errbuf_len)
@@ -1070,6 +1141,7 @@ int bpp_verify_phase2(bpp_ctx *ctx, uint64_t batch, const uint8_t *weights32, ui
     if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle", errbuf, errbuf_len);
     if (!weights32 || !accumulator128) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument", errbuf, errbuf_len);
     Batch &b = *it->second;
+    if (!b.phase1_done) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "bpp_verify_phase1 must succeed first", errbuf, errbuf_len);
     for (uint32_t p = 0; p < b.B; p++)
       if (!sc_is_canonical(weights32 + 32 * (size_t)p))
         return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "weight is not canonical", errbuf, errbuf_len);
@@ -1077,13 +1149,10 @@ int bpp_verify_phase2(bpp_ctx *ctx, uint64_t batch, const uint8_t *weights32, ui
     hipStream_t s = ctx->stream;
     layout_groups(ctx, b, 0);
     memcpy(b.h_weights.data(), weights32, (size_t)b.B * 32);
-    HIP_CHECK(hipMemcpyAsync(b.weights.p, b.h_weights.data(), (size_t)b.B * 32, hipMemcpyHostToDevice, s));
-    for (int i = 0; i < 4; i++) tm.mark();
-    run_phase2(ctx, b, tm);
-    DevBuf<uint8_t> d_out;
-    d_out.alloc(128);
-    hipLaunchKernelGGL(k_ge_to_bytes, dim3(1), dim3(64), 0, s, b.msm.R.p, 1u, d_out.p);
-    HIP_CHECK(hipMemcpyAsync(accumulator128, d_out.p, 128, hipMemcpyDeviceToHost, s));
+    enqueue_phase2(ctx, b, tm);
+    if (!ctx->scratch128.p) ctx->scratch128.alloc(128);
+    hipLaunchKernelGGL(k_ge_to_bytes, dim3(1), dim3(64), 0, s, b.msm.R.p, 1u, ctx->scratch128.p);
+    HIP_CHECK(hipMemcpyAsync(accumulator128, ctx->scratch128.p, 128, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     b.have_trace = true;
     return BPP_OK;

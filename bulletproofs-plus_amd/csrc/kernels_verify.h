@@ -165,16 +165,35 @@ __global__ void __launch_bounds__(64) k_from_uniform(const uint8_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// PASS 2 scalar block (src/range_proof.rs:894-1033), one wavefront per proof, lanes over the mn generator
-// indices.  Everything is Montgomery form until the final store.
+// PASS 2 scalar block (src/range_proof.rs:894-1033), split so that nothing depends on the batch weight until the
+// very end (the weight chain runs on the host meanwhile):
+//   k_scalars_shared  1 lane / proof : batch inversion (binary-GCD), powers, sums -> shr[p][*]
+//   k_scalars_lanes   1 wave / proof : lanes over the mn generator indices -> UNWEIGHTED rows + dynamic scalars
+//   k_weights_to_mont, k_reduce_static (sum_p w_p * rows[p][col]), k_weight_dyn (w_p * dyn)
+// Everything is Montgomery form until the final stores.
 // ---------------------------------------------------------------------------------------------
 #define BPP_MAX_ROUNDS 12  // mn <= 64 * 32 = 2048 -> 11 rounds
-
-struct ScalarShared {
-  sc e[BPP_MAX_ROUNDS], einv[BPP_MAX_ROUNDS], esq[BPP_MAX_ROUNDS], esqinv[BPP_MAX_ROUNDS];
-  sc yinvpow[BPP_MAX_ROUNDS];  // y^{-2^b}
-  sc pre[BPP_MAX_ROUNDS + 3];
-};
+#define SH_Z 0
+#define SH_Z2 1
+#define SH_E 2
+#define SH_E2 3
+#define SH_Y 4
+#define SH_YINV 5
+#define SH_YNM 6
+#define SH_YNM1 7
+#define SH_R1E 10
+#define SH_S1E 11
+#define SH_E2Z 12
+#define SH_NEG_E2 13
+#define SH_HS 14
+#define SH_D1(k) (15 + (k))
+#define SH_ARR 21
+#define SH_EJ(j) (SH_ARR + (j))
+#define SH_EINV(j) (SH_ARR + BPP_MAX_ROUNDS + (j))
+#define SH_ESQ(j) (SH_ARR + 2 * BPP_MAX_ROUNDS + (j))
+#define SH_ESQINV(j) (SH_ARR + 3 * BPP_MAX_ROUNDS + (j))
+#define SH_YINVPOW(b) (SH_ARR + 4 * BPP_MAX_ROUNDS + (b))
+#define SH_STRIDE (SH_ARR + 5 * BPP_MAX_ROUNDS)
 
 __device__ __forceinline__ void sc_load_mont(sc &r, const uint8_t *p) {
   sc a;
@@ -182,75 +201,61 @@ __device__ __forceinline__ void sc_load_mont(sc &r, const uint8_t *p) {
   sc_to_mont(r, a);
 }
 
-__global__ void __launch_bounds__(64) k_scalars(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
-                                                const uint64_t *__restrict__ minvals, const sc *__restrict__ chal,
-                                                const uint8_t *__restrict__ weights32, uint32_t n_bits, uint32_t t,
-                                                uint32_t cs, uint32_t max_mn, uint32_t cols, uint32_t B,
-                                                sc *__restrict__ rows, sc *__restrict__ dyn_scalars) {
-  const uint32_t p = blockIdx.x;
+__global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
+                                                       const uint64_t *__restrict__ minvals, const sc *__restrict__ chal,
+                                                       uint32_t n_bits, uint32_t t, uint32_t cs, uint32_t B,
+                                                       sc *__restrict__ shr) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B) return;
-  const uint32_t lane = threadIdx.x;
-  __shared__ ScalarShared sh;
   const ProofDesc d = desc[p];
   const uint32_t r = d.rounds, m = d.m, mn = m * n_bits;
+  if (r > BPP_MAX_ROUNDS - 1) return;  // rejected on the host before PASS 2
   const sc *c = chal + (size_t)p * cs;
+  sc *o = shr + (size_t)p * SH_STRIDE;
   const uint8_t *pr = bytes + d.proof_off;
   const uint8_t *pd1 = pr + 1;
   const uint8_t *pr1 = pr + 1 + 32 * t + 96, *ps1 = pr1 + 32;
-
-  sc one, y = c[0], z = c[1], ef = c[2 + r], w, r1, s1;
+  sc one, y = c[0], z = c[1], ef = c[2 + r], r1, s1;
   sc_mont_one(one);
-  sc_load_mont(w, weights32 + (size_t)p * 32);
   sc_load_mont(r1, pr1);
   sc_load_mont(s1, ps1);
-
-  // ---- batch inversion of [e_0..e_{r-1}, y, y-1] (src/range_proof.rs:897-905), all lanes redundantly ----
-  sc ym1;
+  // batch inversion of [e_0..e_{r-1}, y, y-1] (:897-905): prefix products parked in the output slots
+  sc ym1, acc = one;
   sc_sub(ym1, y, one);
-  sc acc = one;
   for (uint32_t j = 0; j < r + 2; j++) {
-    sc x = (j < r) ? c[2 + j] : (j == r ? y : ym1);
-    if (lane == 0) sh.pre[j] = acc;  // product of x_0..x_{j-1}
+    const sc x = (j < r) ? c[2 + j] : (j == r ? y : ym1);
+    if (j < r) o[SH_EINV(j)] = acc;
+    else if (j == r) o[SH_YINV] = acc;
+    else o[SH_YNM] = acc;
     sc_montmul(acc, acc, x);
   }
-  sc inv_all;
-  sc_mont_invert(inv_all, acc);
-  __syncthreads();
-  sc y_1_inverse, y_inverse, run = inv_all;
+  sc run, y_1_inverse, y_inverse;
+  sc_mont_invert_vartime(run, acc);
   for (int j = (int)r + 1; j >= 0; j--) {
-    sc x = ((uint32_t)j < r) ? c[2 + j] : ((uint32_t)j == r ? y : ym1);
-    sc inv_j, pre = sh.pre[j];
+    const sc x = ((uint32_t)j < r) ? c[2 + j] : ((uint32_t)j == r ? y : ym1);
+    const sc pre = ((uint32_t)j < r) ? o[SH_EINV(j)] : ((uint32_t)j == r ? o[SH_YINV] : o[SH_YNM]);
+    sc inv_j;
     sc_montmul(inv_j, run, pre);
     sc_montmul(run, run, x);
     if ((uint32_t)j == r + 1) y_1_inverse = inv_j;
     else if ((uint32_t)j == r) y_inverse = inv_j;
-    else if (lane == 0) {
-      sh.e[j] = x;
-      sh.einv[j] = inv_j;
+    else {
       sc sq;
+      o[SH_EJ(j)] = x;
+      o[SH_EINV(j)] = inv_j;
       sc_montsq(sq, x);
-      sh.esq[j] = sq;
+      o[SH_ESQ(j)] = sq;
       sc_montsq(sq, inv_j);
-      sh.esqinv[j] = sq;
+      o[SH_ESQINV(j)] = sq;
     }
   }
-  // y^{-2^b}
   {
     sc pw = y_inverse;
     for (uint32_t b = 0; b < r; b++) {
-      if (lane == 0) sh.yinvpow[b] = pw;
+      o[SH_YINVPOW(b)] = pw;
       sc_montsq(pw, pw);
     }
   }
-  __syncthreads();
-  // s[0] = prod e_j^{-1}  (challenges_inv_prod, :899)
-  sc s0 = one;
-  for (uint32_t j = 0; j < r; j++) {
-    sc t0 = sh.einv[j];
-    sc_montmul(s0, s0, t0);
-  }
-  (void)s0;
-
   sc z_square, e_square, y_nm, y_nm_1, y_sum, tmp;
   sc_montsq(z_square, z);
   sc_montsq(e_square, ef);
@@ -259,9 +264,7 @@ __global__ void __launch_bounds__(64) k_scalars(const uint8_t *__restrict__ byte
   sc_sub(tmp, y_nm, one);
   sc_montmul(tmp, tmp, y);
   sc_montmul(y_sum, tmp, y_1_inverse);  // :916
-
-  // d_sum (:932-938)
-  sc d_sum = z_square, d_tmp = z_square;
+  sc d_sum = z_square, d_tmp = z_square;  // :932-938
   for (uint32_t mm = m; mm > 1; mm >>= 1) {
     sc_montmul(tmp, d_sum, d_tmp);
     sc_add(d_sum, d_sum, tmp);
@@ -269,105 +272,39 @@ __global__ void __launch_bounds__(64) k_scalars(const uint8_t *__restrict__ byte
   }
   {
     sc tn;  // 2^n - 1
-    uint64_t v = (n_bits >= 64) ? ~0ULL : ((1ULL << n_bits) - 1ULL);
+    const uint64_t v = (n_bits >= 64) ? ~0ULL : ((1ULL << n_bits) - 1ULL);
     sc_mont_from_u64(tn, v);
     sc_montmul(d_sum, d_sum, tn);
   }
-
   sc r1_e, s1_e, e_square_z, neg_e_square;
   sc_montmul(r1_e, r1, ef);
   sc_montmul(s1_e, s1, ef);
   sc_montmul(e_square_z, e_square, z);
   sc_neg(neg_e_square, e_square);
-
-  // ---- generator scalars (:972-1003): lane i handles i, i+64, ... ----
-  sc *row = rows + (size_t)p * cols;
-  for (uint32_t i = lane; i < max_mn; i += 64) {
-    sc gi, hi;
-    if (i < mn) {
-      sc s_i = one, s_rev = one, yinv_i = one;
-      for (uint32_t b = 0; b < r; b++) {
-        const uint32_t j = r - 1 - b;
-        const bool bit = (i >> b) & 1u;
-        sc a = bit ? sh.e[j] : sh.einv[j];
-        sc a_rev = bit ? sh.einv[j] : sh.e[j];
-        sc_montmul(s_i, s_i, a);
-        sc_montmul(s_rev, s_rev, a_rev);
-        if (bit) {
-          sc yp = sh.yinvpow[b];
-          sc_montmul(yinv_i, yinv_i, yp);
-        }
-      }
-      sc y_nm_i;
-      sc_montmul(y_nm_i, y_nm, yinv_i);  // y^{mn-i}
-      // d[i] = z^{2(j+1)} * 2^k, i = j*n + k  (:919-929)
-      const uint32_t party = i / n_bits, k = i % n_bits;
-      sc d_i = z_square;
-      for (uint32_t q = 0; q < party; q++) sc_montmul(d_i, d_i, z_square);
-      sc two_k;
-      sc_mont_from_u64(two_k, 1ULL << k);
-      sc_montmul(d_i, d_i, two_k);
-      sc g, h, u;
-      sc_montmul(g, r1_e, yinv_i);
-      sc_montmul(g, g, s_i);
-      sc_add(g, g, e_square_z);
-      sc_montmul(gi, w, g);
-      sc_montmul(h, s1_e, s_rev);
-      sc_montmul(u, d_i, y_nm_i);
-      sc_add(u, u, z);
-      sc_montmul(u, u, e_square);
-      sc_sub(h, h, u);
-      sc_montmul(hi, w, h);
-    } else {
-      sc_0(gi);
-      sc_0(hi);
-    }
-    row[2 * i] = gi;
-    row[2 * i + 1] = hi;
-  }
-
-  // ---- dynamic scalars (:1006-1015, :1022-1032), canonical form for the MSM ----
-  const uint32_t ndyn = m + 3 + 2 * r;
-  sc w_neg_e2;
-  sc_montmul(w_neg_e2, w, neg_e_square);
-  for (uint32_t q = lane; q < ndyn; q += 64) {
-    sc v;
-    if (q < m) {
-      sc zp = z_square;
-      for (uint32_t jj = 0; jj < q; jj++) sc_montmul(zp, zp, z_square);
-      sc_montmul(v, w_neg_e2, zp);
-      sc_montmul(v, v, y_nm_1);
-    } else if (q == m) {
-      sc ne;
-      sc_neg(ne, ef);
-      sc_montmul(v, w, ne);
-    } else if (q == m + 1) {
-      sc_neg(v, w);
-    } else if (q == m + 2) {
-      v = w_neg_e2;
-    } else if (q < m + 3 + r) {
-      sc x = sh.esq[q - (m + 3)];
-      sc_montmul(v, w_neg_e2, x);
-    } else {
-      sc x = sh.esqinv[q - (m + 3 + r)];
-      sc_montmul(v, w_neg_e2, x);
-    }
-    sc_from_mont(v, v);
-    dyn_scalars[d.dyn_off + q] = v;
-  }
-
-  // ---- Pedersen base scalars (:1011-1020) ----
-  if (lane == 0) {
-    sc hs;
-    sc_0(hs);
+  o[SH_Z] = z;
+  o[SH_Z2] = z_square;
+  o[SH_E] = ef;
+  o[SH_E2] = e_square;
+  o[SH_Y] = y;
+  o[SH_YINV] = y_inverse;
+  o[SH_YNM] = y_nm;
+  o[SH_YNM1] = y_nm_1;
+  o[SH_R1E] = r1_e;
+  o[SH_S1E] = s1_e;
+  o[SH_E2Z] = e_square_z;
+  o[SH_NEG_E2] = neg_e_square;
+  // Pedersen h-base contribution without the weight (:1011-1017)
+  sc hs;
+  sc_0(hs);
+  {
     sc zp = z_square;
     for (uint32_t j = 0; j < m; j++) {
-      sc weighted, vm;
-      sc_montmul(weighted, w_neg_e2, zp);
-      sc_montmul(weighted, weighted, y_nm_1);
+      sc wv, vm;
+      sc_montmul(wv, neg_e_square, zp);
+      sc_montmul(wv, wv, y_nm_1);
       sc_mont_from_u64(vm, minvals[d.minval_idx + j]);
-      sc_montmul(weighted, weighted, vm);
-      sc_sub(hs, hs, weighted);
+      sc_montmul(wv, wv, vm);
+      sc_sub(hs, hs, wv);
       sc_montmul(zp, zp, z_square);
     }
     sc a, b2, u;
@@ -380,29 +317,145 @@ __global__ void __launch_bounds__(64) k_scalars(const uint8_t *__restrict__ byte
     sc_add(b2, b2, u);
     sc_montmul(b2, b2, e_square);
     sc_add(a, a, b2);
-    sc_montmul(a, a, w);
     sc_add(hs, hs, a);
-    row[2 * max_mn + t] = hs;
   }
-  if (lane >= 1 && lane <= t) {
+  o[SH_HS] = hs;
+  for (uint32_t k = 0; k < t; k++) {
     sc d1;
-    sc_load_mont(d1, pd1 + 32 * (lane - 1));
-    sc_montmul(d1, d1, w);
-    row[2 * max_mn + (lane - 1)] = d1;
+    sc_load_mont(d1, pd1 + 32 * k);
+    o[SH_D1(k)] = d1;
   }
 }
 
-// Column sums of rows[] per group (the `+=` into gi/hi/g/h_base_scalars of src/range_proof.rs:785-788,999-1020):
-// one wavefront per (column, group); limb-wise u64 sums, wave shuffle reduction, one Montgomery exit.
-__global__ void __launch_bounds__(64) k_reduce_static(const sc *__restrict__ rows, const uint32_t *__restrict__ group_first,
-                                                      uint32_t cols, sc *__restrict__ out /* [G][cols] canonical */) {
+struct LaneShared {
+  sc e[BPP_MAX_ROUNDS], einv[BPP_MAX_ROUNDS], yinvpow[BPP_MAX_ROUNDS];
+};
+
+__global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restrict__ desc, const sc *__restrict__ shr,
+                                                      uint32_t n_bits, uint32_t t, uint32_t max_mn, uint32_t cols, uint32_t B,
+                                                      sc *__restrict__ rows, sc *__restrict__ dyn_unw) {
+  const uint32_t p = blockIdx.x;
+  if (p >= B) return;
+  const uint32_t lane = threadIdx.x;
+  __shared__ LaneShared sh;
+  const ProofDesc d = desc[p];
+  const uint32_t r = d.rounds, m = d.m, mn = m * n_bits;
+  if (r > BPP_MAX_ROUNDS - 1) return;
+  const sc *S = shr + (size_t)p * SH_STRIDE;
+  if (lane < r) {
+    sh.e[lane] = S[SH_EJ(lane)];
+    sh.einv[lane] = S[SH_EINV(lane)];
+    sh.yinvpow[lane] = S[SH_YINVPOW(lane)];
+  }
+  __syncthreads();
+  sc one;
+  sc_mont_one(one);
+  const sc z = S[SH_Z], z_square = S[SH_Z2], e_square = S[SH_E2], y_nm = S[SH_YNM], y_nm_1 = S[SH_YNM1];
+  const sc r1_e = S[SH_R1E], s1_e = S[SH_S1E], e_square_z = S[SH_E2Z], neg_e_square = S[SH_NEG_E2];
+  // generator scalars (:972-1003) without the weight
+  sc *row = rows + (size_t)p * cols;
+  for (uint32_t i = lane; i < max_mn; i += 64) {
+    sc gi, hi;
+    if (i < mn) {
+      sc s_i = one, s_rev = one, yinv_i = one;
+      for (uint32_t b = 0; b < r; b++) {
+        const uint32_t j = r - 1 - b;
+        const bool bit = (i >> b) & 1u;
+        const sc a = bit ? sh.e[j] : sh.einv[j];
+        const sc a_rev = bit ? sh.einv[j] : sh.e[j];
+        sc_montmul(s_i, s_i, a);
+        sc_montmul(s_rev, s_rev, a_rev);
+        if (bit) {
+          const sc yp = sh.yinvpow[b];
+          sc_montmul(yinv_i, yinv_i, yp);
+        }
+      }
+      sc y_nm_i;
+      sc_montmul(y_nm_i, y_nm, yinv_i);  // y^{mn-i}
+      const uint32_t party = i / n_bits, k = i % n_bits;  // d[i] = z^{2(party+1)} * 2^k  (:919-929)
+      sc d_i = z_square;
+      for (uint32_t q = 0; q < party; q++) sc_montmul(d_i, d_i, z_square);
+      sc two_k;
+      sc_mont_from_u64(two_k, 1ULL << k);
+      sc_montmul(d_i, d_i, two_k);
+      sc u;
+      sc_montmul(gi, r1_e, yinv_i);
+      sc_montmul(gi, gi, s_i);
+      sc_add(gi, gi, e_square_z);
+      sc_montmul(hi, s1_e, s_rev);
+      sc_montmul(u, d_i, y_nm_i);
+      sc_add(u, u, z);
+      sc_montmul(u, u, e_square);
+      sc_sub(hi, hi, u);
+    } else {
+      sc_0(gi);
+      sc_0(hi);
+    }
+    row[2 * i] = gi;
+    row[2 * i + 1] = hi;
+  }
+  // dynamic scalars (:1006-1015, :1022-1032) without the weight
+  const uint32_t ndyn = m + 3 + 2 * r;
+  for (uint32_t q = lane; q < ndyn; q += 64) {
+    sc v;
+    if (q < m) {
+      sc zp = z_square;
+      for (uint32_t jj = 0; jj < q; jj++) sc_montmul(zp, zp, z_square);
+      sc_montmul(v, neg_e_square, zp);
+      sc_montmul(v, v, y_nm_1);
+    } else if (q == m) {
+      const sc ef = S[SH_E];
+      sc_neg(v, ef);
+    } else if (q == m + 1) {
+      sc_neg(v, one);
+    } else if (q == m + 2) {
+      v = neg_e_square;
+    } else if (q < m + 3 + r) {
+      const sc x = S[SH_ESQ(q - (m + 3))];
+      sc_montmul(v, neg_e_square, x);
+    } else {
+      const sc x = S[SH_ESQINV(q - (m + 3 + r))];
+      sc_montmul(v, neg_e_square, x);
+    }
+    dyn_unw[d.dyn_off + q] = v;
+  }
+  if (lane == 0) row[2 * max_mn + t] = S[SH_HS];
+  if (lane >= 1 && lane <= t) row[2 * max_mn + (lane - 1)] = S[SH_D1(lane - 1)];
+}
+
+__global__ void k_weights_to_mont(const uint8_t *__restrict__ weights32, uint32_t B, sc *__restrict__ wm) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  sc w;
+  sc_load_mont(w, weights32 + (size_t)p * 32);
+  wm[p] = w;
+}
+
+// dyn[q] = w_owner(q) * dyn_unw[q], canonical
+__global__ void __launch_bounds__(64) k_weight_dyn(const sc *__restrict__ dyn_unw, const uint32_t *__restrict__ owner,
+                                                   const sc *__restrict__ wm, uint32_t n, sc *__restrict__ out) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  sc v;
+  sc_montmul(v, dyn_unw[q], wm[owner[q] & 0x7fffffffu]);
+  sc_from_mont(v, v);
+  out[q] = v;
+}
+
+// Weighted column sums per group: static[g][col] = sum_{p in g} w_p * rows[p][col]   (the `+=` into
+// gi/hi/g/h_base_scalars of src/range_proof.rs:785-788,999-1020).  One wavefront per (column, group): lane-strided
+// Montgomery products, limb-wise u64 sums, wave shuffle reduction, one Montgomery exit.
+__global__ void __launch_bounds__(64) k_reduce_static(const sc *__restrict__ rows, const sc *__restrict__ wm,
+                                                      const uint32_t *__restrict__ group_first, uint32_t cols,
+                                                      sc *__restrict__ out /* [G][cols] canonical */) {
   const uint32_t col = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
   const uint32_t p0 = group_first[g], p1 = group_first[g + 1];
   uint64_t acc[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) acc[i] = 0;
   for (uint32_t p = p0 + lane; p < p1; p += 64) {
-    const sc v = rows[(size_t)p * cols + col];
+    sc v;
+    sc_montmul(v, rows[(size_t)p * cols + col], wm[p]);
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[i] += v.v[i];
   }
@@ -411,7 +464,6 @@ __global__ void __launch_bounds__(64) k_reduce_static(const sc *__restrict__ row
     for (int off = 32; off >= 1; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
   }
   if (lane == 0) {
-    // S = sum of < 2^32 values < l: carry-normalise into 8 words + overflow word
     uint32_t wds[8];
     uint64_t carry = 0;
 #pragma unroll
@@ -420,7 +472,7 @@ __global__ void __launch_bounds__(64) k_reduce_static(const sc *__restrict__ row
       wds[i] = (uint32_t)carry;
       carry >>= 32;
     }
-    // value = lo + carry * 2^256 (Montgomery form of the true sum).  from_mont(lo) + carry  (2^256 * R^-1 = 1)
+    // value = lo + carry * 2^256 (Montgomery form of the true sum): from_mont(lo) + carry, since 2^256 * R^-1 = 1
     sc lo, res, hi;
     sc_const(lo, wds);
     sc_from_mont(res, lo);
@@ -468,11 +520,11 @@ __global__ void __launch_bounds__(64) k_masks(const uint8_t *__restrict__ bytes,
   sc y = c[0], z = c[1], ef = c[2 + r];
   sc e_square, e_square_inv, z_square, y_nm_1, zy_inv, tmp;
   sc_montsq(e_square, ef);
-  sc_mont_invert(e_square_inv, e_square);
+  sc_mont_invert_vartime(e_square_inv, e_square);
   sc_montsq(z_square, z);
   sc_mont_pow_u32(y_nm_1, y, mn + 1);
   sc_montmul(tmp, z_square, y_nm_1);
-  sc_mont_invert(zy_inv, tmp);
+  sc_mont_invert_vartime(zy_inv, tmp);
   for (uint32_t k = 0; k < t; k++) {
     sc mask, n1, n2;
     sc_load_mont(mask, pd1 + 32 * k);
@@ -487,7 +539,7 @@ __global__ void __launch_bounds__(64) k_masks(const uint8_t *__restrict__ bytes,
     for (uint32_t j = 0; j < r; j++) {
       sc ej = c[2 + j], ej2, ej2inv, ejinv;
       sc_montsq(ej2, ej);
-      sc_mont_invert(ejinv, ej);
+      sc_mont_invert_vartime(ejinv, ej);
       sc_montsq(ej2inv, ejinv);
       dev_nonce(n1, seed, "dL", 2, (int)j, (int)k);
       sc_montmul(n1, n1, ej2);

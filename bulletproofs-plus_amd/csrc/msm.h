@@ -76,13 +76,17 @@ __global__ void __launch_bounds__(256) k_msm_digits(const sc *__restrict__ scala
   }
 }
 
-// ---- single-block exclusive scan of `n` u32 (n up to a few million) ----
+// ---- exclusive scan of each group's bucket counts (one 1024-thread block per group); starts[] are absolute
+// positions in sorted[]: group g owns sorted[group_off[g]*K, group_off[g+1]*K) ----
 __global__ void __launch_bounds__(1024) k_scan_exclusive(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                         uint32_t n) {
+                                                         const uint32_t *__restrict__ group_off, MsmPlan plan) {
   __shared__ uint32_t part[1024];
-  const uint32_t tid = threadIdx.x;
+  const uint32_t g = blockIdx.x, tid = threadIdx.x;
+  const uint32_t n = plan.K * plan.nb;
+  in += (size_t)g * n;
+  out += (size_t)g * n;
   const uint32_t per = (n + 1023u) / 1024u;
-  const uint32_t a = tid * per, b = (a + per < n) ? a + per : n;
+  const uint32_t a = tid * per < n ? tid * per : n, b = (a + per < n) ? a + per : n;
   uint32_t s = 0;
   for (uint32_t i = a; i < b; i++) s += in[i];
   part[tid] = s;
@@ -93,7 +97,7 @@ __global__ void __launch_bounds__(1024) k_scan_exclusive(const uint32_t *__restr
     part[tid] += v;
     __syncthreads();
   }
-  uint32_t run = (tid == 0) ? 0 : part[tid - 1];
+  uint32_t run = group_off[g] * plan.K + ((tid == 0) ? 0 : part[tid - 1]);
   for (uint32_t i = a; i < b; i++) {
     uint32_t v = in[i];
     out[i] = run;
@@ -134,11 +138,9 @@ __global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t *__restric
   ge_identity(acc);
   for (uint32_t i = 0; i < n; i++) {
     const uint32_t e = sorted[a + i];
-    const niels q = *point_ptr(tabs, term_pidx[e & 0x7fffffffu]);
-    if (e >> 31)
-      ge_msub(acc, acc, q);
-    else
-      ge_madd(acc, acc, q);
+    niels q = *point_ptr(tabs, term_pidx[e & 0x7fffffffu]);
+    niels_cneg(q, (e >> 31) != 0);  // branch-free: lanes of one wave mix additions and subtractions
+    ge_madd(acc, acc, q);
   }
   buckets[bkt] = acc;
 }
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(64) k_msm_final(const ge *__restrict__ W, MsmP
   const ge *w = W + (size_t)g * plan.K;
   ge acc = w[plan.K - 1];
   for (int k = (int)plan.K - 2; k >= 0; k--) {
-    for (uint32_t i = 0; i < plan.c; i++) ge_dbl(acc, acc);
+    ge_dbl_n(acc, acc, (int)plan.c);
     const ge x = w[k];
     ge_add(acc, acc, x);
   }

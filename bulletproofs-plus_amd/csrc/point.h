@@ -50,6 +50,19 @@ BPP_HD void niels_from_affine(niels &r, const fe &x, const fe &y) {
   fe_mul(r.xy2d, t, d2);
 }
 
+// q = neg ? -q : q   (-(x,y) = (-x,y): swap y+x / y-x, negate 2dxy)
+BPP_HD void niels_cneg(niels &q, bool neg) {
+  fe n;
+  fe_neg(n, q.xy2d);
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    const uint32_t a = q.yplusx.v[i], b = q.yminusx.v[i];
+    q.yplusx.v[i] = neg ? b : a;
+    q.yminusx.v[i] = neg ? a : b;
+    q.xy2d.v[i] = neg ? n.v[i] : q.xy2d.v[i];
+  }
+}
+
 // r = p + q (q affine niels): 7 mul
 BPP_HD void ge_madd(ge &r, const ge &p, const niels &q) {
   fe a, b, c, d, e, f, g, h;
@@ -134,6 +147,36 @@ BPP_HD void ge_dbl(ge &r, const ge &p) {
   fe_mul(r.Y, g, h);
   fe_mul(r.Z, f, g);
   fe_mul(r.T, e, h);
+}
+
+// r = 2^n p (n >= 1): only the last doubling needs T (3M + 4S for the others)
+BPP_HD void ge_dbl_n(ge &r, const ge &p, int n) {
+  fe X, Y, Z;
+  fe_copy(X, p.X);
+  fe_copy(Y, p.Y);
+  fe_copy(Z, p.Z);
+  for (int i = 0; i < n; i++) {
+    fe a, b, c, e, f, g, h, t;
+    fe_sq(a, X);
+    fe_sq(b, Y);
+    fe_sq(c, Z);
+    fe_add(c, c, c);
+    fe_add(h, a, b);
+    fe_add(t, X, Y);
+    fe_sq(t, t);
+    fe_sub(e, h, t);
+    fe_sub(g, a, b);
+    fe_add(f, c, g);
+    fe_carry(f);
+    fe_carry(h);
+    fe_mul(X, e, f);
+    fe_mul(Y, g, h);
+    fe_mul(Z, f, g);
+    if (i == n - 1) fe_mul(r.T, e, h);
+  }
+  fe_copy(r.X, X);
+  fe_copy(r.Y, Y);
+  fe_copy(r.Z, Z);
 }
 
 BPP_HD void ge_neg(ge &r, const ge &p) {
