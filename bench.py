@@ -6,10 +6,13 @@
 A step = one pass of the hot path (RangeProof::verify: transcript replay, decompression, scalar block, weight chain,
 final MSM) over one resident batch.  Workload at N=1 = BASELINE.json configs[1]: 1024 non-aggregated 64-bit proofs,
 extension degree 1, inputs already resident in HBM (tests/golden/bench_cfg2.bin, produced by tests/golden/make_golden.py
-with the recipe of benches/range_proof.rs:206-262).  N>1 (launched by torch.distributed.run, one rank per GPU):
-every rank holds its own 1024-proof shard (weak scaling); mode "wide" verifies the union as ONE reference batch
-(all_gather of transcript-RNG bytes + all_gather of accumulator points over RCCL), mode "shard" treats each shard as
-an independent reference batch.  Prints ONE JSON line on rank 0.
+with the recipe of benches/range_proof.rs:206-262).  The engine keeps --batches-per-launch such batches resident per call
+(each one its own reference batch: own weight transcript, own final MSM) and --concurrency calls in flight; every step
+is still one complete verification of one 1024-proof batch, and EXACTLY --steps of them are timed.
+N>1 (launched by torch.distributed.run, one rank per GPU), weak scaling: mode "shard" (default) = every rank verifies
+its own batches exactly as at N=1, verdicts combined by one all_reduce; mode "wide" = the union of all ranks' shards is
+ONE reference batch per step (all_gather of transcript-RNG bytes + all_gather of accumulator points over RCCL).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import importlib
@@ -27,15 +30,15 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default="wide", choices=["wide", "shard"])
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--mode", default="shard", choices=["wide", "shard"])
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--chunk", type=int, default=0, help="proofs per reference batch at N=1 (0 = whole batch)")
-    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "8")),
+    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "2")),
                     help="resident batches in flight per GPU (one engine/stream + one host thread each); a step is still "
                          "one complete verify of one batch")
-    ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "16")),
+    ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "32")),
                     help="resident 1024-proof batches handled by one engine call; each stays its own reference batch "
                          "(own weight chain, own final MSM): one call = that many steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -56,7 +59,8 @@ def main():
                              % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: exercises the RCCL path)
+    if use_dist:
         dist.init_process_group("nccl", device_id=device)
 
     data = load_bench("bench_%s.bin" % args.config)
@@ -69,7 +73,7 @@ def main():
     import threading
     from concurrent.futures import ThreadPoolExecutor
 
-    wide = world > 1 and args.mode == "wide"
+    wide = use_dist and args.mode == "wide"
     S = 1 if wide else max(1, args.concurrency)  # cross-rank collectives must stay in program order -> no threads
     R = 1 if (wide or args.chunk) else max(1, args.batches_per_launch)
     while args.steps % R:
@@ -130,7 +134,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     run_steps(max(-(-args.warmup // R), S if args.warmup else 0))
@@ -138,11 +142,11 @@ def main():
     t0 = time.perf_counter()
     lat, profs = run_steps(args.steps // R)
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ok_all = 1
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -174,15 +178,21 @@ def main():
         if prof_sum and prof_sum.get("msm_final_ms", 0) > 0:
             k = len(profs)
             avg = {n: v / k for n, v in prof_sum.items()}
-            msm_ms = avg["msm_digits_ms"] + avg["msm_sort_ms"] + avg["msm_accumulate_ms"] + avg["msm_bucket_reduce_ms"] + avg["msm_final_ms"]
-            terms = int(avg["msm_terms"])  # all R groups of one launch
+            terms = int(avg["msm_terms"])  # over all R groups of one launch
+            K = int(avg["msm_windows"])
+            acc_ms = avg["msm_accumulate_ms"]
             msm_bytes = 64 * terms  # 32 B scalar + 32 B compressed point per MSM term
-            achieved = msm_bytes / (msm_ms * 1e-3) / 1e9
+            achieved = msm_bytes / (acc_ms * 1e-3) / 1e9
+            # integer roofline of the same kernel: one mixed addition per (term, window) = 7 field multiplications
+            # = 700 v_mad_u64_u32; peak = 49 lanes/clk/CU x 256 CU x 2.4 GHz (tools/microbench/int_rates.hip)
+            mads = terms * K * 700.0
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                               "kernel": "final MSM (k_msm_digits .. k_msm_final)", "kernel_ms": msm_ms,
-                               "algorithmic_bytes": msm_bytes, "msm_terms": terms,
-                               "note": "integer-VALU bound, not HBM bound (SURVEY 8d); fraction is expected to be small"}
+                               "kernel": "k_msm_accumulate (Pippenger bucket accumulation of the final MSM)",
+                               "kernel_ms": acc_ms, "algorithmic_bytes": msm_bytes, "msm_terms_per_launch": terms,
+                               "note": "integer-VALU bound, not HBM bound (SURVEY 8d): see valu",
+                               "valu": {"achieved_Tmad_per_s": mads / (acc_ms * 1e-3) / 1e12, "peak_Tmad_per_s": 30.1,
+                                        "frac": mads / (acc_ms * 1e-3) / 30.1e12}}
             out["stages_ms"] = {n: round(v, 4) for n, v in avg.items() if n.endswith("_ms")}
             out["pcie_inclusive_upload_ms"] = 1e3 * t_upload
         if not args.no_cpu_baseline:
@@ -201,7 +211,7 @@ def main():
     for _, eng, rb in lanes:
         rb.close()
         eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
