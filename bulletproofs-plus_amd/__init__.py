@@ -7,8 +7,8 @@ host-side mirror of the reference's RangeProof / RangeStatement / RangeParameter
 """
 from . import _build, _lib  # noqa: F401
 from .api import (  # noqa: F401
-    EngineError, Engine, ExtendedMask, ExtensionDegree, MAX_RANGE_PROOF_BATCH_SIZE, PedersenGens, Precomputation,
-    ProofError, ProofErrorKind, RangeParameters, RangeProof, RangeStatement, ResidentBatch, Transcript, VerifyAction,
+    CommitmentOpening, EngineError, Engine, ExtendedMask, ExtensionDegree, MAX_RANGE_PROOF_BATCH_SIZE, PedersenGens, Precomputation,
+    ProofError, ProofErrorKind, RangeParameters, RangeProof, RangeStatement, RangeWitness, ResidentBatch, Transcript, VerifyAction,
     accumulators_sum_is_identity, create_pedersen_gens_with_extension_degree, weights_from_chain,
 )
 

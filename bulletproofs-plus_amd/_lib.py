@@ -15,6 +15,13 @@ class VerifyItem(Structure):
                 ("transcript_state", c_void_p), ("transcript_label", c_void_p), ("label_len", c_size_t)]
 
 
+class ProveItem(Structure):
+    _fields_ = [("values", c_void_p), ("blindings32", c_void_p), ("commitments32", c_void_p), ("m", c_uint32),
+                ("min_values", c_void_p), ("min_present", c_void_p), ("seed_nonce32", c_void_p),
+                ("transcript_state", c_void_p), ("transcript_label", c_void_p), ("label_len", c_size_t),
+                ("rng_bytes", c_void_p), ("rng_len", c_size_t)]
+
+
 class Profile(Structure):
     _fields_ = [(n, c_float) for n in ("transcripts_ms", "decompress_ms", "chain_host_ms", "scalars_ms", "reduce_ms",
                                        "msm_digits_ms", "msm_sort_ms", "msm_accumulate_ms", "msm_bucket_reduce_ms",
@@ -47,6 +54,8 @@ SYMBOLS = [
     ("bpp_weights_from_chain", c_int, [c_void_p, c_size_t, c_void_p]),
     ("bpp_verify_phase2", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t]),
     ("bpp_accumulators_sum_is_identity", c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_int)]),
+    ("bpp_prove_batch", c_int, [c_void_p, c_uint64, POINTER(ProveItem), c_size_t, c_void_p, c_size_t, POINTER(c_size_t),
+                                c_void_p, c_size_t]),
     ("bpp_batch_trace", c_int, [c_void_p, c_uint64, c_int, c_void_p, c_size_t, POINTER(c_size_t)]),
     ("bpp_batch_shape", c_int, [c_void_p, c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32),
                                 POINTER(c_uint32), POINTER(c_uint32)]),

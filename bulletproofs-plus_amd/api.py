@@ -305,6 +305,43 @@ class RangeStatement:
         return self
 
 
+class CommitmentOpening:
+    """src/commitment_opening.rs:14-37: value + extended blinding factors (32-byte canonical scalars)"""
+
+    def __init__(self, v, r):
+        self.v = int(v)
+        self.r = [bytes(x) for x in r]
+
+    @staticmethod
+    def new(v, r):
+        return CommitmentOpening(v, r)
+
+    def r_len(self):
+        if not self.r:
+            raise ProofError(ProofErrorKind.InvalidLength, "Extended blinding factors cannot be empty")
+        return len(self.r)
+
+
+class RangeWitness:
+    """src/range_witness.rs:15-41"""
+
+    def __init__(self):
+        raise TypeError("use RangeWitness.init")
+
+    @classmethod
+    def init(cls, openings):
+        if not openings:
+            raise ProofError(ProofErrorKind.InvalidLength, "Vector openings cannot be empty")
+        t = openings[0].r_len()
+        for o in openings[1:]:
+            if o.r_len() != t:
+                raise ProofError(ProofErrorKind.InvalidLength, "Extended blinding factors must have consistent length")
+        self = object.__new__(cls)
+        self.openings = list(openings)
+        self.extension_degree = ExtensionDegree.try_from(t)
+        return self
+
+
 class ExtendedMask:
     """src/extended_mask.rs:14-41"""
 
@@ -382,6 +419,85 @@ class RangeProof:
         if len(data) < 1:
             raise ProofError(ProofErrorKind.InvalidLength, "Serialized proof is too short")
         return ExtensionDegree.try_from(data[0])
+
+    # ---- proving ----
+    @staticmethod
+    def rounds_for(statement):
+        mn = statement.generators.bit_length() * len(statement.commitments_compressed)
+        return max(mn.bit_length() - 1, 0)
+
+    @staticmethod
+    def prove_batch(transcripts, statements, witnesses, rng_bytes):
+        """n x RangeProof::prove_with_rng (src/range_proof.rs:232-608) in one engine call.
+
+        rng_bytes[i]: the bytes the external RNG hands out for proof i, 32 per draw, (rounds + 3) draws."""
+        if not statements or len(statements) != len(witnesses) or len(transcripts) != len(statements) or \
+                len(rng_bytes) != len(statements):
+            raise ProofError(ProofErrorKind.InvalidArgument, "Range statements, witnesses, transcripts length mismatch")
+        params = statements[0].generators
+        eng = params.engine
+        n = len(statements)
+        items = (_lib.ProveItem * n)()
+        keep = []
+        for i, (tr, st, w, rb) in enumerate(zip(transcripts, statements, witnesses, rng_bytes)):
+            if st.generators is not params:
+                raise ProofError(ProofErrorKind.InvalidArgument, "one RangeParameters object per prove batch")
+            m = len(st.commitments_compressed)
+            # :248-260
+            if len(w.openings) != m:
+                raise ProofError(ProofErrorKind.InvalidLength, "Witness openings and statement commitments do not match!")
+            if int(w.extension_degree) != int(params.extension_degree()):
+                raise ProofError(ProofErrorKind.InvalidLength, "Witness and statement extension degrees do not match!")
+            vals = (c_uint64 * m)(*[o.v for o in w.openings])
+            bl = _buf(b"".join(b"".join(o.r) for o in w.openings))
+            cb = _buf(b"".join(st.commitments_compressed))
+            mv = (c_uint64 * m)(*[(v if v is not None else 0) for v in st.minimum_value_promises])
+            mp = (ctypes.c_uint8 * m)(*[(1 if v is not None else 0) for v in st.minimum_value_promises])
+            rbuf = _buf(rb)
+            keep += [vals, bl, cb, mv, mp, rbuf]
+            it = items[i]
+            it.values = ctypes.cast(vals, c_void_p)
+            it.blindings32 = ctypes.cast(bl, c_void_p)
+            it.commitments32 = ctypes.cast(cb, c_void_p)
+            it.m = m
+            it.min_values = ctypes.cast(mv, c_void_p)
+            it.min_present = ctypes.cast(mp, c_void_p)
+            it.rng_bytes = ctypes.cast(rbuf, c_void_p)
+            it.rng_len = len(rb)
+            if st.seed_nonce is not None:
+                sb = _buf(st.seed_nonce)
+                keep.append(sb)
+                it.seed_nonce32 = ctypes.cast(sb, c_void_p)
+            if tr.state is not None:
+                tb = _buf(tr.state)
+                keep.append(tb)
+                it.transcript_state = ctypes.cast(tb, c_void_p)
+            else:
+                lb = _buf(tr.label)
+                keep.append(lb)
+                it.transcript_label = ctypes.cast(lb, c_void_p)
+                it.label_len = len(tr.label)
+        stride = 1 + 32 * (6 + 5 + 2 * 12)
+        out = (ctypes.c_uint8 * (stride * n))()
+        plen = c_size_t()
+        err = ctypes.create_string_buffer(256)
+        rc = eng.lib.bpp_prove_batch(eng.ctx, params.handle, items, n, out, stride, byref(plen), err, 256)
+        _check(rc, eng.ctx, err)
+        raw = bytes(out)
+        return [RangeProof.from_bytes(raw[i * stride:i * stride + plen.value]) for i in range(n)]
+
+    @staticmethod
+    def prove_with_rng(transcript, statement, witness, rng):
+        """RangeProof::prove_with_rng; `rng` = object with fill_bytes(n) (the external RNG) or the bytes themselves"""
+        need = 32 * (RangeProof.rounds_for(statement) + 3)
+        rb = rng if isinstance(rng, (bytes, bytearray)) else b"".join(rng.fill_bytes(32) for _ in range(need // 32))
+        return RangeProof.prove_batch([transcript], [statement], [witness], [bytes(rb)])[0]
+
+    @staticmethod
+    def prove(transcript, statement, witness):
+        """RangeProof::prove (OsRng, src/range_proof.rs:222-228)"""
+        import os as _os
+        return RangeProof.prove_with_rng(transcript, statement, witness, _os.urandom(32 * (RangeProof.rounds_for(statement) + 3)))
 
     # ---- verification ----
     @staticmethod

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/bpp.h"
+#include "kernels_prove.h"
 #include "kernels_verify.h"
 #include "msm.h"
 
@@ -156,6 +157,7 @@ struct Params {
   DevBuf<uint8_t> d_hg32;           // compressed H, G_0..G_{t-1}
   std::vector<uint8_t> hg32;        // host copy
   std::vector<uint8_t> gi32, hi32;  // compressed generators, party-major
+  DevBuf<cached> fb_table;          // prover's fixed-base window table, built on first use (table_len x 4096 x 160 B)
 };
 
 struct Precomp {
@@ -1259,3 +1261,172 @@ int bpp_profile_get(bpp_ctx *ctx, bpp_profile *out) {
 }
 
 }  // extern "C"
+
+// ================================================================= batch prover
+extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_item *items, size_t n_items, uint8_t *proofs_out,
+                               size_t proof_stride, size_t *proof_len, char *errbuf, size_t errbuf_len) {
+  BPP_ENTRY(ctx);
+  try {
+    auto pit = ctx->params.find(params);
+    if (pit == ctx->params.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle", errbuf, errbuf_len);
+    Params &P = *pit->second;
+    if (!items || n_items == 0 || !proofs_out) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument", errbuf, errbuf_len);
+    const uint32_t n = P.n_bits, t = P.t, m = items[0].m, B = (uint32_t)n_items;
+    // RangeStatement::init (src/range_statement.rs:43-62)
+    if (m == 0 || (m & (m - 1))) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Number of commitments must be a power of two"};
+    if (P.m_max < m) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Not enough generators for this statement"};
+    const uint32_t mn = m * n;
+    if (mn < 2) throw ProofErr{BPP_ERR_INVALID_LENGTH, "bit_length * aggregation factor must be at least 2"};
+    uint32_t rounds = 0;
+    while ((1u << rounds) < mn) rounds++;
+    const size_t plen = 1 + 32 * (size_t)(t + 5 + 2 * rounds);
+    if (proof_len) *proof_len = plen;
+    if (proof_stride < plen) return fail(ctx, BPP_ERR_INVALID_LENGTH, "proof_stride too small", errbuf, errbuf_len);
+    const uint32_t wit_len = m * (8 + 32 * t), ext_len = 32 * (rounds + 3);
+
+    std::vector<ProveDesc> desc(B);
+    std::vector<uint8_t> bytes, states;
+    std::vector<uint64_t> minvals((size_t)B * m);
+    std::vector<uint8_t> minpres((size_t)B * m);
+    std::map<std::string, uint32_t> state_ids;
+    bytes.reserve((size_t)B * (wit_len + 32 * m + ext_len + 32));
+    for (uint32_t i = 0; i < B; i++) {
+      const bpp_prove_item &it = items[i];
+      ProveDesc &d = desc[i];
+      if (it.m != m) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "all items of one prove batch must share the aggregation factor"};
+      if (!it.values || !it.blindings32 || !it.commitments32 || !it.rng_bytes || (!it.min_values && it.min_present))
+        throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "null witness / statement field"};
+      if (it.seed_nonce32 && m > 1)
+        throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Mask recovery is not supported with an aggregated statement"};
+      if (it.rng_len < ext_len) throw ProofErr{BPP_ERR_INVALID_LENGTH, "not enough external randomness: need (rounds + 3) * 32 bytes"};
+      d.m = m;
+      d.minval_idx = i * m;
+      for (uint32_t j = 0; j < m; j++) {
+        // :264-271
+        if (n < 64 && (it.values[j] >> n) > 0) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Value exceeds bit vector capacity!"};
+        const bool present = it.min_present ? it.min_present[j] != 0 : false;
+        const uint64_t mv = present ? it.min_values[j] : 0;
+        // :308-311
+        if (present && it.values[j] < mv) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Minimum value is larger than value"};
+        minvals[(size_t)i * m + j] = mv;
+        minpres[(size_t)i * m + j] = present ? 1 : 0;
+      }
+      for (uint32_t q = 0; q < m * t; q++)
+        if (!sc_is_canonical(it.blindings32 + 32 * (size_t)q)) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "blinding factor is not canonical"};
+      if (it.seed_nonce32 && !sc_is_canonical(it.seed_nonce32)) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "seed nonce is not canonical"};
+      d.wit_off = (uint32_t)bytes.size();
+      for (uint32_t j = 0; j < m; j++) {
+        for (int k = 0; k < 8; k++) bytes.push_back((uint8_t)(it.values[j] >> (8 * k)));
+        bytes.insert(bytes.end(), it.blindings32 + (size_t)j * t * 32, it.blindings32 + (size_t)(j + 1) * t * 32);
+      }
+      d.commit_off = (uint32_t)bytes.size();
+      bytes.insert(bytes.end(), it.commitments32, it.commitments32 + (size_t)m * 32);
+      d.ext_off = (uint32_t)bytes.size();
+      bytes.insert(bytes.end(), it.rng_bytes, it.rng_bytes + ext_len);
+      d.seed_off = (uint32_t)bytes.size();
+      d.flags = it.seed_nonce32 ? 1u : 0u;
+      if (it.seed_nonce32) bytes.insert(bytes.end(), it.seed_nonce32, it.seed_nonce32 + 32);
+      else bytes.insert(bytes.end(), 32, 0);
+      std::string key;
+      if (it.transcript_state) {
+        key.assign((const char *)it.transcript_state, 203);
+        key.push_back('S');
+      } else {
+        key.assign((const char *)it.transcript_label, it.transcript_label ? it.label_len : 0);
+        key.push_back('L');
+      }
+      auto sit = state_ids.find(key);
+      if (sit == state_ids.end()) {
+        uint32_t id = (uint32_t)(states.size() / 203);
+        states.resize(states.size() + 203);
+        if (it.transcript_state) {
+          memcpy(&states[(size_t)id * 203], it.transcript_state, 203);
+          if (states[(size_t)id * 203 + 200] >= BPP_STROBE_R) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "transcript state has pos >= rate"};
+        } else {
+          Strobe st;
+          merlin_new(st, it.transcript_label, (uint32_t)(it.transcript_label ? it.label_len : 0));
+          strobe_to_bytes(&states[(size_t)id * 203], st);
+        }
+        sit = state_ids.emplace(key, id).first;
+      }
+      d.state_idx = sit->second;
+    }
+
+    hipStream_t s = ctx->stream;
+    const uint32_t n_gen = 2 * P.n_bits * P.m_max;
+    if (!P.fb_table.p) {  // fixed-base window tables for every generator of these parameters (one-off)
+      P.fb_table.alloc((size_t)P.table_len * FB_STRIDE);
+      hipLaunchKernelGGL(k_fb_build, dim3(cdiv(P.table_len * FB_WINDOWS, 64)), dim3(64), 0, s, P.table.p, P.table_len, P.fb_table.p);
+      HIP_CHECK(hipGetLastError());
+    }
+    const uint32_t stride = 2 * mn + t + 1;
+    DevBuf<uint8_t> d_bytes, d_states, d_minpres, d_a32, d_lr, d_a1b, d_proofs, d_commit32;
+    DevBuf<ProveDesc> d_desc;
+    DevBuf<uint64_t> d_minvals;
+    DevBuf<ProveState> d_ps;
+    DevBuf<sc> d_vec, d_ts, d_cts;
+    DevBuf<uint32_t> d_tg, d_tc, d_ctg, d_ctc;
+    d_bytes.alloc(bytes.size());
+    d_states.alloc(states.size());
+    d_minpres.alloc(minpres.size());
+    d_minvals.alloc(minvals.size());
+    d_desc.alloc(B);
+    d_ps.alloc(B);
+    d_vec.alloc((size_t)B * (5 * mn + 2));
+    d_ts.alloc((size_t)B * 2 * stride);
+    d_tg.alloc((size_t)B * 2 * stride);
+    d_tc.alloc((size_t)B * 2);
+    d_a32.alloc((size_t)B * 32);
+    d_lr.alloc((size_t)rounds * B * 64);
+    d_a1b.alloc((size_t)B * 64);
+    d_proofs.alloc((size_t)B * plen);
+    d_commit32.alloc((size_t)B * m * 32);
+    d_cts.alloc((size_t)B * m * (1 + t));
+    d_ctg.alloc((size_t)B * m * (1 + t));
+    d_ctc.alloc((size_t)B * m);
+    HIP_CHECK(hipMemcpyAsync(d_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_states.p, states.data(), states.size(), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_minpres.p, minpres.data(), minpres.size(), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_minvals.p, minvals.data(), minvals.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_desc.p, desc.data(), (size_t)B * sizeof(ProveDesc), hipMemcpyHostToDevice, s));
+    const dim3 lane_grid(cdiv(B, 64)), b64(64);
+    // witness check (:275-284): commit(v_j, r_j) for every opening, compared with the statement's commitments
+    hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(B * m, 64)), b64, 0, s, d_bytes.p, d_desc.p, t, n_gen, B, m, 1 + t, d_cts.p,
+                       d_ctg.p, d_ctc.p);
+    hipLaunchKernelGGL(k_fb_msm, dim3(B * m), b64, 0, s, d_cts.p, d_ctg.p, d_ctc.p, 1 + t, P.fb_table.p, d_commit32.p);
+    hipLaunchKernelGGL(kp_init, lane_grid, b64, 0, s, d_bytes.p, d_desc.p, d_minvals.p, d_states.p, P.d_hg32.p, n, t, B, d_ps.p);
+    hipLaunchKernelGGL(kp_check_commitments, lane_grid, b64, 0, s, d_bytes.p, d_desc.p, d_commit32.p, B, d_ps.p);
+    hipLaunchKernelGGL(kp_A, dim3(B), b64, 0, s, d_bytes.p, d_desc.p, d_minvals.p, d_minpres.p, P.table.p, P.fb_table.p, n_gen, n, t,
+                       d_ps.p, d_a32.p);
+    for (uint32_t j = 0; j <= rounds; j++) {
+      const uint8_t *lr_prev = j ? d_lr.p + (size_t)(j - 1) * B * 64 : nullptr;
+      hipLaunchKernelGGL(kp_lane, lane_grid, b64, 0, s, d_bytes.p, d_desc.p, n, t, B, j, rounds, d_a32.p, lr_prev, d_ps.p);
+      hipLaunchKernelGGL(kp_wave, dim3(B), b64, 0, s, d_bytes.p, d_desc.p, d_minvals.p, d_minpres.p, n, t, n_gen, j, rounds, stride,
+                         d_ps.p, d_vec.p, d_ts.p, d_tg.p, d_tc.p);
+      uint8_t *out = (j < rounds) ? d_lr.p + (size_t)j * B * 64 : d_a1b.p;
+      hipLaunchKernelGGL(k_fb_msm, dim3(2 * B), b64, 0, s, d_ts.p, d_tg.p, d_tc.p, stride, P.fb_table.p, out);
+    }
+    hipLaunchKernelGGL(kp_finish, lane_grid, b64, 0, s, d_desc.p, n, t, B, rounds, d_a32.p, d_lr.p, d_a1b.p, d_vec.p, d_ps.p,
+                       d_proofs.p, (uint32_t)plen);
+    HIP_CHECK(hipGetLastError());
+    std::vector<uint8_t> h_proofs((size_t)B * plen);
+    std::vector<ProveState> h_ps(B);
+    HIP_CHECK(hipMemcpyAsync(h_proofs.data(), d_proofs.p, h_proofs.size(), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(h_ps.data(), d_ps.p, (size_t)B * sizeof(ProveState), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    // zeroize the device copies of witness-derived data (the reference uses Zeroizing<> for these)
+    HIP_CHECK(hipMemsetAsync(d_bytes.p, 0, bytes.size(), s));
+    HIP_CHECK(hipMemsetAsync(d_vec.p, 0, (size_t)B * (5 * mn + 2) * sizeof(sc), s));
+    HIP_CHECK(hipMemsetAsync(d_ps.p, 0, (size_t)B * sizeof(ProveState), s));
+    HIP_CHECK(hipMemsetAsync(d_ts.p, 0, (size_t)B * 2 * stride * sizeof(sc), s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < B; i++) {
+      if (h_ps[i].status & PV_STATUS_COMMIT_MISMATCH) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Witness opening is invalid!"};
+      if (h_ps[i].status & PV_STATUS_TRANSCRIPT)
+        throw ProofErr{BPP_ERR_VERIFICATION_FAILED, "Identity element cannot be added to the transcript / zero challenge"};
+    }
+    for (uint32_t i = 0; i < B; i++) memcpy(proofs_out + (size_t)i * proof_stride, &h_proofs[(size_t)i * plen], plen);
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, errbuf, errbuf_len)
+}

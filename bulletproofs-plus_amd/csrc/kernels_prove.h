@@ -1,0 +1,677 @@
+// Device kernels of the batch prover: RangeProof::prove_with_rng (src/range_proof.rs:232-608) for B proofs at once.
+//
+// Schedule (canonical encodings make every algebraically equal schedule byte-identical):
+//   * no generator folding.  Round j's L_j / R_j are computed directly over the ORIGINAL generators:
+//       Gf[i] = sum_{u = i mod len} cG[u] G_u,  Hf[i] = sum cH[u] H_u   (len = mn >> j)
+//     with per-proof coefficient vectors cG/cH that absorb e^-1, e*y^-n, e, e^-1 each round (:511-521);
+//     every G_u / H_u lands in exactly one of L_j, R_j, so a round is two MSMs of mn + t + 1 terms over FIXED bases.
+//   * fixed-base MSM: 8-bit signed windows over a precomputed table in HBM (fb table: for each generator, 32 windows x
+//     128 multiples in projective-niels form, 160 B each) -> 32 additions per term, no doublings, no buckets.
+//   * per proof and round: one lane for the Fiat-Shamir / RNG / inversion step (kp_lane), one wavefront for the
+//     scalar-vector work (kp_wave), one wavefront per output point for the MSM (k_fb_msm).
+// All scalars are Montgomery form in HBM; canonical only in MSM inputs, transcript bytes and the proof.
+#pragma once
+#include "kernels_verify.h"
+
+namespace bpp {
+
+// ---------------------------------------------------------------- fixed-base tables
+struct cached {  // projective niels
+  fe yplusx, yminusx, z, t2d;
+};
+#define FB_WINDOWS 32
+#define FB_ENTRIES 128
+#define FB_STRIDE (FB_WINDOWS * FB_ENTRIES)  // entries per generator
+
+BPP_HD void ge_to_cached(cached &r, const ge &p) {
+  fe d2;
+  fe_add(r.yplusx, p.Y, p.X);
+  fe_carry(r.yplusx);
+  fe_sub(r.yminusx, p.Y, p.X);
+  fe_copy(r.z, p.Z);
+  fe_carry(r.z);
+  fe_const(d2, FE_D2);
+  fe_mul(r.t2d, p.T, d2);
+}
+
+// r = p + (neg ? -q : q), q projective niels: 8 mul
+BPP_HD void ge_add_cached(ge &r, const ge &p, const cached &q, bool neg) {
+  fe a, b, c, d, e, f, g, h, qa, qb, qt, nt;
+  fe_neg(nt, q.t2d);
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    qa.v[i] = neg ? q.yminusx.v[i] : q.yplusx.v[i];
+    qb.v[i] = neg ? q.yplusx.v[i] : q.yminusx.v[i];
+    qt.v[i] = neg ? nt.v[i] : q.t2d.v[i];
+  }
+  fe_add(a, p.Y, p.X);
+  fe_sub(b, p.Y, p.X);
+  fe_mul(a, a, qa);
+  fe_mul(b, b, qb);
+  fe_mul(c, qt, p.T);
+  fe_mul(d, p.Z, q.z);
+  fe_add(d, d, d);
+  fe_sub(e, a, b);
+  fe_add(h, a, b);
+  fe_add(g, d, c);
+  fe_sub(f, d, c);
+  fe_mul(r.X, e, f);
+  fe_mul(r.Y, h, g);
+  fe_carry(g);
+  fe_mul(r.Z, g, f);
+  fe_mul(r.T, e, h);
+}
+
+// one lane per (generator, window): entries d * 2^(8w) * P, d = 1..128
+__global__ void __launch_bounds__(64) k_fb_build(const niels *__restrict__ gens, uint32_t n_gens, cached *__restrict__ tbl) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_gens * FB_WINDOWS) return;
+  const uint32_t g = i / FB_WINDOWS, w = i % FB_WINDOWS;
+  ge base;
+  ge_identity(base);
+  const niels q = gens[g];
+  ge_madd(base, base, q);
+  if (w) ge_dbl_n(base, base, (int)(8 * w));
+  cached cb;
+  ge_to_cached(cb, base);
+  ge acc = base;
+  cached *out = tbl + ((size_t)g * FB_WINDOWS + w) * FB_ENTRIES;
+  for (uint32_t d = 0; d < FB_ENTRIES; d++) {
+    cached c;
+    ge_to_cached(c, acc);
+    out[d] = c;
+    if (d + 1 < FB_ENTRIES) ge_add_cached(acc, acc, cb, false);
+  }
+}
+
+// out[o] = sum_i scal[o][i] * Gen[gidx[o][i]], i < count[o]; one wavefront per output; result compressed.
+// scal: canonical scalars, row stride `stride`; gidx rows likewise.
+__global__ void __launch_bounds__(64) k_fb_msm(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx,
+                                               const uint32_t *__restrict__ count, uint32_t stride,
+                                               const cached *__restrict__ tbl, uint8_t *__restrict__ out32) {
+  const uint32_t o = blockIdx.x, lane = threadIdx.x;
+  const uint32_t n = count[o];
+  __shared__ ge red[64];
+  ge acc;
+  ge_identity(acc);
+  for (uint32_t i = lane; i < n; i += 64) {
+    const sc s = scal[(size_t)o * stride + i];
+    const cached *row = tbl + (size_t)gidx[(size_t)o * stride + i] * FB_STRIDE;
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < FB_WINDOWS; w++) {
+      uint32_t v = ((s.v[w >> 2] >> (8 * (w & 3))) & 0xffu) + carry;
+      bool neg = v > 128u;
+      uint32_t mag = neg ? 256u - v : v;
+      carry = neg ? 1u : 0u;
+      if (mag) {
+        const cached c = row[(size_t)w * FB_ENTRIES + (mag - 1)];
+        ge_add_cached(acc, acc, c, neg);
+      }
+    }
+  }
+  red[lane] = acc;
+  __syncthreads();
+  for (uint32_t off = 32; off >= 1; off >>= 1) {
+    if (lane < off) {
+      ge x = red[lane], y2 = red[lane + off];
+      ge_add(x, x, y2);
+      red[lane] = x;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    uint8_t c32[32];
+    ristretto_compress(c32, red[0]);
+    for (int k = 0; k < 32; k++) out32[(size_t)o * 32 + k] = c32[k];
+  }
+}
+
+// ---------------------------------------------------------------- per-proof prover state
+struct ProveDesc {
+  uint32_t m;           // aggregation factor (uniform over a prove batch)
+  uint32_t wit_off;     // byte offset of the witness bytes (v LE64 || r[0..t) per opening) in bytes[]
+  uint32_t commit_off;  // m compressed commitments
+  uint32_t ext_off;     // (rounds+3) x 32 bytes of external randomness
+  uint32_t minval_idx;  // m minimum values / presence flags
+  uint32_t state_idx;
+  uint32_t flags;       // bit0: seed nonce present
+  uint32_t seed_off;    // byte offset of the 32-byte seed nonce (if any)
+};
+
+struct ProveState {
+  Strobe tr;   // the proof's merlin transcript
+  Strobe rng;  // current TranscriptRng (src/transcripts.rs:185-194)
+  sc y, z, e, einv, esq, einvsq, yinv_nhalf, yinv_prev, r, s;
+  sc alpha[6], dl[6], dr[6], dd[6], eta[6];
+  uint32_t status;  // nonzero: proving failed (BPP_ERR_*)
+};
+
+#define PV_STATUS_COMMIT_MISMATCH 2u  // InvalidArgument: "Witness opening is invalid!" (:275-284)
+#define PV_STATUS_TRANSCRIPT 1u       // VerificationFailed: identity point / zero challenge
+
+// build_rng (src/transcripts.rs:185-194): clone, rekey with the witness bytes, finalize with 32 external bytes
+__device__ __forceinline__ void pv_build_rng(Strobe &rng, const Strobe &tr, const uint8_t *wit, uint32_t wit_len,
+                                             const uint8_t *ext32) {
+  rng = tr;
+  merlin_rng_rekey(rng, (const uint8_t *)"witness", 7, wit, wit_len);
+  uint8_t r32[32];
+  for (int i = 0; i < 32; i++) r32[i] = ext32[i];
+  merlin_rng_finalize(rng, r32);
+}
+// Scalar::random_not_zero(transcript_rng)
+__device__ __forceinline__ void pv_random(sc &out, Strobe &rng) {
+  do {
+    uint8_t w[64];
+    merlin_rng_fill(rng, w, 64);
+    sc_mont_from_wide(out, w);
+  } while (sc_iszero(out));
+}
+__device__ __forceinline__ void pv_nonce_or_random(sc &out, Strobe &rng, const uint8_t *seed, bool has_seed, const char *label,
+                                                   uint32_t llen, int j, int k) {
+  if (has_seed)
+    dev_nonce(out, seed, label, llen, j, k);
+  else
+    pv_random(out, rng);
+}
+__device__ __forceinline__ bool pv_validate_append(Strobe &tr, const char *label, uint32_t llen, const uint8_t *p32) {
+  uint8_t b[32];
+  uint32_t nz = 0;
+  for (int i = 0; i < 32; i++) {
+    b[i] = p32[i];
+    nz |= b[i];
+  }
+  merlin_append_message(tr, (const uint8_t *)label, llen, b, 32);
+  return nz != 0;
+}
+
+// ---- stage 0, one lane per proof: RangeProofTranscript::new (:287-297), alpha (:325-333) ----
+__global__ void __launch_bounds__(64) kp_init(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
+                                              const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ states,
+                                              const uint8_t *__restrict__ hg32, uint32_t n_bits, uint32_t t, uint32_t B,
+                                              ProveState *__restrict__ ps) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  const ProveDesc d = desc[p];
+  ProveState &st = ps[p];
+  st.status = 0;
+  Strobe tr, rng;
+  strobe_from_bytes(tr, states + 203u * d.state_idx);
+  merlin_append_message(tr, (const uint8_t *)"dom-sep", 7, (const uint8_t *)"Bulletproofs+ Range Proof", 25);
+  merlin_append_message(tr, (const uint8_t *)"H", 1, hg32, 32);
+  for (uint32_t k = 0; k < t; k++) merlin_append_message(tr, (const uint8_t *)"G", 1, hg32 + 32 * (k + 1), 32);
+  merlin_append_u64(tr, (const uint8_t *)"N", 1, n_bits);
+  merlin_append_u64(tr, (const uint8_t *)"T", 1, t);
+  merlin_append_u64(tr, (const uint8_t *)"M", 1, d.m);
+  for (uint32_t j = 0; j < d.m; j++) merlin_append_message(tr, (const uint8_t *)"Ci", 2, bytes + d.commit_off + 32 * j, 32);
+  for (uint32_t j = 0; j < d.m; j++)
+    merlin_append_u64(tr, (const uint8_t *)"vi - minimum_value", 18, minvals[d.minval_idx + j]);
+  const uint32_t wit_len = d.m * (8 + 32 * t);
+  pv_build_rng(rng, tr, bytes + d.wit_off, wit_len, bytes + d.ext_off);
+  const bool has_seed = d.flags & 1u;
+  for (uint32_t k = 0; k < t; k++) {
+    sc a;
+    pv_nonce_or_random(a, rng, bytes + d.seed_off, has_seed, "alpha", 5, -1, (int)k);
+    st.alpha[k] = a;
+  }
+  st.tr = tr;
+  st.rng = rng;
+}
+
+// ---- A = sum_{bit=1} G_i - sum_{bit=0} H_i + sum_k alpha_k G_k  (:300-345), one wavefront per proof ----
+// a_L/a_R are never materialised as scalars here: they are 0/1 and 0/-1.
+__global__ void __launch_bounds__(64) kp_A(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
+                                           const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present,
+                                           const niels *__restrict__ gens, const cached *__restrict__ tbl, uint32_t n_gen,
+                                           uint32_t n_bits, uint32_t t, const ProveState *__restrict__ ps,
+                                           uint8_t *__restrict__ a_out32) {
+  const uint32_t p = blockIdx.x, lane = threadIdx.x;
+  const ProveDesc d = desc[p];
+  const uint32_t mn = d.m * n_bits;
+  __shared__ ge red[64];
+  ge acc;
+  ge_identity(acc);
+  for (uint32_t i = lane; i < mn; i += 64) {
+    const uint32_t party = i / n_bits, bit_idx = i % n_bits;
+    const uint8_t *w = bytes + d.wit_off + party * (8 + 32 * t);
+    uint64_t v = 0;
+    for (int k = 0; k < 8; k++) v |= (uint64_t)w[k] << (8 * k);
+    if (min_present[d.minval_idx + party]) v -= minvals[d.minval_idx + party];
+    const bool bit = (v >> bit_idx) & 1ULL;
+    niels q = gens[2 * i + (bit ? 0 : 1)];  // G_i or H_i
+    niels_cneg(q, !bit);                     // a_R = a_L - 1 = -1 where the bit is 0
+    ge_madd(acc, acc, q);
+  }
+  if (lane < t) {  // alpha_k * G_k through the fixed-base table
+    sc s;
+    sc_from_mont(s, ps[p].alpha[lane]);
+    const cached *row = tbl + (size_t)(n_gen + lane) * FB_STRIDE;
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < FB_WINDOWS; w++) {
+      uint32_t v = ((s.v[w >> 2] >> (8 * (w & 3))) & 0xffu) + carry;
+      bool neg = v > 128u;
+      uint32_t mag = neg ? 256u - v : v;
+      carry = neg ? 1u : 0u;
+      if (mag) {
+        const cached c = row[(size_t)w * FB_ENTRIES + (mag - 1)];
+        ge_add_cached(acc, acc, c, neg);
+      }
+    }
+  }
+  red[lane] = acc;
+  __syncthreads();
+  for (uint32_t off = 32; off >= 1; off >>= 1) {
+    if (lane < off) {
+      ge x = red[lane], y2 = red[lane + off];
+      ge_add(x, x, y2);
+      red[lane] = x;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    uint8_t c32[32];
+    ristretto_compress(c32, red[0]);
+    for (int k = 0; k < 32; k++) a_out32[(size_t)p * 32 + k] = c32[k];
+  }
+}
+
+// ---- lane kernel, step j = 0..r (one lane per proof): Fiat-Shamir, RNG draws, inversions ----
+//   j == 0      : challenges_y_z(A) (:348), then the draws of round 0
+//   1 <= j <= r : challenge_round_e(L_{j-1}, R_{j-1}) (:498-508), alpha update (:535-537), then the draws of round j
+//                 (j < r: d_L, d_R :437-464, y^-n :426-432;  j == r: r, s, d, eta :542-571)
+__global__ void __launch_bounds__(64) kp_lane(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
+                                              uint32_t n_bits, uint32_t t, uint32_t B, uint32_t j, uint32_t rounds,
+                                              const uint8_t *__restrict__ a32, const uint8_t *__restrict__ lr32 /* [B][2][32] of round j-1 */,
+                                              ProveState *__restrict__ ps) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  const ProveDesc d = desc[p];
+  ProveState &st = ps[p];
+  const uint32_t mn = d.m * n_bits, wit_len = d.m * (8 + 32 * t);
+  const bool has_seed = d.flags & 1u;
+  const uint8_t *seed = bytes + d.seed_off;
+  bool ok = true;
+  Strobe tr = st.tr, rng;
+  if (j == 0) {
+    ok = pv_validate_append(tr, "A", 1, a32 + (size_t)p * 32) && ok;
+    pv_build_rng(rng, tr, bytes + d.wit_off, wit_len, bytes + d.ext_off + 32);
+    sc v;
+    ok = dev_challenge(tr, (const uint8_t *)"y", 1, v) && ok;
+    st.y = v;
+    ok = dev_challenge(tr, (const uint8_t *)"z", 1, v) && ok;
+    st.z = v;
+  } else {
+    ok = pv_validate_append(tr, "L", 1, lr32 + (size_t)p * 64) && ok;
+    ok = pv_validate_append(tr, "R", 1, lr32 + (size_t)p * 64 + 32) && ok;
+    pv_build_rng(rng, tr, bytes + d.wit_off, wit_len, bytes + d.ext_off + 32 * (1 + j));
+    sc e, einv, esq, einvsq;
+    ok = dev_challenge(tr, (const uint8_t *)"e", 1, e) && ok;
+    sc_mont_invert_vartime(einv, e);
+    sc_montsq(esq, e);
+    sc_montsq(einvsq, einv);
+    st.e = e;
+    st.einv = einv;
+    st.esq = esq;
+    st.einvsq = einvsq;
+    for (uint32_t k = 0; k < t; k++) {
+      sc a = st.alpha[k], u, v;
+      sc_montmul(u, st.dl[k], esq);
+      sc_montmul(v, st.dr[k], einvsq);
+      sc_add(a, a, u);
+      sc_add(a, a, v);
+      st.alpha[k] = a;
+    }
+  }
+  if (j < rounds) {
+    for (uint32_t k = 0; k < t; k++) {
+      sc v;
+      pv_nonce_or_random(v, rng, seed, has_seed, "dL", 2, (int)j, (int)k);
+      st.dl[k] = v;
+    }
+    for (uint32_t k = 0; k < t; k++) {
+      sc v;
+      pv_nonce_or_random(v, rng, seed, has_seed, "dR", 2, (int)j, (int)k);
+      st.dr[k] = v;
+    }
+    const uint32_t n_half = mn >> (j + 1);
+    sc yn, yinv;
+    sc_mont_pow_u32(yn, st.y, n_half);
+    sc_mont_invert_vartime(yinv, yn);
+    st.yinv_prev = st.yinv_nhalf;  // the fold of step j still needs round j-1's y^-n
+    st.yinv_nhalf = yinv;
+  } else {
+    sc v;
+    st.yinv_prev = st.yinv_nhalf;
+    pv_random(v, rng);
+    st.r = v;
+    pv_random(v, rng);
+    st.s = v;
+    for (uint32_t k = 0; k < t; k++) {
+      pv_nonce_or_random(v, rng, seed, has_seed, "d", 1, -1, (int)k);
+      st.dd[k] = v;
+    }
+    for (uint32_t k = 0; k < t; k++) {
+      pv_nonce_or_random(v, rng, seed, has_seed, "eta", 3, -1, (int)k);
+      st.eta[k] = v;
+    }
+  }
+  st.tr = tr;
+  if (!ok) st.status |= PV_STATUS_TRANSCRIPT;
+}
+
+// ---- wave kernel, step j = 0..r (one wavefront per proof): vector prep / fold / inner products / MSM term lists ----
+// vec layout per proof (Montgomery): a[mn] | b[mn] | cG[mn] | cH[mn] | ypow[mn+2]
+// term rows per proof: 2 outputs x stride; gidx uses the table order (2i = G_i, 2i+1 = H_i, n_gen + k = G_k, n_gen + t = H)
+__global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
+                                              const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present,
+                                              uint32_t n_bits, uint32_t t, uint32_t n_gen, uint32_t j, uint32_t rounds,
+                                              uint32_t stride, ProveState *__restrict__ ps, sc *__restrict__ vec,
+                                              sc *__restrict__ term_scal, uint32_t *__restrict__ term_gidx,
+                                              uint32_t *__restrict__ term_count) {
+  const uint32_t p = blockIdx.x, lane = threadIdx.x;
+  const ProveDesc d = desc[p];
+  ProveState &st = ps[p];
+  const uint32_t mn = d.m * n_bits;
+  sc *a = vec + (size_t)p * (5 * mn + 2), *b = a + mn, *cG = b + mn, *cH = cG + mn, *ypow = cH + mn;
+  sc one;
+  sc_mont_one(one);
+  __shared__ sc red[64];
+
+  if (j == 0) {
+    // y powers (:353-359) by lane-strided exponentiation, d (:362-373), a_L - z, a_R + d*y^(mn-i) + z (:376-381)
+    const sc y = st.y, z = st.z;
+    sc z_square;
+    sc_montsq(z_square, z);
+    for (uint32_t i = lane; i < mn + 2; i += 64) {
+      sc v;
+      sc_mont_pow_u32(v, y, i);
+      ypow[i] = v;
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < mn; i += 64) {
+      const uint32_t party = i / n_bits, bit_idx = i % n_bits;
+      const uint8_t *w = bytes + d.wit_off + party * (8 + 32 * t);
+      uint64_t v = 0;
+      for (int k = 0; k < 8; k++) v |= (uint64_t)w[k] << (8 * k);
+      if (min_present[d.minval_idx + party]) v -= minvals[d.minval_idx + party];
+      const bool bit = (v >> bit_idx) & 1ULL;
+      sc al, ar, di, two_k, u;
+      if (bit) {
+        al = one;
+        sc_0(ar);
+      } else {
+        sc_0(al);
+        sc_neg(ar, one);
+      }
+      di = z_square;
+      for (uint32_t q = 0; q < party; q++) sc_montmul(di, di, z_square);
+      sc_mont_from_u64(two_k, 1ULL << bit_idx);
+      sc_montmul(di, di, two_k);
+      sc_sub(al, al, z);
+      sc_montmul(u, di, ypow[mn - i]);
+      sc_add(u, u, z);
+      sc_add(ar, ar, u);
+      a[i] = al;
+      b[i] = ar;
+      cG[i] = one;
+      cH[i] = one;
+    }
+    // alpha[k] += sum_j z^(2(j+1)) * r_{j,k} * y^(mn+1)  (:382-392)
+    __syncthreads();
+    if (lane < t) {
+      sc acc = st.alpha[lane], zp = one;
+      const sc ymn1 = ypow[mn + 1];
+      for (uint32_t party = 0; party < d.m; party++) {
+        sc rjk, u;
+        sc_montmul(zp, zp, z_square);
+        sc_load_mont(rjk, bytes + d.wit_off + party * (8 + 32 * t) + 8 + 32 * lane);
+        sc_montmul(u, zp, rjk);
+        sc_montmul(u, u, ymn1);
+        sc_add(acc, acc, u);
+      }
+      st.alpha[lane] = acc;
+    }
+  } else {
+    // fold with e_{j-1} (:511-533): len = mn >> (j-1)
+    const uint32_t len = mn >> (j - 1), nh = len >> 1;
+    const sc e = st.e, einv = st.einv, yinv = st.yinv_prev;
+    sc yn, e_yinv;
+    yn = ypow[nh];
+    sc_montmul(e_yinv, e, yinv);
+    // a' = a_lo*e + (a_hi*y^n)*e^-1 ; b' = b_lo*e^-1 + b_hi*e   (each lane reads both halves before anyone writes)
+    for (uint32_t base = 0; base < nh; base += 64) {
+      const uint32_t i = base + lane;
+      sc na, nb;
+      if (i < nh) {
+        sc u, v;
+        sc_montmul(u, a[i], e);
+        sc_montmul(v, a[nh + i], yn);
+        sc_montmul(v, v, einv);
+        sc_add(na, u, v);
+        sc_montmul(u, b[i], einv);
+        sc_montmul(v, b[nh + i], e);
+        sc_add(nb, u, v);
+      }
+      __syncthreads();
+      if (i < nh) {
+        a[i] = na;
+        b[i] = nb;
+      }
+    }
+    for (uint32_t u = lane; u < mn; u += 64) {
+      const bool lo = (u & (len - 1)) < nh;
+      sc g = cG[u], h = cH[u];
+      sc_montmul(g, g, lo ? einv : e_yinv);
+      sc_montmul(h, h, lo ? e : einv);
+      cG[u] = g;
+      cH[u] = h;
+    }
+  }
+  __syncthreads();
+
+  sc *ts = term_scal + (size_t)p * 2 * stride;
+  uint32_t *tg = term_gidx + (size_t)p * 2 * stride;
+  if (j < rounds) {
+    // round j: len = mn >> j
+    const uint32_t len = mn >> j, nh = len >> 1;
+    const sc yinv = st.yinv_nhalf, yn = ypow[nh];
+    // c_L = sum a_lo[i] y^(i+1) b_hi[i];  c_R = sum a_hi[i] y^(nh+1+i) b_lo[i]   (:468-479)
+    sc cl, cr;
+    sc_0(cl);
+    sc_0(cr);
+    for (uint32_t i = lane; i < nh; i += 64) {
+      sc u;
+      sc_montmul(u, a[i], ypow[i + 1]);
+      sc_montmul(u, u, b[nh + i]);
+      sc_add(cl, cl, u);
+      sc_montmul(u, a[nh + i], ypow[nh + 1 + i]);
+      sc_montmul(u, u, b[i]);
+      sc_add(cr, cr, u);
+    }
+    for (int pass = 0; pass < 2; pass++) {
+      red[lane] = pass ? cr : cl;
+      __syncthreads();
+      for (uint32_t off = 32; off >= 1; off >>= 1) {
+        if (lane < off) {
+          sc x = red[lane], y2 = red[lane + off];
+          sc_add(x, x, y2);
+          red[lane] = x;
+        }
+        __syncthreads();
+      }
+      if (pass) cr = red[0];
+      else cl = red[0];
+      __syncthreads();
+    }
+    // term lists.  L (:482-488): c_L H, d_L G_k, (a_lo y^-n) on Gf_hi, b_hi on Hf_lo.  R (:489-495) symmetric.
+    // output 0 = L, output 1 = R; every original G_u / H_u goes to exactly one of them.
+    for (uint32_t u = lane; u < mn; u += 64) {
+      const uint32_t fi = u & (len - 1);
+      const bool lo = fi < nh;
+      const uint32_t i = lo ? fi : fi - nh;
+      sc sg, sh;
+      if (lo) {  // G_u in R with a_hi*y^n ; H_u in L with b_hi
+        sc_montmul(sg, a[nh + i], yn);
+        sc_montmul(sg, sg, cG[u]);
+        sc_montmul(sh, b[nh + i], cH[u]);
+      } else {  // G_u in L with a_lo*y^-n ; H_u in R with b_lo
+        sc_montmul(sg, a[i], yinv);
+        sc_montmul(sg, sg, cG[u]);
+        sc_montmul(sh, b[i], cH[u]);
+      }
+      sc_from_mont(sg, sg);
+      sc_from_mont(sh, sh);
+      // position within the output's row: the u-th G term and u-th H term of each half, packed densely
+      const uint32_t rank = (u / len) * nh + i;  // index among the mn/2 generators of this kind in this output
+      const uint32_t og = lo ? 1u : 0u, oh = lo ? 0u : 1u;
+      ts[og * stride + rank] = sg;
+      tg[og * stride + rank] = 2 * u;
+      ts[oh * stride + (mn >> 1) + rank] = sh;
+      tg[oh * stride + (mn >> 1) + rank] = 2 * u + 1;
+    }
+    if (lane <= t) {
+      // lanes 0..t-1: d_L[k] G_k / d_R[k] G_k ; lane t: c_L H / c_R H
+      sc sl, sr;
+      if (lane < t) {
+        sl = st.dl[lane];
+        sr = st.dr[lane];
+      } else {
+        sl = cl;
+        sr = cr;
+      }
+      sc_from_mont(sl, sl);
+      sc_from_mont(sr, sr);
+      ts[0 * stride + mn + lane] = sl;
+      tg[0 * stride + mn + lane] = n_gen + lane;
+      ts[1 * stride + mn + lane] = sr;
+      tg[1 * stride + mn + lane] = n_gen + lane;
+    }
+    if (lane == 0) {
+      term_count[2 * p] = mn + t + 1;
+      term_count[2 * p + 1] = mn + t + 1;
+    }
+  } else {
+    // final step (:574-584): A1 = r Gf[0] + s Hf[0] + (r y b + s y a) H + sum d_k G_k ;  B = (r y s) H + sum eta_k G_k
+    const sc r = st.r, s = st.s, y = st.y;
+    for (uint32_t u = lane; u < mn; u += 64) {
+      sc sg, sh;
+      sc_montmul(sg, r, cG[u]);
+      sc_montmul(sh, s, cH[u]);
+      sc_from_mont(sg, sg);
+      sc_from_mont(sh, sh);
+      ts[2 * u] = sg;
+      tg[2 * u] = 2 * u;
+      ts[2 * u + 1] = sh;
+      tg[2 * u + 1] = 2 * u + 1;
+    }
+    if (lane <= t) {
+      sc s1v, s2v;
+      if (lane < t) {
+        s1v = st.dd[lane];
+        s2v = st.eta[lane];
+      } else {
+        sc u, v;
+        sc_montmul(u, r, y);
+        sc_montmul(u, u, b[0]);
+        sc_montmul(v, s, y);
+        sc_montmul(v, v, a[0]);
+        sc_add(s1v, u, v);
+        sc_montmul(s2v, r, y);
+        sc_montmul(s2v, s2v, s);
+      }
+      sc_from_mont(s1v, s1v);
+      sc_from_mont(s2v, s2v);
+      ts[0 * stride + 2 * mn + lane] = s1v;
+      tg[0 * stride + 2 * mn + lane] = n_gen + lane;
+      ts[1 * stride + lane] = s2v;
+      tg[1 * stride + lane] = n_gen + lane;
+    }
+    if (lane == 0) {
+      term_count[2 * p] = 2 * mn + t + 1;
+      term_count[2 * p + 1] = t + 1;
+    }
+  }
+}
+
+// ---- final lane kernel: challenge_final_e, responses, wire bytes (:587-607, to_bytes :1120-1150) ----
+// proof layout: [t] d1[t] A A1 B r1 s1 (L_j R_j)...
+__global__ void __launch_bounds__(64) kp_finish(const ProveDesc *__restrict__ desc, uint32_t n_bits, uint32_t t, uint32_t B,
+                                                uint32_t rounds, const uint8_t *__restrict__ a32,
+                                                const uint8_t *__restrict__ lr_all /* [rounds][B][2][32] */,
+                                                const uint8_t *__restrict__ a1b32 /* [B][2][32] */, const sc *__restrict__ vec,
+                                                ProveState *__restrict__ ps, uint8_t *__restrict__ proofs, uint32_t proof_stride) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  ProveState &st = ps[p];
+  const uint32_t mn = desc[p].m * n_bits;
+  const sc *a = vec + (size_t)p * (5 * mn + 2), *b = a + mn;
+  Strobe tr = st.tr;
+  bool ok = pv_validate_append(tr, "A1", 2, a1b32 + (size_t)p * 64);
+  ok = pv_validate_append(tr, "B", 1, a1b32 + (size_t)p * 64 + 32) && ok;
+  sc e, esq, r1, s1, u;
+  ok = dev_challenge(tr, (const uint8_t *)"e", 1, e) && ok;
+  sc_montsq(esq, e);
+  sc_montmul(u, a[0], e);
+  sc_add(r1, st.r, u);
+  sc_montmul(u, b[0], e);
+  sc_add(s1, st.s, u);
+  uint8_t *o = proofs + (size_t)p * proof_stride;
+  uint8_t tmp[32];
+  *o++ = (uint8_t)t;
+  for (uint32_t k = 0; k < t; k++) {
+    sc d1, v;
+    sc_montmul(v, st.dd[k], e);
+    sc_add(d1, st.eta[k], v);
+    sc_montmul(v, st.alpha[k], esq);
+    sc_add(d1, d1, v);
+    sc_from_mont(d1, d1);
+    sc_store_words(tmp, d1);
+    for (int i = 0; i < 32; i++) *o++ = tmp[i];
+  }
+  for (int i = 0; i < 32; i++) *o++ = a32[(size_t)p * 32 + i];
+  for (int i = 0; i < 64; i++) *o++ = a1b32[(size_t)p * 64 + i];
+  sc_from_mont(r1, r1);
+  sc_store_words(tmp, r1);
+  for (int i = 0; i < 32; i++) *o++ = tmp[i];
+  sc_from_mont(s1, s1);
+  sc_store_words(tmp, s1);
+  for (int i = 0; i < 32; i++) *o++ = tmp[i];
+  for (uint32_t j = 0; j < rounds; j++)
+    for (int i = 0; i < 64; i++) *o++ = lr_all[((size_t)j * B + p) * 64 + i];
+  if (!ok) st.status |= PV_STATUS_TRANSCRIPT;
+}
+
+// commitment check (:275-284): compare the engine's commit(v_j, r_j) with the statement's commitments
+__global__ void kp_check_commitments(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
+                                     const uint8_t *__restrict__ computed32 /* [B][m][32] */, uint32_t B, ProveState *__restrict__ ps) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  const ProveDesc d = desc[p];
+  uint32_t diff = 0;
+  for (uint32_t i = 0; i < 32 * d.m; i++) diff |= (uint32_t)(bytes[d.commit_off + i] ^ computed32[(size_t)p * 32 * d.m + i]);
+  if (diff) ps[p].status |= PV_STATUS_COMMIT_MISMATCH;
+}
+
+// term lists for the commitment check: output (p, j) = v_j H + sum_k r_{j,k} G_k
+__global__ void kp_commit_terms(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc, uint32_t t, uint32_t n_gen,
+                                uint32_t B, uint32_t m, uint32_t stride, sc *__restrict__ ts, uint32_t *__restrict__ tg,
+                                uint32_t *__restrict__ tc) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= B * m) return;
+  const uint32_t p = o / m, j = o % m;
+  const uint8_t *w = bytes + desc[p].wit_off + j * (8 + 32 * t);
+  sc v;
+  sc_0(v);
+  v.v[0] = (uint32_t)w[0] | ((uint32_t)w[1] << 8) | ((uint32_t)w[2] << 16) | ((uint32_t)w[3] << 24);
+  v.v[1] = (uint32_t)w[4] | ((uint32_t)w[5] << 8) | ((uint32_t)w[6] << 16) | ((uint32_t)w[7] << 24);
+  ts[(size_t)o * stride] = v;
+  tg[(size_t)o * stride] = n_gen + t;
+  for (uint32_t k = 0; k < t; k++) {
+    sc r;
+    sc_load_words(r, w + 8 + 32 * k);
+    ts[(size_t)o * stride + 1 + k] = r;
+    tg[(size_t)o * stride + 1 + k] = n_gen + k;
+  }
+  tc[o] = 1 + t;
+}
+
+}  // namespace bpp

@@ -133,6 +133,34 @@ int bpp_verify_phase2(bpp_ctx *ctx, uint64_t batch, const uint8_t *weights32 /* 
                       uint8_t accumulator128[128], char *errbuf, size_t errbuf_len);
 int bpp_accumulators_sum_is_identity(bpp_ctx *ctx, const uint8_t *accumulators128, size_t n, int *is_identity);
 
+/* ---- B2: batch prover = RangeProof::prove_with_rng (src/range_proof.rs:232-608), one call for n independent proofs ----
+ * Every item is one (statement, witness, transcript, rng) quadruple of the reference API:
+ *   values/blindings32  RangeWitness: per opening v (u64) and r[0..t) (src/commitment_opening.rs:14-37)
+ *   commitments32       statement.commitments_compressed; each must equal commit(v_j, r_j) (:275-284)
+ *   min_values/min_present, seed_nonce32   as in bpp_verify_item (src/range_statement.rs:21-32)
+ *   transcript_*        the caller's merlin::Transcript (state or Transcript::new(label))
+ *   rng_bytes           what the external `rng` would have returned: (rounds + 3) draws of 32 bytes, rounds = log2(m * n)
+ *                       (the reference pulls exactly that many through TranscriptRngBuilder::finalize)
+ * All items of one call must share the aggregation factor m.  Output: to_bytes() of each proof, 1 + 32*(t + 5 + 2*rounds)
+ * bytes, written at proofs_out + i * proof_stride; *proof_len receives that length.  Same inputs -> same bytes as the
+ * reference (any equivalent schedule yields identical canonical encodings). */
+typedef struct {
+  const uint64_t *values;        /* m */
+  const uint8_t *blindings32;    /* m x t x 32 */
+  const uint8_t *commitments32;  /* m x 32 */
+  uint32_t m;
+  const uint64_t *min_values;
+  const uint8_t *min_present;    /* NULL = all None */
+  const uint8_t *seed_nonce32;   /* NULL = None; only with m == 1 */
+  const uint8_t *transcript_state;
+  const uint8_t *transcript_label;
+  size_t label_len;
+  const uint8_t *rng_bytes;
+  size_t rng_len;                /* >= (rounds + 3) * 32 */
+} bpp_prove_item;
+int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_item *items, size_t n_items, uint8_t *proofs_out,
+                    size_t proof_stride, size_t *proof_len, char *errbuf, size_t errbuf_len);
+
 /* ---- parity / diagnostics: intermediates of the last verify on `batch`, for differential tests ---- */
 #define BPP_TRACE_CHALLENGES 1     /* per proof (rmax+3) x 32: y, z, e_0.., e_final (canonical), rmax = max rounds */
 #define BPP_TRACE_RNG_OUT 2        /* n x 32 */
