@@ -46,6 +46,8 @@ SYMBOLS = [
     ("bpp_pedersen_commit", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_uint32, c_size_t, c_void_p]),
     ("bpp_verify_batch", c_int, [c_void_p, c_uint64, POINTER(VerifyItem), c_size_t, c_int, c_size_t, c_void_p,
                                  c_void_p, c_void_p, c_size_t]),
+    ("bpp_verify_batch_with_challenges", c_int, [c_void_p, c_uint64, POINTER(VerifyItem), c_size_t, POINTER(c_void_p),
+                                                 c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t]),
     ("bpp_batch_upload", c_int, [c_void_p, c_uint64, POINTER(VerifyItem), c_size_t, POINTER(c_uint64), c_void_p,
                                  c_size_t]),
     ("bpp_batch_destroy", c_int, [c_void_p, c_uint64]),

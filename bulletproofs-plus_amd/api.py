@@ -589,6 +589,28 @@ class RangeProof:
         return out
 
 
+def verify_batch_with_challenges(statements, proofs, challenges, rng_outputs, action, chunk=MAX_RANGE_PROOF_BATCH_SIZE):
+    """bpp_verify_batch_with_challenges: PASS 1 done by the caller.  challenges[i] = [y, z, e_0.., e_final] (32-byte
+    scalars), rng_outputs[i] = the 32 transcript-RNG bytes of proof i."""
+    trs = [Transcript.new(b"")] * len(proofs)
+    RangeProof._check_batch_args(trs, statements, proofs)
+    params = RangeProof._largest_params(statements)
+    eng = params.engine
+    items, keep = RangeProof._items(trs, statements, proofs)
+    n, t = len(proofs), int(params.extension_degree())
+    bufs = [_buf(b"".join(c)) for c in challenges]
+    ptrs = (c_void_p * n)(*[ctypes.cast(b, c_void_p) for b in bufs])
+    masks = (ctypes.c_uint8 * (n * t * 32))()
+    present = (ctypes.c_uint8 * n)()
+    err = ctypes.create_string_buffer(256)
+    rc = eng.lib.bpp_verify_batch_with_challenges(eng.ctx, params.handle, items, n, ptrs, _buf(b"".join(rng_outputs)),
+                                                  int(action), chunk, masks, present, err, 256)
+    _check(rc, eng.ctx, err)
+    raw = bytes(masks)
+    return [ExtendedMask.assign(t, [raw[(i * t + k) * 32:(i * t + k) * 32 + 32] for k in range(t)]) if present[i] else None
+            for i in range(n)]
+
+
 class ResidentBatch:
     """A batch kept in HBM (bpp_batch_upload / bpp_verify_resident), plus the parity trace accessors."""
 

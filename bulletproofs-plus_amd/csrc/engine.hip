@@ -182,7 +182,9 @@ struct Batch {
   uint32_t B = 0, rmax = 0, cs = 0, max_mn = 0, total_dyn = 0, sum_m = 0, cols = 0;
   std::vector<ProofDesc> desc;
   std::vector<uint8_t> rounds_bad;  // 0 ok, 3 InvalidLength, 5 SizeOverflow  (src/range_proof.rs:875-888)
-  bool any_seed = false, any_rounds_bad = false;
+  bool any_seed = false, any_rounds_bad = false, ext_challenges = false;
+  std::vector<uint32_t> ext_status;
+  DevBuf<uint32_t> d_ext_status;
   // device-resident inputs
   DevBuf<uint8_t> bytes, states, seeds;
   DevBuf<ProofDesc> d_desc;
@@ -702,9 +704,11 @@ int bpp_weights_from_chain(const uint8_t *rng32_all, size_t n_total, uint8_t *we
 }
 
 // ---------------------------------------------------------------- B2: batches
-int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, uint64_t *batch,
-                     char *errbuf, size_t errbuf_len) {
-  BPP_ENTRY(ctx);
+}  // extern "C"
+
+namespace {
+int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, uint64_t *batch,
+                const uint8_t *const *challenges32, const uint8_t *rng_out32, char *errbuf, size_t errbuf_len) {
   try {
     auto pit = ctx->params.find(params);
     if (pit == ctx->params.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle", errbuf, errbuf_len);
@@ -865,6 +869,42 @@ int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items
     B->h_rng.resize(n_items * 32);
     B->h_weights.resize(n_items * 32);
     B->h_status.resize(n_items);
+    if (challenges32) {
+      // caller-side Fiat-Shamir: challenges arrive canonical, are kept in Montgomery form like k_transcripts' output
+      if (!rng_out32) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "rng_out32 is required with external challenges"};
+      B->ext_challenges = true;
+      B->ext_status.assign(n_items, 0);
+      std::vector<sc> hc((size_t)n_items * B->cs);
+      memset(hc.data(), 0, hc.size() * sizeof(sc));
+      for (size_t i = 0; i < n_items; i++) {
+        const ProofDesc &d = B->desc[i];
+        if (!challenges32[i]) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "missing challenges for a proof"};
+        for (uint32_t k = 0; k < d.rounds + 3; k++) {
+          const uint8_t *c = challenges32[i] + 32 * (size_t)k;
+          if (!sc_is_canonical(c)) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "challenge is not canonical"};
+          sc v;
+          sc_load_words(v, c);
+          if (sc_iszero(v)) B->ext_status[i] |= BPP_ST_TRANSCRIPT_FAIL;  // transcript_protocol.rs:71-77
+          sc_to_mont(v, v);
+          hc[i * B->cs + k] = v;
+        }
+        // validate_and_append_point (transcript_protocol.rs:48-61): A, A1, B, L_j, R_j must not be the identity encoding
+        const uint8_t *pA = items[i].proof + 1 + 32 * P.t;
+        auto zero32 = [](const uint8_t *p) {
+          uint8_t r = 0;
+          for (int k = 0; k < 32; k++) r |= p[k];
+          return r == 0;
+        };
+        bool ident = zero32(pA) || zero32(pA + 32) || zero32(pA + 64);
+        for (uint32_t j = 0; j < 2 * d.rounds; j++) ident = ident || zero32(pA + 160 + 32 * j);
+        if (ident) B->ext_status[i] |= BPP_ST_TRANSCRIPT_FAIL;
+      }
+      HIP_CHECK(hipMemcpyAsync(B->chal.p, hc.data(), hc.size() * sizeof(sc), hipMemcpyHostToDevice, s));
+      memcpy(B->h_rng.data(), rng_out32, n_items * 32);
+      HIP_CHECK(hipMemcpyAsync(B->rng_out.p, rng_out32, n_items * 32, hipMemcpyHostToDevice, s));
+      B->d_ext_status.alloc(n_items);
+      HIP_CHECK(hipMemcpyAsync(B->d_ext_status.p, B->ext_status.data(), n_items * 4, hipMemcpyHostToDevice, s));
+    }
     HIP_CHECK(hipStreamSynchronize(s));
     uint64_t h = ctx->next_handle++;
     ctx->batches[h] = std::move(B);
@@ -872,6 +912,15 @@ int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items
     return BPP_OK;
   }
   BPP_CATCH(ctx, errbuf, errbuf_len)
+}
+}  // namespace
+
+extern "C" {
+
+int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, uint64_t *batch,
+                     char *errbuf, size_t errbuf_len) {
+  BPP_ENTRY(ctx);
+  return upload_impl(ctx, params, items, n_items, batch, nullptr, nullptr, errbuf, errbuf_len);
 }
 
 int bpp_batch_destroy(bpp_ctx *ctx, uint64_t batch) {
@@ -894,11 +943,16 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
     HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_rng, hipEventDisableTiming));
     ctx->ev_rng_ready = true;
   }
-  HIP_CHECK(hipMemsetAsync(b.status.p, 0, (size_t)b.B * 4, s));
-  HIP_CHECK(hipMemsetAsync(b.chal.p, 0, (size_t)b.B * b.cs * sizeof(sc), s));
-  tm.mark(M_START);
-  hipLaunchKernelGGL(k_transcripts, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.states.p,
-                     P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p);
+  if (b.ext_challenges) {  // caller did PASS 1: challenges + rng bytes are already resident
+    HIP_CHECK(hipMemcpyAsync(b.status.p, b.d_ext_status.p, (size_t)b.B * 4, hipMemcpyDeviceToDevice, s));
+    tm.mark(M_START);
+  } else {
+    HIP_CHECK(hipMemsetAsync(b.status.p, 0, (size_t)b.B * 4, s));
+    HIP_CHECK(hipMemsetAsync(b.chal.p, 0, (size_t)b.B * b.cs * sizeof(sc), s));
+    tm.mark(M_START);
+    hipLaunchKernelGGL(k_transcripts, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.states.p,
+                       P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p);
+  }
   tm.mark(M_TRANSCRIPTS);
   HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
@@ -1103,6 +1157,22 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
     return BPP_OK;
   }
   BPP_CATCH(ctx, errbuf, errbuf_len)
+}
+
+int bpp_verify_batch_with_challenges(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items,
+                                     const uint8_t *const *challenges32, const uint8_t *rng_out32, int action, size_t chunk,
+                                     uint8_t *masks_out, uint8_t *mask_present, char *errbuf, size_t errbuf_len) {
+  uint64_t h = 0;
+  int rc;
+  {
+    BPP_ENTRY(ctx);
+    if (!challenges32 || !rng_out32) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument", errbuf, errbuf_len);
+    rc = upload_impl(ctx, params, items, n_items, &h, challenges32, rng_out32, errbuf, errbuf_len);
+  }
+  if (rc != BPP_OK) return rc;
+  rc = bpp_verify_resident(ctx, h, action, chunk, masks_out, mask_present, errbuf, errbuf_len);
+  (void)bpp_batch_destroy(ctx, h);
+  return rc;
 }
 
 int bpp_verify_batch(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, int action,

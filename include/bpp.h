@@ -109,6 +109,16 @@ typedef struct {
 int bpp_verify_batch(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, int action,
                      size_t chunk, uint8_t *masks_out, uint8_t *mask_present, char *errbuf, size_t errbuf_len);
 
+/* Variant for callers that keep merlin on their side (SURVEY 8b option (i)): the Fiat-Shamir replay of PASS 1
+ * (src/range_proof.rs:816-850) is done by the caller, who passes per proof
+ *   challenges32[i] : (rounds_i + 3) x 32 canonical scalars  y, z, e_0 .. e_{rounds-1}, e_final   (:833-842)
+ *   rng_out32       : n_items x 32, the 32 bytes drawn from transcript.to_verifier_rng(...)         (:845-848)
+ * and the engine runs everything else (weight chain, decompression, PASS 2, MSM, mask recovery).  The transcript
+ * fields of the items are ignored.  Identity-encoded proof members and zero challenges are still rejected. */
+int bpp_verify_batch_with_challenges(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items,
+                                     const uint8_t *const *challenges32, const uint8_t *rng_out32, int action, size_t chunk,
+                                     uint8_t *masks_out, uint8_t *mask_present, char *errbuf, size_t errbuf_len);
+
 /* Same in two steps so a batch can stay resident in HBM: upload parses/validates/packs and copies to the device;
  * verify_resident runs only device work plus the (inherently sequential) weight chain. */
 int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, uint64_t *batch,

@@ -257,3 +257,27 @@ def test_baseline_cfg3_full_size(bpp, engine):
 def test_smoke_entry(bpp):
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+def test_verify_with_external_challenges(bpp, engine):
+    """SURVEY 8b option (i): the caller replays Merlin (here: the oracle's transcript code), the engine does the rest"""
+    c = make_batch(bpp, engine, 8, [1, 2, 1], 2, seed=b"extchal")
+    want_masks, tr = oracle_verify_trace(c, action=1)
+    chal = [[sb(y), sb(z)] + [sb(e) for e in rounds] + [sb(ef)] for (y, z, rounds, ef) in tr["challenges"]]
+    got = bpp.verify_batch_with_challenges(c.statements_private, c.proofs, chal, tr["rng_outputs"],
+                                           bpp.VerifyAction.RecoverAndVerify, chunk=0)
+    assert [m.blindings() if m else None for m in got] == want_masks
+    # a wrong challenge or a wrong rng output makes the batch fail (wrong weights alone do NOT: any weights work)
+    bad = [list(x) for x in chal]
+    bad[1][0] = sb(12345)
+    assert _kind(bpp, lambda: bpp.verify_batch_with_challenges(c.statements_public, c.proofs, bad, tr["rng_outputs"],
+                                                               bpp.VerifyAction.VerifyOnly, chunk=0)) == bpp.ProofErrorKind.VerificationFailed
+    bad[1][0] = sb(0)
+    assert _kind(bpp, lambda: bpp.verify_batch_with_challenges(c.statements_public, c.proofs, bad, tr["rng_outputs"],
+                                                               bpp.VerifyAction.VerifyOnly, chunk=0)) == bpp.ProofErrorKind.VerificationFailed
+    bad[1][0] = C.L.to_bytes(32, "little")
+    assert _kind(bpp, lambda: bpp.verify_batch_with_challenges(c.statements_public, c.proofs, bad, tr["rng_outputs"],
+                                                               bpp.VerifyAction.VerifyOnly, chunk=0)) == bpp.ProofErrorKind.InvalidArgument
+    other_rng = [hashlib.sha256(x).digest() for x in tr["rng_outputs"]]
+    assert bpp.verify_batch_with_challenges(c.statements_public, c.proofs, chal, other_rng, bpp.VerifyAction.VerifyOnly,
+                                            chunk=0) == [None] * 3
