@@ -54,6 +54,7 @@ SYMBOLS = [
     ("bpp_verify_resident", c_int, [c_void_p, c_uint64, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t]),
     ("bpp_verify_phase1", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_size_t]),
     ("bpp_weights_from_chain", c_int, [c_void_p, c_size_t, c_void_p]),
+    ("bpp_weights_from_chains", c_int, [c_void_p, c_size_t, c_size_t, c_void_p]),
     ("bpp_verify_phase2", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t]),
     ("bpp_accumulators_sum_is_identity", c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_int)]),
     ("bpp_prove_batch", c_int, [c_void_p, c_uint64, POINTER(ProveItem), c_size_t, c_void_p, c_size_t, POINTER(c_size_t),

@@ -681,6 +681,15 @@ def weights_from_chain(rng32_all):
     return bytes(out)[:32 * n]
 
 
+def weights_from_chains(rng32_all, n_groups):
+    """n_groups independent weight transcripts over equal slices of rng32_all (vectorised lockstep on the host)"""
+    n = len(rng32_all) // 32
+    assert n % n_groups == 0
+    out = (ctypes.c_uint8 * (32 * max(n, 1)))()
+    _check(_lib.load().bpp_weights_from_chains(_buf(rng32_all), n_groups, n // n_groups, out))
+    return bytes(out)[:32 * n]
+
+
 def accumulators_sum_is_identity(engine, accumulators128):
     n = len(accumulators128) // 128
     flag = c_int()

@@ -12,7 +12,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -21,6 +25,7 @@
 #include <vector>
 
 #include "../../include/bpp.h"
+#include "chain_host.h"
 #include "kernels_prove.h"
 #include "kernels_verify.h"
 #include "msm.h"
@@ -129,6 +134,8 @@ void keccak_sponge(const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen,
 void shake256(const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen) { keccak_sponge(in, inlen, out, outlen, 136, 0x1f); }
 void sha3_512(const uint8_t *in, size_t inlen, uint8_t out[64]) { keccak_sponge(in, inlen, out, 64, 72, 0x06); }
 
+void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G);
+
 // weight transcript (src/range_proof.rs:811,849,853,894)
 void weights_from_chain_host(const uint8_t *rng32, size_t n, uint8_t *weights32) {
   Strobe wt;
@@ -167,7 +174,7 @@ struct Precomp {
 
 struct MsmWork {
   DevBuf<int16_t> digits;
-  DevBuf<uint32_t> counts, starts, cursor, sorted;
+  DevBuf<uint32_t> counts, starts, sorted, order, order_hist;
   DevBuf<ge> buckets, Q, W, R;
   DevBuf<uint8_t> comp32;
   DevBuf<uint32_t> is_identity;
@@ -182,7 +189,7 @@ struct Batch {
   uint32_t B = 0, rmax = 0, cs = 0, max_mn = 0, total_dyn = 0, sum_m = 0, cols = 0;
   std::vector<ProofDesc> desc;
   std::vector<uint8_t> rounds_bad;  // 0 ok, 3 InvalidLength, 5 SizeOverflow  (src/range_proof.rs:875-888)
-  bool any_seed = false, any_rounds_bad = false, ext_challenges = false;
+  bool any_seed = false, any_rounds_bad = false, ext_challenges = false, uniform_rounds = true;
   std::vector<uint32_t> ext_status;
   DevBuf<uint32_t> d_ext_status;
   // device-resident inputs
@@ -286,8 +293,9 @@ void msm_prepare(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &sidx, co
   w.digits.alloc((size_t)n * plan.K);
   w.counts.alloc(nbk);
   w.starts.alloc(nbk);
-  w.cursor.alloc(nbk);
   w.sorted.alloc((size_t)n * plan.K);
+  w.order.alloc(nbk);
+  w.order_hist.alloc(512);
   w.buckets.alloc(nbk);
   w.Q.alloc((size_t)G * plan.K * plan.c);
   w.W.alloc((size_t)G * plan.K);
@@ -307,21 +315,25 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
   const MsmPlan plan = w.plan;
   const size_t nbk = (size_t)plan.G * plan.K * plan.nb;
   hipStream_t s = ctx->stream;
-  HIP_CHECK(hipMemsetAsync(w.counts.p, 0, nbk * 4, s));
-  HIP_CHECK(hipMemsetAsync(w.cursor.p, 0, nbk * 4, s));
   dim3 gt(cdiv(w.max_group_terms, 256), plan.G);
-  hipLaunchKernelGGL(k_msm_digits, gt, dim3(256), 0, s, scalars, w.term_sidx.p, w.group_off.p, plan, w.digits.p,
-                     w.counts.p);
+  hipLaunchKernelGGL(k_msm_digits, gt, dim3(256), 0, s, scalars, w.term_sidx.p, w.group_off.p, plan, w.digits.p);
   if (tm) tm->mark(M_DIGITS);
-  hipLaunchKernelGGL(k_scan_exclusive, dim3(plan.G), dim3(1024), 0, s, w.counts.p, w.starts.p, w.group_off.p, plan);
-  hipLaunchKernelGGL(k_msm_scatter, gt, dim3(256), 0, s, w.digits.p, w.group_off.p, plan, w.starts.p, w.cursor.p,
-                     w.sorted.p);
+  hipLaunchKernelGGL(k_msm_sort, dim3(plan.K, plan.G), dim3(1024), 2 * plan.nb * sizeof(uint32_t), s, w.digits.p, w.group_off.p,
+                     plan, w.counts.p, w.starts.p, w.sorted.p);
   if (tm) tm->mark(M_SORT);
+  HIP_CHECK(hipMemsetAsync(w.order_hist.p, 0, 512 * 4, s));
+  hipLaunchKernelGGL(k_order_hist, dim3(cdiv((uint32_t)nbk, 1024)), dim3(1024), 0, s, w.counts.p, (uint32_t)nbk, w.order_hist.p);
+  hipLaunchKernelGGL(k_order_scatter, dim3(cdiv((uint32_t)nbk, 1024)), dim3(1024), 0, s, w.counts.p, (uint32_t)nbk, w.order_hist.p,
+                     w.order_hist.p + 256, w.order.p);
   hipLaunchKernelGGL(k_msm_accumulate, dim3(cdiv((uint32_t)nbk, 64)), dim3(64), 0, s, w.sorted.p, w.starts.p,
-                     w.counts.p, w.term_pidx.p, tabs, (uint32_t)nbk, w.buckets.p);
+                     w.counts.p, w.order.p, w.term_pidx.p, tabs, (uint32_t)nbk, w.buckets.p);
   if (tm) tm->mark(M_ACC);
-  hipLaunchKernelGGL(k_msm_bitsum, dim3(plan.c, plan.K, plan.G), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.Q.p);
-  hipLaunchKernelGGL(k_msm_window, dim3(cdiv(plan.G * plan.K, 64)), dim3(64), 0, s, w.Q.p, plan, w.W.p);
+  if (plan.c <= 11) {
+    hipLaunchKernelGGL(k_msm_window_rc, dim3(plan.G * plan.K), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.W.p);
+  } else {
+    hipLaunchKernelGGL(k_msm_bitsum, dim3(plan.c, plan.K, plan.G), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.Q.p);
+    hipLaunchKernelGGL(k_msm_window, dim3(cdiv(plan.G * plan.K, 64)), dim3(64), 0, s, w.Q.p, plan, w.W.p);
+  }
   if (tm) tm->mark(M_BUCKET);
   hipLaunchKernelGGL(k_msm_final, dim3(cdiv(plan.G, 64)), dim3(64), 0, s, w.W.p, plan, w.R.p, w.comp32.p,
                      w.is_identity.p);
@@ -697,6 +709,16 @@ int bpp_transcript_new(const uint8_t *label, size_t label_len, uint8_t state203[
   return BPP_OK;
 }
 
+int bpp_weights_from_chains(const uint8_t *rng32_all, size_t n_groups, size_t n_per_group, uint8_t *weights32_out) {
+  if ((!rng32_all || !weights32_out) && n_groups * n_per_group) return BPP_ERR_INVALID_ARGUMENT;
+  if (n_groups == 0 || n_per_group == 0) return BPP_OK;
+  if (n_groups * n_per_group > (1u << 30)) return BPP_ERR_SIZE_OVERFLOW;
+  std::vector<uint32_t> first(n_groups + 1);
+  for (size_t g = 0; g <= n_groups; g++) first[g] = (uint32_t)(g * n_per_group);
+  run_weight_chains_generic(rng32_all, weights32_out, first.data(), (uint32_t)n_groups);
+  return BPP_OK;
+}
+
 int bpp_weights_from_chain(const uint8_t *rng32_all, size_t n_total, uint8_t *weights32_out) {
   if ((!rng32_all || !weights32_out) && n_total) return BPP_ERR_INVALID_ARGUMENT;
   weights_from_chain_host(rng32_all, n_total, weights32_out);
@@ -802,6 +824,7 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
       else if ((1ull << pi.rounds) != mn)
         B->rounds_bad[i] = BPP_ERR_INVALID_LENGTH;
       if (B->rounds_bad[i]) B->any_rounds_bad = true;
+      if (i && pi.rounds != B->desc[0].rounds) B->uniform_rounds = false;
       B->rmax = std::max(B->rmax, pi.rounds);
       B->max_mn = std::max(B->max_mn, (uint32_t)mn);
     }
@@ -948,7 +971,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
     tm.mark(M_START);
   } else {
     HIP_CHECK(hipMemsetAsync(b.status.p, 0, (size_t)b.B * 4, s));
-    HIP_CHECK(hipMemsetAsync(b.chal.p, 0, (size_t)b.B * b.cs * sizeof(sc), s));
+    if (!b.uniform_rounds) HIP_CHECK(hipMemsetAsync(b.chal.p, 0, (size_t)b.B * b.cs * sizeof(sc), s));  // trace padding only
     tm.mark(M_START);
     hipLaunchKernelGGL(k_transcripts, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.states.p,
                        P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p);
@@ -962,12 +985,157 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
   if (!pass1_only) {
     hipLaunchKernelGGL(k_scalars_shared, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.chal.p,
                        P.n_bits, P.t, b.cs, b.B, b.shr.p);
-    hipLaunchKernelGGL(k_scalars_lanes, dim3(b.B), dim3(64), 0, s, b.d_desc.p, b.shr.p, P.n_bits, P.t, b.max_mn, b.cols,
-                       b.B, b.rows.p, b.dyn_unw.p);
+    const uint32_t rm = std::min(b.rmax, (uint32_t)BPP_MAX_ROUNDS - 1);
+    const uint32_t nhi_max = 1u << (rm > BPP_LANES_LB ? rm - BPP_LANES_LB : 0);
+    hipLaunchKernelGGL(k_scalars_lanes, dim3(b.B), dim3(64), (BPP_LANES_FIXED + 2 * nhi_max) * sizeof(sc), s, b.d_desc.p, b.shr.p,
+                       P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, b.rows.p, b.dyn_unw.p);
     tm.mark(M_SCALARS);
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventSynchronize(ctx->ev_rng));
+}
+
+// Weight chains of all groups (src/range_proof.rs:811,849,853,894).  Chunks are independent reference batches: groups of
+// equal size run W at a time in lockstep on vector Keccak (chain_host.h), bundles are spread over host threads.
+void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G);
+void run_weight_chains(Batch &b) { run_weight_chains_generic(b.h_rng.data(), b.h_weights.data(), b.h_group_first.data(), b.G); }
+// Persistent host workers for the weight chains (spawning threads per call costs more than a 1024-proof chain).
+class HostPool {
+ public:
+  static HostPool &get() {
+    static HostPool *p = new HostPool();  // leaked on purpose: detached workers may still wait at process exit
+    return *p;
+  }
+  uint32_t size() const { return (uint32_t)workers_.size() + 1; }
+  // run fn(i) for i in [0, n) on the pool + the calling thread; returns when all are done
+  void parallel_for(uint32_t n, const std::function<void(uint32_t)> &fn) {
+    if (n == 0) return;
+    if (n == 1 || workers_.empty()) {
+      for (uint32_t i = 0; i < n; i++) fn(i);
+      return;
+    }
+    auto job = std::make_shared<Job>();
+    job->fn = &fn;
+    job->n = n;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      jobs_.push_back(job);
+    }
+    cv_.notify_all();
+    work_on(*job);
+    std::unique_lock<std::mutex> lk(job->mu);
+    job->cv.wait(lk, [&] { return job->done.load() == n; });
+    std::lock_guard<std::mutex> lk2(mu_);
+    for (auto it = jobs_.begin(); it != jobs_.end(); ++it)
+      if (it->get() == job.get()) {
+        jobs_.erase(it);
+        break;
+      }
+  }
+
+ private:
+  struct Job {
+    const std::function<void(uint32_t)> *fn;
+    uint32_t n;
+    std::atomic<uint32_t> next{0}, done{0};
+    std::mutex mu;
+    std::condition_variable cv;
+  };
+  HostPool() {
+    uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const char *e = getenv("BPP_HOST_THREADS");
+    uint32_t want = e ? (uint32_t)atoi(e) : std::min(hw, 32u);
+    want = std::max(1u, std::min(want, 256u));
+    for (uint32_t i = 1; i < want; i++) workers_.emplace_back([this] { loop(); });
+    for (auto &t : workers_) t.detach();
+  }
+  static void work_on(Job &j) {
+    for (;;) {
+      uint32_t i = j.next.fetch_add(1);
+      if (i >= j.n) return;
+      (*j.fn)(i);
+      if (j.done.fetch_add(1) + 1 == j.n) {
+        std::lock_guard<std::mutex> lk(j.mu);
+        j.cv.notify_all();
+      }
+    }
+  }
+  void loop() {
+    for (;;) {
+      std::shared_ptr<Job> job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] {
+          for (auto &j : jobs_)
+            if (j->next.load() < j->n) return true;
+          return false;
+        });
+        for (auto &j : jobs_)
+          if (j->next.load() < j->n) {
+            job = j;
+            break;
+          }
+      }
+      if (job) work_on(*job);
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::shared_ptr<Job>> jobs_;
+};
+
+void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G) {
+  static const int simd = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") ? 8
+                          : (__builtin_cpu_supports("avx2") ? 4 : 1);
+  HostPool &pool = HostPool::get();
+  // one scalar chain per worker is the fastest in wall time; lockstep vector bundles (chain_host.h) halve the CPU time
+  // per proof and are used once the groups clearly outnumber the workers
+  const uint32_t W = (G > 2 * pool.size()) ? (uint32_t)simd : 1u;
+  struct Unit {
+    uint32_t g0, cnt;
+  };
+  std::vector<Unit> units;
+  for (uint32_t g = 0; g < G;) {
+    const uint32_t n = group_first[g + 1] - group_first[g];
+    uint32_t cnt = 1;
+    while (cnt < W && g + cnt < G && group_first[g + cnt + 1] - group_first[g + cnt] == n) cnt++;
+    units.push_back({g, cnt});
+    g += cnt;
+  }
+  auto scalar_chain = [&](uint32_t g) {
+    const uint32_t p0 = group_first[g], p1 = group_first[g + 1];
+    weights_from_chain_host(h_rng + (size_t)p0 * 32, p1 - p0, h_weights + (size_t)p0 * 32);
+  };
+  std::function<void(uint32_t)> run_unit = [&](uint32_t ui) {
+    const Unit &u = units[ui];
+    uint32_t g = u.g0, left = u.cnt;
+    const size_t n = group_first[g + 1] - group_first[g];
+    while (left) {
+      uint32_t w = (left >= 8 && simd >= 8) ? 8 : ((left >= 4 && simd >= 4) ? 4 : 1);
+      if (w == 1) {
+        scalar_chain(g);
+      } else {
+        const uint8_t *in[8];
+        uint8_t *out[8];
+        for (uint32_t k = 0; k < w; k++) {
+          in[k] = h_rng + (size_t)group_first[g + k] * 32;
+          out[k] = h_weights + (size_t)group_first[g + k] * 32;
+        }
+        if (w == 8) weights_chain_x8(in, n, out);
+        else weights_chain_x4(in, n, out);
+        // Scalar::random_not_zero: a zero draw (2^-252) means the lockstep result is off from there on -> redo scalar
+        for (uint32_t k = 0; k < w; k++) {
+          bool zero = false;
+          for (size_t i = 0; i < n && !zero; i++) zero = weight_is_zero(out[k] + 32 * i);
+          if (zero) scalar_chain(g + k);
+        }
+      }
+      g += w;
+      left -= w;
+    }
+  };
+  pool.parallel_for((uint32_t)units.size(), run_unit);
 }
 
 void fetch_status(bpp_ctx *ctx, Batch &b) {
@@ -1102,23 +1270,7 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
       // weight chains: one per chunk (src/range_proof.rs:811,849,853,894); the device keeps working meanwhile
       auto c0 = std::chrono::steady_clock::now();
       if (want_msm) {
-        // chunks are independent reference batches -> their (sequential) chains run on separate host threads
-        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-        const uint32_t nthreads = std::min(std::min(b.G, hw), 64u);
-        auto run = [&](uint32_t tid) {
-          for (uint32_t g = tid; g < b.G; g += nthreads) {
-            const uint32_t p0 = b.h_group_first[g], p1 = b.h_group_first[g + 1];
-            weights_from_chain_host(&b.h_rng[(size_t)p0 * 32], p1 - p0, &b.h_weights[(size_t)p0 * 32]);
-          }
-        };
-        if (nthreads <= 1) {
-          run(0);
-        } else {
-          std::vector<std::thread> pool;
-          for (uint32_t tid = 1; tid < nthreads; tid++) pool.emplace_back(run, tid);
-          run(0);
-          for (auto &th : pool) th.join();
-        }
+        run_weight_chains(b);
       }
       chain_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c0).count();
       if (action != BPP_VERIFY_ONLY && b.any_seed) {  // masks (:941-969)

@@ -14,10 +14,15 @@
 #include <hip/hip_runtime.h>
 #define BPP_HD __host__ __device__ __forceinline__
 #define BPP_D __device__ __forceinline__
+// helpers that are called many times or sit off the critical chain: real calls keep register pressure of the callers low
+#define BPP_HD_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define BPP_HD inline
 #define BPP_D inline
+#define BPP_HD_NOINLINE inline
 #endif
+
+#define BPP_CONST static constexpr
 
 namespace bpp {
 

@@ -111,9 +111,12 @@ __global__ void __launch_bounds__(64) k_transcripts(const uint8_t *__restrict__ 
   if (!ok) atomicOr(&status[p], BPP_ST_TRANSCRIPT_FAIL);
 }
 
+#ifndef BPP_DECOMPRESS_WAVES
+#define BPP_DECOMPRESS_WAVES 1  // measured: forcing <= 128 VGPRs (4 waves) spills 2 KB/lane and is slower overall
+#endif
 // CompressedRistretto::decompress for every proof point and commitment (src/range_proof.rs:859-866,1067-1109),
 // one lane per point.  src_off[i] = byte offset in bytes[]; owner[i] = proof index | (is_commitment << 31).
-__global__ void __launch_bounds__(64) k_decompress(const uint8_t *__restrict__ bytes, const uint32_t *__restrict__ src_off,
+__global__ void __launch_bounds__(64, BPP_DECOMPRESS_WAVES) k_decompress(const uint8_t *__restrict__ bytes, const uint32_t *__restrict__ src_off,
                                                    const uint32_t *__restrict__ owner, uint32_t n,
                                                    niels *__restrict__ out, uint32_t *__restrict__ status) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,65 +330,94 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
   }
 }
 
-struct LaneShared {
-  sc e[BPP_MAX_ROUNDS], einv[BPP_MAX_ROUNDS], yinvpow[BPP_MAX_ROUNDS];
-};
+// s[i] = prod_b (bit b of i ? e_{r-1-b} : e_{r-1-b}^-1) and y^-i factor over the bits of i: both are built from two
+// small LDS tables (low LB bits, high HB bits) -> 1 product per use instead of r.
+// Dynamic LDS (sized by the batch's largest round count so small proofs keep full occupancy):
+//   slo[8] | ylo[8] | cz[32] | shi[nhi_max] | yhi[nhi_max]      (sc = 32 B each)
+// cz[party] = to_mont(e^2 * z^(2(party+1))): times the PLAIN integer 2^k gives e^2 * d[i] in Montgomery form
+#define BPP_LANES_LB 3
+#define BPP_LANES_FIXED (8 + 8 + 32)
 
 __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restrict__ desc, const sc *__restrict__ shr,
                                                       uint32_t n_bits, uint32_t t, uint32_t max_mn, uint32_t cols, uint32_t B,
-                                                      sc *__restrict__ rows, sc *__restrict__ dyn_unw) {
+                                                      uint32_t nhi_max, sc *__restrict__ rows, sc *__restrict__ dyn_unw) {
   const uint32_t p = blockIdx.x;
   if (p >= B) return;
   const uint32_t lane = threadIdx.x;
-  __shared__ LaneShared sh;
+  extern __shared__ sc lanes_lds[];
+  struct {
+    sc *slo, *ylo, *cz, *shi, *yhi;
+  } sh;
+  sh.slo = lanes_lds;
+  sh.ylo = lanes_lds + 8;
+  sh.cz = lanes_lds + 16;
+  sh.shi = lanes_lds + BPP_LANES_FIXED;
+  sh.yhi = sh.shi + nhi_max;
   const ProofDesc d = desc[p];
   const uint32_t r = d.rounds, m = d.m, mn = m * n_bits;
-  if (r > BPP_MAX_ROUNDS - 1) return;
+  if (r > BPP_MAX_ROUNDS - 1 || m > 32) return;
   const sc *S = shr + (size_t)p * SH_STRIDE;
-  if (lane < r) {
-    sh.e[lane] = S[SH_EJ(lane)];
-    sh.einv[lane] = S[SH_EINV(lane)];
-    sh.yinvpow[lane] = S[SH_YINVPOW(lane)];
-  }
-  __syncthreads();
   sc one;
   sc_mont_one(one);
+  const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, HB = r - LB;
+  const uint32_t nlo = 1u << LB, nhi = 1u << HB;
+  if (nhi > nhi_max) return;
+  // tables: entry index space [0, nlo) = slo/ylo, [nlo, nlo+nhi) = shi/yhi
+  for (uint32_t idx = lane; idx < nlo + nhi; idx += 64) {
+    const bool is_hi = idx >= nlo;
+    const uint32_t v = is_hi ? idx - nlo : idx, b0 = is_hi ? LB : 0, nbits = is_hi ? HB : LB;
+    sc sv = one, yv = one;
+    for (uint32_t bb = 0; bb < nbits; bb++) {
+      const uint32_t b = b0 + bb, j = r - 1 - b;
+      const bool bit = (v >> bb) & 1u;
+      const sc f = bit ? S[SH_EJ(j)] : S[SH_EINV(j)];
+      sc_montmul(sv, sv, f);
+      if (bit) {
+        const sc yp = S[SH_YINVPOW(b)];
+        sc_montmul(yv, yv, yp);
+      }
+    }
+    if (is_hi) {
+      sh.shi[v] = sv;
+      sh.yhi[v] = yv;
+    } else {
+      sh.slo[v] = sv;
+      sh.ylo[v] = yv;
+    }
+  }
   const sc z = S[SH_Z], z_square = S[SH_Z2], e_square = S[SH_E2], y_nm = S[SH_YNM], y_nm_1 = S[SH_YNM1];
   const sc r1_e = S[SH_R1E], s1_e = S[SH_S1E], e_square_z = S[SH_E2Z], neg_e_square = S[SH_NEG_E2];
+  if (lane < m) {
+    sc zp, r2;
+    sc_mont_pow_u32(zp, z_square, lane + 1);
+    sc_montmul(zp, zp, e_square);
+    sc_const(r2, SC_R2);
+    sc_montmul(zp, zp, r2);
+    sh.cz[lane] = zp;
+  }
+  __syncthreads();
   // generator scalars (:972-1003) without the weight
   sc *row = rows + (size_t)p * cols;
   for (uint32_t i = lane; i < max_mn; i += 64) {
     sc gi, hi;
     if (i < mn) {
-      sc s_i = one, s_rev = one, yinv_i = one;
-      for (uint32_t b = 0; b < r; b++) {
-        const uint32_t j = r - 1 - b;
-        const bool bit = (i >> b) & 1u;
-        const sc a = bit ? sh.e[j] : sh.einv[j];
-        const sc a_rev = bit ? sh.einv[j] : sh.e[j];
-        sc_montmul(s_i, s_i, a);
-        sc_montmul(s_rev, s_rev, a_rev);
-        if (bit) {
-          const sc yp = sh.yinvpow[b];
-          sc_montmul(yinv_i, yinv_i, yp);
-        }
-      }
-      sc y_nm_i;
+      const uint32_t lo = i & (nlo - 1), hi_i = i >> LB;
+      const uint32_t rlo = (~lo) & (nlo - 1), rhi = (~hi_i) & (nhi - 1);
+      sc s_i, s_rev, yinv_i, y_nm_i, u, two_k;
+      sc_montmul(s_i, sh.slo[lo], sh.shi[hi_i]);
+      sc_montmul(s_rev, sh.slo[rlo], sh.shi[rhi]);
+      sc_montmul(yinv_i, sh.ylo[lo], sh.yhi[hi_i]);
       sc_montmul(y_nm_i, y_nm, yinv_i);  // y^{mn-i}
       const uint32_t party = i / n_bits, k = i % n_bits;  // d[i] = z^{2(party+1)} * 2^k  (:919-929)
-      sc d_i = z_square;
-      for (uint32_t q = 0; q < party; q++) sc_montmul(d_i, d_i, z_square);
-      sc two_k;
-      sc_mont_from_u64(two_k, 1ULL << k);
-      sc_montmul(d_i, d_i, two_k);
-      sc u;
+      sc_0(two_k);
+      two_k.v[k >> 5] = 1u << (k & 31);
+      sc_montmul(u, sh.cz[party], two_k);  // e^2 * d[i]
+      sc_montmul(u, u, y_nm_i);
+      sc_add(u, u, e_square_z);            // e^2 (d[i] y^{mn-i} + z)
       sc_montmul(gi, r1_e, yinv_i);
       sc_montmul(gi, gi, s_i);
       sc_add(gi, gi, e_square_z);
       sc_montmul(hi, s1_e, s_rev);
-      sc_montmul(u, d_i, y_nm_i);
-      sc_add(u, u, z);
-      sc_montmul(u, u, e_square);
       sc_sub(hi, hi, u);
     } else {
       sc_0(gi);
@@ -399,8 +431,8 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
   for (uint32_t q = lane; q < ndyn; q += 64) {
     sc v;
     if (q < m) {
-      sc zp = z_square;
-      for (uint32_t jj = 0; jj < q; jj++) sc_montmul(zp, zp, z_square);
+      sc zp;
+      sc_mont_pow_u32(zp, z_square, q + 1);
       sc_montmul(v, neg_e_square, zp);
       sc_montmul(v, v, y_nm_1);
     } else if (q == m) {
@@ -421,6 +453,7 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
   }
   if (lane == 0) row[2 * max_mn + t] = S[SH_HS];
   if (lane >= 1 && lane <= t) row[2 * max_mn + (lane - 1)] = S[SH_D1(lane - 1)];
+  (void)z;
 }
 
 __global__ void k_weights_to_mont(const uint8_t *__restrict__ weights32, uint32_t B, sc *__restrict__ wm) {

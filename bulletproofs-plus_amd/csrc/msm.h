@@ -7,9 +7,9 @@
 //
 // One launch sequence serves G independent MSMs ("groups").  A term is (scalar index, point index); group g owns
 // terms [group_off[g], group_off[g+1]).  Pipeline:
-//   k_msm_digits      scalar -> K signed c-bit digits; per-bucket histogram (LDS-aggregated atomics)
-//   k_scan_exclusive  bucket start offsets
-//   k_msm_scatter     counting sort: term ids (sign in bit 31) grouped by (group, window, |digit|)
+//   k_msm_digits      scalar -> K signed c-bit digits (window-major per group)
+//   k_msm_sort        LDS-staged counting sort, one workgroup per (group, window): bucket histogram + offsets in LDS,
+//                     term ids (sign in bit 31) grouped by |digit|; no global atomics
 //   k_msm_accumulate  one lane per bucket: sum of its points (mixed additions, 7M each)
 //   k_msm_bitsum      Q[g][k][b] = sum of buckets whose digit has bit b set   (wave tree reduction in LDS)
 //   k_msm_window      W[g][k]    = sum_b 2^b Q[g][k][b]
@@ -38,19 +38,19 @@ __device__ __forceinline__ const niels *point_ptr(const PointTables &t, uint32_t
   return idx < t.n_a ? (t.tab_a + idx) : (t.tab_b + (idx - t.n_a));
 }
 
-// ---- digits + histogram.  grid = (ceil(maxGroupTerms/256), G), block 256 ----
+// ---- signed digits.  grid = (ceil(maxGroupTerms/256), G), block 256.
+// Layout digitsT[goff[g]*K + k*ng + i] (window-major inside a group): the sort kernel reads one window contiguously ----
 __global__ void __launch_bounds__(256) k_msm_digits(const sc *__restrict__ scalars, const uint32_t *__restrict__ term_sidx,
                                                     const uint32_t *__restrict__ group_off, MsmPlan plan,
-                                                    int16_t *__restrict__ digits /* [n_terms][K] */,
-                                                    uint32_t *__restrict__ counts /* [G][K][nb] */) {
+                                                    int16_t *__restrict__ digitsT) {
   const uint32_t g = blockIdx.y;
-  const uint32_t t0 = group_off[g], t1 = group_off[g + 1];
-  const uint32_t term = t0 + blockIdx.x * blockDim.x + threadIdx.x;
-  if (term >= t1) return;
-  const sc s = scalars[term_sidx[term]];
+  const uint32_t t0 = group_off[g], t1 = group_off[g + 1], ng = t1 - t0;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ng) return;
+  const sc s = scalars[term_sidx[t0 + i]];
   const uint32_t c = plan.c, K = plan.K, nb = plan.nb;
+  int16_t *out = digitsT + (size_t)t0 * K + i;
   uint32_t carry = 0;
-  uint32_t *cnt = counts + (size_t)g * K * nb;
   for (uint32_t k = 0; k < K; k++) {
     const uint32_t bit = k * c;
     const uint32_t wi = bit >> 5, sh = bit & 31;
@@ -68,28 +68,37 @@ __global__ void __launch_bounds__(256) k_msm_digits(const sc *__restrict__ scala
       dgt = (int32_t)v;
       carry = 0;
     }
-    digits[(size_t)term * K + k] = (int16_t)dgt;
-    if (dgt != 0) {
-      uint32_t mag = (uint32_t)(dgt < 0 ? -dgt : dgt);
-      atomicAdd(&cnt[(size_t)k * nb + (mag - 1)], 1u);
-    }
+    out[(size_t)k * ng] = (int16_t)dgt;
   }
 }
 
-// ---- exclusive scan of each group's bucket counts (one 1024-thread block per group); starts[] are absolute
-// positions in sorted[]: group g owns sorted[group_off[g]*K, group_off[g+1]*K) ----
-__global__ void __launch_bounds__(1024) k_scan_exclusive(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                         const uint32_t *__restrict__ group_off, MsmPlan plan) {
+// ---- LDS-staged counting sort: one workgroup per (window, group) keeps that window's bucket table in LDS.
+// Pass 1 histograms the window's digits with LDS atomics, an in-LDS scan turns counts into offsets, pass 2 scatters
+// term ids (sign in bit 31) into sorted[] -- no global atomics, no global scan.  grid = (K, G), block 1024.
+// Region of (g, k) in sorted[]: [goff[g]*K + k*ng, +ng).  Dynamic LDS: 2 * nb u32. ----
+__global__ void __launch_bounds__(1024) k_msm_sort(const int16_t *__restrict__ digitsT, const uint32_t *__restrict__ group_off,
+                                                   MsmPlan plan, uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
+                                                   uint32_t *__restrict__ sorted) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t k = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, nb = plan.nb, K = plan.K;
+  uint32_t *hist = lds, *cur = lds + nb;
   __shared__ uint32_t part[1024];
-  const uint32_t g = blockIdx.x, tid = threadIdx.x;
-  const uint32_t n = plan.K * plan.nb;
-  in += (size_t)g * n;
-  out += (size_t)g * n;
-  const uint32_t per = (n + 1023u) / 1024u;
-  const uint32_t a = tid * per < n ? tid * per : n, b = (a + per < n) ? a + per : n;
-  uint32_t s = 0;
-  for (uint32_t i = a; i < b; i++) s += in[i];
-  part[tid] = s;
+  const uint32_t t0 = group_off[g], ng = group_off[g + 1] - t0;
+  const int16_t *dg = digitsT + (size_t)t0 * K + (size_t)k * ng;
+  const uint32_t region = t0 * K + k * ng;
+  for (uint32_t j = tid; j < nb; j += 1024) hist[j] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < ng; i += 1024) {
+    const int32_t d = dg[i];
+    if (d) atomicAdd(&hist[(uint32_t)(d < 0 ? -d : d) - 1], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of hist[0..nb): thread t owns a contiguous run of `per` bins
+  const uint32_t per = (nb + 1023u) / 1024u;
+  const uint32_t a = tid * per < nb ? tid * per : nb, b = (a + per < nb) ? a + per : nb;
+  uint32_t sum = 0;
+  for (uint32_t j = a; j < b; j++) sum += hist[j];
+  part[tid] = sum;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {
     uint32_t v = (tid >= off) ? part[tid - off] : 0;
@@ -97,43 +106,77 @@ __global__ void __launch_bounds__(1024) k_scan_exclusive(const uint32_t *__restr
     part[tid] += v;
     __syncthreads();
   }
-  uint32_t run = group_off[g] * plan.K + ((tid == 0) ? 0 : part[tid - 1]);
-  for (uint32_t i = a; i < b; i++) {
-    uint32_t v = in[i];
-    out[i] = run;
-    run += v;
+  uint32_t run = (tid == 0) ? 0 : part[tid - 1];
+  const size_t bbase = ((size_t)g * K + k) * nb;
+  for (uint32_t j = a; j < b; j++) {
+    const uint32_t cnt = hist[j];
+    counts[bbase + j] = cnt;
+    starts[bbase + j] = region + run;
+    cur[j] = run;
+    run += cnt;
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < ng; i += 1024) {
+    const int32_t d = dg[i];
+    if (d) {
+      const uint32_t pos = atomicAdd(&cur[(uint32_t)(d < 0 ? -d : d) - 1], 1u);
+      sorted[region + pos] = (t0 + i) | (d < 0 ? 0x80000000u : 0u);
+    }
   }
 }
 
-// ---- counting-sort scatter.  grid = (ceil(maxGroupTerms/256), G) ----
-__global__ void __launch_bounds__(256) k_msm_scatter(const int16_t *__restrict__ digits,
-                                                     const uint32_t *__restrict__ group_off, MsmPlan plan,
-                                                     const uint32_t *__restrict__ starts, uint32_t *__restrict__ cursor,
-                                                     uint32_t *__restrict__ sorted) {
-  const uint32_t g = blockIdx.y;
-  const uint32_t t0 = group_off[g], t1 = group_off[g + 1];
-  const uint32_t term = t0 + blockIdx.x * blockDim.x + threadIdx.x;
-  if (term >= t1) return;
-  const uint32_t K = plan.K, nb = plan.nb;
-  for (uint32_t k = 0; k < K; k++) {
-    const int32_t dgt = digits[(size_t)term * K + k];
-    if (dgt == 0) continue;
-    const uint32_t mag = (uint32_t)(dgt < 0 ? -dgt : dgt);
-    const size_t bucket = ((size_t)g * K + k) * nb + (mag - 1);
-    const uint32_t pos = atomicAdd(&cursor[bucket], 1u);
-    sorted[starts[bucket] + pos] = term | (dgt < 0 ? 0x80000000u : 0u);
+// ---- order buckets by size (descending) so that the 64 lanes of a wavefront run equally long chains.
+// Counting sort over the bucket counts (clamped to 255): k_order_hist builds the global histogram with LDS-aggregated
+// atomics, k_order_scatter reserves one range per (block, size class) and writes bucket ids. ----
+__global__ void __launch_bounds__(1024) k_order_hist(const uint32_t *__restrict__ counts, uint32_t n, uint32_t *__restrict__ hist) {
+  __shared__ uint32_t h[256];
+  const uint32_t tid = threadIdx.x;
+  if (tid < 256) h[tid] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * 1024 + tid;
+  if (i < n) atomicAdd(&h[counts[i] < 255u ? counts[i] : 255u], 1u);
+  __syncthreads();
+  if (tid < 256 && h[tid]) atomicAdd(&hist[tid], h[tid]);
+}
+__global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t *__restrict__ counts, uint32_t n,
+                                                        const uint32_t *__restrict__ hist, uint32_t *__restrict__ cursor,
+                                                        uint32_t *__restrict__ order) {
+  __shared__ uint32_t h[256], base[256], start[256];
+  const uint32_t tid = threadIdx.x;
+  if (tid < 256) h[tid] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * 1024 + tid;
+  uint32_t cls = 0, local = 0;
+  if (i < n) {
+    cls = counts[i] < 255u ? counts[i] : 255u;
+    local = atomicAdd(&h[cls], 1u);
   }
+  __syncthreads();
+  if (tid == 0) {  // descending start offsets of the size classes
+    uint32_t run = 0;
+    for (int c = 255; c >= 0; c--) {
+      start[c] = run;
+      run += hist[c];
+    }
+  }
+  __syncthreads();
+  if (tid < 256 && h[tid]) base[tid] = start[tid] + atomicAdd(&cursor[tid], h[tid]);
+  __syncthreads();
+  if (i < n) order[base[cls] + local] = i;
 }
 
-// ---- bucket sums: one lane per bucket ----
+// ---- bucket sums: one lane per bucket, buckets taken in size order ----
 __global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t *__restrict__ sorted,
                                                        const uint32_t *__restrict__ starts,
                                                        const uint32_t *__restrict__ counts,
+                                                       const uint32_t *__restrict__ order,
                                                        const uint32_t *__restrict__ term_pidx, PointTables tabs,
                                                        uint32_t n_buckets, ge *__restrict__ buckets) {
-  const uint32_t bkt = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bkt >= n_buckets) return;
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_buckets) return;
+  const uint32_t bkt = order[gid];
   const uint32_t a = starts[bkt], n = counts[bkt];
+  if (n == 0) return;  // empty buckets are skipped by the reduction (counts[] == 0)
   ge acc;
   ge_identity(acc);
   for (uint32_t i = 0; i < n; i++) {
@@ -143,6 +186,69 @@ __global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t *__restric
     ge_madd(acc, acc, q);
   }
   buckets[bkt] = acc;
+}
+
+// ---- W[g][k] = sum_j j * B_j over the nb = A * Bc buckets of one window, one wavefront per (g, k).
+// With j = Bc*a + b (a in [0,A), b in [1,Bc]):  W = Bc * sum_a a*R_a + sum_b b*C_b  where R_a / C_b are the row / column
+// sums of the A x Bc bucket grid.  Lanes 0..A-1 build row sums, lanes 32..32+Bc-1 column sums (<= 32 sequential adds),
+// both weighted sums come from a parallel suffix scan + tree sum through LDS (10 add latencies).  ~2.1 adds per bucket
+// instead of (c/2) for the bit-plane method.  Requires A, Bc <= 32 (c <= 11). ----
+__global__ void __launch_bounds__(64) k_msm_window_rc(const ge *__restrict__ buckets, const uint32_t *__restrict__ counts,
+                                                      MsmPlan plan, ge *__restrict__ W) {
+  const uint32_t gk = blockIdx.x, lane = threadIdx.x;
+  const uint32_t nb = plan.nb, lb = plan.c - 1;
+  const uint32_t lBc = lb / 2, Bc = 1u << lBc, A = nb >> lBc;  // A >= Bc
+  const size_t base = (size_t)gk * nb;
+  __shared__ ge red[64];
+  ge acc;
+  ge_identity(acc);
+  const bool is_row = lane < 32;
+  const uint32_t idx = is_row ? lane : lane - 32;
+  if (is_row ? (idx < A) : (idx < Bc)) {
+    const uint32_t cnt = is_row ? Bc : A;
+    for (uint32_t q = 0; q < cnt; q++) {
+      // bucket index j-1 with j = Bc*a + b, b in [1, Bc]
+      const uint32_t j0 = is_row ? (Bc * idx + q) : (Bc * q + idx);
+      if (counts[base + j0]) {
+        const ge x = buckets[base + j0];
+        ge_add(acc, acc, x);
+      }
+    }
+  }
+  // suffix scan within each half: x[i] = sum_{i' >= i} x[i']
+  red[lane] = acc;
+  __syncthreads();
+  const uint32_t half_n = is_row ? A : Bc;
+  for (uint32_t off = 1; off < 32; off <<= 1) {
+    ge y2;
+    const bool act = idx + off < half_n;
+    if (act) y2 = red[lane + off];
+    __syncthreads();
+    if (act) {
+      ge_add(acc, acc, y2);
+      red[lane] = acc;
+    }
+    __syncthreads();
+  }
+  // rows: sum_a a*R_a = sum_{i>=1} suffix_i ; columns (b = idx+1): sum_b b*C_b = sum_{i>=0} suffix_i
+  if (is_row ? (idx == 0 || idx >= A) : (idx >= Bc)) ge_identity(acc);
+  red[lane] = acc;
+  __syncthreads();
+  for (uint32_t off = 16; off >= 1; off >>= 1) {
+    if (idx < off) {
+      ge x = red[lane], y2 = red[lane + off];
+      ge_add(x, x, y2);
+      red[lane] = x;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    ge rows = red[0];
+    const ge cols = red[32];
+    if (lBc) ge_dbl_n(rows, rows, (int)lBc);
+    ge_add(rows, rows, cols);
+    W[gk] = rows;
+  }
 }
 
 // ---- Q[g][k][b] = sum over buckets j (digit j+1) with bit b of (j+1) set.  grid = (c, K, G), block 64 ----

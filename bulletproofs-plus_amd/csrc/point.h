@@ -11,7 +11,6 @@
 
 namespace bpp {
 
-#define BPP_CONST static constexpr
 #include "field_consts.inc"
 
 BPP_HD void fe_const(fe &h, const uint32_t c[10]) {

@@ -139,6 +139,10 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
 int bpp_verify_phase1(bpp_ctx *ctx, uint64_t batch, uint8_t *rng_out32 /* n_items x 32 */, char *errbuf,
                       size_t errbuf_len);
 int bpp_weights_from_chain(const uint8_t *rng32_all, size_t n_total, uint8_t *weights32_out /* n_total x 32 */);
+/* n_groups independent weight transcripts of n_per_group proofs each (what verify_resident runs for chunk > 0): same
+ * result as n_groups calls of bpp_weights_from_chain, but the chains advance in lockstep on vector Keccak (AVX-512: 8,
+ * AVX2: 4 chains per core) and bundles are spread over host threads. */
+int bpp_weights_from_chains(const uint8_t *rng32_all, size_t n_groups, size_t n_per_group, uint8_t *weights32_out);
 int bpp_verify_phase2(bpp_ctx *ctx, uint64_t batch, const uint8_t *weights32 /* n_items x 32 */,
                       uint8_t accumulator128[128], char *errbuf, size_t errbuf_len);
 int bpp_accumulators_sum_is_identity(bpp_ctx *ctx, const uint8_t *accumulators128, size_t n, int *is_identity);

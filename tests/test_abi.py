@@ -64,3 +64,23 @@ def test_from_bytes_mirror_matches_reference_rules():
         else:
             raise AssertionError("expected ProofError")
     assert pkg.RangeProof.extension_degree_from_proof_bytes(raw) == pkg.ExtensionDegree.DefaultPedersen
+
+
+def test_vectorised_weight_chains_equal_the_scalar_chain():
+    """bpp_weights_from_chains (lockstep AVX-512 / AVX2 Keccak, threads) == per-group bpp_weights_from_chain == oracle"""
+    import hashlib
+    pkg = importlib.import_module("bulletproofs-plus_amd")
+    from oracle.pyref import curve as C
+    from oracle.pyref import merlin as M
+    from oracle.pyref import protocol as O
+    for groups, per in [(1, 5), (3, 7), (4, 9), (8, 33), (9, 4), (13, 6), (21, 3)]:
+        rng = b"".join(hashlib.sha256(b"c%d-%d" % (groups, i)).digest() for i in range(groups * per))
+        got = pkg.weights_from_chains(rng, groups)
+        want = b"".join(pkg.weights_from_chain(rng[32 * per * g:32 * per * (g + 1)]) for g in range(groups))
+        assert got == want
+    rng = b"".join(hashlib.sha256(b"o%d" % i).digest() for i in range(40))
+    wt = M.Transcript(b"Bulletproofs+ verifier weights")
+    for i in range(40):
+        wt.append_message(b"proof", rng[32 * i:32 * i + 32])
+    r = wt.build_rng().finalize(M.NullRng())
+    assert pkg.weights_from_chains(rng, 1) == b"".join(C.scalar_bytes(O.random_not_zero(r)) for _ in range(40))
