@@ -319,14 +319,14 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
   hipLaunchKernelGGL(k_msm_digits, gt, dim3(256), 0, s, scalars, w.term_sidx.p, w.group_off.p, plan, w.digits.p);
   if (tm) tm->mark(M_DIGITS);
   hipLaunchKernelGGL(k_msm_sort, dim3(plan.K, plan.G), dim3(1024), 2 * plan.nb * sizeof(uint32_t), s, w.digits.p, w.group_off.p,
-                     plan, w.counts.p, w.starts.p, w.sorted.p);
+                     w.term_pidx.p, plan, w.counts.p, w.starts.p, w.sorted.p);
   if (tm) tm->mark(M_SORT);
   HIP_CHECK(hipMemsetAsync(w.order_hist.p, 0, 512 * 4, s));
   hipLaunchKernelGGL(k_order_hist, dim3(cdiv((uint32_t)nbk, 1024)), dim3(1024), 0, s, w.counts.p, (uint32_t)nbk, w.order_hist.p);
   hipLaunchKernelGGL(k_order_scatter, dim3(cdiv((uint32_t)nbk, 1024)), dim3(1024), 0, s, w.counts.p, (uint32_t)nbk, w.order_hist.p,
                      w.order_hist.p + 256, w.order.p);
   hipLaunchKernelGGL(k_msm_accumulate, dim3(cdiv((uint32_t)nbk, 64)), dim3(64), 0, s, w.sorted.p, w.starts.p,
-                     w.counts.p, w.order.p, w.term_pidx.p, tabs, (uint32_t)nbk, w.buckets.p);
+                     w.counts.p, w.order.p, tabs, (uint32_t)nbk, w.buckets.p);
   if (tm) tm->mark(M_ACC);
   if (plan.c <= 11) {
     hipLaunchKernelGGL(k_msm_window_rc, dim3(plan.G * plan.K), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.W.p);
@@ -987,7 +987,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
                        P.n_bits, P.t, b.cs, b.B, b.shr.p);
     const uint32_t rm = std::min(b.rmax, (uint32_t)BPP_MAX_ROUNDS - 1);
     const uint32_t nhi_max = 1u << (rm > BPP_LANES_LB ? rm - BPP_LANES_LB : 0);
-    hipLaunchKernelGGL(k_scalars_lanes, dim3(b.B), dim3(64), (BPP_LANES_FIXED + 2 * nhi_max) * sizeof(sc), s, b.d_desc.p, b.shr.p,
+    hipLaunchKernelGGL(k_scalars_lanes, dim3(b.B), dim3(64), (BPP_LANES_FIXED + 3 * nhi_max) * sizeof(sc), s, b.d_desc.p, b.shr.p,
                        P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, b.rows.p, b.dyn_unw.p);
     tm.mark(M_SCALARS);
   }

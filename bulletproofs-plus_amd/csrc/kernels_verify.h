@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(64) k_from_uniform(const uint8_t *__restrict__
 #define SH_S1E 11
 #define SH_E2Z 12
 #define SH_NEG_E2 13
+#define SH_NEG_E2_YNM1 8
 #define SH_HS 14
 #define SH_D1(k) (15 + (k))
 #define SH_ARR 21
@@ -296,6 +297,11 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
   o[SH_S1E] = s1_e;
   o[SH_E2Z] = e_square_z;
   o[SH_NEG_E2] = neg_e_square;
+  {
+    sc ny;
+    sc_montmul(ny, neg_e_square, y_nm_1);
+    o[SH_NEG_E2_YNM1] = ny;
+  }
   // Pedersen h-base contribution without the weight (:1011-1017)
   sc hs;
   sc_0(hs);
@@ -330,13 +336,16 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
   }
 }
 
-// s[i] = prod_b (bit b of i ? e_{r-1-b} : e_{r-1-b}^-1) and y^-i factor over the bits of i: both are built from two
-// small LDS tables (low LB bits, high HB bits) -> 1 product per use instead of r.
+// Generator scalars without the weight.  With i = (hi << LB) | lo, s[i] = slo[lo]*shi[hi] and y^-i = ylo[lo]*yhi[hi]
+// (products over the bits of i), so every per-index quantity is ONE product of a "low" and a "high" table entry:
+//   g[i]      = r1e * y^-i * s[i]              = glo[lo]  * ghi[hi]      glo = r1e*ylo*slo,  ghi = yhi*shi
+//   y^(mn-i)  = y^mn * y^-i                    = ynlo[lo] * yhi[hi]      ynlo = y^mn*ylo
+//   h[i]      = s1e * s[mn-1-i]                = hlo[~lo] * shi[~hi]     hlo = s1e*slo
 // Dynamic LDS (sized by the batch's largest round count so small proofs keep full occupancy):
-//   slo[8] | ylo[8] | cz[32] | shi[nhi_max] | yhi[nhi_max]      (sc = 32 B each)
-// cz[party] = to_mont(e^2 * z^(2(party+1))): times the PLAIN integer 2^k gives e^2 * d[i] in Montgomery form
+//   glo[8] ynlo[8] hlo[8] | cz[32] zp[32] | ghi[nhi] yhi[nhi] shi[nhi]        (sc = 32 B each)
+// cz[party] = to_mont(e^2 * z^(2(party+1))): times the PLAIN integer 2^k it gives e^2 * d[i] in Montgomery form.
 #define BPP_LANES_LB 3
-#define BPP_LANES_FIXED (8 + 8 + 32)
+#define BPP_LANES_FIXED (3 * 8 + 64)
 
 __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restrict__ desc, const sc *__restrict__ shr,
                                                       uint32_t n_bits, uint32_t t, uint32_t max_mn, uint32_t cols, uint32_t B,
@@ -345,14 +354,8 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
   if (p >= B) return;
   const uint32_t lane = threadIdx.x;
   extern __shared__ sc lanes_lds[];
-  struct {
-    sc *slo, *ylo, *cz, *shi, *yhi;
-  } sh;
-  sh.slo = lanes_lds;
-  sh.ylo = lanes_lds + 8;
-  sh.cz = lanes_lds + 16;
-  sh.shi = lanes_lds + BPP_LANES_FIXED;
-  sh.yhi = sh.shi + nhi_max;
+  sc *glo = lanes_lds, *ynlo = lanes_lds + 8, *hlo = lanes_lds + 16, *cz = lanes_lds + 24, *zp = lanes_lds + 56;
+  sc *ghi = lanes_lds + BPP_LANES_FIXED, *yhi = ghi + nhi_max, *shi = yhi + nhi_max;
   const ProofDesc d = desc[p];
   const uint32_t r = d.rounds, m = d.m, mn = m * n_bits;
   if (r > BPP_MAX_ROUNDS - 1 || m > 32) return;
@@ -362,62 +365,69 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
   const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, HB = r - LB;
   const uint32_t nlo = 1u << LB, nhi = 1u << HB;
   if (nhi > nhi_max) return;
-  // tables: entry index space [0, nlo) = slo/ylo, [nlo, nlo+nhi) = shi/yhi
-  for (uint32_t idx = lane; idx < nlo + nhi; idx += 64) {
-    const bool is_hi = idx >= nlo;
-    const uint32_t v = is_hi ? idx - nlo : idx, b0 = is_hi ? LB : 0, nbits = is_hi ? HB : LB;
-    sc sv = one, yv = one;
-    for (uint32_t bb = 0; bb < nbits; bb++) {
-      const uint32_t b = b0 + bb, j = r - 1 - b;
-      const bool bit = (v >> bb) & 1u;
-      const sc f = bit ? S[SH_EJ(j)] : S[SH_EINV(j)];
-      sc_montmul(sv, sv, f);
-      if (bit) {
-        const sc yp = S[SH_YINVPOW(b)];
-        sc_montmul(yv, yv, yp);
+  const sc z_square = S[SH_Z2], e_square = S[SH_E2], e_square_z = S[SH_E2Z];
+  // ---- tables: one entry per lane per pass, low entries first, then high entries, then the per-party powers of z^2
+  for (uint32_t idx = lane; idx < nlo + nhi + m; idx += 64) {
+    if (idx < nlo + nhi) {
+      const bool is_hi = idx >= nlo;
+      const uint32_t v = is_hi ? idx - nlo : idx, b0 = is_hi ? LB : 0, nbits = is_hi ? HB : LB;
+      sc sv = one, yv = one;
+      for (uint32_t bb = 0; bb < nbits; bb++) {
+        const uint32_t b = b0 + bb, j = r - 1 - b;
+        const bool bit = (v >> bb) & 1u;
+        const sc f = bit ? S[SH_EJ(j)] : S[SH_EINV(j)];
+        sc_montmul(sv, sv, f);
+        if (bit) {
+          const sc yp = S[SH_YINVPOW(b)];
+          sc_montmul(yv, yv, yp);
+        }
       }
-    }
-    if (is_hi) {
-      sh.shi[v] = sv;
-      sh.yhi[v] = yv;
+      if (is_hi) {
+        sc gv;
+        sc_montmul(gv, yv, sv);
+        ghi[v] = gv;
+        yhi[v] = yv;
+        shi[v] = sv;
+      } else {
+        sc gv, yn, hv;
+        const sc r1_e = S[SH_R1E], s1_e = S[SH_S1E], y_nm = S[SH_YNM];
+        sc_montmul(gv, yv, sv);
+        sc_montmul(gv, gv, r1_e);
+        sc_montmul(yn, yv, y_nm);
+        sc_montmul(hv, sv, s1_e);
+        glo[v] = gv;
+        ynlo[v] = yn;
+        hlo[v] = hv;
+      }
     } else {
-      sh.slo[v] = sv;
-      sh.ylo[v] = yv;
+      const uint32_t party = idx - (nlo + nhi);
+      sc zz, c2, r2;
+      sc_mont_pow_u32(zz, z_square, party + 1);
+      sc_montmul(c2, zz, e_square);
+      sc_const(r2, SC_R2);
+      sc_montmul(c2, c2, r2);
+      zp[party] = zz;
+      cz[party] = c2;
     }
-  }
-  const sc z = S[SH_Z], z_square = S[SH_Z2], e_square = S[SH_E2], y_nm = S[SH_YNM], y_nm_1 = S[SH_YNM1];
-  const sc r1_e = S[SH_R1E], s1_e = S[SH_S1E], e_square_z = S[SH_E2Z], neg_e_square = S[SH_NEG_E2];
-  if (lane < m) {
-    sc zp, r2;
-    sc_mont_pow_u32(zp, z_square, lane + 1);
-    sc_montmul(zp, zp, e_square);
-    sc_const(r2, SC_R2);
-    sc_montmul(zp, zp, r2);
-    sh.cz[lane] = zp;
   }
   __syncthreads();
-  // generator scalars (:972-1003) without the weight
   sc *row = rows + (size_t)p * cols;
   for (uint32_t i = lane; i < max_mn; i += 64) {
     sc gi, hi;
     if (i < mn) {
       const uint32_t lo = i & (nlo - 1), hi_i = i >> LB;
       const uint32_t rlo = (~lo) & (nlo - 1), rhi = (~hi_i) & (nhi - 1);
-      sc s_i, s_rev, yinv_i, y_nm_i, u, two_k;
-      sc_montmul(s_i, sh.slo[lo], sh.shi[hi_i]);
-      sc_montmul(s_rev, sh.slo[rlo], sh.shi[rhi]);
-      sc_montmul(yinv_i, sh.ylo[lo], sh.yhi[hi_i]);
-      sc_montmul(y_nm_i, y_nm, yinv_i);  // y^{mn-i}
+      sc y_nm_i, u, two_k;
+      sc_montmul(gi, glo[lo], ghi[hi_i]);
+      sc_add(gi, gi, e_square_z);
+      sc_montmul(y_nm_i, ynlo[lo], yhi[hi_i]);  // y^{mn-i}
       const uint32_t party = i / n_bits, k = i % n_bits;  // d[i] = z^{2(party+1)} * 2^k  (:919-929)
       sc_0(two_k);
       two_k.v[k >> 5] = 1u << (k & 31);
-      sc_montmul(u, sh.cz[party], two_k);  // e^2 * d[i]
+      sc_montmul(u, cz[party], two_k);  // e^2 * d[i]
       sc_montmul(u, u, y_nm_i);
-      sc_add(u, u, e_square_z);            // e^2 (d[i] y^{mn-i} + z)
-      sc_montmul(gi, r1_e, yinv_i);
-      sc_montmul(gi, gi, s_i);
-      sc_add(gi, gi, e_square_z);
-      sc_montmul(hi, s1_e, s_rev);
+      sc_add(u, u, e_square_z);  // e^2 (d[i] y^{mn-i} + z)
+      sc_montmul(hi, hlo[rlo], shi[rhi]);
       sc_sub(hi, hi, u);
     } else {
       sc_0(gi);
@@ -426,34 +436,31 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     row[2 * i] = gi;
     row[2 * i + 1] = hi;
   }
-  // dynamic scalars (:1006-1015, :1022-1032) without the weight
+  // dynamic scalars (:1006-1015, :1022-1032) without the weight: v = A_q * B_q, operands picked per lane (no branches
+  // around the product): C_j: (-e^2 y^{mn+1}) * z^{2(j+1)};  A1: -e;  B: -1;  A: -e^2;  L_j: -e^2 * e_j^2;  R_j: -e^2 * e_j^-2
   const uint32_t ndyn = m + 3 + 2 * r;
   for (uint32_t q = lane; q < ndyn; q += 64) {
-    sc v;
+    sc a, bq;
     if (q < m) {
-      sc zp;
-      sc_mont_pow_u32(zp, z_square, q + 1);
-      sc_montmul(v, neg_e_square, zp);
-      sc_montmul(v, v, y_nm_1);
+      a = S[SH_NEG_E2_YNM1];
+      bq = zp[q];
     } else if (q == m) {
       const sc ef = S[SH_E];
-      sc_neg(v, ef);
+      sc_neg(a, ef);
+      bq = one;
     } else if (q == m + 1) {
-      sc_neg(v, one);
-    } else if (q == m + 2) {
-      v = neg_e_square;
-    } else if (q < m + 3 + r) {
-      const sc x = S[SH_ESQ(q - (m + 3))];
-      sc_montmul(v, neg_e_square, x);
+      sc_neg(a, one);
+      bq = one;
     } else {
-      const sc x = S[SH_ESQINV(q - (m + 3 + r))];
-      sc_montmul(v, neg_e_square, x);
+      a = S[SH_NEG_E2];
+      bq = (q == m + 2) ? one : ((q < m + 3 + r) ? S[SH_ESQ(q - (m + 3))] : S[SH_ESQINV(q - (m + 3 + r))]);
     }
+    sc v;
+    sc_montmul(v, a, bq);
     dyn_unw[d.dyn_off + q] = v;
   }
   if (lane == 0) row[2 * max_mn + t] = S[SH_HS];
   if (lane >= 1 && lane <= t) row[2 * max_mn + (lane - 1)] = S[SH_D1(lane - 1)];
-  (void)z;
 }
 
 __global__ void k_weights_to_mont(const uint8_t *__restrict__ weights32, uint32_t B, sc *__restrict__ wm) {

@@ -77,7 +77,8 @@ __global__ void __launch_bounds__(256) k_msm_digits(const sc *__restrict__ scala
 // term ids (sign in bit 31) into sorted[] -- no global atomics, no global scan.  grid = (K, G), block 1024.
 // Region of (g, k) in sorted[]: [goff[g]*K + k*ng, +ng).  Dynamic LDS: 2 * nb u32. ----
 __global__ void __launch_bounds__(1024) k_msm_sort(const int16_t *__restrict__ digitsT, const uint32_t *__restrict__ group_off,
-                                                   MsmPlan plan, uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
+                                                   const uint32_t *__restrict__ term_pidx, MsmPlan plan,
+                                                   uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
                                                    uint32_t *__restrict__ sorted) {
   extern __shared__ uint32_t lds[];
   const uint32_t k = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, nb = plan.nb, K = plan.K;
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(1024) k_msm_sort(const int16_t *__restrict__ d
     const int32_t d = dg[i];
     if (d) {
       const uint32_t pos = atomicAdd(&cur[(uint32_t)(d < 0 ? -d : d) - 1], 1u);
-      sorted[region + pos] = (t0 + i) | (d < 0 ? 0x80000000u : 0u);
+      sorted[region + pos] = term_pidx[t0 + i] | (d < 0 ? 0x80000000u : 0u);  // point index, sign in bit 31
     }
   }
 }
@@ -169,8 +170,7 @@ __global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t *__restri
 __global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t *__restrict__ sorted,
                                                        const uint32_t *__restrict__ starts,
                                                        const uint32_t *__restrict__ counts,
-                                                       const uint32_t *__restrict__ order,
-                                                       const uint32_t *__restrict__ term_pidx, PointTables tabs,
+                                                       const uint32_t *__restrict__ order, PointTables tabs,
                                                        uint32_t n_buckets, ge *__restrict__ buckets) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= n_buckets) return;
@@ -179,11 +179,18 @@ __global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t *__restric
   if (n == 0) return;  // empty buckets are skipped by the reduction (counts[] == 0)
   ge acc;
   ge_identity(acc);
+  // software pipeline: the next entry's index and point are in flight while the current addition runs
+  uint32_t e = sorted[a];
+  niels q = *point_ptr(tabs, e & 0x7fffffffu);
   for (uint32_t i = 0; i < n; i++) {
-    const uint32_t e = sorted[a + i];
-    niels q = *point_ptr(tabs, term_pidx[e & 0x7fffffffu]);
-    niels_cneg(q, (e >> 31) != 0);  // branch-free: lanes of one wave mix additions and subtractions
-    ge_madd(acc, acc, q);
+    const uint32_t e_cur = e;
+    niels q_cur = q;
+    if (i + 1 < n) {
+      e = sorted[a + i + 1];
+      q = *point_ptr(tabs, e & 0x7fffffffu);
+    }
+    niels_cneg(q_cur, (e_cur >> 31) != 0);  // branch-free: lanes of one wave mix additions and subtractions
+    ge_madd(acc, acc, q_cur);
   }
   buckets[bkt] = acc;
 }
