@@ -30,12 +30,12 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--mode", default="shard", choices=["wide", "shard"])
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--chunk", type=int, default=0, help="proofs per reference batch at N=1 (0 = whole batch)")
-    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "2")),
+    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "4")),
                     help="resident batches in flight per GPU (one engine/stream + one host thread each); a step is still "
                          "one complete verify of one batch")
     ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "32")),

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64) k_transcripts(const uint8_t *__restrict__ 
 }
 
 #ifndef BPP_DECOMPRESS_WAVES
-#define BPP_DECOMPRESS_WAVES 1  // measured: forcing <= 128 VGPRs (4 waves) spills 2 KB/lane and is slower overall
+#define BPP_DECOMPRESS_WAVES 2  // measured: forcing <= 128 VGPRs (4 waves) spills 2 KB/lane and is slower overall
 #endif
 // CompressedRistretto::decompress for every proof point and commitment (src/range_proof.rs:859-866,1067-1109),
 // one lane per point.  src_off[i] = byte offset in bytes[]; owner[i] = proof index | (is_commitment << 31).
@@ -121,11 +121,8 @@ __global__ void __launch_bounds__(64, BPP_DECOMPRESS_WAVES) k_decompress(const u
                                                    niels *__restrict__ out, uint32_t *__restrict__ status) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint8_t s[32];
-  const uint8_t *src = bytes + src_off[i];
-  for (int k = 0; k < 32; k++) s[k] = src[k];
   niels q;
-  bool ok = ristretto_decompress(q, s);
+  bool ok = ristretto_decompress_lean(q, bytes + src_off[i]);
   if (!ok) {
     niels_identity(q);
     uint32_t o = owner[i];

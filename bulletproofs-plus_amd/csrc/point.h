@@ -247,6 +247,84 @@ BPP_HD bool ristretto_decompress(niels &out, const uint8_t s_bytes[32]) {
   return ok;
 }
 
+// Same function, scheduled for registers: the 254-squaring chain runs with only (w, accumulator) live; everything the
+// epilogue needs (u1, u2, v) is RECOMPUTED from the input bytes afterwards (6 multiplications out of ~270) instead of
+// being kept alive across the chain.  The compiler barrier keeps it from merging the two computations again.
+BPP_D bool ristretto_decompress_lean(niels &out, const uint8_t *s_bytes) {
+  fe r;
+  {
+    fe s, ss, u1, u2, u2_sqr, v, t, one, d, w, v3, v7;
+    uint8_t sb[32];
+    for (int i = 0; i < 32; i++) sb[i] = s_bytes[i];
+    fe_frombytes(s, sb);
+    fe_1(one);
+    fe_sq(ss, s);
+    fe_sub(u1, one, ss);
+    fe_add(u2, one, ss);
+    fe_carry(u2);
+    fe_sq(u2_sqr, u2);
+    fe_const(d, FE_D);
+    fe_sq(t, u1);
+    fe_mul(t, t, d);
+    fe_neg(t, t);
+    fe_sub(v, t, u2_sqr);
+    fe_mul(w, v, u2_sqr);
+    // SQRT_RATIO_M1(1, w): r = w^3 * (w^7)^((p-5)/8)
+    fe_sq(v3, w);
+    fe_mul(v3, v3, w);
+    fe_sq(v7, v3);
+    fe_mul(v7, v7, w);
+    fe_pow22523(r, v7);
+    fe_mul(r, r, v3);
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::: "memory");
+#endif
+  fe s, ss, u1, u2, u2_sqr, v, t, one, d, w, check, sqrt_m1, neg_one, neg_i, rp, den_x, den_y, x, y;
+  uint8_t sb[32], chk[32];
+  for (int i = 0; i < 32; i++) sb[i] = s_bytes[i];
+  fe_frombytes(s, sb);
+  fe_tobytes(chk, s);
+  uint32_t diff = 0;
+  for (int i = 0; i < 32; i++) diff |= (uint32_t)(chk[i] ^ sb[i]);
+  bool ok = (diff == 0) && ((sb[0] & 1) == 0);
+  fe_1(one);
+  fe_sq(ss, s);
+  fe_sub(u1, one, ss);
+  fe_add(u2, one, ss);
+  fe_carry(u2);
+  fe_sq(u2_sqr, u2);
+  fe_const(d, FE_D);
+  fe_sq(t, u1);
+  fe_mul(t, t, d);
+  fe_neg(t, t);
+  fe_sub(v, t, u2_sqr);
+  fe_mul(w, v, u2_sqr);
+  fe_sq(check, r);
+  fe_mul(check, check, w);
+  fe_const(sqrt_m1, FE_SQRT_M1);
+  fe_neg(neg_one, one);
+  fe_neg(neg_i, sqrt_m1);
+  const bool correct_sign = fe_eq(check, one);
+  const bool flipped_sign = fe_eq(check, neg_one);
+  const bool flipped_sign_i = fe_eq(check, neg_i);
+  fe_mul(rp, r, sqrt_m1);
+  fe_cmov(r, rp, flipped_sign || flipped_sign_i);
+  fe_abs(r, r);
+  const bool was_square = correct_sign || flipped_sign;
+  fe_mul(den_x, r, u2);
+  fe_mul(den_y, r, den_x);
+  fe_mul(den_y, den_y, v);
+  fe_mul(x, s, den_x);
+  fe_add(x, x, x);
+  fe_abs(x, x);
+  fe_mul(y, u1, den_y);
+  fe_mul(t, x, y);
+  ok = ok && was_square && !fe_isnegative(t) && !fe_iszero(y);
+  niels_from_affine(out, x, y);
+  return ok;
+}
+
 // RFC 9496 4.3.2 Encode
 BPP_HD void ristretto_compress(uint8_t out[32], const ge &p) {
   fe u1, u2, t, one, invsqrt, den1, den2, z_inv, ix0, iy0, ench, x, y, den_inv, sqrt_m1, c, s;
