@@ -185,9 +185,14 @@ def main():
             achieved = msm_bytes / (acc_ms * 1e-3) / 1e9
             # integer roofline of the same kernel: one mixed addition per (term, window) = 7 field multiplications
             # = 700 v_mad_u64_u32; peak = 49 lanes/clk/CU x 256 CU x 2.4 GHz (tools/microbench/int_rates.hip)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath):  # PMC figure of the same kernel/workload, collected in its own rocprofv3 passes
+                tj = json.load(open(tpath))
+                traffic = tj["hbm_bytes_per_launch"] * (terms / 528448.0)
             mads = terms * K * 700.0
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                                "kernel": "k_msm_accumulate (Pippenger bucket accumulation of the final MSM)",
                                "kernel_ms": acc_ms, "algorithmic_bytes": msm_bytes, "msm_terms_per_launch": terms,
                                "note": "integer-VALU bound, not HBM bound (SURVEY 8d): see valu",

@@ -295,7 +295,7 @@ void msm_prepare(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &sidx, co
   w.starts.alloc(nbk);
   w.sorted.alloc((size_t)n * plan.K);
   w.order.alloc(nbk);
-  w.order_hist.alloc(512);
+  w.order_hist.alloc((size_t)G * 512);
   w.buckets.alloc(nbk);
   w.Q.alloc((size_t)G * plan.K * plan.c);
   w.W.alloc((size_t)G * plan.K);
@@ -321,12 +321,14 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
   hipLaunchKernelGGL(k_msm_sort, dim3(plan.K, plan.G), dim3(1024), 2 * plan.nb * sizeof(uint32_t), s, w.digits.p, w.group_off.p,
                      w.term_pidx.p, plan, w.counts.p, w.starts.p, w.sorted.p);
   if (tm) tm->mark(M_SORT);
-  HIP_CHECK(hipMemsetAsync(w.order_hist.p, 0, 512 * 4, s));
-  hipLaunchKernelGGL(k_order_hist, dim3(cdiv((uint32_t)nbk, 1024)), dim3(1024), 0, s, w.counts.p, (uint32_t)nbk, w.order_hist.p);
-  hipLaunchKernelGGL(k_order_scatter, dim3(cdiv((uint32_t)nbk, 1024)), dim3(1024), 0, s, w.counts.p, (uint32_t)nbk, w.order_hist.p,
-                     w.order_hist.p + 256, w.order.p);
-  hipLaunchKernelGGL(k_msm_accumulate, dim3(cdiv((uint32_t)nbk, 64)), dim3(64), 0, s, w.sorted.p, w.starts.p,
-                     w.counts.p, w.order.p, tabs, (uint32_t)nbk, w.buckets.p);
+  const uint32_t per_group = plan.K * plan.nb;
+  HIP_CHECK(hipMemsetAsync(w.order_hist.p, 0, (size_t)plan.G * 512 * 4, s));
+  dim3 og(cdiv(per_group, 1024), plan.G);
+  hipLaunchKernelGGL(k_order_hist, og, dim3(1024), 0, s, w.counts.p, per_group, w.order_hist.p);
+  hipLaunchKernelGGL(k_order_scatter, og, dim3(1024), 0, s, w.counts.p, per_group, w.order_hist.p,
+                     w.order_hist.p + (size_t)plan.G * 256, w.order.p);
+  hipLaunchKernelGGL(k_msm_accumulate, dim3(8 * cdiv(plan.G, 8) * cdiv(per_group, 64)), dim3(64), 0, s, w.sorted.p, w.starts.p,
+                     w.counts.p, w.order.p, tabs, per_group, plan.G, w.buckets.p);
   if (tm) tm->mark(M_ACC);
   if (plan.c <= 11) {
     hipLaunchKernelGGL(k_msm_window_rc, dim3(plan.G * plan.K), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.W.p);

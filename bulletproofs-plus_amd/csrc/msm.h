@@ -126,55 +126,67 @@ __global__ void __launch_bounds__(1024) k_msm_sort(const int16_t *__restrict__ d
   }
 }
 
-// ---- order buckets by size (descending) so that the 64 lanes of a wavefront run equally long chains.
-// Counting sort over the bucket counts (clamped to 255): k_order_hist builds the global histogram with LDS-aggregated
-// atomics, k_order_scatter reserves one range per (block, size class) and writes bucket ids. ----
-__global__ void __launch_bounds__(1024) k_order_hist(const uint32_t *__restrict__ counts, uint32_t n, uint32_t *__restrict__ hist) {
+// ---- order each group's buckets by size (descending) so that the 64 lanes of a wavefront run equally long chains,
+// while a group's buckets stay together (its ~2 MB point set is meant to live in ONE XCD's L2, see k_msm_accumulate).
+// Counting sort over the bucket counts (clamped to 255), per group: k_order_hist builds hist[g][256] with LDS-aggregated
+// atomics, k_order_scatter reserves one range per (block, size class).  grid = (ceil(K*nb/1024), G). ----
+__global__ void __launch_bounds__(1024) k_order_hist(const uint32_t *__restrict__ counts, uint32_t per_group,
+                                                     uint32_t *__restrict__ hist /* [G][256] */) {
   __shared__ uint32_t h[256];
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, g = blockIdx.y;
   if (tid < 256) h[tid] = 0;
   __syncthreads();
   const uint32_t i = blockIdx.x * 1024 + tid;
-  if (i < n) atomicAdd(&h[counts[i] < 255u ? counts[i] : 255u], 1u);
+  if (i < per_group) {
+    const uint32_t c = counts[(size_t)g * per_group + i];
+    atomicAdd(&h[c < 255u ? c : 255u], 1u);
+  }
   __syncthreads();
-  if (tid < 256 && h[tid]) atomicAdd(&hist[tid], h[tid]);
+  if (tid < 256 && h[tid]) atomicAdd(&hist[g * 256 + tid], h[tid]);
 }
-__global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t *__restrict__ counts, uint32_t n,
+__global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t *__restrict__ counts, uint32_t per_group,
                                                         const uint32_t *__restrict__ hist, uint32_t *__restrict__ cursor,
                                                         uint32_t *__restrict__ order) {
   __shared__ uint32_t h[256], base[256], start[256];
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, g = blockIdx.y;
   if (tid < 256) h[tid] = 0;
   __syncthreads();
   const uint32_t i = blockIdx.x * 1024 + tid;
   uint32_t cls = 0, local = 0;
-  if (i < n) {
-    cls = counts[i] < 255u ? counts[i] : 255u;
+  if (i < per_group) {
+    const uint32_t c = counts[(size_t)g * per_group + i];
+    cls = c < 255u ? c : 255u;
     local = atomicAdd(&h[cls], 1u);
   }
   __syncthreads();
-  if (tid == 0) {  // descending start offsets of the size classes
+  if (tid == 0) {  // descending start offsets of the size classes of this group
     uint32_t run = 0;
     for (int c = 255; c >= 0; c--) {
       start[c] = run;
-      run += hist[c];
+      run += hist[g * 256 + c];
     }
   }
   __syncthreads();
-  if (tid < 256 && h[tid]) base[tid] = start[tid] + atomicAdd(&cursor[tid], h[tid]);
+  if (tid < 256 && h[tid]) base[tid] = start[tid] + atomicAdd(&cursor[g * 256 + tid], h[tid]);
   __syncthreads();
-  if (i < n) order[base[cls] + local] = i;
+  if (i < per_group) order[(size_t)g * per_group + base[cls] + local] = g * per_group + i;
 }
 
-// ---- bucket sums: one lane per bucket, buckets taken in size order ----
+// ---- bucket sums: one lane per bucket.  XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs
+// (blockIdx % 8), so XCD x takes the groups x, x+8, x+16, ... one after the other; a group's buckets (in size order)
+// are consecutive for that XCD and its point set stays resident in that XCD's 4 MB L2 instead of being re-fetched
+// through the fabric by every wavefront.  grid = 8 * ceil(G/8) * ceil(per_group/64) blocks of 64. ----
 __global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t *__restrict__ sorted,
                                                        const uint32_t *__restrict__ starts,
                                                        const uint32_t *__restrict__ counts,
                                                        const uint32_t *__restrict__ order, PointTables tabs,
-                                                       uint32_t n_buckets, ge *__restrict__ buckets) {
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= n_buckets) return;
-  const uint32_t bkt = order[gid];
+                                                       uint32_t per_group, uint32_t G, ge *__restrict__ buckets) {
+  const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+  const uint32_t bpg = (per_group + 63u) / 64u;  // blocks per group
+  const uint32_t g = xcd + 8u * (j / bpg);
+  const uint32_t slot = (j % bpg) * 64u + threadIdx.x;
+  if (g >= G || slot >= per_group) return;
+  const uint32_t bkt = order[(size_t)g * per_group + slot];
   const uint32_t a = starts[bkt], n = counts[bkt];
   if (n == 0) return;  // empty buckets are skipped by the reduction (counts[] == 0)
   ge acc;
