@@ -431,11 +431,15 @@ class RangeProof:
         """n x RangeProof::prove_with_rng (src/range_proof.rs:232-608) in one engine call.
 
         rng_bytes[i]: the bytes the external RNG hands out for proof i, 32 per draw, (rounds + 3) draws."""
+        return RangeProof._prove_call(RangeProof._prove_marshal(transcripts, statements, witnesses, rng_bytes))
+
+    @staticmethod
+    def _prove_marshal(transcripts, statements, witnesses, rng_bytes):
+        """host checks of :248-260 + the bpp_prove_item array (ctypes marshalling, kept apart so that it can be timed apart)"""
         if not statements or len(statements) != len(witnesses) or len(transcripts) != len(statements) or \
                 len(rng_bytes) != len(statements):
             raise ProofError(ProofErrorKind.InvalidArgument, "Range statements, witnesses, transcripts length mismatch")
         params = statements[0].generators
-        eng = params.engine
         n = len(statements)
         items = (_lib.ProveItem * n)()
         keep = []
@@ -477,6 +481,12 @@ class RangeProof:
                 keep.append(lb)
                 it.transcript_label = ctypes.cast(lb, c_void_p)
                 it.label_len = len(tr.label)
+        return params, items, n, keep
+
+    @staticmethod
+    def _prove_call(marshalled, parse=True):
+        params, items, n, _keep = marshalled
+        eng = params.engine
         stride = 1 + 32 * (6 + 5 + 2 * 12)
         out = (ctypes.c_uint8 * (stride * n))()
         plen = c_size_t()
@@ -484,6 +494,8 @@ class RangeProof:
         rc = eng.lib.bpp_prove_batch(eng.ctx, params.handle, items, n, out, stride, byref(plen), err, 256)
         _check(rc, eng.ctx, err)
         raw = bytes(out)
+        if not parse:
+            return [raw[i * stride:i * stride + plen.value] for i in range(n)]
         return [RangeProof.from_bytes(raw[i * stride:i * stride + plen.value]) for i in range(n)]
 
     @staticmethod

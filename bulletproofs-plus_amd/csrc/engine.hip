@@ -164,7 +164,8 @@ struct Params {
   DevBuf<uint8_t> d_hg32;           // compressed H, G_0..G_{t-1}
   std::vector<uint8_t> hg32;        // host copy
   std::vector<uint8_t> gi32, hi32;  // compressed generators, party-major
-  DevBuf<cached> fb_table;          // prover's fixed-base window table, built on first use (table_len x 4096 x 160 B)
+  DevBuf<fbent> fb_table;           // prover's fixed-base window table, built on first use (table_len x 4096 x 128 B)
+  DevBuf<fbent> fb_ped;             // same for the Pedersen bases only [G_0..G_{t-1}, H], always resident (commit)
 };
 
 struct Precomp {
@@ -231,6 +232,10 @@ struct bpp_ctx {
   hipEvent_t ev_rng;
   bool ev_rng_ready = false;
   DevBuf<uint8_t> scratch128;
+  // batch prover: one device arena, page-locked staging and the sub-batch streams, all reused across calls
+  DevBuf<uint8_t> prove_arena;
+  PinnedBuf<uint8_t> prove_pin_in, prove_pin_out;
+  std::vector<hipStream_t> prove_streams;
 };
 
 namespace {
@@ -475,6 +480,11 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->ev_rng_ready) (void)hipEventDestroy(ctx->ev_rng);
   ctx->scratch128.release();
+  for (auto &ps : ctx->prove_streams) {
+    (void)hipStreamSynchronize(ps);
+    (void)hipStreamDestroy(ps);
+  }
+  ctx->prove_arena.release();
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -635,6 +645,11 @@ int bpp_params_create(bpp_ctx *ctx, uint32_t bit_length, uint32_t max_aggregatio
       for (int i = 0; i < 32; i++) z = z && P->hg32[(size_t)k * 32 + i] == 0;
       if (z) return fail(ctx, BPP_ERR_VERIFICATION_FAILED, "Identity element cannot be added to the transcript");
     }
+    P->fb_ped.alloc((size_t)(t + 1) * FB_STRIDE);
+    hipLaunchKernelGGL(k_fb_build, dim3(cdiv((t + 1) * FB_WINDOWS, 64)), dim3(64), 0, ctx->stream, P->table.p + n_gen, t + 1,
+                       P->fb_ped.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
     P->d_hg32.alloc(P->hg32.size());
     HIP_CHECK(hipMemcpy(P->d_hg32.p, P->hg32.data(), P->hg32.size(), hipMemcpyHostToDevice));
     uint64_t h = ctx->next_handle++;
@@ -672,32 +687,37 @@ int bpp_pedersen_commit(bpp_ctx *ctx, uint64_t params, const uint64_t *values, c
     Params &P = *it->second;
     if (n_blind == 0 || n_blind > P.t) return fail(ctx, BPP_ERR_INVALID_LENGTH, "blinding vector");
     if (count == 0) return BPP_OK;
-    // group j: value*H + sum_k r_k G_k  -> scalars [v, r_0..], points [H, G_0..] out of the params table
-    const uint32_t per = 1 + n_blind, n_gen = 2 * P.n_bits * P.m_max;
+    // output j = value*H + sum_k r_k G_k over the resident fixed-base table of the Pedersen bases
+    const uint32_t per = 1 + n_blind;
     std::vector<uint8_t> sb(count * per * 32, 0);
-    std::vector<uint32_t> sidx(count * per), pidx(count * per), goff(count + 1);
+    std::vector<uint32_t> gidx(count * per), cnt(count, per);
     for (size_t j = 0; j < count; j++) {
       uint8_t *v = &sb[(j * per) * 32];
       for (int k = 0; k < 8; k++) v[k] = (uint8_t)(values[j] >> (8 * k));
       memcpy(v + 32, blindings32 + j * n_blind * 32, (size_t)n_blind * 32);
       for (uint32_t k = 0; k < n_blind; k++)
         if (!sc_is_canonical(v + 32 + 32 * k)) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "scalar is not canonical");
-      goff[j] = (uint32_t)(j * per);
-      for (uint32_t k = 0; k < per; k++) {
-        sidx[j * per + k] = (uint32_t)(j * per + k);
-        pidx[j * per + k] = (k == 0) ? (n_gen + P.t) : (n_gen + k - 1);
-      }
+      gidx[j * per] = P.t;  // H is the last entry of fb_ped
+      for (uint32_t k = 0; k < n_blind; k++) gidx[j * per + 1 + k] = k;
     }
-    goff[count] = (uint32_t)(count * per);
     DevBuf<sc> d_sc;
+    DevBuf<uint32_t> d_g, d_c;
+    DevBuf<uint8_t> d_out;
     d_sc.alloc(count * per);
-    HIP_CHECK(hipMemcpyAsync(d_sc.p, sb.data(), sb.size(), hipMemcpyHostToDevice, ctx->stream));
-    MsmWork w;
-    msm_prepare(ctx, w, sidx, pidx, goff);
-    PointTables tabs{P.table.p, nullptr, P.table_len};
-    msm_run(ctx, w, d_sc.p, tabs, nullptr);
-    HIP_CHECK(hipMemcpyAsync(commitments32, w.comp32.p, count * 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    d_g.alloc(count * per);
+    d_c.alloc(count);
+    d_out.alloc(count * 32);
+    hipStream_t s = ctx->stream;
+    HIP_CHECK(hipMemcpyAsync(d_sc.p, sb.data(), sb.size(), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_g.p, gidx.data(), gidx.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_c.p, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, s));
+    DevBuf<ge> d_ge;
+    d_ge.alloc(count);
+    hipLaunchKernelGGL(k_fb_msm, dim3((uint32_t)count), dim3(FB_THREADS), 0, s, d_sc.p, d_g.p, d_c.p, per, P.fb_ped.p, d_ge.p);
+    hipLaunchKernelGGL(k_compress_ge, dim3(cdiv((uint32_t)count, 64)), dim3(64), 0, s, d_ge.p, (uint32_t)count, d_out.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(commitments32, d_out.p, count * 32, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
     return BPP_OK;
   }
   BPP_CATCH(ctx, nullptr, 0)
@@ -1576,74 +1596,155 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       d.state_idx = sit->second;
     }
 
-    hipStream_t s = ctx->stream;
+    hipStream_t s0 = ctx->stream;
     const uint32_t n_gen = 2 * P.n_bits * P.m_max;
     if (!P.fb_table.p) {  // fixed-base window tables for every generator of these parameters (one-off)
       P.fb_table.alloc((size_t)P.table_len * FB_STRIDE);
-      hipLaunchKernelGGL(k_fb_build, dim3(cdiv(P.table_len * FB_WINDOWS, 64)), dim3(64), 0, s, P.table.p, P.table_len, P.fb_table.p);
+      hipLaunchKernelGGL(k_fb_build, dim3(cdiv(P.table_len * FB_WINDOWS, 64)), dim3(64), 0, s0, P.table.p, P.table_len, P.fb_table.p);
       HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(s0));
+    }
+    // The batch runs as up to PROVE_SUBS sub-batches, each on its own stream: a round is lane step (one lane per proof,
+    // Fiat-Shamir latency, a handful of wavefronts) -> wave step -> fixed-base MSM (fills the chip), so one sub-batch's
+    // lane step overlaps another's MSM.  All device buffers come out of one arena allocation per call.
+    uint32_t PROVE_SUBS = 2;
+    if (const char *e = getenv("BPP_PROVE_SUBS")) PROVE_SUBS = std::max(1, std::min(16, atoi(e)));
+    const uint32_t sub_size = std::max<uint32_t>(64, cdiv(B, PROVE_SUBS));
+    const uint32_t n_sub = cdiv(B, sub_size);
+    while (ctx->prove_streams.size() < n_sub) {
+      hipStream_t ns;
+      HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+      ctx->prove_streams.push_back(ns);
     }
     const uint32_t stride = 2 * mn + t + 1;
-    DevBuf<uint8_t> d_bytes, d_states, d_minpres, d_a32, d_lr, d_a1b, d_proofs, d_commit32;
-    DevBuf<ProveDesc> d_desc;
-    DevBuf<uint64_t> d_minvals;
-    DevBuf<ProveState> d_ps;
-    DevBuf<sc> d_vec, d_ts, d_cts;
-    DevBuf<uint32_t> d_tg, d_tc, d_ctg, d_ctc;
-    d_bytes.alloc(bytes.size());
-    d_states.alloc(states.size());
-    d_minpres.alloc(minpres.size());
-    d_minvals.alloc(minvals.size());
-    d_desc.alloc(B);
-    d_ps.alloc(B);
-    d_vec.alloc((size_t)B * (5 * mn + 2));
-    d_ts.alloc((size_t)B * 2 * stride);
-    d_tg.alloc((size_t)B * 2 * stride);
-    d_tc.alloc((size_t)B * 2);
-    d_a32.alloc((size_t)B * 32);
-    d_lr.alloc((size_t)rounds * B * 64);
-    d_a1b.alloc((size_t)B * 64);
-    d_proofs.alloc((size_t)B * plen);
-    d_commit32.alloc((size_t)B * m * 32);
-    d_cts.alloc((size_t)B * m * (1 + t));
-    d_ctg.alloc((size_t)B * m * (1 + t));
-    d_ctc.alloc((size_t)B * m);
-    HIP_CHECK(hipMemcpyAsync(d_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(d_states.p, states.data(), states.size(), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(d_minpres.p, minpres.data(), minpres.size(), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(d_minvals.p, minvals.data(), minvals.size() * 8, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(d_desc.p, desc.data(), (size_t)B * sizeof(ProveDesc), hipMemcpyHostToDevice, s));
-    const dim3 lane_grid(cdiv(B, 64)), b64(64);
-    // witness check (:275-284): commit(v_j, r_j) for every opening, compared with the statement's commitments
-    hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(B * m, 64)), b64, 0, s, d_bytes.p, d_desc.p, t, n_gen, B, m, 1 + t, d_cts.p,
-                       d_ctg.p, d_ctc.p);
-    hipLaunchKernelGGL(k_fb_msm, dim3(B * m), b64, 0, s, d_cts.p, d_ctg.p, d_ctc.p, 1 + t, P.fb_table.p, d_commit32.p);
-    hipLaunchKernelGGL(kp_init, lane_grid, b64, 0, s, d_bytes.p, d_desc.p, d_minvals.p, d_states.p, P.d_hg32.p, n, t, B, d_ps.p);
-    hipLaunchKernelGGL(kp_check_commitments, lane_grid, b64, 0, s, d_bytes.p, d_desc.p, d_commit32.p, B, d_ps.p);
-    hipLaunchKernelGGL(kp_A, dim3(B), b64, 0, s, d_bytes.p, d_desc.p, d_minvals.p, d_minpres.p, P.table.p, P.fb_table.p, n_gen, n, t,
-                       d_ps.p, d_a32.p);
-    for (uint32_t j = 0; j <= rounds; j++) {
-      const uint8_t *lr_prev = j ? d_lr.p + (size_t)(j - 1) * B * 64 : nullptr;
-      hipLaunchKernelGGL(kp_lane, lane_grid, b64, 0, s, d_bytes.p, d_desc.p, n, t, B, j, rounds, d_a32.p, lr_prev, d_ps.p);
-      hipLaunchKernelGGL(kp_wave, dim3(B), b64, 0, s, d_bytes.p, d_desc.p, d_minvals.p, d_minpres.p, n, t, n_gen, j, rounds, stride,
-                         d_ps.p, d_vec.p, d_ts.p, d_tg.p, d_tc.p);
-      uint8_t *out = (j < rounds) ? d_lr.p + (size_t)j * B * 64 : d_a1b.p;
-      hipLaunchKernelGGL(k_fb_msm, dim3(2 * B), b64, 0, s, d_ts.p, d_tg.p, d_tc.p, stride, P.fb_table.p, out);
+    struct Sub {
+      uint32_t lo, nb;
+      size_t bytes_lo, bytes_len, arena_lo, arena_len;
+      uint8_t *d_bytes, *d_states, *d_minpres, *d_a32, *d_lr, *d_a1b, *d_proofs, *d_commit32;
+      ProveDesc *d_desc;
+      uint64_t *d_minvals;
+      ProveState *d_ps;
+      sc *d_vec, *d_ts, *d_cts;
+      uint32_t *d_tg, *d_tc, *d_ctg, *d_ctc;
+      ge *d_ge;
+    };
+    std::vector<Sub> subs(n_sub);
+    size_t arena_need = 0;
+    uint8_t *arena_base = nullptr;
+    auto take = [&](size_t nbytes) {
+      arena_need = (arena_need + 255) & ~(size_t)255;
+      uint8_t *p = arena_base ? arena_base + arena_need : nullptr;
+      arena_need += nbytes;
+      return p;
+    };
+    auto carve = [&]() {
+      arena_need = 0;
+      for (uint32_t q = 0; q < n_sub; q++) {
+        Sub &u = subs[q];
+        u.lo = q * sub_size;
+        u.nb = std::min(sub_size, B - u.lo);
+        u.bytes_lo = desc[u.lo].wit_off;
+        u.bytes_len = (u.lo + u.nb < B ? desc[u.lo + u.nb].wit_off : bytes.size()) - u.bytes_lo;
+        const size_t nb = u.nb;
+        arena_need = (arena_need + 255) & ~(size_t)255;
+        u.arena_lo = arena_need;
+        u.d_bytes = take(u.bytes_len);
+        u.d_states = take(states.size());
+        u.d_minpres = take(nb * m);
+        u.d_minvals = (uint64_t *)take(nb * m * 8);
+        u.d_desc = (ProveDesc *)take(nb * sizeof(ProveDesc));
+        u.d_ps = (ProveState *)take(nb * sizeof(ProveState));
+        u.d_vec = (sc *)take(nb * (5 * (size_t)mn + 2) * sizeof(sc));
+        u.d_ts = (sc *)take(nb * 2 * stride * sizeof(sc));
+        u.d_tg = (uint32_t *)take(nb * 2 * stride * 4);
+        u.d_tc = (uint32_t *)take(nb * 2 * 4);
+        u.d_a32 = take(nb * 32);
+        u.d_lr = take((size_t)rounds * nb * 64);
+        u.d_a1b = take(nb * 64);
+        u.d_proofs = take(nb * plen);
+        u.d_commit32 = take(nb * m * 32);
+        u.d_cts = (sc *)take(nb * m * (1 + t) * sizeof(sc));
+        u.d_ctg = (uint32_t *)take(nb * m * (1 + t) * 4);
+        u.d_ctc = (uint32_t *)take(nb * m * 4);
+        u.d_ge = (ge *)take(std::max<size_t>(nb * m, 2 * nb) * sizeof(ge));
+        u.arena_len = arena_need - u.arena_lo;
+      }
+    };
+    carve();
+    ctx->prove_arena.alloc(arena_need + 256);
+    arena_base = ctx->prove_arena.p;
+    carve();
+    // descriptors are relative to each sub-batch's own byte block / minimum-value rows
+    for (uint32_t q = 0; q < n_sub; q++)
+      for (uint32_t i = 0; i < subs[q].nb; i++) {
+        ProveDesc &d = desc[subs[q].lo + i];
+        d.wit_off -= (uint32_t)subs[q].bytes_lo;
+        d.commit_off -= (uint32_t)subs[q].bytes_lo;
+        d.ext_off -= (uint32_t)subs[q].bytes_lo;
+        d.seed_off -= (uint32_t)subs[q].bytes_lo;
+        d.minval_idx = i * m;
+      }
+    // page-locked staging so that no copy stalls the enqueue of the next sub-batch
+    const size_t in_need = bytes.size() + states.size() + minpres.size() + minvals.size() * 8 + (size_t)B * sizeof(ProveDesc) + 64;
+    ctx->prove_pin_in.resize(in_need);
+    ctx->prove_pin_out.resize((size_t)B * plen + (size_t)B * sizeof(ProveState) + 64);
+    uint8_t *pin = ctx->prove_pin_in.p;
+    uint8_t *pin_bytes = pin;
+    memcpy(pin_bytes, bytes.data(), bytes.size());
+    uint8_t *pin_states = pin_bytes + bytes.size();
+    memcpy(pin_states, states.data(), states.size());
+    uint8_t *pin_minpres = pin_states + states.size();
+    memcpy(pin_minpres, minpres.data(), minpres.size());
+    uint8_t *pin_minvals = pin_minpres + ((minpres.size() + 7) & ~(size_t)7);
+    memcpy(pin_minvals, minvals.data(), minvals.size() * 8);
+    uint8_t *pin_desc = pin_minvals + minvals.size() * 8;
+    memcpy(pin_desc, desc.data(), (size_t)B * sizeof(ProveDesc));
+    uint8_t *pin_proofs = ctx->prove_pin_out.p;
+    ProveState *pin_ps = (ProveState *)(pin_proofs + (((size_t)B * plen + 15) & ~(size_t)15));
+
+    const dim3 b64(64);
+    for (uint32_t q = 0; q < n_sub; q++) {
+      Sub &u = subs[q];
+      hipStream_t s = ctx->prove_streams[q];
+      const uint32_t nb = u.nb;
+      const dim3 lane_grid(cdiv(nb, 64));
+      HIP_CHECK(hipMemcpyAsync(u.d_bytes, pin_bytes + u.bytes_lo, u.bytes_len, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(u.d_states, pin_states, states.size(), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(u.d_minpres, pin_minpres + (size_t)u.lo * m, (size_t)nb * m, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(u.d_minvals, pin_minvals + (size_t)u.lo * m * 8, (size_t)nb * m * 8, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(u.d_desc, pin_desc + (size_t)u.lo * sizeof(ProveDesc), (size_t)nb * sizeof(ProveDesc),
+                               hipMemcpyHostToDevice, s));
+      // witness check (:275-284): commit(v_j, r_j) for every opening, compared with the statement's commitments
+      hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_bytes, u.d_desc, t, n_gen, nb, m, 1 + t, u.d_cts,
+                         u.d_ctg, u.d_ctc);
+      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(FB_THREADS), 0, s, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, u.d_ge);
+      hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_ge, nb * m, u.d_commit32);
+      hipLaunchKernelGGL(kp_init, lane_grid, b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_states, P.d_hg32.p, n, t, nb, u.d_ps);
+      hipLaunchKernelGGL(kp_check_commitments, lane_grid, b64, 0, s, u.d_bytes, u.d_desc, u.d_commit32, nb, u.d_ps);
+      hipLaunchKernelGGL(kp_A, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, P.table.p, P.fb_table.p, n_gen, n,
+                         t, u.d_ps, u.d_a32);
+      for (uint32_t j = 0; j <= rounds; j++) {
+        const uint8_t *lr_prev = j ? u.d_lr + (size_t)(j - 1) * nb * 64 : nullptr;
+        hipLaunchKernelGGL(kp_lane, lane_grid, b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
+        hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
+                           stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
+        uint8_t *out = (j < rounds) ? u.d_lr + (size_t)j * nb * 64 : u.d_a1b;
+        hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(FB_THREADS), 0, s, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, u.d_ge);
+        hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);
+      }
+      hipLaunchKernelGGL(kp_finish, lane_grid, b64, 0, s, u.d_desc, n, t, nb, rounds, u.d_a32, u.d_lr, u.d_a1b, u.d_vec, u.d_ps,
+                         u.d_proofs, (uint32_t)plen);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(pin_proofs + (size_t)u.lo * plen, u.d_proofs, (size_t)nb * plen, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(pin_ps + u.lo, u.d_ps, (size_t)nb * sizeof(ProveState), hipMemcpyDeviceToHost, s));
+      // zeroize the device copies of witness-derived data (the reference uses Zeroizing<> for these)
+      HIP_CHECK(hipMemsetAsync(arena_base + u.arena_lo, 0, u.arena_len, s));
     }
-    hipLaunchKernelGGL(kp_finish, lane_grid, b64, 0, s, d_desc.p, n, t, B, rounds, d_a32.p, d_lr.p, d_a1b.p, d_vec.p, d_ps.p,
-                       d_proofs.p, (uint32_t)plen);
-    HIP_CHECK(hipGetLastError());
-    std::vector<uint8_t> h_proofs((size_t)B * plen);
-    std::vector<ProveState> h_ps(B);
-    HIP_CHECK(hipMemcpyAsync(h_proofs.data(), d_proofs.p, h_proofs.size(), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipMemcpyAsync(h_ps.data(), d_ps.p, (size_t)B * sizeof(ProveState), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    // zeroize the device copies of witness-derived data (the reference uses Zeroizing<> for these)
-    HIP_CHECK(hipMemsetAsync(d_bytes.p, 0, bytes.size(), s));
-    HIP_CHECK(hipMemsetAsync(d_vec.p, 0, (size_t)B * (5 * mn + 2) * sizeof(sc), s));
-    HIP_CHECK(hipMemsetAsync(d_ps.p, 0, (size_t)B * sizeof(ProveState), s));
-    HIP_CHECK(hipMemsetAsync(d_ts.p, 0, (size_t)B * 2 * stride * sizeof(sc), s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    for (uint32_t q = 0; q < n_sub; q++) HIP_CHECK(hipStreamSynchronize(ctx->prove_streams[q]));
+    memset(pin, 0, in_need);
+    const std::vector<ProveState> h_ps(pin_ps, pin_ps + B);
+    const uint8_t *h_proofs = pin_proofs;
+    memset((void *)pin_ps, 0, (size_t)B * sizeof(ProveState));
     for (uint32_t i = 0; i < B; i++) {
       if (h_ps[i].status & PV_STATUS_COMMIT_MISMATCH) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Witness opening is invalid!"};
       if (h_ps[i].status & PV_STATUS_TRANSCRIPT)

@@ -16,13 +16,19 @@
 namespace bpp {
 
 // ---------------------------------------------------------------- fixed-base tables
-struct cached {  // projective niels
-  fe yplusx, yminusx, z, t2d;
+// One table entry = one affine Niels point padded to a full 128-byte line: a lookup is exactly one aligned line
+// (a 160-byte projective entry straddles two), and the mixed addition costs 7 multiplications instead of 8.
+struct alignas(128) fbent {
+  niels q;
+  uint32_t pad[2];
 };
 #define FB_WINDOWS 32
 #define FB_ENTRIES 128
 #define FB_STRIDE (FB_WINDOWS * FB_ENTRIES)  // entries per generator
 
+struct cached {  // projective niels (table construction only)
+  fe yplusx, yminusx, z, t2d;
+};
 BPP_HD void ge_to_cached(cached &r, const ge &p) {
   fe d2;
   fe_add(r.yplusx, p.Y, p.X);
@@ -34,21 +40,14 @@ BPP_HD void ge_to_cached(cached &r, const ge &p) {
   fe_mul(r.t2d, p.T, d2);
 }
 
-// r = p + (neg ? -q : q), q projective niels: 8 mul
-BPP_HD void ge_add_cached(ge &r, const ge &p, const cached &q, bool neg) {
-  fe a, b, c, d, e, f, g, h, qa, qb, qt, nt;
-  fe_neg(nt, q.t2d);
-#pragma unroll
-  for (int i = 0; i < 10; i++) {
-    qa.v[i] = neg ? q.yminusx.v[i] : q.yplusx.v[i];
-    qb.v[i] = neg ? q.yplusx.v[i] : q.yminusx.v[i];
-    qt.v[i] = neg ? nt.v[i] : q.t2d.v[i];
-  }
+// r = p + q, q projective niels: 8 mul
+BPP_HD void ge_add_cached(ge &r, const ge &p, const cached &q) {
+  fe a, b, c, d, e, f, g, h;
   fe_add(a, p.Y, p.X);
   fe_sub(b, p.Y, p.X);
-  fe_mul(a, a, qa);
-  fe_mul(b, b, qb);
-  fe_mul(c, qt, p.T);
+  fe_mul(a, a, q.yplusx);
+  fe_mul(b, b, q.yminusx);
+  fe_mul(c, q.t2d, p.T);
   fe_mul(d, p.Z, q.z);
   fe_add(d, d, d);
   fe_sub(e, a, b);
@@ -62,8 +61,9 @@ BPP_HD void ge_add_cached(ge &r, const ge &p, const cached &q, bool neg) {
   fe_mul(r.T, e, h);
 }
 
-// one lane per (generator, window): entries d * 2^(8w) * P, d = 1..128
-__global__ void __launch_bounds__(64) k_fb_build(const niels *__restrict__ gens, uint32_t n_gens, cached *__restrict__ tbl) {
+// one lane per (generator, window): entries d * 2^(8w) * P, d = 1..128, normalised to affine (one inversion each;
+// the table is built once per parameter set)
+__global__ void __launch_bounds__(64) k_fb_build(const niels *__restrict__ gens, uint32_t n_gens, fbent *__restrict__ tbl) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_gens * FB_WINDOWS) return;
   const uint32_t g = i / FB_WINDOWS, w = i % FB_WINDOWS;
@@ -75,55 +75,114 @@ __global__ void __launch_bounds__(64) k_fb_build(const niels *__restrict__ gens,
   cached cb;
   ge_to_cached(cb, base);
   ge acc = base;
-  cached *out = tbl + ((size_t)g * FB_WINDOWS + w) * FB_ENTRIES;
+  fbent *out = tbl + ((size_t)g * FB_WINDOWS + w) * FB_ENTRIES;
   for (uint32_t d = 0; d < FB_ENTRIES; d++) {
-    cached c;
-    ge_to_cached(c, acc);
-    out[d] = c;
-    if (d + 1 < FB_ENTRIES) ge_add_cached(acc, acc, cb, false);
+    fe zi, x, y;
+    fe_invert(zi, acc.Z);
+    fe_mul(x, acc.X, zi);
+    fe_mul(y, acc.Y, zi);
+    niels e;
+    niels_from_affine(e, x, y);
+    fe_carry(e.yminusx);
+    out[d].q = e;
+    if (d + 1 < FB_ENTRIES) ge_add_cached(acc, acc, cb);
   }
 }
 
-// out[o] = sum_i scal[o][i] * Gen[gidx[o][i]], i < count[o]; one wavefront per output; result compressed.
-// scal: canonical scalars, row stride `stride`; gidx rows likewise.
-__global__ void __launch_bounds__(64) k_fb_msm(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx,
-                                               const uint32_t *__restrict__ count, uint32_t stride,
-                                               const cached *__restrict__ tbl, uint8_t *__restrict__ out32) {
-  const uint32_t o = blockIdx.x, lane = threadIdx.x;
+// out[o] = sum_i scal[o][i] * Gen[gidx[o][i]], i < count[o]; one workgroup of FB_THREADS lanes per output.
+// scal: canonical scalars, row stride `stride`; gidx rows likewise.  Result left in extended coordinates (k_compress_ge
+// turns a whole launch's outputs into bytes, one lane each, instead of one busy lane per workgroup here).
+//   phase 1 (per chunk of FB_CHUNK terms): recode scalars to signed 8-bit digits in LDS (digit in [-127, 128], 0x80 = +128)
+//   phase 2: flat (term, window) work items, stride FB_THREADS -> every lane gets the same number of additions; the table
+//            line of item k+1 is requested before item k is added.
+#define FB_THREADS 256
+#define FB_CHUNK 512
+struct FbStage {
+  uint32_t dig[FB_CHUNK * 8];  // 32 digits per term, 4 per word
+  uint32_t gi[FB_CHUNK];
+};
+union FbShared {
+  ge red[FB_THREADS];
+  FbStage st;
+};
+
+BPP_D void fb_fetch(niels &q, int &d, const FbStage &st, const fbent *__restrict__ tbl, uint32_t it) {
+  const uint32_t i = it >> 5, w = it & 31u;
+  const uint32_t byte = (st.dig[i * 8 + (w >> 2)] >> (8 * (w & 3))) & 0xffu;
+  d = byte == 0x80u ? 128 : (int)(int8_t)byte;
+  const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+  q = tbl[(size_t)st.gi[i] * FB_STRIDE + (size_t)w * FB_ENTRIES + (mag ? mag - 1u : 0u)].q;
+}
+
+__global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx,
+                                                       const uint32_t *__restrict__ count, uint32_t stride,
+                                                       const fbent *__restrict__ tbl, ge *__restrict__ out) {
+  const uint32_t o = blockIdx.x, tid = threadIdx.x;
   const uint32_t n = count[o];
-  __shared__ ge red[64];
+  __shared__ FbShared sh;
   ge acc;
   ge_identity(acc);
-  for (uint32_t i = lane; i < n; i += 64) {
-    const sc s = scal[(size_t)o * stride + i];
-    const cached *row = tbl + (size_t)gidx[(size_t)o * stride + i] * FB_STRIDE;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < FB_WINDOWS; w++) {
-      uint32_t v = ((s.v[w >> 2] >> (8 * (w & 3))) & 0xffu) + carry;
-      bool neg = v > 128u;
-      uint32_t mag = neg ? 256u - v : v;
-      carry = neg ? 1u : 0u;
-      if (mag) {
-        const cached c = row[(size_t)w * FB_ENTRIES + (mag - 1)];
-        ge_add_cached(acc, acc, c, neg);
+  for (uint32_t base = 0; base < n; base += FB_CHUNK) {
+    const uint32_t cn = n - base < FB_CHUNK ? n - base : FB_CHUNK;
+    __syncthreads();  // the previous chunk's digits are no longer read
+    for (uint32_t i = tid; i < cn; i += FB_THREADS) {
+      const sc s = scal[(size_t)o * stride + base + i];
+      uint32_t carry = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+          const uint32_t v = ((s.v[j] >> (8 * k)) & 0xffu) + carry;  // 0..256
+          carry = v > 128u ? 1u : 0u;                                // digit = v - 256 * carry
+          packed |= (v & 0xffu) << (8 * k);
+        }
+        sh.st.dig[i * 8 + j] = packed;
+      }
+      // canonical scalars are < 2^253: the top digit never carries out
+      sh.st.gi[i] = gidx[(size_t)o * stride + base + i];
+    }
+    __syncthreads();
+    const uint32_t items = cn * 32;
+    uint32_t it = tid;
+    niels nxt;
+    int nd = 0;
+    if (it < items) fb_fetch(nxt, nd, sh.st, tbl, it);
+    while (it < items) {
+      niels cur = nxt;
+      const int cd = nd;
+      it += FB_THREADS;
+      if (it < items) fb_fetch(nxt, nd, sh.st, tbl, it);
+      if (cd != 0) {
+        niels_cneg(cur, cd < 0);
+        ge_madd(acc, acc, cur);
       }
     }
   }
-  red[lane] = acc;
   __syncthreads();
-  for (uint32_t off = 32; off >= 1; off >>= 1) {
-    if (lane < off) {
-      ge x = red[lane], y2 = red[lane + off];
+  sh.red[tid] = acc;
+  __syncthreads();
+  for (uint32_t off = FB_THREADS / 2; off >= 1; off >>= 1) {
+    if (tid < off) {
+      ge x = sh.red[tid], y2 = sh.red[tid + off];
       ge_add(x, x, y2);
-      red[lane] = x;
+      sh.red[tid] = x;
     }
     __syncthreads();
   }
-  if (lane == 0) {
-    uint8_t c32[32];
-    ristretto_compress(c32, red[0]);
-    for (int k = 0; k < 32; k++) out32[(size_t)o * 32 + k] = c32[k];
-  }
+  if (tid == 0) out[o] = sh.red[0];
+}
+
+// one lane per point: extended coordinates -> 32-byte Ristretto encoding
+__global__ void __launch_bounds__(64) k_compress_ge(const ge *__restrict__ in, uint32_t count, uint8_t *__restrict__ out32) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint8_t c32[32];
+  ristretto_compress(c32, in[i]);
+  uint32_t *o = (uint32_t *)(out32 + (size_t)i * 32);
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    o[k] = (uint32_t)c32[4 * k] | ((uint32_t)c32[4 * k + 1] << 8) | ((uint32_t)c32[4 * k + 2] << 16) | ((uint32_t)c32[4 * k + 3] << 24);
 }
 
 // ---------------------------------------------------------------- per-proof prover state
@@ -221,7 +280,7 @@ __global__ void __launch_bounds__(64) kp_init(const uint8_t *__restrict__ bytes,
 // a_L/a_R are never materialised as scalars here: they are 0/1 and 0/-1.
 __global__ void __launch_bounds__(64) kp_A(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
                                            const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present,
-                                           const niels *__restrict__ gens, const cached *__restrict__ tbl, uint32_t n_gen,
+                                           const niels *__restrict__ gens, const fbent *__restrict__ tbl, uint32_t n_gen,
                                            uint32_t n_bits, uint32_t t, const ProveState *__restrict__ ps,
                                            uint8_t *__restrict__ a_out32) {
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
@@ -244,7 +303,7 @@ __global__ void __launch_bounds__(64) kp_A(const uint8_t *__restrict__ bytes, co
   if (lane < t) {  // alpha_k * G_k through the fixed-base table
     sc s;
     sc_from_mont(s, ps[p].alpha[lane]);
-    const cached *row = tbl + (size_t)(n_gen + lane) * FB_STRIDE;
+    const fbent *row = tbl + (size_t)(n_gen + lane) * FB_STRIDE;
     uint32_t carry = 0;
     for (uint32_t w = 0; w < FB_WINDOWS; w++) {
       uint32_t v = ((s.v[w >> 2] >> (8 * (w & 3))) & 0xffu) + carry;
@@ -252,8 +311,9 @@ __global__ void __launch_bounds__(64) kp_A(const uint8_t *__restrict__ bytes, co
       uint32_t mag = neg ? 256u - v : v;
       carry = neg ? 1u : 0u;
       if (mag) {
-        const cached c = row[(size_t)w * FB_ENTRIES + (mag - 1)];
-        ge_add_cached(acc, acc, c, neg);
+        niels c = row[(size_t)w * FB_ENTRIES + (mag - 1)].q;
+        niels_cneg(c, neg);
+        ge_madd(acc, acc, c);
       }
     }
   }
