@@ -8,8 +8,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbpp_hip.so")
 HOSTTEST_LIB = os.path.join(HERE, "libbpp_hosttest.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["field.h", "scalar.h", "point.h", "merlin.h", "blake2b.h", "kernels_verify.h", "msm.h",
-           "field_consts.inc", "scalar_consts.inc", os.path.join("..", "..", "include", "bpp.h")]
+# every header / include file next to the sources is a dependency (a stale .so after a header-only edit is a silent trap)
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join("..", "..", "include", "bpp.h")]
 
 
 def _stale(target, deps):

@@ -1719,13 +1719,13 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
                          u.d_ctg, u.d_ctc);
       hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(FB_THREADS), 0, s, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, u.d_ge);
       hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_ge, nb * m, u.d_commit32);
-      hipLaunchKernelGGL(kp_init, lane_grid, b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_states, P.d_hg32.p, n, t, nb, u.d_ps);
+      hipLaunchKernelGGL(kp_init, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_states, P.d_hg32.p, n, t, nb, u.d_ps);
       hipLaunchKernelGGL(kp_check_commitments, lane_grid, b64, 0, s, u.d_bytes, u.d_desc, u.d_commit32, nb, u.d_ps);
       hipLaunchKernelGGL(kp_A, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, P.table.p, P.fb_table.p, n_gen, n,
                          t, u.d_ps, u.d_a32);
       for (uint32_t j = 0; j <= rounds; j++) {
         const uint8_t *lr_prev = j ? u.d_lr + (size_t)(j - 1) * nb * 64 : nullptr;
-        hipLaunchKernelGGL(kp_lane, lane_grid, b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
+        hipLaunchKernelGGL(kp_lane, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
         hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
                            stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
         uint8_t *out = (j < rounds) ? u.d_lr + (size_t)j * nb * 64 : u.d_a1b;

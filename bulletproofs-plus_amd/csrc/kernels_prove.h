@@ -12,6 +12,7 @@
 // All scalars are Montgomery form in HBM; canonical only in MSM inputs, transcript bytes and the proof.
 #pragma once
 #include "kernels_verify.h"
+#include "wstrobe.h"
 
 namespace bpp {
 
@@ -243,37 +244,88 @@ __device__ __forceinline__ bool pv_validate_append(Strobe &tr, const char *label
   return nz != 0;
 }
 
-// ---- stage 0, one lane per proof: RangeProofTranscript::new (:287-297), alpha (:325-333) ----
+// ---- wavefront-cooperative helpers (wstrobe.h): one proof per 64-lane workgroup ----
+struct ProveLds {
+  uint64_t tr[25], rng[25];
+  uint8_t buf[64];
+  sc xch[2];
+};
+// build_rng (src/transcripts.rs:185-194): clone, rekey with the witness bytes, finalize with 32 external bytes
+__device__ __forceinline__ void pw_build_rng(WStrobe &rng, ProveLds &L, const KeccakLanes &K, const WStrobe &tr, const uint8_t *wit,
+                                             uint32_t wit_len, const uint8_t *ext32) {
+  ws_clone(rng, L.rng, tr);
+  wm_rng_rekey(rng, K, "witness", 7, BytesAt{wit}, wit_len);
+  wm_rng_finalize(rng, K, BytesAt{ext32});
+}
+// Scalar::random_not_zero(transcript_rng); every lane ends up with the same scalar
+__device__ __forceinline__ void pw_random(sc &out, WStrobe &rng, ProveLds &L, const KeccakLanes &K) {
+  do {
+    wm_rng_fill(rng, K, L.buf, 64);
+    sc_mont_from_wide(out, L.buf);
+  } while (sc_iszero(out));
+}
+__device__ __forceinline__ bool pw_challenge(WStrobe &tr, ProveLds &L, const KeccakLanes &K, const char *label, uint32_t llen, sc &out) {
+  wm_challenge_bytes(tr, K, label, llen, L.buf, 64);
+  sc_mont_from_wide(out, L.buf);
+  return !sc_iszero(out);
+}
+__device__ __forceinline__ bool pw_validate_append(WStrobe &tr, const KeccakLanes &K, const char *label, uint32_t llen,
+                                                   const uint8_t *p32) {
+  const bool nz = __ballot(threadIdx.x < 32 && p32[threadIdx.x & 31u] != 0) != 0;
+  wm_append_message(tr, K, label, llen, BytesAt{p32}, 32);
+  return nz;
+}
+// t scalars "label"[k]: nonces (lane k computes its own BLAKE2b) or sequential draws from the transcript RNG; dst in HBM
+__device__ __forceinline__ void pw_nonces_or_randoms(sc *dst, uint32_t t, WStrobe &rng, ProveLds &L, const KeccakLanes &K,
+                                                     const uint8_t *seed, bool has_seed, const char *label, uint32_t llen, int j) {
+  if (has_seed) {
+    if (threadIdx.x < t) {
+      sc v;
+      dev_nonce(v, seed, label, llen, j, (int)threadIdx.x);
+      dst[threadIdx.x] = v;
+    }
+  } else {
+    for (uint32_t k = 0; k < t; k++) {
+      sc v;
+      pw_random(v, rng, L, K);
+      if (threadIdx.x == 0) dst[k] = v;
+    }
+  }
+}
+
+// ---- stage 0, one wavefront per proof: RangeProofTranscript::new (:287-297), alpha (:325-333) ----
 __global__ void __launch_bounds__(64) kp_init(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
                                               const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ states,
                                               const uint8_t *__restrict__ hg32, uint32_t n_bits, uint32_t t, uint32_t B,
                                               ProveState *__restrict__ ps) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t p = blockIdx.x;
   if (p >= B) return;
+  __shared__ ProveLds L;
+  const KeccakLanes K = keccak_lanes();
   const ProveDesc d = desc[p];
   ProveState &st = ps[p];
-  st.status = 0;
-  Strobe tr, rng;
-  strobe_from_bytes(tr, states + 203u * d.state_idx);
-  merlin_append_message(tr, (const uint8_t *)"dom-sep", 7, (const uint8_t *)"Bulletproofs+ Range Proof", 25);
-  merlin_append_message(tr, (const uint8_t *)"H", 1, hg32, 32);
-  for (uint32_t k = 0; k < t; k++) merlin_append_message(tr, (const uint8_t *)"G", 1, hg32 + 32 * (k + 1), 32);
-  merlin_append_u64(tr, (const uint8_t *)"N", 1, n_bits);
-  merlin_append_u64(tr, (const uint8_t *)"T", 1, t);
-  merlin_append_u64(tr, (const uint8_t *)"M", 1, d.m);
-  for (uint32_t j = 0; j < d.m; j++) merlin_append_message(tr, (const uint8_t *)"Ci", 2, bytes + d.commit_off + 32 * j, 32);
-  for (uint32_t j = 0; j < d.m; j++)
-    merlin_append_u64(tr, (const uint8_t *)"vi - minimum_value", 18, minvals[d.minval_idx + j]);
+  if (threadIdx.x == 0) st.status = 0;
+  const uint8_t *sb = states + 203u * d.state_idx;
+  for (uint32_t k = threadIdx.x; k < 200; k += 64) ((uint8_t *)L.tr)[k] = sb[k];
+  WStrobe tr, rng;
+  tr.st = L.tr;
+  tr.pos = sb[200];
+  tr.pos_begin = sb[201];
+  tr.cur_flags = sb[202];
+  __syncthreads();
+  wm_append_message(tr, K, "dom-sep", 7, BytesAt{(const uint8_t *)"Bulletproofs+ Range Proof"}, 25);
+  wm_append_message(tr, K, "H", 1, BytesAt{hg32}, 32);
+  for (uint32_t k = 0; k < t; k++) wm_append_message(tr, K, "G", 1, BytesAt{hg32 + 32 * (k + 1)}, 32);
+  wm_append_u64(tr, K, "N", 1, n_bits);
+  wm_append_u64(tr, K, "T", 1, t);
+  wm_append_u64(tr, K, "M", 1, d.m);
+  for (uint32_t j = 0; j < d.m; j++) wm_append_message(tr, K, "Ci", 2, BytesAt{bytes + d.commit_off + 32 * j}, 32);
+  for (uint32_t j = 0; j < d.m; j++) wm_append_u64(tr, K, "vi - minimum_value", 18, minvals[d.minval_idx + j]);
   const uint32_t wit_len = d.m * (8 + 32 * t);
-  pv_build_rng(rng, tr, bytes + d.wit_off, wit_len, bytes + d.ext_off);
   const bool has_seed = d.flags & 1u;
-  for (uint32_t k = 0; k < t; k++) {
-    sc a;
-    pv_nonce_or_random(a, rng, bytes + d.seed_off, has_seed, "alpha", 5, -1, (int)k);
-    st.alpha[k] = a;
-  }
-  st.tr = tr;
-  st.rng = rng;
+  if (!has_seed) pw_build_rng(rng, L, K, tr, bytes + d.wit_off, wit_len, bytes + d.ext_off);
+  pw_nonces_or_randoms(st.alpha, t, rng, L, K, bytes + d.seed_off, has_seed, "alpha", 5, -1);
+  ws_store(st.tr, tr);
 }
 
 // ---- A = sum_{bit=1} G_i - sum_{bit=0} H_i + sum_k alpha_k G_k  (:300-345), one wavefront per proof ----
@@ -334,88 +386,105 @@ __global__ void __launch_bounds__(64) kp_A(const uint8_t *__restrict__ bytes, co
   }
 }
 
-// ---- lane kernel, step j = 0..r (one lane per proof): Fiat-Shamir, RNG draws, inversions ----
+// ---- Fiat-Shamir kernel, step j = 0..r (one wavefront per proof, wstrobe.h): challenges, RNG draws, inversions ----
 //   j == 0      : challenges_y_z(A) (:348), then the draws of round 0
 //   1 <= j <= r : challenge_round_e(L_{j-1}, R_{j-1}) (:498-508), alpha update (:535-537), then the draws of round j
 //                 (j < r: d_L, d_R :437-464, y^-n :426-432;  j == r: r, s, d, eta :542-571)
+// The per-round TranscriptRng is a throw-away clone (src/transcripts.rs:185-194): it is only built when something is
+// drawn from it (no seed nonce, or the final round's r and s).
 __global__ void __launch_bounds__(64) kp_lane(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
                                               uint32_t n_bits, uint32_t t, uint32_t B, uint32_t j, uint32_t rounds,
                                               const uint8_t *__restrict__ a32, const uint8_t *__restrict__ lr32 /* [B][2][32] of round j-1 */,
                                               ProveState *__restrict__ ps) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t p = blockIdx.x, lane = threadIdx.x;
   if (p >= B) return;
+  __shared__ ProveLds L;
+  const KeccakLanes K = keccak_lanes();
   const ProveDesc d = desc[p];
   ProveState &st = ps[p];
   const uint32_t mn = d.m * n_bits, wit_len = d.m * (8 + 32 * t);
   const bool has_seed = d.flags & 1u;
   const uint8_t *seed = bytes + d.seed_off;
   bool ok = true;
-  Strobe tr = st.tr, rng;
+  WStrobe tr, rng;
+  ws_load(tr, L.tr, st.tr);
+  sc e, y;
+  // the round's TranscriptRng is cloned after the points are appended and BEFORE the challenge is drawn
+  // (src/transcripts.rs:126-131,142-147)
+  const bool need_rng = !has_seed || j == rounds;
   if (j == 0) {
-    ok = pv_validate_append(tr, "A", 1, a32 + (size_t)p * 32) && ok;
-    pv_build_rng(rng, tr, bytes + d.wit_off, wit_len, bytes + d.ext_off + 32);
-    sc v;
-    ok = dev_challenge(tr, (const uint8_t *)"y", 1, v) && ok;
-    st.y = v;
-    ok = dev_challenge(tr, (const uint8_t *)"z", 1, v) && ok;
-    st.z = v;
+    ok = pw_validate_append(tr, K, "A", 1, a32 + (size_t)p * 32) && ok;
+    if (need_rng) pw_build_rng(rng, L, K, tr, bytes + d.wit_off, wit_len, bytes + d.ext_off + 32 * (1 + j));
+    sc z;
+    ok = pw_challenge(tr, L, K, "y", 1, y) && ok;
+    ok = pw_challenge(tr, L, K, "z", 1, z) && ok;
+    if (lane == 0) {
+      st.y = y;
+      st.z = z;
+    }
+    sc_copy(e, y);  // placeholder operand of the paired inversion below
   } else {
-    ok = pv_validate_append(tr, "L", 1, lr32 + (size_t)p * 64) && ok;
-    ok = pv_validate_append(tr, "R", 1, lr32 + (size_t)p * 64 + 32) && ok;
-    pv_build_rng(rng, tr, bytes + d.wit_off, wit_len, bytes + d.ext_off + 32 * (1 + j));
-    sc e, einv, esq, einvsq;
-    ok = dev_challenge(tr, (const uint8_t *)"e", 1, e) && ok;
-    sc_mont_invert_vartime(einv, e);
+    ok = pw_validate_append(tr, K, "L", 1, lr32 + (size_t)p * 64) && ok;
+    ok = pw_validate_append(tr, K, "R", 1, lr32 + (size_t)p * 64 + 32) && ok;
+    if (need_rng) pw_build_rng(rng, L, K, tr, bytes + d.wit_off, wit_len, bytes + d.ext_off + 32 * (1 + j));
+    ok = pw_challenge(tr, L, K, "e", 1, e) && ok;
+    y = st.y;
+  }
+  // the round's two inversions side by side: even lanes invert e, odd lanes y^(n/2^(j+1))
+  const uint32_t n_half = mn >> (j + 1);
+  sc yn, inv, einv, yinv;
+  if (j < rounds) sc_mont_pow_u32(yn, y, n_half);
+  else sc_copy(yn, e);
+  {
+    sc x;
+#pragma unroll
+    for (int q = 0; q < 8; q++) x.v[q] = (lane & 1u) ? yn.v[q] : e.v[q];
+    sc_mont_invert_vartime(inv, x);
+    if (lane < 2) L.xch[lane] = inv;
+    __syncthreads();
+    einv = L.xch[0];
+    yinv = L.xch[1];
+    __syncthreads();
+  }
+  if (j > 0) {
+    sc esq, einvsq;
     sc_montsq(esq, e);
     sc_montsq(einvsq, einv);
-    st.e = e;
-    st.einv = einv;
-    st.esq = esq;
-    st.einvsq = einvsq;
-    for (uint32_t k = 0; k < t; k++) {
-      sc a = st.alpha[k], u, v;
-      sc_montmul(u, st.dl[k], esq);
-      sc_montmul(v, st.dr[k], einvsq);
+    if (lane == 0) {
+      st.e = e;
+      st.einv = einv;
+      st.esq = esq;
+      st.einvsq = einvsq;
+    }
+    if (lane < t) {  // alpha_k += d_L,k e^2 + d_R,k e^-2
+      sc a = st.alpha[lane], u, v;
+      sc_montmul(u, st.dl[lane], esq);
+      sc_montmul(v, st.dr[lane], einvsq);
       sc_add(a, a, u);
       sc_add(a, a, v);
-      st.alpha[k] = a;
+      st.alpha[lane] = a;
     }
+    __syncthreads();  // dl / dr are overwritten below
   }
   if (j < rounds) {
-    for (uint32_t k = 0; k < t; k++) {
-      sc v;
-      pv_nonce_or_random(v, rng, seed, has_seed, "dL", 2, (int)j, (int)k);
-      st.dl[k] = v;
+    pw_nonces_or_randoms(st.dl, t, rng, L, K, seed, has_seed, "dL", 2, (int)j);
+    pw_nonces_or_randoms(st.dr, t, rng, L, K, seed, has_seed, "dR", 2, (int)j);
+    if (lane == 0) {
+      st.yinv_prev = st.yinv_nhalf;  // the fold of step j still needs round j-1's y^-n
+      st.yinv_nhalf = yinv;
     }
-    for (uint32_t k = 0; k < t; k++) {
-      sc v;
-      pv_nonce_or_random(v, rng, seed, has_seed, "dR", 2, (int)j, (int)k);
-      st.dr[k] = v;
-    }
-    const uint32_t n_half = mn >> (j + 1);
-    sc yn, yinv;
-    sc_mont_pow_u32(yn, st.y, n_half);
-    sc_mont_invert_vartime(yinv, yn);
-    st.yinv_prev = st.yinv_nhalf;  // the fold of step j still needs round j-1's y^-n
-    st.yinv_nhalf = yinv;
   } else {
     sc v;
-    st.yinv_prev = st.yinv_nhalf;
-    pv_random(v, rng);
-    st.r = v;
-    pv_random(v, rng);
-    st.s = v;
-    for (uint32_t k = 0; k < t; k++) {
-      pv_nonce_or_random(v, rng, seed, has_seed, "d", 1, -1, (int)k);
-      st.dd[k] = v;
-    }
-    for (uint32_t k = 0; k < t; k++) {
-      pv_nonce_or_random(v, rng, seed, has_seed, "eta", 3, -1, (int)k);
-      st.eta[k] = v;
-    }
+    if (lane == 0) st.yinv_prev = st.yinv_nhalf;
+    pw_random(v, rng, L, K);
+    if (lane == 0) st.r = v;
+    pw_random(v, rng, L, K);
+    if (lane == 0) st.s = v;
+    pw_nonces_or_randoms(st.dd, t, rng, L, K, seed, has_seed, "d", 1, -1);
+    pw_nonces_or_randoms(st.eta, t, rng, L, K, seed, has_seed, "eta", 3, -1);
   }
-  st.tr = tr;
-  if (!ok) st.status |= PV_STATUS_TRANSCRIPT;
+  ws_store(st.tr, tr);
+  if (!ok && lane == 0) st.status |= PV_STATUS_TRANSCRIPT;
 }
 
 // ---- wave kernel, step j = 0..r (one wavefront per proof): vector prep / fold / inner products / MSM term lists ----

@@ -1,0 +1,233 @@
+// Wavefront-cooperative STROBE-128 / Merlin (device only): ONE transcript per 64-lane wavefront.
+//
+// merlin.h runs a whole sponge in one lane (right when thousands of independent transcripts are replayed side by side,
+// k_transcripts).  The prover's Fiat-Shamir step is different: a round cannot start before the previous round's
+// challenge exists, so per proof it is a pure latency chain of ~15 Keccak-f per round, and one lane needs ~26 us per
+// permutation.  Here the 200-byte state lives in LDS and the wavefront shares the work:
+//   * absorb / overwrite / squeeze touch up to 64 state bytes per step (lane k <-> byte pos + k),
+//   * Keccak-f[1600] keeps one 64-bit state word per lane (25 lanes); theta's column parities, pi and chi's row
+//     neighbours are cross-lane reads (ds_bpermute), rho is a per-lane rotate: 9 shuffles per round instead of ~150
+//     dependent 64-bit operations.
+// pos / pos_begin / cur_flags are wave-uniform registers.  Byte-for-byte the same sponge as merlin.h (tests compare the
+// prover's output with the oracle).  Must be called by all 64 lanes of a one-wavefront workgroup.
+#pragma once
+#include "merlin.h"
+
+namespace bpp {
+
+struct WStrobe {
+  uint64_t *st;  // 25 words in LDS
+  uint32_t pos, pos_begin, cur_flags;
+};
+
+// per-lane constants of the cooperative permutation (lane i <-> state word a[x + 5y], i = x + 5y)
+struct KeccakLanes {
+  int c1, c2, c3, c4;  // the other four words of this lane's column
+  int xm1, xp1;        // a lane of column x-1 / x+1
+  int pinv;            // pi: this lane's new word comes from lane pinv (already rotated there)
+  int n1, n2;          // chi: row neighbours x+1, x+2
+  uint32_t rot;        // rho offset of this lane's word
+  bool lane0;
+};
+
+__device__ __forceinline__ KeccakLanes keccak_lanes() {
+  const uint8_t ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+  const uint32_t l = threadIdx.x;
+  const int i = l < 25 ? (int)l : 0;  // lanes 25..63 shadow lane 0 and never write back
+  const int x = i % 5, y = i / 5;
+  KeccakLanes k;
+  k.c1 = x + 5 * ((y + 1) % 5);
+  k.c2 = x + 5 * ((y + 2) % 5);
+  k.c3 = x + 5 * ((y + 3) % 5);
+  k.c4 = x + 5 * ((y + 4) % 5);
+  k.xm1 = (x + 4) % 5;
+  k.xp1 = (x + 1) % 5;
+  // b[ys + 5 * ((2 xs + 3 ys) % 5)] = rot(a[xs + 5 ys])  ->  for destination (x, y): ys = x, xs = 3 (y - 3 x) mod 5
+  const int ys = x, xs = (3 * ((y + 15 - 3 * x) % 5)) % 5;
+  k.pinv = xs + 5 * ys;
+  k.n1 = 5 * y + (x + 1) % 5;
+  k.n2 = 5 * y + (x + 2) % 5;
+  uint32_t r = 0;
+#pragma unroll
+  for (int q = 0; q < 25; q++) r = (q == i) ? ROT[q] : r;
+  k.rot = r;
+  k.lane0 = i == 0;
+  return k;
+}
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) { return (uint64_t)__shfl((unsigned long long)v, src, 64); }
+
+__device__ __forceinline__ void keccak_f1600_wave(uint64_t *st, const KeccakLanes &K) {
+  const uint64_t RC[24] = {
+      0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL,
+      0x000000000000808BULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+      0x000000000000008AULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000AULL,
+      0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+      0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+      0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+  const uint32_t l = threadIdx.x;
+  uint64_t a = st[l < 25 ? l : 0];
+#pragma unroll 1
+  for (int rnd = 0; rnd < 24; rnd++) {
+    const uint64_t c = a ^ shfl64(a, K.c1) ^ shfl64(a, K.c2) ^ shfl64(a, K.c3) ^ shfl64(a, K.c4);  // theta
+    const uint64_t cp = shfl64(c, K.xp1);
+    a ^= shfl64(c, K.xm1) ^ ((cp << 1) | (cp >> 63));
+    const uint64_t r = (a << K.rot) | (a >> ((64u - K.rot) & 63u));       // rho (rot = 0: a | a)
+    const uint64_t b = shfl64(r, K.pinv);                                    // pi
+    a = b ^ (~shfl64(b, K.n1) & shfl64(b, K.n2));                            // chi
+    if (K.lane0) a ^= RC[rnd];                                               // iota
+  }
+  if (l < 25) st[l] = a;
+}
+
+__device__ __forceinline__ void ws_run_f(WStrobe &s, const KeccakLanes &K) {
+  uint8_t *b = (uint8_t *)s.st;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    b[s.pos] ^= (uint8_t)s.pos_begin;
+    b[s.pos + 1] ^= 0x04;
+    b[BPP_STROBE_R + 1] ^= 0x80;
+  }
+  __syncthreads();
+  keccak_f1600_wave(s.st, K);
+  __syncthreads();
+  s.pos = 0;
+  s.pos_begin = 0;
+}
+
+// byte_at(k) = k-th byte of the message, evaluated by the lane that owns the state byte
+template <class F>
+__device__ __forceinline__ void ws_absorb(WStrobe &s, const KeccakLanes &K, F byte_at, uint32_t n) {
+  uint8_t *b = (uint8_t *)s.st;
+  uint32_t off = 0;
+  while (off < n) {
+    const uint32_t room = BPP_STROBE_R - s.pos, chunk = n - off < room ? n - off : room;
+    for (uint32_t k = threadIdx.x; k < chunk; k += 64) b[s.pos + k] ^= byte_at(off + k);
+    s.pos += chunk;
+    off += chunk;
+    if (s.pos == BPP_STROBE_R) ws_run_f(s, K);
+  }
+}
+template <class F>
+__device__ __forceinline__ void ws_overwrite(WStrobe &s, const KeccakLanes &K, F byte_at, uint32_t n) {
+  uint8_t *b = (uint8_t *)s.st;
+  uint32_t off = 0;
+  while (off < n) {
+    const uint32_t room = BPP_STROBE_R - s.pos, chunk = n - off < room ? n - off : room;
+    for (uint32_t k = threadIdx.x; k < chunk; k += 64) b[s.pos + k] = byte_at(off + k);
+    s.pos += chunk;
+    off += chunk;
+    if (s.pos == BPP_STROBE_R) ws_run_f(s, K);
+  }
+}
+// out: LDS (or global) bytes, visible to every lane after the trailing barrier
+__device__ __forceinline__ void ws_squeeze(WStrobe &s, const KeccakLanes &K, uint8_t *out, uint32_t n) {
+  uint8_t *b = (uint8_t *)s.st;
+  uint32_t off = 0;
+  __syncthreads();
+  while (off < n) {
+    const uint32_t room = BPP_STROBE_R - s.pos, chunk = n - off < room ? n - off : room;
+    for (uint32_t k = threadIdx.x; k < chunk; k += 64) {
+      out[off + k] = b[s.pos + k];
+      b[s.pos + k] = 0;
+    }
+    s.pos += chunk;
+    off += chunk;
+    if (s.pos == BPP_STROBE_R) ws_run_f(s, K);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void ws_begin_op(WStrobe &s, const KeccakLanes &K, uint32_t flags, bool more) {
+  if (more) return;
+  const uint32_t old_begin = s.pos_begin;
+  s.pos_begin = s.pos + 1;
+  s.cur_flags = flags;
+  ws_absorb(s, K, [=](uint32_t k) { return (uint8_t)(k == 0 ? old_begin : flags); }, 2);
+  if ((flags & (BPP_FLAG_C | BPP_FLAG_K)) && s.pos != 0) ws_run_f(s, K);
+}
+
+struct BytesAt {  // message bytes behind a pointer (global memory, constant strings)
+  const uint8_t *p;
+  __device__ __forceinline__ uint8_t operator()(uint32_t k) const { return p[k]; }
+};
+struct WordAt {  // little-endian bytes of an integer held in registers
+  uint64_t v;
+  __device__ __forceinline__ uint8_t operator()(uint32_t k) const { return (uint8_t)(v >> (8 * k)); }
+};
+struct ZeroAt {
+  __device__ __forceinline__ uint8_t operator()(uint32_t) const { return 0; }
+};
+
+template <class F>
+__device__ __forceinline__ void wm_append_message(WStrobe &s, const KeccakLanes &K, const char *label, uint32_t llen, F msg,
+                                                  uint32_t mlen) {
+  ws_begin_op(s, K, BPP_FLAG_M | BPP_FLAG_A, false);
+  ws_absorb(s, K, BytesAt{(const uint8_t *)label}, llen);
+  ws_absorb(s, K, WordAt{mlen}, 4);  // meta_ad(len, more = true)
+  ws_begin_op(s, K, BPP_FLAG_A, false);
+  ws_absorb(s, K, msg, mlen);
+}
+__device__ __forceinline__ void wm_append_u64(WStrobe &s, const KeccakLanes &K, const char *label, uint32_t llen, uint64_t x) {
+  wm_append_message(s, K, label, llen, WordAt{x}, 8);
+}
+__device__ __forceinline__ void wm_challenge_bytes(WStrobe &s, const KeccakLanes &K, const char *label, uint32_t llen, uint8_t *out,
+                                                   uint32_t n) {
+  ws_begin_op(s, K, BPP_FLAG_M | BPP_FLAG_A, false);
+  ws_absorb(s, K, BytesAt{(const uint8_t *)label}, llen);
+  ws_absorb(s, K, WordAt{n}, 4);
+  ws_begin_op(s, K, BPP_FLAG_I | BPP_FLAG_A | BPP_FLAG_C, false);
+  ws_squeeze(s, K, out, n);
+}
+// TranscriptRngBuilder::rekey_with_witness_bytes / finalize, TranscriptRng::fill_bytes
+template <class F>
+__device__ __forceinline__ void wm_rng_rekey(WStrobe &rng, const KeccakLanes &K, const char *label, uint32_t llen, F w, uint32_t wlen) {
+  ws_begin_op(rng, K, BPP_FLAG_M | BPP_FLAG_A, false);
+  ws_absorb(rng, K, BytesAt{(const uint8_t *)label}, llen);
+  ws_absorb(rng, K, WordAt{wlen}, 4);
+  ws_begin_op(rng, K, BPP_FLAG_A | BPP_FLAG_C, false);
+  ws_overwrite(rng, K, w, wlen);
+}
+template <class F>
+__device__ __forceinline__ void wm_rng_finalize(WStrobe &rng, const KeccakLanes &K, F random32) {
+  ws_begin_op(rng, K, BPP_FLAG_M | BPP_FLAG_A, false);
+  ws_absorb(rng, K, BytesAt{(const uint8_t *)"rng"}, 3);
+  ws_begin_op(rng, K, BPP_FLAG_A | BPP_FLAG_C, false);
+  ws_overwrite(rng, K, random32, 32);
+}
+__device__ __forceinline__ void wm_rng_fill(WStrobe &rng, const KeccakLanes &K, uint8_t *out, uint32_t n) {
+  ws_begin_op(rng, K, BPP_FLAG_M | BPP_FLAG_A, false);
+  ws_absorb(rng, K, WordAt{n}, 4);
+  ws_begin_op(rng, K, BPP_FLAG_I | BPP_FLAG_A | BPP_FLAG_C, false);
+  ws_squeeze(rng, K, out, n);
+}
+
+// state <-> the per-proof Strobe kept in HBM between kernels
+__device__ __forceinline__ void ws_load(WStrobe &s, uint64_t *lds25, const Strobe &g) {
+  if (threadIdx.x < 25) lds25[threadIdx.x] = g.st[threadIdx.x];
+  s.st = lds25;
+  s.pos = g.pos;
+  s.pos_begin = g.pos_begin;
+  s.cur_flags = g.cur_flags;
+  __syncthreads();
+}
+__device__ __forceinline__ void ws_store(Strobe &g, const WStrobe &s) {
+  __syncthreads();
+  if (threadIdx.x < 25) g.st[threadIdx.x] = s.st[threadIdx.x];
+  if (threadIdx.x == 0) {
+    g.pos = s.pos;
+    g.pos_begin = s.pos_begin;
+    g.cur_flags = s.cur_flags;
+  }
+}
+__device__ __forceinline__ void ws_clone(WStrobe &dst, uint64_t *lds25, const WStrobe &src) {
+  __syncthreads();
+  if (threadIdx.x < 25) lds25[threadIdx.x] = src.st[threadIdx.x];
+  dst.st = lds25;
+  dst.pos = src.pos;
+  dst.pos_begin = src.pos_begin;
+  dst.cur_flags = src.cur_flags;
+  __syncthreads();
+}
+
+}  // namespace bpp
