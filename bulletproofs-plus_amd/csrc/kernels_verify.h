@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(64) k_from_uniform(const uint8_t *__restrict__
 // PASS 2 scalar block (src/range_proof.rs:894-1033), split so that nothing depends on the batch weight until the
 // very end (the weight chain runs on the host meanwhile):
 //   k_scalars_shared  1 lane / proof : batch inversion (binary-GCD), powers, sums -> shr[p][*]
-//   k_scalars_lanes   1 wave / proof : lanes over the mn generator indices -> UNWEIGHTED rows + dynamic scalars
+//   k_scalars_lanes   1 wave / ppw proofs : lanes over (proof, generator index) -> UNWEIGHTED rows + dynamic scalars
 //   k_weights_to_mont, k_reduce_static (sum_p w_p * rows[p][col]), k_weight_dyn (w_p * dyn)
 // Everything is Montgomery form until the final stores.
 // ---------------------------------------------------------------------------------------------
@@ -344,27 +344,48 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
 #define BPP_LANES_LB 3
 #define BPP_LANES_FIXED (3 * 8 + 64)
 
+// One workgroup serves `ppw` consecutive proofs: a 64-bit single-commitment proof only has 8 + 8 + 1 table entries and
+// 64 generator pairs, so one proof per wavefront leaves three quarters of the lanes idle in the table phase.  All
+// three phases run over flattened (proof, index) items.
+#define BPP_LANES_MAX_PPW 8
 __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restrict__ desc, const sc *__restrict__ shr,
                                                       uint32_t n_bits, uint32_t t, uint32_t max_mn, uint32_t cols, uint32_t B,
-                                                      uint32_t nhi_max, sc *__restrict__ rows, sc *__restrict__ dyn_unw) {
-  const uint32_t p = blockIdx.x;
-  if (p >= B) return;
+                                                      uint32_t nhi_max, uint32_t ppw, uint32_t tab_max, uint32_t ndyn_max,
+                                                      sc *__restrict__ rows, sc *__restrict__ dyn_unw) {
+  const uint32_t p0 = blockIdx.x * ppw;
   const uint32_t lane = threadIdx.x;
   extern __shared__ sc lanes_lds[];
-  sc *glo = lanes_lds, *ynlo = lanes_lds + 8, *hlo = lanes_lds + 16, *cz = lanes_lds + 24, *zp = lanes_lds + 56;
-  sc *ghi = lanes_lds + BPP_LANES_FIXED, *yhi = ghi + nhi_max, *shi = yhi + nhi_max;
-  const ProofDesc d = desc[p];
-  const uint32_t r = d.rounds, m = d.m, mn = m * n_bits;
-  if (r > BPP_MAX_ROUNDS - 1 || m > 32) return;
-  const sc *S = shr + (size_t)p * SH_STRIDE;
+  __shared__ uint32_t s_r[BPP_LANES_MAX_PPW], s_m[BPP_LANES_MAX_PPW], s_dyn[BPP_LANES_MAX_PPW];
+  const uint32_t per = BPP_LANES_FIXED + 3 * nhi_max;  // LDS entries per proof
+  if (lane < ppw) {
+    const uint32_t p = p0 + lane;
+    uint32_t r = ~0u, m = 0, dyn_off = 0;
+    if (p < B) {
+      const ProofDesc d = desc[p];
+      const uint32_t hb = d.rounds > BPP_LANES_LB ? d.rounds - BPP_LANES_LB : 0;
+      if (d.rounds <= BPP_MAX_ROUNDS - 1 && d.m <= 32 && (1u << hb) <= nhi_max) r = d.rounds;
+      m = d.m;
+      dyn_off = d.dyn_off;
+    }
+    s_r[lane] = r;  // ~0: nothing to do for this slot (past the end, or a shape rejected on the host before PASS 2)
+    s_m[lane] = m;
+    s_dyn[lane] = dyn_off;
+  }
+  __syncthreads();
   sc one;
   sc_mont_one(one);
-  const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, HB = r - LB;
-  const uint32_t nlo = 1u << LB, nhi = 1u << HB;
-  if (nhi > nhi_max) return;
-  const sc z_square = S[SH_Z2], e_square = S[SH_E2], e_square_z = S[SH_E2Z];
-  // ---- tables: one entry per lane per pass, low entries first, then high entries, then the per-party powers of z^2
-  for (uint32_t idx = lane; idx < nlo + nhi + m; idx += 64) {
+  // ---- tables: low entries first, then high entries, then the per-party powers of z^2
+  for (uint32_t it = lane; it < ppw * tab_max; it += 64) {
+    const uint32_t sub = it / tab_max, idx = it - sub * tab_max;
+    const uint32_t r = s_r[sub], m = s_m[sub];
+    if (r == ~0u) continue;
+    const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, HB = r - LB;
+    const uint32_t nlo = 1u << LB, nhi = 1u << HB;
+    if (idx >= nlo + nhi + m) continue;
+    const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
+    sc *T = lanes_lds + (size_t)sub * per;
+    sc *glo = T, *ynlo = T + 8, *hlo = T + 16, *cz = T + 24, *zp = T + 56;
+    sc *ghi = T + BPP_LANES_FIXED, *yhi = ghi + nhi_max, *shi = yhi + nhi_max;
     if (idx < nlo + nhi) {
       const bool is_hi = idx >= nlo;
       const uint32_t v = is_hi ? idx - nlo : idx, b0 = is_hi ? LB : 0, nbits = is_hi ? HB : LB;
@@ -398,6 +419,7 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
       }
     } else {
       const uint32_t party = idx - (nlo + nhi);
+      const sc z_square = S[SH_Z2], e_square = S[SH_E2];
       sc zz, c2, r2;
       sc_mont_pow_u32(zz, z_square, party + 1);
       sc_montmul(c2, zz, e_square);
@@ -408,10 +430,22 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     }
   }
   __syncthreads();
-  sc *row = rows + (size_t)p * cols;
-  for (uint32_t i = lane; i < max_mn; i += 64) {
+  // ---- generator rows
+  for (uint32_t it = lane; it < ppw * max_mn; it += 64) {
+    const uint32_t sub = it / max_mn, i = it - sub * max_mn;
+    const uint32_t r = s_r[sub];
+    if (r == ~0u) continue;
+    const uint32_t mn = s_m[sub] * n_bits;
+    const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, HB = r - LB;
+    const uint32_t nlo = 1u << LB, nhi = 1u << HB;
+    const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
+    const sc *T = lanes_lds + (size_t)sub * per;
+    const sc *glo = T, *ynlo = T + 8, *hlo = T + 16, *cz = T + 24;
+    const sc *ghi = T + BPP_LANES_FIXED, *yhi = ghi + nhi_max, *shi = yhi + nhi_max;
+    sc *row = rows + (size_t)(p0 + sub) * cols;
     sc gi, hi;
     if (i < mn) {
+      const sc e_square_z = S[SH_E2Z];
       const uint32_t lo = i & (nlo - 1), hi_i = i >> LB;
       const uint32_t rlo = (~lo) & (nlo - 1), rhi = (~hi_i) & (nhi - 1);
       sc y_nm_i, u, two_k;
@@ -433,10 +467,15 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     row[2 * i] = gi;
     row[2 * i + 1] = hi;
   }
-  // dynamic scalars (:1006-1015, :1022-1032) without the weight: v = A_q * B_q, operands picked per lane (no branches
-  // around the product): C_j: (-e^2 y^{mn+1}) * z^{2(j+1)};  A1: -e;  B: -1;  A: -e^2;  L_j: -e^2 * e_j^2;  R_j: -e^2 * e_j^-2
-  const uint32_t ndyn = m + 3 + 2 * r;
-  for (uint32_t q = lane; q < ndyn; q += 64) {
+  // ---- dynamic scalars (:1006-1015, :1022-1032) without the weight: v = A_q * B_q, operands picked per lane (no
+  // branches around the product): C_j: (-e^2 y^{mn+1}) * z^{2(j+1)};  A1: -e;  B: -1;  A: -e^2;  L_j: -e^2 * e_j^2;
+  // R_j: -e^2 * e_j^-2
+  for (uint32_t it = lane; it < ppw * ndyn_max; it += 64) {
+    const uint32_t sub = it / ndyn_max, q = it - sub * ndyn_max;
+    const uint32_t r = s_r[sub], m = s_m[sub];
+    if (r == ~0u || q >= m + 3 + 2 * r) continue;
+    const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
+    const sc *zp = lanes_lds + (size_t)sub * per + 56;
     sc a, bq;
     if (q < m) {
       a = S[SH_NEG_E2_YNM1];
@@ -454,10 +493,16 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     }
     sc v;
     sc_montmul(v, a, bq);
-    dyn_unw[d.dyn_off + q] = v;
+    dyn_unw[s_dyn[sub] + q] = v;
   }
-  if (lane == 0) row[2 * max_mn + t] = S[SH_HS];
-  if (lane >= 1 && lane <= t) row[2 * max_mn + (lane - 1)] = S[SH_D1(lane - 1)];
+  for (uint32_t it = lane; it < ppw * (t + 1); it += 64) {
+    const uint32_t sub = it / (t + 1), k = it - sub * (t + 1);
+    if (s_r[sub] == ~0u) continue;
+    const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
+    sc *row = rows + (size_t)(p0 + sub) * cols;
+    if (k == 0) row[2 * max_mn + t] = S[SH_HS];
+    else row[2 * max_mn + (k - 1)] = S[SH_D1(k - 1)];
+  }
 }
 
 __global__ void k_weights_to_mont(const uint8_t *__restrict__ weights32, uint32_t B, sc *__restrict__ wm) {
