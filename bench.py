@@ -3,12 +3,13 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode wide|shard] [--config cfg2|cfg3] [--no-cpu-baseline]
 
-A step = one pass of the hot path (RangeProof::verify: transcript replay, decompression, scalar block, weight chain,
-final MSM) over one resident batch.  Workload at N=1 = BASELINE.json configs[1]: 1024 non-aggregated 64-bit proofs,
-extension degree 1, inputs already resident in HBM (tests/golden/bench_cfg2.bin, produced by tests/golden/make_golden.py
-with the recipe of benches/range_proof.rs:206-262).  The engine keeps --batches-per-launch such batches resident per call
-(each one its own reference batch: own weight transcript, own final MSM) and --concurrency calls in flight; every step
-is still one complete verification of one 1024-proof batch, and EXACTLY --steps of them are timed.
+A step = one engine call = one pass of the hot path (RangeProof::verify: transcript replay, decompression, scalar block,
+weight chain, final MSM) over one resident input of --batches-per-step (default 64) INDEPENDENT reference batches of
+BASELINE.json configs[1]: 1024 non-aggregated 64-bit proofs each, extension degree 1, already resident in HBM
+(tests/golden/bench_cfg2.bin, produced by tests/golden/make_golden.py with the recipe of benches/range_proof.rs:206-262).
+Every 1024-proof batch keeps its own weight transcript, its own final MSM and its own identity test, exactly as if it had
+been passed to the reference's verify() alone; --concurrency steps are in flight per GPU and EXACTLY --steps are timed.
+value = proofs verified per second = steps x batches-per-step x 1024 / elapsed.
 N>1 (launched by torch.distributed.run, one rank per GPU), weak scaling: mode "shard" (default) = every rank verifies
 its own batches exactly as at N=1, verdicts combined by one all_reduce; mode "wide" = the union of all ranks' shards is
 ONE reference batch per step (all_gather of transcript-RNG bytes + all_gather of accumulator points over RCCL).
@@ -30,17 +31,17 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1024)
-    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--mode", default="shard", choices=["wide", "shard"])
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--chunk", type=int, default=0, help="proofs per reference batch at N=1 (0 = whole batch)")
     ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "4")),
-                    help="resident batches in flight per GPU (one engine/stream + one host thread each); a step is still "
-                         "one complete verify of one batch")
-    ap.add_argument("--batches-per-launch", type=int, default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "32")),
-                    help="resident 1024-proof batches handled by one engine call; each stays its own reference batch "
-                         "(own weight chain, own final MSM): one call = that many steps")
+                    help="steps in flight per GPU (one engine/stream + one host thread each)")
+    ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_launch", type=int,
+                    default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "64")),
+                    help="independent 1024-proof reference batches verified by one step (one engine call); each keeps its "
+                         "own weight chain, final MSM and identity test")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -76,11 +77,9 @@ def main():
     wide = use_dist and args.mode == "wide"
     S = 1 if wide else max(1, args.concurrency)  # cross-rank collectives must stay in program order -> no threads
     R = 1 if (wide or args.chunk) else max(1, args.batches_per_launch)
-    while args.steps % R:
-        R -= 1  # EXACTLY `steps` steps: one engine call = R steps
-    S = max(1, min(S, args.steps // R))
+    S = max(1, min(S, args.steps))
     lanes = []  # one engine + stream + resident copy of the batch per in-flight slot
-    t_upload = 0.0
+    t_upload = t_marshal = 0.0
     for i in range(S):
         stream = torch.cuda.Stream(device=device)
         eng = bpp.Engine(local_rank, stream=stream.cuda_stream)
@@ -94,9 +93,8 @@ def main():
         sts = [bpp.RangeStatement.init(params, it["commitments"], it["min_values"], None) for it in its]
         proofs = [bpp.RangeProof.from_bytes(it["proof"]) for it in its]
         trs = [bpp.Transcript.new(data["label"]) for _ in its]
-        t_up0 = time.perf_counter()
         rb = bpp.ResidentBatch(trs, sts, proofs)
-        t_upload = time.perf_counter() - t_up0
+        t_upload, t_marshal = rb.upload_seconds, rb.marshal_seconds
         lanes.append((stream, eng, rb))
 
     if wide:
@@ -137,10 +135,10 @@ def main():
         if use_dist:
             dist.barrier()
 
-    run_steps(max(-(-args.warmup // R), S if args.warmup else 0))
+    run_steps(args.warmup)
     sync()
     t0 = time.perf_counter()
-    lat, profs = run_steps(args.steps // R)
+    lat, profs = run_steps(args.steps)
     torch.cuda.synchronize(device)
     if use_dist:
         dist.barrier()
@@ -159,21 +157,22 @@ def main():
             prof_sum[k] = prof_sum.get(k, 0.0) + v
 
     if rank == 0:
-        total = n_local * world * args.steps
+        total = n_local * R * world * args.steps
         out = {
             "metric": "64-bit range proofs verified/sec (batch)", "value": total / elapsed, "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: %d x aggregation-%d 64-bit proofs per GPU, extension degree %d, "
-                                   "VerifyOnly, resident in HBM" % (1 if args.config == "cfg2" else 2, n_local, data["m"], data["t"]),
-                       "batch_per_gpu": n_local,
+            "config": {"workload": "BASELINE configs[%d]: reference batches of %d x aggregation-%d 64-bit proofs, extension "
+                                   "degree %d, VerifyOnly, resident in HBM; one step = %d such batches in one engine call"
+                                   % (1 if args.config == "cfg2" else 2, n_local, data["m"], data["t"], R),
+                       "proofs_per_reference_batch": n_local, "batches_per_step": R, "proofs_per_step_per_gpu": n_local * R,
                        "mode": ("one reference batch over all ranks (all_gather rng bytes + accumulators)" if wide else
                                 ("each %d-proof chunk is a reference batch" % args.chunk if args.chunk else
                                  "each 1024-proof resident batch is one reference batch (private verify())")),
-                       "batches_per_launch": R, "launches_in_flight_per_gpu": S,
+                       "steps_in_flight_per_gpu": S,
                        "parallelism": "proof-sharded x%d" % world},
-            "launch_latency_ms": 1e3 * sum(lat) / len(lat),
+            "step_latency_ms": 1e3 * sum(lat) / len(lat),
         }
         if prof_sum and prof_sum.get("msm_final_ms", 0) > 0:
             k = len(profs)
@@ -199,7 +198,9 @@ def main():
                                "valu": {"achieved_Tmad_per_s": mads / (acc_ms * 1e-3) / 1e12, "peak_Tmad_per_s": 30.1,
                                         "frac": mads / (acc_ms * 1e-3) / 30.1e12}}
             out["stages_ms"] = {n: round(v, 4) for n, v in avg.items() if n.endswith("_ms")}
+            # bpp_batch_upload alone: host proof/statement buffers -> parsed, packed and resident (R batches of 1024)
             out["pcie_inclusive_upload_ms"] = 1e3 * t_upload
+            out["python_marshal_ms"] = 1e3 * t_marshal
         if not args.no_cpu_baseline:
             from oracle import cport  # cpu_baseline leg only
             cp = cport.Params(data["bit_length"], data["m"], data["t"])
