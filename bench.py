@@ -188,7 +188,7 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tpath):  # PMC figure of the same kernel/workload, collected in its own rocprofv3 passes
                 tj = json.load(open(tpath))
-                traffic = tj["hbm_bytes_per_launch"] * (terms / 528448.0)
+                traffic = tj["hbm_bytes_per_launch"] * (terms / float(tj["msm_terms_per_launch"]))
             mads = terms * K * 700.0
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

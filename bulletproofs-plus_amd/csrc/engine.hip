@@ -246,8 +246,8 @@ int fail(bpp_ctx *ctx, int code, const std::string &m, char *errbuf = nullptr, s
   return code;
 }
 
-enum Mark { M_START = 0, M_TRANSCRIPTS, M_DECOMPRESS, M_SCALARS, M_WEIGHTS_IN, M_REDUCE, M_DIGITS, M_SORT, M_ACC, M_BUCKET,
-            M_FINAL, M_COUNT };
+enum Mark { M_START = 0, M_TRANSCRIPTS, M_DECOMPRESS, M_SCALARS, M_WEIGHTS_IN, M_REDUCE, M_DIGITS, M_SORT, M_ORDER, M_ACC,
+            M_BUCKET, M_FINAL, M_COUNT };
 
 struct StageTimer {
   bpp_ctx *ctx;
@@ -332,6 +332,7 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
   hipLaunchKernelGGL(k_order_hist, og, dim3(1024), 0, s, w.counts.p, per_group, w.order_hist.p);
   hipLaunchKernelGGL(k_order_scatter, og, dim3(1024), 0, s, w.counts.p, per_group, w.order_hist.p,
                      w.order_hist.p + (size_t)plan.G * 256, w.order.p);
+  if (tm) tm->mark(M_ORDER);  // msm_accumulate_ms brackets k_msm_accumulate alone (the roofline kernel)
   hipLaunchKernelGGL(k_msm_accumulate, dim3(8 * cdiv(plan.G, 8) * cdiv(per_group, 64)), dim3(64), 0, s, w.sorted.p, w.starts.p,
                      w.counts.p, w.order.p, tabs, per_group, plan.G, w.buckets.p);
   if (tm) tm->mark(M_ACC);
@@ -1254,8 +1255,8 @@ void collect_profile(bpp_ctx *ctx, Batch &b, StageTimer &tm, float chain_ms, flo
   pf.chain_host_ms = chain_ms;
   pf.reduce_ms = tm.between(M_WEIGHTS_IN, M_REDUCE);
   pf.msm_digits_ms = tm.between(M_REDUCE, M_DIGITS);
-  pf.msm_sort_ms = tm.between(M_DIGITS, M_SORT);
-  pf.msm_accumulate_ms = tm.between(M_SORT, M_ACC);
+  pf.msm_sort_ms = tm.between(M_DIGITS, M_ORDER);  // counting sort + size ordering of the buckets
+  pf.msm_accumulate_ms = tm.between(M_ORDER, M_ACC);
   pf.msm_bucket_reduce_ms = tm.between(M_ACC, M_BUCKET);
   pf.msm_final_ms = tm.between(M_BUCKET, M_FINAL);
   pf.total_ms = total_host_ms;
