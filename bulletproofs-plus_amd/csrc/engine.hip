@@ -1118,9 +1118,12 @@ void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const u
   static const int simd = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") ? 8
                           : (__builtin_cpu_supports("avx2") ? 4 : 1);
   HostPool &pool = HostPool::get();
-  // one scalar chain per worker is the fastest in wall time; lockstep vector bundles (chain_host.h) halve the CPU time
-  // per proof and are used once the groups clearly outnumber the workers
-  const uint32_t W = (G > 2 * pool.size()) ? (uint32_t)simd : 1u;
+  // One scalar chain per worker has the lowest latency when workers are plentiful; lock-step vector bundles
+  // (chain_host.h) need ~5x less CPU time per chain and keep the GPU fed when several calls / ranks share few cores
+  // (measured, 64 groups x 4 calls in flight: 4 host threads 14.9 M proofs/s lock-step vs 12.5 M scalar; 32 threads
+  // 15.3 M vs 15.5 M).  Used as soon as the groups outnumber half the workers.
+  static const int force = getenv("BPP_CHAIN_LOCKSTEP") ? atoi(getenv("BPP_CHAIN_LOCKSTEP")) : -1;
+  const uint32_t W = force >= 0 ? (force ? (uint32_t)simd : 1u) : ((G >= 2u * (uint32_t)simd && 2 * G > pool.size()) ? (uint32_t)simd : 1u);
   struct Unit {
     uint32_t g0, cnt;
   };

@@ -4,6 +4,7 @@
 #include "scalar.h"
 #include "merlin.h"
 #include "blake2b.h"
+#include "chain_host.h"
 using namespace bpp;
 extern "C" {
 void ht_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe x, y, z; fe_frombytes(x, a); fe_frombytes(y, b); fe_mul(z, x, y); fe_tobytes(out, z); }
@@ -38,4 +39,13 @@ void ht_merlin_kat(const uint8_t *label, uint32_t llen, const uint8_t *ml, uint3
 void ht_merlin_rng(const uint8_t state[203], const uint8_t *wit, uint32_t wlen, const uint8_t rnd[32], uint8_t *out, uint32_t n) {
   Strobe s; strobe_from_bytes(s, state); if (wlen) merlin_rng_rekey(s, (const uint8_t *)"witness", 7, wit, wlen); merlin_rng_finalize(s, rnd); merlin_rng_fill(s, out, n); }
 void ht_blake2b(const uint8_t *key, uint32_t klen, const uint8_t *persona, uint32_t plen, uint8_t out[64]) { blake2b512_keyed_personal_empty(out, key, klen, persona, plen); }
+// batch-weight chains (chain_host.h): `width` chains of n proofs each in lock-step (1 = the template's scalar instance,
+// 4 = AVX2, 8 = AVX-512); returns 0 when the CPU lacks the instruction set
+int ht_weight_chains(const uint8_t *rng /* [width][n][32] */, uint32_t n, uint32_t width, uint8_t *out /* [width][n][32] */) {
+  const uint8_t *in[8]; uint8_t *o[8];
+  for (uint32_t k = 0; k < width && k < 8; k++) { in[k] = rng + (size_t)k * n * 32; o[k] = out + (size_t)k * n * 32; }
+  if (width == 1) { weights_chain_multi_impl<1>(in, n, o); return 1; }
+  if (width == 4) { if (!__builtin_cpu_supports("avx2")) return 0; weights_chain_x4(in, n, o); return 1; }
+  if (width == 8) { if (!(__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl"))) return 0; weights_chain_x8(in, n, o); return 1; }
+  return -1; }
 }

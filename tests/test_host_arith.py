@@ -123,3 +123,26 @@ def test_merlin_and_blake2b(ht):
         out = _buf(64)
         ht.ht_blake2b(key, len(key), lab.encode(), len(lab), out)
         assert int.from_bytes(out.raw, "little") % L == O.nonce(sn, lab, j, k)
+
+
+def test_weight_chains_lockstep(ht):
+    """host batch-weight transcript (src/range_proof.rs:811,849,853,894): scalar and lock-step vector instances of
+    chain_host.h against the oracle's Merlin; every chain of a bundle must come out as if it had run alone"""
+    from oracle.pyref import protocol as O
+    import ctypes
+    ht.ht_weight_chains.restype = ctypes.c_int
+    for n in (1, 3, 40, 129):  # 129 proofs cross several sponge blocks in both the absorb and the squeeze phase
+        for width in (1, 4, 8):
+            rng = b"".join(_r(b"chain%d" % width, 1000 * n + i) for i in range(width * n))
+            out = ctypes.create_string_buffer(32 * width * n)
+            rc = ht.ht_weight_chains(rng, n, width, out)
+            if rc == 0:
+                pytest.skip("CPU without the vector instruction set of the %d-wide instance" % width)
+            assert rc == 1
+            for k in range(width):
+                t = M.Transcript(b"Bulletproofs+ verifier weights")
+                for i in range(n):
+                    t.append_message(b"proof", rng[(k * n + i) * 32:(k * n + i + 1) * 32])
+                wr = t.build_rng().finalize(O.NullRng())
+                want = b"".join(C.scalar_bytes(O.random_not_zero(wr)) for _ in range(n))
+                assert out.raw[k * n * 32:(k + 1) * n * 32] == want, (n, width, k)
