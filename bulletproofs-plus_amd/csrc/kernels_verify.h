@@ -554,13 +554,15 @@ __global__ void __launch_bounds__(64) k_reduce_static(const sc *__restrict__ row
       wds[i] = (uint32_t)carry;
       carry >>= 32;
     }
-    // value = lo + carry * 2^256 (Montgomery form of the true sum): from_mont(lo) + carry, since 2^256 * R^-1 = 1
-    sc lo, res, hi;
+    // value = lo + carry * 2^256 (Montgomery form of the true sum): from_mont(lo) + carry * 2^256 * R^-1
+    sc lo, res, hi, p256;
     sc_const(lo, wds);
     sc_from_mont(res, lo);
     sc_0(hi);
     hi.v[0] = (uint32_t)carry;
     hi.v[1] = (uint32_t)(carry >> 32);
+    sc_const(p256, SC_P256);
+    sc_montmul(hi, hi, p256);
     sc_add(res, res, hi);
     out[(size_t)g * cols + col] = res;
   }

@@ -20,6 +20,13 @@ def test_generated_constants_are_current(tmp_path):
     assert arr(fld, "FE_D") == g.limbs10(g.D)
     assert arr(fld, "FE_SQRT_M1") == g.limbs10(g.SQRT_M1)
     assert arr(fld, "FE_INVSQRT_A_MINUS_D") == g.limbs10(g.INVSQRT_A_MINUS_D)
-    assert arr(scl, "SC_R2") == g.words8(pow(2, 512, g.L))
-    assert arr(scl, "SC_R3") == g.words8(pow(2, 768, g.L))
-    assert (-pow(g.L, -1, 2**32)) % 2**32 == 0x12547E1B
+    assert g.SC_R_BITS == 261  # nine 29-bit limbs (csrc/scalar.h)
+    assert arr(scl, "SC_R1") == g.words8(pow(2, 261, g.L))
+    assert arr(scl, "SC_R2") == g.words8(pow(2, 522, g.L))
+    assert arr(scl, "SC_R3") == g.words8(pow(2, 783, g.L))
+    assert arr(scl, "SC_P256") == g.words8(pow(2, 256, g.L))
+    assert arr(scl, "SC_WIDE_HI") == g.words8(pow(2, 256 + 522, g.L))
+    l29 = arr(scl, "SC_L29")
+    assert sum(v << (29 * i) for i, v in enumerate(l29)) == g.L and l29[5:8] == [0, 0, 0] and l29[8] == 1 << 20
+    linv = int(re.search(r"BPP_LINV29 0x([0-9a-f]+)u", scl).group(1), 16)
+    assert (linv * g.L + 1) % 2**29 == 0
