@@ -23,6 +23,10 @@ int ht_sc_canonical(const uint8_t a[32]) { return sc_is_canonical(a) ? 1 : 0; }
 int ht_decompress_compress(const uint8_t in[32], uint8_t out[32]) {
   niels n; bool ok = ristretto_decompress(n, in); if (!ok) return 0;
   ge p; ge_identity(p); ge_madd(p, p, n); ristretto_compress(out, p); return 1; }
+// decode, rebuild the extended point straight from the Niels form (ge_from_niels), negate optionally, add P: 2P or identity
+int ht_from_niels(const uint8_t in[32], int neg, uint8_t out[32]) {
+  niels n; if (!ristretto_decompress(n, in)) return 0;
+  niels m = n; niels_cneg(m, neg != 0); ge p; ge_from_niels(p, m); ge_madd(p, p, n); ristretto_compress(out, p); return 1; }
 void ht_from_uniform(const uint8_t in[64], uint8_t out[32]) { ge p; ristretto_from_uniform(p, in); ristretto_compress(out, p); }
 // out = compress(k*P) by double-and-add using dbl/madd/add; also exercises msub and ge_to_niels
 int ht_scalarmult(const uint8_t k[32], const uint8_t pin[32], uint8_t out[32]) {

@@ -176,6 +176,8 @@ __global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t *__restri
 // (blockIdx % 8), so XCD x takes the groups x, x+8, x+16, ... one after the other; a group's buckets (in size order)
 // are consecutive for that XCD and its point set stays resident in that XCD's 4 MB L2 instead of being re-fetched
 // through the fabric by every wavefront.  grid = 8 * ceil(G/8) * ceil(per_group/64) blocks of 64. ----
+// Measured alternatives that lose: a 4-waves-per-SIMD bound (128 VGPRs) spills; turning the first point into the
+// accumulator with ge_from_niels (saves one of ~17 additions) costs 40-50 more VGPRs and a wavefront of occupancy.
 __global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t *__restrict__ sorted,
                                                        const uint32_t *__restrict__ starts,
                                                        const uint32_t *__restrict__ counts,

@@ -416,6 +416,19 @@ BPP_HD void ristretto_from_uniform(ge &out, const uint8_t b[64]) {
   ge_add(out, p0, p1);
 }
 
+// affine niels -> extended, no inversion: (2x : 2y : 2 : 2xy) with 2xy = (2dxy) / d
+BPP_HD void ge_from_niels(ge &r, const niels &q) {
+  fe dinv;
+  fe_const(dinv, FE_D_INV);
+  fe_sub(r.X, q.yplusx, q.yminusx);
+  fe_carry(r.X);
+  fe_add(r.Y, q.yplusx, q.yminusx);
+  fe_carry(r.Y);
+  fe_0(r.Z);
+  r.Z.v[0] = 2;
+  fe_mul(r.T, q.xy2d, dinv);
+}
+
 // extended -> affine niels (one inversion)
 BPP_HD void ge_to_niels(niels &out, const ge &p) {
   fe zi, x, y;

@@ -80,6 +80,9 @@ def test_ristretto(ht):
         assert o.raw == pt.compress()
         o2 = _buf()
         assert ht.ht_decompress_compress(o.raw, o2) == 1 and o2.raw == o.raw
+        o4 = _buf()
+        assert ht.ht_from_niels(o.raw, 0, o4) == 1 and o4.raw == (pt * 2).compress()  # ge_from_niels(P) + P
+        assert ht.ht_from_niels(o.raw, 1, o4) == 1 and o4.raw == bytes(32)            # ge_from_niels(-P) + P
         k = int.from_bytes(_r(b"k", i), "little") % L
         o3 = _buf()
         assert ht.ht_scalarmult(k.to_bytes(32, "little"), o.raw, o3) == 1 and o3.raw == (pt * k).compress()
