@@ -164,7 +164,8 @@ struct Params {
   DevBuf<uint8_t> d_hg32;           // compressed H, G_0..G_{t-1}
   std::vector<uint8_t> hg32;        // host copy
   std::vector<uint8_t> gi32, hi32;  // compressed generators, party-major
-  DevBuf<fbent> fb_table;           // prover's fixed-base window table, built on first use (table_len x 4096 x 128 B)
+  DevBuf<fbent> fb_table;           // prover's fixed-base window table, built on first use (geometry fb_geo)
+  FbGeom fb_geo{}, fb_ped_geo{};
   DevBuf<fbent> fb_ped;             // same for the Pedersen bases only [G_0..G_{t-1}, H], always resident (commit)
 };
 
@@ -646,9 +647,11 @@ int bpp_params_create(bpp_ctx *ctx, uint32_t bit_length, uint32_t max_aggregatio
       for (int i = 0; i < 32; i++) z = z && P->hg32[(size_t)k * 32 + i] == 0;
       if (z) return fail(ctx, BPP_ERR_VERIFICATION_FAILED, "Identity element cannot be added to the transcript");
     }
-    P->fb_ped.alloc((size_t)(t + 1) * FB_STRIDE);
-    hipLaunchKernelGGL(k_fb_build, dim3(cdiv((t + 1) * FB_WINDOWS, 64)), dim3(64), 0, ctx->stream, P->table.p + n_gen, t + 1,
-                       P->fb_ped.p);
+    P->fb_ped_geo = fb_geometry(t + 1);
+    P->fb_ped.alloc((size_t)(t + 1) * fb_stride(P->fb_ped_geo));
+    hipLaunchKernelGGL(k_fb_build,
+                       dim3(cdiv((t + 1) * P->fb_ped_geo.windows * cdiv(P->fb_ped_geo.entries, FB_BUILD_BLOCK), 64)), dim3(64), 0,
+                       ctx->stream, P->table.p + n_gen, t + 1, P->fb_ped_geo, P->fb_ped.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     P->d_hg32.alloc(P->hg32.size());
@@ -714,7 +717,8 @@ int bpp_pedersen_commit(bpp_ctx *ctx, uint64_t params, const uint64_t *values, c
     HIP_CHECK(hipMemcpyAsync(d_c.p, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, s));
     DevBuf<ge> d_ge;
     d_ge.alloc(count);
-    hipLaunchKernelGGL(k_fb_msm, dim3((uint32_t)count), dim3(FB_THREADS), 0, s, d_sc.p, d_g.p, d_c.p, per, P.fb_ped.p, d_ge.p);
+    hipLaunchKernelGGL(k_fb_msm, dim3((uint32_t)count), dim3(FB_THREADS), 0, s, d_sc.p, d_g.p, d_c.p, per, P.fb_ped.p, P.fb_ped_geo,
+                       d_ge.p);
     hipLaunchKernelGGL(k_compress_ge, dim3(cdiv((uint32_t)count, 64)), dim3(64), 0, s, d_ge.p, (uint32_t)count, d_out.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(commitments32, d_out.p, count * 32, hipMemcpyDeviceToHost, s));
@@ -1609,8 +1613,10 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     hipStream_t s0 = ctx->stream;
     const uint32_t n_gen = 2 * P.n_bits * P.m_max;
     if (!P.fb_table.p) {  // fixed-base window tables for every generator of these parameters (one-off)
-      P.fb_table.alloc((size_t)P.table_len * FB_STRIDE);
-      hipLaunchKernelGGL(k_fb_build, dim3(cdiv(P.table_len * FB_WINDOWS, 64)), dim3(64), 0, s0, P.table.p, P.table_len, P.fb_table.p);
+      P.fb_geo = fb_geometry(P.table_len);
+      P.fb_table.alloc((size_t)P.table_len * fb_stride(P.fb_geo));
+      hipLaunchKernelGGL(k_fb_build, dim3(cdiv(P.table_len * P.fb_geo.windows * cdiv(P.fb_geo.entries, FB_BUILD_BLOCK), 64)),
+                         dim3(64), 0, s0, P.table.p, P.table_len, P.fb_geo, P.fb_table.p);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipStreamSynchronize(s0));
     }
@@ -1727,11 +1733,12 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       // witness check (:275-284): commit(v_j, r_j) for every opening, compared with the statement's commitments
       hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_bytes, u.d_desc, t, n_gen, nb, m, 1 + t, u.d_cts,
                          u.d_ctg, u.d_ctc);
-      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(FB_THREADS), 0, s, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, u.d_ge);
+      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(FB_THREADS), 0, s, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, P.fb_geo,
+                         u.d_ge);
       hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_ge, nb * m, u.d_commit32);
       hipLaunchKernelGGL(kp_init, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_states, P.d_hg32.p, n, t, nb, u.d_ps);
       hipLaunchKernelGGL(kp_check_commitments, lane_grid, b64, 0, s, u.d_bytes, u.d_desc, u.d_commit32, nb, u.d_ps);
-      hipLaunchKernelGGL(kp_A, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, P.table.p, P.fb_table.p, n_gen, n,
+      hipLaunchKernelGGL(kp_A, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, P.table.p, P.fb_table.p, P.fb_geo, n_gen, n,
                          t, u.d_ps, u.d_a32);
       for (uint32_t j = 0; j <= rounds; j++) {
         const uint8_t *lr_prev = j ? u.d_lr + (size_t)(j - 1) * nb * 64 : nullptr;
@@ -1739,7 +1746,8 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
                            stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
         uint8_t *out = (j < rounds) ? u.d_lr + (size_t)j * nb * 64 : u.d_a1b;
-        hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(FB_THREADS), 0, s, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, u.d_ge);
+        hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(FB_THREADS), 0, s, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, P.fb_geo,
+                           u.d_ge);
         hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);
       }
       hipLaunchKernelGGL(kp_finish, lane_grid, b64, 0, s, u.d_desc, n, t, nb, rounds, u.d_a32, u.d_lr, u.d_a1b, u.d_vec, u.d_ps,

@@ -5,12 +5,15 @@
 //       Gf[i] = sum_{u = i mod len} cG[u] G_u,  Hf[i] = sum cH[u] H_u   (len = mn >> j)
 //     with per-proof coefficient vectors cG/cH that absorb e^-1, e*y^-n, e, e^-1 each round (:511-521);
 //     every G_u / H_u lands in exactly one of L_j, R_j, so a round is two MSMs of mn + t + 1 terms over FIXED bases.
-//   * fixed-base MSM: 8-bit signed windows over a precomputed table in HBM (fb table: for each generator, 32 windows x
-//     128 multiples in projective-niels form, 160 B each) -> 32 additions per term, no doublings, no buckets.
+//   * fixed-base MSM: signed windows over a precomputed table in HBM (per generator ceil(254/w) windows x 2^(w-1)
+//     multiples, affine Niels padded to one 128-byte line; w = 8..11 chosen by fb_geometry) -> 23 additions per term
+//     at w = 11, no doublings, no buckets.
 //   * per proof and round: one lane for the Fiat-Shamir / RNG / inversion step (kp_lane), one wavefront for the
 //     scalar-vector work (kp_wave), one wavefront per output point for the MSM (k_fb_msm).
 // All scalars are Montgomery form in HBM; canonical only in MSM inputs, transcript bytes and the proof.
 #pragma once
+#include <stdlib.h>
+
 #include "kernels_verify.h"
 #include "wstrobe.h"
 
@@ -23,9 +26,50 @@ struct alignas(128) fbent {
   niels q;
   uint32_t pad[2];
 };
-#define FB_WINDOWS 32
-#define FB_ENTRIES 128
-#define FB_STRIDE (FB_WINDOWS * FB_ENTRIES)  // entries per generator
+// Window width is chosen per parameter set (fb_geometry): the widest window whose table stays under ~1.8 GB, because
+// random 128-byte lines come at 21 G lines/s out of <= 2 GB but only ~10 G lines/s out of larger tables (TLB reach,
+// tools/microbench/rand_lines.hip).  11 bits (<= 600 generators) = 24 windows of 1024 entries, 23 additions per term.
+struct FbGeom {
+  uint32_t wbits;    // window width
+  uint32_t windows;  // ceil(254 / wbits): the top window never carries out
+  uint32_t entries;  // 2^(wbits-1) signed multiples 1..2^(wbits-1)
+};
+#define FB_MAX_WINDOWS 32
+#define FB_BUILD_BLOCK 128  // entries per lane of k_fb_build
+inline FbGeom fb_geometry(uint32_t n_gens) {  // host side
+  uint32_t w = 8;
+  const char *forced = getenv("BPP_FB_WBITS");  // tests: exercise every geometry on small parameter sets
+  const uint32_t top = forced ? (uint32_t)atoi(forced) : 11u;
+  for (uint32_t cand = (top >= 8 && top <= 11) ? top : 11u; cand > 8; cand--) {
+    const uint64_t bytes = (uint64_t)n_gens * ((254 + cand - 1) / cand) * (1ull << (cand - 1)) * 128ull;
+    if (bytes <= 1800ull << 20) {
+      w = cand;
+      break;
+    }
+  }
+  FbGeom g;
+  g.wbits = w;
+  g.windows = (254 + w - 1) / w;
+  g.entries = 1u << (w - 1);
+  return g;
+}
+BPP_HD size_t fb_stride(const FbGeom &g) { return (size_t)g.windows * g.entries; }  // entries per generator
+
+// signed digits of a canonical scalar, digit in [-(2^(w-1) - 1), 2^(w-1)]
+BPP_HD void fb_recode(int16_t *dig, const sc &s, const FbGeom &g) {
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < g.windows; w++) {
+    const uint32_t bit = w * g.wbits, wi = bit >> 5, sh = bit & 31u;
+    uint32_t raw = 0;
+    if (wi < 8) {
+      const uint64_t two = (uint64_t)s.v[wi] | ((wi + 1 < 8) ? ((uint64_t)s.v[wi + 1] << 32) : 0ull);
+      raw = (uint32_t)(two >> sh) & ((1u << g.wbits) - 1u);
+    }
+    const uint32_t v = raw + carry;
+    carry = v > g.entries ? 1u : 0u;
+    dig[w] = (int16_t)((int32_t)v - (int32_t)(carry << g.wbits));
+  }
+}
 
 struct cached {  // projective niels (table construction only)
   fe yplusx, yminusx, z, t2d;
@@ -62,22 +106,33 @@ BPP_HD void ge_add_cached(ge &r, const ge &p, const cached &q) {
   fe_mul(r.T, e, h);
 }
 
-// one lane per (generator, window): entries d * 2^(8w) * P, d = 1..128, normalised to affine (one inversion each;
-// the table is built once per parameter set)
-__global__ void __launch_bounds__(64) k_fb_build(const niels *__restrict__ gens, uint32_t n_gens, fbent *__restrict__ tbl) {
+// one lane per (generator, window, block of FB_BUILD_BLOCK entries): entries d * 2^(wbits*w) * P, normalised to affine
+// (one inversion each; the table is built once per parameter set)
+__global__ void __launch_bounds__(64) k_fb_build(const niels *__restrict__ gens, uint32_t n_gens, FbGeom geo,
+                                                 fbent *__restrict__ tbl) {
+  const uint32_t blocks = (geo.entries + FB_BUILD_BLOCK - 1) / FB_BUILD_BLOCK;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_gens * FB_WINDOWS) return;
-  const uint32_t g = i / FB_WINDOWS, w = i % FB_WINDOWS;
+  if (i >= n_gens * geo.windows * blocks) return;
+  const uint32_t blk = i % blocks, gw = i / blocks, g = gw / geo.windows, w = gw % geo.windows;
   ge base;
   ge_identity(base);
   const niels q = gens[g];
   ge_madd(base, base, q);
-  if (w) ge_dbl_n(base, base, (int)(8 * w));
+  if (w) ge_dbl_n(base, base, (int)(geo.wbits * w));
   cached cb;
   ge_to_cached(cb, base);
-  ge acc = base;
-  fbent *out = tbl + ((size_t)g * FB_WINDOWS + w) * FB_ENTRIES;
-  for (uint32_t d = 0; d < FB_ENTRIES; d++) {
+  // acc = (blk * FB_BUILD_BLOCK + 1) * base by double-and-add from the top bit
+  const uint32_t first = blk * FB_BUILD_BLOCK + 1;
+  ge acc;
+  ge_identity(acc);
+  for (int bit = 31; bit >= 0; bit--) {
+    if ((first >> bit) == 0) continue;
+    ge_dbl(acc, acc);
+    if ((first >> bit) & 1u) ge_add_cached(acc, acc, cb);
+  }
+  fbent *out = tbl + ((size_t)g * geo.windows + w) * geo.entries + (first - 1);
+  const uint32_t cnt = geo.entries - (first - 1) < FB_BUILD_BLOCK ? geo.entries - (first - 1) : FB_BUILD_BLOCK;
+  for (uint32_t d = 0; d < cnt; d++) {
     fe zi, x, y;
     fe_invert(zi, acc.Z);
     fe_mul(x, acc.X, zi);
@@ -86,20 +141,20 @@ __global__ void __launch_bounds__(64) k_fb_build(const niels *__restrict__ gens,
     niels_from_affine(e, x, y);
     fe_carry(e.yminusx);
     out[d].q = e;
-    if (d + 1 < FB_ENTRIES) ge_add_cached(acc, acc, cb);
+    if (d + 1 < cnt) ge_add_cached(acc, acc, cb);
   }
 }
 
 // out[o] = sum_i scal[o][i] * Gen[gidx[o][i]], i < count[o]; one workgroup of FB_THREADS lanes per output.
 // scal: canonical scalars, row stride `stride`; gidx rows likewise.  Result left in extended coordinates (k_compress_ge
 // turns a whole launch's outputs into bytes, one lane each, instead of one busy lane per workgroup here).
-//   phase 1 (per chunk of FB_CHUNK terms): recode scalars to signed 8-bit digits in LDS (digit in [-127, 128], 0x80 = +128)
+//   phase 1 (per chunk of FB_CHUNK terms): recode scalars to signed digits in LDS (fb_recode)
 //   phase 2: flat (term, window) work items, stride FB_THREADS -> every lane gets the same number of additions; the table
 //            line of item k+1 is requested before item k is added.
 #define FB_THREADS 256
 #define FB_CHUNK 512
 struct FbStage {
-  uint32_t dig[FB_CHUNK * 8];  // 32 digits per term, 4 per word
+  int16_t dig[FB_CHUNK * FB_MAX_WINDOWS];
   uint32_t gi[FB_CHUNK];
 };
 union FbShared {
@@ -107,17 +162,16 @@ union FbShared {
   FbStage st;
 };
 
-BPP_D void fb_fetch(niels &q, int &d, const FbStage &st, const fbent *__restrict__ tbl, uint32_t it) {
-  const uint32_t i = it >> 5, w = it & 31u;
-  const uint32_t byte = (st.dig[i * 8 + (w >> 2)] >> (8 * (w & 3))) & 0xffu;
-  d = byte == 0x80u ? 128 : (int)(int8_t)byte;
+BPP_D void fb_fetch(niels &q, int &d, const FbStage &st, const fbent *__restrict__ tbl, const FbGeom &geo, uint32_t it) {
+  const uint32_t i = it / geo.windows, w = it - i * geo.windows;
+  d = st.dig[it];
   const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-  q = tbl[(size_t)st.gi[i] * FB_STRIDE + (size_t)w * FB_ENTRIES + (mag ? mag - 1u : 0u)].q;
+  q = tbl[((size_t)st.gi[i] * geo.windows + w) * geo.entries + (mag ? mag - 1u : 0u)].q;
 }
 
 __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx,
                                                        const uint32_t *__restrict__ count, uint32_t stride,
-                                                       const fbent *__restrict__ tbl, ge *__restrict__ out) {
+                                                       const fbent *__restrict__ tbl, FbGeom geo, ge *__restrict__ out) {
   const uint32_t o = blockIdx.x, tid = threadIdx.x;
   const uint32_t n = count[o];
   __shared__ FbShared sh;
@@ -128,32 +182,20 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ sc
     __syncthreads();  // the previous chunk's digits are no longer read
     for (uint32_t i = tid; i < cn; i += FB_THREADS) {
       const sc s = scal[(size_t)o * stride + base + i];
-      uint32_t carry = 0;
-#pragma unroll
-      for (uint32_t j = 0; j < 8; j++) {
-        uint32_t packed = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-          const uint32_t v = ((s.v[j] >> (8 * k)) & 0xffu) + carry;  // 0..256
-          carry = v > 128u ? 1u : 0u;                                // digit = v - 256 * carry
-          packed |= (v & 0xffu) << (8 * k);
-        }
-        sh.st.dig[i * 8 + j] = packed;
-      }
-      // canonical scalars are < 2^253: the top digit never carries out
+      fb_recode(sh.st.dig + (size_t)i * geo.windows, s, geo);
       sh.st.gi[i] = gidx[(size_t)o * stride + base + i];
     }
     __syncthreads();
-    const uint32_t items = cn * 32;
+    const uint32_t items = cn * geo.windows;
     uint32_t it = tid;
     niels nxt;
     int nd = 0;
-    if (it < items) fb_fetch(nxt, nd, sh.st, tbl, it);
+    if (it < items) fb_fetch(nxt, nd, sh.st, tbl, geo, it);
     while (it < items) {
       niels cur = nxt;
       const int cd = nd;
       it += FB_THREADS;
-      if (it < items) fb_fetch(nxt, nd, sh.st, tbl, it);
+      if (it < items) fb_fetch(nxt, nd, sh.st, tbl, geo, it);
       if (cd != 0) {
         niels_cneg(cur, cd < 0);
         ge_madd(acc, acc, cur);
@@ -332,8 +374,8 @@ __global__ void __launch_bounds__(64) kp_init(const uint8_t *__restrict__ bytes,
 // a_L/a_R are never materialised as scalars here: they are 0/1 and 0/-1.
 __global__ void __launch_bounds__(64) kp_A(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
                                            const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present,
-                                           const niels *__restrict__ gens, const fbent *__restrict__ tbl, uint32_t n_gen,
-                                           uint32_t n_bits, uint32_t t, const ProveState *__restrict__ ps,
+                                           const niels *__restrict__ gens, const fbent *__restrict__ tbl, FbGeom geo,
+                                           uint32_t n_gen, uint32_t n_bits, uint32_t t, const ProveState *__restrict__ ps,
                                            uint8_t *__restrict__ a_out32) {
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
   const ProveDesc d = desc[p];
@@ -355,16 +397,15 @@ __global__ void __launch_bounds__(64) kp_A(const uint8_t *__restrict__ bytes, co
   if (lane < t) {  // alpha_k * G_k through the fixed-base table
     sc s;
     sc_from_mont(s, ps[p].alpha[lane]);
-    const fbent *row = tbl + (size_t)(n_gen + lane) * FB_STRIDE;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < FB_WINDOWS; w++) {
-      uint32_t v = ((s.v[w >> 2] >> (8 * (w & 3))) & 0xffu) + carry;
-      bool neg = v > 128u;
-      uint32_t mag = neg ? 256u - v : v;
-      carry = neg ? 1u : 0u;
-      if (mag) {
-        niels c = row[(size_t)w * FB_ENTRIES + (mag - 1)].q;
-        niels_cneg(c, neg);
+    const fbent *row = tbl + (size_t)(n_gen + lane) * fb_stride(geo);
+    int16_t dig[FB_MAX_WINDOWS];
+    fb_recode(dig, s, geo);
+    for (uint32_t w = 0; w < geo.windows; w++) {
+      const int dgt = dig[w];
+      if (dgt != 0) {
+        const uint32_t mag = (uint32_t)(dgt < 0 ? -dgt : dgt);
+        niels c = row[(size_t)w * geo.entries + (mag - 1)].q;
+        niels_cneg(c, dgt < 0);
         ge_madd(acc, acc, c);
       }
     }

@@ -135,3 +135,24 @@ def test_prove_and_verify_round_trip_large(bpp, engine):
     swapped = [proofs[1], proofs[0]] + proofs[2:]
     assert _kind(bpp, lambda: bpp.RangeProof.verify_batch(trs, sts, swapped, bpp.VerifyAction.VerifyOnly)) == \
         bpp.ProofErrorKind.VerificationFailed
+
+
+@pytest.mark.parametrize("wbits", [8, 9, 10, 11])
+def test_every_fixed_base_window_width(bpp, wbits, monkeypatch):
+    """the prover's fixed-base tables pick their window width from the size of the parameter set (8..11 bits); force each
+    one on a small set: proof bytes and Pedersen commitments must not depend on it"""
+    monkeypatch.setenv("BPP_FB_WBITS", str(wbits))
+    eng = bpp.Engine(0)
+    try:
+        n, m, t = 16, 2, 2
+        params = bpp.RangeParameters.init(n, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=eng)
+        sts, wits, exts, raw = _inputs(bpp, params, n, m, t, 2, b"wbits", "third")
+        got = bpp.RangeProof.prove_batch([bpp.Transcript.new(LABEL)] * 2, sts, wits, exts)
+        cp = cport.Params(n, m, t)
+        for i in range(2):
+            want, comm = cp.prove(LABEL, raw["vals"][i], raw["blinds"][i], raw["mins"][i], raw["seeds"][i], exts[i])
+            assert comm == raw["comms"][i]  # commit_many went through the resident Pedersen table of the same width
+            assert got[i].to_bytes() == want
+        cp.close()
+    finally:
+        eng.close()

@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) k_rand(const uint4 *__restrict__ tbl, uin
 }
 
 int main() {
-  const size_t sizes_mb[] = {2, 16, 64, 128, 256, 288, 512, 2048};
+  const size_t sizes_mb[] = {2, 16, 64, 256, 512, 2048, 4096, 8192, 16384, 32768, 65536};
   uint32_t *sink;
   hipMalloc((void **)&sink, 4);
   for (size_t mb : sizes_mb) {
@@ -31,7 +31,7 @@ int main() {
     uint4 *tbl;
     if (hipMalloc((void **)&tbl, bytes) != hipSuccess) return 1;
     hipMemset(tbl, 1, bytes);
-    const uint32_t n_lines = (uint32_t)(bytes / 128);
+    const uint32_t n_lines = (uint32_t)(bytes / 128);  // < 2^32 up to 512 GB
     for (int bpl : {128, 64}) {
       const uint32_t blocks = 256 * 12, iters = 256;
       hipEvent_t e0, e1;
