@@ -19,6 +19,7 @@ void ht_sc_addsub(const uint8_t a[32], const uint8_t b[32], uint8_t sum[32], uin
 void ht_sc_wide(const uint8_t a[64], uint8_t out[32]) { sc z; sc_mont_from_wide(z, a); sc_from_mont(z, z); sc_store_words(out, z); }
 void ht_sc_invert(const uint8_t a[32], uint8_t out[32]) { sc x; sc_load_words(x, a); sc_to_mont(x, x); sc_mont_invert(x, x); sc_from_mont(x, x); sc_store_words(out, x); }
 void ht_sc_invert_vartime(const uint8_t a[32], uint8_t out[32]) { sc x; sc_load_words(x, a); sc_to_mont(x, x); sc_mont_invert_vartime(x, x); sc_from_mont(x, x); sc_store_words(out, x); }
+void ht_sc_invert_plain(const uint8_t a[32], int which, uint8_t out[32]) { sc x, y; sc_load_words(x, a); if (which) sc_invert_vartime_plain(y, x); else sc_invert_xgcd_plain(y, x); sc_store_words(out, y); }
 int ht_sc_canonical(const uint8_t a[32]) { return sc_is_canonical(a) ? 1 : 0; }
 int ht_decompress_compress(const uint8_t in[32], uint8_t out[32]) {
   niels n; bool ok = ristretto_decompress(n, in); if (!ok) return 0;

@@ -149,3 +149,17 @@ def test_weight_chains_lockstep(ht):
                 wr = t.build_rng().finalize(O.NullRng())
                 want = b"".join(C.scalar_bytes(O.random_not_zero(wr)) for _ in range(n))
                 assert out.raw[k * n * 32:(k + 1) * n * 32] == want, (n, width, k)
+
+
+def test_scalar_inversions_agree(ht):
+    """divsteps inversion (sc_invert_vartime_plain) and the bit-at-a-time binary GCD it replaced, against pow(a, -1, l):
+    random values, small values, values next to l and powers of two (long runs of zero bits stress the divstep batching)"""
+    vals = [int.from_bytes(_r(b"inv", i), "little") % L for i in range(300)]
+    vals += [1, 2, 3, 5, L - 1, L - 2, (L - 1) // 2, (L + 1) // 2, 2**252, 2**252 - 1, 2**128, 2**200 + 1, 2**30, 2**30 - 1,
+             2**60, 2**31, 0]
+    for a in vals:
+        for which in (0, 1):
+            o = _buf()
+            ht.ht_sc_invert_plain(a.to_bytes(32, "little"), which, o)
+            got = int.from_bytes(o.raw, "little")
+            assert got == (pow(a, -1, L) if a else 0), (hex(a), which)
