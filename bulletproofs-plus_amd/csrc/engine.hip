@@ -241,6 +241,13 @@ struct bpp_ctx {
 
 namespace {
 
+// lanes per output point of k_fb_msm: enough (term, window) items per lane to outweigh the log2(lanes) reduction tree
+static uint32_t fb_threads(uint32_t terms, const FbGeom &g) {
+  if (const char *e = getenv("BPP_FB_THREADS")) return (uint32_t)atoi(e);
+  const uint32_t items = terms * g.windows;
+  return items >= 4096 ? 256u : (items >= 1024 ? 128u : 64u);
+}
+
 int fail(bpp_ctx *ctx, int code, const std::string &m, char *errbuf = nullptr, size_t len = 0) {
   if (ctx) ctx->err = m;
   set_err(errbuf, len, m);
@@ -717,7 +724,7 @@ int bpp_pedersen_commit(bpp_ctx *ctx, uint64_t params, const uint64_t *values, c
     HIP_CHECK(hipMemcpyAsync(d_c.p, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, s));
     DevBuf<ge> d_ge;
     d_ge.alloc(count);
-    hipLaunchKernelGGL(k_fb_msm, dim3((uint32_t)count), dim3(FB_THREADS), 0, s, d_sc.p, d_g.p, d_c.p, per, P.fb_ped.p, P.fb_ped_geo,
+    hipLaunchKernelGGL(k_fb_msm, dim3((uint32_t)count), dim3(fb_threads(per, P.fb_ped_geo)), 0, s, d_sc.p, d_g.p, d_c.p, per, P.fb_ped.p, P.fb_ped_geo,
                        d_ge.p);
     hipLaunchKernelGGL(k_compress_ge, dim3(cdiv((uint32_t)count, 64)), dim3(64), 0, s, d_ge.p, (uint32_t)count, d_out.p);
     HIP_CHECK(hipGetLastError());
@@ -1733,7 +1740,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       // witness check (:275-284): commit(v_j, r_j) for every opening, compared with the statement's commitments
       hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_bytes, u.d_desc, t, n_gen, nb, m, 1 + t, u.d_cts,
                          u.d_ctg, u.d_ctc);
-      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(FB_THREADS), 0, s, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, P.fb_geo,
+      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(1 + t, P.fb_geo)), 0, s, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, P.fb_geo,
                          u.d_ge);
       hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_ge, nb * m, u.d_commit32);
       hipLaunchKernelGGL(kp_init, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_states, P.d_hg32.p, n, t, nb, u.d_ps);
@@ -1746,7 +1753,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
                            stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
         uint8_t *out = (j < rounds) ? u.d_lr + (size_t)j * nb * 64 : u.d_a1b;
-        hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(FB_THREADS), 0, s, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, P.fb_geo,
+        hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(fb_threads(mn + t + 1, P.fb_geo)), 0, s, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, P.fb_geo,
                            u.d_ge);
         hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);
       }

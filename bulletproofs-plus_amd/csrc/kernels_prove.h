@@ -172,7 +172,7 @@ BPP_D void fb_fetch(niels &q, int &d, const FbStage &st, const fbent *__restrict
 __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx,
                                                        const uint32_t *__restrict__ count, uint32_t stride,
                                                        const fbent *__restrict__ tbl, FbGeom geo, ge *__restrict__ out) {
-  const uint32_t o = blockIdx.x, tid = threadIdx.x;
+  const uint32_t o = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;  // 64, 128 or 256 lanes per output
   const uint32_t n = count[o];
   __shared__ FbShared sh;
   ge acc;
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ sc
   for (uint32_t base = 0; base < n; base += FB_CHUNK) {
     const uint32_t cn = n - base < FB_CHUNK ? n - base : FB_CHUNK;
     __syncthreads();  // the previous chunk's digits are no longer read
-    for (uint32_t i = tid; i < cn; i += FB_THREADS) {
+    for (uint32_t i = tid; i < cn; i += nthr) {
       const sc s = scal[(size_t)o * stride + base + i];
       fb_recode(sh.st.dig + (size_t)i * geo.windows, s, geo);
       sh.st.gi[i] = gidx[(size_t)o * stride + base + i];
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ sc
     while (it < items) {
       niels cur = nxt;
       const int cd = nd;
-      it += FB_THREADS;
+      it += nthr;
       if (it < items) fb_fetch(nxt, nd, sh.st, tbl, geo, it);
       if (cd != 0) {
         niels_cneg(cur, cd < 0);
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ sc
   __syncthreads();
   sh.red[tid] = acc;
   __syncthreads();
-  for (uint32_t off = FB_THREADS / 2; off >= 1; off >>= 1) {
+  for (uint32_t off = nthr / 2; off >= 1; off >>= 1) {
     if (tid < off) {
       ge x = sh.red[tid], y2 = sh.red[tid + off];
       ge_add(x, x, y2);
