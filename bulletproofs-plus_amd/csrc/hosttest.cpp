@@ -28,6 +28,10 @@ int ht_decompress_compress(const uint8_t in[32], uint8_t out[32]) {
 int ht_from_niels(const uint8_t in[32], int neg, uint8_t out[32]) {
   niels n; if (!ristretto_decompress(n, in)) return 0;
   niels m = n; niels_cneg(m, neg != 0); ge p; ge_from_niels(p, m); ge_madd(p, p, n); ristretto_compress(out, p); return 1; }
+// the device's decoding schedule (k_decompress) on the host: same verdict and point as the plain schedule
+int ht_decompress_lean(const uint8_t in[32], uint8_t out[32]) {
+  niels n; if (!ristretto_decompress_lean(n, in)) return 0;
+  ge p; ge_identity(p); ge_madd(p, p, n); ristretto_compress(out, p); return 1; }
 void ht_from_uniform(const uint8_t in[64], uint8_t out[32]) { ge p; ristretto_from_uniform(p, in); ristretto_compress(out, p); }
 // out = compress(k*P) by double-and-add using dbl/madd/add; also exercises msub and ge_to_niels
 int ht_scalarmult(const uint8_t k[32], const uint8_t pin[32], uint8_t out[32]) {

@@ -250,7 +250,7 @@ BPP_HD bool ristretto_decompress(niels &out, const uint8_t s_bytes[32]) {
 // Same function, scheduled for registers: the 254-squaring chain runs with only (w, accumulator) live; everything the
 // epilogue needs (u1, u2, v) is RECOMPUTED from the input bytes afterwards (6 multiplications out of ~270) instead of
 // being kept alive across the chain.  The compiler barrier keeps it from merging the two computations again.
-BPP_D bool ristretto_decompress_lean(niels &out, const uint8_t *s_bytes) {
+BPP_HD bool ristretto_decompress_lean(niels &out, const uint8_t *s_bytes) {
   fe r;
   {
     fe s, ss, u1, u2, u2_sqr, v, t, one, d, w, v3, v7;
@@ -269,13 +269,13 @@ BPP_D bool ristretto_decompress_lean(niels &out, const uint8_t *s_bytes) {
     fe_neg(t, t);
     fe_sub(v, t, u2_sqr);
     fe_mul(w, v, u2_sqr);
-    // SQRT_RATIO_M1(1, w): r = w^3 * (w^7)^((p-5)/8)
-    fe_sq(v3, w);
-    fe_mul(v3, v3, w);
-    fe_sq(v7, v3);
-    fe_mul(v7, v7, w);
-    fe_pow22523(r, v7);
-    fe_mul(r, r, v3);
+    // SQRT_RATIO_M1(1, w).  dalek computes r0 = w^3 (w^7)^((p-5)/8); r = w^((p-5)/8) differs from it by the factor
+    // c^3, c = w^((p-1)/4) a fourth root of unity, so w r^2 = c where dalek sees c^7 = c^-1: "1" and "-1" (w is a square:
+    // the root is r resp. r*sqrt(-1)) are recognised identically and give the same non-negative root; for a non-square
+    // the decoding fails either way and r is not used.  Saves 2 squarings + 3 multiplications per point.
+    fe_pow22523(r, w);
+    (void)v3;
+    (void)v7;
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" ::: "memory");

@@ -80,6 +80,8 @@ def test_ristretto(ht):
         assert o.raw == pt.compress()
         o2 = _buf()
         assert ht.ht_decompress_compress(o.raw, o2) == 1 and o2.raw == o.raw
+        o5 = _buf()
+        assert ht.ht_decompress_lean(o.raw, o5) == 1 and o5.raw == o.raw
         o4 = _buf()
         assert ht.ht_from_niels(o.raw, 0, o4) == 1 and o4.raw == (pt * 2).compress()  # ge_from_niels(P) + P
         assert ht.ht_from_niels(o.raw, 1, o4) == 1 and o4.raw == bytes(32)            # ge_from_niels(-P) + P
@@ -89,8 +91,9 @@ def test_ristretto(ht):
     for i in range(120):  # random strings: accept/reject must agree with the oracle
         s = _r(b"bad", i)
         assert (ht.ht_decompress_compress(s, _buf()) == 1) == (C.decompress(s) is not None)
+        assert (ht.ht_decompress_lean(s, _buf()) == 1) == (C.decompress(s) is not None)
     for s in [P.to_bytes(32, "little"), (1).to_bytes(32, "little"), b"\xff" * 32, (2**255).to_bytes(32, "little")]:
-        assert ht.ht_decompress_compress(s, _buf()) == 0
+        assert ht.ht_decompress_compress(s, _buf()) == 0 and ht.ht_decompress_lean(s, _buf()) == 0
     assert ht.ht_is_identity(bytes(32)) == 1 and ht.ht_is_identity(C.BASEPOINT.compress()) == 0
 
 
