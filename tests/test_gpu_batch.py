@@ -10,7 +10,7 @@ from oracle.pyref import curve as C
 from oracle.pyref import merlin as M
 from oracle.pyref import protocol as O
 from tests.golden.loader import load_bench
-from tests.helpers import make_batch, oracle_verify_trace, sb
+from tests.helpers import LABEL, make_batch, oracle_verify_trace, sb
 
 pytestmark = pytest.mark.gpu
 
@@ -281,3 +281,63 @@ def test_verify_with_external_challenges(bpp, engine):
     other_rng = [hashlib.sha256(x).digest() for x in tr["rng_outputs"]]
     assert bpp.verify_batch_with_challenges(c.statements_public, c.proofs, chal, other_rng, bpp.VerifyAction.VerifyOnly,
                                             chunk=0) == [None] * 3
+
+
+def test_concurrent_contexts(bpp):
+    """four host threads, each with its own context / stream (the C ABI is thread-safe per context; contexts share the
+    host chain pool): three verify different valid inputs repeatedly, one keeps hitting an invalid proof, one proves;
+    every thread must see exactly its own outcome"""
+    import threading
+    K, A = bpp.ProofErrorKind, bpp.VerifyAction
+    results, errors = {}, []
+
+    def verifier(idx, bad):
+        try:
+            eng = bpp.Engine(0)
+            c = make_batch(bpp, eng, 16, [1] * (24 + idx), 1, seed=b"conc-%d" % idx)
+            proofs = list(c.proofs)
+            if bad:
+                raw = bytearray(proofs[5].to_bytes())
+                raw[1 + 32 * 1 + 96] ^= 1  # r1: only the final MSM notices
+                proofs[5] = bpp.RangeProof.from_bytes(bytes(raw))
+            out = []
+            for it in range(6):
+                try:
+                    masks = bpp.RangeProof.verify_batch(c.transcripts(), c.statements_private, proofs, A.RecoverAndVerify)
+                    out.append(("ok", [m.blindings() for m in masks] == [[sb(x) for x in em] for em in c.expected_masks]))
+                except bpp.ProofError as e:
+                    out.append(("err", int(e.kind)))
+            results[idx] = out
+            eng.close()
+        except Exception as e:  # noqa: BLE001 - surfaced below
+            errors.append((idx, repr(e)))
+
+    def prover(idx):
+        try:
+            from tests.test_gpu_prove import _inputs
+            from oracle import cport
+            eng = bpp.Engine(0)
+            params = bpp.RangeParameters.init(16, 2, bpp.create_pedersen_gens_with_extension_degree(1), engine=eng)
+            sts, wits, exts, raw = _inputs(bpp, params, 16, 2, 1, 3, b"conc-prove", "third")
+            cp = cport.Params(16, 2, 1)
+            want = [cp.prove(LABEL, raw["vals"][i], raw["blinds"][i], raw["mins"][i], raw["seeds"][i], exts[i])[0] for i in range(3)]
+            cp.close()
+            out = []
+            for it in range(4):
+                got = bpp.RangeProof.prove_batch([bpp.Transcript.new(LABEL)] * 3, sts, wits, exts)
+                out.append(("ok", [g.to_bytes() for g in got] == want))
+            results[idx] = out
+            eng.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((idx, repr(e)))
+
+    threads = [threading.Thread(target=verifier, args=(0, False)), threading.Thread(target=verifier, args=(1, True)),
+               threading.Thread(target=verifier, args=(2, False)), threading.Thread(target=prover, args=(3,))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert results[0] == [("ok", True)] * 6 and results[2] == [("ok", True)] * 6
+    assert results[1] == [("err", int(K.VerificationFailed))] * 6
+    assert results[3] == [("ok", True)] * 4
