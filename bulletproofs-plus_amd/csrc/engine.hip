@@ -296,7 +296,8 @@ void msm_prepare(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &sidx, co
   for (uint32_t g = 0; g < G; g++) maxg = std::max(maxg, goff[g + 1] - goff[g]);
   MsmPlan plan;
   plan.c = choose_window(maxg);
-  plan.K = (254 + plan.c - 1) / plan.c;
+  plan.K = (253 + plan.c - 1) / plan.c;
+  plan.K_wide = plan.K - (plan.K * plan.c - 253);  // 253 = K_wide * c + (K - K_wide) * (c - 1)
   plan.nb = 1u << (plan.c - 1);
   plan.G = G;
   plan.n_terms = n;

@@ -20,9 +20,14 @@
 
 namespace bpp {
 
+// Window layout: 253 = K_wide * c + (K - K_wide) * (c - 1).  Canonical scalars are < l < 2^252 + 2^125, so 253 bits and
+// no carry out of the top window; with equal widths the top window would hold only 253 mod c bits and concentrate every
+// term of a group in a handful of buckets (one lane adding thousands of points in sequence) unless c divides 253 (c =
+// 11).  Windows of c-1 bits simply leave the upper half of their 2^(c-1) buckets empty.
 struct MsmPlan {
-  uint32_t c;        // window bits
+  uint32_t c;        // window bits (wide windows)
   uint32_t K;        // windows
+  uint32_t K_wide;   // windows [0, K_wide) have c bits, windows [K_wide, K) have c - 1
   uint32_t nb;       // buckets per window = 2^(c-1)
   uint32_t G;        // groups
   uint32_t n_terms;  // total terms
@@ -48,27 +53,28 @@ __global__ void __launch_bounds__(256) k_msm_digits(const sc *__restrict__ scala
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ng) return;
   const sc s = scalars[term_sidx[t0 + i]];
-  const uint32_t c = plan.c, K = plan.K, nb = plan.nb;
+  const uint32_t K = plan.K;
   int16_t *out = digitsT + (size_t)t0 * K + i;
-  uint32_t carry = 0;
+  uint32_t carry = 0, bit = 0;
   for (uint32_t k = 0; k < K; k++) {
-    const uint32_t bit = k * c;
+    const uint32_t wd = k < plan.K_wide ? plan.c : plan.c - 1;  // this window's width
     const uint32_t wi = bit >> 5, sh = bit & 31;
     uint32_t raw = 0;
     if (wi < 8) {
       uint64_t two = (uint64_t)s.v[wi] | ((wi + 1 < 8) ? ((uint64_t)s.v[wi + 1] << 32) : 0ULL);
-      raw = (uint32_t)(two >> sh) & ((1u << c) - 1u);
+      raw = (uint32_t)(two >> sh) & ((1u << wd) - 1u);
     }
     uint32_t v = raw + carry;
     int32_t dgt;
-    if (v > nb) {  // nb = 2^(c-1): digits in (-2^(c-1), 2^(c-1)]
-      dgt = (int32_t)v - (int32_t)(1u << c);
+    if (v > (1u << (wd - 1))) {  // digits in (-2^(wd-1), 2^(wd-1)]
+      dgt = (int32_t)v - (int32_t)(1u << wd);
       carry = 1;
     } else {
       dgt = (int32_t)v;
       carry = 0;
     }
     out[(size_t)k * ng] = (int16_t)dgt;
+    bit += wd;
   }
 }
 
@@ -322,7 +328,7 @@ __global__ void __launch_bounds__(64) k_msm_final(const ge *__restrict__ W, MsmP
   const ge *w = W + (size_t)g * plan.K;
   ge acc = w[plan.K - 1];
   for (int k = (int)plan.K - 2; k >= 0; k--) {
-    ge_dbl_n(acc, acc, (int)plan.c);
+    ge_dbl_n(acc, acc, (uint32_t)k < plan.K_wide ? (int)plan.c : (int)plan.c - 1);  // width of window k
     const ge x = w[k];
     ge_add(acc, acc, x);
   }
