@@ -1008,8 +1008,16 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
     HIP_CHECK(hipMemsetAsync(b.status.p, 0, (size_t)b.B * 4, s));
     if (!b.uniform_rounds) HIP_CHECK(hipMemsetAsync(b.chal.p, 0, (size_t)b.B * b.cs * sizeof(sc), s));  // trace padding only
     tm.mark(M_START);
-    hipLaunchKernelGGL(k_transcripts, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.states.p,
-                       P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p);
+    // small inputs: one proof per wavefront (latency); large inputs: one proof per lane (issue slots)
+    const char *fw = getenv("BPP_TRANSCRIPTS_WAVE");  // tests force either kernel
+    const int force_wave = fw ? atoi(fw) : -1;
+    const bool wave = force_wave >= 0 ? force_wave != 0 : b.B <= BPP_TRANSCRIPTS_WAVE_MAX;
+    if (wave)
+      hipLaunchKernelGGL(k_transcripts_wave, dim3(b.B), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.states.p,
+                         P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p);
+    else
+      hipLaunchKernelGGL(k_transcripts, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.states.p,
+                         P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p);
   }
   tm.mark(M_TRANSCRIPTS);
   HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));

@@ -12,6 +12,7 @@
 #pragma once
 #include "blake2b.h"
 #include "merlin.h"
+#include "wstrobe.h"
 #include "point.h"
 #include "scalar.h"
 
@@ -109,6 +110,87 @@ __global__ void __launch_bounds__(64) k_transcripts(const uint8_t *__restrict__ 
   merlin_rng_fill(s, out, 32);
   for (int i = 0; i < 32; i++) rng_out[(size_t)p * 32 + i] = out[i];
   if (!ok) atomicOr(&status[p], BPP_ST_TRANSCRIPT_FAIL);
+}
+
+// The same PASS 1 with one proof per WAVEFRONT on the cooperative sponge of wstrobe.h (state in LDS, 25-lane Keccak-f).
+// Per proof it uses ~7x the issue slots of the one-lane kernel but finishes in a fifth of the time, so the host picks
+// it for small batches (B <= BPP_TRANSCRIPTS_WAVE_MAX), where PASS 1 is pure latency on a nearly idle chip.
+#define BPP_TRANSCRIPTS_WAVE_MAX 4096u
+struct TranscriptLds {
+  uint64_t st[25];
+  uint8_t buf[64];
+};
+__device__ __forceinline__ bool wave_challenge(WStrobe &s, TranscriptLds &L, const KeccakLanes &K, const char *label, uint32_t llen,
+                                               sc &out) {
+  wm_challenge_bytes(s, K, label, llen, L.buf, 64);
+  sc_mont_from_wide(out, L.buf);
+  return !sc_iszero(out);
+}
+__device__ __forceinline__ bool wave_nonzero32(const uint8_t *p32) {
+  return __ballot(threadIdx.x < 32 && p32[threadIdx.x & 31u] != 0) != 0;
+}
+__global__ void __launch_bounds__(64) k_transcripts_wave(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
+                                                         const uint64_t *__restrict__ minvals,
+                                                         const uint8_t *__restrict__ states, const uint8_t *__restrict__ hg32,
+                                                         uint32_t n_bits, uint32_t t, uint32_t B, uint32_t cs,
+                                                         sc *__restrict__ chal, uint8_t *__restrict__ rng_out,
+                                                         uint32_t *__restrict__ status) {
+  const uint32_t p = blockIdx.x, lane = threadIdx.x;
+  if (p >= B) return;
+  __shared__ TranscriptLds L;
+  const KeccakLanes K = keccak_lanes();
+  const ProofDesc d = desc[p];
+  const uint8_t *sb = states + 203u * d.state_idx;
+  for (uint32_t k = lane; k < 200; k += 64) ((uint8_t *)L.st)[k] = sb[k];
+  WStrobe s;
+  s.st = L.st;
+  s.pos = sb[200];
+  s.pos_begin = sb[201];
+  s.cur_flags = sb[202];
+  __syncthreads();
+  bool ok = true;
+  const uint8_t *pr = bytes + d.proof_off;
+  const uint8_t *pd1 = pr + 1;
+  const uint8_t *pA = pr + 1 + 32 * t;
+  const uint8_t *pA1 = pA + 32, *pB = pA + 64, *pr1 = pA + 96, *ps1 = pA + 128, *pLR = pA + 160;
+
+  wm_append_message(s, K, "dom-sep", 7, BytesAt{(const uint8_t *)"Bulletproofs+ Range Proof"}, 25);
+  wm_append_message(s, K, "H", 1, BytesAt{hg32}, 32);
+  for (uint32_t k = 0; k < t; k++) wm_append_message(s, K, "G", 1, BytesAt{hg32 + 32 * (k + 1)}, 32);
+  wm_append_u64(s, K, "N", 1, n_bits);
+  wm_append_u64(s, K, "T", 1, t);
+  wm_append_u64(s, K, "M", 1, d.m);
+  for (uint32_t j = 0; j < d.m; j++) wm_append_message(s, K, "Ci", 2, BytesAt{bytes + d.commit_off + 32 * j}, 32);
+  for (uint32_t j = 0; j < d.m; j++) wm_append_u64(s, K, "vi - minimum_value", 18, minvals[d.minval_idx + j]);
+
+  sc *c = chal + (size_t)p * cs;
+  sc v;
+  ok = ok && wave_nonzero32(pA);
+  wm_append_message(s, K, "A", 1, BytesAt{pA}, 32);
+  ok = wave_challenge(s, L, K, "y", 1, v) && ok;
+  if (lane == 0) c[0] = v;
+  ok = wave_challenge(s, L, K, "z", 1, v) && ok;
+  if (lane == 0) c[1] = v;
+  for (uint32_t j = 0; j < d.rounds; j++) {
+    ok = ok && wave_nonzero32(pLR + 64 * j) && wave_nonzero32(pLR + 64 * j + 32);
+    wm_append_message(s, K, "L", 1, BytesAt{pLR + 64 * j}, 32);
+    wm_append_message(s, K, "R", 1, BytesAt{pLR + 64 * j + 32}, 32);
+    ok = wave_challenge(s, L, K, "e", 1, v) && ok;
+    if (lane == 0) c[2 + j] = v;
+  }
+  ok = ok && wave_nonzero32(pA1) && wave_nonzero32(pB);
+  wm_append_message(s, K, "A1", 2, BytesAt{pA1}, 32);
+  wm_append_message(s, K, "B", 1, BytesAt{pB}, 32);
+  ok = wave_challenge(s, L, K, "e", 1, v) && ok;
+  if (lane == 0) c[2 + d.rounds] = v;
+  // to_verifier_rng (src/transcripts.rs:166-179) + NullRng finalize + 32 bytes (src/range_proof.rs:845-848)
+  wm_append_message(s, K, "r1", 2, BytesAt{pr1}, 32);
+  wm_append_message(s, K, "s1", 2, BytesAt{ps1}, 32);
+  for (uint32_t k = 0; k < t; k++) wm_append_message(s, K, "d1", 2, BytesAt{pd1 + 32 * k}, 32);
+  wm_rng_finalize(s, K, ZeroAt{});
+  wm_rng_fill(s, K, L.buf, 32);
+  if (lane < 32) rng_out[(size_t)p * 32 + lane] = L.buf[lane];
+  if (!ok && lane == 0) atomicOr(&status[p], BPP_ST_TRANSCRIPT_FAIL);
 }
 
 #ifndef BPP_DECOMPRESS_WAVES

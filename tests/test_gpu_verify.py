@@ -139,3 +139,25 @@ def test_intermediates_bit_exact(bpp, engine, n, batch, t):
     assert rb.trace(5) == b"".join(sb(x) for x in tr["dynamic_scalars"])
     assert rb.trace(6) == tr["msm_result"] == bytes(32)
     rb.close()
+
+
+@pytest.mark.parametrize("wave", ["0", "1"])
+def test_both_pass1_kernels(bpp, engine, monkeypatch, wave):
+    """PASS 1 has a one-lane-per-proof kernel (large inputs) and a one-wavefront-per-proof kernel on the cooperative
+    sponge (small inputs); force each: challenges and transcript-RNG bytes must equal the oracle's, identity members must
+    be reported by both"""
+    monkeypatch.setenv("BPP_TRANSCRIPTS_WAVE", wave)
+    case = make_batch(bpp, engine, 16, [1, 2, 1, 4], 2, seed=b"pass1-kernels")
+    _, tr = oracle_verify_trace(case, action=0)
+    rb = bpp.ResidentBatch(case.transcripts(), case.statements_public, case.proofs)
+    rb.verify(bpp.VerifyAction.VerifyOnly, chunk=0)
+    assert rb.trace(1) == trace_challenge_bytes(tr, rb.shape()["max_rounds"])
+    assert rb.trace(2) == b"".join(tr["rng_outputs"])
+    rb.close()
+    raw = bytearray(case.proofs[2].to_bytes())
+    raw[1 + 32 * 2 + 32:1 + 32 * 2 + 64] = bytes(32)  # A1 = identity encoding
+    bad = list(case.proofs)
+    bad[2] = bpp.RangeProof.from_bytes(bytes(raw))
+    with pytest.raises(bpp.ProofError) as e:
+        bpp.RangeProof.verify_batch(case.transcripts(), case.statements_public, bad, bpp.VerifyAction.VerifyOnly)
+    assert e.value.kind == bpp.ProofErrorKind.VerificationFailed
