@@ -352,8 +352,15 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
     hipLaunchKernelGGL(k_msm_window, dim3(cdiv(plan.G * plan.K, 64)), dim3(64), 0, s, w.Q.p, plan, w.W.p);
   }
   if (tm) tm->mark(M_BUCKET);
-  hipLaunchKernelGGL(k_msm_final, dim3(cdiv(plan.G, 64)), dim3(64), 0, s, w.W.p, plan, w.R.p, w.comp32.p,
-                     w.is_identity.p);
+  {
+    const char *fq = getenv("BPP_MSM_FINAL_QUAD");  // tests force either kernel
+    if (fq ? atoi(fq) != 0 : true)
+      hipLaunchKernelGGL(k_msm_final_quad, dim3(cdiv(plan.G, 16)), dim3(64), 0, s, w.W.p, plan, w.R.p, w.comp32.p,
+                         w.is_identity.p);
+    else
+      hipLaunchKernelGGL(k_msm_final, dim3(cdiv(plan.G, 64)), dim3(64), 0, s, w.W.p, plan, w.R.p, w.comp32.p,
+                         w.is_identity.p);
+  }
   if (tm) tm->mark(M_FINAL);
   HIP_CHECK(hipGetLastError());
 }

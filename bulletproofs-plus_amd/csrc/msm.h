@@ -339,6 +339,130 @@ __global__ void __launch_bounds__(64) k_msm_final(const ge *__restrict__ W, MsmP
   is_identity[g] = ge_is_ristretto_identity(acc) ? 1u : 0u;
 }
 
+// ---- The same final step with FOUR lanes per group (one quad).  The Horner recurrence is 253 sequential doublings: on
+// one lane that is ~1000 dependent instructions per doubling and 0.7 ms whatever the batch size.  A doubling is four
+// independent squarings (X^2, Y^2, Z^2, (X+Y)^2) followed by four independent products (E*F, G*H, F*G, E*H), and so is
+// an addition (two rounds of four products): each lane of the quad does one of them and the operands travel by
+// quad-permute DPP moves (no LDS).  Lane q keeps coordinate q of the accumulator (X, Y, Z, T).  Same field operations in
+// the same order as ge_dbl_n / ge_add, so the result is bit-identical.  grid = ceil(G / 16) blocks of 64 lanes. ----
+template <int S>
+__device__ __forceinline__ void quad_bcast(fe &r, const fe &v) {
+#pragma unroll
+  for (int i = 0; i < 10; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.v[i], S * 0x55, 0xf, 0xf, false);
+}
+// per-lane choice among four field elements by bit masks (ternaries get turned into divergent branches with the
+// multiplication duplicated in every arm, which serialises the four lanes again)
+struct QuadMask {
+  uint32_t m0, m1, m2, m3;
+};
+__device__ __forceinline__ QuadMask quad_mask(uint32_t q) {
+  QuadMask k;
+  k.m0 = 0u - (uint32_t)(q == 0);
+  k.m1 = 0u - (uint32_t)(q == 1);
+  k.m2 = 0u - (uint32_t)(q == 2);
+  k.m3 = 0u - (uint32_t)(q == 3);
+  // keep the masks opaque to the optimiser
+  asm volatile("" : "+v"(k.m0), "+v"(k.m1), "+v"(k.m2), "+v"(k.m3));
+  return k;
+}
+__device__ __forceinline__ void fe_sel4(fe &r, const QuadMask &k, const fe &a0, const fe &a1, const fe &a2, const fe &a3) {
+#pragma unroll
+  for (int i = 0; i < 10; i++) r.v[i] = (a0.v[i] & k.m0) | (a1.v[i] & k.m1) | (a2.v[i] & k.m2) | (a3.v[i] & k.m3);
+}
+// second round shared by doubling and addition: lane q returns (E*F, G*H, F*G, E*H)[q]
+__device__ __forceinline__ void quad_efgh(fe &m, const QuadMask &q, const fe &E, const fe &F, const fe &G, const fe &H) {
+  fe l, r;
+  fe_sel4(l, q, E, G, F, E);
+  fe_sel4(r, q, F, H, G, H);
+  fe_mul(m, l, r);
+}
+
+__global__ void __launch_bounds__(64) k_msm_final_quad(const ge *__restrict__ W, MsmPlan plan, ge *__restrict__ R,
+                                                       uint8_t *__restrict__ comp32, uint32_t *__restrict__ is_identity) {
+  const uint32_t lane = threadIdx.x, qi = lane & 3u;
+  const QuadMask q = quad_mask(qi);
+  const uint32_t g = blockIdx.x * 16u + (lane >> 2);
+  const bool active = g < plan.G;
+  const ge *w = W + (size_t)(active ? g : plan.G - 1) * plan.K;  // idle quads shadow the last group and write nothing
+  fe m;
+  {
+    const ge top = w[plan.K - 1];
+    fe_sel4(m, q, top.X, top.Y, top.Z, top.T);
+  }
+  fe d2, one;
+  fe_const(d2, FE_D2);
+  fe_1(one);
+  for (int k = (int)plan.K - 2; k >= 0; k--) {
+    const int n = (uint32_t)k < plan.K_wide ? (int)plan.c : (int)plan.c - 1;  // width of window k
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+      fe x, y, v, s2;
+      quad_bcast<0>(x, m);
+      quad_bcast<1>(y, m);
+      fe_add(v, x, y);
+#pragma unroll
+      for (int j = 0; j < 10; j++) v.v[j] = (v.v[j] & q.m3) | (m.v[j] & ~q.m3);  // X, Y, Z, X + Y
+      fe_sq(s2, v);
+      fe a, b, c, t, e, f, gg, h;
+      quad_bcast<0>(a, s2);
+      quad_bcast<1>(b, s2);
+      quad_bcast<2>(c, s2);
+      quad_bcast<3>(t, s2);
+      fe_add(c, c, c);
+      fe_add(h, a, b);
+      fe_sub(e, h, t);
+      fe_sub(gg, a, b);
+      fe_add(f, c, gg);
+      fe_carry(f);
+      fe_carry(h);
+      quad_efgh(m, q, e, f, gg, h);
+    }
+    // acc += W_k
+    {
+      fe X, Y, Z, T;
+      quad_bcast<0>(X, m);
+      quad_bcast<1>(Y, m);
+      quad_bcast<2>(Z, m);
+      quad_bcast<3>(T, m);
+      const ge wk = w[k];
+      fe l0, r0, l1, r1, l, r, s2;
+      fe_sub(l0, Y, X);
+      fe_sub(r0, wk.Y, wk.X);
+      fe_add(l1, Y, X);
+      fe_add(r1, wk.Y, wk.X);
+      fe_sel4(l, q, l0, l1, T, Z);
+      fe_sel4(r, q, r0, r1, wk.T, wk.Z);
+      fe_mul(s2, l, r);  // a, b, T*T', Z*Z'
+      fe_sel4(r, q, one, one, d2, one);
+      fe_mul(s2, s2, r);  // lane 2: c = T*T'*2d; the others multiply by one
+      fe a, b, c, d, e, f, gg, h;
+      quad_bcast<0>(a, s2);
+      quad_bcast<1>(b, s2);
+      quad_bcast<2>(c, s2);
+      quad_bcast<3>(d, s2);
+      fe_add(d, d, d);
+      fe_sub(e, b, a);
+      fe_sub(f, d, c);
+      fe_add(gg, d, c);
+      fe_add(h, b, a);
+      fe_carry(gg);
+      quad_efgh(m, q, e, f, gg, h);
+    }
+  }
+  ge acc;
+  quad_bcast<0>(acc.X, m);
+  quad_bcast<1>(acc.Y, m);
+  quad_bcast<2>(acc.Z, m);
+  quad_bcast<3>(acc.T, m);
+  if (active && qi == 0) {
+    R[g] = acc;
+    uint8_t c32[32];
+    ristretto_compress(c32, acc);
+    for (int i = 0; i < 32; i++) comp32[(size_t)g * 32 + i] = c32[i];
+    is_identity[g] = ge_is_ristretto_identity(acc) ? 1u : 0u;
+  }
+}
+
 // extended point -> 128 canonical bytes (X,Y,Z,T) and back, for the cross-GPU accumulator exchange
 __global__ void k_ge_to_bytes(const ge *__restrict__ R, uint32_t n, uint8_t *__restrict__ out128) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
