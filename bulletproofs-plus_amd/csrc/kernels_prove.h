@@ -216,18 +216,6 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ sc
   if (tid == 0) out[o] = sh.red[0];
 }
 
-// one lane per point: extended coordinates -> 32-byte Ristretto encoding
-__global__ void __launch_bounds__(64) k_compress_ge(const ge *__restrict__ in, uint32_t count, uint8_t *__restrict__ out32) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  uint8_t c32[32];
-  ristretto_compress(c32, in[i]);
-  uint32_t *o = (uint32_t *)(out32 + (size_t)i * 32);
-#pragma unroll
-  for (int k = 0; k < 8; k++)
-    o[k] = (uint32_t)c32[4 * k] | ((uint32_t)c32[4 * k + 1] << 8) | ((uint32_t)c32[4 * k + 2] << 16) | ((uint32_t)c32[4 * k + 3] << 24);
-}
-
 // ---------------------------------------------------------------- per-proof prover state
 struct ProveDesc {
   uint32_t m;           // aggregation factor (uniform over a prove batch)

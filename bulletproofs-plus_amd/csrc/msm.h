@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(64) k_msm_window(const ge *__restrict__ Q, Msm
 
 // ---- R[g] = sum_k 2^(ck) W[g][k]; outputs: extended point, canonical encoding, identity flag ----
 __global__ void __launch_bounds__(64) k_msm_final(const ge *__restrict__ W, MsmPlan plan, ge *__restrict__ R,
-                                                  uint8_t *__restrict__ comp32, uint32_t *__restrict__ is_identity) {
+                                                  uint32_t *__restrict__ is_identity) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= plan.G) return;
   const ge *w = W + (size_t)g * plan.K;
@@ -332,10 +332,7 @@ __global__ void __launch_bounds__(64) k_msm_final(const ge *__restrict__ W, MsmP
     const ge x = w[k];
     ge_add(acc, acc, x);
   }
-  R[g] = acc;
-  uint8_t c32[32];
-  ristretto_compress(c32, acc);
-  for (int i = 0; i < 32; i++) comp32[(size_t)g * 32 + i] = c32[i];
+  R[g] = acc;  // the 32-byte encoding is produced on demand (k_compress_ge): verification only needs the identity test
   is_identity[g] = ge_is_ristretto_identity(acc) ? 1u : 0u;
 }
 
@@ -378,7 +375,7 @@ __device__ __forceinline__ void quad_efgh(fe &m, const QuadMask &q, const fe &E,
 }
 
 __global__ void __launch_bounds__(64) k_msm_final_quad(const ge *__restrict__ W, MsmPlan plan, ge *__restrict__ R,
-                                                       uint8_t *__restrict__ comp32, uint32_t *__restrict__ is_identity) {
+                                                       uint32_t *__restrict__ is_identity) {
   const uint32_t lane = threadIdx.x, qi = lane & 3u;
   const QuadMask q = quad_mask(qi);
   const uint32_t g = blockIdx.x * 16u + (lane >> 2);
@@ -456,11 +453,20 @@ __global__ void __launch_bounds__(64) k_msm_final_quad(const ge *__restrict__ W,
   quad_bcast<3>(acc.T, m);
   if (active && qi == 0) {
     R[g] = acc;
-    uint8_t c32[32];
-    ristretto_compress(c32, acc);
-    for (int i = 0; i < 32; i++) comp32[(size_t)g * 32 + i] = c32[i];
     is_identity[g] = ge_is_ristretto_identity(acc) ? 1u : 0u;
   }
+}
+
+// one lane per point: extended coordinates -> 32-byte Ristretto encoding
+__global__ void __launch_bounds__(64) k_compress_ge(const ge *__restrict__ in, uint32_t count, uint8_t *__restrict__ out32) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint8_t c32[32];
+  ristretto_compress(c32, in[i]);
+  uint32_t *o = (uint32_t *)(out32 + (size_t)i * 32);
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    o[k] = (uint32_t)c32[4 * k] | ((uint32_t)c32[4 * k + 1] << 8) | ((uint32_t)c32[4 * k + 2] << 16) | ((uint32_t)c32[4 * k + 3] << 24);
 }
 
 // extended point -> 128 canonical bytes (X,Y,Z,T) and back, for the cross-GPU accumulator exchange
