@@ -263,29 +263,63 @@ BPP_HD void fe_abs(fe &h, const fe &f) {
 }
 
 // z^(2^252 - 3)
+// Scheduling fence: the ten limbs pass through an empty asm, so the instruction scheduler cannot interleave the field
+// operation before it with the one after it.  The addition chains below are strictly sequential, yet without fences
+// the scheduler overlaps neighbouring operations until fe_pow22523 alone is allocated 364 VGPRs (k_decompress: 256 +
+// 218 spilled); with them it is ~150 and the kernels around it fit 3-4 wavefronts per SIMD without scratch.
+BPP_HD void fe_fence(fe &x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3]), "+v"(x.v[4]), "+v"(x.v[5]), "+v"(x.v[6]), "+v"(x.v[7]),
+               "+v"(x.v[8]), "+v"(x.v[9]));
+#else
+  (void)x;
+#endif
+}
+
 BPP_HD void fe_pow22523(fe &out, const fe &z) {
   fe t0, t1, t2;
   fe_sq(t0, z);          // 2
+  fe_fence(t0);
   fe_sqn(t1, t0, 2);     // 8
+  fe_fence(t1);
   fe_mul(t1, z, t1);     // 9
+  fe_fence(t1);
   fe_mul(t0, t0, t1);    // 11
+  fe_fence(t0);
   fe_sq(t0, t0);         // 22
+  fe_fence(t0);
   fe_mul(t0, t1, t0);    // 31 = 2^5 - 1
+  fe_fence(t0);
   fe_sqn(t1, t0, 5);
+  fe_fence(t1);
   fe_mul(t0, t1, t0);    // 2^10 - 1
+  fe_fence(t0);
   fe_sqn(t1, t0, 10);
+  fe_fence(t1);
   fe_mul(t1, t1, t0);    // 2^20 - 1
+  fe_fence(t1);
   fe_sqn(t2, t1, 20);
+  fe_fence(t2);
   fe_mul(t1, t2, t1);    // 2^40 - 1
+  fe_fence(t1);
   fe_sqn(t1, t1, 10);
+  fe_fence(t1);
   fe_mul(t0, t1, t0);    // 2^50 - 1
+  fe_fence(t0);
   fe_sqn(t1, t0, 50);
+  fe_fence(t1);
   fe_mul(t1, t1, t0);    // 2^100 - 1
+  fe_fence(t1);
   fe_sqn(t2, t1, 100);
+  fe_fence(t2);
   fe_mul(t1, t2, t1);    // 2^200 - 1
+  fe_fence(t1);
   fe_sqn(t1, t1, 50);
+  fe_fence(t1);
   fe_mul(t0, t1, t0);    // 2^250 - 1
+  fe_fence(t0);
   fe_sqn(t0, t0, 2);     // 2^252 - 4
+  fe_fence(t0);
   fe_mul(out, t0, z);    // 2^252 - 3
 }
 
@@ -293,26 +327,47 @@ BPP_HD void fe_pow22523(fe &out, const fe &z) {
 BPP_HD void fe_invert(fe &out, const fe &z) {
   fe t0, t1, t2, t3;
   fe_sq(t0, z);          // 2
+  fe_fence(t0);
   fe_sqn(t1, t0, 2);     // 8
+  fe_fence(t1);
   fe_mul(t1, z, t1);     // 9
+  fe_fence(t1);
   fe_mul(t0, t0, t1);    // 11
+  fe_fence(t0);
   fe_sq(t2, t0);         // 22
+  fe_fence(t2);
   fe_mul(t1, t1, t2);    // 31
+  fe_fence(t1);
   fe_sqn(t2, t1, 5);
+  fe_fence(t2);
   fe_mul(t1, t2, t1);    // 2^10 - 1
+  fe_fence(t1);
   fe_sqn(t2, t1, 10);
+  fe_fence(t2);
   fe_mul(t2, t2, t1);    // 2^20 - 1
+  fe_fence(t2);
   fe_sqn(t3, t2, 20);
+  fe_fence(t3);
   fe_mul(t2, t3, t2);    // 2^40 - 1
+  fe_fence(t2);
   fe_sqn(t2, t2, 10);
+  fe_fence(t2);
   fe_mul(t1, t2, t1);    // 2^50 - 1
+  fe_fence(t1);
   fe_sqn(t2, t1, 50);
+  fe_fence(t2);
   fe_mul(t2, t2, t1);    // 2^100 - 1
+  fe_fence(t2);
   fe_sqn(t3, t2, 100);
+  fe_fence(t3);
   fe_mul(t2, t3, t2);    // 2^200 - 1
+  fe_fence(t2);
   fe_sqn(t2, t2, 50);
+  fe_fence(t2);
   fe_mul(t1, t2, t1);    // 2^250 - 1
+  fe_fence(t1);
   fe_sqn(t1, t1, 5);     // 2^255 - 32
+  fe_fence(t1);
   fe_mul(out, t1, t0);   // 2^255 - 21
 }
 
