@@ -160,8 +160,8 @@ BPP_HD void fe_sqn(fe &h, const fe &f, int n) {
   for (int i = 1; i < n; i++) fe_sq(h, h);
 }
 
-// canonical little-endian bytes
-BPP_HD void fe_tobytes(uint8_t s[32], const fe &f) {
+// canonical value as 8 little-endian 32-bit words (the primitive: byte arrays cost one register per byte on the GPU)
+BPP_HD void fe_towords(uint32_t w[8], const fe &f) {
   fe h;
   fe_copy(h, f);
   fe_carry(h);
@@ -180,7 +180,6 @@ BPP_HD void fe_tobytes(uint8_t s[32], const fe &f) {
   }
   h.v[9] &= 0x1ffffffu;
   // pack 26/25-bit limbs at bit offsets 0,26,51,77,102,128,153,179,204,230
-  uint32_t w[8];
   w[0] = h.v[0] | (h.v[1] << 26);
   w[1] = (h.v[1] >> 6) | (h.v[2] << 19);
   w[2] = (h.v[2] >> 13) | (h.v[3] << 13);
@@ -189,6 +188,12 @@ BPP_HD void fe_tobytes(uint8_t s[32], const fe &f) {
   w[5] = (h.v[6] >> 7) | (h.v[7] << 19);
   w[6] = (h.v[7] >> 13) | (h.v[8] << 12);
   w[7] = (h.v[8] >> 20) | (h.v[9] << 6);
+}
+
+// canonical little-endian bytes
+BPP_HD void fe_tobytes(uint8_t s[32], const fe &f) {
+  uint32_t w[8];
+  fe_towords(w, f);
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     s[4 * i + 0] = (uint8_t)(w[i]);
@@ -198,23 +203,8 @@ BPP_HD void fe_tobytes(uint8_t s[32], const fe &f) {
   }
 }
 
-// canonical value as 8 little-endian words (same as fe_tobytes, word form)
-BPP_HD void fe_towords(uint32_t w[8], const fe &f) {
-  uint8_t s[32];
-  fe_tobytes(s, f);
-#pragma unroll
-  for (int i = 0; i < 8; i++)
-    w[i] = (uint32_t)s[4 * i] | ((uint32_t)s[4 * i + 1] << 8) | ((uint32_t)s[4 * i + 2] << 16) |
-           ((uint32_t)s[4 * i + 3] << 24);
-}
-
 // bit 255 ignored (dalek FieldElement::from_bytes)
-BPP_HD void fe_frombytes(fe &h, const uint8_t s[32]) {
-  uint32_t w[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++)
-    w[i] = (uint32_t)s[4 * i] | ((uint32_t)s[4 * i + 1] << 8) | ((uint32_t)s[4 * i + 2] << 16) |
-           ((uint32_t)s[4 * i + 3] << 24);
+BPP_HD void fe_fromwords(fe &h, const uint32_t w[8]) {
   h.v[0] = w[0] & 0x3ffffffu;
   h.v[1] = ((w[0] >> 26) | (w[1] << 6)) & 0x1ffffffu;
   h.v[2] = ((w[1] >> 19) | (w[2] << 13)) & 0x3ffffffu;
@@ -226,19 +216,27 @@ BPP_HD void fe_frombytes(fe &h, const uint8_t s[32]) {
   h.v[8] = ((w[6] >> 12) | (w[7] << 20)) & 0x3ffffffu;
   h.v[9] = (w[7] >> 6) & 0x1ffffffu;
 }
+BPP_HD void fe_frombytes(fe &h, const uint8_t s[32]) {
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    w[i] = (uint32_t)s[4 * i] | ((uint32_t)s[4 * i + 1] << 8) | ((uint32_t)s[4 * i + 2] << 16) |
+           ((uint32_t)s[4 * i + 3] << 24);
+  fe_fromwords(h, w);
+}
 
 BPP_HD bool fe_isnegative(const fe &f) {
-  uint8_t s[32];
-  fe_tobytes(s, f);
-  return s[0] & 1;
+  uint32_t w[8];
+  fe_towords(w, f);
+  return w[0] & 1u;
 }
 
 BPP_HD bool fe_iszero(const fe &f) {
-  uint8_t s[32];
-  fe_tobytes(s, f);
+  uint32_t w[8];
+  fe_towords(w, f);
   uint32_t r = 0;
 #pragma unroll
-  for (int i = 0; i < 32; i++) r |= s[i];
+  for (int i = 0; i < 8; i++) r |= w[i];
   return r == 0;
 }
 

@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(64) k_transcripts_wave(const uint8_t *__restri
 }
 
 #ifndef BPP_DECOMPRESS_WAVES
-#define BPP_DECOMPRESS_WAVES 2  // measured: forcing <= 128 VGPRs (4 waves) spills 2 KB/lane and is slower overall
+#define BPP_DECOMPRESS_WAVES 3  // 168 VGPRs; the ~40 spilled registers are outside the squaring chain
 #endif
 // CompressedRistretto::decompress for every proof point and commitment (src/range_proof.rs:859-866,1067-1109),
 // one lane per point.  src_off[i] = byte offset in bytes[]; owner[i] = proof index | (is_commitment << 31).

@@ -254,21 +254,29 @@ BPP_HD bool ristretto_decompress_lean(niels &out, const uint8_t *s_bytes) {
   fe r;
   {
     fe s, ss, u1, u2, u2_sqr, v, t, one, d, w, v3, v7;
-    uint8_t sb[32];
-    for (int i = 0; i < 32; i++) sb[i] = s_bytes[i];
-    fe_frombytes(s, sb);
+    uint32_t sw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      sw[i] = (uint32_t)s_bytes[4 * i] | ((uint32_t)s_bytes[4 * i + 1] << 8) | ((uint32_t)s_bytes[4 * i + 2] << 16) |
+              ((uint32_t)s_bytes[4 * i + 3] << 24);
+    fe_fromwords(s, sw);
     fe_1(one);
     fe_sq(ss, s);
+  fe_fence(ss);
     fe_sub(u1, one, ss);
     fe_add(u2, one, ss);
     fe_carry(u2);
     fe_sq(u2_sqr, u2);
+  fe_fence(u2_sqr);
     fe_const(d, FE_D);
     fe_sq(t, u1);
+  fe_fence(t);
     fe_mul(t, t, d);
+  fe_fence(t);
     fe_neg(t, t);
     fe_sub(v, t, u2_sqr);
     fe_mul(w, v, u2_sqr);
+  fe_fence(w);
     // SQRT_RATIO_M1(1, w).  dalek computes r0 = w^3 (w^7)^((p-5)/8); r = w^((p-5)/8) differs from it by the factor
     // c^3, c = w^((p-1)/4) a fourth root of unity, so w r^2 = c where dalek sees c^7 = c^-1: "1" and "-1" (w is a square:
     // the root is r resp. r*sqrt(-1)) are recognised identically and give the same non-negative root; for a non-square
@@ -281,27 +289,38 @@ BPP_HD bool ristretto_decompress_lean(niels &out, const uint8_t *s_bytes) {
   asm volatile("" ::: "memory");
 #endif
   fe s, ss, u1, u2, u2_sqr, v, t, one, d, w, check, sqrt_m1, neg_one, neg_i, rp, den_x, den_y, x, y;
-  uint8_t sb[32], chk[32];
-  for (int i = 0; i < 32; i++) sb[i] = s_bytes[i];
-  fe_frombytes(s, sb);
-  fe_tobytes(chk, s);
+  uint32_t sw[8], chk[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    sw[i] = (uint32_t)s_bytes[4 * i] | ((uint32_t)s_bytes[4 * i + 1] << 8) | ((uint32_t)s_bytes[4 * i + 2] << 16) |
+            ((uint32_t)s_bytes[4 * i + 3] << 24);
+  fe_fromwords(s, sw);
+  fe_towords(chk, s);
   uint32_t diff = 0;
-  for (int i = 0; i < 32; i++) diff |= (uint32_t)(chk[i] ^ sb[i]);
-  bool ok = (diff == 0) && ((sb[0] & 1) == 0);
+#pragma unroll
+  for (int i = 0; i < 8; i++) diff |= chk[i] ^ sw[i];  // canonical: re-encoding gives the same 256 bits (bit 255 clear)
+  bool ok = (diff == 0) && ((sw[0] & 1u) == 0);
   fe_1(one);
   fe_sq(ss, s);
+  fe_fence(ss);
   fe_sub(u1, one, ss);
   fe_add(u2, one, ss);
   fe_carry(u2);
   fe_sq(u2_sqr, u2);
+  fe_fence(u2_sqr);
   fe_const(d, FE_D);
   fe_sq(t, u1);
+  fe_fence(t);
   fe_mul(t, t, d);
+  fe_fence(t);
   fe_neg(t, t);
   fe_sub(v, t, u2_sqr);
   fe_mul(w, v, u2_sqr);
+  fe_fence(w);
   fe_sq(check, r);
+  fe_fence(check);
   fe_mul(check, check, w);
+  fe_fence(check);
   fe_const(sqrt_m1, FE_SQRT_M1);
   fe_neg(neg_one, one);
   fe_neg(neg_i, sqrt_m1);
@@ -309,17 +328,24 @@ BPP_HD bool ristretto_decompress_lean(niels &out, const uint8_t *s_bytes) {
   const bool flipped_sign = fe_eq(check, neg_one);
   const bool flipped_sign_i = fe_eq(check, neg_i);
   fe_mul(rp, r, sqrt_m1);
+  fe_fence(rp);
   fe_cmov(r, rp, flipped_sign || flipped_sign_i);
   fe_abs(r, r);
   const bool was_square = correct_sign || flipped_sign;
   fe_mul(den_x, r, u2);
+  fe_fence(den_x);
   fe_mul(den_y, r, den_x);
+  fe_fence(den_y);
   fe_mul(den_y, den_y, v);
+  fe_fence(den_y);
   fe_mul(x, s, den_x);
+  fe_fence(x);
   fe_add(x, x, x);
   fe_abs(x, x);
   fe_mul(y, u1, den_y);
+  fe_fence(y);
   fe_mul(t, x, y);
+  fe_fence(t);
   ok = ok && was_square && !fe_isnegative(t) && !fe_iszero(y);
   niels_from_affine(out, x, y);
   return ok;
