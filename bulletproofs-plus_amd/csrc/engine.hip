@@ -199,6 +199,7 @@ struct Batch {
   DevBuf<ProofDesc> d_desc;
   DevBuf<uint64_t> minvals;
   DevBuf<uint32_t> src_off, owner;
+  DevBuf<uint32_t> idx_commit, idx_proof, status0;  // dynamic slots of the commitments / of the proof points; initial status
   // device work buffers
   DevBuf<sc> chal, rows, scal, shr, dyn_unw, wm;
   DevBuf<uint8_t> rng_out, weights, masks, chal_bytes;
@@ -919,6 +920,15 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
     HIP_CHECK(hipMemcpyAsync(B->minvals.p, minvals.data(), minvals.size() * 8, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(B->src_off.p, src_off.data(), (size_t)dyn * 4, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(B->owner.p, owner.data(), (size_t)dyn * 4, hipMemcpyHostToDevice, s));
+    std::vector<uint32_t> idx_commit, idx_proof;
+    idx_commit.reserve(sum_m);
+    idx_proof.reserve(dyn - sum_m);
+    for (uint32_t q = 0; q < dyn; q++) ((owner[q] >> 31) ? idx_commit : idx_proof).push_back(q);
+    B->idx_commit.alloc(idx_commit.size());
+    B->idx_proof.alloc(idx_proof.size());
+    HIP_CHECK(hipMemcpyAsync(B->idx_commit.p, idx_commit.data(), idx_commit.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(B->idx_proof.p, idx_proof.data(), idx_proof.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));  // the index vectors are locals
     // work buffers
     B->chal.alloc((size_t)n_items * B->cs);
     B->rng_out.alloc(n_items * 32);
@@ -969,6 +979,17 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
       B->d_ext_status.alloc(n_items);
       HIP_CHECK(hipMemcpyAsync(B->d_ext_status.p, B->ext_status.data(), n_items * 4, hipMemcpyHostToDevice, s));
     }
+    // initial per-proof status of every verification of this batch: caller-side PASS-1 findings (if any) and the
+    // statement's commitments, decoded here once (the reference's RangeStatement holds decompressed points)
+    B->status0.alloc(n_items);
+    if (B->ext_challenges)
+      HIP_CHECK(hipMemcpyAsync(B->status0.p, B->d_ext_status.p, n_items * 4, hipMemcpyDeviceToDevice, s));
+    else
+      HIP_CHECK(hipMemsetAsync(B->status0.p, 0, n_items * 4, s));
+    if (B->sum_m)
+      hipLaunchKernelGGL(k_decompress, dim3(cdiv(B->sum_m, 64)), dim3(64), 0, s, B->bytes.p, B->src_off.p, B->owner.p,
+                         B->idx_commit.p, B->sum_m, B->dynpts.p, B->status0.p);
+    HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(s));
     uint64_t h = ctx->next_handle++;
     ctx->batches[h] = std::move(B);
@@ -1007,11 +1028,10 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
     HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_rng, hipEventDisableTiming));
     ctx->ev_rng_ready = true;
   }
+  HIP_CHECK(hipMemcpyAsync(b.status.p, b.status0.p, (size_t)b.B * 4, hipMemcpyDeviceToDevice, s));
   if (b.ext_challenges) {  // caller did PASS 1: challenges + rng bytes are already resident
-    HIP_CHECK(hipMemcpyAsync(b.status.p, b.d_ext_status.p, (size_t)b.B * 4, hipMemcpyDeviceToDevice, s));
     tm.mark(M_START);
   } else {
-    HIP_CHECK(hipMemsetAsync(b.status.p, 0, (size_t)b.B * 4, s));
     if (!b.uniform_rounds) HIP_CHECK(hipMemsetAsync(b.chal.p, 0, (size_t)b.B * b.cs * sizeof(sc), s));  // trace padding only
     tm.mark(M_START);
     // small inputs: one proof per wavefront (latency); large inputs: one proof per lane (issue slots)
@@ -1028,8 +1048,9 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
   tm.mark(M_TRANSCRIPTS);
   HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
-  hipLaunchKernelGGL(k_decompress, dim3(cdiv(b.total_dyn, 64)), dim3(64), 0, s, b.bytes.p, b.src_off.p, b.owner.p,
-                     b.total_dyn, b.dynpts.p, b.status.p);
+  const uint32_t n_proof_pts = b.total_dyn - b.sum_m;
+  hipLaunchKernelGGL(k_decompress, dim3(cdiv(n_proof_pts, 64)), dim3(64), 0, s, b.bytes.p, b.src_off.p, b.owner.p,
+                     b.idx_proof.p, n_proof_pts, b.dynpts.p, b.status.p);
   tm.mark(M_DECOMPRESS);
   if (!pass1_only) {
     hipLaunchKernelGGL(k_scalars_shared, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.chal.p,

@@ -199,18 +199,20 @@ __global__ void __launch_bounds__(64) k_transcripts_wave(const uint8_t *__restri
 // CompressedRistretto::decompress for every proof point and commitment (src/range_proof.rs:859-866,1067-1109),
 // one lane per point.  src_off[i] = byte offset in bytes[]; owner[i] = proof index | (is_commitment << 31).
 __global__ void __launch_bounds__(64, BPP_DECOMPRESS_WAVES) k_decompress(const uint8_t *__restrict__ bytes, const uint32_t *__restrict__ src_off,
-                                                   const uint32_t *__restrict__ owner, uint32_t n,
+                                                   const uint32_t *__restrict__ owner, const uint32_t *__restrict__ idx, uint32_t n,
                                                    niels *__restrict__ out, uint32_t *__restrict__ status) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const uint32_t e = idx[i];  // dynamic slot: the statement's commitments are decoded once at upload (the reference's
+                              // RangeStatement holds points), the proof's own points on every verification
   niels q;
-  bool ok = ristretto_decompress_lean(q, bytes + src_off[i]);
+  bool ok = ristretto_decompress_lean(q, bytes + src_off[e]);
   if (!ok) {
     niels_identity(q);
-    uint32_t o = owner[i];
+    uint32_t o = owner[e];
     atomicOr(&status[o & 0x7fffffffu], (o >> 31) ? BPP_ST_COMMIT_FAIL : BPP_ST_DECOMPRESS_FAIL);
   }
-  out[i] = q;
+  out[e] = q;
 }
 
 // Plain batch decompression for the B1 entry points (bpp_precomp_create / bpp_msm_*).
