@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--mode", default="shard", choices=["wide", "shard"])
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--chunk", type=int, default=0, help="proofs per reference batch at N=1 (0 = whole batch)")
-    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "4")),
+    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "6")),
                     help="steps in flight per GPU (one engine/stream + one host thread each)")
     ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_launch", type=int,
                     default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "64")),
@@ -151,6 +151,16 @@ def main():
         flag = torch.tensor([ok_all], dtype=torch.int32, device=device)  # verdicts of independent shards
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         assert int(flag.item()) == 1
+    # calibration after the timed region: the roofline kernel with nothing co-running (in the timed region several steps
+    # share the chip, so each launch of it is stretched by its neighbours)
+    alone_ms = None
+    if not wide:
+        sync()
+        alone = [one_step(0)[1] for _ in range(3)]
+        vals = [a.get("msm_accumulate_ms", 0.0) for a in alone if a]
+        if vals and min(vals) > 0:
+            alone_ms = sum(vals) / len(vals)
+        sync()
     prof_sum = {}
     for pf in profs:
         for k, v in pf.items():
@@ -197,6 +207,10 @@ def main():
                                "note": "integer-VALU bound, not HBM bound (SURVEY 8d): see valu",
                                "valu": {"achieved_Tmad_per_s": mads / (acc_ms * 1e-3) / 1e12, "peak_Tmad_per_s": 30.1,
                                         "frac": mads / (acc_ms * 1e-3) / 30.1e12}}
+            if alone_ms:  # same kernel, same launch, no other step in flight (3 launches after the timed region)
+                out["roofline"]["alone"] = {"kernel_ms": alone_ms, "achieved": msm_bytes / (alone_ms * 1e-3) / 1e9,
+                                            "frac": msm_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                            "valu_frac": mads / (alone_ms * 1e-3) / 30.1e12}
             out["stages_ms"] = {n: round(v, 4) for n, v in avg.items() if n.endswith("_ms")}
             # bpp_batch_upload alone: host proof/statement buffers -> parsed, packed and resident (R batches of 1024)
             out["pcie_inclusive_upload_ms"] = 1e3 * t_upload
