@@ -70,6 +70,10 @@ struct DevBuf {
     HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
     n = count;
   }
+  void swap(DevBuf &o) {
+    std::swap(p, o.p);
+    std::swap(n, o.n);
+  }
 };
 
 // page-locked host memory: asynchronous copies to/from it do not stall other streams or host threads
@@ -95,6 +99,10 @@ struct PinnedBuf {
   const T *data() const { return p; }
   T &operator[](size_t i) { return p[i]; }
   const T &operator[](size_t i) const { return p[i]; }
+  void swap(PinnedBuf &o) {
+    std::swap(p, o.p);
+    std::swap(n, o.n);
+  }
 };
 
 struct ProofErr {
@@ -203,7 +211,7 @@ struct Batch {
   // device work buffers
   DevBuf<sc> chal, rows, scal, shr, dyn_unw, wm;
   DevBuf<uint8_t> rng_out, weights, masks, chal_bytes;
-  DevBuf<uint32_t> status, group_first;
+  DevBuf<uint32_t> status, group_first, group_dlo;
   DevBuf<niels> dynpts;
   MsmWork msm;
   // layout of the last verify
@@ -214,6 +222,21 @@ struct Batch {
   PinnedBuf<uint32_t> h_status, h_ident;
   bool have_trace = false, phase1_done = false;
 };
+
+// A destroyed batch leaves its device and pinned allocations to the next upload on the same context (a caller that
+// verifies fresh host buffers call after call would otherwise pay ~30 hipMalloc/hipFree pairs, 15-25 ms, per call).
+void adopt_buffers(Batch &dst, Batch &src) {
+#define BPP_ADOPT(f) dst.f.swap(src.f)
+  BPP_ADOPT(d_ext_status); BPP_ADOPT(bytes); BPP_ADOPT(states); BPP_ADOPT(seeds); BPP_ADOPT(d_desc); BPP_ADOPT(minvals);
+  BPP_ADOPT(src_off); BPP_ADOPT(owner); BPP_ADOPT(idx_commit); BPP_ADOPT(idx_proof); BPP_ADOPT(status0); BPP_ADOPT(chal);
+  BPP_ADOPT(rows); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(dyn_unw); BPP_ADOPT(wm); BPP_ADOPT(rng_out); BPP_ADOPT(weights);
+  BPP_ADOPT(masks); BPP_ADOPT(chal_bytes); BPP_ADOPT(status); BPP_ADOPT(group_first); BPP_ADOPT(group_dlo); BPP_ADOPT(dynpts);
+  BPP_ADOPT(msm.digits); BPP_ADOPT(msm.counts); BPP_ADOPT(msm.starts); BPP_ADOPT(msm.sorted); BPP_ADOPT(msm.order);
+  BPP_ADOPT(msm.order_hist); BPP_ADOPT(msm.buckets); BPP_ADOPT(msm.Q); BPP_ADOPT(msm.W); BPP_ADOPT(msm.R); BPP_ADOPT(msm.comp32);
+  BPP_ADOPT(msm.is_identity); BPP_ADOPT(msm.term_sidx); BPP_ADOPT(msm.term_pidx); BPP_ADOPT(msm.group_off);
+  BPP_ADOPT(h_rng); BPP_ADOPT(h_weights); BPP_ADOPT(h_status); BPP_ADOPT(h_ident);
+#undef BPP_ADOPT
+}
 
 }  // namespace
 
@@ -227,6 +250,10 @@ struct bpp_ctx {
   std::map<uint64_t, std::unique_ptr<Params>> params;
   std::map<uint64_t, std::unique_ptr<Precomp>> precomps;
   std::map<uint64_t, std::unique_ptr<Batch>> batches;
+  std::unique_ptr<Batch> spare_batch;  // buffers of the last destroyed batch (adopt_buffers)
+  PinnedBuf<uint8_t> pin_upload, pin_upload2;  // page-locked staging of bpp_batch_upload (bytes; descriptors etc.)
+  PinnedBuf<uint32_t> pin_small;       // staging for small host->device arrays (a pageable hipMemcpyAsync of a few
+                                       // hundred bytes was measured at ~10 ms on this stack)
   bool profile = false;
   bpp_profile prof{};
   hipEvent_t ev[16];
@@ -290,9 +317,10 @@ uint32_t choose_window(uint32_t group_terms) {
   return c;
 }
 
-void msm_prepare(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &sidx, const std::vector<uint32_t> &pidx,
-                 const std::vector<uint32_t> &goff) {
-  const uint32_t G = (uint32_t)goff.size() - 1, n = (uint32_t)sidx.size();
+// plan + work buffers for G groups with term offsets goff[0..G]; the term lists (term_sidx / term_pidx) are filled by
+// the caller, from host vectors (msm_prepare) or by a kernel (layout_groups)
+void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff) {
+  const uint32_t G = (uint32_t)goff.size() - 1, n = goff[G];
   uint32_t maxg = 0;
   for (uint32_t g = 0; g < G; g++) maxg = std::max(maxg, goff[g + 1] - goff[g]);
   MsmPlan plan;
@@ -320,10 +348,24 @@ void msm_prepare(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &sidx, co
   w.term_sidx.alloc(n);
   w.term_pidx.alloc(n);
   w.group_off.alloc(G + 1);
-  HIP_CHECK(hipMemcpyAsync(w.term_sidx.p, sidx.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIP_CHECK(hipMemcpyAsync(w.term_pidx.p, pidx.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIP_CHECK(hipMemcpyAsync(w.group_off.p, goff.data(), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));  // host vectors may go away
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));  // pin_small may still feed an earlier copy
+  ctx->pin_small.resize(3 * (size_t)(G + 1));
+  memcpy(ctx->pin_small.data(), goff.data(), (G + 1) * 4);
+  HIP_CHECK(hipMemcpyAsync(w.group_off.p, ctx->pin_small.data(), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+}
+
+void msm_prepare(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &sidx, const std::vector<uint32_t> &pidx,
+                 const std::vector<uint32_t> &goff) {
+  msm_plan_alloc(ctx, w, goff);
+  const uint32_t n = (uint32_t)sidx.size(), G1 = (uint32_t)goff.size();
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->pin_small.resize(3 * (size_t)G1 + 2 * (size_t)n);  // (may move the buffer: goff's copy has completed)
+  uint32_t *pin = ctx->pin_small.data() + 3 * (size_t)G1;
+  memcpy(pin, sidx.data(), (size_t)n * 4);
+  memcpy(pin + n, pidx.data(), (size_t)n * 4);
+  HIP_CHECK(hipMemcpyAsync(w.term_sidx.p, pin, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(w.term_pidx.p, pin + n, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
 }
 
 void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, StageTimer *tm) {
@@ -491,6 +533,7 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->batches.clear();
+  ctx->spare_batch.reset();
   ctx->precomps.clear();
   ctx->params.clear();
   if (ctx->ev_ready)
@@ -782,12 +825,16 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
       return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "Range statements or proofs length empty", errbuf, errbuf_len);
     if (n_items > (1u << 24)) return fail(ctx, BPP_ERR_SIZE_OVERFLOW, "batch too large", errbuf, errbuf_len);
     auto B = std::make_unique<Batch>();
+    if (ctx->spare_batch) {
+      adopt_buffers(*B, *ctx->spare_batch);
+      ctx->spare_batch.reset();
+    }
     B->params = &P;
     B->params_handle = params;
     B->B = (uint32_t)n_items;
     B->desc.resize(n_items);
     B->rounds_bad.assign(n_items, 0);
-    std::vector<uint8_t> bytes, seeds(n_items * 32, 0), states;
+    std::vector<uint8_t> seeds(n_items * 32, 0), states;
     std::vector<uint64_t> minvals;
     std::map<std::string, uint32_t> state_ids;
     size_t proof_bytes = 0, sum_m = 0;
@@ -795,7 +842,13 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
       proof_bytes += items[i].proof_len;
       sum_m += items[i].m;
     }
-    bytes.reserve(proof_bytes + sum_m * 32);
+    // proof and commitment bytes are assembled directly in page-locked staging: a pageable source makes hipMemcpyAsync
+    // return early and the 40 MB transfer trickle on at ~2.4 GB/s behind the call (it showed up as 23 ms in the first
+    // verification of every freshly uploaded batch)
+    const size_t bytes_total = proof_bytes + sum_m * 32;
+    ctx->pin_upload.resize(bytes_total + 64);
+    uint8_t *bytes = ctx->pin_upload.data();
+    size_t bytes_len = 0;
     std::vector<uint32_t> commit_rel(n_items);
     uint32_t dyn = 0;
     for (size_t i = 0; i < n_items; i++) {
@@ -814,8 +867,9 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
       parse_proof(it.proof, it.proof_len, pi);
       // verify_statements_and_generators_consistency (src/range_proof.rs:637-659): extension degree of every proof
       if (pi.t != P.t) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Inconsistent extension degree"};
-      d.proof_off = (uint32_t)bytes.size();
-      bytes.insert(bytes.end(), it.proof, it.proof + it.proof_len);
+      d.proof_off = (uint32_t)bytes_len;
+      memcpy(bytes + bytes_len, it.proof, it.proof_len);
+      bytes_len += it.proof_len;
       d.rounds = pi.rounds;
       d.m = it.m;
       d.minval_idx = (uint32_t)minvals.size();
@@ -834,7 +888,13 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
         memcpy(&seeds[i * 32], it.seed_nonce32, 32);
         B->any_seed = true;
       }
-      // transcript: explicit state wins, else Transcript::new(label)
+      // transcript: explicit state wins, else Transcript::new(label).  Same source as the previous item (the common case:
+      // one label for the whole batch) -> same id, no key building / map lookup
+      const bpp_verify_item *prev = i ? &items[i - 1] : nullptr;
+      if (prev && prev->transcript_state == it.transcript_state && prev->transcript_label == it.transcript_label &&
+          prev->label_len == it.label_len) {
+        d.state_idx = B->desc[i - 1].state_idx;
+      } else {
       std::string key;
       if (it.transcript_state) {
         key.assign((const char *)it.transcript_state, 203);
@@ -859,6 +919,7 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
         sit = state_ids.emplace(key, id).first;
       }
       d.state_idx = sit->second;
+      }
       // structural checks evaluated with PASS-2 precedence at verify time (:875-888)
       const uint64_t mn = (uint64_t)it.m * P.n_bits;
       if (pi.rounds >= 32)
@@ -872,63 +933,44 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
     }
     // commitments after all proofs
     for (size_t i = 0; i < n_items; i++) {
-      B->desc[i].commit_off = (uint32_t)bytes.size();
-      bytes.insert(bytes.end(), items[i].commitments32, items[i].commitments32 + (size_t)items[i].m * 32);
+      B->desc[i].commit_off = (uint32_t)bytes_len;
+      memcpy(bytes + bytes_len, items[i].commitments32, (size_t)items[i].m * 32);
+      bytes_len += (size_t)items[i].m * 32;
     }
     B->total_dyn = dyn;
     B->sum_m = (uint32_t)sum_m;
     B->cs = B->rmax + 3;
     B->cols = 2 * B->max_mn + P.t + 1;
-    // point sources in dynamic-slot order: C_j.., A1, B, A, L.., R..
-    std::vector<uint32_t> src_off(dyn), owner(dyn);
-    for (size_t i = 0; i < n_items; i++) {
-      const ProofDesc &d = B->desc[i];
-      uint32_t q = d.dyn_off;
-      const uint32_t pA = d.proof_off + 1 + 32 * P.t;
-      for (uint32_t j = 0; j < d.m; j++) {
-        src_off[q] = d.commit_off + 32 * j;
-        owner[q++] = (uint32_t)i | 0x80000000u;
-      }
-      src_off[q] = pA + 32;  // A1
-      owner[q++] = (uint32_t)i;
-      src_off[q] = pA + 64;  // B
-      owner[q++] = (uint32_t)i;
-      src_off[q] = pA;  // A
-      owner[q++] = (uint32_t)i;
-      for (uint32_t j = 0; j < d.rounds; j++) {
-        src_off[q] = pA + 160 + 64 * j;
-        owner[q++] = (uint32_t)i;
-      }
-      for (uint32_t j = 0; j < d.rounds; j++) {
-        src_off[q] = pA + 160 + 64 * j + 32;
-        owner[q++] = (uint32_t)i;
-      }
-    }
-    // device copies
+    // device copies (all sources page-locked: the copies are real stream-ordered DMA)
     hipStream_t s = ctx->stream;
-    B->bytes.alloc(bytes.size());
+    B->bytes.alloc(bytes_len);
     B->states.alloc(states.size());
     B->seeds.alloc(seeds.size());
     B->d_desc.alloc(n_items);
     B->minvals.alloc(minvals.size());
     B->src_off.alloc(dyn);
     B->owner.alloc(dyn);
-    HIP_CHECK(hipMemcpyAsync(B->bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(B->states.p, states.data(), states.size(), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(B->seeds.p, seeds.data(), seeds.size(), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(B->d_desc.p, B->desc.data(), n_items * sizeof(ProofDesc), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(B->minvals.p, minvals.data(), minvals.size() * 8, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(B->src_off.p, src_off.data(), (size_t)dyn * 4, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(B->owner.p, owner.data(), (size_t)dyn * 4, hipMemcpyHostToDevice, s));
-    std::vector<uint32_t> idx_commit, idx_proof;
-    idx_commit.reserve(sum_m);
-    idx_proof.reserve(dyn - sum_m);
-    for (uint32_t q = 0; q < dyn; q++) ((owner[q] >> 31) ? idx_commit : idx_proof).push_back(q);
-    B->idx_commit.alloc(idx_commit.size());
-    B->idx_proof.alloc(idx_proof.size());
-    HIP_CHECK(hipMemcpyAsync(B->idx_commit.p, idx_commit.data(), idx_commit.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(B->idx_proof.p, idx_proof.data(), idx_proof.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipStreamSynchronize(s));  // the index vectors are locals
+    B->idx_commit.alloc(sum_m);
+    B->idx_proof.alloc(dyn - sum_m);
+    {
+      const size_t o_desc = 0, o_min = o_desc + n_items * sizeof(ProofDesc), o_seed = o_min + minvals.size() * 8,
+                   o_state = o_seed + seeds.size(), total = o_state + states.size();
+      ctx->pin_upload2.resize(total + 64);
+      uint8_t *st = ctx->pin_upload2.data();
+      memcpy(st + o_desc, B->desc.data(), n_items * sizeof(ProofDesc));
+      memcpy(st + o_min, minvals.data(), minvals.size() * 8);
+      memcpy(st + o_seed, seeds.data(), seeds.size());
+      memcpy(st + o_state, states.data(), states.size());
+      HIP_CHECK(hipMemcpyAsync(B->bytes.p, bytes, bytes_len, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(B->d_desc.p, st + o_desc, n_items * sizeof(ProofDesc), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(B->minvals.p, st + o_min, minvals.size() * 8, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(B->seeds.p, st + o_seed, seeds.size(), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(B->states.p, st + o_state, states.size(), hipMemcpyHostToDevice, s));
+    }
+    // point sources in dynamic-slot order C_j.., A1, B, A, L.., R.. and the two slot lists, written by one lane per proof
+    hipLaunchKernelGGL(k_build_slots, dim3(cdiv((uint32_t)n_items, 64)), dim3(64), 0, s, B->d_desc.p, (uint32_t)n_items, P.t,
+                       B->src_off.p, B->owner.p, B->idx_commit.p, B->idx_proof.p);
+    HIP_CHECK(hipGetLastError());
     // work buffers
     B->chal.alloc((size_t)n_items * B->cs);
     B->rng_out.alloc(n_items * 32);
@@ -1011,7 +1053,11 @@ int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items
 int bpp_batch_destroy(bpp_ctx *ctx, uint64_t batch) {
   BPP_ENTRY(ctx);
   (void)hipStreamSynchronize(ctx->stream);
-  return ctx->batches.erase(batch) ? BPP_OK : BPP_ERR_BAD_HANDLE;
+  auto it = ctx->batches.find(batch);
+  if (it == ctx->batches.end()) return BPP_ERR_BAD_HANDLE;
+  ctx->spare_batch = std::move(it->second);  // nothing of it is in flight any more; its allocations serve the next upload
+  ctx->batches.erase(it);
+  return BPP_OK;
 }
 
 }  // extern "C"
@@ -1252,28 +1298,34 @@ void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk) {
   b.h_group_first.resize(G + 1);
   for (uint32_t g = 0; g <= G; g++) b.h_group_first[g] = std::min(g * cz, b.B);
   b.group_first.alloc(G + 1);
-  HIP_CHECK(hipMemcpyAsync(b.group_first.p, b.h_group_first.data(), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
   b.scal.alloc((size_t)G * b.cols + b.total_dyn);
-  // terms of group g: static columns (first 2*max_mn generators, then g bases, then h) + its proofs' dynamic slots
+  // terms of group g: static columns (first 2*max_mn generators, then g bases, then h) + its proofs' dynamic slots.
+  // Only the G + 1 offsets come from the host; the ~1 M term entries are written by k_layout_terms (building them on the
+  // host and copying two pageable vectors cost ~20 ms per freshly uploaded batch)
   const uint32_t n_gen = 2 * P.n_bits * P.m_max;
-  std::vector<uint32_t> sidx, pidx, goff(G + 1);
-  sidx.reserve((size_t)G * b.cols + b.total_dyn);
-  pidx.reserve((size_t)G * b.cols + b.total_dyn);
+  std::vector<uint32_t> goff(G + 1), dlo(G + 1);
+  uint32_t run = 0, maxg = 0;
   for (uint32_t g = 0; g < G; g++) {
-    goff[g] = (uint32_t)sidx.size();
-    for (uint32_t cidx = 0; cidx < b.cols; cidx++) {
-      sidx.push_back(g * b.cols + cidx);
-      pidx.push_back(cidx < 2 * b.max_mn ? cidx : n_gen + (cidx - 2 * b.max_mn));
-    }
+    goff[g] = run;
     const uint32_t p0 = b.h_group_first[g], p1 = b.h_group_first[g + 1];
     const uint32_t d0 = b.desc[p0].dyn_off, d1 = (p1 < b.B) ? b.desc[p1].dyn_off : b.total_dyn;
-    for (uint32_t q = d0; q < d1; q++) {
-      sidx.push_back(G * b.cols + q);
-      pidx.push_back(P.table_len + q);
-    }
+    dlo[g] = d0;
+    run += b.cols + (d1 - d0);
+    maxg = std::max(maxg, b.cols + (d1 - d0));
   }
-  goff[G] = (uint32_t)sidx.size();
-  msm_prepare(ctx, b.msm, sidx, pidx, goff);
+  goff[G] = run;
+  dlo[G] = b.total_dyn;
+  msm_plan_alloc(ctx, b.msm, goff);  // leaves goff in pin_small[0 .. G]
+  b.group_dlo.alloc(G + 1);
+  uint32_t *pin = ctx->pin_small.data();
+  memcpy(pin + (G + 1), b.h_group_first.data(), (G + 1) * 4);
+  memcpy(pin + 2 * (size_t)(G + 1), dlo.data(), (G + 1) * 4);
+  HIP_CHECK(hipMemcpyAsync(b.group_first.p, pin + (G + 1), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(b.group_dlo.p, pin + 2 * (size_t)(G + 1), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_layout_terms, dim3(cdiv(maxg, 256), G), dim3(256), 0, ctx->stream, b.msm.group_off.p, b.group_dlo.p, G,
+                     b.cols, b.max_mn, n_gen, P.table_len, b.msm.term_sidx.p, b.msm.term_pidx.p);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));  // goff / dlo are locals
   b.last_chunk = chunk;
 }
 

@@ -589,6 +589,60 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
   }
 }
 
+// Per proof: byte offsets of its points in dynamic-slot order (C_j.., A1, B, A, L.., R..), their owners (bit 31 = statement
+// commitment) and the two slot lists k_decompress walks: commitments (decoded at upload) and proof points (every verify).
+// Slots of proof p start at dyn_off; its commitments are entries [minval_idx, minval_idx + m) of idx_commit (minval_idx =
+// commitments of all earlier proofs), its proof points entries [dyn_off - minval_idx, ..) of idx_proof.
+__global__ void __launch_bounds__(64) k_build_slots(const ProofDesc *__restrict__ desc, uint32_t B, uint32_t t,
+                                                    uint32_t *__restrict__ src_off, uint32_t *__restrict__ owner,
+                                                    uint32_t *__restrict__ idx_commit, uint32_t *__restrict__ idx_proof) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  const ProofDesc d = desc[p];
+  uint32_t q = d.dyn_off, ic = d.minval_idx, ip = d.dyn_off - d.minval_idx;
+  const uint32_t pA = d.proof_off + 1 + 32 * t;
+  for (uint32_t j = 0; j < d.m; j++) {
+    src_off[q] = d.commit_off + 32 * j;
+    owner[q] = p | 0x80000000u;
+    idx_commit[ic++] = q++;
+  }
+  const uint32_t fixed[3] = {pA + 32, pA + 64, pA};  // A1, B, A
+  for (uint32_t j = 0; j < 3; j++) {
+    src_off[q] = fixed[j];
+    owner[q] = p;
+    idx_proof[ip++] = q++;
+  }
+  for (uint32_t j = 0; j < d.rounds; j++) {
+    src_off[q] = pA + 160 + 64 * j;
+    owner[q] = p;
+    idx_proof[ip++] = q++;
+  }
+  for (uint32_t j = 0; j < d.rounds; j++) {
+    src_off[q] = pA + 160 + 64 * j + 32;
+    owner[q] = p;
+    idx_proof[ip++] = q++;
+  }
+}
+
+// MSM term lists of a chunked batch: group g = its static columns, then the dynamic slots [dlo[g], dlo[g+1]) of its proofs.
+// term_sidx -> index into scal[] (static part G*cols first, then dynamic), term_pidx -> index into the point tables
+// (generator table first, then dynpts).  grid = (ceil(max terms per group / 256), G).
+__global__ void __launch_bounds__(256) k_layout_terms(const uint32_t *__restrict__ goff, const uint32_t *__restrict__ dlo, uint32_t G,
+                                                      uint32_t cols, uint32_t max_mn, uint32_t n_gen, uint32_t table_len,
+                                                      uint32_t *__restrict__ term_sidx, uint32_t *__restrict__ term_pidx) {
+  const uint32_t g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t0 = goff[g], ng = goff[g + 1] - t0;
+  if (i >= ng) return;
+  if (i < cols) {
+    term_sidx[t0 + i] = g * cols + i;
+    term_pidx[t0 + i] = i < 2 * max_mn ? i : n_gen + (i - 2 * max_mn);
+  } else {
+    const uint32_t q = dlo[g] + (i - cols);
+    term_sidx[t0 + i] = G * cols + q;
+    term_pidx[t0 + i] = table_len + q;
+  }
+}
+
 __global__ void k_weights_to_mont(const uint8_t *__restrict__ weights32, uint32_t B, sc *__restrict__ wm) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B) return;
