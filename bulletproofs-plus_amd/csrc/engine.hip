@@ -846,6 +846,9 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
     // return early and the 40 MB transfer trickle on at ~2.4 GB/s behind the call (it showed up as 23 ms in the first
     // verification of every freshly uploaded batch)
     const size_t bytes_total = proof_bytes + sum_m * 32;
+    // 32-bit byte offsets and slot numbers (bit 31 of a slot / point index carries a flag)
+    if (bytes_total >= (1ull << 32) || sum_m >= (1ull << 28))
+      return fail(ctx, BPP_ERR_SIZE_OVERFLOW, "batch too large for one call (4 GB of proof bytes)", errbuf, errbuf_len);
     ctx->pin_upload.resize(bytes_total + 64);
     uint8_t *bytes = ctx->pin_upload.data();
     size_t bytes_len = 0;
