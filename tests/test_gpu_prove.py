@@ -156,3 +156,34 @@ def test_every_fixed_base_window_width(bpp, wbits, monkeypatch):
         cp.close()
     finally:
         eng.close()
+
+
+def test_prover_baseline_cfg5_full_size(bpp, engine):
+    """BASELINE configs[4]: 1024 aggregation-4 proofs, extension degree 3, 64 bits, in one bpp_prove_batch call.  Full-size
+    properties: every proof verifies (round trip through the engine's verifier, one reference batch of 1024), a sample is
+    byte-identical to the oracle's prover, and a proof bound to another statement is rejected"""
+    n, m, t, count = 64, 4, 3, 1024
+    params = bpp.RangeParameters.init(n, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=engine)
+    rng = Prng(b"cfg5-full")
+    rounds = (n * m).bit_length() - 1
+    blind = [sb(O.random_not_zero(rng)) for _ in range(t)]
+    vals = [[rng.next_u64() % (1 << 63) for _ in range(m)] for _ in range(count)]
+    mins = [[v // 3 for v in vs] for vs in vals]
+    exts = [rng.fill_bytes(32 * (rounds + 3)) for _ in range(count)]
+    comms = params.commit_many([x for v in vals for x in v], [blind] * (count * m))
+    comms = [comms[i * m:(i + 1) * m] for i in range(count)]
+    sts = [bpp.RangeStatement.init(params, comms[i], mins[i], None) for i in range(count)]
+    wits = [bpp.RangeWitness.init([bpp.CommitmentOpening.new(vals[i][j], blind) for j in range(m)]) for i in range(count)]
+    trs = [bpp.Transcript.new(LABEL)] * count
+    proofs = bpp.RangeProof.prove_batch(trs, sts, wits, exts)
+    assert len(proofs) == count and all(len(p.to_bytes()) == 1 + 32 * (t + 5 + 2 * rounds) for p in proofs)
+    assert bpp.RangeProof.verify_batch(trs, sts, proofs, bpp.VerifyAction.VerifyOnly) == [None] * count
+    cp = cport.Params(n, m, t)
+    for i in (0, 1, 511, 1023):
+        want, comm = cp.prove(LABEL, vals[i], [blind] * m, mins[i], None, exts[i])
+        assert comm == comms[i] and proofs[i].to_bytes() == want
+    cp.close()
+    swapped = list(proofs)
+    swapped[3], swapped[4] = swapped[4], swapped[3]
+    assert _kind(bpp, lambda: bpp.RangeProof.verify_batch(trs, sts, swapped, bpp.VerifyAction.VerifyOnly)) == \
+        bpp.ProofErrorKind.VerificationFailed
