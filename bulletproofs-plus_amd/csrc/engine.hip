@@ -143,6 +143,7 @@ void shake256(const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen) { ke
 void sha3_512(const uint8_t *in, size_t inlen, uint8_t out[64]) { keccak_sponge(in, inlen, out, 64, 72, 0x06); }
 
 void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G);
+void host_parallel_for(uint32_t n, const std::function<void(uint32_t)> &fn);  // on the persistent host pool
 
 // weight transcript (src/range_proof.rs:811,849,853,894)
 void weights_from_chain_host(const uint8_t *rng32, size_t n, uint8_t *weights32) {
@@ -835,26 +836,85 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
     B->desc.resize(n_items);
     B->rounds_bad.assign(n_items, 0);
     std::vector<uint8_t> seeds(n_items * 32, 0), states;
-    std::vector<uint64_t> minvals;
     std::map<std::string, uint32_t> state_ids;
+    // ---- pass A (serial, cheap, validates nothing): running offsets, the round count implied by each proof's length,
+    // transcript ids.  A malformed item gets harmless numbers here; pass B reports it.
+    struct Pre {
+      uint32_t minval_idx, dyn_off, rounds;
+      size_t proof_off;
+    };
+    std::vector<Pre> pre(n_items);
     size_t proof_bytes = 0, sum_m = 0;
+    uint64_t dyn64 = 0;
+    size_t tr_err_index = n_items;  // first item whose explicit transcript state is unusable
     for (size_t i = 0; i < n_items; i++) {
-      proof_bytes += items[i].proof_len;
-      sum_m += items[i].m;
+      const bpp_verify_item &it = items[i];
+      ProofDesc &d = B->desc[i];
+      uint32_t rounds = 0;
+      if (it.proof && it.proof_len >= 1) {
+        const size_t t0 = it.proof[0], nchunks = (it.proof_len - 1) / 32;
+        if (nchunks > t0 + 5) rounds = (uint32_t)std::min<size_t>((nchunks - (t0 + 5)) / 2, 1u << 20);
+      }
+      pre[i] = Pre{(uint32_t)sum_m, (uint32_t)dyn64, rounds, proof_bytes};
+      proof_bytes += it.proof ? it.proof_len : 0;
+      sum_m += it.m;
+      dyn64 += (uint64_t)it.m + 3 + 2 * (uint64_t)rounds;
+      // transcript: explicit state wins, else Transcript::new(label).  Same source as the previous item (the common case:
+      // one label for the whole batch) -> same id, no key building / map lookup
+      const bpp_verify_item *prev = i ? &items[i - 1] : nullptr;
+      if (prev && prev->transcript_state == it.transcript_state && prev->transcript_label == it.transcript_label &&
+          prev->label_len == it.label_len) {
+        d.state_idx = B->desc[i - 1].state_idx;
+        continue;
+      }
+      std::string key;
+      if (it.transcript_state) {
+        key.assign((const char *)it.transcript_state, 203);
+        key.push_back('S');
+      } else {
+        key.assign((const char *)it.transcript_label, it.transcript_label ? it.label_len : 0);
+        key.push_back('L');
+      }
+      auto sit = state_ids.find(key);
+      if (sit == state_ids.end()) {
+        uint32_t id = (uint32_t)(states.size() / 203);
+        states.resize(states.size() + 203);
+        if (it.transcript_state) {
+          memcpy(&states[(size_t)id * 203], it.transcript_state, 203);
+          if (states[(size_t)id * 203 + 200] >= BPP_STROBE_R && tr_err_index == n_items) tr_err_index = i;
+        } else {
+          Strobe st;
+          merlin_new(st, it.transcript_label, (uint32_t)(it.transcript_label ? it.label_len : 0));
+          strobe_to_bytes(&states[(size_t)id * 203], st);
+        }
+        sit = state_ids.emplace(key, id).first;
+      }
+      d.state_idx = sit->second;
     }
     // proof and commitment bytes are assembled directly in page-locked staging: a pageable source makes hipMemcpyAsync
     // return early and the 40 MB transfer trickle on at ~2.4 GB/s behind the call (it showed up as 23 ms in the first
     // verification of every freshly uploaded batch)
     const size_t bytes_total = proof_bytes + sum_m * 32;
     // 32-bit byte offsets and slot numbers (bit 31 of a slot / point index carries a flag)
-    if (bytes_total >= (1ull << 32) || sum_m >= (1ull << 28))
+    if (bytes_total >= (1ull << 32) || sum_m >= (1ull << 28) || dyn64 >= (1ull << 31))
       return fail(ctx, BPP_ERR_SIZE_OVERFLOW, "batch too large for one call (4 GB of proof bytes)", errbuf, errbuf_len);
     ctx->pin_upload.resize(bytes_total + 64);
     uint8_t *bytes = ctx->pin_upload.data();
-    size_t bytes_len = 0;
-    std::vector<uint32_t> commit_rel(n_items);
-    uint32_t dyn = 0;
-    for (size_t i = 0; i < n_items; i++) {
+    const size_t bytes_len = bytes_total;
+    const uint32_t dyn = (uint32_t)dyn64;
+    std::vector<uint64_t> minvals(sum_m, 0);
+    // ---- pass B (host pool): per item, the checks in the reference's order + the copies.  Every worker stops at the
+    // first bad item of its range; the lowest index over all ranges is reported, as the serial loop would
+    struct Part {
+      size_t err_index;
+      ProofErr err;
+      bool any_seed = false, any_rounds_bad = false, uniform = true;
+      uint32_t rmax = 0, max_mn = 0;
+    };
+    const uint32_t n_parts = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, n_items / 512));
+    std::vector<Part> parts(n_parts);
+    const uint32_t rounds0 = pre[0].rounds;
+    auto one_item = [&](size_t i, Part &pt) {
       const bpp_verify_item &it = items[i];
       ProofDesc &d = B->desc[i];
       // RangeStatement::init (src/range_statement.rs:36-73)
@@ -870,75 +930,66 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
       parse_proof(it.proof, it.proof_len, pi);
       // verify_statements_and_generators_consistency (src/range_proof.rs:637-659): extension degree of every proof
       if (pi.t != P.t) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Inconsistent extension degree"};
-      d.proof_off = (uint32_t)bytes_len;
-      memcpy(bytes + bytes_len, it.proof, it.proof_len);
-      bytes_len += it.proof_len;
-      d.rounds = pi.rounds;
+      d.proof_off = (uint32_t)pre[i].proof_off;
+      memcpy(bytes + pre[i].proof_off, it.proof, it.proof_len);
+      d.rounds = pi.rounds;  // == pre[i].rounds for every proof that parses
       d.m = it.m;
-      d.minval_idx = (uint32_t)minvals.size();
+      d.minval_idx = pre[i].minval_idx;
       for (uint32_t j = 0; j < it.m; j++) {
         bool present = it.min_present ? it.min_present[j] != 0 : false;
         uint64_t v = (present && it.min_values) ? it.min_values[j] : 0;
         // :675-681
         if (present && P.n_bits < 64 && (v >> P.n_bits) > 0)
           throw ProofErr{BPP_ERR_INVALID_LENGTH, "Minimum value promise exceeds bit vector capacity"};
-        minvals.push_back(v);
+        minvals[pre[i].minval_idx + j] = v;
       }
-      d.dyn_off = dyn;
-      dyn += it.m + 3 + 2 * pi.rounds;
+      d.dyn_off = pre[i].dyn_off;
       d.flags = it.seed_nonce32 ? 1u : 0u;
       if (it.seed_nonce32) {
         memcpy(&seeds[i * 32], it.seed_nonce32, 32);
-        B->any_seed = true;
+        pt.any_seed = true;
       }
-      // transcript: explicit state wins, else Transcript::new(label).  Same source as the previous item (the common case:
-      // one label for the whole batch) -> same id, no key building / map lookup
-      const bpp_verify_item *prev = i ? &items[i - 1] : nullptr;
-      if (prev && prev->transcript_state == it.transcript_state && prev->transcript_label == it.transcript_label &&
-          prev->label_len == it.label_len) {
-        d.state_idx = B->desc[i - 1].state_idx;
-      } else {
-      std::string key;
-      if (it.transcript_state) {
-        key.assign((const char *)it.transcript_state, 203);
-        key.push_back('S');
-      } else {
-        key.assign((const char *)it.transcript_label, it.transcript_label ? it.label_len : 0);
-        key.push_back('L');
-      }
-      auto sit = state_ids.find(key);
-      if (sit == state_ids.end()) {
-        uint32_t id = (uint32_t)(states.size() / 203);
-        states.resize(states.size() + 203);
-        if (it.transcript_state) {
-          memcpy(&states[(size_t)id * 203], it.transcript_state, 203);
-          if (states[(size_t)id * 203 + 200] >= BPP_STROBE_R)
-            throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "transcript state has pos >= rate"};
-        } else {
-          Strobe s;
-          merlin_new(s, it.transcript_label, (uint32_t)(it.transcript_label ? it.label_len : 0));
-          strobe_to_bytes(&states[(size_t)id * 203], s);
-        }
-        sit = state_ids.emplace(key, id).first;
-      }
-      d.state_idx = sit->second;
-      }
+      if (i == tr_err_index) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "transcript state has pos >= rate"};
       // structural checks evaluated with PASS-2 precedence at verify time (:875-888)
       const uint64_t mn = (uint64_t)it.m * P.n_bits;
       if (pi.rounds >= 32)
         B->rounds_bad[i] = BPP_ERR_SIZE_OVERFLOW;
       else if ((1ull << pi.rounds) != mn)
         B->rounds_bad[i] = BPP_ERR_INVALID_LENGTH;
-      if (B->rounds_bad[i]) B->any_rounds_bad = true;
-      if (i && pi.rounds != B->desc[0].rounds) B->uniform_rounds = false;
-      B->rmax = std::max(B->rmax, pi.rounds);
-      B->max_mn = std::max(B->max_mn, (uint32_t)mn);
-    }
-    // commitments after all proofs
-    for (size_t i = 0; i < n_items; i++) {
-      B->desc[i].commit_off = (uint32_t)bytes_len;
-      memcpy(bytes + bytes_len, items[i].commitments32, (size_t)items[i].m * 32);
-      bytes_len += (size_t)items[i].m * 32;
+      if (B->rounds_bad[i]) pt.any_rounds_bad = true;
+      if (pi.rounds != rounds0) pt.uniform = false;
+      pt.rmax = std::max(pt.rmax, pi.rounds);
+      pt.max_mn = std::max(pt.max_mn, (uint32_t)mn);
+      // commitments follow all proofs
+      d.commit_off = (uint32_t)(proof_bytes + 32 * (size_t)pre[i].minval_idx);
+      memcpy(bytes + d.commit_off, it.commitments32, (size_t)it.m * 32);
+    };
+    host_parallel_for(n_parts, [&](uint32_t k) {
+      Part &pt = parts[k];
+      pt.err_index = n_items;
+      const size_t lo = n_items * k / n_parts, hi = n_items * (k + 1) / n_parts;
+      for (size_t i = lo; i < hi; i++) {
+        try {
+          one_item(i, pt);
+        } catch (const ProofErr &e) {
+          pt.err_index = i;
+          pt.err = e;
+          return;
+        }
+      }
+    });
+    {
+      const Part *first = nullptr;
+      for (const Part &pt : parts)
+        if (pt.err_index < n_items && (!first || pt.err_index < first->err_index)) first = &pt;
+      if (first) throw first->err;
+      for (const Part &pt : parts) {
+        B->any_seed = B->any_seed || pt.any_seed;
+        B->any_rounds_bad = B->any_rounds_bad || pt.any_rounds_bad;
+        B->uniform_rounds = B->uniform_rounds && pt.uniform;
+        B->rmax = std::max(B->rmax, pt.rmax);
+        B->max_mn = std::max(B->max_mn, pt.max_mn);
+      }
     }
     B->total_dyn = dyn;
     B->sum_m = (uint32_t)sum_m;
@@ -1209,6 +1260,8 @@ class HostPool {
   std::condition_variable cv_;
   std::deque<std::shared_ptr<Job>> jobs_;
 };
+
+void host_parallel_for(uint32_t n, const std::function<void(uint32_t)> &fn) { HostPool::get().parallel_for(n, fn); }
 
 void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G) {
   static const int simd = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") ? 8
