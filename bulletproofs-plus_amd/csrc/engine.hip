@@ -324,13 +324,7 @@ void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff)
   const uint32_t G = (uint32_t)goff.size() - 1, n = goff[G];
   uint32_t maxg = 0;
   for (uint32_t g = 0; g < G; g++) maxg = std::max(maxg, goff[g + 1] - goff[g]);
-  MsmPlan plan;
-  plan.c = choose_window(maxg);
-  plan.K = (253 + plan.c - 1) / plan.c;
-  plan.K_wide = plan.K - (plan.K * plan.c - 253);  // 253 = K_wide * c + (K - K_wide) * (c - 1)
-  plan.nb = 1u << (plan.c - 1);
-  plan.G = G;
-  plan.n_terms = n;
+  const MsmPlan plan = msm_make_plan(choose_window(maxg), G, n);
   w.plan = plan;
   w.max_group_terms = maxg;
   const size_t nbk = (size_t)G * plan.K * plan.nb;

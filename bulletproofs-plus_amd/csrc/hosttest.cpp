@@ -5,6 +5,7 @@
 #include "merlin.h"
 #include "blake2b.h"
 #include "chain_host.h"
+#include "recode.h"
 using namespace bpp;
 extern "C" {
 void ht_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe x, y, z; fe_frombytes(x, a); fe_frombytes(y, b); fe_mul(z, x, y); fe_tobytes(out, z); }
@@ -57,4 +58,17 @@ int ht_weight_chains(const uint8_t *rng /* [width][n][32] */, uint32_t n, uint32
   if (width == 4) { if (!__builtin_cpu_supports("avx2")) return 0; weights_chain_x4(in, n, o); return 1; }
   if (width == 8) { if (!(__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl"))) return 0; weights_chain_x8(in, n, o); return 1; }
   return -1; }
+// recodings: digits of a canonical scalar for MSM window width c (uneven windows) / fixed-base window width w
+int ht_msm_recode(const uint8_t a[32], uint32_t c, int16_t *digits /* K */, uint32_t *widths /* K */) {
+  sc x; sc_load_words(x, a);
+  const MsmPlan plan = msm_make_plan(c, 1, 1);
+  msm_recode(digits, 1, x, plan);
+  for (uint32_t k = 0; k < plan.K; k++) widths[k] = k < plan.K_wide ? plan.c : plan.c - 1;
+  return (int)plan.K; }
+int ht_fb_recode(const uint8_t a[32], uint32_t n_gens, int16_t *digits /* 32 */, uint32_t *wbits) {
+  sc x; sc_load_words(x, a);
+  const FbGeom g = fb_geometry(n_gens);
+  fb_recode(digits, x, g);
+  *wbits = g.wbits;
+  return (int)g.windows; }
 }

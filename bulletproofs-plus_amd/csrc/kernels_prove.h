@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "kernels_verify.h"
+#include "recode.h"
 #include "wstrobe.h"
 
 namespace bpp {
@@ -26,51 +27,6 @@ struct alignas(128) fbent {
   niels q;
   uint32_t pad[2];
 };
-// Window width is chosen per parameter set (fb_geometry): the widest window whose table stays under ~1.8 GB, because
-// random 128-byte lines come at 21 G lines/s out of <= 2 GB but only ~10 G lines/s out of larger tables (TLB reach,
-// tools/microbench/rand_lines.hip).  11 bits (<= 600 generators) = 24 windows of 1024 entries, 23 additions per term.
-struct FbGeom {
-  uint32_t wbits;    // window width
-  uint32_t windows;  // ceil(254 / wbits): the top window never carries out
-  uint32_t entries;  // 2^(wbits-1) signed multiples 1..2^(wbits-1)
-};
-#define FB_MAX_WINDOWS 32
-#define FB_BUILD_BLOCK 128  // entries per lane of k_fb_build
-inline FbGeom fb_geometry(uint32_t n_gens) {  // host side
-  uint32_t w = 8;
-  const char *forced = getenv("BPP_FB_WBITS");  // tests: exercise every geometry on small parameter sets
-  const uint32_t top = forced ? (uint32_t)atoi(forced) : 11u;
-  for (uint32_t cand = (top >= 8 && top <= 11) ? top : 11u; cand > 8; cand--) {
-    const uint64_t bytes = (uint64_t)n_gens * ((254 + cand - 1) / cand) * (1ull << (cand - 1)) * 128ull;
-    if (bytes <= 1800ull << 20) {
-      w = cand;
-      break;
-    }
-  }
-  FbGeom g;
-  g.wbits = w;
-  g.windows = (254 + w - 1) / w;
-  g.entries = 1u << (w - 1);
-  return g;
-}
-BPP_HD size_t fb_stride(const FbGeom &g) { return (size_t)g.windows * g.entries; }  // entries per generator
-
-// signed digits of a canonical scalar, digit in [-(2^(w-1) - 1), 2^(w-1)]
-BPP_HD void fb_recode(int16_t *dig, const sc &s, const FbGeom &g) {
-  uint32_t carry = 0;
-  for (uint32_t w = 0; w < g.windows; w++) {
-    const uint32_t bit = w * g.wbits, wi = bit >> 5, sh = bit & 31u;
-    uint32_t raw = 0;
-    if (wi < 8) {
-      const uint64_t two = (uint64_t)s.v[wi] | ((wi + 1 < 8) ? ((uint64_t)s.v[wi + 1] << 32) : 0ull);
-      raw = (uint32_t)(two >> sh) & ((1u << g.wbits) - 1u);
-    }
-    const uint32_t v = raw + carry;
-    carry = v > g.entries ? 1u : 0u;
-    dig[w] = (int16_t)((int32_t)v - (int32_t)(carry << g.wbits));
-  }
-}
-
 struct cached {  // projective niels (table construction only)
   fe yplusx, yminusx, z, t2d;
 };

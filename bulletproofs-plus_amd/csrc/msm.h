@@ -16,22 +16,10 @@
 //   k_msm_final       R[g]       = sum_k 2^(c k) W[g][k]; canonical encoding + identity flag
 #pragma once
 #include "point.h"
+#include "recode.h"
 #include "scalar.h"
 
 namespace bpp {
-
-// Window layout: 253 = K_wide * c + (K - K_wide) * (c - 1).  Canonical scalars are < l < 2^252 + 2^125, so 253 bits and
-// no carry out of the top window; with equal widths the top window would hold only 253 mod c bits and concentrate every
-// term of a group in a handful of buckets (one lane adding thousands of points in sequence) unless c divides 253 (c =
-// 11).  Windows of c-1 bits simply leave the upper half of their 2^(c-1) buckets empty.
-struct MsmPlan {
-  uint32_t c;        // window bits (wide windows)
-  uint32_t K;        // windows
-  uint32_t K_wide;   // windows [0, K_wide) have c bits, windows [K_wide, K) have c - 1
-  uint32_t nb;       // buckets per window = 2^(c-1)
-  uint32_t G;        // groups
-  uint32_t n_terms;  // total terms
-};
 
 // point fetch: index < n_tab -> table A (generators), else table B (dynamic points of the batch)
 struct PointTables {
@@ -53,29 +41,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const sc *__restrict__ scala
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ng) return;
   const sc s = scalars[term_sidx[t0 + i]];
-  const uint32_t K = plan.K;
-  int16_t *out = digitsT + (size_t)t0 * K + i;
-  uint32_t carry = 0, bit = 0;
-  for (uint32_t k = 0; k < K; k++) {
-    const uint32_t wd = k < plan.K_wide ? plan.c : plan.c - 1;  // this window's width
-    const uint32_t wi = bit >> 5, sh = bit & 31;
-    uint32_t raw = 0;
-    if (wi < 8) {
-      uint64_t two = (uint64_t)s.v[wi] | ((wi + 1 < 8) ? ((uint64_t)s.v[wi + 1] << 32) : 0ULL);
-      raw = (uint32_t)(two >> sh) & ((1u << wd) - 1u);
-    }
-    uint32_t v = raw + carry;
-    int32_t dgt;
-    if (v > (1u << (wd - 1))) {  // digits in (-2^(wd-1), 2^(wd-1)]
-      dgt = (int32_t)v - (int32_t)(1u << wd);
-      carry = 1;
-    } else {
-      dgt = (int32_t)v;
-      carry = 0;
-    }
-    out[(size_t)k * ng] = (int16_t)dgt;
-    bit += wd;
-  }
+  msm_recode(digitsT + (size_t)t0 * plan.K + i, ng, s, plan);
 }
 
 // ---- LDS-staged counting sort: one workgroup per (window, group) keeps that window's bucket table in LDS.

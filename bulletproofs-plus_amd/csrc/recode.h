@@ -1,0 +1,106 @@
+// Scalar recodings shared by host and device (host-compiled by tests/: every digit string must add up to its scalar).
+//   msm_recode : signed digits of the Pippenger MSM, uneven windows (MsmPlan)
+//   fb_recode  : signed digits of the prover's fixed-base tables (FbGeom)
+#pragma once
+#include <stdlib.h>
+
+#include "scalar.h"
+
+namespace bpp {
+
+// Window layout: 253 = K_wide * c + (K - K_wide) * (c - 1).  Canonical scalars are < l < 2^252 + 2^125, so 253 bits and
+// no carry out of the top window; with equal widths the top window would hold only 253 mod c bits and concentrate every
+// term of a group in a handful of buckets (one lane adding thousands of points in sequence) unless c divides 253 (c =
+// 11).  Windows of c-1 bits simply leave the upper half of their 2^(c-1) buckets empty.
+struct MsmPlan {
+  uint32_t c;        // window bits (wide windows)
+  uint32_t K;        // windows
+  uint32_t K_wide;   // windows [0, K_wide) have c bits, windows [K_wide, K) have c - 1
+  uint32_t nb;       // buckets per window = 2^(c-1)
+  uint32_t G;        // groups
+  uint32_t n_terms;  // total terms
+};
+
+// digits of one canonical scalar, written with stride `stride` (window-major layout of k_msm_digits: stride = terms of the group)
+BPP_HD void msm_recode(int16_t *out, size_t stride, const sc &s, const MsmPlan &plan) {
+  uint32_t carry = 0, bit = 0;
+  for (uint32_t k = 0; k < plan.K; k++) {
+    const uint32_t wd = k < plan.K_wide ? plan.c : plan.c - 1;  // this window's width
+    const uint32_t wi = bit >> 5, sh = bit & 31;
+    uint32_t raw = 0;
+    if (wi < 8) {
+      uint64_t two = (uint64_t)s.v[wi] | ((wi + 1 < 8) ? ((uint64_t)s.v[wi + 1] << 32) : 0ULL);
+      raw = (uint32_t)(two >> sh) & ((1u << wd) - 1u);
+    }
+    uint32_t v = raw + carry;
+    int32_t dgt;
+    if (v > (1u << (wd - 1))) {  // digits in (-2^(wd-1), 2^(wd-1)]
+      dgt = (int32_t)v - (int32_t)(1u << wd);
+      carry = 1;
+    } else {
+      dgt = (int32_t)v;
+      carry = 0;
+    }
+    out[(size_t)k * stride] = (int16_t)dgt;
+    bit += wd;
+  }
+}
+
+// plan for a group of `terms` terms with window width c
+inline MsmPlan msm_make_plan(uint32_t c, uint32_t G, uint32_t n_terms) {
+  MsmPlan plan;
+  plan.c = c;
+  plan.K = (253 + c - 1) / c;
+  plan.K_wide = plan.K - (plan.K * c - 253);  // 253 = K_wide * c + (K - K_wide) * (c - 1)
+  plan.nb = 1u << (c - 1);
+  plan.G = G;
+  plan.n_terms = n_terms;
+  return plan;
+}
+
+// Window width is chosen per parameter set (fb_geometry): the widest window whose table stays under ~1.8 GB, because
+// random 128-byte lines come at 21 G lines/s out of <= 2 GB but only ~10 G lines/s out of larger tables (TLB reach,
+// tools/microbench/rand_lines.hip).  11 bits (<= 600 generators) = 24 windows of 1024 entries, 23 additions per term.
+struct FbGeom {
+  uint32_t wbits;    // window width
+  uint32_t windows;  // ceil(254 / wbits): the top window never carries out
+  uint32_t entries;  // 2^(wbits-1) signed multiples 1..2^(wbits-1)
+};
+#define FB_MAX_WINDOWS 32
+#define FB_BUILD_BLOCK 128  // entries per lane of k_fb_build
+inline FbGeom fb_geometry(uint32_t n_gens) {  // host side
+  uint32_t w = 8;
+  const char *forced = getenv("BPP_FB_WBITS");  // tests: exercise every geometry on small parameter sets
+  const uint32_t top = forced ? (uint32_t)atoi(forced) : 11u;
+  for (uint32_t cand = (top >= 8 && top <= 11) ? top : 11u; cand > 8; cand--) {
+    const uint64_t bytes = (uint64_t)n_gens * ((254 + cand - 1) / cand) * (1ull << (cand - 1)) * 128ull;
+    if (bytes <= 1800ull << 20) {
+      w = cand;
+      break;
+    }
+  }
+  FbGeom g;
+  g.wbits = w;
+  g.windows = (254 + w - 1) / w;
+  g.entries = 1u << (w - 1);
+  return g;
+}
+BPP_HD size_t fb_stride(const FbGeom &g) { return (size_t)g.windows * g.entries; }  // entries per generator
+
+// signed digits of a canonical scalar, digit in [-(2^(w-1) - 1), 2^(w-1)]
+BPP_HD void fb_recode(int16_t *dig, const sc &s, const FbGeom &g) {
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < g.windows; w++) {
+    const uint32_t bit = w * g.wbits, wi = bit >> 5, sh = bit & 31u;
+    uint32_t raw = 0;
+    if (wi < 8) {
+      const uint64_t two = (uint64_t)s.v[wi] | ((wi + 1 < 8) ? ((uint64_t)s.v[wi + 1] << 32) : 0ull);
+      raw = (uint32_t)(two >> sh) & ((1u << g.wbits) - 1u);
+    }
+    const uint32_t v = raw + carry;
+    carry = v > g.entries ? 1u : 0u;
+    dig[w] = (int16_t)((int32_t)v - (int32_t)(carry << g.wbits));
+  }
+}
+
+}  // namespace bpp

@@ -166,3 +166,37 @@ def test_scalar_inversions_agree(ht):
             ht.ht_sc_invert_plain(a.to_bytes(32, "little"), which, o)
             got = int.from_bytes(o.raw, "little")
             assert got == (pow(a, -1, L) if a else 0), (hex(a), which)
+
+
+def test_scalar_recodings(ht, monkeypatch):
+    """signed-digit recodings used by the MSM (uneven windows of c and c-1 bits, 253 bits in total) and by the prover's
+    fixed-base tables: the digits must add up to the scalar, stay in (-2^(w-1), 2^(w-1)] and the widths must sum to 253
+    (MSM) -- for every window width, on random scalars and on the extremes of [0, l)"""
+    vals = [int.from_bytes(_r(b"rec", i), "little") % L for i in range(40)]
+    vals += [0, 1, L - 1, L - 2, 2**252, 2**252 - 1, 2**252 + 1, (1 << 252) - (1 << 200), 0x8080808080808080 << 64]
+    for c in range(4, 15):
+        for a in vals:
+            dig = (ctypes.c_int16 * 64)()
+            wid = (ctypes.c_uint32 * 64)()
+            K = ht.ht_msm_recode(a.to_bytes(32, "little"), c, dig, wid)
+            assert sum(wid[:K]) == 253 and all(w in (c, c - 1) for w in wid[:K]) and K == -(-253 // c)
+            off, total = 0, 0
+            for k in range(K):
+                assert -(1 << (wid[k] - 1)) < dig[k] <= (1 << (wid[k] - 1)), (c, k, dig[k])
+                total += dig[k] << off
+                off += wid[k]
+            assert total == a, (c, hex(a))
+    for forced, n_gens in [(None, 5), (None, 516), (None, 1026), (None, 5000), ("8", 5), ("9", 5), ("10", 5), ("11", 5)]:
+        if forced:
+            monkeypatch.setenv("BPP_FB_WBITS", forced)
+        else:
+            monkeypatch.delenv("BPP_FB_WBITS", raising=False)
+        for a in vals:
+            dig = (ctypes.c_int16 * 32)()
+            wb = ctypes.c_uint32()
+            W = ht.ht_fb_recode(a.to_bytes(32, "little"), n_gens, dig, ctypes.byref(wb))
+            w = wb.value
+            assert 8 <= w <= 11 and W == -(-254 // w) and (forced is None or w == int(forced))
+            assert W * (1 << (w - 1)) * 128 * n_gens <= 1800 << 20 or w == 8
+            assert all(-(1 << (w - 1)) < dig[k] <= (1 << (w - 1)) for k in range(W))
+            assert sum(dig[k] << (w * k) for k in range(W)) == a
