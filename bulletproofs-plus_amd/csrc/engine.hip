@@ -380,10 +380,19 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
   hipLaunchKernelGGL(k_order_scatter, og, dim3(1024), 0, s, w.counts.p, per_group, w.order_hist.p,
                      w.order_hist.p + (size_t)plan.G * 256, w.order.p);
   if (tm) tm->mark(M_ORDER);  // msm_accumulate_ms brackets k_msm_accumulate alone (the roofline kernel)
-  hipLaunchKernelGGL(k_msm_accumulate, dim3(8 * cdiv(plan.G, 8) * cdiv(per_group, 64)), dim3(64), 0, s, w.sorted.p, w.starts.p,
-                     w.counts.p, w.order.p, tabs, per_group, plan.G, w.buckets.p);
+  // few buckets on an idle chip (one batch per call): quad forms, ~3x shorter dependency chains (tests force either form)
+  const char *fq2 = getenv("BPP_MSM_QUAD");
+  const bool small = fq2 ? atoi(fq2) != 0 : (size_t)plan.G * per_group <= 100000;
+  if (small)
+    hipLaunchKernelGGL(k_msm_accumulate_quad, dim3(cdiv(plan.G * per_group, 16)), dim3(64), 0, s, w.sorted.p, w.starts.p,
+                       w.counts.p, w.order.p, tabs, plan.G * per_group, w.buckets.p);
+  else
+    hipLaunchKernelGGL(k_msm_accumulate, dim3(8 * cdiv(plan.G, 8) * cdiv(per_group, 64)), dim3(64), 0, s, w.sorted.p, w.starts.p,
+                       w.counts.p, w.order.p, tabs, per_group, plan.G, w.buckets.p);
   if (tm) tm->mark(M_ACC);
-  if (plan.c <= 11) {
+  if (plan.c <= 11 && small) {
+    hipLaunchKernelGGL(k_msm_window_rc_quad, dim3(plan.G * plan.K), dim3(256), 0, s, w.buckets.p, w.counts.p, plan, w.W.p);
+  } else if (plan.c <= 11) {
     hipLaunchKernelGGL(k_msm_window_rc, dim3(plan.G * plan.K), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.W.p);
   } else {
     hipLaunchKernelGGL(k_msm_bitsum, dim3(plan.c, plan.K, plan.G), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.Q.p);

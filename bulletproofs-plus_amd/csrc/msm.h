@@ -340,6 +340,71 @@ __device__ __forceinline__ void quad_efgh(fe &m, const QuadMask &q, const fe &E,
   fe_mul(m, l, r);
 }
 
+// acc += other, acc spread over the quad (lane q holds coordinate q in m): the nine products of ge_add in three rounds
+__device__ __forceinline__ void quad_ge_add(fe &m, const QuadMask &q, const ge &other, const fe &d2, const fe &one) {
+  fe X, Y, Z, T;
+  quad_bcast<0>(X, m);
+  quad_bcast<1>(Y, m);
+  quad_bcast<2>(Z, m);
+  quad_bcast<3>(T, m);
+  fe l0, r0, l1, r1, l, r, s2;
+  fe_sub(l0, Y, X);
+  fe_sub(r0, other.Y, other.X);
+  fe_add(l1, Y, X);
+  fe_add(r1, other.Y, other.X);
+  fe_sel4(l, q, l0, l1, T, Z);
+  fe_sel4(r, q, r0, r1, other.T, other.Z);
+  fe_mul(s2, l, r);  // a, b, T*T', Z*Z'
+  fe_sel4(r, q, one, one, d2, one);
+  fe_mul(s2, s2, r);  // lane 2: c = T*T'*2d; the others multiply by one
+  fe a, b, c, d, e, f, gg, h;
+  quad_bcast<0>(a, s2);
+  quad_bcast<1>(b, s2);
+  quad_bcast<2>(c, s2);
+  quad_bcast<3>(d, s2);
+  fe_add(d, d, d);
+  fe_sub(e, b, a);
+  fe_sub(f, d, c);
+  fe_add(gg, d, c);
+  fe_add(h, b, a);
+  fe_carry(gg);
+  quad_efgh(m, q, e, f, gg, h);
+}
+// acc += pt (affine Niels, already sign-adjusted): the seven products of ge_madd in two rounds
+__device__ __forceinline__ void quad_ge_madd(fe &m, const QuadMask &q, const niels &pt) {
+  fe X, Y, Z, T;
+  quad_bcast<0>(X, m);
+  quad_bcast<1>(Y, m);
+  quad_bcast<2>(Z, m);
+  quad_bcast<3>(T, m);
+  fe l0, l1, l, r, s2, zz;
+  fe_add(l0, Y, X);
+  fe_sub(l1, Y, X);
+  fe_sel4(l, q, l0, l1, T, Z);
+  fe_1(zz);
+  zz.v[0] = 2;  // lane 3: d = 2 Z
+  fe_sel4(r, q, pt.yplusx, pt.yminusx, pt.xy2d, zz);
+  fe_mul(s2, l, r);  // a, b, c, d
+  fe a, b, c, d, e, f, gg, h;
+  quad_bcast<0>(a, s2);
+  quad_bcast<1>(b, s2);
+  quad_bcast<2>(c, s2);
+  quad_bcast<3>(d, s2);
+  fe_sub(e, a, b);
+  fe_add(h, a, b);
+  fe_add(gg, d, c);
+  fe_sub(f, d, c);
+  fe_carry(gg);
+  quad_efgh(m, q, e, f, gg, h);  // X3 = e*f, Y3 = g*h, Z3 = f*g, T3 = e*h
+}
+__device__ __forceinline__ void quad_load(fe &m, const QuadMask &q, const ge &p) { fe_sel4(m, q, p.X, p.Y, p.Z, p.T); }
+__device__ __forceinline__ void quad_gather(ge &p, const fe &m) {
+  quad_bcast<0>(p.X, m);
+  quad_bcast<1>(p.Y, m);
+  quad_bcast<2>(p.Z, m);
+  quad_bcast<3>(p.T, m);
+}
+
 __global__ void __launch_bounds__(64) k_msm_final_quad(const ge *__restrict__ W, MsmPlan plan, ge *__restrict__ R,
                                                        uint32_t *__restrict__ is_identity) {
   const uint32_t lane = threadIdx.x, qi = lane & 3u;
@@ -382,34 +447,8 @@ __global__ void __launch_bounds__(64) k_msm_final_quad(const ge *__restrict__ W,
     }
     // acc += W_k
     {
-      fe X, Y, Z, T;
-      quad_bcast<0>(X, m);
-      quad_bcast<1>(Y, m);
-      quad_bcast<2>(Z, m);
-      quad_bcast<3>(T, m);
       const ge wk = w[k];
-      fe l0, r0, l1, r1, l, r, s2;
-      fe_sub(l0, Y, X);
-      fe_sub(r0, wk.Y, wk.X);
-      fe_add(l1, Y, X);
-      fe_add(r1, wk.Y, wk.X);
-      fe_sel4(l, q, l0, l1, T, Z);
-      fe_sel4(r, q, r0, r1, wk.T, wk.Z);
-      fe_mul(s2, l, r);  // a, b, T*T', Z*Z'
-      fe_sel4(r, q, one, one, d2, one);
-      fe_mul(s2, s2, r);  // lane 2: c = T*T'*2d; the others multiply by one
-      fe a, b, c, d, e, f, gg, h;
-      quad_bcast<0>(a, s2);
-      quad_bcast<1>(b, s2);
-      quad_bcast<2>(c, s2);
-      quad_bcast<3>(d, s2);
-      fe_add(d, d, d);
-      fe_sub(e, b, a);
-      fe_sub(f, d, c);
-      fe_add(gg, d, c);
-      fe_add(h, b, a);
-      fe_carry(gg);
-      quad_efgh(m, q, e, f, gg, h);
+      quad_ge_add(m, q, wk, d2, one);
     }
   }
   ge acc;
@@ -420,6 +459,106 @@ __global__ void __launch_bounds__(64) k_msm_final_quad(const ge *__restrict__ W,
   if (active && qi == 0) {
     R[g] = acc;
     is_identity[g] = ge_is_ristretto_identity(acc) ? 1u : 0u;
+  }
+}
+
+// ---- Latency forms of the bucket accumulation and of the row/column bucket reduction for SMALL inputs (a single
+// batch: a few thousand buckets on an otherwise idle chip): four lanes per bucket / per row-column accumulator, every
+// addition split over the quad (quad_ge_madd / quad_ge_add).  Same arithmetic, ~3x shorter dependency chains. ----
+__global__ void __launch_bounds__(64) k_msm_accumulate_quad(const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ starts,
+                                                            const uint32_t *__restrict__ counts, const uint32_t *__restrict__ order,
+                                                            PointTables tabs, uint32_t n_buckets, ge *__restrict__ buckets) {
+  const uint32_t lane = threadIdx.x, qi = lane & 3u;
+  const QuadMask q = quad_mask(qi);
+  const uint32_t slot = blockIdx.x * 16u + (lane >> 2);
+  if (slot >= n_buckets) return;  // whole quads leave together
+  const uint32_t bkt = order[slot];
+  const uint32_t a = starts[bkt], n = counts[bkt];
+  if (n == 0) return;
+  fe m;
+  {
+    ge id;
+    ge_identity(id);
+    quad_load(m, q, id);
+  }
+  uint32_t e = sorted[a];
+  niels pt = *point_ptr(tabs, e & 0x7fffffffu);
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t e_cur = e;
+    niels cur = pt;
+    if (i + 1 < n) {
+      e = sorted[a + i + 1];
+      pt = *point_ptr(tabs, e & 0x7fffffffu);
+    }
+    niels_cneg(cur, (e_cur >> 31) != 0);
+    quad_ge_madd(m, q, cur);
+  }
+  // lane q writes coordinate q
+  fe *dst = (fe *)(buckets + bkt);
+  dst[qi] = m;
+}
+
+// one workgroup of 256 lanes per (group, window): quad i plays the part of lane i of k_msm_window_rc
+__global__ void __launch_bounds__(256) k_msm_window_rc_quad(const ge *__restrict__ buckets, const uint32_t *__restrict__ counts,
+                                                            MsmPlan plan, ge *__restrict__ W) {
+  const uint32_t gk = blockIdx.x, tid = threadIdx.x, qi = tid & 3u, lane = tid >> 2;
+  const QuadMask q = quad_mask(qi);
+  const uint32_t nb = plan.nb, lb = plan.c - 1;
+  const uint32_t lBc = lb / 2, Bc = 1u << lBc, A = nb >> lBc;  // A >= Bc
+  const size_t base = (size_t)gk * nb;
+  __shared__ ge red[64];
+  fe d2, one, m;
+  fe_const(d2, FE_D2);
+  fe_1(one);
+  ge id;
+  ge_identity(id);
+  quad_load(m, q, id);
+  const bool is_row = lane < 32;
+  const uint32_t idx = is_row ? lane : lane - 32;
+  if (is_row ? (idx < A) : (idx < Bc)) {
+    const uint32_t cnt = is_row ? Bc : A;
+    for (uint32_t k = 0; k < cnt; k++) {
+      const uint32_t j0 = is_row ? (Bc * idx + k) : (Bc * k + idx);
+      if (counts[base + j0]) {
+        const ge x = buckets[base + j0];
+        quad_ge_add(m, q, x, d2, one);
+      }
+    }
+  }
+  fe *slot = (fe *)&red[lane];
+  // suffix scan within each half: x[i] = sum_{i' >= i} x[i']
+  slot[qi] = m;
+  __syncthreads();
+  const uint32_t half_n = is_row ? A : Bc;
+  for (uint32_t off = 1; off < 32; off <<= 1) {
+    ge y2;
+    const bool act = idx + off < half_n;
+    if (act) y2 = red[lane + off];
+    __syncthreads();
+    if (act) {
+      quad_ge_add(m, q, y2, d2, one);
+      slot[qi] = m;
+    }
+    __syncthreads();
+  }
+  // rows: sum_a a*R_a = sum_{i>=1} suffix_i ; columns (b = idx+1): sum_b b*C_b = sum_{i>=0} suffix_i
+  if (is_row ? (idx == 0 || idx >= A) : (idx >= Bc)) quad_load(m, q, id);
+  slot[qi] = m;
+  __syncthreads();
+  for (uint32_t off = 16; off >= 1; off >>= 1) {
+    if (idx < off) {
+      const ge y2 = red[lane + off];
+      quad_ge_add(m, q, y2, d2, one);
+      slot[qi] = m;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    ge rows = red[0];
+    const ge cols = red[32];
+    if (lBc) ge_dbl_n(rows, rows, (int)lBc);
+    ge_add(rows, rows, cols);
+    W[gk] = rows;
   }
 }
 

@@ -161,3 +161,28 @@ def test_both_pass1_kernels(bpp, engine, monkeypatch, wave):
     with pytest.raises(bpp.ProofError) as e:
         bpp.RangeProof.verify_batch(case.transcripts(), case.statements_public, bad, bpp.VerifyAction.VerifyOnly)
     assert e.value.kind == bpp.ProofErrorKind.VerificationFailed
+
+
+@pytest.mark.parametrize("quad", ["0", "1"])
+def test_both_bucket_kernel_forms(bpp, engine, monkeypatch, quad):
+    """bucket accumulation / row-column reduction exist in a one-lane-per-bucket form (many buckets) and a quad form (few
+    buckets, latency); force each on the same input: MSM result, accept / reject and the B1 multiscalar API must agree"""
+    monkeypatch.setenv("BPP_MSM_QUAD", quad)
+    case = make_batch(bpp, engine, 32, [1, 2, 1, 1, 4, 1], 1, seed=b"bucket-forms")
+    rb = bpp.ResidentBatch(case.transcripts(), case.statements_public, case.proofs)
+    assert rb.verify(bpp.VerifyAction.VerifyOnly, chunk=0) == [None] * 6
+    assert rb.trace(6) == bytes(32)
+    rb.close()
+    raw = bytearray(case.proofs[4].to_bytes())
+    raw[1 + 32 + 96 + 5] ^= 2  # r1
+    bad = list(case.proofs)
+    bad[4] = bpp.RangeProof.from_bytes(bytes(raw))
+    with pytest.raises(bpp.ProofError) as e:
+        bpp.RangeProof.verify_batch(case.transcripts(), case.statements_public, bad, bpp.VerifyAction.VerifyOnly)
+    assert e.value.kind == bpp.ProofErrorKind.VerificationFailed
+    n = 300
+    pts = [C.from_uniform_bytes(_h(b"bf-p", i, 64)) for i in range(40)]
+    pts = [pts[i % 40] for i in range(n)]
+    scalars = [int.from_bytes(_h(b"bf-s", i), "little") % C.L for i in range(n)]
+    got = engine.msm_vartime([sb(s_) for s_ in scalars], [p_.compress() for p_ in pts])
+    assert got == C.multiscalar_mul(scalars, pts).compress()
