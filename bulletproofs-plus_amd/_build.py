@@ -49,6 +49,21 @@ def build_hosttest(force=False):
     return HOSTTEST_LIB
 
 
+SANITIZER_BIN = os.path.join(HERE, "hosttest_upload_asan")
+
+
+def build_sanitizer_harness(force=False):
+    """hosttest_upload.cpp (host packer of bpp_batch_upload + the arithmetic probes) under ASan + UBSan: an executable,
+    run by tests/test_host_sanitizers.py.  GPU sanitizers are not available on the pool; this is the CPU build."""
+    src = os.path.join(CSRC, "hosttest_upload.cpp")
+    deps = [src, os.path.join(CSRC, "hosttest.cpp")] + [os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _stale(SANITIZER_BIN, deps):
+        return SANITIZER_BIN
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-fno-omit-frame-pointer", "-o", SANITIZER_BIN, src], check=True, cwd=CSRC)
+    return SANITIZER_BIN
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     build_hosttest(force="--force" in sys.argv)

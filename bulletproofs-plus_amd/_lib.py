@@ -37,11 +37,13 @@ SYMBOLS = [
     ("bpp_ctx_last_error", c_char_p, [c_void_p]),
     ("bpp_precomp_create", c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_uint64)]),
     ("bpp_precomp_destroy", c_int, [c_void_p, c_uint64]),
+    ("bpp_precomp_retain", c_int, [c_void_p, c_uint64]),
     ("bpp_msm_mixed", c_int, [c_void_p, c_uint64, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("bpp_msm_vartime", c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("bpp_msm_vartime_batched", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("bpp_params_create", c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, POINTER(c_uint64)]),
     ("bpp_params_destroy", c_int, [c_void_p, c_uint64]),
+    ("bpp_params_retain", c_int, [c_void_p, c_uint64]),
     ("bpp_params_export", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("bpp_pedersen_commit", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_uint32, c_size_t, c_void_p]),
     ("bpp_verify_batch", c_int, [c_void_p, c_uint64, POINTER(VerifyItem), c_size_t, c_int, c_size_t, c_void_p,

@@ -240,6 +240,21 @@ class RangeParameters:
         self.pc_gens = PedersenGens(self._t, self._h, self._g)
         return self
 
+    def share(self, engine):
+        """Arc::clone for another context of the same device (bpp_params_retain): the SAME device tables, usable from
+        `engine` concurrently with every other holder (src/traits.rs:42 `Precomputation: Send + Sync`)."""
+        _check(engine.lib.bpp_params_retain(engine.ctx, self.handle), engine.ctx)
+        other = object.__new__(RangeParameters)
+        other.__dict__.update(self.__dict__)
+        other.engine = engine
+        return other
+
+    def close(self):
+        """drop this holder's reference (bpp_params_destroy)"""
+        if self.handle.value:
+            self.engine.lib.bpp_params_destroy(self.engine.ctx, self.handle)
+            self.handle = c_uint64()
+
     def bit_length(self):
         return self._n
 

@@ -18,6 +18,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -29,6 +30,7 @@
 #include "kernels_prove.h"
 #include "kernels_verify.h"
 #include "msm.h"
+#include "upload_host.h"
 
 using namespace bpp;
 
@@ -105,10 +107,17 @@ struct PinnedBuf {
   }
 };
 
-struct ProofErr {
-  int code;
-  std::string msg;
+// runs on every exit path of a scope (return, ProofErr, EngineError): used to wipe secret-bearing buffers, as the
+// reference does with Zeroizing<> (src/range_proof.rs:300-301,325,438-464, src/commitment_opening.rs:14)
+struct ScopeExit {
+  std::function<void()> f;
+  ~ScopeExit() {
+    if (f) f();
+  }
 };
+inline void wipe(void *p, size_t n) {
+  if (p && n) explicit_bzero(p, n);
+}
 
 void set_err(char *errbuf, size_t len, const std::string &m) {
   if (errbuf && len) {
@@ -166,7 +175,12 @@ void weights_from_chain_host(const uint8_t *rng32, size_t n, uint8_t *weights32)
 }
 
 // ------------------------------------------------------------------ objects
+// RangeParameters / Precomputation objects are process-wide, reference-counted and read-only once built (the reference
+// shares them through Arc, `Precomputation: Send + Sync`, src/traits.rs:42, src/generators/bulletproof_gens.rs:52,103):
+// any context of the same device may use a handle concurrently; only work buffers are per context.
 struct Params {
+  int device = 0;
+  std::mutex fb_mu;  // serialises the one-off build of the prover's fixed-base table
   uint32_t n_bits, m_max, t;
   DevBuf<niels> table;  // [2*n*m_max interleaved G,H | t g_bases | h_base]
   uint32_t table_len;
@@ -179,9 +193,61 @@ struct Params {
 };
 
 struct Precomp {
+  int device = 0;
   DevBuf<niels> table;
   uint32_t count;
 };
+
+template <typename T>
+struct SharedRegistry {
+  struct Entry {
+    std::shared_ptr<T> obj;
+    uint32_t refs;
+  };
+  std::mutex mu;
+  std::map<uint64_t, Entry> live;
+  uint64_t add(std::shared_ptr<T> o);
+  std::shared_ptr<T> get(uint64_t h) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = live.find(h);
+    return it == live.end() ? nullptr : it->second.obj;
+  }
+  bool retain(uint64_t h) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = live.find(h);
+    if (it == live.end()) return false;
+    it->second.refs++;
+    return true;
+  }
+  // drops one reference; the object itself lives on while a call or a resident batch still holds its shared_ptr
+  bool release(uint64_t h) {
+    std::shared_ptr<T> dying;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = live.find(h);
+    if (it == live.end()) return false;
+    if (--it->second.refs == 0) {
+      dying = std::move(it->second.obj);
+      live.erase(it);
+    }
+    return true;
+  }
+};
+std::atomic<uint64_t> g_next_handle{1};
+template <typename T>
+uint64_t SharedRegistry<T>::add(std::shared_ptr<T> o) {
+  const uint64_t h = g_next_handle.fetch_add(1);
+  std::lock_guard<std::mutex> lk(mu);
+  live[h] = Entry{std::move(o), 1};
+  return h;
+}
+SharedRegistry<Params> &params_registry() {
+  static SharedRegistry<Params> *r = new SharedRegistry<Params>();  // leaked: contexts may outlive static destruction
+  return *r;
+}
+SharedRegistry<Precomp> &precomp_registry() {
+  static SharedRegistry<Precomp> *r = new SharedRegistry<Precomp>();
+  return *r;
+}
 
 struct MsmWork {
   DevBuf<int16_t> digits;
@@ -195,12 +261,13 @@ struct MsmWork {
 };
 
 struct Batch {
-  Params *params = nullptr;
+  std::shared_ptr<Params> params;
   uint64_t params_handle = 0;
   uint32_t B = 0, rmax = 0, cs = 0, max_mn = 0, total_dyn = 0, sum_m = 0, cols = 0;
   std::vector<ProofDesc> desc;
   std::vector<uint8_t> rounds_bad;  // 0 ok, 3 InvalidLength, 5 SizeOverflow  (src/range_proof.rs:875-888)
-  bool any_seed = false, any_rounds_bad = false, ext_challenges = false, uniform_rounds = true;
+  std::vector<uint8_t> defer;       // BPP_DEFER_* findings of verify()'s consistency loops (:637-682), raised per chunk
+  bool any_seed = false, any_rounds_bad = false, any_defer = false, ext_challenges = false, uniform_rounds = true;
   std::vector<uint32_t> ext_status;
   DevBuf<uint32_t> d_ext_status;
   // device-resident inputs
@@ -247,9 +314,8 @@ struct bpp_ctx {
   bool own_stream = false;
   std::string err;
   std::mutex mu;
-  uint64_t next_handle = 1;
-  std::map<uint64_t, std::unique_ptr<Params>> params;
-  std::map<uint64_t, std::unique_ptr<Precomp>> precomps;
+  // references this context holds on shared objects (created or retained here): released when the context dies
+  std::multiset<uint64_t> held_params, held_precomps;
   std::map<uint64_t, std::unique_ptr<Batch>> batches;
   std::unique_ptr<Batch> spare_batch;  // buffers of the last destroyed batch (adopt_buffers)
   PinnedBuf<uint8_t> pin_upload, pin_upload2;  // page-locked staging of bpp_batch_upload (bytes; descriptors etc.)
@@ -470,37 +536,6 @@ int msm_host_entry(bpp_ctx *ctx, const niels *tab_a, uint32_t n_a, const uint8_t
   return BPP_OK;
 }
 
-// ------------------------------------------------------------------ batch upload (host parsing + packing)
-struct ParsedItem {
-  uint32_t t, rounds;
-};
-
-// RangeProof::from_bytes (src/range_proof.rs:1155-1257): structure + canonical scalars; points are not validated here
-void parse_proof(const uint8_t *p, size_t len, ParsedItem &out) {
-  if (len < 1) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Serialized proof is too short"};
-  uint32_t t = p[0];
-  if (t < 1 || t > 6) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Extension degree not valid"};
-  size_t body = len - 1, nchunks = body / 32, rem = body % 32;
-  auto need = [&](size_t idx) {
-    if (idx >= nchunks) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Serialized proof is too short"};
-  };
-  auto scalar_at = [&](size_t idx) {
-    need(idx);
-    if (!sc_is_canonical(p + 1 + 32 * idx)) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Invalid parsing"};
-  };
-  for (size_t k = 0; k < t; k++) scalar_at(k);
-  need(t);
-  need(t + 1);
-  need(t + 2);
-  scalar_at(t + 3);
-  scalar_at(t + 4);
-  size_t rest = nchunks - (t + 5);
-  if (rest / 2 == 0) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Serialized proof is too short"};
-  if ((rest % 2) || rem) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Unused data after deserialization"};
-  out.t = t;
-  out.rounds = (uint32_t)(rest / 2);
-}
-
 }  // namespace
 
 // =================================================================== C ABI
@@ -538,8 +573,8 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   ctx->batches.clear();
   ctx->spare_batch.reset();
-  ctx->precomps.clear();
-  ctx->params.clear();
+  for (uint64_t h : ctx->held_precomps) (void)precomp_registry().release(h);
+  for (uint64_t h : ctx->held_params) (void)params_registry().release(h);
   if (ctx->ev_ready)
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->ev_rng_ready) (void)hipEventDestroy(ctx->ev_rng);
@@ -569,15 +604,16 @@ int bpp_precomp_create(bpp_ctx *ctx, const uint8_t *points32, size_t count, uint
   BPP_ENTRY(ctx);
   try {
     if (!handle || (!points32 && count)) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument");
-    auto pc = std::make_unique<Precomp>();
+    auto pc = std::make_shared<Precomp>();
+    pc->device = ctx->device;
     pc->count = (uint32_t)count;
     pc->table.alloc(count);
     if (count) {
       uint32_t bad = decompress_to_device(ctx, points32, count, pc->table.p);
       if (bad) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "point is not a canonical ristretto255 encoding");
     }
-    uint64_t h = ctx->next_handle++;
-    ctx->precomps[h] = std::move(pc);
+    const uint64_t h = precomp_registry().add(std::move(pc));
+    ctx->held_precomps.insert(h);
     *handle = h;
     return BPP_OK;
   }
@@ -586,16 +622,19 @@ int bpp_precomp_create(bpp_ctx *ctx, const uint8_t *points32, size_t count, uint
 
 int bpp_precomp_destroy(bpp_ctx *ctx, uint64_t handle) {
   BPP_ENTRY(ctx);
-  return ctx->precomps.erase(handle) ? BPP_OK : BPP_ERR_BAD_HANDLE;
+  auto it = ctx->held_precomps.find(handle);
+  if (it == ctx->held_precomps.end()) return BPP_ERR_BAD_HANDLE;  // this context holds no reference on it
+  ctx->held_precomps.erase(it);
+  return precomp_registry().release(handle) ? BPP_OK : BPP_ERR_BAD_HANDLE;
 }
 
 int bpp_msm_mixed(bpp_ctx *ctx, uint64_t handle, const uint8_t *static_scalars32, size_t n_static,
                   const uint8_t *dyn_scalars32, const uint8_t *dyn_points32, size_t n_dyn, uint8_t out_point32[32]) {
   BPP_ENTRY(ctx);
   try {
-    auto it = ctx->precomps.find(handle);
-    if (it == ctx->precomps.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown precomputation handle");
-    Precomp &pc = *it->second;
+    const std::shared_ptr<Precomp> pcp = precomp_registry().get(handle);
+    if (!pcp || pcp->device != ctx->device) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown precomputation handle");
+    Precomp &pc = *pcp;
     if (n_static > pc.count) return fail(ctx, BPP_ERR_INVALID_LENGTH, "more static scalars than precomputed points");
     return msm_host_entry(ctx, pc.table.p, pc.count, static_scalars32, n_static, dyn_scalars32, dyn_points32, n_dyn,
                           nullptr, 1, out_point32);
@@ -641,7 +680,8 @@ int bpp_params_create(bpp_ctx *ctx, uint32_t bit_length, uint32_t max_aggregatio
       return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "Extension degree not valid");
     if ((uint64_t)bit_length * max_aggregation > 2048)
       return fail(ctx, BPP_ERR_SIZE_OVERFLOW, "bit_length * max_aggregation > 2048 is not supported by this engine");
-    auto P = std::make_unique<Params>();
+    auto P = std::make_shared<Params>();
+    P->device = ctx->device;
     P->n_bits = bit_length;
     P->m_max = max_aggregation;
     P->t = extension_degree;
@@ -718,8 +758,8 @@ int bpp_params_create(bpp_ctx *ctx, uint32_t bit_length, uint32_t max_aggregatio
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     P->d_hg32.alloc(P->hg32.size());
     HIP_CHECK(hipMemcpy(P->d_hg32.p, P->hg32.data(), P->hg32.size(), hipMemcpyHostToDevice));
-    uint64_t h = ctx->next_handle++;
-    ctx->params[h] = std::move(P);
+    const uint64_t h = params_registry().add(std::move(P));
+    ctx->held_params.insert(h);
     *params = h;
     return BPP_OK;
   }
@@ -728,15 +768,37 @@ int bpp_params_create(bpp_ctx *ctx, uint32_t bit_length, uint32_t max_aggregatio
 
 int bpp_params_destroy(bpp_ctx *ctx, uint64_t params) {
   BPP_ENTRY(ctx);
-  return ctx->params.erase(params) ? BPP_OK : BPP_ERR_BAD_HANDLE;
+  auto it = ctx->held_params.find(params);
+  if (it == ctx->held_params.end()) return BPP_ERR_BAD_HANDLE;  // this context holds no reference on it
+  ctx->held_params.erase(it);
+  // resident batches and calls in flight keep their own shared_ptr: the tables are freed when the last user is gone
+  return params_registry().release(params) ? BPP_OK : BPP_ERR_BAD_HANDLE;
+}
+
+int bpp_params_retain(bpp_ctx *ctx, uint64_t params) {
+  BPP_ENTRY(ctx);
+  const std::shared_ptr<Params> P = params_registry().get(params);
+  if (!P || P->device != ctx->device) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle (or another device's)");
+  if (!params_registry().retain(params)) return BPP_ERR_BAD_HANDLE;
+  ctx->held_params.insert(params);
+  return BPP_OK;
+}
+
+int bpp_precomp_retain(bpp_ctx *ctx, uint64_t handle) {
+  BPP_ENTRY(ctx);
+  const std::shared_ptr<Precomp> pc = precomp_registry().get(handle);
+  if (!pc || pc->device != ctx->device) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown precomputation handle (or another device's)");
+  if (!precomp_registry().retain(handle)) return BPP_ERR_BAD_HANDLE;
+  ctx->held_precomps.insert(handle);
+  return BPP_OK;
 }
 
 int bpp_params_export(bpp_ctx *ctx, uint64_t params, uint8_t *gi_out32, uint8_t *hi_out32, uint8_t *h_out32,
                       uint8_t *g_out32) {
   BPP_ENTRY(ctx);
-  auto it = ctx->params.find(params);
-  if (it == ctx->params.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle");
-  Params &P = *it->second;
+  const std::shared_ptr<Params> Pp = params_registry().get(params);
+  if (!Pp || Pp->device != ctx->device) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle");
+  Params &P = *Pp;
   if (gi_out32) memcpy(gi_out32, P.gi32.data(), P.gi32.size());
   if (hi_out32) memcpy(hi_out32, P.hi32.data(), P.hi32.size());
   if (h_out32) memcpy(h_out32, P.hg32.data(), 32);
@@ -748,14 +810,22 @@ int bpp_pedersen_commit(bpp_ctx *ctx, uint64_t params, const uint64_t *values, c
                         uint32_t n_blind, size_t count, uint8_t *commitments32) {
   BPP_ENTRY(ctx);
   try {
-    auto it = ctx->params.find(params);
-    if (it == ctx->params.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle");
-    Params &P = *it->second;
+    const std::shared_ptr<Params> Pp = params_registry().get(params);
+    if (!Pp || Pp->device != ctx->device) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle");
+    Params &P = *Pp;
     if (n_blind == 0 || n_blind > P.t) return fail(ctx, BPP_ERR_INVALID_LENGTH, "blinding vector");
     if (count == 0) return BPP_OK;
     // output j = value*H + sum_k r_k G_k over the resident fixed-base table of the Pedersen bases
     const uint32_t per = 1 + n_blind;
-    std::vector<uint8_t> sb(count * per * 32, 0);
+    std::vector<uint8_t> sb(count * per * 32, 0);  // values and blinding factors: wiped on every exit path
+    DevBuf<sc> d_sc;
+    ScopeExit wipe_secrets{[&] {
+      wipe(sb.data(), sb.size());
+      if (d_sc.p) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemset(d_sc.p, 0, d_sc.n * sizeof(sc));
+      }
+    }};
     std::vector<uint32_t> gidx(count * per), cnt(count, per);
     for (size_t j = 0; j < count; j++) {
       uint8_t *v = &sb[(j * per) * 32];
@@ -766,7 +836,6 @@ int bpp_pedersen_commit(bpp_ctx *ctx, uint64_t params, const uint64_t *values, c
       gidx[j * per] = P.t;  // H is the last entry of fb_ped
       for (uint32_t k = 0; k < n_blind; k++) gidx[j * per + 1 + k] = k;
     }
-    DevBuf<sc> d_sc;
     DevBuf<uint32_t> d_g, d_c;
     DevBuf<uint8_t> d_out;
     d_sc.alloc(count * per);
@@ -821,9 +890,9 @@ namespace {
 int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, uint64_t *batch,
                 const uint8_t *const *challenges32, const uint8_t *rng_out32, char *errbuf, size_t errbuf_len) {
   try {
-    auto pit = ctx->params.find(params);
-    if (pit == ctx->params.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle", errbuf, errbuf_len);
-    Params &P = *pit->second;
+    const std::shared_ptr<Params> Pp = params_registry().get(params);
+    if (!Pp || Pp->device != ctx->device) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle", errbuf, errbuf_len);
+    Params &P = *Pp;
     // verify_batch: by definition an empty batch fails (src/range_proof.rs:719-723)
     if (!items || n_items == 0 || !batch)
       return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "Range statements or proofs length empty", errbuf, errbuf_len);
@@ -833,167 +902,34 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
       adopt_buffers(*B, *ctx->spare_batch);
       ctx->spare_batch.reset();
     }
-    B->params = &P;
+    B->params = Pp;
     B->params_handle = params;
     B->B = (uint32_t)n_items;
-    B->desc.resize(n_items);
-    B->rounds_bad.assign(n_items, 0);
-    std::vector<uint8_t> seeds(n_items * 32, 0), states;
-    std::map<std::string, uint32_t> state_ids;
-    // ---- pass A (serial, cheap, validates nothing): running offsets, the round count implied by each proof's length,
-    // transcript ids.  A malformed item gets harmless numbers here; pass B reports it.
-    struct Pre {
-      uint32_t minval_idx, dyn_off, rounds;
-      size_t proof_off;
-    };
-    std::vector<Pre> pre(n_items);
-    size_t proof_bytes = 0, sum_m = 0;
-    uint64_t dyn64 = 0;
-    size_t tr_err_index = n_items;  // first item whose explicit transcript state is unusable
-    for (size_t i = 0; i < n_items; i++) {
-      const bpp_verify_item &it = items[i];
-      ProofDesc &d = B->desc[i];
-      uint32_t rounds = 0;
-      if (it.proof && it.proof_len >= 1) {
-        const size_t t0 = it.proof[0], nchunks = (it.proof_len - 1) / 32;
-        if (nchunks > t0 + 5) rounds = (uint32_t)std::min<size_t>((nchunks - (t0 + 5)) / 2, 1u << 20);
-      }
-      pre[i] = Pre{(uint32_t)sum_m, (uint32_t)dyn64, rounds, proof_bytes};
-      proof_bytes += it.proof ? it.proof_len : 0;
-      sum_m += it.m;
-      dyn64 += (uint64_t)it.m + 3 + 2 * (uint64_t)rounds;
-      // transcript: explicit state wins, else Transcript::new(label).  Same source as the previous item (the common case:
-      // one label for the whole batch) -> same id, no key building / map lookup
-      const bpp_verify_item *prev = i ? &items[i - 1] : nullptr;
-      if (prev && prev->transcript_state == it.transcript_state && prev->transcript_label == it.transcript_label &&
-          prev->label_len == it.label_len) {
-        d.state_idx = B->desc[i - 1].state_idx;
-        continue;
-      }
-      std::string key;
-      if (it.transcript_state) {
-        key.assign((const char *)it.transcript_state, 203);
-        key.push_back('S');
-      } else {
-        key.assign((const char *)it.transcript_label, it.transcript_label ? it.label_len : 0);
-        key.push_back('L');
-      }
-      auto sit = state_ids.find(key);
-      if (sit == state_ids.end()) {
-        uint32_t id = (uint32_t)(states.size() / 203);
-        states.resize(states.size() + 203);
-        if (it.transcript_state) {
-          memcpy(&states[(size_t)id * 203], it.transcript_state, 203);
-          if (states[(size_t)id * 203 + 200] >= BPP_STROBE_R && tr_err_index == n_items) tr_err_index = i;
-        } else {
-          Strobe st;
-          merlin_new(st, it.transcript_label, (uint32_t)(it.transcript_label ? it.label_len : 0));
-          strobe_to_bytes(&states[(size_t)id * 203], st);
-        }
-        sit = state_ids.emplace(key, id).first;
-      }
-      d.state_idx = sit->second;
-    }
-    // proof and commitment bytes are assembled directly in page-locked staging: a pageable source makes hipMemcpyAsync
-    // return early and the 40 MB transfer trickle on at ~2.4 GB/s behind the call (it showed up as 23 ms in the first
-    // verification of every freshly uploaded batch)
-    const size_t bytes_total = proof_bytes + sum_m * 32;
-    // 32-bit byte offsets and slot numbers (bit 31 of a slot / point index carries a flag)
-    if (bytes_total >= (1ull << 32) || sum_m >= (1ull << 28) || dyn64 >= (1ull << 31))
-      return fail(ctx, BPP_ERR_SIZE_OVERFLOW, "batch too large for one call (4 GB of proof bytes)", errbuf, errbuf_len);
-    ctx->pin_upload.resize(bytes_total + 64);
+    // host planner (upload_host.h): pass A sizes the layout, pass B validates and packs on the host pool.  Proof and
+    // commitment bytes are assembled directly in page-locked staging: a pageable source makes hipMemcpyAsync return early
+    // and the 40 MB transfer trickle on at ~2.4 GB/s behind the call (it showed up as 23 ms in the first verification of
+    // every freshly uploaded batch)
+    UploadPlan pl;
+    upload_pass_a(items, n_items, pl);
+    ctx->pin_upload.resize(pl.bytes_total + BPP_BYTES_SLACK);
     uint8_t *bytes = ctx->pin_upload.data();
-    const size_t bytes_len = bytes_total;
-    const uint32_t dyn = (uint32_t)dyn64;
-    std::vector<uint64_t> minvals(sum_m, 0);
-    // ---- pass B (host pool): per item, the checks in the reference's order + the copies.  Every worker stops at the
-    // first bad item of its range; the lowest index over all ranges is reported, as the serial loop would
-    struct Part {
-      size_t err_index;
-      ProofErr err;
-      bool any_seed = false, any_rounds_bad = false, uniform = true;
-      uint32_t rmax = 0, max_mn = 0;
-    };
-    const uint32_t n_parts = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, n_items / 512));
-    std::vector<Part> parts(n_parts);
-    const uint32_t rounds0 = pre[0].rounds;
-    auto one_item = [&](size_t i, Part &pt) {
-      const bpp_verify_item &it = items[i];
-      ProofDesc &d = B->desc[i];
-      // RangeStatement::init (src/range_statement.rs:36-73)
-      if (it.m == 0 || (it.m & (it.m - 1)))
-        throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Number of commitments must be a power of two"};
-      if (!it.commitments32 || (!it.min_values && it.min_present))
-        throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Incorrect number of minimum value promises"};
-      if (P.m_max < it.m) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Not enough generators for this statement"};
-      if (it.seed_nonce32 && it.m > 1)
-        throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Mask recovery is not supported with an aggregated statement"};
-      if (!it.proof) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Serialized proof is too short"};
-      ParsedItem pi;
-      parse_proof(it.proof, it.proof_len, pi);
-      // verify_statements_and_generators_consistency (src/range_proof.rs:637-659): extension degree of every proof
-      if (pi.t != P.t) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Inconsistent extension degree"};
-      d.proof_off = (uint32_t)pre[i].proof_off;
-      memcpy(bytes + pre[i].proof_off, it.proof, it.proof_len);
-      d.rounds = pi.rounds;  // == pre[i].rounds for every proof that parses
-      d.m = it.m;
-      d.minval_idx = pre[i].minval_idx;
-      for (uint32_t j = 0; j < it.m; j++) {
-        bool present = it.min_present ? it.min_present[j] != 0 : false;
-        uint64_t v = (present && it.min_values) ? it.min_values[j] : 0;
-        // :675-681
-        if (present && P.n_bits < 64 && (v >> P.n_bits) > 0)
-          throw ProofErr{BPP_ERR_INVALID_LENGTH, "Minimum value promise exceeds bit vector capacity"};
-        minvals[pre[i].minval_idx + j] = v;
-      }
-      d.dyn_off = pre[i].dyn_off;
-      d.flags = it.seed_nonce32 ? 1u : 0u;
-      if (it.seed_nonce32) {
-        memcpy(&seeds[i * 32], it.seed_nonce32, 32);
-        pt.any_seed = true;
-      }
-      if (i == tr_err_index) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "transcript state has pos >= rate"};
-      // structural checks evaluated with PASS-2 precedence at verify time (:875-888)
-      const uint64_t mn = (uint64_t)it.m * P.n_bits;
-      if (pi.rounds >= 32)
-        B->rounds_bad[i] = BPP_ERR_SIZE_OVERFLOW;
-      else if ((1ull << pi.rounds) != mn)
-        B->rounds_bad[i] = BPP_ERR_INVALID_LENGTH;
-      if (B->rounds_bad[i]) pt.any_rounds_bad = true;
-      if (pi.rounds != rounds0) pt.uniform = false;
-      pt.rmax = std::max(pt.rmax, pi.rounds);
-      pt.max_mn = std::max(pt.max_mn, (uint32_t)mn);
-      // commitments follow all proofs
-      d.commit_off = (uint32_t)(proof_bytes + 32 * (size_t)pre[i].minval_idx);
-      memcpy(bytes + d.commit_off, it.commitments32, (size_t)it.m * 32);
-    };
-    host_parallel_for(n_parts, [&](uint32_t k) {
-      Part &pt = parts[k];
-      pt.err_index = n_items;
-      const size_t lo = n_items * k / n_parts, hi = n_items * (k + 1) / n_parts;
-      for (size_t i = lo; i < hi; i++) {
-        try {
-          one_item(i, pt);
-        } catch (const ProofErr &e) {
-          pt.err_index = i;
-          pt.err = e;
-          return;
-        }
-      }
-    });
-    {
-      const Part *first = nullptr;
-      for (const Part &pt : parts)
-        if (pt.err_index < n_items && (!first || pt.err_index < first->err_index)) first = &pt;
-      if (first) throw first->err;
-      for (const Part &pt : parts) {
-        B->any_seed = B->any_seed || pt.any_seed;
-        B->any_rounds_bad = B->any_rounds_bad || pt.any_rounds_bad;
-        B->uniform_rounds = B->uniform_rounds && pt.uniform;
-        B->rmax = std::max(B->rmax, pt.rmax);
-        B->max_mn = std::max(B->max_mn, pt.max_mn);
-      }
-    }
+    memset(bytes + pl.bytes_total, 0, BPP_BYTES_SLACK);
+    const size_t bytes_len = pl.bytes_total + BPP_BYTES_SLACK;
+    upload_pass_b(items, ParamShape{P.n_bits, P.m_max, P.t}, pl, bytes,
+                  [](uint32_t n, const std::function<void(uint32_t)> &fn) { host_parallel_for(n, fn); });
+    B->desc.swap(pl.desc);
+    B->rounds_bad.swap(pl.rounds_bad);
+    B->defer.swap(pl.defer);
+    B->any_seed = pl.any_seed;
+    B->any_rounds_bad = pl.any_rounds_bad;
+    B->any_defer = pl.any_defer;
+    B->uniform_rounds = pl.uniform_rounds;
+    B->rmax = pl.rmax;
+    B->max_mn = pl.max_mn;
+    const std::vector<uint8_t> &seeds = pl.seeds, &states = pl.states;
+    const std::vector<uint64_t> &minvals = pl.minvals;
+    const size_t sum_m = pl.sum_m;
+    const uint32_t dyn = pl.total_dyn;
     B->total_dyn = dyn;
     B->sum_m = (uint32_t)sum_m;
     B->cs = B->rmax + 3;
@@ -1062,6 +998,7 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
           hc[i * B->cs + k] = v;
         }
         // validate_and_append_point (transcript_protocol.rs:48-61): A, A1, B, L_j, R_j must not be the identity encoding
+        if (B->defer[i] & BPP_DEFER_DEGREE) continue;  // other layout: its chunk fails before PASS 1 is looked at
         const uint8_t *pA = items[i].proof + 1 + 32 * P.t;
         auto zero32 = [](const uint8_t *p) {
           uint8_t r = 0;
@@ -1090,7 +1027,7 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
                          B->idx_commit.p, B->sum_m, B->dynpts.p, B->status0.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(s));
-    uint64_t h = ctx->next_handle++;
+    const uint64_t h = g_next_handle.fetch_add(1);
     ctx->batches[h] = std::move(B);
     *batch = h;
     return BPP_OK;
@@ -1444,6 +1381,8 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
     StageTimer tm(ctx);
     hipStream_t s = ctx->stream;
     layout_groups(ctx, b, chunk);
+    // verify()'s own consistency loops (:637-682) come before anything else of the call: with one group nothing needs to run
+    if (b.any_defer && b.G == 1) check_deferred(b.defer, 0, b.B);
     // a proof whose L/R count does not fit its statement makes the call fail (src/range_proof.rs:875-888).  With a
     // single group only the precedence against PASS-1 / decompression errors is still open, so PASS 2 is skipped;
     // with several groups the earlier groups' MSM verdicts still matter (the kernels tolerate the odd shapes).
@@ -1482,6 +1421,7 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
 
     // errors surface chunk by chunk, in the reference's order; a chunk's MSM verdict precedes later chunks' errors
     for (uint32_t g = 0; g < b.G; g++) {
+      if (b.any_defer) check_deferred(b.defer, b.h_group_first[g], b.h_group_first[g + 1]);  // :637-682
       check_chunk_errors(b, b.h_group_first[g], b.h_group_first[g + 1]);
       if (want_msm && !h_ident[g]) throw ProofErr{BPP_ERR_VERIFICATION_FAILED, "Range proof batch not valid"};
     }
@@ -1536,6 +1476,7 @@ int bpp_verify_phase1(bpp_ctx *ctx, uint64_t batch, uint8_t *rng_out32, char *er
     Batch &b = *it->second;
     StageTimer tm(ctx);
     layout_groups(ctx, b, 0);
+    if (b.any_defer) check_deferred(b.defer, 0, b.B);
     enqueue_phase1(ctx, b, tm, b.any_rounds_bad);
     fetch_status(ctx, b);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1680,9 +1621,9 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
                                size_t proof_stride, size_t *proof_len, char *errbuf, size_t errbuf_len) {
   BPP_ENTRY(ctx);
   try {
-    auto pit = ctx->params.find(params);
-    if (pit == ctx->params.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle", errbuf, errbuf_len);
-    Params &P = *pit->second;
+    const std::shared_ptr<Params> Pp = params_registry().get(params);
+    if (!Pp || Pp->device != ctx->device) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle", errbuf, errbuf_len);
+    Params &P = *Pp;
     if (!items || n_items == 0 || !proofs_out) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument", errbuf, errbuf_len);
     const uint32_t n = P.n_bits, t = P.t, m = items[0].m, B = (uint32_t)n_items;
     // RangeStatement::init (src/range_statement.rs:43-62)
@@ -1699,6 +1640,19 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
 
     std::vector<ProveDesc> desc(B);
     std::vector<uint8_t> bytes, states;
+    // `bytes` (values, blinding factors, seed nonces), the page-locked staging in both directions (witness bytes in,
+    // ProveState out) and the device arena hold witness-derived data: wiped on EVERY exit path, including the
+    // "Witness opening is invalid!" and HIP-error ones
+    bool arena_clean = true;
+    ScopeExit wipe_secrets{[&] {
+      wipe(bytes.data(), bytes.size());
+      wipe(ctx->prove_pin_in.p, ctx->prove_pin_in.n);
+      wipe(ctx->prove_pin_out.p, ctx->prove_pin_out.n);
+      if (!arena_clean && ctx->prove_arena.p) {
+        for (auto &ps : ctx->prove_streams) (void)hipStreamSynchronize(ps);
+        (void)hipMemset(ctx->prove_arena.p, 0, ctx->prove_arena.n);
+      }
+    }};
     std::vector<uint64_t> minvals((size_t)B * m);
     std::vector<uint8_t> minpres((size_t)B * m);
     std::map<std::string, uint32_t> state_ids;
@@ -1767,13 +1721,16 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
 
     hipStream_t s0 = ctx->stream;
     const uint32_t n_gen = 2 * P.n_bits * P.m_max;
-    if (!P.fb_table.p) {  // fixed-base window tables for every generator of these parameters (one-off)
+    {  // fixed-base window tables for every generator of these parameters (one-off; contexts sharing P serialise here)
+     std::lock_guard<std::mutex> fb_lock(P.fb_mu);
+     if (!P.fb_table.p) {
       P.fb_geo = fb_geometry(P.table_len);
       P.fb_table.alloc((size_t)P.table_len * fb_stride(P.fb_geo));
       hipLaunchKernelGGL(k_fb_build, dim3(cdiv(P.table_len * P.fb_geo.windows * cdiv(P.fb_geo.entries, FB_BUILD_BLOCK), 64)),
                          dim3(64), 0, s0, P.table.p, P.table_len, P.fb_geo, P.fb_table.p);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipStreamSynchronize(s0));
+     }
     }
     // The batch runs as up to PROVE_SUBS sub-batches, each on its own stream: a round is lane step (one lane per proof,
     // Fiat-Shamir latency, a handful of wavefronts) -> wave step -> fixed-base MSM (fills the chip), so one sub-batch's
@@ -1874,6 +1831,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     ProveState *pin_ps = (ProveState *)(pin_proofs + (((size_t)B * plen + 15) & ~(size_t)15));
 
     const dim3 b64(64);
+    arena_clean = false;
     for (uint32_t q = 0; q < n_sub; q++) {
       Sub &u = subs[q];
       hipStream_t s = ctx->prove_streams[q];
@@ -1914,16 +1872,13 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       HIP_CHECK(hipMemsetAsync(arena_base + u.arena_lo, 0, u.arena_len, s));
     }
     for (uint32_t q = 0; q < n_sub; q++) HIP_CHECK(hipStreamSynchronize(ctx->prove_streams[q]));
-    memset(pin, 0, in_need);
-    const std::vector<ProveState> h_ps(pin_ps, pin_ps + B);
-    const uint8_t *h_proofs = pin_proofs;
-    memset((void *)pin_ps, 0, (size_t)B * sizeof(ProveState));
-    for (uint32_t i = 0; i < B; i++) {
-      if (h_ps[i].status & PV_STATUS_COMMIT_MISMATCH) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Witness opening is invalid!"};
-      if (h_ps[i].status & PV_STATUS_TRANSCRIPT)
+    arena_clean = true;  // every sub-batch's arena range was zeroed on its stream
+    for (uint32_t i = 0; i < B; i++) {  // only the status word of the (secret-bearing) ProveState is looked at
+      if (pin_ps[i].status & PV_STATUS_COMMIT_MISMATCH) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Witness opening is invalid!"};
+      if (pin_ps[i].status & PV_STATUS_TRANSCRIPT)
         throw ProofErr{BPP_ERR_VERIFICATION_FAILED, "Identity element cannot be added to the transcript / zero challenge"};
     }
-    for (uint32_t i = 0; i < B; i++) memcpy(proofs_out + (size_t)i * proof_stride, &h_proofs[(size_t)i * plen], plen);
+    for (uint32_t i = 0; i < B; i++) memcpy(proofs_out + (size_t)i * proof_stride, &pin_proofs[(size_t)i * plen], plen);
     return BPP_OK;
   }
   BPP_CATCH(ctx, errbuf, errbuf_len)

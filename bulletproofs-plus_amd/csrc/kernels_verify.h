@@ -11,28 +11,13 @@
 //   scal[...]      canonical scalars the MSM consumes: [G x cols static | total dynamic]
 #pragma once
 #include "blake2b.h"
+#include "layout.h"
 #include "merlin.h"
 #include "wstrobe.h"
 #include "point.h"
 #include "scalar.h"
 
 namespace bpp {
-
-struct ProofDesc {
-  uint32_t proof_off;   // byte offset of the proof in bytes[]
-  uint32_t rounds;      // number of (L,R) pairs present in the proof
-  uint32_t m;           // aggregation factor of the statement
-  uint32_t commit_off;  // byte offset of the m compressed commitments in bytes[]
-  uint32_t minval_idx;  // index of the first minimum value
-  uint32_t dyn_off;     // index of the first dynamic (scalar, point) slot
-  uint32_t state_idx;   // which initial transcript state
-  uint32_t flags;       // bit0: seed nonce present
-};
-
-// status bits written by the kernels
-#define BPP_ST_TRANSCRIPT_FAIL 1u  // identity encoding appended or zero challenge -> VerificationFailed
-#define BPP_ST_DECOMPRESS_FAIL 2u  // proof point not a canonical encoding          -> InvalidArgument
-#define BPP_ST_COMMIT_FAIL 4u      // statement commitment does not decode           -> InvalidArgument
 
 __device__ __forceinline__ bool bytes32_all_zero(const uint8_t *p) {
   uint32_t r = 0;

@@ -11,7 +11,12 @@
  *  - points cross the boundary as 32-byte canonical ristretto255 encodings, scalars as 32-byte canonical
  *    little-endian integers mod l; no C++ or torch types; caller owns every buffer; nothing is retained.
  *  - return value: 0 = Ok; 1..5 = the reference's ProofError variants (src/errors.rs:11-28); negative = engine fault.
- *  - a ctx is bound to one HIP device and one stream; params/precomp/batch handles belong to their ctx.
+ *  - a ctx is bound to one HIP device and one stream and serialises its own calls; batch handles belong to their ctx.
+ *  - params / precomp handles are process-wide, reference-counted, read-only objects (the reference shares its
+ *    generators and `Precomputation: Send + Sync` tables through Arc: src/traits.rs:42,
+ *    src/generators/bulletproof_gens.rs:52,103): ANY ctx of the same device may pass a live handle, from any thread,
+ *    concurrently; bpp_*_retain is Arc::clone, bpp_*_destroy is drop.  Device tables are freed when the last
+ *    reference, resident batch and call in flight is gone.
  *  - every entry point fails (negative code) if no gfx950 device is usable: there is NO CPU fallback.
  */
 #ifndef BPP_H
@@ -61,6 +66,9 @@ const char *bpp_ctx_last_error(bpp_ctx *ctx);
  * A point that does not decode makes the call return BPP_ERR_INVALID_ARGUMENT. */
 int bpp_precomp_create(bpp_ctx *ctx, const uint8_t *points32, size_t count, uint64_t *handle);
 int bpp_precomp_destroy(bpp_ctx *ctx, uint64_t handle);
+/* Arc::clone: `ctx` takes its own reference on a handle created by another context of the same device (dropped by
+ * bpp_precomp_destroy(ctx, handle) or when ctx is destroyed) */
+int bpp_precomp_retain(bpp_ctx *ctx, uint64_t handle);
 int bpp_msm_mixed(bpp_ctx *ctx, uint64_t handle, const uint8_t *static_scalars32, size_t n_static,
                   const uint8_t *dyn_scalars32, const uint8_t *dyn_points32, size_t n_dyn, uint8_t out_point32[32]);
 int bpp_msm_vartime(bpp_ctx *ctx, const uint8_t *scalars32, const uint8_t *points32, size_t n,
@@ -76,6 +84,10 @@ int bpp_msm_vartime_batched(bpp_ctx *ctx, const uint8_t *scalars32, const uint8_
 int bpp_params_create(bpp_ctx *ctx, uint32_t bit_length, uint32_t max_aggregation, uint32_t extension_degree,
                       const uint8_t *h_base32, const uint8_t *g_bases32, uint64_t *params);
 int bpp_params_destroy(bpp_ctx *ctx, uint64_t params);
+/* Arc::clone of a RangeParameters object (src/range_parameters.rs:20-30 holds Arc'd generators): `ctx` takes its own
+ * reference on `params`, whichever context created it; one set of device tables (generators, and the prover's
+ * fixed-base windows once built) serves every holder */
+int bpp_params_retain(bpp_ctx *ctx, uint64_t params);
 /* compressed generators, party-major like gi_base_iter()/hi_base_iter() (src/range_parameters.rs:99-106):
  * gi_out32, hi_out32: bit_length*max_aggregation x 32; h_out32: 32; g_out32: extension_degree x 32. Any may be NULL. */
 int bpp_params_export(bpp_ctx *ctx, uint64_t params, uint8_t *gi_out32, uint8_t *hi_out32, uint8_t *h_out32,

@@ -26,13 +26,24 @@ def _pt_from(b):
     return C.Point(*[int.from_bytes(b[32 * i:32 * i + 32], "little") for i in range(4)])
 
 
+def _with_member_a(proof, enc):
+    """the proof with its member A replaced by the 32-byte encoding `enc` (wire offset 1 + 32 t)"""
+    raw = bytearray(proof.to_bytes())
+    raw[1 + 32 * proof.extension_degree:1 + 32 * proof.extension_degree + 32] = enc
+    return O.RangeProof.from_bytes(bytes(raw))
+
+
 class OracleOps:
-    def __init__(self, case, lo, hi, tamper=False):
+    def __init__(self, case, lo, hi, tamper=None):
         self.sts = case.o_statements_public[lo:hi]
         self.proofs = case.o_proofs[lo:hi]
-        if tamper:
+        if tamper == "promise":  # only the final MSM notices
             s = self.sts[0]
             self.sts = [O.RangeStatement(s.generators, s.commitments, [(v + 1 if v is not None else 1) for v in s.minimum_value_promises], None)] + self.sts[1:]
+        elif tamper == "identity":  # PASS-1 error: identity element appended to the transcript -> VerificationFailed
+            self.proofs = [self.proofs[0], _with_member_a(self.proofs[1], bytes(32))]
+        elif tamper == "badpoint":  # PASS-2 error: A does not decode -> InvalidArgument
+            self.proofs = [_with_member_a(self.proofs[0], b"\x01" + bytes(31)), self.proofs[1]]
         self.label = case.label
         self.weights_used = None
 
@@ -40,8 +51,13 @@ class OracleOps:
         return [M.Transcript(self.label) for _ in self.proofs]
 
     def phase1(self):
+        """like bpp_verify_phase1: the rng bytes, or the first error of this shard in the reference's order of checks"""
+        api = importlib.import_module("bulletproofs-plus_amd")
         tr = {}
-        O.verify(self._tr(), self.sts, self.proofs, O.VERIFY_ONLY, trace=tr, check=False)
+        try:
+            O.verify(self._tr(), self.sts, self.proofs, O.VERIFY_ONLY, trace=tr, check=False)
+        except O.ProofError as e:
+            raise api.ProofError(e.kind, e.msg)
         return b"".join(tr["rng_outputs"])
 
     def phase2(self, weights32):
@@ -66,7 +82,15 @@ class OracleOps:
         return True
 
 
-SCENARIOS = [("wide", False), ("wide", True), ("shard", False), ("shard", True)]
+# (mode, what rank 0 holds, what rank 1 holds, ProofError kind every rank must see | None)
+SCENARIOS = [("wide", None, None, None), ("wide", None, "promise", 1), ("shard", None, None, None),
+             ("shard", None, "promise", 1),
+             # a phase-1 failure on ONE rank: every rank still reaches both collectives and raises the same error
+             ("wide", None, "identity", 1), ("wide", None, "badpoint", 2), ("wide", "badpoint", None, 2),
+             # PASS-1 errors of ANY proof come before PASS-2 errors (src/range_proof.rs:816-850 vs :859-888)
+             ("wide", "badpoint", "identity", 1),
+             # and the ranks are still in step afterwards
+             ("wide", None, None, None)]
 
 
 def _worker(rank, world, port, q):
@@ -80,13 +104,13 @@ def _worker(rank, world, port, q):
         O.verify([M.Transcript(case.label) for _ in case.o_proofs], case.o_statements_public, case.o_proofs,
                  O.VERIFY_ONLY, trace=tr)
         out = []
-        for mode, tamper in SCENARIOS:
-            ops = OracleOps(case, 2 * rank, 2 * rank + 2, tamper=(tamper and rank == 1))
+        for mode, t0, t1, _want in SCENARIOS:
+            ops = OracleOps(case, 2 * rank, 2 * rank + 2, tamper=(t0, t1)[rank])
             try:
                 res = ("ok", dmod.verify_sharded(ops, 2, torch.device("cpu"), mode=mode))
             except bpp.ProofError as e:
                 res = ("err", int(e.kind))
-            if mode == "wide" and not tamper:
+            if mode == "wide" and t0 is None and t1 is None:
                 # the weights each rank used are exactly the single-process reference weights of its proofs
                 assert ops.weights_used == tr["weights"][2 * rank:2 * rank + 2]
             out.append(res)
@@ -114,9 +138,9 @@ def test_world_size_2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for i, (mode, tamper) in enumerate(SCENARIOS):
+    for i, (mode, t0, t1, want) in enumerate(SCENARIOS):
         for rank in (0, 1):
-            if tamper:
-                assert res[rank][i] == ("err", 1), (mode, rank, res[rank][i])  # VerificationFailed on every rank
+            if want is not None:
+                assert res[rank][i] == ("err", want), (mode, t0, t1, rank, res[rank][i])  # the same error on every rank
             else:
-                assert res[rank][i] == ("ok", True), (mode, rank, res[rank][i])
+                assert res[rank][i] == ("ok", True), (mode, t0, t1, rank, res[rank][i])
