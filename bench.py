@@ -1,236 +1,400 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric on MI355X: 64-bit range proofs verified / second (batch).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode wide|shard] [--config cfg2|cfg3] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--no-extra] [--no-cpu-baseline]
 
-A step = one engine call = one pass of the hot path (RangeProof::verify: transcript replay, decompression, scalar block,
-weight chain, final MSM) over one resident input of --batches-per-step (default 64) INDEPENDENT reference batches of
-BASELINE.json configs[1]: 1024 non-aggregated 64-bit proofs each, extension degree 1, already resident in HBM
-(tests/golden/bench_cfg2.bin, produced by tests/golden/make_golden.py with the recipe of benches/range_proof.rs:206-262).
-Every 1024-proof batch keeps its own weight transcript, its own final MSM and its own identity test, exactly as if it had
-been passed to the reference's verify() alone; --concurrency steps are in flight per GPU and EXACTLY --steps are timed.
-value = proofs verified per second = steps x batches-per-step x 1024 / elapsed.
-N>1 (launched by torch.distributed.run, one rank per GPU), weak scaling: mode "shard" (default) = every rank verifies
-its own batches exactly as at N=1, verdicts combined by one all_reduce; mode "wide" = the union of all ranks' shards is
-ONE reference batch per step (all_gather of transcript-RNG bytes + all_gather of accumulator points over RCCL).
-Prints ONE JSON line on rank 0.
+Headline (value): BASELINE.json configs[1].  A step = one engine call = one pass of the hot path (RangeProof::verify:
+transcript replay, decompression, scalar block, weight chain, final MSM) over one resident input of --batches-per-step
+(default 64) INDEPENDENT reference batches of 1024 non-aggregated 64-bit proofs each, extension degree 1, resident in HBM.
+Every 1024-proof batch keeps its own weight transcript, final MSM and identity test, exactly as if it had been passed
+to the reference's verify() alone.  --concurrency steps are in flight per GPU and EXACTLY --steps are timed;
+value = steps x batches-per-step x 1024 x N / elapsed.  All 64 batches of a step are DISTINCT proofs, made at start-up
+on the box by the engine's own batch prover with the recipe of benches/range_proof.rs:206-262 (the prover's bytes are
+pinned against the oracle in tests/test_gpu_prove.py); every slot holds the same 64 batches in another order.
+
+The same JSON line carries, under "extra", the other BASELINE configs as their own timed legs, each with the roofline of
+its dominant kernel: configs[2] (256 x aggregation-8), one 4096-proof reference batch on one GPU (north_star's target
+sentence), single-call latency at 1 and 256 proofs (configs[0]'s shape, benches/range_proof.rs:115-119), the batch
+prover on configs[4]; "cpu_baseline" times the oracle/c port on one host core AND on all host cores.
+
+N > 1: `python bench.py --gpus N` starts `python -m torch.distributed.run` as a CHILD process (before anything touches
+the GPU) and relays its JSON line; under torchrun it runs as one rank per GPU.  value = weak scaling, every rank runs
+the N=1 step on its own (differently seeded) batches, verdicts combined by one all_reduce; "extra.wide" = BASELINE
+configs[3]: 4096 proofs as ONE reference batch sharded over the N ranks (all_gather of the transcript-RNG bytes,
+replayed weight chain, all_gather of the 128-byte accumulators over RCCL).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+VALU_PEAK_TMAD = 30.1   # measured v_mad_u64_u32 issue peak (tools/microbench/int_rates.hip), see DESIGN.md 4
+LABEL = b"BatchedRangeProofTest"  # benches/range_proof.rs:49
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--mode", default="shard", choices=["wide", "shard"])
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"])
-    ap.add_argument("--chunk", type=int, default=0, help="proofs per reference batch at N=1 (0 = whole batch)")
     ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "6")),
                     help="steps in flight per GPU (one engine/stream + one host thread each)")
-    ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_launch", type=int,
+    ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_step", type=int,
                     default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "64")),
-                    help="independent 1024-proof reference batches verified by one step (one engine call); each keeps its "
-                         "own weight chain, final MSM and identity test")
+                    help="independent 1024-proof reference batches verified by one step (one engine call)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (cfg3, 4096-wide, latency, prover)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per cpu_baseline leg")
+    ap.add_argument("--wide-steps", type=int, default=40)
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """plain `python bench.py --gpus N`: one rank per GPU under torch.distributed.run, as a child process (an exec from
+    a process that has touched the GPU is forbidden on the pool; this one has not even imported torch yet)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
+def make_inputs(np, packed, params, count, seed, chunk=8192):
+    """`count` (statement, proof) pairs with the recipe of benches/range_proof.rs:206-262: value = next_u64 mod 2^63,
+    minimum-value promise value / 3, ONE random blinding repeated t times, seed nonce iff m == 1, label
+    "BatchedRangeProofTest".  Proofs come from the engine's batch prover (bpp_prove_batch)."""
+    n_bits, m, t = params.bit_length(), params.max_aggregation_factor(), int(params.extension_degree())
+    rounds = (n_bits * m).bit_length() - 1
+    rng = np.random.default_rng(seed)
+    values = rng.integers(0, 1 << 63, size=(count, m), dtype=np.uint64)
+    one = rng.integers(0, 256, size=(count, m, 32), dtype=np.uint8)
+    one[..., 31] &= 0x0f  # < 2^252 < l: canonical (zero has probability 2^-252)
+    one[..., 0] |= 1
+    blindings = np.ascontiguousarray(np.repeat(one[:, :, None, :], t, axis=2))
+    min_values = values // np.uint64(3)
+    min_present = np.ones((count, m), dtype=np.uint8)
+    seeds = None
+    if m == 1:
+        seeds = rng.integers(0, 256, size=(count, 32), dtype=np.uint8)
+        seeds[:, 31] &= 0x0f
+    ext = rng.integers(0, 256, size=(count, 32 * (rounds + 3)), dtype=np.uint8)
+    commitments = packed.commit(params, values.reshape(-1), blindings.reshape(count * m, t, 32)).reshape(count, m, 32)
+    proofs = []
+    for lo in range(0, count, chunk):
+        hi = min(count, lo + chunk)
+        proofs.append(packed.prove(params, values[lo:hi], blindings[lo:hi], commitments[lo:hi], min_values[lo:hi],
+                                   min_present[lo:hi], None if seeds is None else seeds[lo:hi], LABEL, ext[lo:hi]))
+    return {"proofs": np.concatenate(proofs), "commitments": commitments, "min_values": min_values, "min_present": min_present,
+            "values": values, "blindings": blindings, "seeds": seeds, "ext": ext}
+
+
+class Leg:
+    """S slots (engine + stream + resident copy of the input) verifying `chunk`-proof reference batches"""
+
+    def __init__(self, bpp, packed, torch, device, params0, data, batch_proofs, batches, slots, chunk):
+        import numpy as np
+        self.bpp, self.chunk, self.slots = bpp, chunk, []
+        self.proofs_per_step = batch_proofs * batches
+        nb = data["proofs"].shape[0] // batch_proofs
+        self.upload_s = self.marshal_s = 0.0
+        for i in range(slots):
+            stream = torch.cuda.Stream(device=device)
+            eng = bpp.Engine(device.index, stream=stream.cuda_stream)
+            eng.profile(True)
+            params = params0.share(eng)  # ONE generator table for every slot (src/traits.rs:42 `Send + Sync`)
+            # the same `nb` distinct batches in another order for every slot
+            order = [(i * 11 + k) % nb for k in range(batches)]
+            idx = np.concatenate([np.arange(b * batch_proofs, (b + 1) * batch_proofs) for b in order])
+            rb = packed.ResidentBatch(params, data["proofs"][idx], data["commitments"][idx], data["min_values"][idx],
+                                      data["min_present"][idx], None, LABEL)
+            self.upload_s, self.marshal_s = rb.upload_seconds, rb.marshal_seconds
+            rb.prepare(chunk)   # group layout, MSM plan, work buffers: not in any timed call
+            rb.verify_only(chunk)  # every slot has run once (events, lazily built state) before anything is timed
+            self.slots.append((stream, eng, params, rb))
+
+    def one_step(self, slot):
+        _, eng, _, rb = self.slots[slot]
+        t0 = time.perf_counter()
+        rb.verify_only(self.chunk)  # raises on an invalid batch
+        return time.perf_counter() - t0, eng.last_profile()
+
+    def run_steps(self, count):
+        """`count` complete steps, at most len(slots) in flight; returns (latencies, stage profiles)"""
+        S = min(len(self.slots), max(count, 1))
+        if S == 1:
+            res = [self.one_step(0) for _ in range(count)]
+        else:
+            nxt, lock, out = [0], threading.Lock(), [[] for _ in range(S)]
+
+            def worker(slot):
+                while True:
+                    with lock:
+                        if nxt[0] >= count:
+                            return
+                        nxt[0] += 1
+                    out[slot].append(self.one_step(slot))
+            ths = [threading.Thread(target=worker, args=(s,)) for s in range(S)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            res = [r for part in out for r in part]
+        return [r[0] for r in res], [r[1] for r in res]
+
+    def close(self):
+        for _, eng, params, rb in self.slots:
+            rb.close()
+            params.close()
+            eng.close()
+
+
+def kernel_roofline(profs, alone_ms=None):
+    """roofline object of k_msm_accumulate from per-step stage profiles (hipEvents on the engine's stream)"""
+    profs = [p for p in profs if p and p.get("msm_final_ms", 0) > 0]
+    if not profs:
+        return None, {}
+    avg = {k: sum(p[k] for p in profs) / len(profs) for k in profs[0]}
+    terms, K, acc_ms = int(avg["msm_terms"]), int(avg["msm_windows"]), avg["msm_accumulate_ms"]
+    msm_bytes = 64 * terms  # 32 B scalar + 32 B compressed point per MSM term
+    achieved = msm_bytes / (acc_ms * 1e-3) / 1e9
+    mads = terms * K * 700.0  # one mixed addition per (term, window) = 7 field multiplications = 700 v_mad_u64_u32
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+           # HBM bytes per launch come from rocprofv3 PMC passes, which cannot run inside this process: see the file
+           "traffic": None, "traffic_profile": "profiles/r02_traffic.json (FETCH_SIZE / WRITE_SIZE passes of this command)",
+           "kernel": "k_msm_accumulate (Pippenger bucket accumulation of the final MSM)", "kernel_ms": acc_ms,
+           "algorithmic_bytes": msm_bytes, "msm_terms_per_launch": terms, "msm_window_bits": int(avg["msm_window_bits"]),
+           "msm_windows": K, "msm_groups": int(avg["msm_groups"]),
+           "note": "integer-VALU bound, not HBM bound (SURVEY 8d): see valu",
+           "valu": {"achieved_Tmad_per_s": mads / (acc_ms * 1e-3) / 1e12, "peak_Tmad_per_s": VALU_PEAK_TMAD,
+                    "frac": mads / (acc_ms * 1e-3) / (VALU_PEAK_TMAD * 1e12)}}
+    if alone_ms:  # same kernel, same launch, no other step in flight (3 launches after the timed region)
+        out["alone"] = {"kernel_ms": alone_ms, "achieved": msm_bytes / (alone_ms * 1e-3) / 1e9,
+                        "frac": msm_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "valu_frac": mads / (alone_ms * 1e-3) / (VALU_PEAK_TMAD * 1e12)}
+    return out, {n: round(v, 4) for n, v in avg.items() if n.endswith("_ms")}
+
+
+def timed(leg, steps, warmup, sync):
+    leg.run_steps(warmup)
+    sync()
+    t0 = time.perf_counter()
+    lat, profs = leg.run_steps(steps)
+    sync()
+    return time.perf_counter() - t0, lat, profs
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     bpp = importlib.import_module("bulletproofs-plus_amd")
-    from tests.golden.loader import load_bench
+    packed = importlib.import_module("bulletproofs-plus_amd.packed")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: exercises the RCCL path)
     if use_dist:
         dist.init_process_group("nccl", device_id=device)
 
-    data = load_bench("bench_%s.bin" % args.config)
-    items = data["items"]
-    if world > 1:  # each rank verifies a different rotation of the fixture, so shards are not byte-identical
-        k = (rank * 131) % len(items)
-        items = items[k:] + items[:k]
-    n_local = len(items)
-
-    import threading
-    from concurrent.futures import ThreadPoolExecutor
-
-    wide = use_dist and args.mode == "wide"
-    S = 1 if wide else max(1, args.concurrency)  # cross-rank collectives must stay in program order -> no threads
-    R = 1 if (wide or args.chunk) else max(1, args.batches_per_launch)
-    S = max(1, min(S, args.steps))
-    lanes = []  # one engine + stream + resident copy of the batch per in-flight slot
-    t_upload = t_marshal = 0.0
-    for i in range(S):
-        stream = torch.cuda.Stream(device=device)
-        eng = bpp.Engine(local_rank, stream=stream.cuda_stream)
-        eng.profile(True)
-        params = bpp.RangeParameters.init(data["bit_length"], data["m"],
-                                          bpp.create_pedersen_gens_with_extension_degree(data["t"]), engine=eng)
-        its = []
-        for r in range(R):  # R distinct rotations of the fixture = R different 1024-proof batches
-            k = ((i * R + r) * 37) % len(items)
-            its += items[k:] + items[:k]
-        sts = [bpp.RangeStatement.init(params, it["commitments"], it["min_values"], None) for it in its]
-        proofs = [bpp.RangeProof.from_bytes(it["proof"]) for it in its]
-        trs = [bpp.Transcript.new(data["label"]) for _ in its]
-        rb = bpp.ResidentBatch(trs, sts, proofs)
-        t_upload, t_marshal = rb.upload_seconds, rb.marshal_seconds
-        lanes.append((stream, eng, rb))
-
-    if wide:
-        dmod = importlib.import_module("bulletproofs-plus_amd.dist")
-        ops = dmod.LocalEngineOps(lanes[0][2])
-
-    def one_step(slot):
-        _, eng, rb = lanes[slot]
-        t0 = time.perf_counter()
-        if wide:
-            dmod.verify_sharded(ops, n_local, device, mode="wide")
-        else:
-            rb.verify(bpp.VerifyAction.VerifyOnly, chunk=(args.chunk or n_local))  # raises on an invalid batch
-        return time.perf_counter() - t0, eng.last_profile()
-
-    def run_steps(count):
-        """`count` complete steps, at most S in flight; returns (per-step latencies, per-step stage profiles)"""
-        if S == 1:
-            res = [one_step(0) for _ in range(count)]
-        else:
-            nxt = [0]
-            lock = threading.Lock()
-
-            def worker(slot):
-                out = []
-                while True:
-                    with lock:
-                        if nxt[0] >= count:
-                            return out
-                        nxt[0] += 1
-                    out.append(one_step(slot))
-            with ThreadPoolExecutor(S) as ex:
-                res = [r for part in ex.map(worker, range(S)) for r in part]
-        return [r[0] for r in res], [r[1] for r in res]
-
     def sync():
         torch.cuda.synchronize(device)
         if use_dist:
             dist.barrier()
 
-    run_steps(args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    lat, profs = run_steps(args.steps)
-    torch.cuda.synchronize(device)
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ok_all = 1
+    G = bpp.create_pedersen_gens_with_extension_degree
+    eng0 = bpp.Engine(local_rank)
+    eng0.profile(True)
+    t_setup = time.perf_counter()
+
+    # ------------------------------------------------------------------ headline: BASELINE configs[1]
+    R, S = max(1, args.batches_per_step), max(1, args.concurrency)
+    params2 = bpp.RangeParameters.init(64, 1, G(1), engine=eng0)
+    data2 = make_inputs(np, packed, params2, 1024 * R, seed=8675309 + 1000 * rank)
+    leg = Leg(bpp, packed, torch, device, params2, data2, 1024, R, S, 1024)
+    gen_s = time.perf_counter() - t_setup
+    elapsed, lat, profs = timed(leg, args.steps, args.warmup, sync)
+    ok_all = 1  # every step raised nothing: all batches of all steps verified
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        flag = torch.tensor([ok_all], dtype=torch.int32, device=device)  # verdicts of independent shards
+        flag = torch.tensor([ok_all], dtype=torch.int32, device=device)  # verdicts of the independent shards
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        assert int(flag.item()) == 1
+        ok_all = int(flag.item())
+    assert ok_all == 1
     # calibration after the timed region: the roofline kernel with nothing co-running (in the timed region several steps
     # share the chip, so each launch of it is stretched by its neighbours)
-    alone_ms = None
-    if not wide:
-        sync()
-        alone = [one_step(0)[1] for _ in range(3)]
-        vals = [a.get("msm_accumulate_ms", 0.0) for a in alone if a]
-        if vals and min(vals) > 0:
-            alone_ms = sum(vals) / len(vals)
-        sync()
-    prof_sum = {}
-    for pf in profs:
-        for k, v in pf.items():
-            prof_sum[k] = prof_sum.get(k, 0.0) + v
+    sync()
+    alone = [leg.one_step(0)[1].get("msm_accumulate_ms", 0.0) for _ in range(3)]
+    alone_ms = sum(alone) / len(alone) if min(alone) > 0 else None
+    sync()
+    roof, stages = kernel_roofline(profs, alone_ms)
+    total = 1024 * R * world * args.steps
+    out = {
+        "metric": "64-bit range proofs verified/sec (batch)", "value": total / elapsed, "unit": "proofs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: reference batches of 1024 x aggregation-1 64-bit proofs, extension degree 1, "
+                               "VerifyOnly, resident in HBM; one step = %d such batches (all distinct proofs) in one engine call" % R,
+                   "proofs_per_reference_batch": 1024, "batches_per_step": R, "proofs_per_step_per_gpu": 1024 * R,
+                   "mode": "each 1024-proof batch is one reference batch: own weight transcript, own final MSM, own identity test",
+                   "steps_in_flight_per_gpu": len(leg.slots), "parallelism": "proof-sharded x%d" % world,
+                   "inputs": "%d distinct proofs per rank, proved on the box by bpp_prove_batch (recipe of "
+                             "benches/range_proof.rs:206-262), %.1f s" % (1024 * R, gen_s)},
+        "step_latency_ms": 1e3 * sum(lat) / len(lat),
+        "host_threads": bpp.host_threads(), "nproc": os.cpu_count(),
+    }
+    if roof:
+        out["roofline"] = roof
+        out["stages_ms"] = stages
+    # bpp_batch_upload alone: host proof/statement buffers -> parsed, packed and resident (R batches of 1024); never `value`
+    out["pcie_inclusive_upload_ms"] = 1e3 * leg.upload_s
+    leg.close()
 
-    if rank == 0:
-        total = n_local * R * world * args.steps
-        out = {
-            "metric": "64-bit range proofs verified/sec (batch)", "value": total / elapsed, "unit": "proofs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: reference batches of %d x aggregation-%d 64-bit proofs, extension "
-                                   "degree %d, VerifyOnly, resident in HBM; one step = %d such batches in one engine call"
-                                   % (1 if args.config == "cfg2" else 2, n_local, data["m"], data["t"], R),
-                       "proofs_per_reference_batch": n_local, "batches_per_step": R, "proofs_per_step_per_gpu": n_local * R,
-                       "mode": ("one reference batch over all ranks (all_gather rng bytes + accumulators)" if wide else
-                                ("each %d-proof chunk is a reference batch" % args.chunk if args.chunk else
-                                 "each 1024-proof resident batch is one reference batch (private verify())")),
-                       "steps_in_flight_per_gpu": S,
-                       "parallelism": "proof-sharded x%d" % world},
-            "step_latency_ms": 1e3 * sum(lat) / len(lat),
-        }
-        if prof_sum and prof_sum.get("msm_final_ms", 0) > 0:
-            k = len(profs)
-            avg = {n: v / k for n, v in prof_sum.items()}
-            terms = int(avg["msm_terms"])  # over all R groups of one launch
-            K = int(avg["msm_windows"])
-            acc_ms = avg["msm_accumulate_ms"]
-            msm_bytes = 64 * terms  # 32 B scalar + 32 B compressed point per MSM term
-            achieved = msm_bytes / (acc_ms * 1e-3) / 1e9
-            # integer roofline of the same kernel: one mixed addition per (term, window) = 7 field multiplications
-            # = 700 v_mad_u64_u32; peak = 49 lanes/clk/CU x 256 CU x 2.4 GHz (tools/microbench/int_rates.hip)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tpath):  # PMC figure of the same kernel/workload, collected in its own rocprofv3 passes
-                tj = json.load(open(tpath))
-                traffic = tj["hbm_bytes_per_launch"] * (terms / float(tj["msm_terms_per_launch"]))
-            mads = terms * K * 700.0
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                               "kernel": "k_msm_accumulate (Pippenger bucket accumulation of the final MSM)",
-                               "kernel_ms": acc_ms, "algorithmic_bytes": msm_bytes, "msm_terms_per_launch": terms,
-                               "note": "integer-VALU bound, not HBM bound (SURVEY 8d): see valu",
-                               "valu": {"achieved_Tmad_per_s": mads / (acc_ms * 1e-3) / 1e12, "peak_Tmad_per_s": 30.1,
-                                        "frac": mads / (acc_ms * 1e-3) / 30.1e12}}
-            if alone_ms:  # same kernel, same launch, no other step in flight (3 launches after the timed region)
-                out["roofline"]["alone"] = {"kernel_ms": alone_ms, "achieved": msm_bytes / (alone_ms * 1e-3) / 1e9,
-                                            "frac": msm_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                            "valu_frac": mads / (alone_ms * 1e-3) / 30.1e12}
-            out["stages_ms"] = {n: round(v, 4) for n, v in avg.items() if n.endswith("_ms")}
-            # bpp_batch_upload alone: host proof/statement buffers -> parsed, packed and resident (R batches of 1024)
-            out["pcie_inclusive_upload_ms"] = 1e3 * t_upload
-            out["python_marshal_ms"] = 1e3 * t_marshal
-        if not args.no_cpu_baseline:
-            from oracle import cport  # cpu_baseline leg only
-            cp = cport.Params(data["bit_length"], data["m"], data["t"])
-            sample = data["items"][:256]  # one reference-sized batch (MAX_RANGE_PROOF_BATCH_SIZE)
-            rc, sec1 = cp.verify_timed(sample, 256, 1)
-            iters = max(1, int(args.cpu_seconds / max(sec1, 1e-3)))
-            rc, sec = cp.verify_timed(sample, 256, iters)
-            assert rc == 0
-            out["cpu_baseline"] = {"value": len(sample) * iters / sec, "unit": "proofs/s", "cores": 1, "kind": "port",
-                                   "sample": "%d x verify of one 256-proof reference batch (first 256 proofs of the workload), "
-                                             "single thread, oracle/c port with dalek's algorithms" % iters}
-            cp.close()
-        print(json.dumps(out))
-    for _, eng, rb in lanes:
+    extra = {}
+    # ------------------------------------------------------------------ N > 1: BASELINE configs[3], one batch over all ranks
+    if use_dist:
+        dmod = importlib.import_module("bulletproofs-plus_amd.dist")
+        n_local = 4096 // world
+        stream = torch.cuda.Stream(device=device)
+        weng = bpp.Engine(local_rank, stream=stream.cuda_stream)
+        wparams = params2.share(weng)
+        lo = n_local * rank  # ranks were seeded differently: any n_local of this rank's proofs are its shard
+        rb = packed.ResidentBatch(wparams, data2["proofs"][:n_local], data2["commitments"][:n_local],
+                                  data2["min_values"][:n_local], data2["min_present"][:n_local], None, LABEL)
+        ops = dmod.LocalEngineOps(rb)
+        for _ in range(5):
+            dmod.verify_sharded(ops, n_local, device, mode="wide")
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.wide_steps):
+            dmod.verify_sharded(ops, n_local, device, mode="wide")
+        sync()
+        wel = time.perf_counter() - t0
+        tt = torch.tensor([wel], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wel = float(tt.item())
+        extra["wide"] = {"workload": "BASELINE configs[3]: 4096 non-aggregated 64-bit proofs as ONE reference batch, %d per rank; "
+                                     "all_gather of 32 B/proof transcript-RNG bytes, weight chain replayed on every rank, "
+                                     "all_gather of the 128-byte accumulators, rank-local sum + identity test" % n_local,
+                         "rccl_ranks": world, "proofs_per_s": 4096 * args.wide_steps / wel, "ms_per_batch": 1e3 * wel / args.wide_steps,
+                         "steps": args.wide_steps, "in_flight": 1, "first_proof_of_shard": lo}
         rb.close()
-        eng.close()
+        wparams.close()
+        weng.close()
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        # -------------------------------------------------------------- configs[2]: 256 x aggregation-8
+        p3 = bpp.RangeParameters.init(64, 8, G(1), engine=eng0)
+        R3 = 32
+        d3 = make_inputs(np, packed, p3, 256 * R3, seed=8675309 + 3)
+        leg3 = Leg(bpp, packed, torch, device, p3, d3, 256, R3, 4, 256)
+        el3, lat3, pr3 = timed(leg3, 48, 8, sync)
+        sync()
+        al3 = [leg3.one_step(0)[1].get("msm_accumulate_ms", 0.0) for _ in range(3)]
+        roof3, st3 = kernel_roofline(pr3, sum(al3) / 3 if min(al3) > 0 else None)
+        extra["cfg3"] = {"workload": "BASELINE configs[2]: reference batches of 256 x aggregation-8 64-bit proofs, extension degree 1; "
+                                     "one step = %d such batches, 4 steps in flight" % R3,
+                         "proofs_per_s": 256 * R3 * 48 / el3, "ms_per_step": 1e3 * el3 / 48, "steps": 48, "roofline": roof3,
+                         "stages_ms": st3}
+        leg3.close()
+        p3.close()
+        # -------------------------------------------------------------- one 4096-proof reference batch (north_star's sentence)
+        Sw = 6
+        legw = Leg(bpp, packed, torch, device, params2, data2, 4096, 1, Sw, 0)
+        elw, latw, prw = timed(legw, 120, 12, sync)
+        sync()
+        alw = [legw.one_step(0) for _ in range(5)]
+        roofw, stw = kernel_roofline(prw, sum(a[1].get("msm_accumulate_ms", 0.0) for a in alw) / 5)
+        extra["wide4096"] = {"workload": "4096 non-aggregated 64-bit proofs as ONE reference batch (chunk = 0: one weight chain over "
+                                         "4096, one 65 667-term MSM) on one GPU; %d calls in flight, each on another 4096 proofs" % Sw,
+                             "proofs_per_s": 4096 * 120 / elw, "ms_per_batch_in_flight": 1e3 * sum(latw) / len(latw),
+                             "ms_per_batch_alone": 1e3 * sum(a[0] for a in alw) / 5, "steps": 120, "roofline": roofw, "stages_ms": stw}
+        legw.close()
+        # -------------------------------------------------------------- single-call latency (configs[0]'s shape)
+        lat_out = {}
+        for nb in (1, 256):
+            legl = Leg(bpp, packed, torch, device, params2, data2, nb, 1, 1, 0)
+            legl.run_steps(10)
+            ls, lp = legl.run_steps(50)
+            ls.sort()
+            rl, sl = kernel_roofline(lp)
+            lat_out["batch_%d" % nb] = {"ms_per_call_median": 1e3 * ls[len(ls) // 2], "ms_per_call_min": 1e3 * ls[0],
+                                        "proofs_per_s": nb / ls[len(ls) // 2], "roofline": rl, "stages_ms": sl}
+            legl.close()
+        extra["latency"] = dict(lat_out, workload="BASELINE configs[0]'s shape through the engine: ONE call at a time, 1 and 256 "
+                                                  "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input")
+        # -------------------------------------------------------------- configs[4]: batch prover
+        p5 = bpp.RangeParameters.init(64, 4, G(3), engine=eng0)
+        d5 = make_inputs(np, packed, p5, 1024, seed=8675309 + 5)  # also builds the fixed-base tables (warm-up)
+        t0 = time.perf_counter()
+        iters5 = 6
+        for _ in range(iters5):
+            packed.prove(p5, d5["values"], d5["blindings"], d5["commitments"], d5["min_values"], d5["min_present"], None, LABEL,
+                         d5["ext"])
+        el5 = time.perf_counter() - t0
+        pp = eng0.last_prove_profile()
+        fb_bytes = 64 * pp["fb_terms"]
+        extra["prover"] = {"workload": "BASELINE configs[4]: bpp_prove_batch over 1024 x aggregation-4 64-bit proofs, extension "
+                                       "degree 3; host witness buffers in, proof bytes out (PCIe-inclusive)",
+                           "proofs_per_s": 1024 * iters5 / el5, "ms_per_call": 1e3 * el5 / iters5, "calls": iters5,
+                           "roofline": {"bound": "hbm", "kernel": "k_fb_msm (fixed-base MSM of every L/R/A1/B and the witness check)",
+                                        "kernel_ms": pp["fb_msm_ms"], "launches": pp["fb_launches"], "algorithmic_bytes": fb_bytes,
+                                        "achieved": fb_bytes / (pp["fb_msm_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                        "frac": fb_bytes / (pp["fb_msm_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                                        "fb_window_bits": pp["fb_window_bits"], "fb_terms": pp["fb_terms"],
+                                        "note": "sum of the launches' event times over both sub-batch streams; 64 B per term"}}
+        p5.close()
+    if extra and rank == 0:
+        out["extra"] = extra
+
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import cport  # cpu_baseline leg only: the oracle is the thing timed here, never the product path
+        cp = cport.Params(64, 1, 1)
+        ncpu = os.cpu_count() or 1
+        k = 256 * max(1, min(ncpu, 4))
+        pr, cm, mv = data2["proofs"], data2["commitments"], data2["min_values"]
+        sample = [{"proof": pr[i].tobytes(), "commitments": [cm[i, 0].tobytes()], "min_values": [int(mv[i, 0])],
+                   "seed_nonce": None, "label": LABEL} for i in range(k)]
+        rc, sec1 = cp.verify_timed(sample[:256], 256, 1)
+        iters = max(1, int(args.cpu_seconds / max(sec1, 1e-3)))
+        rc, sec = cp.verify_timed(sample[:256], 256, iters)
+        assert rc == 0
+        rcm, secm = cp.verify_timed_mt(sample, 256, iters, ncpu)
+        assert rcm == 0
+        out["cpu_baseline"] = {"value": 256 * iters / sec, "unit": "proofs/s", "cores": 1, "kind": "port",
+                               "sample": "%d x verify of one 256-proof reference batch (MAX_RANGE_PROOF_BATCH_SIZE) of the workload, "
+                                         "single thread, oracle/c port with dalek's algorithms (the reference is single-threaded)" % iters,
+                               "all_cores": {"value": 256 * iters * ncpu / secm, "unit": "proofs/s", "cores": ncpu,
+                                             "sample": "%d threads, each %d x verify of a 256-proof reference batch" % (ncpu, iters)},
+                               "nproc": ncpu}
+        cp.close()
+    if rank == 0:
+        print(json.dumps(out))
+    params2.close()
+    eng0.close()
     if use_dist:
         dist.destroy_process_group()
 

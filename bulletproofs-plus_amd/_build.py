@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
     if not force and not _stale(LIB, deps):
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", LIB] + os.environ.get("BPP_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)
@@ -60,7 +60,7 @@ def build_sanitizer_harness(force=False):
     if not force and not _stale(SANITIZER_BIN, deps):
         return SANITIZER_BIN
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-                    "-fno-omit-frame-pointer", "-o", SANITIZER_BIN, src], check=True, cwd=CSRC)
+                    "-fno-omit-frame-pointer", "-DBPP_FE_BOUNDS_CHECK", "-o", SANITIZER_BIN, src], check=True, cwd=CSRC)
     return SANITIZER_BIN
 
 

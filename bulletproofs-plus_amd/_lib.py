@@ -29,6 +29,11 @@ class Profile(Structure):
                [(n, c_uint32) for n in ("msm_terms", "msm_window_bits", "msm_windows", "msm_groups")]
 
 
+class ProveProfile(Structure):
+    _fields_ = [("fb_msm_ms", c_float), ("total_ms", c_float), ("fb_terms", c_uint64), ("fb_launches", c_uint32),
+                ("fb_window_bits", c_uint32), ("fb_windows", c_uint32), ("sub_batches", c_uint32)]
+
+
 # every symbol include/bpp.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("bpp_ctx_create", c_int, [POINTER(c_void_p), c_int]),
@@ -66,6 +71,9 @@ SYMBOLS = [
                                 POINTER(c_uint32), POINTER(c_uint32)]),
     ("bpp_profile_enable", c_int, [c_void_p, c_int]),
     ("bpp_profile_get", c_int, [c_void_p, POINTER(Profile)]),
+    ("bpp_prove_profile_get", c_int, [c_void_p, POINTER(ProveProfile)]),
+    ("bpp_batch_prepare", c_int, [c_void_p, c_uint64, c_size_t]),
+    ("bpp_host_threads", c_int, []),
     ("bpp_transcript_new", c_int, [c_void_p, c_size_t, c_void_p]),
 ]
 

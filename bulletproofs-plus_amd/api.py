@@ -146,6 +146,11 @@ class Engine:
         self.lib.bpp_profile_get(self.ctx, byref(p))
         return {n: getattr(p, n) for n, _ in _lib.Profile._fields_}
 
+    def last_prove_profile(self):
+        p = _lib.ProveProfile()
+        self.lib.bpp_prove_profile_get(self.ctx, byref(p))
+        return {n: getattr(p, n) for n, _ in _lib.ProveProfile._fields_}
+
 
 class Precomputation:
     """VartimeRistrettoPrecomputation (src/ristretto.rs:62-64, built at src/generators/bulletproof_gens.rs:103)."""
@@ -671,6 +676,17 @@ class ResidentBatch:
         return [ExtendedMask.assign(t, [raw[(i * t + k) * 32:(i * t + k) * 32 + 32] for k in range(t)])
                 if present[i] else None for i in range(self.n)]
 
+    def verify_only(self, chunk=0):
+        """VerifyAction::VerifyOnly without the mask vector (all None by definition): no per-item work on the host"""
+        err = ctypes.create_string_buffer(256)
+        rc = self.engine.lib.bpp_verify_resident(self.engine.ctx, self.handle, int(VerifyAction.VerifyOnly), chunk, None, None,
+                                                 err, 256)
+        _check(rc, self.engine.ctx, err)
+
+    def prepare(self, chunk=0):
+        """bpp_batch_prepare: the one-off planning / allocation of verify(chunk=...) done ahead of the first call"""
+        _check(self.engine.lib.bpp_batch_prepare(self.engine.ctx, self.handle, chunk), self.engine.ctx)
+
     def phase1(self):
         out = (ctypes.c_uint8 * (self.n * 32))()
         err = ctypes.create_string_buffer(256)
@@ -702,6 +718,11 @@ class ResidentBatch:
         if self.handle.value:
             self.engine.lib.bpp_batch_destroy(self.engine.ctx, self.handle)
             self.handle = c_uint64()
+
+
+def host_threads():
+    """size of the engine's host worker pool (weight chains, upload packer)"""
+    return int(_lib.load().bpp_host_threads())
 
 
 def weights_from_chain(rng32_all):

@@ -153,6 +153,7 @@ void sha3_512(const uint8_t *in, size_t inlen, uint8_t out[64]) { keccak_sponge(
 
 void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G);
 void host_parallel_for(uint32_t n, const std::function<void(uint32_t)> &fn);  // on the persistent host pool
+uint32_t host_pool_size();
 
 // weight transcript (src/range_proof.rs:811,849,853,894)
 void weights_from_chain_host(const uint8_t *rng32, size_t n, uint8_t *weights32) {
@@ -332,6 +333,8 @@ struct bpp_ctx {
   DevBuf<uint8_t> prove_arena;
   PinnedBuf<uint8_t> prove_pin_in, prove_pin_out;
   std::vector<hipStream_t> prove_streams;
+  std::vector<hipEvent_t> prove_events;  // pairs around every k_fb_msm launch of the last bpp_prove_batch (profiling only)
+  bpp_prove_profile pprof{};
 };
 
 namespace {
@@ -583,6 +586,7 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
     (void)hipStreamSynchronize(ps);
     (void)hipStreamDestroy(ps);
   }
+  for (auto &e : ctx->prove_events) (void)hipEventDestroy(e);
   ctx->prove_arena.release();
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1044,6 +1048,8 @@ int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items
   return upload_impl(ctx, params, items, n_items, batch, nullptr, nullptr, errbuf, errbuf_len);
 }
 
+int bpp_host_threads(void) { return (int)host_pool_size(); }
+
 int bpp_batch_destroy(bpp_ctx *ctx, uint64_t batch) {
   BPP_ENTRY(ctx);
   (void)hipStreamSynchronize(ctx->stream);
@@ -1202,6 +1208,7 @@ class HostPool {
 };
 
 void host_parallel_for(uint32_t n, const std::function<void(uint32_t)> &fn) { HostPool::get().parallel_for(n, fn); }
+uint32_t host_pool_size() { return HostPool::get().size(); }
 
 void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G) {
   static const int simd = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") ? 8
@@ -1334,7 +1341,7 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
   tm.mark(M_WEIGHTS_IN);
   sc *dyn_scal = b.scal.p + (size_t)b.G * b.cols;
   hipLaunchKernelGGL(k_weights_to_mont, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.weights.p, b.B, b.wm.p);
-  hipLaunchKernelGGL(k_reduce_static, dim3(b.cols, b.G), dim3(64), 0, s, b.rows.p, b.wm.p, b.group_first.p, b.cols, b.scal.p);
+  hipLaunchKernelGGL(k_reduce_static, dim3(cdiv(b.cols, BPP_REDUCE_TILE), b.G), dim3(64), 0, s, b.rows.p, b.wm.p, b.group_first.p, b.cols, b.scal.p);
   hipLaunchKernelGGL(k_weight_dyn, dim3(cdiv(b.total_dyn, 64)), dim3(64), 0, s, b.dyn_unw.p, b.owner.p, b.wm.p, b.total_dyn,
                      dyn_scal);
   tm.mark(M_REDUCE);
@@ -1367,6 +1374,23 @@ void collect_profile(bpp_ctx *ctx, Batch &b, StageTimer &tm, float chain_ms, flo
 }  // namespace
 
 extern "C" {
+
+int bpp_batch_prepare(bpp_ctx *ctx, uint64_t batch, size_t chunk) {
+  BPP_ENTRY(ctx);
+  try {
+    auto it = ctx->batches.find(batch);
+    if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle");
+    StageTimer tm(ctx);  // creates the profiling events when profiling is on
+    if (!ctx->ev_rng_ready) {
+      HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_rng, hipEventDisableTiming));
+      ctx->ev_rng_ready = true;
+    }
+    layout_groups(ctx, *it->second, chunk);  // group layout, MSM plan and every work buffer of that plan
+    it->second->h_ident.resize(it->second->G);
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, nullptr, 0)
+}
 
 int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, uint8_t *masks_out, uint8_t *mask_present,
                         char *errbuf, size_t errbuf_len) {
@@ -1608,6 +1632,12 @@ int bpp_profile_enable(bpp_ctx *ctx, int on) {
   return BPP_OK;
 }
 
+int bpp_prove_profile_get(bpp_ctx *ctx, bpp_prove_profile *out) {
+  if (!ctx || !out) return BPP_ERR_BAD_HANDLE;
+  *out = ctx->pprof;
+  return BPP_OK;
+}
+
 int bpp_profile_get(bpp_ctx *ctx, bpp_profile *out) {
   if (!ctx || !out) return BPP_ERR_BAD_HANDLE;
   *out = ctx->prof;
@@ -1831,6 +1861,18 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     ProveState *pin_ps = (ProveState *)(pin_proofs + (((size_t)B * plen + 15) & ~(size_t)15));
 
     const dim3 b64(64);
+    // profiling: an event pair around every k_fb_msm launch (the prover's dominant kernel), summed after the call
+    size_t ev_used = 0;
+    auto fb_mark = [&](hipStream_t st) {
+      if (!ctx->profile) return;
+      if (ev_used == ctx->prove_events.size()) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        ctx->prove_events.push_back(e);
+      }
+      HIP_CHECK(hipEventRecord(ctx->prove_events[ev_used++], st));
+    };
+    const auto t_begin = std::chrono::steady_clock::now();
     arena_clean = false;
     for (uint32_t q = 0; q < n_sub; q++) {
       Sub &u = subs[q];
@@ -1846,8 +1888,10 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       // witness check (:275-284): commit(v_j, r_j) for every opening, compared with the statement's commitments
       hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_bytes, u.d_desc, t, n_gen, nb, m, 1 + t, u.d_cts,
                          u.d_ctg, u.d_ctc);
+      fb_mark(s);
       hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(1 + t, P.fb_geo)), 0, s, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, P.fb_geo,
                          u.d_ge);
+      fb_mark(s);
       hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_ge, nb * m, u.d_commit32);
       hipLaunchKernelGGL(kp_init, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_states, P.d_hg32.p, n, t, nb, u.d_ps);
       hipLaunchKernelGGL(kp_check_commitments, lane_grid, b64, 0, s, u.d_bytes, u.d_desc, u.d_commit32, nb, u.d_ps);
@@ -1859,8 +1903,10 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
                            stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
         uint8_t *out = (j < rounds) ? u.d_lr + (size_t)j * nb * 64 : u.d_a1b;
+        fb_mark(s);
         hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(fb_threads(mn + t + 1, P.fb_geo)), 0, s, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, P.fb_geo,
                            u.d_ge);
+        fb_mark(s);
         hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);
       }
       hipLaunchKernelGGL(kp_finish, lane_grid, b64, 0, s, u.d_desc, n, t, nb, rounds, u.d_a32, u.d_lr, u.d_a1b, u.d_vec, u.d_ps,
@@ -1873,6 +1919,23 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     }
     for (uint32_t q = 0; q < n_sub; q++) HIP_CHECK(hipStreamSynchronize(ctx->prove_streams[q]));
     arena_clean = true;  // every sub-batch's arena range was zeroed on its stream
+    if (ctx->profile) {
+      bpp_prove_profile &pp = ctx->pprof;
+      memset(&pp, 0, sizeof(pp));
+      for (size_t k = 0; k + 1 < ev_used; k += 2) {
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, ctx->prove_events[k], ctx->prove_events[k + 1]));
+        pp.fb_msm_ms += ms;
+      }
+      pp.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+      // terms handed to k_fb_msm: witness check m x (1 + t); per round L and R of mn + t + 1 terms each (every generator
+      // lands in exactly one of the two); A1 and B: 3 + 2t terms together
+      pp.fb_terms = (uint64_t)B * ((uint64_t)m * (1 + t) + (uint64_t)rounds * 2 * (mn + t + 1) + 3 + 2 * t);
+      pp.fb_launches = (uint32_t)(ev_used / 2);
+      pp.fb_window_bits = P.fb_geo.wbits;
+      pp.fb_windows = P.fb_geo.windows;
+      pp.sub_batches = n_sub;
+    }
     for (uint32_t i = 0; i < B; i++) {  // only the status word of the (secret-bearing) ProveState is looked at
       if (pin_ps[i].status & PV_STATUS_COMMIT_MISMATCH) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Witness opening is invalid!"};
       if (pin_ps[i].status & PV_STATUS_TRANSCRIPT)

@@ -2,8 +2,14 @@
 //
 // Representation: 10 unsigned limbs, radix 2^25.5 (26,25,26,25,... bits).  Products are accumulated in
 // 64-bit columns, which hipcc lowers to v_mad_u64_u32 (one instruction per limb product, no carry
-// chains inside the product).  "Reduced" below means every limb < 2^26 (even) / 2^25 (odd) plus a few
-// units in limb 0/1.  fe_mul/fe_sq accept limbs up to 1.5 * 2^27 and always return reduced limbs.
+// chains inside the product).  Limb bounds, E = bound of the even limbs (odd limbs: half of it):
+//   reduced  E <= 2^26           what fe_mul / fe_sq / fe_carry return (limb 1 may carry 2^19 more)
+//   loose    E <= 1.5 * 2^27     a sum of two reduced values, or fe_sub_lazy of two reduced values
+//   wide     E <= 2^28           2 * reduced + 2p - reduced (the "d - c" of a point addition)
+// fe_mul(h, f, g) takes f up to wide and g up to loose (g is the operand that is pre-multiplied by 19 for the wrapped
+// columns: 19 * 1.5 * 2^27 < 2^32); fe_sq takes loose.  The heaviest column of such a product is
+// 124.5 * E_f * E_g <= 2^62.5.  Point formulas in point.h are written against these classes, so that no carry pass runs
+// outside the products; the host build checks every bound when BPP_FE_BOUNDS_CHECK is defined (sanitizer harness).
 //
 // Replaces (reference boundary): curve25519-dalek FieldElement reached through
 // src/range_proof.rs:1067-1109 (decompress) and every point operation of the final MSM (:1050-1057).
@@ -77,42 +83,85 @@ BPP_HD void fe_sub(fe &h, const fe &f, const fe &g) {
   fe_carry(h);
 }
 
+// h = f - g + 2p without a carry pass: g must be reduced (its limbs do not exceed those of 2p); f reduced -> h loose
+BPP_HD void fe_sub_lazy(fe &h, const fe &f, const fe &g) {
+  h.v[0] = f.v[0] + 0x7ffffdau - g.v[0];  // 2 * (2^26 - 19)
+#pragma unroll
+  for (int i = 1; i < 10; i++) h.v[i] = f.v[i] + ((i & 1) ? 0x3fffffeu : 0x7fffffeu) - g.v[i];
+}
+
+// h = 2 f + g (no carry): f, g reduced -> loose
+BPP_HD void fe_dbl_add(fe &h, const fe &f, const fe &g) {
+#pragma unroll
+  for (int i = 0; i < 10; i++) h.v[i] = 2u * f.v[i] + g.v[i];
+}
+
+// h = 2 f - g + 2p (no carry): f, g reduced -> wide
+BPP_HD void fe_dbl_sub_lazy(fe &h, const fe &f, const fe &g) {
+  h.v[0] = 2u * f.v[0] + 0x7ffffdau - g.v[0];
+#pragma unroll
+  for (int i = 1; i < 10; i++) h.v[i] = 2u * f.v[i] + ((i & 1) ? 0x3fffffeu : 0x7fffffeu) - g.v[i];
+}
+
 BPP_HD void fe_neg(fe &h, const fe &f) {
   fe z;
   fe_0(z);
   fe_sub(h, z, f);
 }
 
-// carry a 10-column 64-bit product into reduced limbs
-BPP_HD void fe_reduce_wide(fe &h, uint64_t t[10]) {
-  uint64_t c;
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-    c = t[i] >> fe_bits(i);
-    t[i] &= fe_mask(i);
-    t[i + 1] += c;
-  }
-  c = t[9] >> 25;
-  t[9] &= 0x1ffffffu;
-  t[0] += 19u * c;  // c < 2^39 -> no overflow
-  c = t[0] >> 26;
-  t[0] &= 0x3ffffffu;
-  t[1] += c;  // t[1] < 2^25 + 2^19
-#pragma unroll
-  for (int i = 0; i < 10; i++) h.v[i] = (uint32_t)t[i];
+#if defined(BPP_FE_BOUNDS_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+}  // namespace bpp
+#include <stdio.h>
+#include <stdlib.h>
+namespace bpp {
+inline void fe_bound_fail(const char *what) {
+  fprintf(stderr, "field bound violated: %s\n", what);
+  abort();
+}
+#define BPP_FE_CHECK(cond, what) \
+  do {                           \
+    if (!(cond)) fe_bound_fail(what); \
+  } while (0)
+#else
+#define BPP_FE_CHECK(cond, what) \
+  do {                           \
+  } while (0)
+#endif
+
+// a * b + c with c as the instruction's own 64-bit addend.  Written as `(uint64_t)a * b + c` the compiler re-associates
+// the sums of a column (products first, carry-in last, to shorten the dependency chain) and pays a separate 64-bit
+// addition per limb; pinned, the carry-in rides in the first v_mad_u64_u32 of the column for free.
+BPP_HD uint64_t fe_mad(uint32_t a, uint32_t b, uint64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint64_t d, carry_out;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry_out) : "v"(a), "v"(b), "v"(c));
+  return d;
+#else
+#if defined(BPP_FE_BOUNDS_CHECK)
+  BPP_FE_CHECK((((unsigned __int128)a * b + c) >> 64) == 0, "64-bit column overflow");
+#endif
+  return (uint64_t)a * b + c;
+#endif
 }
 
+// Products: column k of f*g is sum_{i+j = k (mod 10)} f_i g_j (x2 when i and j are both odd: radix 2^25.5; x19 when
+// i + j >= 10: 2^255 = 19), accumulated in one 64-bit register pair by v_mad_u64_u32.  The columns are computed in order
+// and column k's carry SEEDS column k+1's accumulator (the first v_mad_u64_u32 of a column takes it as its 64-bit addend),
+// so the carry chain costs a shift and a mask per limb and no 64-bit addition.  Bounds: limbs up to 1.5 * 2^27 on both
+// sides give column 0 (the heaviest: 267 L^2) 2^63.3, carries stay below 2^38.
 BPP_HD void fe_mul(fe &h, const fe &f, const fe &g) {
   uint32_t g19[10], f2[10];
 #pragma unroll
   for (int i = 0; i < 10; i++) {
+    BPP_FE_CHECK((uint64_t)19u * g.v[i] < (1ull << 32) && (uint64_t)2u * f.v[i] < (1ull << 32), "fe_mul operand limb too large");
     g19[i] = 19u * g.v[i];
     f2[i] = 2u * f.v[i];
   }
-  uint64_t t[10];
+  uint64_t c = 0;
+  uint32_t r[10];
 #pragma unroll
   for (int k = 0; k < 10; k++) {
-    uint64_t acc = 0;
+    uint64_t acc = c;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
       const int j = (k - i + 10) % 10;
@@ -120,39 +169,58 @@ BPP_HD void fe_mul(fe &h, const fe &f, const fe &g) {
       const bool dbl = (i & 1) && (j & 1);
       const uint32_t a = dbl ? f2[i] : f.v[i];
       const uint32_t b = wrap ? g19[j] : g.v[j];
-      acc += (uint64_t)a * b;
+      acc = (k == 0 && i == 0) ? (uint64_t)a * b : fe_mad(a, b, acc);
     }
-    t[k] = acc;
+    r[k] = (uint32_t)acc & fe_mask(k);
+    c = acc >> fe_bits(k);
   }
-  fe_reduce_wide(h, t);
+  // c < 2^39 wraps into limb 0 with weight 19; limb 1 absorbs what limb 0 spills (r[1] < 2^25 + 2^19)
+  const uint64_t t0 = (uint64_t)r[0] + 19u * c;
+  h.v[0] = (uint32_t)t0 & 0x3ffffffu;
+  h.v[1] = r[1] + (uint32_t)(t0 >> 26);
+#pragma unroll
+  for (int i = 2; i < 10; i++) h.v[i] = r[i];
 }
 
+// Squaring: 55 products.  Both operands of every product are pre-scaled limbs, so a column is a plain chain of
+// v_mad_u64_u32 (no doubling of 64-bit products); carries seed the next column as in fe_mul.  The factor of a pair (i < j)
+// is 2 (off-diagonal) x 2 (both odd) x 19 (wrapped): the off-diagonal 2 goes on f_i, the rest on f_j, so f_j is scaled
+// by 1, 2, 19 or -- only for ODD j, whose bound is half that of the even limbs -- 38: loose input (odd limbs
+// <= 1.5 * 2^26) keeps 38 f_j below 2^32.
 BPP_HD void fe_sq(fe &h, const fe &f) {
-  // symmetric products folded: 55 multiplies
-  uint32_t f19[10], f2[10];
+  uint32_t f2[10], f19[10], f38[10];
 #pragma unroll
   for (int i = 0; i < 10; i++) {
-    f19[i] = 19u * f.v[i];
+    BPP_FE_CHECK((uint64_t)((i & 1) ? 38u : 19u) * f.v[i] < (1ull << 32), "fe_sq operand limb too large");
     f2[i] = 2u * f.v[i];
+    f19[i] = 19u * f.v[i];
+    f38[i] = 38u * f.v[i];  // used for odd i only
   }
-  uint64_t t[10];
+  uint64_t c = 0;
+  uint32_t r[10];
 #pragma unroll
   for (int k = 0; k < 10; k++) {
-    uint64_t acc = 0;
+    uint64_t acc = c;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
       const int j = (k - i + 10) % 10;
       if (i > j) continue;
       const bool wrap = i > k;  // i + j == k + 10
       const bool dbl = (i & 1) && (j & 1);
-      // a = f_i * (2 if dbl), b = f_j * (19 if wrap); off-diagonal pairs counted twice
-      uint64_t p = (uint64_t)(dbl ? f2[i] : f.v[i]) * (wrap ? f19[j] : f.v[j]);
-      if (i != j) p += p;
-      acc += p;
+      const bool off = i != j;
+      // total factor = (off ? 2 : 1) * (dbl ? 2 : 1) * (wrap ? 19 : 1): `off` on f_i, the rest on f_j
+      const uint32_t a = off ? f2[i] : f.v[i];
+      const uint32_t b = wrap ? (dbl ? f38[j] : f19[j]) : (dbl ? f2[j] : f.v[j]);
+      acc = (k == 0 && i == 0) ? (uint64_t)a * b : fe_mad(a, b, acc);
     }
-    t[k] = acc;
+    r[k] = (uint32_t)acc & fe_mask(k);
+    c = acc >> fe_bits(k);
   }
-  fe_reduce_wide(h, t);
+  const uint64_t t0 = (uint64_t)r[0] + 19u * c;
+  h.v[0] = (uint32_t)t0 & 0x3ffffffu;
+  h.v[1] = r[1] + (uint32_t)(t0 >> 26);
+#pragma unroll
+  for (int i = 2; i < 10; i++) h.v[i] = r[i];
 }
 
 BPP_HD void fe_sqn(fe &h, const fe &f, int n) {

@@ -29,6 +29,11 @@ int ht_decompress_compress(const uint8_t in[32], uint8_t out[32]) {
 int ht_from_niels(const uint8_t in[32], int neg, uint8_t out[32]) {
   niels n; if (!ristretto_decompress(n, in)) return 0;
   niels m = n; niels_cneg(m, neg != 0); ge p; ge_from_niels(p, m); ge_madd(p, p, n); ristretto_compress(out, p); return 1; }
+// 2P +- P with the sign applied the way the MSM kernels do it (niels_load_swapped + ge_madd_swapped): 3P or P
+int ht_madd_swapped(const uint8_t in[32], int neg, uint8_t out[32]) {
+  niels n; if (!ristretto_decompress(n, in)) return 0;
+  ge p; ge_identity(p); ge_madd(p, p, n); ge_dbl(p, p);
+  niels q; niels_load_swapped(q, &n, neg != 0); ge_madd_swapped(p, p, q, neg != 0); ristretto_compress(out, p); return 1; }
 // the device's decoding schedule (k_decompress) on the host: same verdict and point as the plain schedule
 int ht_decompress_lean(const uint8_t in[32], uint8_t out[32]) {
   niels n; if (!ristretto_decompress_lean(n, in)) return 0;

@@ -23,10 +23,10 @@ namespace bpp {
 // ---------------------------------------------------------------- fixed-base tables
 // One table entry = one affine Niels point padded to a full 128-byte line: a lookup is exactly one aligned line
 // (a 160-byte projective entry straddles two), and the mixed addition costs 7 multiplications instead of 8.
-struct alignas(128) fbent {
-  niels q;
-  uint32_t pad[2];
+struct fbent {
+  niels q;  // niels is itself padded and aligned to 128 bytes (point.h)
 };
+static_assert(sizeof(fbent) == 128, "one fixed-base table entry = one 128-byte line");
 struct cached {  // projective niels (table construction only)
   fe yplusx, yminusx, z, t2d;
 };
@@ -122,7 +122,8 @@ BPP_D void fb_fetch(niels &q, int &d, const FbStage &st, const fbent *__restrict
   const uint32_t i = it / geo.windows, w = it - i * geo.windows;
   d = st.dig[it];
   const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-  q = tbl[((size_t)st.gi[i] * geo.windows + w) * geo.entries + (mag ? mag - 1u : 0u)].q;
+  // y+x / y-x exchanged by address for a negative digit (ge_madd_swapped does the rest of the negation)
+  niels_load_swapped(q, &tbl[((size_t)st.gi[i] * geo.windows + w) * geo.entries + (mag ? mag - 1u : 0u)].q, d < 0);
 }
 
 __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx,
@@ -152,10 +153,7 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ sc
       const int cd = nd;
       it += nthr;
       if (it < items) fb_fetch(nxt, nd, sh.st, tbl, geo, it);
-      if (cd != 0) {
-        niels_cneg(cur, cd < 0);
-        ge_madd(acc, acc, cur);
-      }
+      if (cd != 0) ge_madd_swapped(acc, acc, cur, cd < 0);
     }
   }
   __syncthreads();

@@ -648,27 +648,35 @@ __global__ void __launch_bounds__(64) k_weight_dyn(const sc *__restrict__ dyn_un
 }
 
 // Weighted column sums per group: static[g][col] = sum_{p in g} w_p * rows[p][col]   (the `+=` into
-// gi/hi/g/h_base_scalars of src/range_proof.rs:785-788,999-1020).  One wavefront per (column, group): lane-strided
-// Montgomery products, limb-wise u64 sums, wave shuffle reduction, one Montgomery exit.
+// gi/hi/g/h_base_scalars of src/range_proof.rs:785-788,999-1020).  One wavefront per (tile of 4 columns, group): lane =
+// (proof slot, column in tile), so the four lanes of a proof slot read 4 x 32 = 128 CONTIGUOUS bytes of one proof's row
+// (one lane per column would walk rows[] with a stride of cols x 32 = 4 160 bytes: 61 % of that kernel's cycles were
+// spent waiting on memory); the sixteen proof slots advance through the group together.  Montgomery products, limb-wise
+// u64 sums, shuffle reduction over the proof slots, one Montgomery exit per column.
+#define BPP_REDUCE_TILE 4u
 __global__ void __launch_bounds__(64) k_reduce_static(const sc *__restrict__ rows, const sc *__restrict__ wm,
                                                       const uint32_t *__restrict__ group_first, uint32_t cols,
                                                       sc *__restrict__ out /* [G][cols] canonical */) {
-  const uint32_t col = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+  const uint32_t g = blockIdx.y, lane = threadIdx.x;
+  const uint32_t col = blockIdx.x * BPP_REDUCE_TILE + (lane & (BPP_REDUCE_TILE - 1u)), slot = lane / BPP_REDUCE_TILE;
   const uint32_t p0 = group_first[g], p1 = group_first[g + 1];
+  const bool live = col < cols;
   uint64_t acc[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) acc[i] = 0;
-  for (uint32_t p = p0 + lane; p < p1; p += 64) {
-    sc v;
-    sc_montmul(v, rows[(size_t)p * cols + col], wm[p]);
+  for (uint32_t p = p0 + slot; p < p1; p += 64u / BPP_REDUCE_TILE) {
+    if (live) {
+      sc v;
+      sc_montmul(v, rows[(size_t)p * cols + col], wm[p]);
 #pragma unroll
-    for (int i = 0; i < 8; i++) acc[i] += v.v[i];
+      for (int i = 0; i < 8; i++) acc[i] += v.v[i];
+    }
   }
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    for (int off = 32; off >= 1; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
+    for (int off = 32; off >= (int)BPP_REDUCE_TILE; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
   }
-  if (lane == 0) {
+  if (slot == 0 && live) {
     uint32_t wds[8];
     uint64_t carry = 0;
 #pragma unroll

@@ -150,7 +150,10 @@ __global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t *__restri
 // through the fabric by every wavefront.  grid = 8 * ceil(G/8) * ceil(per_group/64) blocks of 64. ----
 // Measured alternatives that lose: a 4-waves-per-SIMD bound (128 VGPRs) spills; turning the first point into the
 // accumulator with ge_from_niels (saves one of ~17 additions) costs 40-50 more VGPRs and a wavefront of occupancy.
-__global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t *__restrict__ sorted,
+#ifndef BPP_ACC_WAVES
+#define BPP_ACC_WAVES 3  // wavefronts per SIMD the register allocation is bounded for
+#endif
+__global__ void __launch_bounds__(64, BPP_ACC_WAVES) k_msm_accumulate(const uint32_t *__restrict__ sorted,
                                                        const uint32_t *__restrict__ starts,
                                                        const uint32_t *__restrict__ counts,
                                                        const uint32_t *__restrict__ order, PointTables tabs,
@@ -165,18 +168,20 @@ __global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t *__restric
   if (n == 0) return;  // empty buckets are skipped by the reduction (counts[] == 0)
   ge acc;
   ge_identity(acc);
-  // software pipeline: the next entry's index and point are in flight while the current addition runs
+  // software pipeline: the next entry's index and point are in flight while the current addition runs.  The sign of a
+  // term is applied while loading (y+x / y-x exchanged by address) and inside ge_madd_swapped (d - c / d + c exchanged):
+  // branch-free, lanes of one wavefront mix additions and subtractions
   uint32_t e = sorted[a];
-  niels q = *point_ptr(tabs, e & 0x7fffffffu);
+  niels q;
+  niels_load_swapped(q, point_ptr(tabs, e & 0x7fffffffu), (e >> 31) != 0);
   for (uint32_t i = 0; i < n; i++) {
     const uint32_t e_cur = e;
-    niels q_cur = q;
+    const niels q_cur = q;
     if (i + 1 < n) {
       e = sorted[a + i + 1];
-      q = *point_ptr(tabs, e & 0x7fffffffu);
+      niels_load_swapped(q, point_ptr(tabs, e & 0x7fffffffu), (e >> 31) != 0);
     }
-    niels_cneg(q_cur, (e_cur >> 31) != 0);  // branch-free: lanes of one wave mix additions and subtractions
-    ge_madd(acc, acc, q_cur);
+    ge_madd_swapped(acc, acc, q_cur, (e_cur >> 31) != 0);
   }
   buckets[bkt] = acc;
 }

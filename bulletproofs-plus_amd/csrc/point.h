@@ -1,7 +1,9 @@
 // ristretto255 group operations for gfx950 (twisted Edwards a = -1, extended coordinates).
 //
 //   ge      (X:Y:Z:T)            accumulator form, 160 B
-//   niels   (y+x, y-x, 2dxy)     affine operand form, 120 B -- every MSM input point is stored like this
+//   niels   (y+x, y-x, 2dxy)     affine operand form, 120 B padded to ONE aligned 128-byte line -- every MSM input point
+//                                (generator tables, a batch's decoded points, fixed-base windows) is stored like this, so a
+//                                gather touches exactly one line (an unpadded entry straddles two of them 94 % of the time)
 //
 // Replaces (reference boundary): RistrettoPoint / CompressedRistretto of curve25519-dalek as used at
 // src/range_proof.rs:1050-1057 (final MSM), :1067-1109 (decompress), :348,:499-504 (compress),
@@ -21,9 +23,19 @@ BPP_HD void fe_const(fe &h, const uint32_t c[10]) {
 struct ge {
   fe X, Y, Z, T;
 };
-struct niels {
+struct alignas(128) niels {
   fe yplusx, yminusx, xy2d;
 };
+static_assert(sizeof(niels) == 128, "one table entry = one 128-byte line");
+
+// table entry -> registers for a term with sign `neg`: -(x, y) = (-x, y) exchanges y+x and y-x, which costs nothing when
+// done by address while loading; the sign of 2dxy is handled inside ge_madd_swapped
+BPP_HD void niels_load_swapped(niels &q, const niels *src, bool neg) {
+  const fe *pair = &src->yplusx;  // pair[0] = y+x, pair[1] = y-x
+  q.yplusx = pair[neg ? 1 : 0];
+  q.yminusx = pair[neg ? 0 : 1];
+  q.xy2d = src->xy2d;
+}
 
 BPP_HD void ge_identity(ge &r) {
   fe_0(r.X);
@@ -62,51 +74,74 @@ BPP_HD void niels_cneg(niels &q, bool neg) {
   }
 }
 
-// r = p + q (q affine niels): 7 mul
+// r = p + q (q affine niels): 7 mul.  Lazily reduced (field.h limb classes): with reduced coordinates in, Y+X and 2Z+c
+// are loose, Y-X and a-b are lazy differences (loose), 2Z-c is wide; every product pairs a wide-or-smaller first operand
+// with a loose-or-smaller second one, so no carry pass runs outside the seven products.
 BPP_HD void ge_madd(ge &r, const ge &p, const niels &q) {
-  fe a, b, c, d, e, f, g, h;
+  fe a, b, c, e, f, g, h;
   fe_add(a, p.Y, p.X);
-  fe_sub(b, p.Y, p.X);
+  fe_sub_lazy(b, p.Y, p.X);
   fe_mul(a, a, q.yplusx);
   fe_mul(b, b, q.yminusx);
   fe_mul(c, q.xy2d, p.T);
-  fe_add(d, p.Z, p.Z);
-  fe_sub(e, a, b);
+  fe_sub_lazy(e, a, b);
   fe_add(h, a, b);
-  fe_add(g, d, c);
-  fe_sub(f, d, c);
-  fe_mul(r.X, e, f);
-  fe_mul(r.Y, h, g);
-  fe_carry(g);
-  fe_mul(r.Z, g, f);
+  fe_dbl_add(g, p.Z, c);       // d + c, d = 2Z
+  fe_dbl_sub_lazy(f, p.Z, c);  // d - c
+  fe_mul(r.X, f, e);
+  fe_mul(r.Y, g, h);
+  fe_mul(r.Z, f, g);
+  fe_mul(r.T, e, h);
+}
+
+// r = p + (neg ? -q : q) where the CALLER has already exchanged q.yplusx / q.yminusx when neg (-(x, y) = (-x, y) swaps
+// y+x with y-x: free if done while loading the table entry) and q.xy2d is the entry's own: negating 2dxy negates c, which
+// only makes d - c and d + c trade places.  Branch-free: lanes of one wavefront mix additions and subtractions.
+BPP_HD void ge_madd_swapped(ge &r, const ge &p, const niels &q, bool neg) {
+  fe a, b, c, e, f, g, h, u, v;
+  fe_add(a, p.Y, p.X);
+  fe_sub_lazy(b, p.Y, p.X);
+  fe_mul(a, a, q.yplusx);
+  fe_mul(b, b, q.yminusx);
+  fe_mul(c, q.xy2d, p.T);
+  fe_sub_lazy(e, a, b);
+  fe_add(h, a, b);
+  fe_dbl_add(u, p.Z, c);       // loose
+  fe_dbl_sub_lazy(v, p.Z, c);  // wide
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    f.v[i] = neg ? u.v[i] : v.v[i];
+    g.v[i] = neg ? v.v[i] : u.v[i];
+  }
+  fe_mul(r.X, f, e);
+  fe_mul(r.Y, g, h);
+  fe_mul(r.Z, v, u);  // g * f either way
   fe_mul(r.T, e, h);
 }
 
 // r = p - q (q affine niels)
 BPP_HD void ge_msub(ge &r, const ge &p, const niels &q) {
-  fe a, b, c, d, e, f, g, h;
+  fe a, b, c, e, f, g, h;
   fe_add(a, p.Y, p.X);
-  fe_sub(b, p.Y, p.X);
+  fe_sub_lazy(b, p.Y, p.X);
   fe_mul(a, a, q.yminusx);
   fe_mul(b, b, q.yplusx);
   fe_mul(c, q.xy2d, p.T);
-  fe_add(d, p.Z, p.Z);
-  fe_sub(e, a, b);
+  fe_sub_lazy(e, a, b);
   fe_add(h, a, b);
-  fe_sub(g, d, c);
-  fe_add(f, d, c);
-  fe_mul(r.X, e, f);
-  fe_mul(r.Y, h, g);
-  fe_carry(f);
+  fe_dbl_sub_lazy(g, p.Z, c);  // d - c
+  fe_dbl_add(f, p.Z, c);       // d + c
+  fe_mul(r.X, f, e);
+  fe_mul(r.Y, g, h);
   fe_mul(r.Z, g, f);
   fe_mul(r.T, e, h);
 }
 
-// r = p + q, both extended: 9 mul
+// r = p + q, both extended: 9 mul, no carry pass outside the products (same limb classes as ge_madd)
 BPP_HD void ge_add(ge &r, const ge &p, const ge &q) {
-  fe a, b, c, d, e, f, g, h, t, d2;
-  fe_sub(a, p.Y, p.X);
-  fe_sub(t, q.Y, q.X);
+  fe a, b, c, zz, e, f, g, h, t, d2;
+  fe_sub_lazy(a, p.Y, p.X);
+  fe_sub_lazy(t, q.Y, q.X);
   fe_mul(a, a, t);
   fe_add(b, p.Y, p.X);
   fe_add(t, q.Y, q.X);
@@ -114,37 +149,39 @@ BPP_HD void ge_add(ge &r, const ge &p, const ge &q) {
   fe_const(d2, FE_D2);
   fe_mul(c, p.T, q.T);
   fe_mul(c, c, d2);
-  fe_mul(d, p.Z, q.Z);
-  fe_add(d, d, d);
-  fe_sub(e, b, a);
-  fe_sub(f, d, c);
-  fe_add(g, d, c);
+  fe_mul(zz, p.Z, q.Z);
+  fe_sub_lazy(e, b, a);
   fe_add(h, b, a);
-  fe_mul(r.X, e, f);
-  fe_carry(g);
+  fe_dbl_sub_lazy(f, zz, c);  // d - c, d = 2 Z1 Z2: wide
+  fe_dbl_add(g, zz, c);       // d + c: loose
+  fe_mul(r.X, f, e);
   fe_mul(r.Y, g, h);
   fe_mul(r.Z, f, g);
   fe_mul(r.T, e, h);
 }
 
+// one doubling step on (X, Y, Z): e (wide), f (reduced), g, h (loose) with 2p = (e f : g h : f g : e h)
+BPP_HD void ge_dbl_efgh(fe &e, fe &f, fe &g, fe &h, const fe &X, const fe &Y, const fe &Z) {
+  fe a, b, zz, t;
+  fe_sq(a, X);
+  fe_sq(b, Y);
+  fe_sq(zz, Z);
+  fe_add(t, X, Y);
+  fe_sq(t, t);
+  fe_add(h, a, b);
+  fe_sub_lazy(e, h, t);  // a + b - (X + Y)^2 + 2p: wide
+  fe_sub_lazy(g, a, b);
+  fe_dbl_add(f, zz, g);  // 2 Z^2 + a - b + 2p <= 2.5 * 2^27: the one value that needs a carry pass
+  fe_carry(f);
+}
+
 // r = 2p: 4 sq + 4 mul
 BPP_HD void ge_dbl(ge &r, const ge &p) {
-  fe a, b, c, e, f, g, h, t;
-  fe_sq(a, p.X);
-  fe_sq(b, p.Y);
-  fe_sq(c, p.Z);
-  fe_add(c, c, c);
-  fe_add(h, a, b);
-  fe_add(t, p.X, p.Y);
-  fe_sq(t, t);
-  fe_sub(e, h, t);
-  fe_sub(g, a, b);
-  fe_add(f, c, g);
-  fe_carry(f);
-  fe_carry(h);
+  fe e, f, g, h;
+  ge_dbl_efgh(e, f, g, h, p.X, p.Y, p.Z);
   fe_mul(r.X, e, f);
   fe_mul(r.Y, g, h);
-  fe_mul(r.Z, f, g);
+  fe_mul(r.Z, g, f);
   fe_mul(r.T, e, h);
 }
 
@@ -155,22 +192,11 @@ BPP_HD void ge_dbl_n(ge &r, const ge &p, int n) {
   fe_copy(Y, p.Y);
   fe_copy(Z, p.Z);
   for (int i = 0; i < n; i++) {
-    fe a, b, c, e, f, g, h, t;
-    fe_sq(a, X);
-    fe_sq(b, Y);
-    fe_sq(c, Z);
-    fe_add(c, c, c);
-    fe_add(h, a, b);
-    fe_add(t, X, Y);
-    fe_sq(t, t);
-    fe_sub(e, h, t);
-    fe_sub(g, a, b);
-    fe_add(f, c, g);
-    fe_carry(f);
-    fe_carry(h);
+    fe e, f, g, h;
+    ge_dbl_efgh(e, f, g, h, X, Y, Z);
     fe_mul(X, e, f);
     fe_mul(Y, g, h);
-    fe_mul(Z, f, g);
+    fe_mul(Z, g, f);
     if (i == n - 1) fe_mul(r.T, e, h);
   }
   fe_copy(r.X, X);

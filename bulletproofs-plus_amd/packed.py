@@ -1,0 +1,129 @@
+"""Array forms of the batch entry points for large inputs (tens of thousands of proofs per call).
+
+api.py mirrors the reference's object interface (one RangeStatement / RangeProof / RangeWitness object per proof) and
+marshals item by item with ctypes, ~20 us per proof; a caller that already holds its proofs, commitments and openings
+as contiguous arrays uses these instead: the bpp_verify_item / bpp_prove_item arrays of include/bpp.h are built with
+numpy pointer arithmetic (no per-item Python), the calls are the same C ABI calls.
+
+Shapes (n items, aggregation m, extension degree t, rounds = log2(m * bit_length)):
+    proofs        uint8 [n, 1 + 32 (t + 5 + 2 rounds)]     RangeProof::to_bytes()          (src/range_proof.rs:1120-1150)
+    commitments   uint8 [n, m, 32]                         statement.commitments_compressed (src/range_statement.rs:27)
+    min_values    uint64 [n, m], min_present uint8 [n, m]  Option<u64> promises             (src/range_statement.rs:29)
+    seed_nonces   uint8 [n, 32] or None                                                      (src/range_statement.rs:31)
+    values        uint64 [n, m], blindings uint8 [n, m, t, 32]   RangeWitness openings      (src/commitment_opening.rs:14-37)
+    rng_bytes     uint8 [n, 32 (rounds + 3)]               what the external RNG hands out  (src/range_proof.rs:232-608)
+"""
+import ctypes
+import time
+from ctypes import POINTER, byref, c_size_t, c_uint64
+
+import numpy as np
+
+from . import _lib, api
+
+_VERIFY_ITEM = np.dtype([("proof", "<u8"), ("proof_len", "<u8"), ("commitments32", "<u8"), ("m", "<u4"), ("_pad", "<u4"),
+                         ("min_values", "<u8"), ("min_present", "<u8"), ("seed_nonce32", "<u8"), ("transcript_state", "<u8"),
+                         ("transcript_label", "<u8"), ("label_len", "<u8")])
+_PROVE_ITEM = np.dtype([("values", "<u8"), ("blindings32", "<u8"), ("commitments32", "<u8"), ("m", "<u4"), ("_pad", "<u4"),
+                        ("min_values", "<u8"), ("min_present", "<u8"), ("seed_nonce32", "<u8"), ("transcript_state", "<u8"),
+                        ("transcript_label", "<u8"), ("label_len", "<u8"), ("rng_bytes", "<u8"), ("rng_len", "<u8")])
+assert _VERIFY_ITEM.itemsize == ctypes.sizeof(_lib.VerifyItem) and _PROVE_ITEM.itemsize == ctypes.sizeof(_lib.ProveItem)
+
+
+def _c(a, dtype, shape):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if a.shape != tuple(shape):
+        raise api.ProofError(api.ProofErrorKind.InvalidLength, "array of shape %s expected, got %s" % (tuple(shape), a.shape))
+    return a
+
+
+def _rows(a):
+    """addresses of the rows of a C-contiguous array"""
+    return a.ctypes.data + np.arange(a.shape[0], dtype=np.uint64) * np.uint64(a.strides[0])
+
+
+def commit(params, values, blindings):
+    """PedersenGens::commit for k openings (src/generators/pedersen_gens.rs:112-122): uint64 [k], uint8 [k, nb, 32] -> [k, 32]"""
+    values = np.ascontiguousarray(values, dtype=np.uint64)
+    k = values.shape[0]
+    blindings = np.ascontiguousarray(blindings, dtype=np.uint8)
+    nb = blindings.shape[1]
+    blindings = _c(blindings, np.uint8, (k, nb, 32))
+    out = np.zeros((k, 32), dtype=np.uint8)
+    eng = params.engine
+    rc = eng.lib.bpp_pedersen_commit(eng.ctx, params.handle, values.ctypes.data, blindings.ctypes.data, nb, k, out.ctypes.data)
+    api._check(rc, eng.ctx)
+    return out
+
+
+def prove(params, values, blindings, commitments, min_values, min_present, seed_nonces, label, rng_bytes):
+    """n x RangeProof::prove_with_rng in one bpp_prove_batch call -> uint8 [n, proof_len]"""
+    n_bits, t = params.bit_length(), int(params.extension_degree())
+    values = np.ascontiguousarray(values, dtype=np.uint64)
+    n, m = values.shape
+    rounds = max((n_bits * m).bit_length() - 1, 0)
+    blindings = _c(blindings, np.uint8, (n, m, t, 32))
+    commitments = _c(commitments, np.uint8, (n, m, 32))
+    min_values = _c(min_values, np.uint64, (n, m))
+    min_present = _c(min_present, np.uint8, (n, m))
+    rng_bytes = _c(rng_bytes, np.uint8, (n, 32 * (rounds + 3)))
+    lbl = np.frombuffer(bytes(label), dtype=np.uint8).copy() if len(label) else np.zeros(1, dtype=np.uint8)
+    items = np.zeros(n, dtype=_PROVE_ITEM)
+    items["values"] = _rows(values)
+    items["blindings32"] = _rows(blindings)
+    items["commitments32"] = _rows(commitments)
+    items["m"] = m
+    items["min_values"] = _rows(min_values)
+    items["min_present"] = _rows(min_present)
+    if seed_nonces is not None:
+        seed_nonces = _c(seed_nonces, np.uint8, (n, 32))
+        items["seed_nonce32"] = _rows(seed_nonces)
+    items["transcript_label"] = lbl.ctypes.data
+    items["label_len"] = len(label)
+    items["rng_bytes"] = _rows(rng_bytes)
+    items["rng_len"] = rng_bytes.shape[1]
+    plen = 1 + 32 * (t + 5 + 2 * rounds)
+    out = np.zeros((n, plen), dtype=np.uint8)
+    got = c_size_t()
+    err = ctypes.create_string_buffer(256)
+    eng = params.engine
+    rc = eng.lib.bpp_prove_batch(eng.ctx, params.handle, items.ctypes.data_as(POINTER(_lib.ProveItem)), n, out.ctypes.data, plen,
+                                 byref(got), err, 256)
+    api._check(rc, eng.ctx, err)
+    assert got.value == plen
+    return out
+
+
+class ResidentBatch(api.ResidentBatch):
+    """api.ResidentBatch (bpp_batch_upload / bpp_verify_resident / traces) uploaded from arrays"""
+
+    def __init__(self, params, proofs, commitments, min_values, min_present, seed_nonces, label):
+        t0 = time.perf_counter()
+        proofs = np.ascontiguousarray(proofs, dtype=np.uint8)
+        n, plen = proofs.shape
+        commitments = np.ascontiguousarray(commitments, dtype=np.uint8)
+        m = commitments.shape[1]
+        commitments = _c(commitments, np.uint8, (n, m, 32))
+        min_values = _c(min_values, np.uint64, (n, m))
+        min_present = _c(min_present, np.uint8, (n, m))
+        lbl = np.frombuffer(bytes(label), dtype=np.uint8).copy() if len(label) else np.zeros(1, dtype=np.uint8)
+        items = np.zeros(n, dtype=_VERIFY_ITEM)
+        items["proof"] = _rows(proofs)
+        items["proof_len"] = plen
+        items["commitments32"] = _rows(commitments)
+        items["m"] = m
+        items["min_values"] = _rows(min_values)
+        items["min_present"] = _rows(min_present)
+        if seed_nonces is not None:
+            seed_nonces = _c(seed_nonces, np.uint8, (n, 32))
+            items["seed_nonce32"] = _rows(seed_nonces)
+        items["transcript_label"] = lbl.ctypes.data
+        items["label_len"] = len(label)
+        t1 = time.perf_counter()
+        self.params, self.engine, self.n, self.t = params, params.engine, n, int(params.extension_degree())
+        self.handle = c_uint64()
+        err = ctypes.create_string_buffer(256)
+        rc = self.engine.lib.bpp_batch_upload(self.engine.ctx, params.handle, items.ctypes.data_as(POINTER(_lib.VerifyItem)), n,
+                                              byref(self.handle), err, 256)
+        api._check(rc, self.engine.ctx, err)
+        self.marshal_seconds, self.upload_seconds = t1 - t0, time.perf_counter() - t1

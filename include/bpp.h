@@ -138,6 +138,9 @@ int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items
 int bpp_batch_destroy(bpp_ctx *ctx, uint64_t batch);
 int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, uint8_t *masks_out,
                         uint8_t *mask_present, char *errbuf, size_t errbuf_len);
+/* optional: do the one-off work of the first bpp_verify_resident(batch, ..., chunk) now -- group layout, MSM plan and
+ * the allocation of every work buffer of that plan (~15 hipMallocs) -- so that no verification call pays for it */
+int bpp_batch_prepare(bpp_ctx *ctx, uint64_t batch, size_t chunk);
 
 /* ---- phased form of the same verification, for sharding one reference batch across GPUs ----
  * phase1: PASS 1 of verify (src/range_proof.rs:816-850) for this rank's proofs -> the 32 transcript-RNG bytes per
@@ -208,6 +211,19 @@ typedef struct {
 } bpp_profile;
 int bpp_profile_enable(bpp_ctx *ctx, int on);
 int bpp_profile_get(bpp_ctx *ctx, bpp_profile *out);
+
+/* the batch prover's dominant kernel (k_fb_msm, fixed-base MSM) over the last bpp_prove_batch of this ctx: summed event
+ * time of its launches, the terms it consumed (witness check, L/R of every round, A1/B), table geometry */
+typedef struct {
+  float fb_msm_ms, total_ms;
+  uint64_t fb_terms;
+  uint32_t fb_launches, fb_window_bits, fb_windows, sub_batches;
+} bpp_prove_profile;
+int bpp_prove_profile_get(bpp_ctx *ctx, bpp_prove_profile *out);
+
+/* size of the process-wide host worker pool that runs the batch-weight chains and the upload packer
+ * (BPP_HOST_THREADS, default min(cores, 32)): the verifier's throughput depends on it */
+int bpp_host_threads(void);
 
 /* Transcript::new(label) -> 203-byte STROBE state (host helper for callers that keep merlin on their side) */
 int bpp_transcript_new(const uint8_t *label, size_t label_len, uint8_t state203[203]);

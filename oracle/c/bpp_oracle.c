@@ -416,6 +416,28 @@ int oracle_verify_timed(const oracle_params *P, const oracle_item *items, size_t
   return rc;
 }
 
+/* the same on `threads` host threads: thread k verifies the chunk-sized slice k (mod the number of slices) `iters` times;
+   wall time over all threads.  The reference is single-threaded; this is SURVEY 8(d)'s "same code across all host cores,
+   one 256-proof chunk per thread" leg of the CPU baseline. */
+#include <pthread.h>
+typedef struct { const oracle_params *P; const oracle_item *items; size_t n; int iters; int rc; } mt_job;
+static void *mt_worker(void *arg) { mt_job *j = (mt_job *)arg; j->rc = 0;
+  for (int it = 0; it < j->iters && !j->rc; it++) j->rc = oracle_verify(j->P, j->items, j->n, 0, NULL, NULL, NULL);
+  return NULL; }
+int oracle_verify_timed_mt(const oracle_params *P, const oracle_item *items, size_t n_items, size_t chunk, int iters, int threads, double *seconds) {
+  if (threads < 1 || threads > 1024) return -1;
+  if (chunk == 0 || chunk > n_items) chunk = n_items;
+  const size_t slices = n_items / chunk; if (slices == 0) return -1;
+  curve_init();
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads); mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * threads);
+  struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int k = 0; k < threads; k++) { jobs[k] = (mt_job){P, items + (k % slices) * chunk, chunk, iters, 0}; pthread_create(&th[k], NULL, mt_worker, &jobs[k]); }
+  int rc = 0; for (int k = 0; k < threads; k++) { pthread_join(th[k], NULL); if (jobs[k].rc) rc = jobs[k].rc; }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  free(th); free(jobs); return rc;
+}
+
 /* ------------------------------------------------------------------ primitive probes for KAT tests */
 void oracle_from_uniform(const uint8_t in[64], uint8_t out[32]) { curve_init(); ge_p3 p; ristretto_from_uniform(&p, in); ristretto_compress(out, &p); }
 int oracle_decompress_compress(const uint8_t in[32], uint8_t out[32]) { curve_init(); ge_p3 p; if (!ristretto_decompress(&p, in)) return 0; ristretto_compress(out, &p); return 1; }

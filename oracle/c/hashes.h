@@ -9,7 +9,7 @@
 #include <stdint.h>
 #include <string.h>
 
-static uint64_t g_keccak_count = 0; /* instrumentation */
+static __thread uint64_t g_keccak_count = 0; /* instrumentation (per thread: the all-cores baseline must not share a counter line) */
 
 static void keccakf(uint64_t st[25]) {
   static const uint64_t rc[24] = {

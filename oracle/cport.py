@@ -45,6 +45,7 @@ def lib():
                                    c_void_p, c_void_p, c_size_t, c_void_p, POINTER(c_size_t), c_void_p]
         L.oracle_verify.argtypes = [c_void_p, POINTER(Item), c_size_t, c_int, c_void_p, c_void_p, POINTER(Trace)]
         L.oracle_verify_timed.argtypes = [c_void_p, POINTER(Item), c_size_t, c_size_t, c_int, POINTER(c_double)]
+        L.oracle_verify_timed_mt.argtypes = [c_void_p, POINTER(Item), c_size_t, c_size_t, c_int, c_int, POINTER(c_double)]
         L.oracle_keccak_count.restype = c_uint64
         L.oracle_nonce.argtypes = [c_void_p, c_char_p, c_int, c_int, c_void_p]
         L.oracle_msm.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
@@ -145,6 +146,13 @@ class Params:
         arr, keep = self.items(batch)
         sec = c_double()
         rc = lib().oracle_verify_timed(self.h, arr, len(batch), chunk, iters, byref(sec))
+        return rc, sec.value
+
+    def verify_timed_mt(self, batch, chunk, iters, threads):
+        """`threads` host threads, thread k verifying the k-th `chunk`-proof slice of `batch` `iters` times -> (rc, wall s)"""
+        arr, keep = self.items(batch)
+        sec = c_double()
+        rc = lib().oracle_verify_timed_mt(self.h, arr, len(batch), chunk, iters, threads, byref(sec))
         return rc, sec.value
 
     def close(self):

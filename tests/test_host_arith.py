@@ -85,6 +85,9 @@ def test_ristretto(ht):
         o4 = _buf()
         assert ht.ht_from_niels(o.raw, 0, o4) == 1 and o4.raw == (pt * 2).compress()  # ge_from_niels(P) + P
         assert ht.ht_from_niels(o.raw, 1, o4) == 1 and o4.raw == bytes(32)            # ge_from_niels(-P) + P
+        # the MSM kernels' way of applying a term's sign (niels_load_swapped + ge_madd_swapped): 2P + P, 2P - P
+        assert ht.ht_madd_swapped(o.raw, 0, o4) == 1 and o4.raw == (pt * 3).compress()
+        assert ht.ht_madd_swapped(o.raw, 1, o4) == 1 and o4.raw == o.raw
         k = int.from_bytes(_r(b"k", i), "little") % L
         o3 = _buf()
         assert ht.ht_scalarmult(k.to_bytes(32, "little"), o.raw, o3) == 1 and o3.raw == (pt * k).compress()
