@@ -1,0 +1,138 @@
+//! Raw declarations: one `extern "C"` item per symbol of include/bpp.h, same order, same argument meaning.
+#![allow(non_camel_case_types)]
+use core::ffi::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct bpp_ctx {
+    _p: [u8; 0],
+}
+
+pub const BPP_OK: c_int = 0;
+pub const BPP_ERR_VERIFICATION_FAILED: c_int = 1;
+pub const BPP_ERR_INVALID_ARGUMENT: c_int = 2;
+pub const BPP_ERR_INVALID_LENGTH: c_int = 3;
+pub const BPP_ERR_INVALID_BLAKE2B: c_int = 4;
+pub const BPP_ERR_SIZE_OVERFLOW: c_int = 5;
+pub const BPP_ERR_ENGINE: c_int = -1;
+pub const BPP_ERR_NO_DEVICE: c_int = -2;
+pub const BPP_ERR_BAD_HANDLE: c_int = -3;
+pub const BPP_REFERENCE_CHUNK: usize = 256;
+
+/// bpp_verify_item: one (transcript, statement, proof) triple of `RangeProof::verify_batch` (src/range_proof.rs:712-717)
+#[repr(C)]
+pub struct bpp_verify_item {
+    pub proof: *const u8,
+    pub proof_len: usize,
+    pub commitments32: *const u8,
+    pub m: u32,
+    pub min_values: *const u64,
+    pub min_present: *const u8,
+    pub seed_nonce32: *const u8,
+    pub transcript_state: *const u8,
+    pub transcript_label: *const u8,
+    pub label_len: usize,
+}
+
+/// bpp_prove_item: one (transcript, statement, witness, rng) quadruple of `RangeProof::prove_with_rng` (:232-237)
+#[repr(C)]
+pub struct bpp_prove_item {
+    pub values: *const u64,
+    pub blindings32: *const u8,
+    pub commitments32: *const u8,
+    pub m: u32,
+    pub min_values: *const u64,
+    pub min_present: *const u8,
+    pub seed_nonce32: *const u8,
+    pub transcript_state: *const u8,
+    pub transcript_label: *const u8,
+    pub label_len: usize,
+    pub rng_bytes: *const u8,
+    pub rng_len: usize,
+}
+
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct bpp_profile {
+    pub transcripts_ms: f32,
+    pub decompress_ms: f32,
+    pub chain_host_ms: f32,
+    pub scalars_ms: f32,
+    pub reduce_ms: f32,
+    pub msm_digits_ms: f32,
+    pub msm_sort_ms: f32,
+    pub msm_accumulate_ms: f32,
+    pub msm_bucket_reduce_ms: f32,
+    pub msm_final_ms: f32,
+    pub total_ms: f32,
+    pub msm_terms: u32,
+    pub msm_window_bits: u32,
+    pub msm_windows: u32,
+    pub msm_groups: u32,
+}
+
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct bpp_prove_profile {
+    pub fb_msm_ms: f32,
+    pub total_ms: f32,
+    pub fb_terms: u64,
+    pub fb_launches: u32,
+    pub fb_window_bits: u32,
+    pub fb_windows: u32,
+    pub sub_batches: u32,
+}
+
+extern "C" {
+    pub fn bpp_ctx_create(out: *mut *mut bpp_ctx, device_id: c_int) -> c_int;
+    pub fn bpp_ctx_create_on_stream(out: *mut *mut bpp_ctx, device_id: c_int, hip_stream: *mut c_void) -> c_int;
+    pub fn bpp_ctx_destroy(ctx: *mut bpp_ctx);
+    pub fn bpp_ctx_last_error(ctx: *mut bpp_ctx) -> *const c_char;
+    // B1: VartimePrecomputedMultiscalarMul / VartimeMultiscalarMul / MultiscalarMul (src/traits.rs:40-43, src/ristretto.rs:28-64)
+    pub fn bpp_precomp_create(ctx: *mut bpp_ctx, points32: *const u8, count: usize, handle: *mut u64) -> c_int;
+    pub fn bpp_precomp_destroy(ctx: *mut bpp_ctx, handle: u64) -> c_int;
+    pub fn bpp_precomp_retain(ctx: *mut bpp_ctx, handle: u64) -> c_int;
+    pub fn bpp_msm_mixed(ctx: *mut bpp_ctx, handle: u64, static_scalars32: *const u8, n_static: usize, dyn_scalars32: *const u8,
+                         dyn_points32: *const u8, n_dyn: usize, out_point32: *mut u8) -> c_int;
+    pub fn bpp_msm_vartime(ctx: *mut bpp_ctx, scalars32: *const u8, points32: *const u8, n: usize, out_point32: *mut u8) -> c_int;
+    pub fn bpp_msm_vartime_batched(ctx: *mut bpp_ctx, scalars32: *const u8, points32: *const u8, group_off: *const u32,
+                                   n_groups: usize, out_points32: *mut u8) -> c_int;
+    // B2: RangeParameters::init (src/range_parameters.rs:32-58), PedersenGens::commit (src/generators/pedersen_gens.rs:112-122)
+    pub fn bpp_params_create(ctx: *mut bpp_ctx, bit_length: u32, max_aggregation: u32, extension_degree: u32, h_base32: *const u8,
+                             g_bases32: *const u8, params: *mut u64) -> c_int;
+    pub fn bpp_params_destroy(ctx: *mut bpp_ctx, params: u64) -> c_int;
+    pub fn bpp_params_retain(ctx: *mut bpp_ctx, params: u64) -> c_int;
+    pub fn bpp_params_export(ctx: *mut bpp_ctx, params: u64, gi_out32: *mut u8, hi_out32: *mut u8, h_out32: *mut u8, g_out32: *mut u8) -> c_int;
+    pub fn bpp_pedersen_commit(ctx: *mut bpp_ctx, params: u64, values: *const u64, blindings32: *const u8, n_blind: u32, count: usize,
+                               commitments32: *mut u8) -> c_int;
+    // B2: RangeProof::verify_batch / verify (src/range_proof.rs:712-1065)
+    pub fn bpp_verify_batch(ctx: *mut bpp_ctx, params: u64, items: *const bpp_verify_item, n_items: usize, action: c_int, chunk: usize,
+                            masks_out: *mut u8, mask_present: *mut u8, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    pub fn bpp_verify_batch_with_challenges(ctx: *mut bpp_ctx, params: u64, items: *const bpp_verify_item, n_items: usize,
+                                            challenges32: *const *const u8, rng_out32: *const u8, action: c_int, chunk: usize,
+                                            masks_out: *mut u8, mask_present: *mut u8, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    pub fn bpp_batch_upload(ctx: *mut bpp_ctx, params: u64, items: *const bpp_verify_item, n_items: usize, batch: *mut u64,
+                            errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    pub fn bpp_batch_destroy(ctx: *mut bpp_ctx, batch: u64) -> c_int;
+    pub fn bpp_batch_prepare(ctx: *mut bpp_ctx, batch: u64, chunk: usize) -> c_int;
+    pub fn bpp_verify_resident(ctx: *mut bpp_ctx, batch: u64, action: c_int, chunk: usize, masks_out: *mut u8, mask_present: *mut u8,
+                               errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    // sharded form (one reference batch over several GPUs)
+    pub fn bpp_verify_phase1(ctx: *mut bpp_ctx, batch: u64, rng_out32: *mut u8, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    pub fn bpp_weights_from_chain(rng32_all: *const u8, n_total: usize, weights32_out: *mut u8) -> c_int;
+    pub fn bpp_weights_from_chains(rng32_all: *const u8, n_groups: usize, n_per_group: usize, weights32_out: *mut u8) -> c_int;
+    pub fn bpp_verify_phase2(ctx: *mut bpp_ctx, batch: u64, weights32: *const u8, accumulator128: *mut u8, errbuf: *mut c_char,
+                             errbuf_len: usize) -> c_int;
+    pub fn bpp_accumulators_sum_is_identity(ctx: *mut bpp_ctx, accumulators128: *const u8, n: usize, is_identity: *mut c_int) -> c_int;
+    // B2: RangeProof::prove_with_rng (src/range_proof.rs:232-608)
+    pub fn bpp_prove_batch(ctx: *mut bpp_ctx, params: u64, items: *const bpp_prove_item, n_items: usize, proofs_out: *mut u8,
+                           proof_stride: usize, proof_len: *mut usize, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    // diagnostics
+    pub fn bpp_batch_trace(ctx: *mut bpp_ctx, batch: u64, what: c_int, out: *mut u8, out_len: usize, written: *mut usize) -> c_int;
+    pub fn bpp_batch_shape(ctx: *mut bpp_ctx, batch: u64, n_items: *mut u32, max_rounds: *mut u32, max_mn: *mut u32, total_dyn: *mut u32,
+                           groups: *mut u32) -> c_int;
+    pub fn bpp_profile_enable(ctx: *mut bpp_ctx, on: c_int) -> c_int;
+    pub fn bpp_profile_get(ctx: *mut bpp_ctx, out: *mut bpp_profile) -> c_int;
+    pub fn bpp_prove_profile_get(ctx: *mut bpp_ctx, out: *mut bpp_prove_profile) -> c_int;
+    pub fn bpp_host_threads() -> c_int;
+    pub fn bpp_transcript_new(label: *const u8, label_len: usize, state203: *mut u8) -> c_int;
+}

@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
-#define ITER 16384
+#define ITER 65536
 template <int OP>
 __global__ void __launch_bounds__(256) k(uint32_t *out, uint64_t *clk, uint32_t seed) {
   uint32_t a = threadIdx.x + seed, b = blockIdx.x * 7 + 3;
@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint64_t *clk, uint32_t 
       if (OP == 10) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
       if (OP == 11) asm volatile("v_alignbit_b32 %0, %0, %1, 26" : "+v"(r[i]) : "v"(b));
       if (OP == 12) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(b), "v"(a));
-      if (OP == 13) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(b) : "vcc");
+      if (OP == 13) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(b));
       if (OP == 14) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(r[i]) : "v"(b));
       if (OP == 15) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(r[i]), "v"(b) : "vcc");
       if (OP == 16) asm volatile("v_lshrrev_b32 %0, 26, %0" : "+v"(r[i]));
