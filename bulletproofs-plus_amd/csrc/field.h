@@ -183,18 +183,18 @@ BPP_HD void fe_mul(fe &h, const fe &f, const fe &g) {
 }
 
 // Squaring: 55 products.  Both operands of every product are pre-scaled limbs, so a column is a plain chain of
-// v_mad_u64_u32 (no doubling of 64-bit products); carries seed the next column as in fe_mul.  The factor of a pair (i < j)
-// is 2 (off-diagonal) x 2 (both odd) x 19 (wrapped): the off-diagonal 2 goes on f_i, the rest on f_j, so f_j is scaled
-// by 1, 2, 19 or -- only for ODD j, whose bound is half that of the even limbs -- 38: loose input (odd limbs
-// <= 1.5 * 2^26) keeps 38 f_j below 2^32.
+// v_mad_u64_u32 (no doubling of 64-bit products); carries seed the next column as in fe_mul.  The factor of a pair
+// (i <= j) is 2 (off-diagonal) x 2 (both odd) x 19 (wrapped, i + j >= 10).  A wrapped pair takes its 19 -- and for an odd
+// j, whose bound is half that of the even limbs, one factor 2 as well -- on f_j; whatever factor 2 is left goes on f_i.
+// That needs 13 pre-scaled limbs in all: 2 f_0..2 f_7, 19 f_6, 19 f_8, 38 f_5, 38 f_7, 38 f_9; loose input (even limbs
+// <= 1.5 * 2^27, odd <= 1.5 * 2^26) keeps every one of them below 2^32.
 BPP_HD void fe_sq(fe &h, const fe &f) {
-  uint32_t f2[10], f19[10], f38[10];
+  uint32_t f2[10], fw[10];  // fw[j] = 19 f_j (j even) or 38 f_j (j odd)
 #pragma unroll
   for (int i = 0; i < 10; i++) {
     BPP_FE_CHECK((uint64_t)((i & 1) ? 38u : 19u) * f.v[i] < (1ull << 32), "fe_sq operand limb too large");
     f2[i] = 2u * f.v[i];
-    f19[i] = 19u * f.v[i];
-    f38[i] = 38u * f.v[i];  // used for odd i only
+    fw[i] = ((i & 1) ? 38u : 19u) * f.v[i];
   }
   uint64_t c = 0;
   uint32_t r[10];
@@ -208,9 +208,10 @@ BPP_HD void fe_sq(fe &h, const fe &f) {
       const bool wrap = i > k;  // i + j == k + 10
       const bool dbl = (i & 1) && (j & 1);
       const bool off = i != j;
-      // total factor = (off ? 2 : 1) * (dbl ? 2 : 1) * (wrap ? 19 : 1): `off` on f_i, the rest on f_j
-      const uint32_t a = off ? f2[i] : f.v[i];
-      const uint32_t b = wrap ? (dbl ? f38[j] : f19[j]) : (dbl ? f2[j] : f.v[j]);
+      const int total = (off ? 2 : 1) * (dbl ? 2 : 1) * (wrap ? 19 : 1);
+      const int on_j = wrap ? ((j & 1) ? 38 : 19) : ((dbl && off) ? 2 : 1);
+      const uint32_t b = wrap ? fw[j] : ((dbl && off) ? f2[j] : f.v[j]);
+      const uint32_t a = (total / on_j == 2) ? f2[i] : f.v[i];  // the quotient is 1 or 2 for every pair
       acc = (k == 0 && i == 0) ? (uint64_t)a * b : fe_mad(a, b, acc);
     }
     r[k] = (uint32_t)acc & fe_mask(k);

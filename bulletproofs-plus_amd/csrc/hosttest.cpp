@@ -34,6 +34,10 @@ int ht_madd_swapped(const uint8_t in[32], int neg, uint8_t out[32]) {
   niels n; if (!ristretto_decompress(n, in)) return 0;
   ge p; ge_identity(p); ge_madd(p, p, n); ge_dbl(p, p);
   niels q; niels_load_swapped(q, &n, neg != 0); ge_madd_swapped(p, p, q, neg != 0); ristretto_compress(out, p); return 1; }
+// P (or -P) as an accumulator built by ge_from_niels_first from a sign-swapped load, then + P: 2P or the identity
+int ht_from_niels_first(const uint8_t in[32], int neg, uint8_t out[32]) {
+  niels n; if (!ristretto_decompress(n, in)) return 0;
+  niels q; niels_load_swapped(q, &n, neg != 0); ge p; ge_from_niels_first(p, q); ge_madd(p, p, n); ristretto_compress(out, p); return 1; }
 // the device's decoding schedule (k_decompress) on the host: same verdict and point as the plain schedule
 int ht_decompress_lean(const uint8_t in[32], uint8_t out[32]) {
   niels n; if (!ristretto_decompress_lean(n, in)) return 0;

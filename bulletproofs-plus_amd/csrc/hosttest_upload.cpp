@@ -258,6 +258,7 @@ int main() {
       ht_decompress_lean(a, o2);
       ht_madd_swapped(enc, iter & 1, o2);
       ht_from_niels(enc, iter & 1, o2);
+      ht_from_niels_first(enc, iter & 1, o2);
       if (iter < 8) {
         ht_fe_invert(a, o);
         b[31] &= 0x0f;

@@ -166,15 +166,23 @@ __global__ void __launch_bounds__(64, BPP_ACC_WAVES) k_msm_accumulate(const uint
   const uint32_t bkt = order[(size_t)g * per_group + slot];
   const uint32_t a = starts[bkt], n = counts[bkt];
   if (n == 0) return;  // empty buckets are skipped by the reduction (counts[] == 0)
-  ge acc;
-  ge_identity(acc);
   // software pipeline: the next entry's index and point are in flight while the current addition runs.  The sign of a
   // term is applied while loading (y+x / y-x exchanged by address) and inside ge_madd_swapped (d - c / d + c exchanged):
-  // branch-free, lanes of one wavefront mix additions and subtractions
+  // branch-free, lanes of one wavefront mix additions and subtractions.  The first term becomes the accumulator with
+  // one product (ge_from_niels_first) instead of being added to the identity with seven.
   uint32_t e = sorted[a];
   niels q;
   niels_load_swapped(q, point_ptr(tabs, e & 0x7fffffffu), (e >> 31) != 0);
-  for (uint32_t i = 0; i < n; i++) {
+  ge acc;
+  ge_from_niels_first(acc, q);
+  fe_fence(acc.X);  // the prologue is kept apart from the loop: interleaved with it, it costs 30 more live registers
+  fe_fence(acc.Y);  // (a wavefront of occupancy) for one product per bucket
+  fe_fence(acc.T);
+  if (n > 1) {
+    e = sorted[a + 1];
+    niels_load_swapped(q, point_ptr(tabs, e & 0x7fffffffu), (e >> 31) != 0);
+  }
+  for (uint32_t i = 1; i < n; i++) {
     const uint32_t e_cur = e;
     const niels q_cur = q;
     if (i + 1 < n) {

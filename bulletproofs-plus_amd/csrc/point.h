@@ -109,7 +109,7 @@ BPP_HD void ge_madd_swapped(ge &r, const ge &p, const niels &q, bool neg) {
   fe_dbl_add(u, p.Z, c);       // loose
   fe_dbl_sub_lazy(v, p.Z, c);  // wide
 #pragma unroll
-  for (int i = 0; i < 10; i++) {
+  for (int i = 0; i < 10; i++) {  // (and / xor selects instead of these 20 v_cndmask_b32: measured, no difference)
     f.v[i] = neg ? u.v[i] : v.v[i];
     g.v[i] = neg ? v.v[i] : u.v[i];
   }
@@ -466,6 +466,26 @@ BPP_HD void ristretto_from_uniform(ge &out, const uint8_t b[64]) {
   ristretto_elligator(p0, r0);
   ristretto_elligator(p1, r1);
   ge_add(out, p0, p1);
+}
+
+// affine niels -> extended with ONE multiplication: y+x and y-x give e = 2x and h = 2y, and (2e : 2h : 4 : e h) is the
+// point (T = X Y / Z).  This is what "identity + q" evaluates to (every other product of the mixed addition is then a
+// multiplication by 2 or 4), so a bucket's first term costs one product instead of seven.  A sign applied by
+// niels_load_swapped carries over by itself: e changes sign, and T = e h with it.  Output coordinates are reduced.
+BPP_HD void ge_from_niels_first(ge &r, const niels &q) {
+  fe e, h;
+  fe_sub_lazy(e, q.yplusx, q.yminusx);
+  fe_add(h, q.yplusx, q.yminusx);
+  fe_mul(r.T, e, h);
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    r.X.v[i] = 2u * e.v[i];
+    r.Y.v[i] = 2u * h.v[i];
+  }
+  fe_carry(r.X);
+  fe_carry(r.Y);
+  fe_0(r.Z);
+  r.Z.v[0] = 4;
 }
 
 // affine niels -> extended, no inversion: (2x : 2y : 2 : 2xy) with 2xy = (2dxy) / d

@@ -88,6 +88,9 @@ def test_ristretto(ht):
         # the MSM kernels' way of applying a term's sign (niels_load_swapped + ge_madd_swapped): 2P + P, 2P - P
         assert ht.ht_madd_swapped(o.raw, 0, o4) == 1 and o4.raw == (pt * 3).compress()
         assert ht.ht_madd_swapped(o.raw, 1, o4) == 1 and o4.raw == o.raw
+        # a bucket's first term: accumulator = +-P by ge_from_niels_first, then + P
+        assert ht.ht_from_niels_first(o.raw, 0, o4) == 1 and o4.raw == (pt * 2).compress()
+        assert ht.ht_from_niels_first(o.raw, 1, o4) == 1 and o4.raw == bytes(32)
         k = int.from_bytes(_r(b"k", i), "little") % L
         o3 = _buf()
         assert ht.ht_scalarmult(k.to_bytes(32, "little"), o.raw, o3) == 1 and o3.raw == (pt * k).compress()
