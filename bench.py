@@ -37,7 +37,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-VALU_PEAK_TMAD = 30.1   # measured v_mad_u64_u32 issue peak (tools/microbench/int_rates.hip), see DESIGN.md 4
+# v_mad_u64_u32 issue peak: half rate = 64 lanes / clock / CU x 256 CUs x 2.4 GHz.  Measured with an 8 ms kernel at 8 waves per
+# SIMD (tools/microbench/valu_rates.hip): 57.3 lanes / clock / CU at the 2.37 GHz the chip holds = 34.7 T/s
+VALU_PEAK_TMAD = 39.3
 LABEL = b"BatchedRangeProofTest"  # benches/range_proof.rs:49
 
 
@@ -46,7 +48,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "6")),
+    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "4")),
                     help="steps in flight per GPU (one engine/stream + one host thread each)")
     ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_step", type=int,
                     default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "64")),

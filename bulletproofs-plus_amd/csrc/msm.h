@@ -31,6 +31,9 @@ __device__ __forceinline__ const niels *point_ptr(const PointTables &t, uint32_t
   return idx < t.n_a ? (t.tab_a + idx) : (t.tab_b + (idx - t.n_a));
 }
 
+// (Non-temporal loads of the sorted lists and non-temporal 16-byte stores of the buckets were measured: FETCH_SIZE of
+// this kernel went from 389 to 1039 MB per launch, WRITE_SIZE from 240 to 595 MB, its duration from 0.84 to 0.98 ms.)
+
 // ---- signed digits.  grid = (ceil(maxGroupTerms/256), G), block 256.
 // Layout digitsT[goff[g]*K + k*ng + i] (window-major inside a group): the sort kernel reads one window contiguously ----
 __global__ void __launch_bounds__(256) k_msm_digits(const sc *__restrict__ scalars, const uint32_t *__restrict__ term_sidx,
