@@ -60,6 +60,25 @@ def parse_args():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """host threads this process may really run at once: affinity mask, capped by a cgroup CPU quota when there is one
+    (a 1-GPU box of the pool reports 256 logical CPUs but schedules 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, (q + p // 2) // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def self_launch(args):
     """plain `python bench.py --gpus N`: one rank per GPU under torch.distributed.run, as a child process (an exec from
     a process that has touched the GPU is forbidden on the pool; this one has not even imported torch yet)"""
@@ -172,7 +191,10 @@ def kernel_roofline(profs, alone_ms=None):
     terms, K, acc_ms = int(avg["msm_terms"]), int(avg["msm_windows"]), avg["msm_accumulate_ms"]
     msm_bytes = 64 * terms  # 32 B scalar + 32 B compressed point per MSM term
     achieved = msm_bytes / (acc_ms * 1e-3) / 1e9
-    mads = terms * K * 700.0  # one mixed addition per (term, window) = 7 field multiplications = 700 v_mad_u64_u32
+    # v_mad_u64_u32 per launch: a bucket's first term costs one field multiplication (100 mads), every further term a mixed
+    # addition of seven (700); buckets = groups x windows x 2^(c-1), all of them occupied at these sizes
+    buckets = min(int(avg["msm_groups"]) * K * (1 << (int(avg["msm_window_bits"]) - 1)), terms * K)
+    mads = (terms * K - buckets) * 700.0 + buckets * 100.0
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
            # HBM bytes per launch come from rocprofv3 PMC passes, which cannot run inside this process: see the file
            "traffic": None, "traffic_profile": "profiles/r02_traffic.json (FETCH_SIZE / WRITE_SIZE passes of this command)",
@@ -266,7 +288,7 @@ def main():
                    "inputs": "%d distinct proofs per rank, proved on the box by bpp_prove_batch (recipe of "
                              "benches/range_proof.rs:206-262), %.1f s" % (1024 * R, gen_s)},
         "step_latency_ms": 1e3 * sum(lat) / len(lat),
-        "host_threads": bpp.host_threads(), "nproc": os.cpu_count(),
+        "host_threads": bpp.host_threads(), "nproc": os.cpu_count(), "usable_cpus": usable_cpus(),
     }
     if roof:
         out["roofline"] = roof
@@ -375,7 +397,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import cport  # cpu_baseline leg only: the oracle is the thing timed here, never the product path
         cp = cport.Params(64, 1, 1)
-        ncpu = os.cpu_count() or 1
+        ncpu = usable_cpus()
         k = 256 * max(1, min(ncpu, 4))
         pr, cm, mv = data2["proofs"], data2["commitments"], data2["min_values"]
         sample = [{"proof": pr[i].tobytes(), "commitments": [cm[i, 0].tobytes()], "min_values": [int(mv[i, 0])],
@@ -384,14 +406,16 @@ def main():
         iters = max(1, int(args.cpu_seconds / max(sec1, 1e-3)))
         rc, sec = cp.verify_timed(sample[:256], 256, iters)
         assert rc == 0
-        rcm, secm = cp.verify_timed_mt(sample, 256, iters, ncpu)
+        rcm, secm1 = cp.verify_timed_mt(sample, 256, 1, ncpu)  # calibration: logical CPUs may outnumber the schedulable ones
+        iters_mt = max(1, min(iters, int(args.cpu_seconds / max(secm1, 1e-3))))
+        rcm, secm = cp.verify_timed_mt(sample, 256, iters_mt, ncpu)
         assert rcm == 0
         out["cpu_baseline"] = {"value": 256 * iters / sec, "unit": "proofs/s", "cores": 1, "kind": "port",
                                "sample": "%d x verify of one 256-proof reference batch (MAX_RANGE_PROOF_BATCH_SIZE) of the workload, "
                                          "single thread, oracle/c port with dalek's algorithms (the reference is single-threaded)" % iters,
-                               "all_cores": {"value": 256 * iters * ncpu / secm, "unit": "proofs/s", "cores": ncpu,
-                                             "sample": "%d threads, each %d x verify of a 256-proof reference batch" % (ncpu, iters)},
-                               "nproc": ncpu}
+                               "all_cores": {"value": 256 * iters_mt * ncpu / secm, "unit": "proofs/s", "cores": ncpu,
+                                             "sample": "%d threads, each %d x verify of a 256-proof reference batch" % (ncpu, iters_mt)},
+                               "nproc": os.cpu_count(), "usable_cpus": ncpu}
         cp.close()
     if rank == 0:
         print(json.dumps(out))
