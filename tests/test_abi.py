@@ -28,6 +28,9 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_host_only_entry_points():
     pkg = importlib.import_module("bulletproofs-plus_amd")
+    assert 1 <= pkg.host_threads() <= 256
+    packed = importlib.import_module("bulletproofs-plus_amd.packed")  # asserts that its item dtypes match the C structs
+    assert packed._VERIFY_ITEM.itemsize == ctypes.sizeof(pkg._lib.VerifyItem)
     from oracle.pyref import merlin as M
     assert pkg.Transcript.new(b"BatchedRangeProofTest").strobe_state() == M.Transcript(b"BatchedRangeProofTest").strobe.to_bytes()
 
