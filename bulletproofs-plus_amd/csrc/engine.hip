@@ -379,17 +379,6 @@ struct StageTimer {
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// Wavefronts per SIMD a one-wavefront-per-workgroup kernel is LIMITED to, through an unused dynamic LDS allocation
-// (160 KB per CU / (4 SIMDs x w) per workgroup).  Why: a multiply-bound instruction stream issues one v_mad_u64_u32 per
-// ~9.5 cycles per wavefront and ~4.5 per SIMD whatever its instruction-level parallelism, and EVEN occupancies pair up
-// (2 wavefronts: 92 % of the multiply rate, 4: 95 %) where odd ones do not (3: 78 %, 5: 90 %;
-// tools/microbench/mad_chains.hip, profiles/r02_mad_chains.txt).  0 = no limit.  BPP_OCC_<KERNEL> overrides (A/B runs).
-uint32_t occupancy_pad(const char *env, uint32_t default_waves) {
-  uint32_t w = default_waves;
-  if (const char *e = getenv(env)) w = (uint32_t)atoi(e);
-  if (w == 0 || w >= 8) return 0;
-  return (160u * 1024u) / (4u * w) - 64u;  // a little under the exact share: the allocation granule must not cost a slot
-}
 
 // ------------------------------------------------------------------ MSM driver
 uint32_t choose_window(uint32_t group_terms) {
@@ -467,18 +456,14 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
   if (small)
     hipLaunchKernelGGL(k_msm_accumulate_quad, dim3(cdiv(plan.G * per_group, 16)), dim3(64), 0, s, w.sorted.p, w.starts.p,
                        w.counts.p, w.order.p, tabs, plan.G * per_group, w.buckets.p);
-  else if (getenv("BPP_ACC_LDS") ? atoi(getenv("BPP_ACC_LDS")) != 0 : false)  // A/B: next entry staged through LDS (4 wavefronts / SIMD)
-    hipLaunchKernelGGL(k_msm_accumulate_lds, dim3(8 * cdiv(plan.G, 8) * cdiv(per_group, 64)), dim3(64),
-                       std::max(8192u + 64u, occupancy_pad("BPP_OCC_ACC_LDS", 0)) - 8192u - 64u, s, w.sorted.p, w.starts.p,
-                       w.counts.p, w.order.p, tabs, per_group, plan.G, w.buckets.p);
   else
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(8 * cdiv(plan.G, 8) * cdiv(per_group, 64)), dim3(64), occupancy_pad("BPP_OCC_ACC", 0), s, w.sorted.p, w.starts.p,
+    hipLaunchKernelGGL(k_msm_accumulate, dim3(8 * cdiv(plan.G, 8) * cdiv(per_group, 64)), dim3(64), 0, s, w.sorted.p, w.starts.p,
                        w.counts.p, w.order.p, tabs, per_group, plan.G, w.buckets.p);
   if (tm) tm->mark(M_ACC);
   if (plan.c <= 11 && small) {
     hipLaunchKernelGGL(k_msm_window_rc_quad, dim3(plan.G * plan.K), dim3(256), 0, s, w.buckets.p, w.counts.p, plan, w.W.p);
   } else if (plan.c <= 11) {
-    hipLaunchKernelGGL(k_msm_window_rc, dim3(plan.G * plan.K), dim3(64), occupancy_pad("BPP_OCC_WRC", 0), s, w.buckets.p, w.counts.p, plan, w.W.p);
+    hipLaunchKernelGGL(k_msm_window_rc, dim3(plan.G * plan.K), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.W.p);
   } else {
     hipLaunchKernelGGL(k_msm_bitsum, dim3(plan.c, plan.K, plan.G), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.Q.p);
     hipLaunchKernelGGL(k_msm_window, dim3(cdiv(plan.G * plan.K, 64)), dim3(64), 0, s, w.Q.p, plan, w.W.p);
@@ -1111,7 +1096,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
   HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
   const uint32_t n_proof_pts = b.total_dyn - b.sum_m;
-  hipLaunchKernelGGL(k_decompress, dim3(cdiv(n_proof_pts, 64)), dim3(64), occupancy_pad("BPP_OCC_DEC", 0), s, b.bytes.p, b.src_off.p, b.owner.p,
+  hipLaunchKernelGGL(k_decompress, dim3(cdiv(n_proof_pts, 64)), dim3(64), 0, s, b.bytes.p, b.src_off.p, b.owner.p,
                      b.idx_proof.p, n_proof_pts, b.dynpts.p, b.status.p);
   tm.mark(M_DECOMPRESS);
   if (!pass1_only) {
@@ -1124,8 +1109,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
     const uint32_t tab_max = (1u << std::min<uint32_t>(rm, BPP_LANES_LB)) + nhi_max + std::min<uint32_t>(m_max, 32);
     const uint32_t ppw = std::max<uint32_t>(1, std::min<uint32_t>(4, 64 / tab_max));
     const uint32_t ndyn_max = m_max + 3 + 2 * rm;
-    hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64),
-                       std::max<uint32_t>(ppw * (BPP_LANES_FIXED + 3 * nhi_max) * sizeof(sc), occupancy_pad("BPP_OCC_LANES", 0)), s,
+    hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * (BPP_LANES_FIXED + 3 * nhi_max) * sizeof(sc), s,
                        b.d_desc.p, b.shr.p, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, tab_max, ndyn_max, b.rows.p,
                        b.dyn_unw.p);
     tm.mark(M_SCALARS);

@@ -173,18 +173,6 @@ __global__ void __launch_bounds__(64, BPP_ACC_WAVES) k_msm_accumulate(const uint
   // term is applied while loading (y+x / y-x exchanged by address) and inside ge_madd_swapped (d - c / d + c exchanged):
   // branch-free, lanes of one wavefront mix additions and subtractions.  The first term becomes the accumulator with
   // one product (ge_from_niels_first) instead of being added to the identity with seven.
-#if defined(BPP_ACC_NOPREFETCH)  // A/B: no software pipeline (30 fewer live registers), latency left to the other wavefronts
-  uint32_t e = sorted[a];
-  niels q;
-  niels_load_swapped(q, point_ptr(tabs, e & 0x7fffffffu), (e >> 31) != 0);
-  ge acc;
-  ge_from_niels_first(acc, q);
-  for (uint32_t i = 1; i < n; i++) {
-    e = sorted[a + i];
-    niels_load_swapped(q, point_ptr(tabs, e & 0x7fffffffu), (e >> 31) != 0);
-    ge_madd_swapped(acc, acc, q, (e >> 31) != 0);
-  }
-#else
   uint32_t e = sorted[a];
   niels q;
   niels_load_swapped(q, point_ptr(tabs, e & 0x7fffffffu), (e >> 31) != 0);
@@ -207,111 +195,6 @@ __global__ void __launch_bounds__(64, BPP_ACC_WAVES) k_msm_accumulate(const uint
     ge_madd_swapped(acc, acc, q_cur, (e_cur >> 31) != 0);
   }
 #endif
-  buckets[bkt] = acc;
-}
-
-// ---- The same bucket sums with the NEXT table entry staged through LDS instead of registers.  The register form keeps
-// the prefetched entry (30 VGPRs) alive across a whole mixed addition, which puts the kernel at 136 VGPRs = 3 wavefronts
-// per SIMD.  Here every lane's next entry is copied by the LDS DMA path (global_load_lds_dwordx4: 8 x 16 bytes per lane,
-// piece-major, lane i at byte 16 i of each 1 KB piece; no destination registers) while the current addition runs, and
-// is read back (sign swap by LDS address) when the addition is done: 8 KB of LDS per wavefront, <= 128 VGPRs, 4
-// wavefronts per SIMD.  Same arithmetic in the same order: bit-identical buckets. ----
-#ifndef BPP_ACC_LDS_WAVES
-#define BPP_ACC_LDS_WAVES 4
-#endif
-__device__ __forceinline__ void stage_issue(const niels *src, uint8_t *stage) {
-  const uint8_t *p = reinterpret_cast<const uint8_t *>(src);
-#pragma unroll
-  for (int k = 0; k < 8; k++)
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(p + 16 * k),
-                                     (void __attribute__((address_space(3))) *)(stage + 1024 * k), 16, 0, 0);
-}
-// field f (0 = y+x, 1 = y-x, 2 = 2dxy) of the lane's staged entry: dword d sits at piece d / 4 (256 dwords apiece), word d % 4
-__device__ __forceinline__ void stage_field(fe &r, const uint8_t *stage, uint32_t lane, uint32_t f) {
-  const uint32_t *base = reinterpret_cast<const uint32_t *>(stage + lane * 16u);
-  const uint32_t d0 = 10u * f;
-#pragma unroll
-  for (uint32_t i = 0; i < 10; i++) {
-    const uint32_t d = d0 + i;
-    r.v[i] = base[(d >> 2) * 256u + (d & 3u)];
-  }
-}
-__device__ __forceinline__ void stage_fetch(niels &q, const uint8_t *stage, uint32_t lane, bool neg) {
-  stage_field(q.yplusx, stage, lane, neg ? 1u : 0u);
-  stage_field(q.yminusx, stage, lane, neg ? 0u : 1u);
-  stage_field(q.xy2d, stage, lane, 2u);
-}
-#define BPP_LDS_ORDER() asm volatile("" ::: "memory")
-__global__ void __launch_bounds__(64, BPP_ACC_LDS_WAVES) k_msm_accumulate_lds(const uint32_t *__restrict__ sorted,
-                                                                              const uint32_t *__restrict__ starts,
-                                                                              const uint32_t *__restrict__ counts,
-                                                                              const uint32_t *__restrict__ order, PointTables tabs,
-                                                                              uint32_t per_group, uint32_t G, ge *__restrict__ buckets) {
-  __shared__ __attribute__((aligned(16))) uint8_t stage[8192];
-  const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, lane = threadIdx.x;
-  const uint32_t bpg = (per_group + 63u) / 64u;  // blocks per group
-  const uint32_t g = xcd + 8u * (j / bpg);
-  const uint32_t slot = (j % bpg) * 64u + lane;
-  if (g >= G || slot >= per_group) return;
-  const uint32_t bkt = order[(size_t)g * per_group + slot];
-  const uint32_t a_ = starts[bkt], n = counts[bkt];
-  if (n == 0) return;
-  uint32_t e = sorted[a_], e1 = n > 1 ? sorted[a_ + 1] : 0u;
-  stage_issue(point_ptr(tabs, e & 0x7fffffffu), stage);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  niels q;
-  stage_fetch(q, stage, lane, (e >> 31) != 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staged copy has been read: the next one may land
-  uint32_t e2 = 0;
-  if (n > 1) {
-    stage_issue(point_ptr(tabs, e1 & 0x7fffffffu), stage);
-    if (n > 2) e2 = sorted[a_ + 2];
-  }
-  ge acc;
-  ge_from_niels_first(acc, q);
-  for (uint32_t i = 1; i < n; i++) {
-    e = e1;
-    e1 = e2;
-    const bool neg = (e >> 31) != 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // entry i is in LDS (and index i + 1 in its register)
-    // ge_madd_swapped with the entry's three fields read from LDS one at a time, each just before the product that
-    // consumes it (10 live registers instead of 30); the sign swaps y+x / y-x by LDS address
-    fe a, b, c, t, e_, f, g_, h, u, v;
-    stage_field(t, stage, lane, neg ? 1u : 0u);
-    fe_add(a, acc.Y, acc.X);
-    fe_mul(a, a, t);
-    fe_fence(a);
-    BPP_LDS_ORDER();
-    stage_field(t, stage, lane, neg ? 0u : 1u);
-    fe_sub_lazy(b, acc.Y, acc.X);
-    fe_mul(b, b, t);
-    fe_fence(b);
-    BPP_LDS_ORDER();
-    stage_field(t, stage, lane, 2u);
-    fe_mul(c, t, acc.T);
-    fe_fence(c);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staged copy has been read: the next one may land
-    if (i + 1 < n) {
-      stage_issue(point_ptr(tabs, e1 & 0x7fffffffu), stage);
-      if (i + 2 < n) e2 = sorted[a_ + i + 2];
-    }
-    fe_sub_lazy(e_, a, b);
-    fe_add(h, a, b);
-    fe_dbl_add(u, acc.Z, c);
-    fe_dbl_sub_lazy(v, acc.Z, c);
-    fe_mul(acc.Z, v, u);
-    fe_fence(acc.Z);
-#pragma unroll
-    for (int k = 0; k < 10; k++) {
-      f.v[k] = neg ? u.v[k] : v.v[k];
-      g_.v[k] = neg ? v.v[k] : u.v[k];
-    }
-    fe_mul(acc.X, f, e_);
-    fe_fence(acc.X);
-    fe_mul(acc.Y, g_, h);
-    fe_fence(acc.Y);
-    fe_mul(acc.T, e_, h);
-  }
   buckets[bkt] = acc;
 }
 

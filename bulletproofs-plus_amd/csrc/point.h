@@ -15,14 +15,6 @@ namespace bpp {
 
 #include "field_consts.inc"
 
-#if defined(BPP_SEQ_PRODUCTS)
-#define BPP_SEQ(x) fe_fence(x)
-#else
-#define BPP_SEQ(x) \
-  do {             \
-  } while (0)
-#endif
-
 BPP_HD void fe_const(fe &h, const uint32_t c[10]) {
 #pragma unroll
   for (int i = 0; i < 10; i++) h.v[i] = c[i];
@@ -106,33 +98,24 @@ BPP_HD void ge_madd(ge &r, const ge &p, const niels &q) {
 // y+x with y-x: free if done while loading the table entry) and q.xy2d is the entry's own: negating 2dxy negates c, which
 // only makes d - c and d + c trade places.  Branch-free: lanes of one wavefront mix additions and subtractions.
 BPP_HD void ge_madd_swapped(ge &r, const ge &p, const niels &q, bool neg) {
-  // One product at a time (BPP_SEQ fences): a v_mad_u64_u32 stream gains nothing from independent chains inside a
-  // wavefront -- one chain per wavefront already issues at the per-wavefront cadence (tools/microbench/mad_chains.hip) --
-  // while interleaved products cost ~25 live registers, i.e. a wavefront of occupancy.
   fe a, b, c, e, f, g, h, u, v;
   fe_add(a, p.Y, p.X);
   fe_mul(a, a, q.yplusx);
-  BPP_SEQ(a);
   fe_sub_lazy(b, p.Y, p.X);
   fe_mul(b, b, q.yminusx);
-  BPP_SEQ(b);
   fe_mul(c, q.xy2d, p.T);
-  BPP_SEQ(c);
   fe_sub_lazy(e, a, b);
   fe_add(h, a, b);
   fe_dbl_add(u, p.Z, c);       // loose
   fe_dbl_sub_lazy(v, p.Z, c);  // wide
   fe_mul(r.Z, v, u);  // g * f either way
-  BPP_SEQ(r.Z);
 #pragma unroll
   for (int i = 0; i < 10; i++) {  // (and / xor selects instead of these 20 v_cndmask_b32: measured, no difference)
     f.v[i] = neg ? u.v[i] : v.v[i];
     g.v[i] = neg ? v.v[i] : u.v[i];
   }
   fe_mul(r.X, f, e);
-  BPP_SEQ(r.X);
   fe_mul(r.Y, g, h);
-  BPP_SEQ(r.Y);
   fe_mul(r.T, e, h);
 }
 
