@@ -194,7 +194,6 @@ __global__ void __launch_bounds__(64, BPP_ACC_WAVES) k_msm_accumulate(const uint
     }
     ge_madd_swapped(acc, acc, q_cur, (e_cur >> 31) != 0);
   }
-#endif
   buckets[bkt] = acc;
 }
 
