@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per cpu_baseline leg")
     ap.add_argument("--wide-steps", type=int, default=40)
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) that fill roofline.traffic")
     return ap.parse_args()
 
 
@@ -120,6 +122,44 @@ def make_inputs(np, packed, params, count, seed, chunk=8192):
                                    min_present[lo:hi], None if seeds is None else seeds[lo:hi], LABEL, ext[lo:hi]))
     return {"proofs": np.concatenate(proofs), "commitments": commitments, "min_values": min_values, "min_present": min_present,
             "values": values, "blindings": blindings, "seeds": seeds, "ext": ext}
+
+
+def measure_traffic(kernel="k_msm_accumulate"):
+    """HBM-side bytes of one launch of the roofline kernel, measured NOW: two child runs of this script under rocprofv3
+    (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: the TCC block cannot hold both in one pass; kernel trace only, no other
+    trace domain), one step in flight so that the kernel's dispatches do not share the chip.  Children, not exec: this
+    process has initialised the GPU.  Returns None (traffic stays null) if the profiler is missing or a pass fails."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_summary
+        if not shutil.which("rocprofv3"):
+            return None
+        raw = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="bpp_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--no-extra", "--no-cpu-baseline", "--no-traffic", "--concurrency", "1", "--steps", "4",
+                   "--warmup", "1"]
+            r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None
+            kb, n, name = pmc_summary._per_launch(d, counter, kernel)
+            raw[counter] = (kb * 1024.0, n)
+            shutil.rmtree(d, ignore_errors=True)
+        # calibration of the two counters for this kernel's access patterns (tools/microbench/fetch_calib.hip on the same
+        # hardware, profiles/r02_v2_fetch_calib.json): FETCH_SIZE tallies a full 128-byte line request at 64 bytes (x0.500 for
+        # gathers of aligned 128-byte table entries, as for the documented wide-stream case), WRITE_SIZE reads x1.19 for
+        # scattered 160-byte stores
+        f, w = raw["FETCH_SIZE"][0], raw["WRITE_SIZE"][0]
+        return {"traffic": f / 0.5 + w / 1.19, "traffic_raw_counters": {"FETCH_SIZE_bytes": f, "WRITE_SIZE_bytes": w,
+                                                                       "dispatches": [raw["FETCH_SIZE"][1], raw["WRITE_SIZE"][1]]},
+                "traffic_method": "two rocprofv3 child passes of this command (--pmc FETCH_SIZE / --pmc WRITE_SIZE, kernel trace only, one "
+                                  "step in flight), per launch; corrected FETCH / 0.500 + WRITE / 1.19 (profiles/r02_v2_fetch_calib.json); "
+                                  "bytes leaving the XCD L2s, served by the 256 MB Infinity Cache"}
+    except (Exception, SystemExit):  # noqa: BLE001 - the headline number must not depend on the profiler
+        return None
 
 
 class Leg:
@@ -196,8 +236,8 @@ def kernel_roofline(profs, alone_ms=None):
     buckets = min(int(avg["msm_groups"]) * K * (1 << (int(avg["msm_window_bits"]) - 1)), terms * K)
     mads = (terms * K - buckets) * 700.0 + buckets * 100.0
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-           # HBM bytes per launch come from rocprofv3 PMC passes, which cannot run inside this process: see the file
-           "traffic": None, "traffic_profile": "profiles/r02_traffic.json (FETCH_SIZE / WRITE_SIZE passes of this command)",
+           # filled in by measure_traffic() (two rocprofv3 child passes) for the headline leg; else see the file
+           "traffic": None, "traffic_profile": "profiles/r02_v2_traffic.json (FETCH_SIZE / WRITE_SIZE passes of this command)",
            "kernel": "k_msm_accumulate (Pippenger bucket accumulation of the final MSM)", "kernel_ms": acc_ms,
            "algorithmic_bytes": msm_bytes, "msm_terms_per_launch": terms, "msm_window_bits": int(avg["msm_window_bits"]),
            "msm_windows": K, "msm_groups": int(avg["msm_groups"]),
@@ -291,6 +331,11 @@ def main():
         "host_threads": bpp.host_threads(), "nproc": os.cpu_count(), "usable_cpus": usable_cpus(),
     }
     if roof:
+        if rank == 0 and world == 1 and not use_dist and not args.no_traffic:
+            tr = measure_traffic()
+            if tr:
+                roof.update(tr)
+                roof.pop("traffic_profile", None)
         out["roofline"] = roof
         out["stages_ms"] = stages
     # bpp_batch_upload alone: host proof/statement buffers -> parsed, packed and resident (R batches of 1024); never `value`
