@@ -6,6 +6,7 @@
 #include "blake2b.h"
 #include "chain_host.h"
 #include "recode.h"
+#include "upload_host.h"
 using namespace bpp;
 extern "C" {
 void ht_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe x, y, z; fe_frombytes(x, a); fe_frombytes(y, b); fe_mul(z, x, y); fe_tobytes(out, z); }
@@ -38,6 +39,9 @@ int ht_madd_swapped(const uint8_t in[32], int neg, uint8_t out[32]) {
 int ht_from_niels_first(const uint8_t in[32], int neg, uint8_t out[32]) {
   niels n; if (!ristretto_decompress(n, in)) return 0;
   niels q; niels_load_swapped(q, &n, neg != 0); ge p; ge_from_niels_first(p, q); ge_madd(p, p, n); ristretto_compress(out, p); return 1; }
+// the engine's RangeProof::from_bytes (upload_host.h: what bpp_batch_upload applies to raw proof bytes): 0 + (t, rounds), or the ProofError code
+int ht_parse_proof(const uint8_t *p, size_t len, uint32_t *t, uint32_t *rounds) {
+  try { ParsedItem pi; parse_proof(p, len, pi); *t = pi.t; *rounds = pi.rounds; return 0; } catch (const ProofErr &e) { return e.code; } }
 // the device's decoding schedule (k_decompress) on the host: same verdict and point as the plain schedule
 int ht_decompress_lean(const uint8_t in[32], uint8_t out[32]) {
   niels n; if (!ristretto_decompress_lean(n, in)) return 0;

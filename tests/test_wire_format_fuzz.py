@@ -11,6 +11,17 @@ from tests.helpers import make_oracle_batch
 _BASE = make_oracle_batch(4, [1], 2, seed=b"fuzz").o_proofs[0].to_bytes()
 
 
+def _engine_parser():
+    import ctypes
+    pkg = importlib.import_module("bulletproofs-plus_amd")
+    lib = ctypes.CDLL(pkg._build.build_hosttest())
+    lib.ht_parse_proof.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    return lib
+
+
+_HT = _engine_parser()
+
+
 def _outcome(parse, data):
     try:
         return ("ok", parse(data).to_bytes())
@@ -32,3 +43,10 @@ def test_from_bytes_round_trip_and_parity(data):
     assert got == want
     if got[0] == "ok":
         assert got[1] == bytes(data)  # canonical: deserialise-then-serialise is the identity
+    # the engine's own parser (csrc/upload_host.h, applied to raw bytes at bpp_batch_upload) gives the same verdict
+    import ctypes
+    t, r = ctypes.c_uint32(), ctypes.c_uint32()
+    rc = _HT.ht_parse_proof(bytes(data), len(data), ctypes.byref(t), ctypes.byref(r))
+    assert (("ok", None) if rc == 0 else ("err", rc))[0] == want[0] and (rc == 0 or rc == want[1])
+    if rc == 0:
+        assert len(data) == 1 + 32 * (t.value + 5 + 2 * r.value)
