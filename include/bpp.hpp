@@ -101,6 +101,17 @@ class RangeParameters {
     p->t_ = static_cast<uint32_t>(pc.extension_degree);
     return p;
   }
+  // Arc::clone for another context of the same device (bpp_params_retain): the same device tables, usable from `eng`
+  // concurrently with every other holder (`Precomputation: Send + Sync`, src/traits.rs:42)
+  std::shared_ptr<RangeParameters> share(Engine &eng) const {
+    check(bpp_params_retain(eng.ctx(), handle_), bpp_ctx_last_error(eng.ctx()));
+    auto p = std::shared_ptr<RangeParameters>(new RangeParameters(eng));
+    p->handle_ = handle_;
+    p->n_ = n_;
+    p->m_ = m_;
+    p->t_ = t_;
+    return p;
+  }
   ~RangeParameters() {
     if (handle_) bpp_params_destroy(eng_.ctx(), handle_);
   }
