@@ -12,6 +12,14 @@
 
 namespace bpp {
 
+// the inner loops of the vector Keccak-f must be unrolled completely: rolled, a[] / b[] live in memory and are indexed
+// through the PI / ROT tables (1 800 64-byte loads and stores per permutation: 2 us per 8-way permutation instead of 0.2)
+#if defined(__clang__)
+#define BPP_UNROLL_FULL _Pragma("clang loop unroll(full)")
+#else
+#define BPP_UNROLL_FULL _Pragma("GCC unroll 32")
+#endif
+
 template <int W>
 struct VecOps {
   typedef uint64_t vec __attribute__((vector_size(8 * W)));
@@ -27,24 +35,104 @@ static inline __attribute__((always_inline)) void keccak_f1600_vec(typename VecO
       0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
       0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
       0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-  static const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-  static const int PI[25] = {0, 10, 20, 5, 15, 16, 1, 11, 21, 6, 7, 17, 2, 12, 22, 23, 8, 18, 3, 13, 14, 24, 9, 19, 4};
+  constexpr int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+  constexpr int PI[25] = {0, 10, 20, 5, 15, 16, 1, 11, 21, 6, 7, 17, 2, 12, 22, 23, 8, 18, 3, 13, 14, 24, 9, 19, 4};
 #define BPP_VROL(x, n) (((x) << (n)) | ((x) >> (64 - (n))))
   for (int rnd = 0; rnd < 24; rnd++) {
     V c[5], d[5], b[25];
+    BPP_UNROLL_FULL
     for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+    BPP_UNROLL_FULL
     for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ BPP_VROL(c[(x + 1) % 5], 1);
+    BPP_UNROLL_FULL
     for (int i = 0; i < 25; i++) {
       V t = a[i] ^ d[i % 5];
       b[PI[i]] = ROT[i] ? BPP_VROL(t, ROT[i]) : t;
     }
-    for (int y = 0; y < 25; y += 5)
+    BPP_UNROLL_FULL
+    for (int y = 0; y < 25; y += 5) {
+      BPP_UNROLL_FULL
       for (int x = 0; x < 5; x++) a[y + x] = b[y + x] ^ (~b[y + (x + 1) % 5] & b[y + (x + 2) % 5]);
+    }
     V rc;
+    BPP_UNROLL_FULL
     for (int w = 0; w < W; w++) rc[w] = RC[rnd];
     a[0] ^= rc;
   }
 #undef BPP_VROL
+}
+
+// ---- Scalar::from_bytes_mod_order_wide on the HOST: 64 little-endian bytes -> canonical 32 bytes of (value mod l).
+// The device form (scalar.h: 29-bit limbs, 64-bit columns) is shaped for v_mad_u64_u32; compiled for x86-64 it costs ~400 ns
+// per weight and was two thirds of a lock-step bundle's time.  Here: w = lo + hi 2^256 with two Montgomery products on
+// four 64-bit limbs (R = 2^256, unsigned __int128): montmul(lo, R mod l) = lo mod l, montmul(hi, R^2 mod l) = hi 2^256 mod l.
+struct HostScalar64 {
+  static constexpr uint64_t L[4] = {0x5812631a5cf5d3edULL, 0x14def9dea2f79cd6ULL, 0x0ULL, 0x1000000000000000ULL};
+  static constexpr uint64_t R1[4] = {0xd6ec31748d98951dULL, 0xc6ef5bf4737dcf70ULL, 0xfffffffffffffffeULL, 0x0fffffffffffffffULL};
+  static constexpr uint64_t R2[4] = {0xa40611e3449c0f01ULL, 0xd00e1ba768859347ULL, 0xceec73d217f5be65ULL, 0x0399411b7c309a3dULL};
+  static constexpr uint64_t N0 = 0xd2b51da312547e1bULL;  // -l^-1 mod 2^64
+};
+// r = a b 2^-256 mod l, fully reduced; a any 256-bit value, b < l  (CIOS, four limbs)
+static inline void host_montmul64(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+  typedef unsigned __int128 u128;
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)a[j] * b[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * HostScalar64::N0;
+    c = (u128)m * HostScalar64::L[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; j++) {
+      c += (u128)m * HostScalar64::L[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  // t < 2l: one conditional subtraction
+  uint64_t d[4];
+  unsigned __int128 br = 0;
+  for (int j = 0; j < 4; j++) {
+    const unsigned __int128 x = (unsigned __int128)t[j] - HostScalar64::L[j] - (uint64_t)br;
+    d[j] = (uint64_t)x;
+    br = (x >> 64) & 1;
+  }
+  const bool take = t[4] != 0 || br == 0;
+  for (int j = 0; j < 4; j++) r[j] = take ? d[j] : t[j];
+}
+static inline void host_wide_reduce(uint8_t out32[32], const uint8_t wide64[64]) {
+  uint64_t lo[4], hi[4], a[4], b[4];
+  memcpy(lo, wide64, 32);  // little-endian host
+  memcpy(hi, wide64 + 32, 32);
+  host_montmul64(a, lo, HostScalar64::R1);
+  host_montmul64(b, hi, HostScalar64::R2);
+  // a + b mod l (both < l)
+  typedef unsigned __int128 u128;
+  uint64_t s4[4], d[4];
+  u128 c = 0;
+  for (int j = 0; j < 4; j++) {
+    c += (u128)a[j] + b[j];
+    s4[j] = (uint64_t)c;
+    c >>= 64;
+  }
+  u128 br = 0;
+  for (int j = 0; j < 4; j++) {
+    const u128 x = (u128)s4[j] - HostScalar64::L[j] - (uint64_t)br;
+    d[j] = (uint64_t)x;
+    br = (x >> 64) & 1;
+  }
+  const bool take = (uint64_t)c != 0 || br == 0;
+  for (int j = 0; j < 4; j++) s4[j] = take ? d[j] : s4[j];
+  memcpy(out32, s4, 32);
 }
 
 // W lane-transposed STROBE-128 states with shared position bookkeeping
@@ -70,20 +158,48 @@ static inline __attribute__((always_inline)) void ms_run_f(MultiStrobe<W> &s) {
   s.pos = 0;
   s.pos_begin = 0;
 }
+// XOR up to 8 bytes per chain (little-endian words in c, `nb` of them significant, the rest zero) into the state at byte
+// position pos; the caller guarantees pos + nb <= R.  One or two vector XORs instead of nb x W byte operations.
+template <int W>
+static inline __attribute__((always_inline)) void ms_xor_word(MultiStrobe<W> &s, typename VecOps<W>::vec c, uint32_t pos) {
+  const uint32_t q = pos >> 3, sh = 8 * (pos & 7);
+  s.st[q] ^= c << sh;
+  if (sh) s.st[q + 1] ^= c >> (64 - sh);  // st has 25 words, R + 8 <= 200: q + 1 <= 21
+}
+static inline uint64_t ms_load_le(const uint8_t *p, uint32_t nb) {
+  uint64_t v = 0;
+  memcpy(&v, p, nb);  // little-endian host
+  return v;
+}
 // absorb the same-length message of every chain (data[w] + off)
 template <int W>
 static inline __attribute__((always_inline)) void ms_absorb(MultiStrobe<W> &s, const uint8_t *const data[W], size_t off, uint32_t n) {
-  for (uint32_t i = 0; i < n; i++) {
-    for (int w = 0; w < W; w++) ms_xor_byte(s, s.pos, w, data[w][off + i]);
-    s.pos++;
+  typedef typename VecOps<W>::vec V;
+  uint32_t i = 0;
+  while (i < n) {
+    const uint32_t room = BPP_STROBE_R - s.pos, nb = (n - i < 8u ? n - i : 8u) < room ? (n - i < 8u ? n - i : 8u) : room;
+    V c;
+    for (int w = 0; w < W; w++) c[w] = ms_load_le(data[w] + off + i, nb);
+    ms_xor_word<W>(s, c, s.pos);
+    s.pos += nb;
+    i += nb;
     if (s.pos == BPP_STROBE_R) ms_run_f(s);
   }
 }
 template <int W>
 static inline __attribute__((always_inline)) void ms_absorb_same(MultiStrobe<W> &s, const uint8_t *d, uint32_t n) {
-  const uint8_t *rep[W];
-  for (int w = 0; w < W; w++) rep[w] = d;
-  ms_absorb<W>(s, rep, 0, n);
+  typedef typename VecOps<W>::vec V;
+  uint32_t i = 0;
+  while (i < n) {
+    const uint32_t room = BPP_STROBE_R - s.pos, nb = (n - i < 8u ? n - i : 8u) < room ? (n - i < 8u ? n - i : 8u) : room;
+    const uint64_t v = ms_load_le(d + i, nb);
+    V c;
+    for (int w = 0; w < W; w++) c[w] = v;
+    ms_xor_word<W>(s, c, s.pos);
+    s.pos += nb;
+    i += nb;
+    if (s.pos == BPP_STROBE_R) ms_run_f(s);
+  }
 }
 template <int W>
 static inline __attribute__((always_inline)) void ms_begin_op(MultiStrobe<W> &s, uint32_t flags, bool more) {
@@ -94,15 +210,31 @@ static inline __attribute__((always_inline)) void ms_begin_op(MultiStrobe<W> &s,
   ms_absorb_same<W>(s, hdr, 2);
   if ((flags & (BPP_FLAG_C | BPP_FLAG_K)) && s.pos != 0) ms_run_f(s);
 }
+// PRF output: copy n state bytes out per chain and zero them in the state (STROBE's squeeze), 8 bytes at a time
 template <int W>
 static inline __attribute__((always_inline)) void ms_squeeze(MultiStrobe<W> &s, uint8_t *const out[W], uint32_t n) {
-  for (uint32_t i = 0; i < n; i++) {
-    const uint32_t sh = 8 * (s.pos & 7);
+  typedef typename VecOps<W>::vec V;
+  uint32_t i = 0;
+  while (i < n) {
+    const uint32_t room = BPP_STROBE_R - s.pos, nb = (n - i < 8u ? n - i : 8u) < room ? (n - i < 8u ? n - i : 8u) : room;
+    const uint32_t q = s.pos >> 3, sh = 8 * (s.pos & 7);
+    const uint64_t mask = nb == 8 ? ~0ULL : ((1ULL << (8 * nb)) - 1ULL);
+    V v = s.st[q] >> sh;
+    if (sh) v |= s.st[q + 1] << (64 - sh);
     for (int w = 0; w < W; w++) {
-      out[w][i] = (uint8_t)(s.st[s.pos >> 3][w] >> sh);
-      s.st[s.pos >> 3][w] &= ~(0xffULL << sh);
+      const uint64_t x = v[w] & mask;
+      memcpy(out[w] + i, &x, nb);
     }
-    s.pos++;
+    // zero the bytes just read
+    V m0, m1;
+    for (int w = 0; w < W; w++) {
+      m0[w] = ~(mask << sh);
+      m1[w] = sh ? ~(mask >> (64 - sh)) : ~0ULL;
+    }
+    s.st[q] &= m0;
+    if (sh) s.st[q + 1] &= m1;
+    s.pos += nb;
+    i += nb;
     if (s.pos == BPP_STROBE_R) ms_run_f(s);
   }
 }
@@ -133,11 +265,11 @@ static inline __attribute__((always_inline)) void weights_chain_multi_impl(const
   ms_begin_op<W>(s, BPP_FLAG_M | BPP_FLAG_A, false);
   ms_absorb_same<W>(s, (const uint8_t *)"rng", 3);
   ms_begin_op<W>(s, BPP_FLAG_A | BPP_FLAG_C, false);
-  for (uint32_t i = 0; i < 32; i++) {  // overwrite with zeros
-    const uint32_t sh = 8 * (s.pos & 7);
-    for (int w = 0; w < W; w++) s.st[s.pos >> 3][w] &= ~(0xffULL << sh);
-    s.pos++;
-    if (s.pos == BPP_STROBE_R) ms_run_f(s);
+  {  // key(32 zero bytes): overwrite with zeros = squeeze and discard
+    uint8_t sink[W][32];
+    uint8_t *sp[W];
+    for (int w = 0; w < W; w++) sp[w] = sink[w];
+    ms_squeeze<W>(s, sp, 32);
   }
   uint8_t wide[W][64];
   uint8_t *wp[W];
@@ -148,13 +280,8 @@ static inline __attribute__((always_inline)) void weights_chain_multi_impl(const
     ms_absorb_same<W>(s, len4, 4);
     ms_begin_op<W>(s, BPP_FLAG_I | BPP_FLAG_A | BPP_FLAG_C, false);
     ms_squeeze<W>(s, wp, 64);
-    for (int w = 0; w < W; w++) {
-      sc v;
-      sc_mont_from_wide(v, wide[w]);
-      // random_not_zero: a zero draw (probability 2^-252) would desynchronise the lockstep; flagged to the caller
-      sc_from_mont(v, v);
-      sc_store_words(out[w] + 32 * i, v);
-    }
+    // random_not_zero: a zero draw (probability 2^-252) would desynchronise the lockstep; flagged to the caller
+    for (int w = 0; w < W; w++) host_wide_reduce(out[w] + 32 * i, wide[w]);
   }
 }
 

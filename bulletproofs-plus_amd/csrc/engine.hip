@@ -164,14 +164,12 @@ void weights_from_chain_host(const uint8_t *rng32, size_t n, uint8_t *weights32)
   uint8_t zero32[32] = {0};
   merlin_rng_finalize(wt, zero32);  // build_rng().finalize(&mut NullRng)
   for (size_t i = 0; i < n; i++) {
-    sc w;
+    uint8_t *w = weights32 + 32 * i;
     do {  // Scalar::random_not_zero (src/protocols/scalar_protocol.rs:23-30)
       uint8_t wide[64];
       merlin_rng_fill(wt, wide, 64);
-      sc_mont_from_wide(w, wide);
-    } while (sc_iszero(w));
-    sc_from_mont(w, w);
-    sc_store_words(weights32 + 32 * i, w);
+      host_wide_reduce(w, wide);
+    } while (weight_is_zero(w));
   }
 }
 

@@ -19,6 +19,7 @@ void ht_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {
 void ht_sc_addsub(const uint8_t a[32], const uint8_t b[32], uint8_t sum[32], uint8_t dif[32]) {
   sc x, y, z; sc_load_words(x, a); sc_load_words(y, b); sc_add(z, x, y); sc_store_words(sum, z); sc_sub(z, x, y); sc_store_words(dif, z); }
 void ht_sc_wide(const uint8_t a[64], uint8_t out[32]) { sc z; sc_mont_from_wide(z, a); sc_from_mont(z, z); sc_store_words(out, z); }
+void ht_host_wide(const uint8_t a[64], uint8_t out[32]) { host_wide_reduce(out, a); }  // the host weight chains' 64-bit form
 void ht_sc_invert(const uint8_t a[32], uint8_t out[32]) { sc x; sc_load_words(x, a); sc_to_mont(x, x); sc_mont_invert(x, x); sc_from_mont(x, x); sc_store_words(out, x); }
 void ht_sc_invert_vartime(const uint8_t a[32], uint8_t out[32]) { sc x; sc_load_words(x, a); sc_to_mont(x, x); sc_mont_invert_vartime(x, x); sc_from_mont(x, x); sc_store_words(out, x); }
 void ht_sc_invert_plain(const uint8_t a[32], int which, uint8_t out[32]) { sc x, y; sc_load_words(x, a); if (which) sc_invert_vartime_plain(y, x); else sc_invert_xgcd_plain(y, x); sc_store_words(out, y); }

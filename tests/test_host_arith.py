@@ -64,10 +64,14 @@ def test_scalar(ht):
         o = _buf()
         ht.ht_sc_invert((a % L).to_bytes(32, "little"), o)
         assert int.from_bytes(o.raw, "little") == pow(a % L, L - 2, L)
-    for w in [_r(b"w", i, 64) for i in range(50)] + [b"\xff" * 64, bytes(64), L.to_bytes(64, "little"),
-                                                      (L * L - 1).to_bytes(64, "little")]:
+    for w in [_r(b"w", i, 64) for i in range(300)] + [b"\xff" * 64, bytes(64), L.to_bytes(64, "little"),
+                                                       (L * L - 1).to_bytes(64, "little"), (L - 1).to_bytes(64, "little"),
+                                                       ((L << 256) - 1).to_bytes(64, "little"), (2**256 - 1).to_bytes(64, "little"),
+                                                       ((2**256 - 1) << 256).to_bytes(64, "little")]:
         o = _buf()
         ht.ht_sc_wide(w, o)
+        assert int.from_bytes(o.raw, "little") == int.from_bytes(w, "little") % L
+        ht.ht_host_wide(w, o)  # the host weight chains' four-limb form
         assert int.from_bytes(o.raw, "little") == int.from_bytes(w, "little") % L
 
 
