@@ -136,6 +136,9 @@ def measure_traffic(kernel="k_msm_accumulate"):
         import pmc_summary
         if not shutil.which("rocprofv3"):
             return None
+        # already running under a profiler (the driver's, or tools/profile_round.sh): no nested profiler runs
+        if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+            return None
         raw = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="bpp_pmc_", dir="/tmp")

@@ -36,7 +36,10 @@ __device__ __forceinline__ bool dev_challenge(Strobe &s, const uint8_t *label, u
 // PASS 1 of RangeProof::verify (src/range_proof.rs:816-850), one lane per proof.
 // RangeProofTranscript::new / challenges_y_z / challenge_round_e / challenge_final_e / to_verifier_rng
 // (src/transcripts.rs:59-179); the intermediate build_rng() clones are dead for a verifier and skipped.
-__global__ void __launch_bounds__(64) k_transcripts(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
+#ifndef BPP_TRANSCRIPTS_WAVES
+#define BPP_TRANSCRIPTS_WAVES 5  // 96 VGPRs: a PASS-1 wavefront (latency-bound, resident for a long time) then fits next to three k_msm_accumulate wavefronts on a SIMD
+#endif
+__global__ void __launch_bounds__(64, BPP_TRANSCRIPTS_WAVES) k_transcripts(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
                                                     const uint64_t *__restrict__ minvals,
                                                     const uint8_t *__restrict__ states, const uint8_t *__restrict__ hg32,
                                                     uint32_t n_bits, uint32_t t, uint32_t B, uint32_t cs,

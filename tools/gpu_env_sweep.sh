@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 i=0
 for ENVS in "$@"; do
   i=$((i+1))
-  env $ENVS python3 bench.py --no-extra --no-cpu-baseline > gpurun_out/${TAG}_e${i}.json 2> gpurun_out/${TAG}_e${i}.err
+  env $ENVS python3 bench.py --no-extra --no-cpu-baseline --no-traffic > gpurun_out/${TAG}_e${i}.json 2> gpurun_out/${TAG}_e${i}.err
   python3 - <<PY
 import json
 d = json.loads(open("gpurun_out/${TAG}_e${i}.json").read().strip().split("\n")[-1])

@@ -9,7 +9,7 @@ for FLAGS in "$@"; do
   i=$((i+1))
   echo "== variant $i: '$FLAGS'"
   BPP_HIPCC_FLAGS="$FLAGS" python3 -c "import importlib; p=importlib.import_module('bulletproofs-plus_amd'); p._build.build(force=True)"
-  python3 bench.py --no-extra --no-cpu-baseline > gpurun_out/${TAG}_v${i}.json 2> gpurun_out/${TAG}_v${i}.err
+  python3 bench.py --no-extra --no-cpu-baseline --no-traffic > gpurun_out/${TAG}_v${i}.json 2> gpurun_out/${TAG}_v${i}.err
   python3 - <<PY
 import json
 d = json.loads(open("gpurun_out/${TAG}_v${i}.json").read().strip().split("\n")[-1])

@@ -12,14 +12,14 @@ mkdir -p $O
 export TMPDIR=/tmp
 P=$O/prof_$TAG
 rm -rf $P
-rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 bench.py --no-extra --no-cpu-baseline > $O/${TAG}_bench_profiled_run.json 2> $O/${TAG}_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 bench.py --no-extra --no-cpu-baseline --no-traffic > $O/${TAG}_bench_profiled_run.json 2> $O/${TAG}_trace.err
 python3 tools/pmc_summary.py stats $P/trace $O/${TAG}_kernel_stats_cfg2_default.csv
 echo "trace done"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d $P/sq -- python3 bench.py --no-extra --no-cpu-baseline --concurrency 1 --steps 6 --warmup 2 > $O/${TAG}_sq_run.json 2> $O/${TAG}_sq.err
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d $P/sq -- python3 bench.py --no-extra --no-cpu-baseline --no-traffic --concurrency 1 --steps 6 --warmup 2 > $O/${TAG}_sq_run.json 2> $O/${TAG}_sq.err
 python3 tools/pmc_summary.py counters $P/sq $O/${TAG}_pmc_sq_summary.csv
 echo "sq done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/fetch -- python3 bench.py --no-extra --no-cpu-baseline --concurrency 1 --steps 8 --warmup 2 > /dev/null 2> $O/${TAG}_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/write -- python3 bench.py --no-extra --no-cpu-baseline --concurrency 1 --steps 8 --warmup 2 > /dev/null 2> $O/${TAG}_write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/fetch -- python3 bench.py --no-extra --no-cpu-baseline --no-traffic --concurrency 1 --steps 8 --warmup 2 > /dev/null 2> $O/${TAG}_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/write -- python3 bench.py --no-extra --no-cpu-baseline --no-traffic --concurrency 1 --steps 8 --warmup 2 > /dev/null 2> $O/${TAG}_write.err
 echo "traffic passes done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/cfetch -- tools/microbench/fetch_calib > $O/${TAG}_fetch_calib_true.txt 2> $O/${TAG}_cfetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/cwrite -- tools/microbench/fetch_calib > /dev/null 2> $O/${TAG}_cwrite.err
