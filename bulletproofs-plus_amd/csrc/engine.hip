@@ -1107,7 +1107,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
     const uint32_t tab_max = (1u << std::min<uint32_t>(rm, BPP_LANES_LB)) + nhi_max + std::min<uint32_t>(m_max, 32);
     const uint32_t ppw = std::max<uint32_t>(1, std::min<uint32_t>(4, 64 / tab_max));
     const uint32_t ndyn_max = m_max + 3 + 2 * rm;
-    hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * (BPP_LANES_FIXED + 3 * nhi_max) * sizeof(sc), s,
+    hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s,
                        b.d_desc.p, b.shr.p, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, tab_max, ndyn_max, b.rows.p,
                        b.dyn_unw.p);
     tm.mark(M_SCALARS);

@@ -407,14 +407,21 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
 
 // Generator scalars without the weight.  With i = (hi << LB) | lo, s[i] = slo[lo]*shi[hi] and y^-i = ylo[lo]*yhi[hi]
 // (products over the bits of i), so every per-index quantity is ONE product of a "low" and a "high" table entry:
-//   g[i]      = r1e * y^-i * s[i]              = glo[lo]  * ghi[hi]      glo = r1e*ylo*slo,  ghi = yhi*shi
-//   y^(mn-i)  = y^mn * y^-i                    = ynlo[lo] * yhi[hi]      ynlo = y^mn*ylo
-//   h[i]      = s1e * s[mn-1-i]                = hlo[~lo] * shi[~hi]     hlo = s1e*slo
-// Dynamic LDS (sized by the batch's largest round count so small proofs keep full occupancy):
-//   glo[8] ynlo[8] hlo[8] | cz[32] zp[32] | ghi[nhi] yhi[nhi] shi[nhi]        (sc = 32 B each)
-// cz[party] = to_mont(e^2 * z^(2(party+1))): times the PLAIN integer 2^k it gives e^2 * d[i] in Montgomery form.
+//   g[i]            = r1e * y^-i * s[i]        = glo[lo]   * ghi[hi]      glo = r1e*ylo*slo,  ghi = yhi*shi
+//   2^k * y^(mn-i)  = y^mn * y^-i * 2^k        = yn2lo[lo] * y2hi[hi]     k = i mod n (the 2^k of d[i] = z^(2(j+1)) 2^k,
+//                                                                         src/range_proof.rs:919-929, split over the two tables:
+//                                                                         k = klo(lo) + khi(hi); x 2^e = one product with the
+//                                                                         constant 2^e R mod l, SC_POW2_R29)
+//   h[i]            = s1e * s[mn-1-i]          = hlo[~lo]  * shi[~hi]     hlo = s1e*slo
+// so a generator pair costs FOUR Montgomery products: g[i], 2^k y^(mn-i), c2[party] * that (c2 = e^2 z^(2(party+1))),
+// h[i].  The tables live in LDS as nine 29-bit limbs (sc9: unpacked once per entry instead of once per use) and the
+// middle product stays in limbs.  Dynamic LDS per proof (sized by the batch's largest round count so small proofs keep
+// full occupancy):   sc9: glo[8] yn2lo[8] hlo[8] | c2[32] | ghi[nhi] y2hi[nhi] shi[nhi]      sc: zp[32] (z^(2(party+1)))
 #define BPP_LANES_LB 3
-#define BPP_LANES_FIXED (3 * 8 + 64)
+#define BPP_LANES_FIXED9 (3 * 8 + 32)
+BPP_HD constexpr uint32_t lanes_lds_bytes(uint32_t nhi_max) {
+  return (BPP_LANES_FIXED9 + 3u * nhi_max) * (uint32_t)sizeof(sc9) + 32u * (uint32_t)sizeof(sc);
+}
 
 // One workgroup serves `ppw` consecutive proofs: a 64-bit single-commitment proof only has 8 + 8 + 1 table entries and
 // 64 generator pairs, so one proof per wavefront leaves three quarters of the lanes idle in the table phase.  All
@@ -426,9 +433,10 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
                                                       sc *__restrict__ rows, sc *__restrict__ dyn_unw) {
   const uint32_t p0 = blockIdx.x * ppw;
   const uint32_t lane = threadIdx.x;
-  extern __shared__ sc lanes_lds[];
+  extern __shared__ uint32_t lanes_lds_raw[];
   __shared__ uint32_t s_r[BPP_LANES_MAX_PPW], s_m[BPP_LANES_MAX_PPW], s_dyn[BPP_LANES_MAX_PPW];
-  const uint32_t per = BPP_LANES_FIXED + 3 * nhi_max;  // LDS entries per proof
+  const uint32_t per_bytes = lanes_lds_bytes(nhi_max);  // LDS bytes per proof
+  const uint32_t n9 = BPP_LANES_FIXED9 + 3u * nhi_max;  // sc9 entries per proof
   if (lane < ppw) {
     const uint32_t p = p0 + lane;
     uint32_t r = ~0u, m = 0, dyn_off = 0;
@@ -455,9 +463,11 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     const uint32_t nlo = 1u << LB, nhi = 1u << HB;
     if (idx >= nlo + nhi + m) continue;
     const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
-    sc *T = lanes_lds + (size_t)sub * per;
-    sc *glo = T, *ynlo = T + 8, *hlo = T + 16, *cz = T + 24, *zp = T + 56;
-    sc *ghi = T + BPP_LANES_FIXED, *yhi = ghi + nhi_max, *shi = yhi + nhi_max;
+    uint8_t *base = reinterpret_cast<uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes;
+    sc9 *T = reinterpret_cast<sc9 *>(base);
+    sc9 *glo = T, *yn2lo = T + 8, *hlo = T + 16, *c2t = T + 24;
+    sc9 *ghi = T + BPP_LANES_FIXED9, *y2hi = ghi + nhi_max, *shi = y2hi + nhi_max;
+    sc *zp = reinterpret_cast<sc *>(base + (size_t)n9 * sizeof(sc9));
     if (idx < nlo + nhi) {
       const bool is_hi = idx >= nlo;
       const uint32_t v = is_hi ? idx - nlo : idx, b0 = is_hi ? LB : 0, nbits = is_hi ? HB : LB;
@@ -472,33 +482,48 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
           sc_montmul(yv, yv, yp);
         }
       }
+      // this entry's share of k = i mod n_bits (i = (hi << LB) | lo; n_bits and nlo are powers of two)
+      const uint32_t e2k = nlo >= n_bits ? (is_hi ? 0u : (v & (n_bits - 1u))) : (is_hi ? nlo * (v & (n_bits / nlo - 1u)) : v);
+      sc9 p2;
+#pragma unroll
+      for (int q = 0; q < 9; q++) p2.l[q] = SC_POW2_R29[e2k & 63u][q];
       if (is_hi) {
         sc gv;
+        sc9 y9, o9;
         sc_montmul(gv, yv, sv);
-        ghi[v] = gv;
-        yhi[v] = yv;
-        shi[v] = sv;
+        sc9_from(o9, gv);
+        ghi[v] = o9;
+        sc9_from(y9, yv);
+        sc9_montmul_lazy(o9, y9, p2);
+        y2hi[v] = o9;
+        sc9_from(o9, sv);
+        shi[v] = o9;
       } else {
         sc gv, yn, hv;
+        sc9 y9, o9;
         const sc r1_e = S[SH_R1E], s1_e = S[SH_S1E], y_nm = S[SH_YNM];
         sc_montmul(gv, yv, sv);
         sc_montmul(gv, gv, r1_e);
         sc_montmul(yn, yv, y_nm);
         sc_montmul(hv, sv, s1_e);
-        glo[v] = gv;
-        ynlo[v] = yn;
-        hlo[v] = hv;
+        sc9_from(o9, gv);
+        glo[v] = o9;
+        sc9_from(y9, yn);
+        sc9_montmul_lazy(o9, y9, p2);
+        yn2lo[v] = o9;
+        sc9_from(o9, hv);
+        hlo[v] = o9;
       }
     } else {
       const uint32_t party = idx - (nlo + nhi);
       const sc z_square = S[SH_Z2], e_square = S[SH_E2];
-      sc zz, c2, r2;
+      sc zz, c2;
+      sc9 o9;
       sc_mont_pow_u32(zz, z_square, party + 1);
       sc_montmul(c2, zz, e_square);
-      sc_const(r2, SC_R2);
-      sc_montmul(c2, c2, r2);
       zp[party] = zz;
-      cz[party] = c2;
+      sc9_from(o9, c2);
+      c2t[party] = o9;
     }
   }
   __syncthreads();
@@ -511,26 +536,24 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, HB = r - LB;
     const uint32_t nlo = 1u << LB, nhi = 1u << HB;
     const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
-    const sc *T = lanes_lds + (size_t)sub * per;
-    const sc *glo = T, *ynlo = T + 8, *hlo = T + 16, *cz = T + 24;
-    const sc *ghi = T + BPP_LANES_FIXED, *yhi = ghi + nhi_max, *shi = yhi + nhi_max;
+    const sc9 *T = reinterpret_cast<const sc9 *>(reinterpret_cast<const uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes);
+    const sc9 *glo = T, *yn2lo = T + 8, *hlo = T + 16, *c2t = T + 24;
+    const sc9 *ghi = T + BPP_LANES_FIXED9, *y2hi = ghi + nhi_max, *shi = y2hi + nhi_max;
     sc *row = rows + (size_t)(p0 + sub) * cols;
     sc gi, hi;
     if (i < mn) {
       const sc e_square_z = S[SH_E2Z];
       const uint32_t lo = i & (nlo - 1), hi_i = i >> LB;
       const uint32_t rlo = (~lo) & (nlo - 1), rhi = (~hi_i) & (nhi - 1);
-      sc y_nm_i, u, two_k;
-      sc_montmul(gi, glo[lo], ghi[hi_i]);
+      const uint32_t party = i / n_bits;  // d[i] = z^{2(party+1)} * 2^k, k = i % n_bits  (:919-929)
+      sc u;
+      sc9 t9;
+      sc9_montmul(gi, glo[lo], ghi[hi_i]);
       sc_add(gi, gi, e_square_z);
-      sc_montmul(y_nm_i, ynlo[lo], yhi[hi_i]);  // y^{mn-i}
-      const uint32_t party = i / n_bits, k = i % n_bits;  // d[i] = z^{2(party+1)} * 2^k  (:919-929)
-      sc_0(two_k);
-      two_k.v[k >> 5] = 1u << (k & 31);
-      sc_montmul(u, cz[party], two_k);  // e^2 * d[i]
-      sc_montmul(u, u, y_nm_i);
-      sc_add(u, u, e_square_z);  // e^2 (d[i] y^{mn-i} + z)
-      sc_montmul(hi, hlo[rlo], shi[rhi]);
+      sc9_montmul_lazy(t9, yn2lo[lo], y2hi[hi_i]);  // 2^k y^{mn-i}, left in limbs
+      sc9_montmul(u, c2t[party], t9);               // e^2 d[i] y^{mn-i}
+      sc_add(u, u, e_square_z);                     // e^2 (d[i] y^{mn-i} + z)
+      sc9_montmul(hi, hlo[rlo], shi[rhi]);
       sc_sub(hi, hi, u);
     } else {
       sc_0(gi);
@@ -547,7 +570,7 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     const uint32_t r = s_r[sub], m = s_m[sub];
     if (r == ~0u || q >= m + 3 + 2 * r) continue;
     const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
-    const sc *zp = lanes_lds + (size_t)sub * per + 56;
+    const sc *zp = reinterpret_cast<const sc *>(reinterpret_cast<const uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes + (size_t)n9 * sizeof(sc9));
     sc a, bq;
     if (q < m) {
       a = S[SH_NEG_E2_YNM1];

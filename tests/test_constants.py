@@ -30,6 +30,9 @@ def test_generated_constants_are_current(tmp_path):
     assert sum(v << (29 * i) for i, v in enumerate(l29)) == g.L and l29[5:8] == [0, 0, 0] and l29[8] == 1 << 20
     linv = int(re.search(r"BPP_LINV29 0x([0-9a-f]+)u", scl).group(1), 16)
     assert (linv * g.L + 1) % 2**29 == 0
+    pw = re.search(r"SC_POW2_R29\[64\]\[9\] = \{(.*?)\};", scl, re.S).group(1)
+    rows = [[int(x.strip().rstrip("u"), 16) for x in r.split(",")] for r in re.findall(r"\{([^{}]*)\}", pw)]
+    assert len(rows) == 64 and all(sum(v << (29 * i) for i, v in enumerate(r)) == (1 << e) * pow(2, 261, g.L) % g.L for e, r in enumerate(rows))
     l30 = [int(x.strip(), 16) for x in re.search(r"SC_L30\[9\] = \{([^}]*)\}", scl).group(1).split(",")]
     assert sum(v << (30 * i) for i, v in enumerate(l30)) == g.L
     linv30 = int(re.search(r"BPP_LINV30 0x([0-9a-f]+)u", scl).group(1), 16)

@@ -60,6 +60,13 @@ def test_scalar(ht):
                 s, d = _buf(), _buf()
                 ht.ht_sc_addsub(ab, b.to_bytes(32, "little"), s, d)
                 assert int.from_bytes(s.raw, "little") == (a + b) % L and int.from_bytes(d.raw, "little") == (a - b) % L
+        for k, b in enumerate(vals[:3] + EDGE_SC[:4]):  # unpacked (nine-limb) products: (a b) c with a lazy middle, a 2^e
+            c = vals[(k * 7 + 3) % len(vals)]
+            o, o2 = _buf(), _buf()
+            e = (a + 5 * k) % 64
+            ht.ht_sc9_mul3(ab, b.to_bytes(32, "little"), c.to_bytes(32, "little"), e, o, o2)
+            assert int.from_bytes(o.raw, "little") == a * b * c % L
+            assert int.from_bytes(o2.raw, "little") == a * (1 << e) % L
         assert ht.ht_sc_canonical(ab) == (1 if a < L else 0)
         o = _buf()
         ht.ht_sc_invert((a % L).to_bytes(32, "little"), o)
