@@ -152,14 +152,14 @@ def measure_traffic(kernel="k_msm_accumulate"):
             raw[counter] = (kb * 1024.0, n)
             shutil.rmtree(d, ignore_errors=True)
         # calibration of the two counters for this kernel's access patterns (tools/microbench/fetch_calib.hip on the same
-        # hardware, profiles/r02_v2_fetch_calib.json): FETCH_SIZE tallies a full 128-byte line request at 64 bytes (x0.500 for
+        # hardware, profiles/r02_v4_fetch_calib.json): FETCH_SIZE tallies a full 128-byte line request at 64 bytes (x0.500 for
         # gathers of aligned 128-byte table entries, as for the documented wide-stream case), WRITE_SIZE reads x1.19 for
         # scattered 160-byte stores
         f, w = raw["FETCH_SIZE"][0], raw["WRITE_SIZE"][0]
         return {"traffic": f / 0.5 + w / 1.19, "traffic_raw_counters": {"FETCH_SIZE_bytes": f, "WRITE_SIZE_bytes": w,
                                                                        "dispatches": [raw["FETCH_SIZE"][1], raw["WRITE_SIZE"][1]]},
                 "traffic_method": "two rocprofv3 child passes of this command (--pmc FETCH_SIZE / --pmc WRITE_SIZE, kernel trace only, one "
-                                  "step in flight), per launch; corrected FETCH / 0.500 + WRITE / 1.19 (profiles/r02_v2_fetch_calib.json); "
+                                  "step in flight), per launch; corrected FETCH / 0.500 + WRITE / 1.19 (profiles/r02_v4_fetch_calib.json); "
                                   "bytes leaving the XCD L2s, served by the 256 MB Infinity Cache"}
     except (Exception, SystemExit):  # noqa: BLE001 - the headline number must not depend on the profiler
         return None
@@ -240,7 +240,7 @@ def kernel_roofline(profs, alone_ms=None):
     mads = (terms * K - buckets) * 700.0 + buckets * 100.0
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
            # filled in by measure_traffic() (two rocprofv3 child passes) for the headline leg; else see the file
-           "traffic": None, "traffic_profile": "profiles/r02_v2_traffic.json (FETCH_SIZE / WRITE_SIZE passes of this command)",
+           "traffic": None, "traffic_profile": "profiles/r02_v4_traffic.json (FETCH_SIZE / WRITE_SIZE passes of this command)",
            "kernel": "k_msm_accumulate (Pippenger bucket accumulation of the final MSM)", "kernel_ms": acc_ms,
            "algorithmic_bytes": msm_bytes, "msm_terms_per_launch": terms, "msm_window_bits": int(avg["msm_window_bits"]),
            "msm_windows": K, "msm_groups": int(avg["msm_groups"]),
