@@ -276,7 +276,7 @@ struct Batch {
   DevBuf<uint32_t> src_off, owner;
   DevBuf<uint32_t> idx_commit, idx_proof, status0;  // dynamic slots of the commitments / of the proof points; initial status
   // device work buffers
-  DevBuf<sc> chal, rows, scal, shr, dyn_unw, wm;
+  DevBuf<sc> chal, rows, scal, shr, wm;
   DevBuf<uint8_t> rng_out, weights, masks, chal_bytes;
   DevBuf<uint32_t> status, group_first, group_dlo;
   DevBuf<niels> dynpts;
@@ -296,7 +296,7 @@ void adopt_buffers(Batch &dst, Batch &src) {
 #define BPP_ADOPT(f) dst.f.swap(src.f)
   BPP_ADOPT(d_ext_status); BPP_ADOPT(bytes); BPP_ADOPT(states); BPP_ADOPT(seeds); BPP_ADOPT(d_desc); BPP_ADOPT(minvals);
   BPP_ADOPT(src_off); BPP_ADOPT(owner); BPP_ADOPT(idx_commit); BPP_ADOPT(idx_proof); BPP_ADOPT(status0); BPP_ADOPT(chal);
-  BPP_ADOPT(rows); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(dyn_unw); BPP_ADOPT(wm); BPP_ADOPT(rng_out); BPP_ADOPT(weights);
+  BPP_ADOPT(rows); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(wm); BPP_ADOPT(rng_out); BPP_ADOPT(weights);
   BPP_ADOPT(masks); BPP_ADOPT(chal_bytes); BPP_ADOPT(status); BPP_ADOPT(group_first); BPP_ADOPT(group_dlo); BPP_ADOPT(dynpts);
   BPP_ADOPT(msm.digits); BPP_ADOPT(msm.counts); BPP_ADOPT(msm.starts); BPP_ADOPT(msm.sorted); BPP_ADOPT(msm.order);
   BPP_ADOPT(msm.order_hist); BPP_ADOPT(msm.buckets); BPP_ADOPT(msm.Q); BPP_ADOPT(msm.W); BPP_ADOPT(msm.R); BPP_ADOPT(msm.comp32);
@@ -350,7 +350,7 @@ int fail(bpp_ctx *ctx, int code, const std::string &m, char *errbuf = nullptr, s
   return code;
 }
 
-enum Mark { M_START = 0, M_TRANSCRIPTS, M_DECOMPRESS, M_SCALARS, M_WEIGHTS_IN, M_REDUCE, M_DIGITS, M_SORT, M_ORDER, M_ACC,
+enum Mark { M_START = 0, M_TRANSCRIPTS, M_DECOMPRESS, M_SCALARS, M_WEIGHTS_IN, M_LANES, M_REDUCE, M_DIGITS, M_SORT, M_ORDER, M_ACC,
             M_BUCKET, M_FINAL, M_COUNT };
 
 struct StageTimer {
@@ -975,7 +975,6 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
     B->dynpts.alloc(dyn);
     B->rows.alloc((size_t)n_items * B->cols);
     B->shr.alloc((size_t)n_items * SH_STRIDE);
-    B->dyn_unw.alloc(dyn);
     B->wm.alloc(n_items);
     B->masks.alloc(n_items * P.t * 32);
     B->h_rng.resize(n_items * 32);
@@ -1064,7 +1063,7 @@ int bpp_batch_destroy(bpp_ctx *ctx, uint64_t batch) {
 namespace {
 
 // Weight-independent device work for the whole resident batch: PASS 1, decompression and -- unless `pass1_only` --
-// the unweighted PASS-2 scalars.  Returns after the transcript-RNG bytes have reached the host (h_rng); the rest is
+// the per-proof scalar block (k_scalars_shared).  Returns after the transcript-RNG bytes have reached the host (h_rng); the rest is
 // still running on the stream (it overlaps the host weight chain).
 void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
   Params &P = *b.params;
@@ -1097,19 +1096,9 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
   hipLaunchKernelGGL(k_decompress, dim3(cdiv(n_proof_pts, 64)), dim3(64), 0, s, b.bytes.p, b.src_off.p, b.owner.p,
                      b.idx_proof.p, n_proof_pts, b.dynpts.p, b.status.p);
   tm.mark(M_DECOMPRESS);
-  if (!pass1_only) {
+  if (!pass1_only) {  // the weight-independent part of the PASS-2 scalars; the rest (k_scalars_lanes) takes the weights
     hipLaunchKernelGGL(k_scalars_shared, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.chal.p,
                        P.n_bits, P.t, b.cs, b.B, b.shr.p);
-    const uint32_t rm = std::min(b.rmax, (uint32_t)BPP_MAX_ROUNDS - 1);
-    const uint32_t nhi_max = 1u << (rm > BPP_LANES_LB ? rm - BPP_LANES_LB : 0);
-    // proofs per workgroup: as many as fill the 64 lanes of the table phase (8 + nhi + m entries each)
-    const uint32_t m_max = std::max<uint32_t>(1, b.max_mn / std::max<uint32_t>(1, P.n_bits));
-    const uint32_t tab_max = (1u << std::min<uint32_t>(rm, BPP_LANES_LB)) + nhi_max + std::min<uint32_t>(m_max, 32);
-    const uint32_t ppw = std::max<uint32_t>(1, std::min<uint32_t>(4, 64 / tab_max));
-    const uint32_t ndyn_max = m_max + 3 + 2 * rm;
-    hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s,
-                       b.d_desc.p, b.shr.p, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, tab_max, ndyn_max, b.rows.p,
-                       b.dyn_unw.p);
     tm.mark(M_SCALARS);
   }
   HIP_CHECK(hipGetLastError());
@@ -1331,8 +1320,8 @@ void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk) {
   b.last_chunk = chunk;
 }
 
-// Weight-dependent tail: h_weights -> device, weighted reduction of the generator scalars, weighting of the dynamic
-// scalars, final MSM.
+// Weight-dependent tail: h_weights -> device, the weighted generator rows and dynamic scalars (k_scalars_lanes), the
+// per-group column sums, final MSM.
 void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
   Params &P = *b.params;
   hipStream_t s = ctx->stream;
@@ -1340,9 +1329,20 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
   tm.mark(M_WEIGHTS_IN);
   sc *dyn_scal = b.scal.p + (size_t)b.G * b.cols;
   hipLaunchKernelGGL(k_weights_to_mont, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.weights.p, b.B, b.wm.p);
-  hipLaunchKernelGGL(k_reduce_static, dim3(cdiv(b.cols, BPP_REDUCE_TILE), b.G), dim3(64), 0, s, b.rows.p, b.wm.p, b.group_first.p, b.cols, b.scal.p);
-  hipLaunchKernelGGL(k_weight_dyn, dim3(cdiv(b.total_dyn, 64)), dim3(64), 0, s, b.dyn_unw.p, b.owner.p, b.wm.p, b.total_dyn,
-                     dyn_scal);
+  {
+    const uint32_t rm = std::min(b.rmax, (uint32_t)BPP_MAX_ROUNDS - 1);
+    const uint32_t nhi_max = 1u << (rm > BPP_LANES_LB ? rm - BPP_LANES_LB : 0);
+    // proofs per workgroup: as many as fill the 64 lanes of the table phase (8 + nhi + m + 1 entries each)
+    const uint32_t m_max = std::max<uint32_t>(1, b.max_mn / std::max<uint32_t>(1, P.n_bits));
+    const uint32_t tab_max = (1u << std::min<uint32_t>(rm, BPP_LANES_LB)) + nhi_max + std::min<uint32_t>(m_max, 32) + 1;
+    const uint32_t ppw = std::max<uint32_t>(1, std::min<uint32_t>(4, 64 / tab_max));
+    const uint32_t ndyn_max = m_max + 3 + 2 * rm;
+    hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s, b.d_desc.p, b.shr.p,
+                       b.wm.p, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, tab_max, ndyn_max, b.rows.p, dyn_scal);
+  }
+  tm.mark(M_LANES);
+  hipLaunchKernelGGL(k_reduce_static, dim3(cdiv(b.cols, BPP_REDUCE_TILE), b.G), dim3(64), 0, s, b.rows.p, b.group_first.p, b.cols,
+                     b.scal.p);
   tm.mark(M_REDUCE);
   PointTables tabs{P.table.p, b.dynpts.p, P.table_len};
   msm_run(ctx, b.msm, b.scal.p, tabs, &tm);
@@ -1355,9 +1355,9 @@ void collect_profile(bpp_ctx *ctx, Batch &b, StageTimer &tm, float chain_ms, flo
   memset(&pf, 0, sizeof(pf));
   pf.transcripts_ms = tm.between(M_START, M_TRANSCRIPTS);
   pf.decompress_ms = tm.between(M_TRANSCRIPTS, M_DECOMPRESS);  // includes the 32 B/proof device-to-host copy
-  pf.scalars_ms = tm.between(M_DECOMPRESS, M_SCALARS);
+  pf.scalars_ms = tm.between(M_DECOMPRESS, M_SCALARS) + tm.between(M_WEIGHTS_IN, M_LANES);  // shared + lanes
   pf.chain_host_ms = chain_ms;
-  pf.reduce_ms = tm.between(M_WEIGHTS_IN, M_REDUCE);
+  pf.reduce_ms = tm.between(M_LANES, M_REDUCE);
   pf.msm_digits_ms = tm.between(M_REDUCE, M_DIGITS);
   pf.msm_sort_ms = tm.between(M_DIGITS, M_ORDER);  // counting sort + size ordering of the buckets
   pf.msm_accumulate_ms = tm.between(M_ORDER, M_ACC);

@@ -237,11 +237,12 @@ __global__ void __launch_bounds__(64) k_from_uniform(const uint8_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// PASS 2 scalar block (src/range_proof.rs:894-1033), split so that nothing depends on the batch weight until the
-// very end (the weight chain runs on the host meanwhile):
-//   k_scalars_shared  1 lane / proof : batch inversion (binary-GCD), powers, sums -> shr[p][*]
-//   k_scalars_lanes   1 wave / ppw proofs : lanes over (proof, generator index) -> UNWEIGHTED rows + dynamic scalars
-//   k_weights_to_mont, k_reduce_static (sum_p w_p * rows[p][col]), k_weight_dyn (w_p * dyn)
+// PASS 2 scalar block (src/range_proof.rs:894-1033).  The host weight chain (1.2 ms per 64 x 1024 proofs) runs while
+// PASS 1, decompression and k_scalars_shared execute; the weights enter once, in the tables of k_scalars_lanes:
+//   k_scalars_shared  1 lane / proof : batch inversion (divsteps), powers, sums -> shr[p][*]          (no weight)
+//   k_weights_to_mont                : canonical weights -> Montgomery
+//   k_scalars_lanes   1 wave / ppw proofs : lanes over (proof, generator index) -> WEIGHTED rows + dynamic scalars
+//   k_reduce_static                  : per group, column sums of the rows (additions only)
 // Everything is Montgomery form until the final stores.
 // ---------------------------------------------------------------------------------------------
 #define BPP_MAX_ROUNDS 12  // mn <= 64 * 32 = 2048 -> 11 rounds
@@ -413,14 +414,19 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
 //                                                                         k = klo(lo) + khi(hi); x 2^e = one product with the
 //                                                                         constant 2^e R mod l, SC_POW2_R29)
 //   h[i]            = s1e * s[mn-1-i]          = hlo[~lo]  * shi[~hi]     hlo = s1e*slo
+// (with the weight: glo = w*r1e*ylo*slo, hlo = w*s1e*slo, c2 = w*e^2*z^(2(party+1)), e2z = w*e^2*z)
 // so a generator pair costs FOUR Montgomery products: g[i], 2^k y^(mn-i), c2[party] * that (c2 = e^2 z^(2(party+1))),
-// h[i].  The tables live in LDS as nine 29-bit limbs (sc9: unpacked once per entry instead of once per use) and the
+// h[i].  The proof's batch weight w (src/range_proof.rs:894) is multiplied into glo, hlo, c2 and e^2 z once per table entry,
+// so the rows come out WEIGHTED and the per-group column sums need no product at all (round 1 produced unweighted rows so
+// that this stage could overlap the host weight chain, and paid 2 products per generator pair in k_reduce_static; the
+// chain now takes 1.2 ms per step and hides behind PASS 1 / decompression / k_scalars_shared instead).  The tables live in LDS as nine 29-bit limbs (sc9: unpacked once per entry instead of once per use) and the
 // middle product stays in limbs.  Dynamic LDS per proof (sized by the batch's largest round count so small proofs keep
-// full occupancy):   sc9: glo[8] yn2lo[8] hlo[8] | c2[32] | ghi[nhi] y2hi[nhi] shi[nhi]      sc: zp[32] (z^(2(party+1)))
+// full occupancy):   sc9: glo[8] yn2lo[8] hlo[8] | c2[32] | ghi[nhi] y2hi[nhi] shi[nhi]      sc: zp[32] (z^(2(party+1))), e2z, w
 #define BPP_LANES_LB 3
 #define BPP_LANES_FIXED9 (3 * 8 + 32)
+#define BPP_LANES_PACKED (32 + 2)
 BPP_HD constexpr uint32_t lanes_lds_bytes(uint32_t nhi_max) {
-  return (BPP_LANES_FIXED9 + 3u * nhi_max) * (uint32_t)sizeof(sc9) + 32u * (uint32_t)sizeof(sc);
+  return (BPP_LANES_FIXED9 + 3u * nhi_max) * (uint32_t)sizeof(sc9) + (uint32_t)BPP_LANES_PACKED * (uint32_t)sizeof(sc);
 }
 
 // One workgroup serves `ppw` consecutive proofs: a 64-bit single-commitment proof only has 8 + 8 + 1 table entries and
@@ -428,9 +434,11 @@ BPP_HD constexpr uint32_t lanes_lds_bytes(uint32_t nhi_max) {
 // three phases run over flattened (proof, index) items.
 #define BPP_LANES_MAX_PPW 8
 __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restrict__ desc, const sc *__restrict__ shr,
+                                                      const sc *__restrict__ wm /* Montgomery weights, one per proof */,
                                                       uint32_t n_bits, uint32_t t, uint32_t max_mn, uint32_t cols, uint32_t B,
                                                       uint32_t nhi_max, uint32_t ppw, uint32_t tab_max, uint32_t ndyn_max,
-                                                      sc *__restrict__ rows, sc *__restrict__ dyn_unw) {
+                                                      sc *__restrict__ rows /* weighted, Montgomery */,
+                                                      sc *__restrict__ dyn_out /* weighted dynamic scalars, canonical */) {
   const uint32_t p0 = blockIdx.x * ppw;
   const uint32_t lane = threadIdx.x;
   extern __shared__ uint32_t lanes_lds_raw[];
@@ -461,8 +469,9 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     if (r == ~0u) continue;
     const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, HB = r - LB;
     const uint32_t nlo = 1u << LB, nhi = 1u << HB;
-    if (idx >= nlo + nhi + m) continue;
+    if (idx >= nlo + nhi + m + 1) continue;
     const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
+    const sc w = wm[p0 + sub];
     uint8_t *base = reinterpret_cast<uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes;
     sc9 *T = reinterpret_cast<sc9 *>(base);
     sc9 *glo = T, *yn2lo = T + 8, *hlo = T + 16, *c2t = T + 24;
@@ -504,8 +513,10 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
         const sc r1_e = S[SH_R1E], s1_e = S[SH_S1E], y_nm = S[SH_YNM];
         sc_montmul(gv, yv, sv);
         sc_montmul(gv, gv, r1_e);
+        sc_montmul(gv, gv, w);
         sc_montmul(yn, yv, y_nm);
         sc_montmul(hv, sv, s1_e);
+        sc_montmul(hv, hv, w);
         sc9_from(o9, gv);
         glo[v] = o9;
         sc9_from(y9, yn);
@@ -514,16 +525,22 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
         sc9_from(o9, hv);
         hlo[v] = o9;
       }
-    } else {
+    } else if (idx < nlo + nhi + m) {
       const uint32_t party = idx - (nlo + nhi);
       const sc z_square = S[SH_Z2], e_square = S[SH_E2];
       sc zz, c2;
       sc9 o9;
       sc_mont_pow_u32(zz, z_square, party + 1);
       sc_montmul(c2, zz, e_square);
+      sc_montmul(c2, c2, w);
       zp[party] = zz;
       sc9_from(o9, c2);
       c2t[party] = o9;
+    } else {  // the weighted additive constant of every generator scalar, and the weight itself for the other phases
+      sc ez;
+      sc_montmul(ez, S[SH_E2Z], w);
+      zp[32] = ez;
+      zp[33] = w;
     }
   }
   __syncthreads();
@@ -542,7 +559,7 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     sc *row = rows + (size_t)(p0 + sub) * cols;
     sc gi, hi;
     if (i < mn) {
-      const sc e_square_z = S[SH_E2Z];
+      const sc e_square_z = reinterpret_cast<const sc *>(reinterpret_cast<const uint8_t *>(T) + (size_t)n9 * sizeof(sc9))[32];  // w e^2 z
       const uint32_t lo = i & (nlo - 1), hi_i = i >> LB;
       const uint32_t rlo = (~lo) & (nlo - 1), rhi = (~hi_i) & (nhi - 1);
       const uint32_t party = i / n_bits;  // d[i] = z^{2(party+1)} * 2^k, k = i % n_bits  (:919-929)
@@ -588,15 +605,20 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     }
     sc v;
     sc_montmul(v, a, bq);
-    dyn_unw[s_dyn[sub] + q] = v;
+    sc_montmul(v, v, zp[33]);  // x w
+    sc_from_mont(v, v);
+    dyn_out[s_dyn[sub] + q] = v;
   }
   for (uint32_t it = lane; it < ppw * (t + 1); it += 64) {
     const uint32_t sub = it / (t + 1), k = it - sub * (t + 1);
     if (s_r[sub] == ~0u) continue;
     const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
+    const sc w = wm[p0 + sub];
     sc *row = rows + (size_t)(p0 + sub) * cols;
-    if (k == 0) row[2 * max_mn + t] = S[SH_HS];
-    else row[2 * max_mn + (k - 1)] = S[SH_D1(k - 1)];
+    sc v;
+    sc_montmul(v, k == 0 ? S[SH_HS] : S[SH_D1(k - 1)], w);
+    if (k == 0) row[2 * max_mn + t] = v;
+    else row[2 * max_mn + (k - 1)] = v;
   }
 }
 
@@ -662,27 +684,15 @@ __global__ void k_weights_to_mont(const uint8_t *__restrict__ weights32, uint32_
   wm[p] = w;
 }
 
-// dyn[q] = w_owner(q) * dyn_unw[q], canonical
-__global__ void __launch_bounds__(64) k_weight_dyn(const sc *__restrict__ dyn_unw, const uint32_t *__restrict__ owner,
-                                                   const sc *__restrict__ wm, uint32_t n, sc *__restrict__ out) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= n) return;
-  sc v;
-  sc_montmul(v, dyn_unw[q], wm[owner[q] & 0x7fffffffu]);
-  sc_from_mont(v, v);
-  out[q] = v;
-}
-
-// Weighted column sums per group: static[g][col] = sum_{p in g} w_p * rows[p][col]   (the `+=` into
-// gi/hi/g/h_base_scalars of src/range_proof.rs:785-788,999-1020).  One wavefront per (tile of 4 columns, group): lane =
-// (proof slot, column in tile), so the four lanes of a proof slot read 4 x 32 = 128 CONTIGUOUS bytes of one proof's row
-// (one lane per column would walk rows[] with a stride of cols x 32 = 4 160 bytes: 61 % of that kernel's cycles were
-// spent waiting on memory); the sixteen proof slots advance through the group together.  Montgomery products, limb-wise
-// u64 sums, shuffle reduction over the proof slots, one Montgomery exit per column.
+// Column sums per group: static[g][col] = sum_{p in g} rows[p][col], rows already weighted by k_scalars_lanes (the `+=`
+// into gi/hi/g/h_base_scalars of src/range_proof.rs:785-788,999-1020).  One wavefront per (tile of 4 columns, group):
+// lane = (proof slot, column in tile), so the four lanes of a proof slot read 4 x 32 = 128 CONTIGUOUS bytes of one proof's
+// row (one lane per column would walk rows[] with a stride of cols x 32 = 4 160 bytes); the sixteen proof slots advance
+// through the group together.  Limb-wise u64 sums of the Montgomery values, shuffle reduction over the proof slots, one
+// Montgomery exit per column: no multiplication per (proof, column).
 #define BPP_REDUCE_TILE 4u
-__global__ void __launch_bounds__(64) k_reduce_static(const sc *__restrict__ rows, const sc *__restrict__ wm,
-                                                      const uint32_t *__restrict__ group_first, uint32_t cols,
-                                                      sc *__restrict__ out /* [G][cols] canonical */) {
+__global__ void __launch_bounds__(64) k_reduce_static(const sc *__restrict__ rows, const uint32_t *__restrict__ group_first,
+                                                      uint32_t cols, sc *__restrict__ out /* [G][cols] canonical */) {
   const uint32_t g = blockIdx.y, lane = threadIdx.x;
   const uint32_t col = blockIdx.x * BPP_REDUCE_TILE + (lane & (BPP_REDUCE_TILE - 1u)), slot = lane / BPP_REDUCE_TILE;
   const uint32_t p0 = group_first[g], p1 = group_first[g + 1];
@@ -692,8 +702,7 @@ __global__ void __launch_bounds__(64) k_reduce_static(const sc *__restrict__ row
   for (int i = 0; i < 8; i++) acc[i] = 0;
   for (uint32_t p = p0 + slot; p < p1; p += 64u / BPP_REDUCE_TILE) {
     if (live) {
-      sc v;
-      sc_montmul(v, rows[(size_t)p * cols + col], wm[p]);
+      const sc v = rows[(size_t)p * cols + col];
 #pragma unroll
       for (int i = 0; i < 8; i++) acc[i] += v.v[i];
     }
