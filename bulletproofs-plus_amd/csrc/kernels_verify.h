@@ -237,13 +237,19 @@ __global__ void __launch_bounds__(64) k_from_uniform(const uint8_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// PASS 2 scalar block (src/range_proof.rs:894-1033).  The host weight chain (1.2 ms per 64 x 1024 proofs) runs while
-// PASS 1, decompression and k_scalars_shared execute; the weights enter once, in the tables of k_scalars_lanes:
-//   k_scalars_shared  1 lane / proof : batch inversion (divsteps), powers, sums -> shr[p][*]          (no weight)
-//   k_weights_to_mont                : canonical weights -> Montgomery
-//   k_scalars_lanes   1 wave / ppw proofs : lanes over (proof, generator index) -> WEIGHTED rows + dynamic scalars
-//   k_reduce_static                  : per group, column sums of the rows (additions only)
-// Everything is Montgomery form until the final stores.
+// PASS 2 scalar block (src/range_proof.rs:894-1033).  The host weight chain (1.3 ms per 64 x 1024 proofs) runs while
+// PASS 1, decompression and k_scalars_shared execute; the weights enter in k_scalars_weighted:
+//   k_scalars_shared    1 lane / proof : batch inversion (divsteps), powers, sums -> shr[p][*], and the weight-free
+//                                        low / high tables of k_scalars_lanes -> tab[p][*]              (no weight)
+//   k_scalars_weighted  1 lane / proof : w x (low tables, c2, e^2 z) in place, the dynamic scalars (canonical) and the
+//                                        g / h base columns of the proof's row
+//   k_scalars_lanes     1 wave / ppw proofs : tables -> LDS, lanes over (proof, generator index) -> WEIGHTED rows
+//   k_reduce_static                    : per group, column sums of the rows (additions only)
+// A product costs the same ~270 instructions whether one lane of the wavefront needs it or all 64: everything that exists
+// once per proof or once per table entry is therefore computed with one lane per PROOF (64 proofs per wavefront), and
+// only the 4 products per generator pair run with lanes over generator indices.  (Until r02_v5 the tables were built
+// inside k_scalars_lanes, 54 busy lanes in four divergent branches: 5.5 k of that kernel's 9.6 k instructions per
+// wavefront.)  Everything is Montgomery form until the final stores.
 // ---------------------------------------------------------------------------------------------
 #define BPP_MAX_ROUNDS 12  // mn <= 64 * 32 = 2048 -> 11 rounds
 #define SH_Z 0
@@ -269,6 +275,49 @@ __global__ void __launch_bounds__(64) k_from_uniform(const uint8_t *__restrict__
 #define SH_YINVPOW(b) (SH_ARR + 4 * BPP_MAX_ROUNDS + (b))
 #define SH_STRIDE (SH_ARR + 5 * BPP_MAX_ROUNDS)
 
+// Table block of one proof in HBM (entries of 32 bytes, packed Montgomery scalars), written with one lane per proof and
+// read back by k_scalars_lanes with lanes over entries (coalesced):
+//   glo[8] yn2lo[8] hlo[8] | c2[cm] | ghi[nhi_max] y2hi[nhi_max] shi[nhi_max] | e2z        (meaning: see k_scalars_lanes)
+// cm = largest aggregation factor of the batch (<= 32), nhi_max = 2^(largest round count - 3).
+#define BPP_LANES_LB 3
+BPP_HD constexpr uint32_t lanes_tab_stride(uint32_t nhi_max, uint32_t cm) { return 24u + cm + 3u * nhi_max + 1u; }
+// shapes the three kernels skip alike (rejected on the host before PASS 2)
+BPP_HD bool lanes_shape_ok(uint32_t rounds, uint32_t m, uint32_t nhi_max, uint32_t cm) {
+  const uint32_t hb = rounds > BPP_LANES_LB ? rounds - BPP_LANES_LB : 0;
+  return rounds <= BPP_MAX_ROUNDS - 1 && m >= 1 && m <= cm && hb < 31 && (1u << hb) <= nhi_max;
+}
+// this table entry's share of k = i mod n_bits for i = (hi << LB) | lo (n_bits and nlo are powers of two): d[i] carries 2^k
+BPP_HD uint32_t lanes_e2k(bool is_hi, uint32_t v, uint32_t nlo, uint32_t n_bits) {
+  const uint32_t e = nlo >= n_bits ? (is_hi ? 0u : (v & (n_bits - 1u))) : (is_hi ? nlo * (v & (n_bits / nlo - 1u)) : v);
+  return e & 63u;
+}
+__device__ __forceinline__ void sc_mul_pow2(sc &r, const sc &a, uint32_t e) {  // a * 2^e, e < 64
+  sc9 a9, p2;
+  sc9_from(a9, a);
+#pragma unroll
+  for (int q = 0; q < 9; q++) p2.l[q] = SC_POW2_R29[e][q];
+  sc9_montmul(r, a9, p2);
+}
+// s[] over `nbits` bits of the index starting at bit b0: entry 0 = product of the inverse challenges, entry v + 2^b = entry v
+// times e_j^2 (j = r - 1 - b, src/range_proof.rs:972-990 read as a product over the bits of i): nbits - 1 + 2^nbits - 1 products
+__device__ __forceinline__ void lanes_s_tree(sc *dst, const sc *o, uint32_t r, uint32_t b0, uint32_t nbits, const sc &one) {
+  sc a = one;
+  for (uint32_t bb = 0; bb < nbits; bb++) {
+    const sc f = o[SH_EINV(r - 1 - (b0 + bb))];
+    if (bb == 0) a = f;
+    else sc_montmul(a, a, f);
+  }
+  dst[0] = a;
+  for (uint32_t bb = 0; bb < nbits; bb++) {
+    const sc esq = o[SH_ESQ(r - 1 - (b0 + bb))];
+    for (uint32_t v = 0; v < (1u << bb); v++) {
+      sc x = dst[v];
+      sc_montmul(x, x, esq);
+      dst[v + (1u << bb)] = x;
+    }
+  }
+}
+
 __device__ __forceinline__ void sc_load_mont(sc &r, const uint8_t *p) {
   sc a;
   sc_load_words(a, p);
@@ -278,7 +327,8 @@ __device__ __forceinline__ void sc_load_mont(sc &r, const uint8_t *p) {
 __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
                                                        const uint64_t *__restrict__ minvals, const sc *__restrict__ chal,
                                                        uint32_t n_bits, uint32_t t, uint32_t cs, uint32_t B,
-                                                       sc *__restrict__ shr) {
+                                                       sc *__restrict__ shr, uint32_t nhi_max, uint32_t cm,
+                                                       sc *tab /* lanes_tab_stride(nhi_max, cm) entries per proof */) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B) return;
   const ProofDesc d = desc[p];
@@ -404,143 +454,179 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
     sc_load_mont(d1, pd1 + 32 * k);
     o[SH_D1(k)] = d1;
   }
+  // ---- the tables of k_scalars_lanes, before the weight: with i = (hi << LB) | lo
+  //   hlo[lo] = s1e s_lo[lo]   glo[lo] = r1e y^-lo s_lo[lo]   yn2lo[lo] = y^mn y^-lo 2^klo
+  //   shi[hi] = s_hi[hi]       ghi[hi] = y^-(hi << LB) s_hi[hi]   y2hi[hi] = y^-(hi << LB) 2^khi
+  if (!lanes_shape_ok(r, m, nhi_max, cm)) return;
+  const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, HB = r - LB, nlo = 1u << LB, nhi = 1u << HB;
+  sc *T = tab + (size_t)p * lanes_tab_stride(nhi_max, cm);
+  sc *glo = T, *yn2lo = T + 8, *hlo = T + 16, *ghi = T + 24 + cm, *y2hi = ghi + nhi_max, *shi = y2hi + nhi_max;
+  lanes_s_tree(hlo, o, r, 0, LB, one);
+  lanes_s_tree(shi, o, r, LB, HB, one);
+  {
+    sc yr = r1_e, yn = y_nm;
+    for (uint32_t v = 0; v < nlo; v++) {
+      const sc sv = hlo[v];
+      sc x;
+      sc_montmul(x, sv, s1_e);
+      hlo[v] = x;
+      sc_montmul(x, sv, yr);
+      glo[v] = x;
+      sc_mul_pow2(x, yn, lanes_e2k(false, v, nlo, n_bits));
+      yn2lo[v] = x;
+      if (v + 1 < nlo) {
+        sc_montmul(yr, yr, y_inverse);
+        sc_montmul(yn, yn, y_inverse);
+      }
+    }
+  }
+  {
+    sc yh = one, step = one;
+    if (HB) step = o[SH_YINVPOW(LB)];
+    for (uint32_t v = 0; v < nhi; v++) {
+      const sc sv = shi[v];
+      sc x;
+      sc_montmul(x, sv, yh);
+      ghi[v] = x;
+      sc_mul_pow2(x, yh, lanes_e2k(true, v, nlo, n_bits));
+      y2hi[v] = x;
+      if (v + 1 < nhi) sc_montmul(yh, yh, step);
+    }
+  }
 }
 
-// Generator scalars without the weight.  With i = (hi << LB) | lo, s[i] = slo[lo]*shi[hi] and y^-i = ylo[lo]*yhi[hi]
-// (products over the bits of i), so every per-index quantity is ONE product of a "low" and a "high" table entry:
-//   g[i]            = r1e * y^-i * s[i]        = glo[lo]   * ghi[hi]      glo = r1e*ylo*slo,  ghi = yhi*shi
+// The weighted part of the scalar block, one lane per proof (src/range_proof.rs:894, :1006-1032): w into the low tables, the
+// per-party constants and e^2 z (in place in tab[]), the proof's dynamic scalars and its g / h base columns.  A Montgomery
+// product with one CANONICAL operand is the canonical product, so the dynamic scalars (which k_msm_digits wants
+// canonical) take the weight as it arrives and need no conversion:
+//   C_j: (-e^2 y^{mn+1} w) z^{2(j+1)};  A1: -e w;  B: -w;  A: -e^2 w;  L_j: (-e^2 w) e_j^2;  R_j: (-e^2 w) e_j^-2
+__global__ void __launch_bounds__(64) k_scalars_weighted(const ProofDesc *__restrict__ desc, const sc *__restrict__ shr,
+                                                         const uint8_t *__restrict__ weights32, uint32_t n_bits, uint32_t t,
+                                                         uint32_t max_mn, uint32_t cols, uint32_t B, uint32_t nhi_max, uint32_t cm,
+                                                         sc *tab, sc *__restrict__ rows, sc *__restrict__ dyn_out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  const ProofDesc d = desc[p];
+  const uint32_t r = d.rounds, m = d.m;
+  if (!lanes_shape_ok(r, m, nhi_max, cm)) return;
+  const sc *S = shr + (size_t)p * SH_STRIDE;
+  const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, nlo = 1u << LB;
+  sc *T = tab + (size_t)p * lanes_tab_stride(nhi_max, cm);
+  sc *glo = T, *hlo = T + 16, *c2t = T + 24, *e2z = T + 24 + cm + 3 * nhi_max;
+  sc wc, w;
+  sc_load_words(wc, weights32 + (size_t)p * 32);
+  sc_to_mont(w, wc);
+  for (uint32_t v = 0; v < nlo; v++) {
+    sc x = glo[v];
+    sc_montmul(x, x, w);
+    glo[v] = x;
+    x = hlo[v];
+    sc_montmul(x, x, w);
+    hlo[v] = x;
+  }
+  sc *dyn = dyn_out + d.dyn_off;
+  {
+    const sc z_square = S[SH_Z2];
+    sc e2w, nyw, zz = z_square;
+    sc_montmul(e2w, S[SH_E2], w);
+    sc_montmul(nyw, S[SH_NEG_E2_YNM1], wc);
+    for (uint32_t j = 0; j < m; j++) {
+      sc x;
+      sc_montmul(x, zz, e2w);
+      c2t[j] = x;  // w e^2 z^(2(j+1))
+      sc_montmul(x, zz, nyw);
+      dyn[j] = x;
+      if (j + 1 < m) sc_montmul(zz, zz, z_square);
+    }
+    sc x;
+    sc_montmul(x, S[SH_E2Z], w);
+    *e2z = x;
+  }
+  {
+    sc x, ne;
+    sc_neg(ne, S[SH_E]);
+    sc_montmul(x, ne, wc);
+    dyn[m] = x;
+    sc_neg(x, wc);
+    dyn[m + 1] = x;
+    sc ne2w;
+    sc_montmul(ne2w, S[SH_NEG_E2], wc);
+    dyn[m + 2] = ne2w;
+    for (uint32_t j = 0; j < r; j++) {
+      sc_montmul(x, ne2w, S[SH_ESQ(j)]);
+      dyn[m + 3 + j] = x;
+      sc_montmul(x, ne2w, S[SH_ESQINV(j)]);
+      dyn[m + 3 + r + j] = x;
+    }
+  }
+  sc *row = rows + (size_t)p * cols;
+  {
+    sc x;
+    sc_montmul(x, S[SH_HS], w);
+    row[2 * max_mn + t] = x;
+    for (uint32_t k = 0; k < t; k++) {
+      sc_montmul(x, S[SH_D1(k)], w);
+      row[2 * max_mn + k] = x;
+    }
+  }
+}
+
+// Generator scalars.  With i = (hi << LB) | lo, s[i] = slo[lo]*shi[hi] and y^-i = ylo[lo]*yhi[hi] (products over the bits of
+// i), so every per-index quantity is ONE product of a "low" and a "high" table entry:
+//   g[i]            = w r1e y^-i s[i]          = glo[lo]   * ghi[hi]      glo = w*r1e*ylo*slo,  ghi = yhi*shi
 //   2^k * y^(mn-i)  = y^mn * y^-i * 2^k        = yn2lo[lo] * y2hi[hi]     k = i mod n (the 2^k of d[i] = z^(2(j+1)) 2^k,
 //                                                                         src/range_proof.rs:919-929, split over the two tables:
 //                                                                         k = klo(lo) + khi(hi); x 2^e = one product with the
 //                                                                         constant 2^e R mod l, SC_POW2_R29)
-//   h[i]            = s1e * s[mn-1-i]          = hlo[~lo]  * shi[~hi]     hlo = s1e*slo
-// (with the weight: glo = w*r1e*ylo*slo, hlo = w*s1e*slo, c2 = w*e^2*z^(2(party+1)), e2z = w*e^2*z)
-// so a generator pair costs FOUR Montgomery products: g[i], 2^k y^(mn-i), c2[party] * that (c2 = e^2 z^(2(party+1))),
-// h[i].  The proof's batch weight w (src/range_proof.rs:894) is multiplied into glo, hlo, c2 and e^2 z once per table entry,
-// so the rows come out WEIGHTED and the per-group column sums need no product at all (round 1 produced unweighted rows so
-// that this stage could overlap the host weight chain, and paid 2 products per generator pair in k_reduce_static; the
-// chain now takes 1.2 ms per step and hides behind PASS 1 / decompression / k_scalars_shared instead).  The tables live in LDS as nine 29-bit limbs (sc9: unpacked once per entry instead of once per use) and the
-// middle product stays in limbs.  Dynamic LDS per proof (sized by the batch's largest round count so small proofs keep
-// full occupancy):   sc9: glo[8] yn2lo[8] hlo[8] | c2[32] | ghi[nhi] y2hi[nhi] shi[nhi]      sc: zp[32] (z^(2(party+1))), e2z, w
-#define BPP_LANES_LB 3
-#define BPP_LANES_FIXED9 (3 * 8 + 32)
-#define BPP_LANES_PACKED (32 + 2)
-BPP_HD constexpr uint32_t lanes_lds_bytes(uint32_t nhi_max) {
-  return (BPP_LANES_FIXED9 + 3u * nhi_max) * (uint32_t)sizeof(sc9) + (uint32_t)BPP_LANES_PACKED * (uint32_t)sizeof(sc);
+//   h[i]            = w s1e s[mn-1-i]          = hlo[~lo]  * shi[~hi]     hlo = w*s1e*slo
+// so a generator pair costs FOUR Montgomery products: g[i], 2^k y^(mn-i), c2[party] * that (c2 = w e^2 z^(2(party+1))),
+// h[i]; the additive constant is e2z = w e^2 z.  The proof's batch weight w (src/range_proof.rs:894) sits in glo, hlo, c2 and
+// e2z, so the rows come out WEIGHTED and the per-group column sums need no product at all (round 1 produced unweighted
+// rows so that this stage could overlap the host weight chain, and paid 2 products per generator pair in
+// k_reduce_static).  The tables come from tab[] (k_scalars_shared, k_scalars_weighted), are unpacked ONCE per entry into
+// nine 29-bit limbs in LDS (sc9) instead of once per use, and the middle product stays in limbs.  Dynamic LDS per proof:
+//   sc9: glo[8] yn2lo[8] hlo[8] | c2[cm] | ghi[nhi_max] y2hi[nhi_max] shi[nhi_max]      sc: e2z
+BPP_HD constexpr uint32_t lanes_lds_bytes(uint32_t nhi_max, uint32_t cm) {
+  return (lanes_tab_stride(nhi_max, cm) - 1u) * (uint32_t)sizeof(sc9) + (uint32_t)sizeof(sc);
 }
 
-// One workgroup serves `ppw` consecutive proofs: a 64-bit single-commitment proof only has 8 + 8 + 1 table entries and
-// 64 generator pairs, so one proof per wavefront leaves three quarters of the lanes idle in the table phase.  All
-// three phases run over flattened (proof, index) items.
+// One workgroup serves `ppw` consecutive proofs (a 64-bit single-commitment proof has 64 generator pairs: four proofs
+// make four full passes of the 64 lanes); both phases run over flattened (proof, index) items.
 #define BPP_LANES_MAX_PPW 8
-__global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restrict__ desc, const sc *__restrict__ shr,
-                                                      const sc *__restrict__ wm /* Montgomery weights, one per proof */,
-                                                      uint32_t n_bits, uint32_t t, uint32_t max_mn, uint32_t cols, uint32_t B,
-                                                      uint32_t nhi_max, uint32_t ppw, uint32_t tab_max, uint32_t ndyn_max,
-                                                      sc *__restrict__ rows /* weighted, Montgomery */,
-                                                      sc *__restrict__ dyn_out /* weighted dynamic scalars, canonical */) {
+__global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restrict__ desc, const sc *__restrict__ tab,
+                                                      uint32_t n_bits, uint32_t max_mn, uint32_t cols, uint32_t B,
+                                                      uint32_t nhi_max, uint32_t cm, uint32_t ppw,
+                                                      sc *__restrict__ rows /* weighted, Montgomery */) {
   const uint32_t p0 = blockIdx.x * ppw;
   const uint32_t lane = threadIdx.x;
   extern __shared__ uint32_t lanes_lds_raw[];
-  __shared__ uint32_t s_r[BPP_LANES_MAX_PPW], s_m[BPP_LANES_MAX_PPW], s_dyn[BPP_LANES_MAX_PPW];
-  const uint32_t per_bytes = lanes_lds_bytes(nhi_max);  // LDS bytes per proof
-  const uint32_t n9 = BPP_LANES_FIXED9 + 3u * nhi_max;  // sc9 entries per proof
+  __shared__ uint32_t s_r[BPP_LANES_MAX_PPW], s_m[BPP_LANES_MAX_PPW];
+  const uint32_t ts = lanes_tab_stride(nhi_max, cm), n9 = ts - 1u;  // entries per proof: n9 as limbs, then e2z packed
+  const uint32_t per_bytes = lanes_lds_bytes(nhi_max, cm);
   if (lane < ppw) {
     const uint32_t p = p0 + lane;
-    uint32_t r = ~0u, m = 0, dyn_off = 0;
+    uint32_t r = ~0u, m = 0;
     if (p < B) {
       const ProofDesc d = desc[p];
-      const uint32_t hb = d.rounds > BPP_LANES_LB ? d.rounds - BPP_LANES_LB : 0;
-      if (d.rounds <= BPP_MAX_ROUNDS - 1 && d.m <= 32 && (1u << hb) <= nhi_max) r = d.rounds;
+      if (lanes_shape_ok(d.rounds, d.m, nhi_max, cm)) r = d.rounds;
       m = d.m;
-      dyn_off = d.dyn_off;
     }
     s_r[lane] = r;  // ~0: nothing to do for this slot (past the end, or a shape rejected on the host before PASS 2)
     s_m[lane] = m;
-    s_dyn[lane] = dyn_off;
   }
   __syncthreads();
-  sc one;
-  sc_mont_one(one);
-  // ---- tables: low entries first, then high entries, then the per-party powers of z^2
-  for (uint32_t it = lane; it < ppw * tab_max; it += 64) {
-    const uint32_t sub = it / tab_max, idx = it - sub * tab_max;
-    const uint32_t r = s_r[sub], m = s_m[sub];
-    if (r == ~0u) continue;
-    const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, HB = r - LB;
-    const uint32_t nlo = 1u << LB, nhi = 1u << HB;
-    if (idx >= nlo + nhi + m + 1) continue;
-    const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
-    const sc w = wm[p0 + sub];
+  // ---- tables -> LDS (entries a proof's shape does not use are never read)
+  for (uint32_t it = lane; it < ppw * ts; it += 64) {
+    const uint32_t sub = it / ts, idx = it - sub * ts;
+    if (s_r[sub] == ~0u) continue;
+    const sc v = tab[(size_t)(p0 + sub) * ts + idx];
     uint8_t *base = reinterpret_cast<uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes;
-    sc9 *T = reinterpret_cast<sc9 *>(base);
-    sc9 *glo = T, *yn2lo = T + 8, *hlo = T + 16, *c2t = T + 24;
-    sc9 *ghi = T + BPP_LANES_FIXED9, *y2hi = ghi + nhi_max, *shi = y2hi + nhi_max;
-    sc *zp = reinterpret_cast<sc *>(base + (size_t)n9 * sizeof(sc9));
-    if (idx < nlo + nhi) {
-      const bool is_hi = idx >= nlo;
-      const uint32_t v = is_hi ? idx - nlo : idx, b0 = is_hi ? LB : 0, nbits = is_hi ? HB : LB;
-      sc sv = one, yv = one;
-      for (uint32_t bb = 0; bb < nbits; bb++) {
-        const uint32_t b = b0 + bb, j = r - 1 - b;
-        const bool bit = (v >> bb) & 1u;
-        const sc f = bit ? S[SH_EJ(j)] : S[SH_EINV(j)];
-        sc_montmul(sv, sv, f);
-        if (bit) {
-          const sc yp = S[SH_YINVPOW(b)];
-          sc_montmul(yv, yv, yp);
-        }
-      }
-      // this entry's share of k = i mod n_bits (i = (hi << LB) | lo; n_bits and nlo are powers of two)
-      const uint32_t e2k = nlo >= n_bits ? (is_hi ? 0u : (v & (n_bits - 1u))) : (is_hi ? nlo * (v & (n_bits / nlo - 1u)) : v);
-      sc9 p2;
-#pragma unroll
-      for (int q = 0; q < 9; q++) p2.l[q] = SC_POW2_R29[e2k & 63u][q];
-      if (is_hi) {
-        sc gv;
-        sc9 y9, o9;
-        sc_montmul(gv, yv, sv);
-        sc9_from(o9, gv);
-        ghi[v] = o9;
-        sc9_from(y9, yv);
-        sc9_montmul_lazy(o9, y9, p2);
-        y2hi[v] = o9;
-        sc9_from(o9, sv);
-        shi[v] = o9;
-      } else {
-        sc gv, yn, hv;
-        sc9 y9, o9;
-        const sc r1_e = S[SH_R1E], s1_e = S[SH_S1E], y_nm = S[SH_YNM];
-        sc_montmul(gv, yv, sv);
-        sc_montmul(gv, gv, r1_e);
-        sc_montmul(gv, gv, w);
-        sc_montmul(yn, yv, y_nm);
-        sc_montmul(hv, sv, s1_e);
-        sc_montmul(hv, hv, w);
-        sc9_from(o9, gv);
-        glo[v] = o9;
-        sc9_from(y9, yn);
-        sc9_montmul_lazy(o9, y9, p2);
-        yn2lo[v] = o9;
-        sc9_from(o9, hv);
-        hlo[v] = o9;
-      }
-    } else if (idx < nlo + nhi + m) {
-      const uint32_t party = idx - (nlo + nhi);
-      const sc z_square = S[SH_Z2], e_square = S[SH_E2];
-      sc zz, c2;
+    if (idx < n9) {
       sc9 o9;
-      sc_mont_pow_u32(zz, z_square, party + 1);
-      sc_montmul(c2, zz, e_square);
-      sc_montmul(c2, c2, w);
-      zp[party] = zz;
-      sc9_from(o9, c2);
-      c2t[party] = o9;
-    } else {  // the weighted additive constant of every generator scalar, and the weight itself for the other phases
-      sc ez;
-      sc_montmul(ez, S[SH_E2Z], w);
-      zp[32] = ez;
-      zp[33] = w;
+      sc9_from(o9, v);
+      reinterpret_cast<sc9 *>(base)[idx] = o9;
+    } else {
+      *reinterpret_cast<sc *>(base + (size_t)n9 * sizeof(sc9)) = v;
     }
   }
   __syncthreads();
@@ -552,14 +638,13 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     const uint32_t mn = s_m[sub] * n_bits;
     const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, HB = r - LB;
     const uint32_t nlo = 1u << LB, nhi = 1u << HB;
-    const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
     const sc9 *T = reinterpret_cast<const sc9 *>(reinterpret_cast<const uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes);
     const sc9 *glo = T, *yn2lo = T + 8, *hlo = T + 16, *c2t = T + 24;
-    const sc9 *ghi = T + BPP_LANES_FIXED9, *y2hi = ghi + nhi_max, *shi = y2hi + nhi_max;
+    const sc9 *ghi = T + 24 + cm, *y2hi = ghi + nhi_max, *shi = y2hi + nhi_max;
     sc *row = rows + (size_t)(p0 + sub) * cols;
     sc gi, hi;
     if (i < mn) {
-      const sc e_square_z = reinterpret_cast<const sc *>(reinterpret_cast<const uint8_t *>(T) + (size_t)n9 * sizeof(sc9))[32];  // w e^2 z
+      const sc e_square_z = *reinterpret_cast<const sc *>(reinterpret_cast<const uint8_t *>(T) + (size_t)n9 * sizeof(sc9));  // w e^2 z
       const uint32_t lo = i & (nlo - 1), hi_i = i >> LB;
       const uint32_t rlo = (~lo) & (nlo - 1), rhi = (~hi_i) & (nhi - 1);
       const uint32_t party = i / n_bits;  // d[i] = z^{2(party+1)} * 2^k, k = i % n_bits  (:919-929)
@@ -568,8 +653,8 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
       sc9_montmul(gi, glo[lo], ghi[hi_i]);
       sc_add(gi, gi, e_square_z);
       sc9_montmul_lazy(t9, yn2lo[lo], y2hi[hi_i]);  // 2^k y^{mn-i}, left in limbs
-      sc9_montmul(u, c2t[party], t9);               // e^2 d[i] y^{mn-i}
-      sc_add(u, u, e_square_z);                     // e^2 (d[i] y^{mn-i} + z)
+      sc9_montmul(u, c2t[party], t9);               // w e^2 d[i] y^{mn-i}
+      sc_add(u, u, e_square_z);                     // w e^2 (d[i] y^{mn-i} + z)
       sc9_montmul(hi, hlo[rlo], shi[rhi]);
       sc_sub(hi, hi, u);
     } else {
@@ -578,47 +663,6 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     }
     row[2 * i] = gi;
     row[2 * i + 1] = hi;
-  }
-  // ---- dynamic scalars (:1006-1015, :1022-1032) without the weight: v = A_q * B_q, operands picked per lane (no
-  // branches around the product): C_j: (-e^2 y^{mn+1}) * z^{2(j+1)};  A1: -e;  B: -1;  A: -e^2;  L_j: -e^2 * e_j^2;
-  // R_j: -e^2 * e_j^-2
-  for (uint32_t it = lane; it < ppw * ndyn_max; it += 64) {
-    const uint32_t sub = it / ndyn_max, q = it - sub * ndyn_max;
-    const uint32_t r = s_r[sub], m = s_m[sub];
-    if (r == ~0u || q >= m + 3 + 2 * r) continue;
-    const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
-    const sc *zp = reinterpret_cast<const sc *>(reinterpret_cast<const uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes + (size_t)n9 * sizeof(sc9));
-    sc a, bq;
-    if (q < m) {
-      a = S[SH_NEG_E2_YNM1];
-      bq = zp[q];
-    } else if (q == m) {
-      const sc ef = S[SH_E];
-      sc_neg(a, ef);
-      bq = one;
-    } else if (q == m + 1) {
-      sc_neg(a, one);
-      bq = one;
-    } else {
-      a = S[SH_NEG_E2];
-      bq = (q == m + 2) ? one : ((q < m + 3 + r) ? S[SH_ESQ(q - (m + 3))] : S[SH_ESQINV(q - (m + 3 + r))]);
-    }
-    sc v;
-    sc_montmul(v, a, bq);
-    sc_montmul(v, v, zp[33]);  // x w
-    sc_from_mont(v, v);
-    dyn_out[s_dyn[sub] + q] = v;
-  }
-  for (uint32_t it = lane; it < ppw * (t + 1); it += 64) {
-    const uint32_t sub = it / (t + 1), k = it - sub * (t + 1);
-    if (s_r[sub] == ~0u) continue;
-    const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
-    const sc w = wm[p0 + sub];
-    sc *row = rows + (size_t)(p0 + sub) * cols;
-    sc v;
-    sc_montmul(v, k == 0 ? S[SH_HS] : S[SH_D1(k - 1)], w);
-    if (k == 0) row[2 * max_mn + t] = v;
-    else row[2 * max_mn + (k - 1)] = v;
   }
 }
 
@@ -674,14 +718,6 @@ __global__ void __launch_bounds__(256) k_layout_terms(const uint32_t *__restrict
     term_sidx[t0 + i] = G * cols + q;
     term_pidx[t0 + i] = table_len + q;
   }
-}
-
-__global__ void k_weights_to_mont(const uint8_t *__restrict__ weights32, uint32_t B, sc *__restrict__ wm) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= B) return;
-  sc w;
-  sc_load_mont(w, weights32 + (size_t)p * 32);
-  wm[p] = w;
 }
 
 // Column sums per group: static[g][col] = sum_{p in g} rows[p][col], rows already weighted by k_scalars_lanes (the `+=`
