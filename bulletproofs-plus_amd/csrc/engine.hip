@@ -264,11 +264,10 @@ struct Batch {
   uint64_t params_handle = 0;
   uint32_t B = 0, rmax = 0, cs = 0, max_mn = 0, total_dyn = 0, sum_m = 0, cols = 0;
   // shape of the per-proof table block of the scalar stage (kernels_verify.h: lanes_tab_stride)
-  uint32_t lanes_nhi_max() const {
-    const uint32_t rm = std::min(rmax, (uint32_t)BPP_MAX_ROUNDS - 1);
-    return 1u << (rm > BPP_LANES_LB ? rm - BPP_LANES_LB : 0);
+  uint32_t lanes_nhi_max(uint32_t n_bits) const {
+    const uint32_t rm = std::min(rmax, (uint32_t)BPP_MAX_ROUNDS - 1), lb = lanes_lb(n_bits);
+    return 1u << (rm > lb ? rm - lb : 0);
   }
-  uint32_t lanes_cm(uint32_t n_bits) const { return std::min<uint32_t>(32, std::max<uint32_t>(1, max_mn / std::max<uint32_t>(1, n_bits))); }
   std::vector<ProofDesc> desc;
   std::vector<uint8_t> rounds_bad;  // 0 ok, 3 InvalidLength, 5 SizeOverflow  (src/range_proof.rs:875-888)
   std::vector<uint8_t> defer;       // BPP_DEFER_* findings of verify()'s consistency loops (:637-682), raised per chunk
@@ -981,7 +980,7 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
     B->dynpts.alloc(dyn);
     B->rows.alloc((size_t)n_items * B->cols);
     B->shr.alloc((size_t)n_items * SH_STRIDE);
-    B->tab.alloc((size_t)n_items * lanes_tab_stride(B->lanes_nhi_max(), B->lanes_cm(P.n_bits)));
+    B->tab.alloc((size_t)n_items * lanes_tab_stride(B->lanes_nhi_max(P.n_bits)));
     B->masks.alloc(n_items * P.t * 32);
     B->h_rng.resize(n_items * 32);
     B->h_weights.resize(n_items * 32);
@@ -1104,7 +1103,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
   tm.mark(M_DECOMPRESS);
   if (!pass1_only) {  // the weight-independent part of the PASS-2 scalars; the rest (k_scalars_lanes) takes the weights
     hipLaunchKernelGGL(k_scalars_shared, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.chal.p,
-                       P.n_bits, P.t, b.cs, b.B, b.shr.p, b.lanes_nhi_max(), b.lanes_cm(P.n_bits), b.tab.p);
+                       P.n_bits, P.t, b.cs, b.B, b.shr.p, b.lanes_nhi_max(P.n_bits), b.tab.p);
     tm.mark(M_SCALARS);
   }
   HIP_CHECK(hipGetLastError());
@@ -1335,13 +1334,13 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
   tm.mark(M_WEIGHTS_IN);
   sc *dyn_scal = b.scal.p + (size_t)b.G * b.cols;
   {
-    const uint32_t nhi_max = b.lanes_nhi_max(), cm = b.lanes_cm(P.n_bits);
+    const uint32_t nhi_max = b.lanes_nhi_max(P.n_bits);
     hipLaunchKernelGGL(k_scalars_weighted, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.d_desc.p, b.shr.p, b.weights.p, P.n_bits, P.t,
-                       b.max_mn, b.cols, b.B, nhi_max, cm, b.tab.p, b.rows.p, dyn_scal);
+                       b.max_mn, b.cols, b.B, nhi_max, b.tab.p, b.rows.p, dyn_scal);
     // proofs per workgroup: enough (proof, generator pair) items for four passes of the 64 lanes
     const uint32_t ppw = std::max<uint32_t>(1, std::min<uint32_t>(BPP_LANES_MAX_PPW, 256 / std::max<uint32_t>(1, b.max_mn)));
-    hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max, cm), s, b.d_desc.p, b.tab.p,
-                       P.n_bits, b.max_mn, b.cols, b.B, nhi_max, cm, ppw, b.rows.p);
+    hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s, b.d_desc.p, b.tab.p,
+                       P.n_bits, b.max_mn, b.cols, b.B, nhi_max, ppw, b.rows.p);
   }
   tm.mark(M_LANES);
   hipLaunchKernelGGL(k_reduce_static, dim3(cdiv(b.cols, BPP_REDUCE_TILE), b.G), dim3(64), 0, s, b.rows.p, b.group_first.p, b.cols,

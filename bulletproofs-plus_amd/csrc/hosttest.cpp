@@ -23,6 +23,12 @@ void ht_sc9_mul3(const uint8_t a[32], const uint8_t b[32], const uint8_t c[32], 
   sc9_montmul_lazy(t9, x9, y9); sc9_montmul(r, t9, z9); sc_from_mont(r, r); sc_store_words(out, r);
   sc9 p2; for (int i = 0; i < 9; i++) p2.l[i] = SC_POW2_R29[e & 63][i];
   sc9_montmul(r, x9, p2); sc_from_mont(r, r); sc_store_words(out2, r); }
+// a*b + c*d under one reduction (the h-row of k_scalars_lanes)
+void ht_sc9_mul2(const uint8_t a[32], const uint8_t b[32], const uint8_t c[32], const uint8_t d[32], uint8_t out[32]) {
+  sc x, y, z, w, r; sc_load_words(x, a); sc_load_words(y, b); sc_load_words(z, c); sc_load_words(w, d);
+  sc_to_mont(x, x); sc_to_mont(y, y); sc_to_mont(z, z); sc_to_mont(w, w);
+  sc9 x9, y9, z9, w9; sc9_from(x9, x); sc9_from(y9, y); sc9_from(z9, z); sc9_from(w9, w);
+  sc9_montmul2(r, x9, y9, z9, w9); sc_from_mont(r, r); sc_store_words(out, r); }
 void ht_sc_addsub(const uint8_t a[32], const uint8_t b[32], uint8_t sum[32], uint8_t dif[32]) {
   sc x, y, z; sc_load_words(x, a); sc_load_words(y, b); sc_add(z, x, y); sc_store_words(sum, z); sc_sub(z, x, y); sc_store_words(dif, z); }
 void ht_sc_wide(const uint8_t a[64], uint8_t out[32]) { sc z; sc_mont_from_wide(z, a); sc_from_mont(z, z); sc_store_words(out, z); }

@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(64) k_from_uniform(const uint8_t *__restrict__
 // PASS 1, decompression and k_scalars_shared execute; the weights enter in k_scalars_weighted:
 //   k_scalars_shared    1 lane / proof : batch inversion (divsteps), powers, sums -> shr[p][*], and the weight-free
 //                                        low / high tables of k_scalars_lanes -> tab[p][*]              (no weight)
-//   k_scalars_weighted  1 lane / proof : w x (low tables, c2, e^2 z) in place, the dynamic scalars (canonical) and the
+//   k_scalars_weighted  1 lane / proof : w x (low tables, e^2 z) in place, the dynamic scalars (canonical) and the
 //                                        g / h base columns of the proof's row
 //   k_scalars_lanes     1 wave / ppw proofs : tables -> LDS, lanes over (proof, generator index) -> WEIGHTED rows
 //   k_reduce_static                    : per group, column sums of the rows (additions only)
@@ -277,14 +277,17 @@ __global__ void __launch_bounds__(64) k_from_uniform(const uint8_t *__restrict__
 
 // Table block of one proof in HBM (entries of 32 bytes, packed Montgomery scalars), written with one lane per proof and
 // read back by k_scalars_lanes with lanes over entries (coalesced):
-//   glo[8] yn2lo[8] hlo[8] | c2[cm] | ghi[nhi_max] y2hi[nhi_max] shi[nhi_max] | e2z        (meaning: see k_scalars_lanes)
-// cm = largest aggregation factor of the batch (<= 32), nhi_max = 2^(largest round count - 3).
-#define BPP_LANES_LB 3
-BPP_HD constexpr uint32_t lanes_tab_stride(uint32_t nhi_max, uint32_t cm) { return 24u + cm + 3u * nhi_max + 1u; }
+//   glo[8] yn2lo[8] hlo[8] | ghi[nhi_max] y2hi[nhi_max] shi[nhi_max] | e2z        (meaning: see k_scalars_lanes)
+// The generator index splits as i = (hi << LB) | lo with LB = min(3, log2 n_bits) low bits, so that the party of a generator
+// (i / n_bits) is a function of hi alone; nhi_max = 2^(largest round count - LB).
+BPP_HD uint32_t lanes_lb(uint32_t n_bits) {
+  const uint32_t l2 = n_bits ? (uint32_t)__builtin_ctz(n_bits) : 0u;
+  return l2 < 3u ? l2 : 3u;
+}
+BPP_HD constexpr uint32_t lanes_tab_stride(uint32_t nhi_max) { return 24u + 3u * nhi_max + 1u; }
 // shapes the three kernels skip alike (rejected on the host before PASS 2)
-BPP_HD bool lanes_shape_ok(uint32_t rounds, uint32_t m, uint32_t nhi_max, uint32_t cm) {
-  const uint32_t hb = rounds > BPP_LANES_LB ? rounds - BPP_LANES_LB : 0;
-  return rounds <= BPP_MAX_ROUNDS - 1 && m >= 1 && m <= cm && hb < 31 && (1u << hb) <= nhi_max;
+BPP_HD bool lanes_shape_ok(uint32_t rounds, uint32_t m, uint32_t nhi_max, uint32_t lb) {
+  return rounds <= BPP_MAX_ROUNDS - 1 && m >= 1 && m <= 32 && rounds >= lb && (1u << (rounds - lb)) <= nhi_max;
 }
 // this table entry's share of k = i mod n_bits for i = (hi << LB) | lo (n_bits and nlo are powers of two): d[i] carries 2^k
 BPP_HD uint32_t lanes_e2k(bool is_hi, uint32_t v, uint32_t nlo, uint32_t n_bits) {
@@ -327,8 +330,8 @@ __device__ __forceinline__ void sc_load_mont(sc &r, const uint8_t *p) {
 __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
                                                        const uint64_t *__restrict__ minvals, const sc *__restrict__ chal,
                                                        uint32_t n_bits, uint32_t t, uint32_t cs, uint32_t B,
-                                                       sc *__restrict__ shr, uint32_t nhi_max, uint32_t cm,
-                                                       sc *tab /* lanes_tab_stride(nhi_max, cm) entries per proof */) {
+                                                       sc *__restrict__ shr, uint32_t nhi_max,
+                                                       sc *tab /* lanes_tab_stride(nhi_max) entries per proof */) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B) return;
   const ProofDesc d = desc[p];
@@ -454,13 +457,14 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
     sc_load_mont(d1, pd1 + 32 * k);
     o[SH_D1(k)] = d1;
   }
-  // ---- the tables of k_scalars_lanes, before the weight: with i = (hi << LB) | lo
-  //   hlo[lo] = s1e s_lo[lo]   glo[lo] = r1e y^-lo s_lo[lo]   yn2lo[lo] = y^mn y^-lo 2^klo
-  //   shi[hi] = s_hi[hi]       ghi[hi] = y^-(hi << LB) s_hi[hi]   y2hi[hi] = y^-(hi << LB) 2^khi
-  if (!lanes_shape_ok(r, m, nhi_max, cm)) return;
-  const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, HB = r - LB, nlo = 1u << LB, nhi = 1u << HB;
-  sc *T = tab + (size_t)p * lanes_tab_stride(nhi_max, cm);
-  sc *glo = T, *yn2lo = T + 8, *hlo = T + 16, *ghi = T + 24 + cm, *y2hi = ghi + nhi_max, *shi = y2hi + nhi_max;
+  // ---- the tables of k_scalars_lanes, before the weight: with i = (hi << LB) | lo, party = i / n_bits (a function of hi)
+  //   hlo[lo] = s1e s_lo[lo]   glo[lo] = r1e y^-lo s_lo[lo]      yn2lo[lo] = y^mn y^-lo 2^klo
+  //   shi[hi] = s_hi[hi]       ghi[hi] = y^-(hi << LB) s_hi[hi]  y2hi[hi] = y^-(hi << LB) 2^khi z^(2(party+1))
+  const uint32_t LB = lanes_lb(n_bits);
+  if (!lanes_shape_ok(r, m, nhi_max, LB)) return;
+  const uint32_t HB = r - LB, nlo = 1u << LB, nhi = 1u << HB;
+  sc *T = tab + (size_t)p * lanes_tab_stride(nhi_max);
+  sc *glo = T, *yn2lo = T + 8, *hlo = T + 16, *ghi = T + 24, *y2hi = ghi + nhi_max, *shi = y2hi + nhi_max;
   lanes_s_tree(hlo, o, r, 0, LB, one);
   lanes_s_tree(shi, o, r, LB, HB, one);
   {
@@ -481,41 +485,47 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
     }
   }
   {
-    sc yh = one, step = one;
+    sc yh = one, step = one, zz = z_square;  // zz = z^(2(party+1)) of the current entry
     if (HB) step = o[SH_YINVPOW(LB)];
+    const uint32_t per_party = n_bits >> LB;  // high indices per party
     for (uint32_t v = 0; v < nhi; v++) {
       const sc sv = shi[v];
       sc x;
       sc_montmul(x, sv, yh);
       ghi[v] = x;
       sc_mul_pow2(x, yh, lanes_e2k(true, v, nlo, n_bits));
+      sc_montmul(x, x, zz);
       y2hi[v] = x;
-      if (v + 1 < nhi) sc_montmul(yh, yh, step);
+      if (v + 1 < nhi) {
+        sc_montmul(yh, yh, step);
+        if (((v + 1) & (per_party - 1u)) == 0) sc_montmul(zz, zz, z_square);
+      }
     }
   }
 }
 
-// The weighted part of the scalar block, one lane per proof (src/range_proof.rs:894, :1006-1032): w into the low tables, the
-// per-party constants and e^2 z (in place in tab[]), the proof's dynamic scalars and its g / h base columns.  A Montgomery
-// product with one CANONICAL operand is the canonical product, so the dynamic scalars (which k_msm_digits wants
-// canonical) take the weight as it arrives and need no conversion:
+// The weighted part of the scalar block, one lane per proof (src/range_proof.rs:894, :1006-1032): w into the three low
+// tables and e^2 z (in place in tab[]), the proof's dynamic scalars and its g / h base columns.  A Montgomery product with
+// one CANONICAL operand is the canonical product, so the dynamic scalars (which k_msm_digits wants canonical) take the
+// weight as it arrives and need no conversion:
 //   C_j: (-e^2 y^{mn+1} w) z^{2(j+1)};  A1: -e w;  B: -w;  A: -e^2 w;  L_j: (-e^2 w) e_j^2;  R_j: (-e^2 w) e_j^-2
 __global__ void __launch_bounds__(64) k_scalars_weighted(const ProofDesc *__restrict__ desc, const sc *__restrict__ shr,
                                                          const uint8_t *__restrict__ weights32, uint32_t n_bits, uint32_t t,
-                                                         uint32_t max_mn, uint32_t cols, uint32_t B, uint32_t nhi_max, uint32_t cm,
+                                                         uint32_t max_mn, uint32_t cols, uint32_t B, uint32_t nhi_max,
                                                          sc *tab, sc *__restrict__ rows, sc *__restrict__ dyn_out) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B) return;
   const ProofDesc d = desc[p];
   const uint32_t r = d.rounds, m = d.m;
-  if (!lanes_shape_ok(r, m, nhi_max, cm)) return;
+  const uint32_t LB = lanes_lb(n_bits), nlo = 1u << LB;
+  if (!lanes_shape_ok(r, m, nhi_max, LB)) return;
   const sc *S = shr + (size_t)p * SH_STRIDE;
-  const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, nlo = 1u << LB;
-  sc *T = tab + (size_t)p * lanes_tab_stride(nhi_max, cm);
-  sc *glo = T, *hlo = T + 16, *c2t = T + 24, *e2z = T + 24 + cm + 3 * nhi_max;
-  sc wc, w;
+  sc *T = tab + (size_t)p * lanes_tab_stride(nhi_max);
+  sc *glo = T, *yn2lo = T + 8, *hlo = T + 16, *e2z = T + 24 + 3 * nhi_max;
+  sc wc, w, ne2w_m;
   sc_load_words(wc, weights32 + (size_t)p * 32);
   sc_to_mont(w, wc);
+  sc_montmul(ne2w_m, S[SH_NEG_E2], w);  // -w e^2, Montgomery
   for (uint32_t v = 0; v < nlo; v++) {
     sc x = glo[v];
     sc_montmul(x, x, w);
@@ -523,24 +533,26 @@ __global__ void __launch_bounds__(64) k_scalars_weighted(const ProofDesc *__rest
     x = hlo[v];
     sc_montmul(x, x, w);
     hlo[v] = x;
+    x = yn2lo[v];
+    sc_montmul(x, x, ne2w_m);  // -w e^2 y^mn y^-lo 2^klo
+    yn2lo[v] = x;
+  }
+  {
+    sc x;
+    sc_montmul(x, S[SH_E2Z], w);
+    *e2z = x;
   }
   sc *dyn = dyn_out + d.dyn_off;
   {
     const sc z_square = S[SH_Z2];
-    sc e2w, nyw, zz = z_square;
-    sc_montmul(e2w, S[SH_E2], w);
+    sc nyw, zz = z_square;
     sc_montmul(nyw, S[SH_NEG_E2_YNM1], wc);
     for (uint32_t j = 0; j < m; j++) {
       sc x;
-      sc_montmul(x, zz, e2w);
-      c2t[j] = x;  // w e^2 z^(2(j+1))
       sc_montmul(x, zz, nyw);
       dyn[j] = x;
       if (j + 1 < m) sc_montmul(zz, zz, z_square);
     }
-    sc x;
-    sc_montmul(x, S[SH_E2Z], w);
-    *e2z = x;
   }
   {
     sc x, ne;
@@ -573,21 +585,21 @@ __global__ void __launch_bounds__(64) k_scalars_weighted(const ProofDesc *__rest
 
 // Generator scalars.  With i = (hi << LB) | lo, s[i] = slo[lo]*shi[hi] and y^-i = ylo[lo]*yhi[hi] (products over the bits of
 // i), so every per-index quantity is ONE product of a "low" and a "high" table entry:
-//   g[i]            = w r1e y^-i s[i]          = glo[lo]   * ghi[hi]      glo = w*r1e*ylo*slo,  ghi = yhi*shi
-//   2^k * y^(mn-i)  = y^mn * y^-i * 2^k        = yn2lo[lo] * y2hi[hi]     k = i mod n (the 2^k of d[i] = z^(2(j+1)) 2^k,
-//                                                                         src/range_proof.rs:919-929, split over the two tables:
-//                                                                         k = klo(lo) + khi(hi); x 2^e = one product with the
-//                                                                         constant 2^e R mod l, SC_POW2_R29)
-//   h[i]            = w s1e s[mn-1-i]          = hlo[~lo]  * shi[~hi]     hlo = w*s1e*slo
-// so a generator pair costs FOUR Montgomery products: g[i], 2^k y^(mn-i), c2[party] * that (c2 = w e^2 z^(2(party+1))),
-// h[i]; the additive constant is e2z = w e^2 z.  The proof's batch weight w (src/range_proof.rs:894) sits in glo, hlo, c2 and
-// e2z, so the rows come out WEIGHTED and the per-group column sums need no product at all (round 1 produced unweighted
-// rows so that this stage could overlap the host weight chain, and paid 2 products per generator pair in
-// k_reduce_static).  The tables come from tab[] (k_scalars_shared, k_scalars_weighted), are unpacked ONCE per entry into
-// nine 29-bit limbs in LDS (sc9) instead of once per use, and the middle product stays in limbs.  Dynamic LDS per proof:
-//   sc9: glo[8] yn2lo[8] hlo[8] | c2[cm] | ghi[nhi_max] y2hi[nhi_max] shi[nhi_max]      sc: e2z
-BPP_HD constexpr uint32_t lanes_lds_bytes(uint32_t nhi_max, uint32_t cm) {
-  return (lanes_tab_stride(nhi_max, cm) - 1u) * (uint32_t)sizeof(sc9) + (uint32_t)sizeof(sc);
+//   g[i]                     = w r1e y^-i s[i]                 = glo[lo]   * ghi[hi]    glo = w*r1e*ylo*slo,  ghi = yhi*shi
+//   -w e^2 d[i] y^(mn-i)     = -w e^2 y^mn y^-i 2^k z^(2(j+1)) = yn2lo[lo] * y2hi[hi]   d[i] = z^(2(j+1)) 2^k with party j = i / n
+//                                                               and k = i mod n (src/range_proof.rs:919-929); k = klo(lo) + khi(hi),
+//                                                               x 2^e is one product with the constant 2^e R mod l (SC_POW2_R29); j
+//                                                               depends on hi alone (LB <= log2 n), so z^(2(j+1)) sits in y2hi
+//   h[i]                     = w s1e s[mn-1-i]                 = hlo[~lo]  * shi[~hi]   hlo = w*s1e*slo
+// A generator pair costs THREE products under TWO reductions: g[i] + e2z, and h[i] - w e^2 (d[i] y^(mn-i) + z) =
+// (hlo*shi + yn2lo*y2hi) - e2z with both products accumulated in the same columns (sc9_montmul2); e2z = w e^2 z.  The proof's
+// batch weight w (src/range_proof.rs:894) sits in the three low tables and e2z, so the rows come out WEIGHTED and the
+// per-group column sums need no product at all (round 1: 5 products per pair here and 2 more in k_reduce_static).  The tables
+// come from tab[] (k_scalars_shared, k_scalars_weighted) and are unpacked ONCE per entry into nine 29-bit limbs in LDS
+// (sc9) instead of once per use.  Dynamic LDS per proof:
+//   sc9: glo[8] yn2lo[8] hlo[8] | ghi[nhi_max] y2hi[nhi_max] shi[nhi_max]      sc: e2z
+BPP_HD constexpr uint32_t lanes_lds_bytes(uint32_t nhi_max) {
+  return (lanes_tab_stride(nhi_max) - 1u) * (uint32_t)sizeof(sc9) + (uint32_t)sizeof(sc);
 }
 
 // One workgroup serves `ppw` consecutive proofs (a 64-bit single-commitment proof has 64 generator pairs: four proofs
@@ -595,20 +607,21 @@ BPP_HD constexpr uint32_t lanes_lds_bytes(uint32_t nhi_max, uint32_t cm) {
 #define BPP_LANES_MAX_PPW 8
 __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restrict__ desc, const sc *__restrict__ tab,
                                                       uint32_t n_bits, uint32_t max_mn, uint32_t cols, uint32_t B,
-                                                      uint32_t nhi_max, uint32_t cm, uint32_t ppw,
+                                                      uint32_t nhi_max, uint32_t ppw,
                                                       sc *__restrict__ rows /* weighted, Montgomery */) {
   const uint32_t p0 = blockIdx.x * ppw;
   const uint32_t lane = threadIdx.x;
   extern __shared__ uint32_t lanes_lds_raw[];
   __shared__ uint32_t s_r[BPP_LANES_MAX_PPW], s_m[BPP_LANES_MAX_PPW];
-  const uint32_t ts = lanes_tab_stride(nhi_max, cm), n9 = ts - 1u;  // entries per proof: n9 as limbs, then e2z packed
-  const uint32_t per_bytes = lanes_lds_bytes(nhi_max, cm);
+  const uint32_t ts = lanes_tab_stride(nhi_max), n9 = ts - 1u;  // entries per proof: n9 as limbs, then e2z packed
+  const uint32_t per_bytes = lanes_lds_bytes(nhi_max);
+  const uint32_t LB = lanes_lb(n_bits), nlo = 1u << LB;
   if (lane < ppw) {
     const uint32_t p = p0 + lane;
     uint32_t r = ~0u, m = 0;
     if (p < B) {
       const ProofDesc d = desc[p];
-      if (lanes_shape_ok(d.rounds, d.m, nhi_max, cm)) r = d.rounds;
+      if (lanes_shape_ok(d.rounds, d.m, nhi_max, LB)) r = d.rounds;
       m = d.m;
     }
     s_r[lane] = r;  // ~0: nothing to do for this slot (past the end, or a shape rejected on the host before PASS 2)
@@ -636,27 +649,20 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     const uint32_t r = s_r[sub];
     if (r == ~0u) continue;
     const uint32_t mn = s_m[sub] * n_bits;
-    const uint32_t LB = r < BPP_LANES_LB ? r : BPP_LANES_LB, HB = r - LB;
-    const uint32_t nlo = 1u << LB, nhi = 1u << HB;
+    const uint32_t nhi = 1u << (r - LB);
     const sc9 *T = reinterpret_cast<const sc9 *>(reinterpret_cast<const uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes);
-    const sc9 *glo = T, *yn2lo = T + 8, *hlo = T + 16, *c2t = T + 24;
-    const sc9 *ghi = T + 24 + cm, *y2hi = ghi + nhi_max, *shi = y2hi + nhi_max;
+    const sc9 *glo = T, *yn2lo = T + 8, *hlo = T + 16;
+    const sc9 *ghi = T + 24, *y2hi = ghi + nhi_max, *shi = y2hi + nhi_max;
     sc *row = rows + (size_t)(p0 + sub) * cols;
     sc gi, hi;
     if (i < mn) {
       const sc e_square_z = *reinterpret_cast<const sc *>(reinterpret_cast<const uint8_t *>(T) + (size_t)n9 * sizeof(sc9));  // w e^2 z
-      const uint32_t lo = i & (nlo - 1), hi_i = i >> LB;
+      const uint32_t lo = i & (nlo - 1), hi_i = (i >> LB) & (nhi - 1);
       const uint32_t rlo = (~lo) & (nlo - 1), rhi = (~hi_i) & (nhi - 1);
-      const uint32_t party = i / n_bits;  // d[i] = z^{2(party+1)} * 2^k, k = i % n_bits  (:919-929)
-      sc u;
-      sc9 t9;
       sc9_montmul(gi, glo[lo], ghi[hi_i]);
       sc_add(gi, gi, e_square_z);
-      sc9_montmul_lazy(t9, yn2lo[lo], y2hi[hi_i]);  // 2^k y^{mn-i}, left in limbs
-      sc9_montmul(u, c2t[party], t9);               // w e^2 d[i] y^{mn-i}
-      sc_add(u, u, e_square_z);                     // w e^2 (d[i] y^{mn-i} + z)
-      sc9_montmul(hi, hlo[rlo], shi[rhi]);
-      sc_sub(hi, hi, u);
+      sc9_montmul2(hi, hlo[rlo], shi[rhi], yn2lo[lo], y2hi[hi_i]);  // w (s1e s[mn-1-i] - e^2 d[i] y^(mn-i))
+      sc_sub(hi, hi, e_square_z);
     } else {
       sc_0(gi);
       sc_0(hi);

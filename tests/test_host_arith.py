@@ -67,6 +67,9 @@ def test_scalar(ht):
             ht.ht_sc9_mul3(ab, b.to_bytes(32, "little"), c.to_bytes(32, "little"), e, o, o2)
             assert int.from_bytes(o.raw, "little") == a * b * c % L
             assert int.from_bytes(o2.raw, "little") == a * (1 << e) % L
+            d = vals[(k * 11 + 1) % len(vals)]
+            ht.ht_sc9_mul2(ab, b.to_bytes(32, "little"), c.to_bytes(32, "little"), d.to_bytes(32, "little"), o)
+            assert int.from_bytes(o.raw, "little") == (a * b + c * d) % L
         assert ht.ht_sc_canonical(ab) == (1 if a < L else 0)
         o = _buf()
         ht.ht_sc_invert((a % L).to_bytes(32, "little"), o)
