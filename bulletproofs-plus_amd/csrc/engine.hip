@@ -264,8 +264,12 @@ struct Batch {
   uint64_t params_handle = 0;
   uint32_t B = 0, rmax = 0, cs = 0, max_mn = 0, total_dyn = 0, sum_m = 0, cols = 0;
   // shape of the per-proof table block of the scalar stage (kernels_verify.h: lanes_tab_stride)
+  // A proof that claims more rounds than its statement's m * n_bits has bits is refused on the host; the table blocks are
+  // sized for the statements (max_mn), so that one such proof cannot inflate the allocation of the whole batch.
   uint32_t lanes_nhi_max(uint32_t n_bits) const {
-    const uint32_t rm = std::min(rmax, (uint32_t)BPP_MAX_ROUNDS - 1), lb = lanes_lb(n_bits);
+    uint32_t cap = 0;
+    while ((2u << cap) <= std::max<uint32_t>(max_mn, 1)) cap++;  // floor(log2(max_mn))
+    const uint32_t rm = std::min({rmax, (uint32_t)BPP_MAX_ROUNDS - 1, cap}), lb = lanes_lb(n_bits);
     return 1u << (rm > lb ? rm - lb : 0);
   }
   std::vector<ProofDesc> desc;
@@ -940,7 +944,10 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
     const uint32_t dyn = pl.total_dyn;
     B->total_dyn = dyn;
     B->sum_m = (uint32_t)sum_m;
-    B->cs = B->rmax + 3;
+    // challenge slots per proof: y, z, e_0.., e_final.  A proof claiming more rounds than any statement can have (mn <= 2048)
+    // is refused on the host; its transcript is still replayed for the error precedence, its challenges are not kept, so
+    // one such proof cannot inflate the whole batch's buffers.
+    B->cs = std::min(B->rmax, (uint32_t)BPP_MAX_ROUNDS - 1) + 3;
     B->cols = 2 * B->max_mn + P.t + 1;
     // device copies (all sources page-locked: the copies are real stream-ordered DMA)
     hipStream_t s = ctx->stream;
@@ -1002,7 +1009,7 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
           sc_load_words(v, c);
           if (sc_iszero(v)) B->ext_status[i] |= BPP_ST_TRANSCRIPT_FAIL;  // transcript_protocol.rs:71-77
           sc_to_mont(v, v);
-          hc[i * B->cs + k] = v;
+          if (k < B->cs) hc[i * B->cs + k] = v;
         }
         // validate_and_append_point (transcript_protocol.rs:48-61): A, A1, B, L_j, R_j must not be the identity encoding
         if (B->defer[i] & BPP_DEFER_DEGREE) continue;  // other layout: its chunk fails before PASS 1 is looked at
@@ -1568,7 +1575,7 @@ int bpp_batch_shape(bpp_ctx *ctx, uint64_t batch, uint32_t *n_items, uint32_t *m
   if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle");
   Batch &b = *it->second;
   if (n_items) *n_items = b.B;
-  if (max_rounds) *max_rounds = b.rmax;
+  if (max_rounds) *max_rounds = b.cs - 3;  // rounds the challenge trace has slots for (capped at BPP_MAX_ROUNDS - 1)
   if (max_mn) *max_mn = b.max_mn;
   if (total_dyn) *total_dyn = b.total_dyn;
   if (groups) *groups = b.G;

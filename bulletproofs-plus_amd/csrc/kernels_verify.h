@@ -80,13 +80,13 @@ __global__ void __launch_bounds__(64, BPP_TRANSCRIPTS_WAVES) k_transcripts(const
     merlin_append_message(s, (const uint8_t *)"L", 1, pLR + 64 * j, 32);
     merlin_append_message(s, (const uint8_t *)"R", 1, pLR + 64 * j + 32, 32);
     ok = dev_challenge(s, (const uint8_t *)"e", 1, v) && ok;
-    c[2 + j] = v;
+    if (j + 3 < cs) c[2 + j] = v;  // cs covers every well-formed proof; an oversized one is replayed for its status only
   }
   ok = ok && !bytes32_all_zero(pA1) && !bytes32_all_zero(pB);
   merlin_append_message(s, (const uint8_t *)"A1", 2, pA1, 32);
   merlin_append_message(s, (const uint8_t *)"B", 1, pB, 32);
   ok = dev_challenge(s, (const uint8_t *)"e", 1, v) && ok;
-  c[2 + d.rounds] = v;
+  if (d.rounds + 3 <= cs) c[2 + d.rounds] = v;
   // to_verifier_rng (src/transcripts.rs:166-179) + NullRng finalize + 32 bytes (src/range_proof.rs:845-848)
   merlin_append_message(s, (const uint8_t *)"r1", 2, pr1, 32);
   merlin_append_message(s, (const uint8_t *)"s1", 2, ps1, 32);
@@ -164,13 +164,13 @@ __global__ void __launch_bounds__(64) k_transcripts_wave(const uint8_t *__restri
     wm_append_message(s, K, "L", 1, BytesAt{pLR + 64 * j}, 32);
     wm_append_message(s, K, "R", 1, BytesAt{pLR + 64 * j + 32}, 32);
     ok = wave_challenge(s, L, K, "e", 1, v) && ok;
-    if (lane == 0) c[2 + j] = v;
+    if (lane == 0 && j + 3 < cs) c[2 + j] = v;
   }
   ok = ok && wave_nonzero32(pA1) && wave_nonzero32(pB);
   wm_append_message(s, K, "A1", 2, BytesAt{pA1}, 32);
   wm_append_message(s, K, "B", 1, BytesAt{pB}, 32);
   ok = wave_challenge(s, L, K, "e", 1, v) && ok;
-  if (lane == 0) c[2 + d.rounds] = v;
+  if (lane == 0 && d.rounds + 3 <= cs) c[2 + d.rounds] = v;
   // to_verifier_rng (src/transcripts.rs:166-179) + NullRng finalize + 32 bytes (src/range_proof.rs:845-848)
   wm_append_message(s, K, "r1", 2, BytesAt{pr1}, 32);
   wm_append_message(s, K, "s1", 2, BytesAt{ps1}, 32);
@@ -809,6 +809,7 @@ __global__ void __launch_bounds__(64) k_masks(const uint8_t *__restrict__ bytes,
   const uint8_t *seed = seeds32 + (size_t)p * 32;
   const uint8_t *pd1 = bytes + d.proof_off + 1;
   const uint32_t r = d.rounds, mn = d.m * n_bits;
+  if (r + 3 > cs) return;  // more rounds than any statement allows: refused on the host, its challenges were not kept
   sc y = c[0], z = c[1], ef = c[2 + r];
   sc e_square, e_square_inv, z_square, y_nm_1, zy_inv, tmp;
   sc_montsq(e_square, ef);

@@ -191,7 +191,8 @@ int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_item *items, 
                     size_t proof_stride, size_t *proof_len, char *errbuf, size_t errbuf_len);
 
 /* ---- parity / diagnostics: intermediates of the last verify on `batch`, for differential tests ---- */
-#define BPP_TRACE_CHALLENGES 1     /* per proof (rmax+3) x 32: y, z, e_0.., e_final (canonical), rmax = max rounds */
+#define BPP_TRACE_CHALLENGES 1     /* per proof (rmax+3) x 32: y, z, e_0.., e_final (canonical), rmax = bpp_batch_shape's max_rounds
+                                      (largest round count in the batch, at most 11: proofs claiming more are refused) */
 #define BPP_TRACE_RNG_OUT 2        /* n x 32 */
 #define BPP_TRACE_WEIGHTS 3        /* n x 32 */
 #define BPP_TRACE_STATIC_SCALARS 4 /* groups x (2*max_mn + t + 1) x 32: gi0,hi0,gi1,hi1,...,g_0..g_{t-1},h */

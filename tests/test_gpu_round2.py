@@ -154,3 +154,28 @@ def test_params_outlive_destroy_while_batch_resident(bpp):
     with pytest.raises(bpp.EngineError):
         bpp.ResidentBatch(c.transcripts(), c.statements_public, c.proofs)
     eng.close()
+
+
+def test_oversized_proof_does_not_inflate_the_batch(bpp, engine):
+    """a proof claiming far more rounds than any statement allows (mn <= 2048 -> at most 11) is refused with the reference's
+    InvalidLength (:886-888; SizeOverflow from 32 rounds on, :882-885) -- next to valid proofs and in its own chunk -- and the
+    batch's per-proof buffers stay
+    sized for the statements: challenge slots are capped (shape()['max_rounds'] <= 11), so are the scalar-stage tables"""
+    K, A = bpp.ProofErrorKind, bpp.VerifyAction
+    c = make_batch(bpp, engine, 8, [1, 1, 1, 1], 1, seed=b"oversized")
+    raw = c.proofs[1].to_bytes()
+    lr = raw[-64:]
+    for extra, want in ((1, K.InvalidLength), (9, K.InvalidLength), (40, K.SizeOverflow)):  # 4, 12, 43 rounds; the statement has 3
+        big = bpp.RangeProof.from_bytes(raw + lr * extra)
+        proofs = [c.proofs[0], big, c.proofs[2], c.proofs[3]]
+        V = lambda chunk: bpp.RangeProof.verify_batch(c.transcripts(), c.statements_public, proofs, A.VerifyOnly, chunk=chunk)
+        assert _kind(bpp, lambda: V(0)) == want
+        assert _kind(bpp, lambda: V(1)) == want  # chunk 0 verifies, chunk 1 (the oversized proof alone) fails
+        assert _kind(bpp, lambda: V(2)) == want
+        rb = bpp.ResidentBatch(c.transcripts(), c.statements_public, proofs)
+        assert rb.shape()["max_rounds"] <= 11
+        assert _kind(bpp, lambda: rb.verify(A.VerifyOnly, chunk=1)) == want
+        assert len(rb.trace(1)) == 4 * (rb.shape()["max_rounds"] + 3) * 32
+        rb.close()
+    # the same proofs without the oversized one still verify on the same engine
+    assert bpp.RangeProof.verify_batch(c.transcripts(), c.statements_public, c.proofs, A.VerifyOnly, chunk=2) == [None] * 4
