@@ -1109,8 +1109,14 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
                      b.idx_proof.p, n_proof_pts, b.dynpts.p, b.status.p);
   tm.mark(M_DECOMPRESS);
   if (!pass1_only) {  // the weight-independent part of the PASS-2 scalars; the rest (k_scalars_lanes) takes the weights
+    // tables of the generator-row kernel: by the same lane for large inputs, one wavefront per proof for small ones
+    const char *ft = getenv("BPP_TABLES_WAVE");  // tests force either form
+    const bool tw = ft ? atoi(ft) != 0 : b.B <= BPP_TABLES_WAVE_MAX;
     hipLaunchKernelGGL(k_scalars_shared, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.chal.p,
-                       P.n_bits, P.t, b.cs, b.B, b.shr.p, b.lanes_nhi_max(P.n_bits), b.tab.p);
+                       P.n_bits, P.t, b.cs, b.B, b.shr.p, b.lanes_nhi_max(P.n_bits), tw ? (sc *)nullptr : b.tab.p);
+    if (tw)
+      hipLaunchKernelGGL(k_scalars_tables_wave, dim3(b.B), dim3(64), 0, s, b.d_desc.p, b.shr.p, P.n_bits, b.B,
+                         b.lanes_nhi_max(P.n_bits), b.tab.p);
     tm.mark(M_SCALARS);
   }
   HIP_CHECK(hipGetLastError());

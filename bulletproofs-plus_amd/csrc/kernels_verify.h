@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(64, BPP_TRANSCRIPTS_WAVES) k_transcripts(const
 // Per proof it uses ~7x the issue slots of the one-lane kernel but finishes in a fifth of the time, so the host picks
 // it for small batches (B <= BPP_TRANSCRIPTS_WAVE_MAX), where PASS 1 is pure latency on a nearly idle chip.
 #define BPP_TRANSCRIPTS_WAVE_MAX 4096u
+#define BPP_TABLES_WAVE_MAX 2048u  // same idea for the scalar-stage tables (k_scalars_tables_wave)
 struct TranscriptLds {
   uint64_t st[25];
   uint8_t buf[64];
@@ -460,6 +461,7 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
   // ---- the tables of k_scalars_lanes, before the weight: with i = (hi << LB) | lo, party = i / n_bits (a function of hi)
   //   hlo[lo] = s1e s_lo[lo]   glo[lo] = r1e y^-lo s_lo[lo]      yn2lo[lo] = y^mn y^-lo 2^klo
   //   shi[hi] = s_hi[hi]       ghi[hi] = y^-(hi << LB) s_hi[hi]  y2hi[hi] = y^-(hi << LB) 2^khi z^(2(party+1))
+  if (!tab) return;  // small inputs: k_scalars_tables_wave builds them, one wavefront per proof
   const uint32_t LB = lanes_lb(n_bits);
   if (!lanes_shape_ok(r, m, nhi_max, LB)) return;
   const uint32_t HB = r - LB, nlo = 1u << LB, nhi = 1u << HB;
@@ -500,6 +502,58 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
         sc_montmul(yh, yh, step);
         if (((v + 1) & (per_party - 1u)) == 0) sc_montmul(zz, zz, z_square);
       }
+    }
+  }
+}
+
+// The same weight-free tables for small inputs (a few hundred proofs: one lane per proof would leave the chip idle behind a
+// chain of ~85 dependent products): one wavefront per proof, one lane per table entry, every entry straight from the bits
+// of its index (at most 3 + 3 + 5 products deep, HB more for large aggregations).  Same values as k_scalars_shared writes.
+__global__ void __launch_bounds__(64) k_scalars_tables_wave(const ProofDesc *__restrict__ desc, const sc *__restrict__ shr,
+                                                            uint32_t n_bits, uint32_t B, uint32_t nhi_max, sc *__restrict__ tab) {
+  const uint32_t p = blockIdx.x;
+  if (p >= B) return;
+  const ProofDesc d = desc[p];
+  const uint32_t r = d.rounds, m = d.m;
+  const uint32_t LB = lanes_lb(n_bits);
+  if (!lanes_shape_ok(r, m, nhi_max, LB)) return;
+  const uint32_t HB = r - LB, nlo = 1u << LB, nhi = 1u << HB;
+  const sc *S = shr + (size_t)p * SH_STRIDE;
+  sc *T = tab + (size_t)p * lanes_tab_stride(nhi_max);
+  sc *glo = T, *yn2lo = T + 8, *hlo = T + 16, *ghi = T + 24, *y2hi = ghi + nhi_max, *shi = y2hi + nhi_max;
+  sc one;
+  sc_mont_one(one);
+  for (uint32_t it = threadIdx.x; it < nlo + nhi; it += 64) {
+    const bool is_hi = it >= nlo;
+    const uint32_t v = is_hi ? it - nlo : it, b0 = is_hi ? LB : 0, nbits = is_hi ? HB : LB;
+    sc sv = one, yv = one;
+    for (uint32_t bb = 0; bb < nbits; bb++) {
+      const uint32_t b = b0 + bb, j = r - 1 - b;
+      const bool bit = (v >> bb) & 1u;
+      const sc f = bit ? S[SH_EJ(j)] : S[SH_EINV(j)];
+      const sc yp = bit ? S[SH_YINVPOW(b)] : one;
+      sc_montmul(sv, sv, f);
+      sc_montmul(yv, yv, yp);
+    }
+    sc x;
+    if (is_hi) {
+      shi[v] = sv;
+      sc_montmul(x, yv, sv);
+      ghi[v] = x;
+      sc zz;
+      sc_mont_pow_u32(zz, S[SH_Z2], (v >> (__builtin_ctz(n_bits) - LB)) + 1u);  // z^(2(party+1)), party = (v << LB) / n_bits
+      sc_mul_pow2(x, yv, lanes_e2k(true, v, nlo, n_bits));
+      sc_montmul(x, x, zz);
+      y2hi[v] = x;
+    } else {
+      sc_montmul(x, sv, S[SH_S1E]);
+      hlo[v] = x;
+      sc_montmul(x, yv, S[SH_R1E]);
+      sc_montmul(x, x, sv);
+      glo[v] = x;
+      sc_montmul(x, yv, S[SH_YNM]);
+      sc_mul_pow2(x, x, lanes_e2k(false, v, nlo, n_bits));
+      yn2lo[v] = x;
     }
   }
 }

@@ -163,6 +163,23 @@ def test_both_pass1_kernels(bpp, engine, monkeypatch, wave):
     assert e.value.kind == bpp.ProofErrorKind.VerificationFailed
 
 
+@pytest.mark.parametrize("wave", ["0", "1"])
+@pytest.mark.parametrize("n,ms", [(16, [1, 2, 1, 4]), (2, [1, 4, 2]), (64, [8, 1])])
+def test_both_table_kernels(bpp, engine, monkeypatch, wave, n, ms):
+    """the tables of the generator-row kernel are built by one lane per proof (large inputs) or one wavefront per proof (small
+    inputs); force each: static and dynamic MSM scalars must equal the oracle's for mixed aggregation and small bit lengths"""
+    monkeypatch.setenv("BPP_TABLES_WAVE", wave)
+    case = make_batch(bpp, engine, n, ms, 2, seed=b"table-kernels-%d" % n)
+    _, tr = oracle_verify_trace(case, action=0)
+    rb = bpp.ResidentBatch(case.transcripts(), case.statements_public, case.proofs)
+    assert rb.verify(bpp.VerifyAction.VerifyOnly, chunk=0) == [None] * len(ms)
+    static = b"".join(sb(g) + sb(h) for g, h in zip(tr["gi"], tr["hi"])) + b"".join(sb(x) for x in tr["g"]) + sb(tr["h"])
+    assert rb.trace(4) == static
+    assert rb.trace(5) == b"".join(sb(x) for x in tr["dynamic_scalars"])
+    assert rb.trace(6) == tr["msm_result"] == bytes(32)
+    rb.close()
+
+
 @pytest.mark.parametrize("quad", ["0", "1"])
 def test_both_bucket_kernel_forms(bpp, engine, monkeypatch, quad):
     """bucket accumulation / row-column reduction exist in a one-lane-per-bucket form (many buckets) and a quad form (few
