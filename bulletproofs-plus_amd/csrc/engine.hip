@@ -288,6 +288,7 @@ struct Batch {
   DevBuf<sc> chal, rows, scal, shr, tab;
   DevBuf<uint8_t> rng_out, weights, masks, chal_bytes;
   DevBuf<uint32_t> status, group_first, group_dlo;
+  DevBuf<uint32_t> dec_spill;  // k_decompress parks three field elements per proof point here across its squaring chain
   DevBuf<niels> dynpts;
   MsmWork msm;
   // layout of the last verify
@@ -306,7 +307,7 @@ void adopt_buffers(Batch &dst, Batch &src) {
   BPP_ADOPT(d_ext_status); BPP_ADOPT(bytes); BPP_ADOPT(states); BPP_ADOPT(seeds); BPP_ADOPT(d_desc); BPP_ADOPT(minvals);
   BPP_ADOPT(src_off); BPP_ADOPT(owner); BPP_ADOPT(idx_commit); BPP_ADOPT(idx_proof); BPP_ADOPT(status0); BPP_ADOPT(chal);
   BPP_ADOPT(rows); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(tab); BPP_ADOPT(rng_out); BPP_ADOPT(weights);
-  BPP_ADOPT(masks); BPP_ADOPT(chal_bytes); BPP_ADOPT(status); BPP_ADOPT(group_first); BPP_ADOPT(group_dlo); BPP_ADOPT(dynpts);
+  BPP_ADOPT(masks); BPP_ADOPT(chal_bytes); BPP_ADOPT(status); BPP_ADOPT(group_first); BPP_ADOPT(group_dlo); BPP_ADOPT(dynpts); BPP_ADOPT(dec_spill);
   BPP_ADOPT(msm.digits); BPP_ADOPT(msm.counts); BPP_ADOPT(msm.starts); BPP_ADOPT(msm.sorted); BPP_ADOPT(msm.order);
   BPP_ADOPT(msm.order_hist); BPP_ADOPT(msm.buckets); BPP_ADOPT(msm.Q); BPP_ADOPT(msm.W); BPP_ADOPT(msm.R); BPP_ADOPT(msm.comp32);
   BPP_ADOPT(msm.is_identity); BPP_ADOPT(msm.term_sidx); BPP_ADOPT(msm.term_pidx); BPP_ADOPT(msm.group_off);
@@ -385,6 +386,14 @@ struct StageTimer {
 };
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+static bool decompress_spill_enabled() {
+  static const bool on = [] {
+    const char *e = getenv("BPP_DECOMPRESS_SPILL");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return on;
+}
 
 
 // ------------------------------------------------------------------ MSM driver
@@ -985,6 +994,7 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
     B->weights.alloc(n_items * 32);
     B->status.alloc(n_items);
     B->dynpts.alloc(dyn);
+    if (decompress_spill_enabled()) B->dec_spill.alloc((size_t)30 * (dyn - B->sum_m));
     B->rows.alloc((size_t)n_items * B->cols);
     B->shr.alloc((size_t)n_items * SH_STRIDE);
     B->tab.alloc((size_t)n_items * lanes_tab_stride(B->lanes_nhi_max(P.n_bits)));
@@ -1038,7 +1048,7 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
       HIP_CHECK(hipMemsetAsync(B->status0.p, 0, n_items * 4, s));
     if (B->sum_m)
       hipLaunchKernelGGL(k_decompress, dim3(cdiv(B->sum_m, 64)), dim3(64), 0, s, B->bytes.p, B->src_off.p, B->owner.p,
-                         B->idx_commit.p, B->sum_m, B->dynpts.p, B->status0.p);
+                         B->idx_commit.p, B->sum_m, B->dynpts.p, B->status0.p, (uint32_t *)nullptr);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(s));
     const uint64_t h = g_next_handle.fetch_add(1);
@@ -1106,7 +1116,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
   HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
   const uint32_t n_proof_pts = b.total_dyn - b.sum_m;
   hipLaunchKernelGGL(k_decompress, dim3(cdiv(n_proof_pts, 64)), dim3(64), 0, s, b.bytes.p, b.src_off.p, b.owner.p,
-                     b.idx_proof.p, n_proof_pts, b.dynpts.p, b.status.p);
+                     b.idx_proof.p, n_proof_pts, b.dynpts.p, b.status.p, b.dec_spill.p);
   tm.mark(M_DECOMPRESS);
   if (!pass1_only) {  // the weight-independent part of the PASS-2 scalars; the rest (k_scalars_lanes) takes the weights
     // tables of the generator-row kernel: by the same lane for large inputs, one wavefront per proof for small ones

@@ -189,13 +189,14 @@ __global__ void __launch_bounds__(64) k_transcripts_wave(const uint8_t *__restri
 // one lane per point.  src_off[i] = byte offset in bytes[]; owner[i] = proof index | (is_commitment << 31).
 __global__ void __launch_bounds__(64, BPP_DECOMPRESS_WAVES) k_decompress(const uint8_t *__restrict__ bytes, const uint32_t *__restrict__ src_off,
                                                    const uint32_t *__restrict__ owner, const uint32_t *__restrict__ idx, uint32_t n,
-                                                   niels *__restrict__ out, uint32_t *__restrict__ status) {
+                                                   niels *__restrict__ out, uint32_t *__restrict__ status,
+                                                   uint32_t *__restrict__ spill /* [30][n] words or null */) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t e = idx[i];  // dynamic slot: the statement's commitments are decoded once at upload (the reference's
                               // RangeStatement holds points), the proof's own points on every verification
   niels q;
-  bool ok = ristretto_decompress_lean(q, bytes + src_off[e]);
+  bool ok = ristretto_decompress_lean(q, bytes + src_off[e], spill ? spill + i : nullptr, n);
   if (!ok) {
     niels_identity(q);
     uint32_t o = owner[e];
