@@ -14,6 +14,7 @@
 #include "layout.h"
 #include "merlin.h"
 #include "wstrobe.h"
+#include "lstrobe.h"
 #include "point.h"
 #include "scalar.h"
 
@@ -37,66 +38,71 @@ __device__ __forceinline__ bool dev_challenge(Strobe &s, const uint8_t *label, u
 // RangeProofTranscript::new / challenges_y_z / challenge_round_e / challenge_final_e / to_verifier_rng
 // (src/transcripts.rs:59-179); the intermediate build_rng() clones are dead for a verifier and skipped.
 #ifndef BPP_TRANSCRIPTS_WAVES
-#define BPP_TRANSCRIPTS_WAVES 5  // 96 VGPRs: a PASS-1 wavefront (latency-bound, resident for a long time) then fits next to three k_msm_accumulate wavefronts on a SIMD
+#define BPP_TRANSCRIPTS_WAVES 3  // the 12.8 KB LDS sponge of a wavefront (lstrobe.h) allows 12 wavefronts per CU anyway
 #endif
+__device__ __forceinline__ bool lm_challenge_scalar(LStrobe &s, uint64_t label, uint32_t llen, sc &out) {
+  uint32_t w[16];
+  lm_challenge64(s, label, llen, w);
+  sc_mont_from_wide_words(out, w);
+  return !sc_iszero(out);
+}
 __global__ void __launch_bounds__(64, BPP_TRANSCRIPTS_WAVES) k_transcripts(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
                                                     const uint64_t *__restrict__ minvals,
                                                     const uint8_t *__restrict__ states, const uint8_t *__restrict__ hg32,
                                                     uint32_t n_bits, uint32_t t, uint32_t B, uint32_t cs,
                                                     sc *__restrict__ chal, uint8_t *__restrict__ rng_out,
                                                     uint32_t *__restrict__ status) {
+  __shared__ uint32_t sponge[BPP_LS_WORDS * BPP_LS_STRIDE];  // word w of lane l at [w * 64 + l] (lstrobe.h)
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B) return;
   const ProofDesc d = desc[p];
-  Strobe s;
-  strobe_from_bytes(s, states + 203u * d.state_idx);
+  LStrobe s;
+  ls_from_bytes(s, (lds_u32 *)sponge + threadIdx.x, states + 203u * d.state_idx);
   bool ok = true;
   const uint8_t *pr = bytes + d.proof_off;
   const uint8_t *pd1 = pr + 1;
   const uint8_t *pA = pr + 1 + 32 * t;
   const uint8_t *pA1 = pA + 32, *pB = pA + 64, *pr1 = pA + 96, *ps1 = pA + 128, *pLR = pA + 160;
 
-  merlin_append_message(s, (const uint8_t *)"dom-sep", 7, (const uint8_t *)"Bulletproofs+ Range Proof", 25);
-  merlin_append_message(s, (const uint8_t *)"H", 1, hg32, 32);  // validated at params creation
-  for (uint32_t k = 0; k < t; k++) merlin_append_message(s, (const uint8_t *)"G", 1, hg32 + 32 * (k + 1), 32);
-  merlin_append_u64(s, (const uint8_t *)"N", 1, n_bits);
-  merlin_append_u64(s, (const uint8_t *)"T", 1, t);
-  merlin_append_u64(s, (const uint8_t *)"M", 1, d.m);
+  lm_append_mem(s, lm_label("dom-sep", 7), 7, (const uint8_t *)"Bulletproofs+ Range Proof", 25);
+  lm_append_mem(s, lm_label("H", 1), 1, hg32, 32);  // validated at params creation
+  for (uint32_t k = 0; k < t; k++) lm_append_mem(s, lm_label("G", 1), 1, hg32 + 32 * (k + 1), 32);
+  lm_append_u64(s, lm_label("N", 1), 1, n_bits);
+  lm_append_u64(s, lm_label("T", 1), 1, t);
+  lm_append_u64(s, lm_label("M", 1), 1, d.m);
+  for (uint32_t j = 0; j < d.m; j++) lm_append_mem(s, lm_label("Ci", 2), 2, bytes + d.commit_off + 32 * j, 32);  // identity allowed (q3)
   for (uint32_t j = 0; j < d.m; j++)
-    merlin_append_message(s, (const uint8_t *)"Ci", 2, bytes + d.commit_off + 32 * j, 32);  // identity allowed (q3)
-  for (uint32_t j = 0; j < d.m; j++)
-    merlin_append_u64(s, (const uint8_t *)"vi - minimum_value", 18, minvals[d.minval_idx + j]);
+    lm_append_u64_long(s, lm_label("vi - min", 8), lm_label("imum_val", 8), lm_label("ue", 2), 18, minvals[d.minval_idx + j]);
 
   sc *c = chal + (size_t)p * cs;
   sc v;
   ok = ok && !bytes32_all_zero(pA);
-  merlin_append_message(s, (const uint8_t *)"A", 1, pA, 32);
-  ok = dev_challenge(s, (const uint8_t *)"y", 1, v) && ok;
+  lm_append_mem(s, lm_label("A", 1), 1, pA, 32);
+  ok = lm_challenge_scalar(s, lm_label("y", 1), 1, v) && ok;
   c[0] = v;
-  ok = dev_challenge(s, (const uint8_t *)"z", 1, v) && ok;
+  ok = lm_challenge_scalar(s, lm_label("z", 1), 1, v) && ok;
   c[1] = v;
   for (uint32_t j = 0; j < d.rounds; j++) {
     ok = ok && !bytes32_all_zero(pLR + 64 * j) && !bytes32_all_zero(pLR + 64 * j + 32);
-    merlin_append_message(s, (const uint8_t *)"L", 1, pLR + 64 * j, 32);
-    merlin_append_message(s, (const uint8_t *)"R", 1, pLR + 64 * j + 32, 32);
-    ok = dev_challenge(s, (const uint8_t *)"e", 1, v) && ok;
+    lm_append_mem(s, lm_label("L", 1), 1, pLR + 64 * j, 32);
+    lm_append_mem(s, lm_label("R", 1), 1, pLR + 64 * j + 32, 32);
+    ok = lm_challenge_scalar(s, lm_label("e", 1), 1, v) && ok;
     if (j + 3 < cs) c[2 + j] = v;  // cs covers every well-formed proof; an oversized one is replayed for its status only
   }
   ok = ok && !bytes32_all_zero(pA1) && !bytes32_all_zero(pB);
-  merlin_append_message(s, (const uint8_t *)"A1", 2, pA1, 32);
-  merlin_append_message(s, (const uint8_t *)"B", 1, pB, 32);
-  ok = dev_challenge(s, (const uint8_t *)"e", 1, v) && ok;
+  lm_append_mem(s, lm_label("A1", 2), 2, pA1, 32);
+  lm_append_mem(s, lm_label("B", 1), 1, pB, 32);
+  ok = lm_challenge_scalar(s, lm_label("e", 1), 1, v) && ok;
   if (d.rounds + 3 <= cs) c[2 + d.rounds] = v;
   // to_verifier_rng (src/transcripts.rs:166-179) + NullRng finalize + 32 bytes (src/range_proof.rs:845-848)
-  merlin_append_message(s, (const uint8_t *)"r1", 2, pr1, 32);
-  merlin_append_message(s, (const uint8_t *)"s1", 2, ps1, 32);
-  for (uint32_t k = 0; k < t; k++) merlin_append_message(s, (const uint8_t *)"d1", 2, pd1 + 32 * k, 32);
-  uint8_t zero32[32];
-  for (int i = 0; i < 32; i++) zero32[i] = 0;
-  merlin_rng_finalize(s, zero32);
-  uint8_t out[32];
-  merlin_rng_fill(s, out, 32);
-  for (int i = 0; i < 32; i++) rng_out[(size_t)p * 32 + i] = out[i];
+  lm_append_mem(s, lm_label("r1", 2), 2, pr1, 32);
+  lm_append_mem(s, lm_label("s1", 2), 2, ps1, 32);
+  for (uint32_t k = 0; k < t; k++) lm_append_mem(s, lm_label("d1", 2), 2, pd1 + 32 * k, 32);
+  lm_rng_finalize_zero(s);
+  uint32_t out[8];
+  lm_rng_fill32(s, out);
+#pragma unroll
+  for (int i = 0; i < 8; i++) reinterpret_cast<uint32_t *>(rng_out)[(size_t)p * 8 + i] = out[i];
   if (!ok) atomicOr(&status[p], BPP_ST_TRANSCRIPT_FAIL);
 }
 
