@@ -131,8 +131,11 @@ inline void fe_bound_fail(const char *what) {
 // a * b + c with c as the instruction's own 64-bit addend.  Written as `(uint64_t)a * b + c` the compiler re-associates
 // the sums of a column (products first, carry-in last, to shorten the dependency chain) and pays a separate 64-bit
 // addition per limb; pinned, the carry-in rides in the first v_mad_u64_u32 of the column for free.
+#ifndef BPP_FE_PLAIN_MAD
+#define BPP_FE_PLAIN_MAD 0
+#endif
 BPP_HD uint64_t fe_mad(uint32_t a, uint32_t b, uint64_t c) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !BPP_FE_PLAIN_MAD
   uint64_t d, carry_out;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry_out) : "v"(a), "v"(b), "v"(c));
   return d;
@@ -141,6 +144,36 @@ BPP_HD uint64_t fe_mad(uint32_t a, uint32_t b, uint64_t c) {
   BPP_FE_CHECK((((unsigned __int128)a * b + c) >> 64) == 0, "64-bit column overflow");
 #endif
   return (uint64_t)a * b + c;
+#endif
+}
+
+// N multiply-adds into one 64-bit accumulator as ONE asm statement.  Between two separate inline-asm statements of which
+// the second reads what the first wrote, the compiler inserts `s_nop 0` (it must assume a forwarding hazard for
+// instructions it cannot see), and that costs the wavefront a whole issue turn: a dependent chain of v_mad_u64_u32 runs at
+// 9.5 cycles per multiply with the s_nop and 5.2 without, and three wavefronts per SIMD reach 73 % instead of 95 % of the
+// multiplier's rate (tools/microbench/mad_nops.hip).  Inside one statement the hardware interlocks by itself, as it does
+// for the chains the compiler generates from C.  One s_nop is left per column (before the mask / shift that follows).
+template <int N>
+BPP_HD uint64_t fe_mad_chain(uint64_t acc, const uint32_t (&a)[N], const uint32_t (&b)[N]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !BPP_FE_PLAIN_MAD
+  static_assert(N >= 1 && N <= 10, "chain length");
+#define BPP_M(A, B) "v_mad_u64_u32 %0, vcc, %" #A ", %" #B ", %0\n\t"
+  if constexpr (N == 1) asm(BPP_M(1, 2) : "+v"(acc) : "v"(a[0]), "v"(b[0]) : "vcc");
+  if constexpr (N == 2) asm(BPP_M(1, 3) BPP_M(2, 4) : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]) : "vcc");
+  if constexpr (N == 3) asm(BPP_M(1, 4) BPP_M(2, 5) BPP_M(3, 6) : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]) : "vcc");
+  if constexpr (N == 4) asm(BPP_M(1, 5) BPP_M(2, 6) BPP_M(3, 7) BPP_M(4, 8) : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]) : "vcc");
+  if constexpr (N == 5) asm(BPP_M(1, 6) BPP_M(2, 7) BPP_M(3, 8) BPP_M(4, 9) BPP_M(5, 10) : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]) : "vcc");
+  if constexpr (N == 6) asm(BPP_M(1, 7) BPP_M(2, 8) BPP_M(3, 9) BPP_M(4, 10) BPP_M(5, 11) BPP_M(6, 12) : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]) : "vcc");
+  if constexpr (N == 7) asm(BPP_M(1, 8) BPP_M(2, 9) BPP_M(3, 10) BPP_M(4, 11) BPP_M(5, 12) BPP_M(6, 13) BPP_M(7, 14) : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]) : "vcc");
+  if constexpr (N == 8) asm(BPP_M(1, 9) BPP_M(2, 10) BPP_M(3, 11) BPP_M(4, 12) BPP_M(5, 13) BPP_M(6, 14) BPP_M(7, 15) BPP_M(8, 16) : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]) : "vcc");
+  if constexpr (N == 9) asm(BPP_M(1, 10) BPP_M(2, 11) BPP_M(3, 12) BPP_M(4, 13) BPP_M(5, 14) BPP_M(6, 15) BPP_M(7, 16) BPP_M(8, 17) BPP_M(9, 18) : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]) : "vcc");
+  if constexpr (N == 10) asm(BPP_M(1, 11) BPP_M(2, 12) BPP_M(3, 13) BPP_M(4, 14) BPP_M(5, 15) BPP_M(6, 16) BPP_M(7, 17) BPP_M(8, 18) BPP_M(9, 19) BPP_M(10, 20) : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "v"(b[9]) : "vcc");
+#undef BPP_M
+  return acc;
+#else
+#pragma unroll
+  for (int i = 0; i < N; i++) acc = fe_mad(a[i], b[i], acc);
+  return acc;
 #endif
 }
 
@@ -161,16 +194,16 @@ BPP_HD void fe_mul(fe &h, const fe &f, const fe &g) {
   uint32_t r[10];
 #pragma unroll
   for (int k = 0; k < 10; k++) {
-    uint64_t acc = c;
+    uint32_t a[10], b[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) {
       const int j = (k - i + 10) % 10;
       const bool wrap = i > k;
       const bool dbl = (i & 1) && (j & 1);
-      const uint32_t a = dbl ? f2[i] : f.v[i];
-      const uint32_t b = wrap ? g19[j] : g.v[j];
-      acc = (k == 0 && i == 0) ? (uint64_t)a * b : fe_mad(a, b, acc);
+      a[i] = dbl ? f2[i] : f.v[i];
+      b[i] = wrap ? g19[j] : g.v[j];
     }
+    const uint64_t acc = fe_mad_chain<10>(c, a, b);
     r[k] = (uint32_t)acc & fe_mask(k);
     c = acc >> fe_bits(k);
   }
@@ -188,6 +221,28 @@ BPP_HD void fe_mul(fe &h, const fe &f, const fe &g) {
 // j, whose bound is half that of the even limbs, one factor 2 as well -- on f_j; whatever factor 2 is left goes on f_i.
 // That needs 13 pre-scaled limbs in all: 2 f_0..2 f_7, 19 f_6, 19 f_8, 38 f_5, 38 f_7, 38 f_9; loose input (even limbs
 // <= 1.5 * 2^27, odd <= 1.5 * 2^26) keeps every one of them below 2^32.
+template <int K>
+BPP_HD void fe_sq_column(uint64_t &c, uint32_t (&r)[10], const fe &f, const uint32_t (&f2)[10], const uint32_t (&fw)[10]) {
+  constexpr int N = (K & 1) ? 5 : 6;  // pairs (i <= j) with i + j = K (mod 10)
+  uint32_t a[N], b[N];
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    const int j = (K - i + 10) % 10;
+    if (i > j) continue;
+    const bool wrap = i > K;  // i + j == K + 10
+    const bool dbl = (i & 1) && (j & 1);
+    const bool off = i != j;
+    const int total = (off ? 2 : 1) * (dbl ? 2 : 1) * (wrap ? 19 : 1);
+    const int on_j = wrap ? ((j & 1) ? 38 : 19) : ((dbl && off) ? 2 : 1);
+    b[n] = wrap ? fw[j] : ((dbl && off) ? f2[j] : f.v[j]);
+    a[n] = (total / on_j == 2) ? f2[i] : f.v[i];  // the quotient is 1 or 2 for every pair
+    n++;
+  }
+  const uint64_t acc = fe_mad_chain<N>(c, a, b);
+  r[K] = (uint32_t)acc & fe_mask(K);
+  c = acc >> fe_bits(K);
+}
 BPP_HD void fe_sq(fe &h, const fe &f) {
   uint32_t f2[10], fw[10];  // fw[j] = 19 f_j (j even) or 38 f_j (j odd)
 #pragma unroll
@@ -198,25 +253,16 @@ BPP_HD void fe_sq(fe &h, const fe &f) {
   }
   uint64_t c = 0;
   uint32_t r[10];
-#pragma unroll
-  for (int k = 0; k < 10; k++) {
-    uint64_t acc = c;
-#pragma unroll
-    for (int i = 0; i < 10; i++) {
-      const int j = (k - i + 10) % 10;
-      if (i > j) continue;
-      const bool wrap = i > k;  // i + j == k + 10
-      const bool dbl = (i & 1) && (j & 1);
-      const bool off = i != j;
-      const int total = (off ? 2 : 1) * (dbl ? 2 : 1) * (wrap ? 19 : 1);
-      const int on_j = wrap ? ((j & 1) ? 38 : 19) : ((dbl && off) ? 2 : 1);
-      const uint32_t b = wrap ? fw[j] : ((dbl && off) ? f2[j] : f.v[j]);
-      const uint32_t a = (total / on_j == 2) ? f2[i] : f.v[i];  // the quotient is 1 or 2 for every pair
-      acc = (k == 0 && i == 0) ? (uint64_t)a * b : fe_mad(a, b, acc);
-    }
-    r[k] = (uint32_t)acc & fe_mask(k);
-    c = acc >> fe_bits(k);
-  }
+  fe_sq_column<0>(c, r, f, f2, fw);
+  fe_sq_column<1>(c, r, f, f2, fw);
+  fe_sq_column<2>(c, r, f, f2, fw);
+  fe_sq_column<3>(c, r, f, f2, fw);
+  fe_sq_column<4>(c, r, f, f2, fw);
+  fe_sq_column<5>(c, r, f, f2, fw);
+  fe_sq_column<6>(c, r, f, f2, fw);
+  fe_sq_column<7>(c, r, f, f2, fw);
+  fe_sq_column<8>(c, r, f, f2, fw);
+  fe_sq_column<9>(c, r, f, f2, fw);
   const uint64_t t0 = (uint64_t)r[0] + 19u * c;
   h.v[0] = (uint32_t)t0 & 0x3ffffffu;
   h.v[1] = r[1] + (uint32_t)(t0 >> 26);
