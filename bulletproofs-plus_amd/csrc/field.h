@@ -270,9 +270,17 @@ BPP_HD void fe_sq(fe &h, const fe &f) {
   for (int i = 2; i < 10; i++) h.v[i] = r[i];
 }
 
+// n squarings, two per loop iteration through a second set of registers: squaring in place makes the compiler copy every
+// limb that is overwritten while still needed (8 moves per squaring)
 BPP_HD void fe_sqn(fe &h, const fe &f, int n) {
   fe_sq(h, f);
-  for (int i = 1; i < n; i++) fe_sq(h, h);
+  int i = 1;
+  for (; i + 1 < n; i += 2) {
+    fe t;
+    fe_sq(t, h);
+    fe_sq(h, t);
+  }
+  if (i < n) fe_sq(h, h);
 }
 
 // canonical value as 8 little-endian 32-bit words (the primitive: byte arrays cost one register per byte on the GPU)
