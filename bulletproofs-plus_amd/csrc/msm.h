@@ -185,14 +185,24 @@ __global__ void __launch_bounds__(64, BPP_ACC_WAVES) k_msm_accumulate(const uint
     e = sorted[a + 1];
     niels_load_swapped(q, point_ptr(tabs, e & 0x7fffffffu), (e >> 31) != 0);
   }
-  for (uint32_t i = 1; i < n; i++) {
-    const uint32_t e_cur = e;
-    const niels q_cur = q;
+  // two additions per iteration, the entries alternating between two register sets: with one set the prefetched entry has to
+  // be copied into the "current" one every time (30 moves per addition)
+  uint32_t i = 1;
+  while (i < n) {
+    uint32_t e2 = e;
+    niels q2;
+    if (i + 1 < n) {
+      e2 = sorted[a + i + 1];
+      niels_load_swapped(q2, point_ptr(tabs, e2 & 0x7fffffffu), (e2 >> 31) != 0);
+    }
+    ge_madd_swapped(acc, acc, q, (e >> 31) != 0);
+    if (++i >= n) break;
     if (i + 1 < n) {
       e = sorted[a + i + 1];
       niels_load_swapped(q, point_ptr(tabs, e & 0x7fffffffu), (e >> 31) != 0);
     }
-    ge_madd_swapped(acc, acc, q_cur, (e_cur >> 31) != 0);
+    ge_madd_swapped(acc, acc, q2, (e2 >> 31) != 0);
+    ++i;
   }
   buckets[bkt] = acc;
 }
