@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_step", type=int,
                     default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "64")),
                     help="independent 1024-proof reference batches verified by one step (one engine call)")
+    ap.add_argument("--preheat-ms", type=float, default=float(os.environ.get("BPP_BENCH_PREHEAT_MS", "150")),
+                    help="untimed run of the headline leg before the --warmup steps: the clock governor needs ~50 ms of full load "
+                         "to reach the clock it then sustains (tools/clock_ramp.py), a 20-step timed region lasts 55 ms")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (cfg3, 4096-wide, latency, prover)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per cpu_baseline leg")
@@ -254,13 +257,23 @@ def kernel_roofline(profs, alone_ms=None):
     return out, {n: round(v, 4) for n, v in avg.items() if n.endswith("_ms")}
 
 
-def timed(leg, steps, warmup, sync):
+def timed(leg, steps, warmup, sync, clock=None):
+    """`clock` (optional): callable that samples the shader clock; it runs on its own thread DURING the timed steps (one
+    napping wavefront on its own context: nothing is added to the timed work) and its result is returned as 4th value"""
     leg.run_steps(warmup)
     sync()
+    ghz = []
+    th = threading.Thread(target=lambda: ghz.append(clock())) if clock else None
     t0 = time.perf_counter()
+    if th:
+        th.start()
     lat, profs = leg.run_steps(steps)
     sync()
-    return time.perf_counter() - t0, lat, profs
+    el = time.perf_counter() - t0
+    if th:
+        th.join()
+        return el, lat, profs, (ghz[0] if ghz else None)
+    return el, lat, profs
 
 
 def main():
@@ -301,7 +314,18 @@ def main():
     data2 = make_inputs(np, packed, params2, 1024 * R, seed=8675309 + 1000 * rank)
     leg = Leg(bpp, packed, torch, device, params2, data2, 1024, R, S, 1024)
     gen_s = time.perf_counter() - t_setup
-    elapsed, lat, profs = timed(leg, args.steps, args.warmup, sync)
+    # the shader clock held during the timed region (a light kernel sees 2.4 GHz, this load 2.0-2.2): sampled over the
+    # middle of it by one napping wavefront on a context of its own
+    clk_eng = bpp.Engine(local_rank)
+    est_ms = 2.7 * args.steps
+    # Untimed pre-heat: right after a load increase the chip runs at 1.9-2.0 GHz and takes ~50 ms of full load to reach the
+    # 2.3+ GHz it then sustains (tools/clock_ramp.py); 5 warm-up steps are 15 ms.  Without this a 20-step timed region (55 ms)
+    # runs mostly at the ramp's clock and reads 10-15 % low; `shader_clock_ghz` in the line is what the timed region held.
+    if args.preheat_ms > 0:
+        leg.run_steps(max(1, int(args.preheat_ms / 2.7)))
+    elapsed, lat, profs, clock_ghz = timed(leg, args.steps, args.warmup, sync,
+                                           clock=lambda: bpp.shader_clock_ghz(clk_eng, int(1e3 * max(5.0, min(200.0, 0.6 * est_ms)))))
+    clk_eng.close()
     ok_all = 1  # every step raised nothing: all batches of all steps verified
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -318,6 +342,12 @@ def main():
     alone_ms = sum(alone) / len(alone) if min(alone) > 0 else None
     sync()
     roof, stages = kernel_roofline(profs, alone_ms)
+    if roof and clock_ghz:
+        # the multiplier's peak at the clock the chip really held: 64 lanes / clock / CU x 256 CUs x clock
+        at_clock = 64 * 256 * clock_ghz * 1e9 / 1e12
+        roof["valu"]["shader_clock_ghz"] = clock_ghz
+        roof["valu"]["peak_at_clock_Tmad_per_s"] = at_clock
+        roof["valu"]["frac_at_clock"] = roof["valu"]["achieved_Tmad_per_s"] / at_clock
     total = 1024 * R * world * args.steps
     out = {
         "metric": "64-bit range proofs verified/sec (batch)", "value": total / elapsed, "unit": "proofs/s",
@@ -332,6 +362,7 @@ def main():
                              "benches/range_proof.rs:206-262), %.1f s" % (1024 * R, gen_s)},
         "step_latency_ms": 1e3 * sum(lat) / len(lat),
         "host_threads": bpp.host_threads(), "nproc": os.cpu_count(), "usable_cpus": usable_cpus(),
+        "shader_clock_ghz": clock_ghz,
     }
     if roof:
         if rank == 0 and world == 1 and not use_dist and not args.no_traffic:

@@ -1,7 +1,7 @@
 """ctypes binding of include/bpp.h.  There is no fallback: a missing or unloadable libbpp_hip.so raises."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbpp_hip.so")
@@ -74,6 +74,7 @@ SYMBOLS = [
     ("bpp_prove_profile_get", c_int, [c_void_p, POINTER(ProveProfile)]),
     ("bpp_batch_prepare", c_int, [c_void_p, c_uint64, c_size_t]),
     ("bpp_host_threads", c_int, []),
+    ("bpp_shader_clock", c_int, [c_void_p, c_uint32, POINTER(c_double)]),
     ("bpp_transcript_new", c_int, [c_void_p, c_size_t, c_void_p]),
 ]
 

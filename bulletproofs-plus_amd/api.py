@@ -720,6 +720,13 @@ class ResidentBatch:
             self.handle = c_uint64()
 
 
+def shader_clock_ghz(engine, window_us=20000):
+    """the shader clock the device holds while this call naps on `engine`'s stream (other engines keep it busy)"""
+    g = ctypes.c_double()
+    _check(engine.lib.bpp_shader_clock(engine.ctx, int(window_us), byref(g)), engine.ctx)
+    return g.value
+
+
 def host_threads():
     """size of the engine's host worker pool (weight chains, upload packer)"""
     return int(_lib.load().bpp_host_threads())

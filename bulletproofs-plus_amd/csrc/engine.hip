@@ -1070,6 +1070,24 @@ int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items
 
 int bpp_host_threads(void) { return (int)host_pool_size(); }
 
+int bpp_shader_clock(bpp_ctx *ctx, uint32_t window_us, double *ghz) {
+  BPP_ENTRY(ctx);
+  try {
+    if (!ghz) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument");
+    DevBuf<uint64_t> d;
+    d.alloc(2);
+    // s_sleep 127 naps for 127 x 64 clocks: ~3.5 us at 2.3 GHz
+    const uint32_t naps = std::max<uint32_t>(1, std::min<uint32_t>(window_us, 2000000u) * 2 / 7);
+    hipLaunchKernelGGL(k_shader_clock, dim3(1), dim3(64), 0, ctx->stream, d.p, naps);
+    uint64_t h[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, nullptr, 0)
+}
+
 int bpp_batch_destroy(bpp_ctx *ctx, uint64_t batch) {
   BPP_ENTRY(ctx);
   (void)hipStreamSynchronize(ctx->stream);

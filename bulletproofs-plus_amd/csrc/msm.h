@@ -641,4 +641,14 @@ __global__ void k_sum_accumulators(const uint8_t *__restrict__ in128, uint32_t n
   is_identity[0] = ge_is_ristretto_identity(acc) ? 1u : 0u;
 }
 
+// diagnostics (bpp_shader_clock): one wavefront naps and reads the shader-clock counter and the constant 100 MHz one
+__global__ void k_shader_clock(uint64_t *out, uint32_t naps) {
+  const uint64_t c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+  for (uint32_t i = 0; i < naps; i++) __builtin_amdgcn_s_sleep(127);
+  if (threadIdx.x == 0) {
+    out[0] = __builtin_amdgcn_s_memtime() - c0;
+    out[1] = __builtin_amdgcn_s_memrealtime() - w0;
+  }
+}
+
 }  // namespace bpp

@@ -226,6 +226,12 @@ int bpp_prove_profile_get(bpp_ctx *ctx, bpp_prove_profile *out);
  * (BPP_HOST_THREADS, default min(cores, 32)): the verifier's throughput depends on it */
 int bpp_host_threads(void);
 
+/* diagnostics: the shader clock the device holds RIGHT NOW, sampled by one napping wavefront on this context's stream for
+ * about `window_us` microseconds (s_memtime against the 100 MHz s_memrealtime) while other contexts' kernels run.  Under the
+ * verifier's load the chip holds 2.0-2.2 GHz, not the 2.4 GHz of a light kernel: issue-rate peaks have to be priced at
+ * the clock measured (bench.py reports it as shader_clock_ghz). */
+int bpp_shader_clock(bpp_ctx *ctx, uint32_t window_us, double *ghz);
+
 /* Transcript::new(label) -> 203-byte STROBE state (host helper for callers that keep merlin on their side) */
 int bpp_transcript_new(const uint8_t *label, size_t label_len, uint8_t state203[203]);
 
