@@ -321,6 +321,7 @@ def main():
     # Untimed pre-heat: right after a load increase the chip runs at 1.9-2.0 GHz and takes ~50 ms of full load to reach the
     # 2.3+ GHz it then sustains (tools/clock_ramp.py); 5 warm-up steps are 15 ms.  Without this a 20-step timed region (55 ms)
     # runs mostly at the ramp's clock and reads 10-15 % low; `shader_clock_ghz` in the line is what the timed region held.
+    sync()  # under torch.distributed the first barrier builds the communicator (100s of ms): not between warm-up and timing
     if args.preheat_ms > 0:
         leg.run_steps(max(1, int(args.preheat_ms / 2.7)))
     elapsed, lat, profs, clock_ghz = timed(leg, args.steps, args.warmup, sync,
