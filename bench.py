@@ -412,15 +412,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra:
         # -------------------------------------------------------------- configs[2]: 256 x aggregation-8
         p3 = bpp.RangeParameters.init(64, 8, G(1), engine=eng0)
-        R3 = 32
+        R3 = int(os.environ.get("BPP_BENCH_CFG3_BATCHES", "64"))
+        S3 = int(os.environ.get("BPP_BENCH_CFG3_INFLIGHT", "4"))
         d3 = make_inputs(np, packed, p3, 256 * R3, seed=8675309 + 3)
-        leg3 = Leg(bpp, packed, torch, device, p3, d3, 256, R3, 4, 256)
+        leg3 = Leg(bpp, packed, torch, device, p3, d3, 256, R3, S3, 256)
         el3, lat3, pr3 = timed(leg3, 48, 8, sync)
         sync()
         al3 = [leg3.one_step(0)[1].get("msm_accumulate_ms", 0.0) for _ in range(3)]
         roof3, st3 = kernel_roofline(pr3, sum(al3) / 3 if min(al3) > 0 else None)
         extra["cfg3"] = {"workload": "BASELINE configs[2]: reference batches of 256 x aggregation-8 64-bit proofs, extension degree 1; "
-                                     "one step = %d such batches, 4 steps in flight" % R3,
+                                     "one step = %d such batches, %d steps in flight" % (R3, S3),
                          "proofs_per_s": 256 * R3 * 48 / el3, "ms_per_step": 1e3 * el3 / 48, "steps": 48, "roofline": roof3,
                          "stages_ms": st3}
         leg3.close()
