@@ -427,7 +427,7 @@ def main():
         leg3.close()
         p3.close()
         # -------------------------------------------------------------- one 4096-proof reference batch (north_star's sentence)
-        Sw = 6
+        Sw = int(os.environ.get("BPP_BENCH_WIDE_INFLIGHT", "6"))
         legw = Leg(bpp, packed, torch, device, params2, data2, 4096, 1, Sw, 0)
         elw, latw, prw = timed(legw, 120, 12, sync)
         sync()
