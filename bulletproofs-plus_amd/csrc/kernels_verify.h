@@ -107,9 +107,10 @@ __global__ void __launch_bounds__(64, BPP_TRANSCRIPTS_WAVES) k_transcripts(const
 }
 
 // The same PASS 1 with one proof per WAVEFRONT on the cooperative sponge of wstrobe.h (state in LDS, 25-lane Keccak-f).
-// Per proof it uses ~7x the issue slots of the one-lane kernel but finishes in a fifth of the time, so the host picks
-// it for small batches (B <= BPP_TRANSCRIPTS_WAVE_MAX), where PASS 1 is pure latency on a nearly idle chip.
-#define BPP_TRANSCRIPTS_WAVE_MAX 4096u
+// Per proof it uses ~7x the issue slots of the one-lane kernel but finishes in half the time, so the host picks it for
+// small batches (B <= BPP_TRANSCRIPTS_WAVE_MAX), where PASS 1 is pure latency on a nearly idle chip: 0.115 ms up to 256
+// proofs, 0.13 / 0.17 / 0.31 ms for 1024 / 2048 / 4096; the one-lane kernel on the LDS sponge takes 0.24 ms whatever the size.
+#define BPP_TRANSCRIPTS_WAVE_MAX 2048u
 #define BPP_TABLES_WAVE_MAX 2048u  // same idea for the scalar-stage tables (k_scalars_tables_wave)
 struct TranscriptLds {
   uint64_t st[25];

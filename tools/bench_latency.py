@@ -32,7 +32,7 @@ def main():
         from oracle import cport
         cp = cport.Params(data["bit_length"], data["m"], data["t"])
     for B in [int(x) for x in args.sizes.split(",")]:
-        its = data["items"][:B]
+        its = (data["items"] * ((B + len(data["items"]) - 1) // len(data["items"])))[:B]  # sizes above the fixture: repeated proofs
         sts = [bpp.RangeStatement.init(params, it["commitments"], it["min_values"], None) for it in its]
         proofs = [bpp.RangeProof.from_bytes(it["proof"]) for it in its]
         rb = bpp.ResidentBatch([bpp.Transcript.new(data["label"]) for _ in its], sts, proofs)
