@@ -87,6 +87,11 @@ def main():
     th = [threading.Thread(target=worker, args=(k,)) for k in range(args.threads)]
     for x in th:
         x.start()
+    while any(x.is_alive() for x in th):  # a progress line every 30 s (a silent GPU job is taken to be hung)
+        time.sleep(1.0)
+        if int(time.time()) % 30 == 0:
+            with lock:
+                print("progress", json.dumps(stats), file=sys.stderr, flush=True)
     for x in th:
         x.join()
     print(json.dumps(dict(stats, seconds=args.seconds, threads=args.threads, problems=problems)))
