@@ -179,3 +179,9 @@ def test_oversized_proof_does_not_inflate_the_batch(bpp, engine):
         rb.close()
     # the same proofs without the oversized one still verify on the same engine
     assert bpp.RangeProof.verify_batch(c.transcripts(), c.statements_public, c.proofs, A.VerifyOnly, chunk=2) == [None] * 4
+
+
+def test_shader_clock_probe(bpp, engine):
+    """bpp_shader_clock: one napping wavefront reads the shader-clock counter against the constant 100 MHz one"""
+    g = bpp.shader_clock_ghz(engine, window_us=2000)
+    assert 0.3 < g < 3.5, g
