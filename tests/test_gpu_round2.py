@@ -55,16 +55,22 @@ def test_two_loop_precedence(bpp, engine):
 def test_params_shared_by_four_contexts(bpp):
     """ONE RangeParameters handle (one generator table, one fixed-base table) used by four contexts at once: two verify,
     two prove; device memory grows by one table, not four; the handle outlives the context that created it"""
-    import torch
+    import ctypes
     from tests.test_gpu_prove import _inputs
+
+    def free_bytes():  # hipMemGetInfo of the HIP runtime the engine itself runs on (no second runtime in the process)
+        hip = ctypes.CDLL("libamdhip64.so")
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
     K, A = bpp.ProofErrorKind, bpp.VerifyAction
     n, m, t = 16, 2, 1
     owner = bpp.Engine(0)
-    free0 = torch.cuda.mem_get_info(0)[0]
+    free0 = free_bytes()
     params = bpp.RangeParameters.init(n, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=owner)
     sts, wits, exts, raw = _inputs(bpp, params, n, m, t, 4, b"shared-params", "third")
     first = bpp.RangeProof.prove_batch([bpp.Transcript.new(LABEL)] * 4, sts, wits, exts)  # builds the fixed-base table
-    free1 = torch.cuda.mem_get_info(0)[0]
+    free1 = free_bytes()
     table_cost = free0 - free1
     assert table_cost > 50 << 20  # 65 generators x 24 windows x 1024 entries x 128 B = 204 MB
     cp = cport.Params(n, m, t)
@@ -121,7 +127,7 @@ def test_params_shared_by_four_contexts(bpp):
     assert not errors, errors
     assert results[0] == [True] * 3 and results[2] == [True] * 3
     assert results[1] == ["ok"] * 4 and results[3] == [int(K.VerificationFailed)] * 4
-    free2 = torch.cuda.mem_get_info(0)[0]
+    free2 = free_bytes()
     # four more users: their own work buffers only (arena, staging), no second copy of the 200 MB table
     assert free1 - free2 < table_cost // 2, (table_cost, free1 - free2)
     # the creating context goes away; the holders keep using the tables
@@ -139,7 +145,7 @@ def test_params_shared_by_four_contexts(bpp):
     for e in engines:
         e.close()
     stranger.close()
-    free3 = torch.cuda.mem_get_info(0)[0]
+    free3 = free_bytes()
     assert free3 - free2 > table_cost // 2, (table_cost, free3 - free2)
 
 
