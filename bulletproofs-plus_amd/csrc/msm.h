@@ -334,10 +334,15 @@ __global__ void __launch_bounds__(64) k_msm_final(const ge *__restrict__ W, MsmP
 // an addition (two rounds of four products): each lane of the quad does one of them and the operands travel by
 // quad-permute DPP moves (no LDS).  Lane q keeps coordinate q of the accumulator (X, Y, Z, T).  Same field operations in
 // the same order as ge_dbl_n / ge_add, so the result is bit-identical.  grid = ceil(G / 16) blocks of 64 lanes. ----
+// The broadcast results are fenced (an empty asm "defines" them): otherwise the compiler's DPP combine may fold a broadcast
+// into the consumer, and for `x - broadcast(y)` it emits v_subrev_u32_dpp, which on this toolchain / chip computes
+// broadcast(x) - y: `v_subrev_u32_dpp d, A, B quad_perm:[3,3,3,3]` returns B[lane 3] - A[lane] instead of B[lane] - A[lane 3]
+// (v_sub_u32_dpp and v_add_u32_dpp behave as documented; tools/isa/dpp_hazard_check.py refuses the opcode in any build).
 template <int S>
 __device__ __forceinline__ void quad_bcast(fe &r, const fe &v) {
 #pragma unroll
   for (int i = 0; i < 10; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.v[i], S * 0x55, 0xf, 0xf, false);
+  fe_fence(r);
 }
 // per-lane choice among four field elements by bit masks (ternaries get turned into divergent branches with the
 // multiplication duplicated in every arm, which serialises the four lanes again)
@@ -462,13 +467,12 @@ __global__ void __launch_bounds__(64) k_msm_final_quad(const ge *__restrict__ W,
       quad_bcast<1>(b, s2);
       quad_bcast<2>(c, s2);
       quad_bcast<3>(t, s2);
-      fe_add(c, c, c);
+      // limb classes as in ge_dbl_efgh (point.h): e wide (left operand only), g and h loose, f carried: one carry pass
       fe_add(h, a, b);
-      fe_sub(e, h, t);
-      fe_sub(gg, a, b);
-      fe_add(f, c, gg);
+      fe_sub_lazy(e, h, t);
+      fe_sub_lazy(gg, a, b);
+      fe_dbl_add(f, c, gg);
       fe_carry(f);
-      fe_carry(h);
       quad_efgh(m, q, e, f, gg, h);
     }
     // acc += W_k

@@ -4,7 +4,11 @@ broadcasts of the latency-form MSM kernels) read as store DATA by the very next 
 `v_mov_b32_dpp v4, ..` / `scratch_store_dwordx2 off, v[4:5], ..`) arrives stale -- one wait state in between fixes it, a
 wait state before the DPP instruction does not.  This script disassembles the gfx950 code object inside libbpp_hip.so and
 fails if any kernel contains the pattern (DPP result consumed by an immediately following VMEM / scratch / LDS store or
-permute).  usage: dpp_hazard_check.py [path to libbpp_hip.so]"""
+permute).
+
+Second check: no v_subrev / v_subbrev instruction in DPP form.  `v_subrev_u32_dpp d, A, B quad_perm:[3,3,3,3]` returns
+B[lane 3] - A[lane] on the MI355X with this toolchain instead of B[lane] - A[lane 3] (sub and add in DPP form are fine);
+the compiler's DPP combine produces it for `x - broadcast(y)`.  usage: dpp_hazard_check.py [path to libbpp_hip.so]"""
 import os
 import re
 import subprocess
@@ -47,6 +51,8 @@ def check(so):
             hits.append((cur, p))
         prev = None
         op = p.split()[0]
+        if op.startswith(("v_subrev", "v_subbrev")) and ("_dpp" in op or " quad_perm:" in p or " row_" in p):
+            hits.append((cur, p))
         if op.startswith("v_") and ("_dpp" in op or " quad_perm:" in p or " row_" in p):
             n_dpp += 1
             prev = p.replace(",", " ").split()[1]
@@ -57,7 +63,7 @@ def main():
     so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "bulletproofs-plus_amd",
                                                             "libbpp_hip.so")
     n_dpp, hits = check(so)
-    print("%d DPP instructions, %d consumed as store data by the next instruction" % (n_dpp, len(hits)))
+    print("%d DPP instructions, %d hazards (result stored by the next instruction, or subrev in DPP form)" % (n_dpp, len(hits)))
     for fn, p in hits[:20]:
         print("  ", fn[:60], ":", p)
     return 1 if hits else 0
