@@ -344,24 +344,39 @@ __device__ __forceinline__ void quad_bcast(fe &r, const fe &v) {
   for (int i = 0; i < 10; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.v[i], S * 0x55, 0xf, 0xf, false);
   fe_fence(r);
 }
-// per-lane choice among four field elements by bit masks (ternaries get turned into divergent branches with the
-// multiplication duplicated in every arm, which serialises the four lanes again)
+// per-lane choice among four field elements: three v_cndmask per limb under wavefront-wide lane masks held in scalar
+// registers (ternaries get turned into divergent branches with the multiplication duplicated in every arm, which serialises
+// the four lanes again; and/or under per-lane masks cost seven instructions per limb)
 struct QuadMask {
-  uint32_t m0, m1, m2, m3;
+  uint64_t b1, b2, b3;  // lanes whose quad position is 1, 2, 3
 };
 __device__ __forceinline__ QuadMask quad_mask(uint32_t q) {
+  (void)q;  // position in the quad = lane & 3 for every caller (64-lane blocks, quads of adjacent lanes)
   QuadMask k;
-  k.m0 = 0u - (uint32_t)(q == 0);
-  k.m1 = 0u - (uint32_t)(q == 1);
-  k.m2 = 0u - (uint32_t)(q == 2);
-  k.m3 = 0u - (uint32_t)(q == 3);
-  // keep the masks opaque to the optimiser
-  asm volatile("" : "+v"(k.m0), "+v"(k.m1), "+v"(k.m2), "+v"(k.m3));
+  k.b1 = 0x2222222222222222ull;
+  k.b2 = 0x4444444444444444ull;
+  k.b3 = 0x8888888888888888ull;
+  asm volatile("" : "+s"(k.b1), "+s"(k.b2), "+s"(k.b3));  // opaque: keep them in scalar registers, no per-use materialising
   return k;
 }
 __device__ __forceinline__ void fe_sel4(fe &r, const QuadMask &k, const fe &a0, const fe &a1, const fe &a2, const fe &a3) {
 #pragma unroll
-  for (int i = 0; i < 10; i++) r.v[i] = (a0.v[i] & k.m0) | (a1.v[i] & k.m1) | (a2.v[i] & k.m2) | (a3.v[i] & k.m3);
+  for (int i = 0; i < 10; i++) {
+    uint32_t t;
+    asm("v_cndmask_b32 %0, %1, %2, %5\n\tv_cndmask_b32 %0, %0, %3, %6\n\tv_cndmask_b32 %0, %0, %4, %7"
+        : "=&v"(t)
+        : "v"(a0.v[i]), "v"(a1.v[i]), "v"(a2.v[i]), "v"(a3.v[i]), "s"(k.b1), "s"(k.b2), "s"(k.b3));
+    r.v[i] = t;
+  }
+}
+// r = quad position 3 ? b : a
+__device__ __forceinline__ void fe_sel_lane3(fe &r, const QuadMask &k, const fe &a, const fe &b) {
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    uint32_t t;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(t) : "v"(a.v[i]), "v"(b.v[i]), "s"(k.b3));
+    r.v[i] = t;
+  }
 }
 // second round shared by doubling and addition: lane q returns (E*F, G*H, F*G, E*H)[q]
 __device__ __forceinline__ void quad_efgh(fe &m, const QuadMask &q, const fe &E, const fe &F, const fe &G, const fe &H) {
@@ -459,8 +474,7 @@ __global__ void __launch_bounds__(64) k_msm_final_quad(const ge *__restrict__ W,
       quad_bcast<0>(x, m);
       quad_bcast<1>(y, m);
       fe_add(v, x, y);
-#pragma unroll
-      for (int j = 0; j < 10; j++) v.v[j] = (v.v[j] & q.m3) | (m.v[j] & ~q.m3);  // X, Y, Z, X + Y
+      fe_sel_lane3(v, q, m, v);  // X, Y, Z, X + Y
       fe_sq(s2, v);
       fe a, b, c, t, e, f, gg, h;
       quad_bcast<0>(a, s2);
