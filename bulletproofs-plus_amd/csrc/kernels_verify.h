@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(64, BPP_TRANSCRIPTS_WAVES) k_transcripts(const
 // proofs, 0.13 / 0.17 / 0.31 ms for 1024 / 2048 / 4096; the one-lane kernel on the LDS sponge takes 0.24 ms whatever the size.
 #define BPP_TRANSCRIPTS_WAVE_MAX 2048u
 #define BPP_TABLES_WAVE_MAX 2048u  // same idea for the scalar-stage tables (k_scalars_tables_wave)
+#define BPP_SIDE_DECOMPRESS_MAX 2048u  // up to here decompression runs beside PASS 1 on a second stream (engine.hip)
 struct TranscriptLds {
   uint64_t st[25];
   uint8_t buf[64];

@@ -180,6 +180,38 @@ def test_both_table_kernels(bpp, engine, monkeypatch, wave, n, ms):
     rb.close()
 
 
+@pytest.mark.parametrize("side", ["0", "1"])
+def test_decompression_beside_pass1(bpp, engine, monkeypatch, side):
+    """small inputs decompress on a second stream while PASS 1 runs; force each form: same dynamic points, same verdicts, and an
+    undecodable point plus a transcript failure in one batch still surface in the reference's order"""
+    monkeypatch.setenv("BPP_SIDE_DECOMPRESS", side)
+    case = make_batch(bpp, engine, 16, [1, 2, 4, 1, 1], 1, seed=b"side-decompress")
+    _, tr = oracle_verify_trace(case, action=0)
+    for _ in range(3):  # the streams are reused call after call
+        rb = bpp.ResidentBatch(case.transcripts(), case.statements_public, case.proofs)
+        assert rb.verify(bpp.VerifyAction.VerifyOnly, chunk=0) == [None] * 5
+        assert rb.trace(5) == b"".join(sb(x) for x in tr["dynamic_scalars"])
+        assert rb.trace(6) == tr["msm_result"] == bytes(32)
+        rb.close()
+    K = bpp.ProofErrorKind
+    V = lambda proofs: bpp.RangeProof.verify_batch(case.transcripts(), case.statements_public, proofs, bpp.VerifyAction.VerifyOnly)
+
+    def patched(proofs, i, off, data):
+        r = bytearray(proofs[i].to_bytes())
+        r[off:off + len(data)] = data
+        out = list(proofs)
+        out[i] = bpp.RangeProof.from_bytes(bytes(r))
+        return out
+    offA = 1 + 32
+    bad_point = patched(case.proofs, 0, offA, b"\x01" + bytes(31))  # negative field element: never a valid encoding
+    with pytest.raises(bpp.ProofError) as e:
+        V(bad_point)
+    assert e.value.kind == K.InvalidArgument  # found by the decompression kernel
+    with pytest.raises(bpp.ProofError) as e:
+        V(patched(bad_point, 3, offA + 32, bytes(32)))  # identity A1 in a later proof: found by PASS 1, which precedes
+    assert e.value.kind == K.VerificationFailed
+
+
 @pytest.mark.parametrize("quad", ["0", "1"])
 def test_both_bucket_kernel_forms(bpp, engine, monkeypatch, quad):
     """bucket accumulation / row-column reduction exist in a one-lane-per-bucket form (many buckets) and a quad form (few
