@@ -27,7 +27,7 @@ import os
 
 # More than four calls in flight only overlap if the HIP runtime may use more than its default four hardware queues (read
 # once, when the runtime starts: before torch is imported).  The headline (four steps in flight) does not depend on it,
-# the 4096-proof leg does: 5.4 -> 8.5 M proofs/s with eight calls in flight.
+# the 4096-proof leg does: 5.4 -> 8.5 / 10.8 M proofs/s with eight / twelve calls in flight (sixteen need 24 queues: 11.9 M).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import argparse
@@ -178,7 +178,7 @@ def measure_traffic(kernel="k_msm_accumulate"):
 class Leg:
     """S slots (engine + stream + resident copy of the input) verifying `chunk`-proof reference batches"""
 
-    def __init__(self, bpp, packed, torch, device, params0, data, batch_proofs, batches, slots, chunk):
+    def __init__(self, bpp, packed, torch, device, params0, data, batch_proofs, batches, slots, chunk, profile=True):
         import numpy as np
         self.bpp, self.chunk, self.slots = bpp, chunk, []
         self.proofs_per_step = batch_proofs * batches
@@ -187,7 +187,7 @@ class Leg:
         for i in range(slots):
             stream = None  # the engine's own non-blocking stream (its HIP events time the kernels on it)
             eng = bpp.Engine(device.index)
-            eng.profile(True)
+            eng.profile(profile)  # stage events: nothing next to a 2.5 ms step, 10 % of a 0.8 ms call
             params = params0.share(eng)  # ONE generator table for every slot (src/traits.rs:42 `Send + Sync`)
             # the same `nb` distinct batches in another order for every slot
             order = [(i * 11 + k) % nb for k in range(batches)]
@@ -198,6 +198,10 @@ class Leg:
             rb.prepare(chunk)   # group layout, MSM plan, work buffers: not in any timed call
             rb.verify_only(chunk)  # every slot has run once (events, lazily built state) before anything is timed
             self.slots.append((stream, eng, params, rb))
+
+    def set_profile(self, on):
+        for _, eng, _, _ in self.slots:
+            eng.profile(on)
 
     def one_step(self, slot):
         _, eng, _, rb = self.slots[slot]
@@ -434,26 +438,34 @@ def main():
         leg3.close()
         p3.close()
         # -------------------------------------------------------------- one 4096-proof reference batch (north_star's sentence)
-        Sw = int(os.environ.get("BPP_BENCH_WIDE_INFLIGHT", "8"))
-        legw = Leg(bpp, packed, torch, device, params2, data2, 4096, 1, Sw, 0)
-        elw, latw, prw = timed(legw, 120, 12, sync)
+        Sw = int(os.environ.get("BPP_BENCH_WIDE_INFLIGHT", "12"))
+        legw = Leg(bpp, packed, torch, device, params2, data2, 4096, 1, Sw, 0, profile=False)
+        nw = 40 * Sw
+        elw, latw, _ = timed(legw, nw, 12 * Sw, sync)  # the rate: no stage events; warm-up long enough for the clock (as the headline's pre-heat)
+        legw.set_profile(True)
+        _, _, prw = timed(legw, 4 * Sw, Sw, sync)  # stage times with the same calls in flight
         sync()
         alw = [legw.one_step(0) for _ in range(5)]
         roofw, stw = kernel_roofline(prw, sum(a[1].get("msm_accumulate_ms", 0.0) for a in alw) / 5)
         extra["wide4096"] = {"workload": "4096 non-aggregated 64-bit proofs as ONE reference batch (chunk = 0: one weight chain over "
                                          "4096, one 65 667-term MSM) on one GPU; %d calls in flight, each on another 4096 proofs" % Sw,
-                             "proofs_per_s": 4096 * 120 / elw, "ms_per_batch_in_flight": 1e3 * sum(latw) / len(latw),
-                             "ms_per_batch_alone": 1e3 * sum(a[0] for a in alw) / 5, "steps": 120, "roofline": roofw, "stages_ms": stw}
+                             "proofs_per_s": 4096 * nw / elw, "ms_per_batch_in_flight": 1e3 * sum(latw) / len(latw),
+                             "ms_per_batch_alone": 1e3 * sum(a[0] for a in alw) / 5, "steps": nw, "roofline": roofw, "stages_ms": stw}
         legw.close()
         # -------------------------------------------------------------- single-call latency (configs[0]'s shape)
         lat_out = {}
         for nb in (1, 256):
-            legl = Leg(bpp, packed, torch, device, params2, data2, nb, 1, 1, 0)
+            legl = Leg(bpp, packed, torch, device, params2, data2, nb, 1, 1, 0, profile=False)
             legl.run_steps(10)
-            ls, lp = legl.run_steps(50)
+            ls, _ = legl.run_steps(50)  # the latency: no stage events
             ls.sort()
+            legl.set_profile(True)
+            legl.run_steps(3)
+            lsp, lp = legl.run_steps(20)  # stage times (the events add ~0.1 ms to the call)
+            lsp.sort()
             rl, sl = kernel_roofline(lp)
             lat_out["batch_%d" % nb] = {"ms_per_call_median": 1e3 * ls[len(ls) // 2], "ms_per_call_min": 1e3 * ls[0],
+                                        "ms_per_call_median_with_stage_events": 1e3 * lsp[len(lsp) // 2],
                                         "proofs_per_s": nb / ls[len(ls) // 2], "roofline": rl, "stages_ms": sl}
             legl.close()
         extra["latency"] = dict(lat_out, workload="BASELINE configs[0]'s shape through the engine: ONE call at a time, 1 and 256 "

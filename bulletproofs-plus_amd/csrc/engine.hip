@@ -157,20 +157,9 @@ uint32_t host_pool_size();
 
 // weight transcript (src/range_proof.rs:811,849,853,894)
 void weights_from_chain_host(const uint8_t *rng32, size_t n, uint8_t *weights32) {
-  Strobe wt;
-  const char *lbl = "Bulletproofs+ verifier weights";
-  merlin_new(wt, (const uint8_t *)lbl, (uint32_t)strlen(lbl));
-  for (size_t i = 0; i < n; i++) merlin_append_message(wt, (const uint8_t *)"proof", 5, rng32 + 32 * i, 32);
-  uint8_t zero32[32] = {0};
-  merlin_rng_finalize(wt, zero32);  // build_rng().finalize(&mut NullRng)
-  for (size_t i = 0; i < n; i++) {
-    uint8_t *w = weights32 + 32 * i;
-    do {  // Scalar::random_not_zero (src/protocols/scalar_protocol.rs:23-30)
-      uint8_t wide[64];
-      merlin_rng_fill(wt, wide, 64);
-      host_wide_reduce(w, wide);
-    } while (weight_is_zero(w));
-  }
+  static const bool generic = getenv("BPP_CHAIN_GENERIC") && atoi(getenv("BPP_CHAIN_GENERIC"));  // tests: merlin.h's sponge
+  if (generic) weights_chain_generic(rng32, n, weights32);
+  else weights_chain_single(rng32, n, weights32);
 }
 
 // ------------------------------------------------------------------ objects

@@ -85,6 +85,14 @@ int ht_weight_chains(const uint8_t *rng /* [width][n][32] */, uint32_t n, uint32
   if (width == 4) { if (!__builtin_cpu_supports("avx2")) return 0; weights_chain_x4(in, n, o); return 1; }
   if (width == 8) { if (!(__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl"))) return 0; weights_chain_x8(in, n, o); return 1; }
   return -1; }
+// one chain: form 0 = merlin.h's generic sponge, 1 = fast form without BMI, 2 = fast form compiled for BMI (0 when the CPU lacks it),
+// 3 = whatever the engine picks at run time
+int ht_weight_chain_single(const uint8_t *rng /* [n][32] */, uint32_t n, uint32_t form, uint8_t *out /* [n][32] */) {
+  if (form == 0) { weights_chain_generic(rng, n, out); return 1; }
+  if (form == 1) { weights_chain_single_plain(rng, n, out); return 1; }
+  if (form == 2) { if (!(__builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2"))) return 0; weights_chain_single_bmi(rng, n, out); return 1; }
+  if (form == 3) { weights_chain_single(rng, n, out); return 1; }
+  return -1; }
 // recodings: digits of a canonical scalar for MSM window width c (uneven windows) / fixed-base window width w
 int ht_msm_recode(const uint8_t a[32], uint32_t c, int16_t *digits /* K */, uint32_t *widths /* K */) {
   sc x; sc_load_words(x, a);

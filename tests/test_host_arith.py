@@ -220,3 +220,28 @@ def test_scalar_recodings(ht, monkeypatch):
             assert W * (1 << (w - 1)) * 128 * n_gens <= 1800 << 20 or w == 8
             assert all(-(1 << (w - 1)) < dig[k] <= (1 << (w - 1)) for k in range(W))
             assert sum(dig[k] << (w * k) for k in range(W)) == a
+
+
+def test_weight_chain_single_forms(ht):
+    """the low-latency single chain of chain_host.h (state addressed as bytes, unrolled 64-bit Keccak-f, BMI build) against
+    merlin.h's generic sponge and the oracle's Merlin, for lengths that put the block boundary of the sponge at every
+    position of the per-proof message and of the 64-byte squeezes"""
+    from oracle.pyref import protocol as O
+    import ctypes
+    ht.ht_weight_chain_single.restype = ctypes.c_int
+    for n in list(range(1, 24)) + [37, 129, 500]:
+        rng = b"".join(_r(b"single", 1000 * n + i) for i in range(n))
+        outs = []
+        for form in (0, 1, 2, 3):
+            out = ctypes.create_string_buffer(32 * n)
+            rc = ht.ht_weight_chain_single(rng, n, form, out)
+            assert rc in (0, 1)
+            if rc == 1:
+                outs.append(out.raw)
+        assert len(outs) >= 3 and all(o == outs[0] for o in outs), n
+        if n in (1, 7, 37):
+            t = M.Transcript(b"Bulletproofs+ verifier weights")
+            for i in range(n):
+                t.append_message(b"proof", rng[i * 32:(i + 1) * 32])
+            wr = t.build_rng().finalize(O.NullRng())
+            assert outs[0] == b"".join(C.scalar_bytes(O.random_not_zero(wr)) for _ in range(n))

@@ -7,7 +7,7 @@ packed = importlib.import_module("bulletproofs-plus_amd.packed")
 eng0 = bpp.Engine(0)
 p0 = bpp.RangeParameters.init(64, 1, bpp.create_pedersen_gens_with_extension_degree(1), engine=eng0)
 d = bench.make_inputs(np, packed, p0, 4096, seed=5)
-for S in (1, 4, 6, 8):
+for S in [int(x) for x in os.environ.get("WIDE_PROBE_S", "1,4,6,8").split(",")]:
     engs = [bpp.Engine(0) for _ in range(S)]
     ps = [p0.share(e) for e in engs]
     rbs = [packed.ResidentBatch(ps[k], d["proofs"], d["commitments"], d["min_values"], d["min_present"], None, bench.LABEL) for k in range(S)]
