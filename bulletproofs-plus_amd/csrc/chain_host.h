@@ -173,9 +173,10 @@ static inline __attribute__((always_inline)) void ms_xor_word(MultiStrobe<W> &s,
   s.st[q] ^= c << sh;
   if (sh) s.st[q + 1] ^= c >> (64 - sh);  // st has 25 words, R + 8 <= 200: q + 1 <= 21
 }
-static inline uint64_t ms_load_le(const uint8_t *p, uint32_t nb) {
+static inline __attribute__((always_inline)) uint64_t ms_load_le(const uint8_t *p, uint32_t nb) {
   uint64_t v = 0;
-  memcpy(&v, p, nb);  // little-endian host
+  if (nb == 8) memcpy(&v, p, 8);  // little-endian host; the common case as ONE load (a run-time length is a library call)
+  else memcpy(&v, p, nb);
   return v;
 }
 // absorb the same-length message of every chain (data[w] + off)
@@ -230,7 +231,8 @@ static inline __attribute__((always_inline)) void ms_squeeze(MultiStrobe<W> &s, 
     if (sh) v |= s.st[q + 1] << (64 - sh);
     for (int w = 0; w < W; w++) {
       const uint64_t x = v[w] & mask;
-      memcpy(out[w] + i, &x, nb);
+      if (nb == 8) memcpy(out[w] + i, &x, 8);
+      else memcpy(out[w] + i, &x, nb);
     }
     // zero the bytes just read
     V m0, m1;
@@ -411,11 +413,21 @@ static inline __attribute__((always_inline)) void fs_absorb(FastStrobe &s, const
     if (s.pos == BPP_STROBE_R) fs_run_f<PERM>(s);
   }
 }
+// a message of compile-time length that does not reach the end of the block: a handful of fixed-size loads and stores
+template <void (*PERM)(uint64_t *), uint32_t N>
+static inline __attribute__((always_inline)) void fs_absorb_fixed(FastStrobe &s, const uint8_t *d) {
+  if (s.pos + N < BPP_STROBE_R) {
+    fs_xor((uint8_t *)s.st + s.pos, d, N);
+    s.pos += N;
+  } else {
+    fs_absorb<PERM>(s, d, N);
+  }
+}
 template <void (*PERM)(uint64_t *)>
 static inline __attribute__((always_inline)) void fs_begin_op(FastStrobe &s, uint32_t flags) {
   const uint8_t hdr[2] = {(uint8_t)s.pos_begin, (uint8_t)flags};
   s.pos_begin = s.pos + 1;
-  fs_absorb<PERM>(s, hdr, 2);
+  fs_absorb_fixed<PERM, 2>(s, hdr);
   if ((flags & (BPP_FLAG_C | BPP_FLAG_K)) != 0 && s.pos != 0) fs_run_f<PERM>(s);
 }
 // rng: n x 32 transcript-RNG bytes -> out: n x 32 canonical non-zero weights (src/range_proof.rs:811,849,853,894)
@@ -431,9 +443,9 @@ static inline __attribute__((always_inline)) void weights_chain_single_impl(cons
   static const uint8_t proof_len[9] = {'p', 'r', 'o', 'o', 'f', 32, 0, 0, 0};  // label, then meta_ad(u32le(32), more = true)
   for (size_t i = 0; i < n; i++) {  // append_message(b"proof", bytes)
     fs_begin_op<PERM>(s, BPP_FLAG_M | BPP_FLAG_A);
-    fs_absorb<PERM>(s, proof_len, 9);
+    fs_absorb_fixed<PERM, 9>(s, proof_len);
     fs_begin_op<PERM>(s, BPP_FLAG_A);
-    fs_absorb<PERM>(s, rng + 32 * i, 32);
+    fs_absorb_fixed<PERM, 32>(s, rng + 32 * i);
   }
   // build_rng().finalize(&mut NullRng): meta_ad(b"rng"), key(32 zero bytes) = overwrite from position 0
   fs_begin_op<PERM>(s, BPP_FLAG_M | BPP_FLAG_A);
@@ -446,7 +458,7 @@ static inline __attribute__((always_inline)) void weights_chain_single_impl(cons
     uint8_t *w = out + 32 * i;
     do {  // Scalar::random_not_zero (src/protocols/scalar_protocol.rs:23-30): fill_bytes(64) = meta_ad(u32le(64)) + prf(64)
       fs_begin_op<PERM>(s, BPP_FLAG_M | BPP_FLAG_A);
-      fs_absorb<PERM>(s, len64, 4);
+      fs_absorb_fixed<PERM, 4>(s, len64);
       fs_begin_op<PERM>(s, BPP_FLAG_I | BPP_FLAG_A | BPP_FLAG_C);  // forces a permutation: the squeeze starts at position 0
       uint8_t wide[64];
       memcpy(wide, s.st, 64);
