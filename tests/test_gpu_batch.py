@@ -366,3 +366,75 @@ def test_baseline_cfg4_one_gpu(bpp, engine):
     bad[3000] = bpp.RangeProof.from_bytes(bytes(raw))
     k = _kind(bpp, lambda: bpp.RangeProof.verify_batch(trs4, pub4, bad, A.VerifyOnly, chunk=0))
     assert k in (bpp.ProofErrorKind.VerificationFailed, bpp.ProofErrorKind.InvalidArgument)
+
+
+def test_bench_step_full_size_properties(bpp, engine):
+    """bench.py's step (BASELINE configs[1] at the size the metric is quoted on: 64 reference batches of 1024 distinct
+    proofs in one engine call) through size-independent properties: every batch accepts and its MSM result is the identity;
+    a batch's weights and MSM result are functions of that batch alone (the same 1024 proofs verified on their own give the
+    same weights); tampered proofs turn exactly their own batches' results into non-identity points; one of the 65 536
+    batches' proofs checked end to end against the CPU oracle."""
+    import numpy as np
+    import bench
+    packed = importlib.import_module("bulletproofs-plus_amd.packed")
+    params = bpp.RangeParameters.init(64, 1, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    R = 64
+    d = bench.make_inputs(np, packed, params, 1024 * R, seed=20260704)
+    assert len({bytes(p) for p in d["proofs"][::257]}) == len(d["proofs"][::257])  # distinct proofs
+    rb = packed.ResidentBatch(params, d["proofs"], d["commitments"], d["min_values"], d["min_present"], None, bench.LABEL)
+    rb.verify_only(chunk=1024)
+    assert rb.shape()["groups"] == R
+    assert rb.trace(6) == bytes(32) * R
+    weights = rb.trace(3)
+    rb.close()
+    # batch 37 on its own: same weights (one chain per reference batch), same verdict
+    lo, hi = 37 * 1024, 38 * 1024
+    one = packed.ResidentBatch(params, d["proofs"][lo:hi], d["commitments"][lo:hi], d["min_values"][lo:hi], d["min_present"][lo:hi],
+                               None, bench.LABEL)
+    one.verify_only(chunk=0)
+    assert one.trace(3) == weights[32 * lo:32 * hi] and one.trace(6) == bytes(32)
+    one.close()
+    # the CPU oracle agrees on a sample of the prover's output (accept, and the same first weights)
+    cp = cport.Params(64, 1, 1)
+    items = [{"proof": bytes(d["proofs"][i]), "commitments": [bytes(d["commitments"][i, 0])], "min_values": [int(d["min_values"][i, 0])],
+              "seed_nonce": None, "label": bench.LABEL} for i in range(lo, lo + 64)]
+    rc, _, tr = cp.verify(items, action=0, want_trace=True)
+    assert rc == 0
+    cp.close()
+    # tampering: r1 of one proof in batch 5, a minimum-value promise in batch 40, L_0 of a proof in batch 63
+    bad_p = d["proofs"].copy()
+    bad_mv = d["min_values"].copy()
+    bad_p[5 * 1024 + 17, 1 + 32 + 96 + 3] ^= 4
+    bad_mv[40 * 1024 + 1000, 0] += np.uint64(1)
+    bad_p[63 * 1024 + 1023, 1 + 32 + 160 + 7] ^= 1
+    rb = packed.ResidentBatch(params, bad_p, d["commitments"], bad_mv, d["min_present"], None, bench.LABEL)
+    k = _kind(bpp, lambda: rb.verify_only(chunk=1024))
+    assert k in (bpp.ProofErrorKind.VerificationFailed, bpp.ProofErrorKind.InvalidArgument)  # L_0 may stop decoding
+    res = rb.trace(6)
+    nonid = [g for g in range(R) if res[32 * g:32 * g + 32] != bytes(32)]
+    assert set(nonid) >= {5, 40} and set(nonid) <= {5, 40, 63}
+    rb.close()
+    params.close()
+
+
+def test_msm_linearity_at_scale(bpp, engine):
+    """multiscalar multiplication at 200 000 terms (the oracle needs minutes there): msm(s) + msm(t) == msm(s + t) and
+    msm(a s) == a msm(s), the points being 2 000 distinct ones repeated"""
+    n = 200_000
+    pts = [C.from_uniform_bytes(hashlib.shake_256(b"lin-p%d" % i).digest(64)).compress() for i in range(2000)]
+    P = [pts[(7 * i) % 2000] for i in range(n)]
+    s = [int.from_bytes(hashlib.shake_256(b"lin-s%d" % i).digest(32), "little") % C.L for i in range(n)]
+    t = [int.from_bytes(hashlib.shake_256(b"lin-t%d" % i).digest(32), "little") % C.L for i in range(n)]
+    a = int.from_bytes(hashlib.shake_256(b"lin-a").digest(32), "little") % C.L
+    rs = engine.msm_vartime([sb(x) for x in s], P)
+    rt = engine.msm_vartime([sb(x) for x in t], P)
+    rst = engine.msm_vartime([sb((x + y) % C.L) for x, y in zip(s, t)], P)
+    ras = engine.msm_vartime([sb(a * x % C.L) for x in s], P)
+    assert rs != bytes(32) and rs != rt
+    assert engine.msm_vartime([sb(1), sb(1)], [rs, rt]) == rst
+    assert engine.msm_vartime([sb(a)], [rs]) == ras
+    # against the oracle on the folded problem: 2 000 points with the summed scalars
+    folded = [0] * 2000
+    for i, x in enumerate(s):
+        folded[(7 * i) % 2000] = (folded[(7 * i) % 2000] + x) % C.L
+    assert rs == engine.msm_vartime([sb(x) for x in folded], pts)
