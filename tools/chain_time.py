@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Host timing of the batch-weight chains through libbpp_hosttest.so (g++ -O2 build: for the engine's own clang -O3 build use
+tools/microbench/chain_forms.cpp): lock-step bundles of 1 / 4 / 8 chains and the three forms of the single chain."""
 import ctypes, importlib, os, sys, time
-sys.path.insert(0, '/root/repo' if os.path.isdir('/root/repo/tests') else os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("bulletproofs-plus_amd")
 ht = ctypes.CDLL(pkg._build.build_hosttest())
 n = 1024
