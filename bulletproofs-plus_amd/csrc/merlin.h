@@ -10,7 +10,36 @@
 
 namespace bpp {
 
-BPP_HD uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+// The three primitives of a round.  On the device a 64-bit word is two registers: gfx950's three-input boolean
+// instruction v_bitop3_b32 does theta's a ^ b ^ c (table 0x96) and chi's a ^ (~b & c) (table 0xD2) in one instruction per
+// half instead of two, and a rotation by a constant is two v_alignbit_b32 (the compiler's 64-bit shift pair + or takes
+// three): 290 -> 196 VALU instructions per round.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint64_t kk_join(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
+__device__ __forceinline__ uint64_t kk_xor3(uint64_t a, uint64_t b, uint64_t c) {
+  return kk_join(__builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0x96),
+                 __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0x96));
+}
+__device__ __forceinline__ uint64_t kk_chi(uint64_t a, uint64_t b, uint64_t c) {
+  return kk_join(__builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0xD2),
+                 __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0xD2));
+}
+template <int N>
+__device__ __forceinline__ uint64_t kk_rol(uint64_t x) {
+  static_assert(N > 0 && N < 64, "rotation amount");
+  const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  if (N == 32) return kk_join(hi, lo);
+  if (N < 32) return kk_join(__builtin_amdgcn_alignbit(lo, hi, 32 - N), __builtin_amdgcn_alignbit(hi, lo, 32 - N));
+  return kk_join(__builtin_amdgcn_alignbit(hi, lo, 64 - N), __builtin_amdgcn_alignbit(lo, hi, 64 - N));
+}
+#else
+BPP_HD uint64_t kk_xor3(uint64_t a, uint64_t b, uint64_t c) { return a ^ b ^ c; }
+BPP_HD uint64_t kk_chi(uint64_t a, uint64_t b, uint64_t c) { return a ^ (~b & c); }
+template <int N>
+BPP_HD uint64_t kk_rol(uint64_t x) {
+  return (x << N) | (x >> (64 - N));
+}
+#endif
 
 BPP_HD void keccak_f1600(uint64_t a[25]) {
   const uint64_t RC[24] = {
@@ -27,54 +56,50 @@ BPP_HD void keccak_f1600(uint64_t a[25]) {
   uint64_t a20 = a[20], a21 = a[21], a22 = a[22], a23 = a[23], a24 = a[24];
 #pragma unroll 1
   for (int rnd = 0; rnd < 24; rnd++) {
-    // theta
-    uint64_t c0 = a00 ^ a05 ^ a10 ^ a15 ^ a20;
-    uint64_t c1 = a01 ^ a06 ^ a11 ^ a16 ^ a21;
-    uint64_t c2 = a02 ^ a07 ^ a12 ^ a17 ^ a22;
-    uint64_t c3 = a03 ^ a08 ^ a13 ^ a18 ^ a23;
-    uint64_t c4 = a04 ^ a09 ^ a14 ^ a19 ^ a24;
-    uint64_t d0 = c4 ^ rotl64(c1, 1);
-    uint64_t d1 = c0 ^ rotl64(c2, 1);
-    uint64_t d2 = c1 ^ rotl64(c3, 1);
-    uint64_t d3 = c2 ^ rotl64(c4, 1);
-    uint64_t d4 = c3 ^ rotl64(c0, 1);
-    a00 ^= d0; a05 ^= d0; a10 ^= d0; a15 ^= d0; a20 ^= d0;
-    a01 ^= d1; a06 ^= d1; a11 ^= d1; a16 ^= d1; a21 ^= d1;
-    a02 ^= d2; a07 ^= d2; a12 ^= d2; a17 ^= d2; a22 ^= d2;
-    a03 ^= d3; a08 ^= d3; a13 ^= d3; a18 ^= d3; a23 ^= d3;
-    a04 ^= d4; a09 ^= d4; a14 ^= d4; a19 ^= d4; a24 ^= d4;
+    // theta: column parities, then every word takes parity(x-1) ^ rol(parity(x+1), 1) in one three-input xor
+    const uint64_t c0 = kk_xor3(kk_xor3(a00, a05, a10), a15, a20);
+    const uint64_t c1 = kk_xor3(kk_xor3(a01, a06, a11), a16, a21);
+    const uint64_t c2 = kk_xor3(kk_xor3(a02, a07, a12), a17, a22);
+    const uint64_t c3 = kk_xor3(kk_xor3(a03, a08, a13), a18, a23);
+    const uint64_t c4 = kk_xor3(kk_xor3(a04, a09, a14), a19, a24);
+    const uint64_t r0 = kk_rol<1>(c0), r1 = kk_rol<1>(c1), r2 = kk_rol<1>(c2), r3 = kk_rol<1>(c3), r4 = kk_rol<1>(c4);
+    a00 = kk_xor3(a00, c4, r1); a05 = kk_xor3(a05, c4, r1); a10 = kk_xor3(a10, c4, r1); a15 = kk_xor3(a15, c4, r1); a20 = kk_xor3(a20, c4, r1);
+    a01 = kk_xor3(a01, c0, r2); a06 = kk_xor3(a06, c0, r2); a11 = kk_xor3(a11, c0, r2); a16 = kk_xor3(a16, c0, r2); a21 = kk_xor3(a21, c0, r2);
+    a02 = kk_xor3(a02, c1, r3); a07 = kk_xor3(a07, c1, r3); a12 = kk_xor3(a12, c1, r3); a17 = kk_xor3(a17, c1, r3); a22 = kk_xor3(a22, c1, r3);
+    a03 = kk_xor3(a03, c2, r4); a08 = kk_xor3(a08, c2, r4); a13 = kk_xor3(a13, c2, r4); a18 = kk_xor3(a18, c2, r4); a23 = kk_xor3(a23, c2, r4);
+    a04 = kk_xor3(a04, c3, r0); a09 = kk_xor3(a09, c3, r0); a14 = kk_xor3(a14, c3, r0); a19 = kk_xor3(a19, c3, r0); a24 = kk_xor3(a24, c3, r0);
     // rho + pi: b[y][2x+3y] = rot(a[x][y])
-    uint64_t b00 = a00;
-    uint64_t b10 = rotl64(a01, 1);
-    uint64_t b20 = rotl64(a02, 62);
-    uint64_t b05 = rotl64(a03, 28);
-    uint64_t b15 = rotl64(a04, 27);
-    uint64_t b16 = rotl64(a05, 36);
-    uint64_t b01 = rotl64(a06, 44);
-    uint64_t b11 = rotl64(a07, 6);
-    uint64_t b21 = rotl64(a08, 55);
-    uint64_t b06 = rotl64(a09, 20);
-    uint64_t b07 = rotl64(a10, 3);
-    uint64_t b17 = rotl64(a11, 10);
-    uint64_t b02 = rotl64(a12, 43);
-    uint64_t b12 = rotl64(a13, 25);
-    uint64_t b22 = rotl64(a14, 39);
-    uint64_t b23 = rotl64(a15, 41);
-    uint64_t b08 = rotl64(a16, 45);
-    uint64_t b18 = rotl64(a17, 15);
-    uint64_t b03 = rotl64(a18, 21);
-    uint64_t b13 = rotl64(a19, 8);
-    uint64_t b14 = rotl64(a20, 18);
-    uint64_t b24 = rotl64(a21, 2);
-    uint64_t b09 = rotl64(a22, 61);
-    uint64_t b19 = rotl64(a23, 56);
-    uint64_t b04 = rotl64(a24, 14);
+    const uint64_t b00 = a00;
+    const uint64_t b10 = kk_rol<1>(a01);
+    const uint64_t b20 = kk_rol<62>(a02);
+    const uint64_t b05 = kk_rol<28>(a03);
+    const uint64_t b15 = kk_rol<27>(a04);
+    const uint64_t b16 = kk_rol<36>(a05);
+    const uint64_t b01 = kk_rol<44>(a06);
+    const uint64_t b11 = kk_rol<6>(a07);
+    const uint64_t b21 = kk_rol<55>(a08);
+    const uint64_t b06 = kk_rol<20>(a09);
+    const uint64_t b07 = kk_rol<3>(a10);
+    const uint64_t b17 = kk_rol<10>(a11);
+    const uint64_t b02 = kk_rol<43>(a12);
+    const uint64_t b12 = kk_rol<25>(a13);
+    const uint64_t b22 = kk_rol<39>(a14);
+    const uint64_t b23 = kk_rol<41>(a15);
+    const uint64_t b08 = kk_rol<45>(a16);
+    const uint64_t b18 = kk_rol<15>(a17);
+    const uint64_t b03 = kk_rol<21>(a18);
+    const uint64_t b13 = kk_rol<8>(a19);
+    const uint64_t b14 = kk_rol<18>(a20);
+    const uint64_t b24 = kk_rol<2>(a21);
+    const uint64_t b09 = kk_rol<61>(a22);
+    const uint64_t b19 = kk_rol<56>(a23);
+    const uint64_t b04 = kk_rol<14>(a24);
     // chi
-    a00 = b00 ^ (~b01 & b02); a01 = b01 ^ (~b02 & b03); a02 = b02 ^ (~b03 & b04); a03 = b03 ^ (~b04 & b00); a04 = b04 ^ (~b00 & b01);
-    a05 = b05 ^ (~b06 & b07); a06 = b06 ^ (~b07 & b08); a07 = b07 ^ (~b08 & b09); a08 = b08 ^ (~b09 & b05); a09 = b09 ^ (~b05 & b06);
-    a10 = b10 ^ (~b11 & b12); a11 = b11 ^ (~b12 & b13); a12 = b12 ^ (~b13 & b14); a13 = b13 ^ (~b14 & b10); a14 = b14 ^ (~b10 & b11);
-    a15 = b15 ^ (~b16 & b17); a16 = b16 ^ (~b17 & b18); a17 = b17 ^ (~b18 & b19); a18 = b18 ^ (~b19 & b15); a19 = b19 ^ (~b15 & b16);
-    a20 = b20 ^ (~b21 & b22); a21 = b21 ^ (~b22 & b23); a22 = b22 ^ (~b23 & b24); a23 = b23 ^ (~b24 & b20); a24 = b24 ^ (~b20 & b21);
+    a00 = kk_chi(b00, b01, b02); a01 = kk_chi(b01, b02, b03); a02 = kk_chi(b02, b03, b04); a03 = kk_chi(b03, b04, b00); a04 = kk_chi(b04, b00, b01);
+    a05 = kk_chi(b05, b06, b07); a06 = kk_chi(b06, b07, b08); a07 = kk_chi(b07, b08, b09); a08 = kk_chi(b08, b09, b05); a09 = kk_chi(b09, b05, b06);
+    a10 = kk_chi(b10, b11, b12); a11 = kk_chi(b11, b12, b13); a12 = kk_chi(b12, b13, b14); a13 = kk_chi(b13, b14, b10); a14 = kk_chi(b14, b10, b11);
+    a15 = kk_chi(b15, b16, b17); a16 = kk_chi(b16, b17, b18); a17 = kk_chi(b17, b18, b19); a18 = kk_chi(b18, b19, b15); a19 = kk_chi(b19, b15, b16);
+    a20 = kk_chi(b20, b21, b22); a21 = kk_chi(b21, b22, b23); a22 = kk_chi(b22, b23, b24); a23 = kk_chi(b23, b24, b20); a24 = kk_chi(b24, b20, b21);
     a00 ^= RC[rnd];
   }
   a[0] = a00; a[1] = a01; a[2] = a02; a[3] = a03; a[4] = a04;

@@ -72,13 +72,13 @@ __device__ __forceinline__ void keccak_f1600_wave(uint64_t *st, const KeccakLane
   for (int rnd = 0; rnd < 24; rnd++) {
     if (rnd != 0 && K.owner) w[self] = a;
     const volatile lds_u64 *m = w + K.xm1, *p = w + K.xp1;  // theta
-    const uint64_t cm = m[0] ^ m[5] ^ m[10] ^ m[15] ^ m[20];
-    const uint64_t cp = p[0] ^ p[5] ^ p[10] ^ p[15] ^ p[20];
-    a ^= cm ^ ((cp << 1) | (cp >> 63));
+    const uint64_t cm = kk_xor3(kk_xor3(m[0], m[5], m[10]), m[15], m[20]);
+    const uint64_t cp = kk_xor3(kk_xor3(p[0], p[5], p[10]), p[15], p[20]);
+    a = kk_xor3(a, cm, kk_rol<1>(cp));
     const uint64_t r = (a << K.rot) | (a >> ((64u - K.rot) & 63u));  // rho (rot = 0: a | a)
     if (K.owner) w[self] = r;
     const uint64_t b = w[K.pinv], b1 = w[K.pn1], b2 = w[K.pn2];  // pi + chi
-    a = b ^ (~b1 & b2);
+    a = kk_chi(b, b1, b2);
     if (K.lane0) a ^= RC[rnd];  // iota
   }
   if (K.owner) w[self] = a;
