@@ -64,9 +64,15 @@ __global__ void __launch_bounds__(1024) k_msm_sort(const int16_t *__restrict__ d
   const uint32_t region = t0 * K + k * ng;
   for (uint32_t j = tid; j < nb; j += 1024) hist[j] = 0;
   __syncthreads();
-  for (uint32_t i = tid; i < ng; i += 1024) {
-    const int32_t d = dg[i];
-    if (d) atomicAdd(&hist[(uint32_t)(d < 0 ? -d : d) - 1], 1u);
+  // eight independent loads in flight per lane before the first atomic (one load per trip left every trip a full memory
+  // round trip long: the kernel's blocks of sixteen wavefronts sat on their wave slots for 80 us doing nothing)
+  for (uint32_t i0 = tid; i0 < ng; i0 += 8 * 1024) {
+    int32_t d[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) d[u] = (i0 + u * 1024 < ng) ? (int32_t)dg[i0 + u * 1024] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (d[u]) atomicAdd(&hist[(uint32_t)(d[u] < 0 ? -d[u] : d[u]) - 1], 1u);
   }
   __syncthreads();
   // exclusive scan of hist[0..nb): thread t owns a contiguous run of `per` bins
@@ -92,12 +98,21 @@ __global__ void __launch_bounds__(1024) k_msm_sort(const int16_t *__restrict__ d
     run += cnt;
   }
   __syncthreads();
-  for (uint32_t i = tid; i < ng; i += 1024) {
-    const int32_t d = dg[i];
-    if (d) {
-      const uint32_t pos = atomicAdd(&cur[(uint32_t)(d < 0 ? -d : d) - 1], 1u);
-      sorted[region + pos] = term_pidx[t0 + i] | (d < 0 ? 0x80000000u : 0u);  // point index, sign in bit 31
+  for (uint32_t i0 = tid; i0 < ng; i0 += 8 * 1024) {
+    int32_t d[8];
+    uint32_t pi[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const bool in = i0 + u * 1024 < ng;
+      d[u] = in ? (int32_t)dg[i0 + u * 1024] : 0;
+      pi[u] = in ? term_pidx[t0 + i0 + u * 1024] : 0u;
     }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (d[u]) {
+        const uint32_t pos = atomicAdd(&cur[(uint32_t)(d[u] < 0 ? -d[u] : d[u]) - 1], 1u);
+        sorted[region + pos] = pi[u] | (d[u] < 0 ? 0x80000000u : 0u);  // point index, sign in bit 31
+      }
   }
 }
 
