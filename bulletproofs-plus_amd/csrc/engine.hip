@@ -448,7 +448,7 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
   dim3 gt(cdiv(w.max_group_terms, 256), plan.G);
   hipLaunchKernelGGL(k_msm_digits, gt, dim3(256), 0, s, scalars, w.term_sidx.p, w.group_off.p, plan, w.digits.p);
   if (tm) tm->mark(M_DIGITS);
-  hipLaunchKernelGGL(k_msm_sort, dim3(plan.K, plan.G), dim3(1024), 2 * plan.nb * sizeof(uint32_t), s, w.digits.p, w.group_off.p,
+  hipLaunchKernelGGL(k_msm_sort, dim3(plan.K, plan.G), dim3(BPP_SORT_THREADS), 2 * plan.nb * sizeof(uint32_t), s, w.digits.p, w.group_off.p,
                      w.term_pidx.p, plan, w.counts.p, w.starts.p, w.sorted.p);
   if (tm) tm->mark(M_SORT);
   const uint32_t per_group = plan.K * plan.nb;

@@ -51,38 +51,42 @@ __global__ void __launch_bounds__(256) k_msm_digits(const sc *__restrict__ scala
 // Pass 1 histograms the window's digits with LDS atomics, an in-LDS scan turns counts into offsets, pass 2 scatters
 // term ids (sign in bit 31) into sorted[] -- no global atomics, no global scan.  grid = (K, G), block 1024.
 // Region of (g, k) in sorted[]: [goff[g]*K + k*ng, +ng).  Dynamic LDS: 2 * nb u32. ----
-__global__ void __launch_bounds__(1024) k_msm_sort(const int16_t *__restrict__ digitsT, const uint32_t *__restrict__ group_off,
+#ifndef BPP_SORT_THREADS
+#define BPP_SORT_THREADS 1024
+#endif
+__global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_sort(const int16_t *__restrict__ digitsT, const uint32_t *__restrict__ group_off,
                                                    const uint32_t *__restrict__ term_pidx, MsmPlan plan,
                                                    uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
                                                    uint32_t *__restrict__ sorted) {
   extern __shared__ uint32_t lds[];
   const uint32_t k = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, nb = plan.nb, K = plan.K;
   uint32_t *hist = lds, *cur = lds + nb;
-  __shared__ uint32_t part[1024];
+  __shared__ uint32_t part[BPP_SORT_THREADS];
+  constexpr uint32_t T = BPP_SORT_THREADS;
   const uint32_t t0 = group_off[g], ng = group_off[g + 1] - t0;
   const int16_t *dg = digitsT + (size_t)t0 * K + (size_t)k * ng;
   const uint32_t region = t0 * K + k * ng;
-  for (uint32_t j = tid; j < nb; j += 1024) hist[j] = 0;
+  for (uint32_t j = tid; j < nb; j += T) hist[j] = 0;
   __syncthreads();
   // eight independent loads in flight per lane before the first atomic (one load per trip left every trip a full memory
   // round trip long: the kernel's blocks of sixteen wavefronts sat on their wave slots for 80 us doing nothing)
-  for (uint32_t i0 = tid; i0 < ng; i0 += 8 * 1024) {
+  for (uint32_t i0 = tid; i0 < ng; i0 += 8 * T) {
     int32_t d[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) d[u] = (i0 + u * 1024 < ng) ? (int32_t)dg[i0 + u * 1024] : 0;
+    for (int u = 0; u < 8; u++) d[u] = (i0 + u * T < ng) ? (int32_t)dg[i0 + u * T] : 0;
 #pragma unroll
     for (int u = 0; u < 8; u++)
       if (d[u]) atomicAdd(&hist[(uint32_t)(d[u] < 0 ? -d[u] : d[u]) - 1], 1u);
   }
   __syncthreads();
   // exclusive scan of hist[0..nb): thread t owns a contiguous run of `per` bins
-  const uint32_t per = (nb + 1023u) / 1024u;
+  const uint32_t per = (nb + T - 1u) / T;
   const uint32_t a = tid * per < nb ? tid * per : nb, b = (a + per < nb) ? a + per : nb;
   uint32_t sum = 0;
   for (uint32_t j = a; j < b; j++) sum += hist[j];
   part[tid] = sum;
   __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {
+  for (uint32_t off = 1; off < T; off <<= 1) {
     uint32_t v = (tid >= off) ? part[tid - off] : 0;
     __syncthreads();
     part[tid] += v;
@@ -98,14 +102,14 @@ __global__ void __launch_bounds__(1024) k_msm_sort(const int16_t *__restrict__ d
     run += cnt;
   }
   __syncthreads();
-  for (uint32_t i0 = tid; i0 < ng; i0 += 8 * 1024) {
+  for (uint32_t i0 = tid; i0 < ng; i0 += 8 * T) {
     int32_t d[8];
     uint32_t pi[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const bool in = i0 + u * 1024 < ng;
-      d[u] = in ? (int32_t)dg[i0 + u * 1024] : 0;
-      pi[u] = in ? term_pidx[t0 + i0 + u * 1024] : 0u;
+      const bool in = i0 + u * T < ng;
+      d[u] = in ? (int32_t)dg[i0 + u * T] : 0;
+      pi[u] = in ? term_pidx[t0 + i0 + u * T] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < 8; u++)
