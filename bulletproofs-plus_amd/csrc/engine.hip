@@ -1113,7 +1113,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
   HIP_CHECK(hipMemcpyAsync(b.status.p, b.status0.p, (size_t)b.B * 4, hipMemcpyDeviceToDevice, s));
   // Decompression needs nothing PASS 1 produces (both only OR bits into status[]).  A small input leaves most of the chip
   // idle, so its decompression runs beside PASS 1 and the weight-free scalars on a second stream and joins before the
-  // weights are needed (one 256-proof call 0.84 -> 0.77 ms).  Large inputs fill the chip either way: one stream, less
+  // weights are needed (one 256-proof call 0.84 -> 0.79 ms).  Large inputs fill the chip either way: one stream, less
   // bookkeeping (measured: no gain).  Stage profiling keeps the serial order so that its intervals mean something.
   const char *fs = getenv("BPP_SIDE_DECOMPRESS");  // tests force either form
   const bool side = (fs ? atoi(fs) != 0 : b.B <= BPP_SIDE_DECOMPRESS_MAX) && !ctx->profile;
