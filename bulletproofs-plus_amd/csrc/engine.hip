@@ -389,10 +389,15 @@ static bool decompress_spill_enabled() {
 
 
 // ------------------------------------------------------------------ MSM driver
-uint32_t choose_window(uint32_t group_terms) {
+uint32_t choose_window(uint32_t group_terms, uint32_t all_terms) {
   // buckets per window ~ terms / 12  (bucket lists of ~12 points keep the per-lane chains short)
   uint32_t c = 4;
   while (c < 14 && (1u << c) * 12u <= group_terms) c++;  // nb = 2^(c-1)
+  // A small call has the chip to itself: its time is the length of the dependency chains, not the number of additions.
+  // Wider windows shorten the bucket lists (accumulation) and the Horner step (fewer windows to add) for a longer
+  // row / column reduction: three more bits are worth 0.07-0.1 ms up to a few hundred proofs (one proof 0.79 -> 0.68 ms).
+  static const int bias = getenv("BPP_MSM_C_BIAS") ? atoi(getenv("BPP_MSM_C_BIAS")) : 3;
+  if (all_terms <= 20000u) c = (uint32_t)std::max(4, std::min(11, (int)c + bias));
   return c;
 }
 
@@ -402,7 +407,7 @@ void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff)
   const uint32_t G = (uint32_t)goff.size() - 1, n = goff[G];
   uint32_t maxg = 0;
   for (uint32_t g = 0; g < G; g++) maxg = std::max(maxg, goff[g + 1] - goff[g]);
-  const MsmPlan plan = msm_make_plan(choose_window(maxg), G, n);
+  const MsmPlan plan = msm_make_plan(choose_window(maxg, n), G, n);
   w.plan = plan;
   w.max_group_terms = maxg;
   const size_t nbk = (size_t)G * plan.K * plan.nb;
