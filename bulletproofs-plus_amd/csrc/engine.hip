@@ -474,7 +474,7 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
                        w.counts.p, w.order.p, tabs, per_group, plan.G, w.buckets.p);
   if (tm) tm->mark(M_ACC);
   if (plan.c <= 11 && small) {
-    hipLaunchKernelGGL(k_msm_window_rc_quad, dim3(plan.G * plan.K), dim3(256), 0, s, w.buckets.p, w.counts.p, plan, w.W.p);
+    hipLaunchKernelGGL(k_msm_window_rc_quad, dim3(plan.G * plan.K), dim3(1024), 0, s, w.buckets.p, w.counts.p, plan, w.W.p);
   } else if (plan.c <= 11) {
     hipLaunchKernelGGL(k_msm_window_rc, dim3(plan.G * plan.K), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.W.p);
   } else {

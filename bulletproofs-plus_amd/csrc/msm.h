@@ -462,6 +462,27 @@ __device__ __forceinline__ void quad_ge_madd(fe &m, const QuadMask &q, const nie
   fe_carry(gg);
   quad_efgh(m, q, e, f, gg, h);  // X3 = e*f, Y3 = g*h, Z3 = f*g, T3 = e*h
 }
+// acc = 2 acc, acc spread over the quad: four squarings (X^2, Y^2, Z^2, (X+Y)^2), then the four products of quad_efgh
+__device__ __forceinline__ void quad_ge_dbl(fe &m, const QuadMask &q) {
+  fe x, y, v, s2;
+  quad_bcast<0>(x, m);
+  quad_bcast<1>(y, m);
+  fe_add(v, x, y);
+  fe_sel_lane3(v, q, m, v);  // X, Y, Z, X + Y
+  fe_sq(s2, v);
+  fe a, b, c, t, e, f, gg, h;
+  quad_bcast<0>(a, s2);
+  quad_bcast<1>(b, s2);
+  quad_bcast<2>(c, s2);
+  quad_bcast<3>(t, s2);
+  // limb classes as in ge_dbl_efgh (point.h): e wide (left operand only), g and h loose, f carried: one carry pass
+  fe_add(h, a, b);
+  fe_sub_lazy(e, h, t);
+  fe_sub_lazy(gg, a, b);
+  fe_dbl_add(f, c, gg);
+  fe_carry(f);
+  quad_efgh(m, q, e, f, gg, h);
+}
 __device__ __forceinline__ void quad_load(fe &m, const QuadMask &q, const ge &p) { fe_sel4(m, q, p.X, p.Y, p.Z, p.T); }
 __device__ __forceinline__ void quad_gather(ge &p, const fe &m) {
   quad_bcast<0>(p.X, m);
@@ -488,26 +509,7 @@ __global__ void __launch_bounds__(64) k_msm_final_quad(const ge *__restrict__ W,
   for (int k = (int)plan.K - 2; k >= 0; k--) {
     const int n = (uint32_t)k < plan.K_wide ? (int)plan.c : (int)plan.c - 1;  // width of window k
 #pragma unroll 1
-    for (int i = 0; i < n; i++) {
-      fe x, y, v, s2;
-      quad_bcast<0>(x, m);
-      quad_bcast<1>(y, m);
-      fe_add(v, x, y);
-      fe_sel_lane3(v, q, m, v);  // X, Y, Z, X + Y
-      fe_sq(s2, v);
-      fe a, b, c, t, e, f, gg, h;
-      quad_bcast<0>(a, s2);
-      quad_bcast<1>(b, s2);
-      quad_bcast<2>(c, s2);
-      quad_bcast<3>(t, s2);
-      // limb classes as in ge_dbl_efgh (point.h): e wide (left operand only), g and h loose, f carried: one carry pass
-      fe_add(h, a, b);
-      fe_sub_lazy(e, h, t);
-      fe_sub_lazy(gg, a, b);
-      fe_dbl_add(f, c, gg);
-      fe_carry(f);
-      quad_efgh(m, q, e, f, gg, h);
-    }
+    for (int i = 0; i < n; i++) quad_ge_dbl(m, q);
     // acc += W_k
     {
       const ge wk = w[k];
@@ -561,15 +563,19 @@ __global__ void __launch_bounds__(64) k_msm_accumulate_quad(const uint32_t *__re
   dst[qi] = m;
 }
 
-// one workgroup of 256 lanes per (group, window): quad i plays the part of lane i of k_msm_window_rc
-__global__ void __launch_bounds__(256) k_msm_window_rc_quad(const ge *__restrict__ buckets, const uint32_t *__restrict__ counts,
-                                                            MsmPlan plan, ge *__restrict__ W) {
-  const uint32_t gk = blockIdx.x, tid = threadIdx.x, qi = tid & 3u, lane = tid >> 2;
+// one workgroup of 1024 lanes per (group, window): 256 quads.  Quad (seg, i) adds a quarter of the buckets of row / column i
+// of k_msm_window_rc's grid (8 dependent additions instead of 32 at 11 bits; this form only runs when the chip is nearly
+// idle, so lanes are free and the chain is what counts), the four partial sums meet in a two-step tree, then quads
+// (0, i) go on as lane i of k_msm_window_rc does; the closing doublings and addition are split over quad (0, 0).
+#define BPP_RC_QUAD_SEGS 4u
+__global__ void __launch_bounds__(1024) k_msm_window_rc_quad(const ge *__restrict__ buckets, const uint32_t *__restrict__ counts,
+                                                             MsmPlan plan, ge *__restrict__ W) {
+  const uint32_t gk = blockIdx.x, tid = threadIdx.x, qi = tid & 3u, quad = tid >> 2, lane = quad & 63u, seg = quad >> 6;
   const QuadMask q = quad_mask(qi);
   const uint32_t nb = plan.nb, lb = plan.c - 1;
   const uint32_t lBc = lb / 2, Bc = 1u << lBc, A = nb >> lBc;  // A >= Bc
   const size_t base = (size_t)gk * nb;
-  __shared__ ge red[64];
+  __shared__ ge red[64 * BPP_RC_QUAD_SEGS];
   fe d2, one, m;
   fe_const(d2, FE_D2);
   fe_1(one);
@@ -580,7 +586,9 @@ __global__ void __launch_bounds__(256) k_msm_window_rc_quad(const ge *__restrict
   const uint32_t idx = is_row ? lane : lane - 32;
   if (is_row ? (idx < A) : (idx < Bc)) {
     const uint32_t cnt = is_row ? Bc : A;
-    for (uint32_t k = 0; k < cnt; k++) {
+    const uint32_t per = (cnt + BPP_RC_QUAD_SEGS - 1u) / BPP_RC_QUAD_SEGS;
+    const uint32_t k0 = seg * per < cnt ? seg * per : cnt, k1 = k0 + per < cnt ? k0 + per : cnt;
+    for (uint32_t k = k0; k < k1; k++) {
       const uint32_t j0 = is_row ? (Bc * idx + k) : (Bc * k + idx);
       if (counts[base + j0]) {
         const ge x = buckets[base + j0];
@@ -588,14 +596,26 @@ __global__ void __launch_bounds__(256) k_msm_window_rc_quad(const ge *__restrict
       }
     }
   }
-  fe *slot = (fe *)&red[lane];
-  // suffix scan within each half: x[i] = sum_{i' >= i} x[i']
+  fe *slot = (fe *)&red[quad];
   slot[qi] = m;
   __syncthreads();
+  // partial sums of the segments: (0 += 1, 2 += 3), then 0 += 2
+  for (uint32_t step = 1; step < BPP_RC_QUAD_SEGS; step <<= 1) {
+    const bool act = (seg % (2u * step)) == 0 && seg + step < BPP_RC_QUAD_SEGS;
+    if (act) {
+      const ge y2 = red[quad + 64u * step];
+      quad_ge_add(m, q, y2, d2, one);
+    }
+    __syncthreads();
+    if (act) slot[qi] = m;
+    __syncthreads();
+  }
+  const bool lead = seg == 0;  // from here on quads (0, i) only; the others keep the barriers company
+  // suffix scan within each half: x[i] = sum_{i' >= i} x[i']
   const uint32_t half_n = is_row ? A : Bc;
   for (uint32_t off = 1; off < 32; off <<= 1) {
     ge y2;
-    const bool act = idx + off < half_n;
+    const bool act = lead && idx + off < half_n;
     if (act) y2 = red[lane + off];
     __syncthreads();
     if (act) {
@@ -606,22 +626,23 @@ __global__ void __launch_bounds__(256) k_msm_window_rc_quad(const ge *__restrict
   }
   // rows: sum_a a*R_a = sum_{i>=1} suffix_i ; columns (b = idx+1): sum_b b*C_b = sum_{i>=0} suffix_i
   if (is_row ? (idx == 0 || idx >= A) : (idx >= Bc)) quad_load(m, q, id);
-  slot[qi] = m;
+  if (lead) slot[qi] = m;
   __syncthreads();
   for (uint32_t off = 16; off >= 1; off >>= 1) {
-    if (idx < off) {
+    if (lead && idx < off) {
       const ge y2 = red[lane + off];
       quad_ge_add(m, q, y2, d2, one);
       slot[qi] = m;
     }
     __syncthreads();
   }
-  if (tid == 0) {
-    ge rows = red[0];
+  if (quad == 0) {  // W = Bc * rows + cols: m holds the rows' sum (red[0]), spread over the quad
+    for (uint32_t i = 0; i < lBc; i++) quad_ge_dbl(m, q);
     const ge cols = red[32];
-    if (lBc) ge_dbl_n(rows, rows, (int)lBc);
-    ge_add(rows, rows, cols);
-    W[gk] = rows;
+    quad_ge_add(m, q, cols, d2, one);
+    ge w;
+    quad_gather(w, m);
+    if (qi == 0) W[gk] = w;
   }
 }
 
