@@ -1400,8 +1400,14 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
   sc *dyn_scal = b.scal.p + (size_t)b.G * b.cols;
   {
     const uint32_t nhi_max = b.lanes_nhi_max(P.n_bits);
-    hipLaunchKernelGGL(k_scalars_weighted, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.d_desc.p, b.shr.p, b.weights.p, P.n_bits, P.t,
-                       b.max_mn, b.cols, b.B, nhi_max, b.tab.p, b.rows.p, dyn_scal);
+    const char *ft = getenv("BPP_TABLES_WAVE");  // as in enqueue_phase1: small inputs take the one-wavefront-per-proof forms
+    const bool tw = ft ? atoi(ft) != 0 : b.B <= BPP_TABLES_WAVE_MAX;
+    if (tw)
+      hipLaunchKernelGGL(k_scalars_weighted_wave, dim3(b.B), dim3(64), 0, s, b.d_desc.p, b.shr.p, b.weights.p, P.n_bits, P.t,
+                         b.max_mn, b.cols, b.B, nhi_max, b.tab.p, b.rows.p, dyn_scal);
+    else
+      hipLaunchKernelGGL(k_scalars_weighted, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.d_desc.p, b.shr.p, b.weights.p, P.n_bits, P.t,
+                         b.max_mn, b.cols, b.B, nhi_max, b.tab.p, b.rows.p, dyn_scal);
     // proofs per workgroup: enough (proof, generator pair) items for four passes of the 64 lanes
     const uint32_t ppw = std::max<uint32_t>(1, std::min<uint32_t>(BPP_LANES_MAX_PPW, 256 / std::max<uint32_t>(1, b.max_mn)));
     hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s, b.d_desc.p, b.tab.p,
