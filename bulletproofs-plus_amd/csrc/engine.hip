@@ -396,7 +396,8 @@ uint32_t choose_window(uint32_t group_terms, uint32_t all_terms) {
   // A small call has the chip to itself: its time is the length of the dependency chains, not the number of additions.
   // Wider windows shorten the bucket lists (accumulation) and the Horner step (fewer windows to add) for a longer
   // row / column reduction: three more bits are worth 0.07-0.1 ms up to a few hundred proofs (one proof 0.79 -> 0.68 ms).
-  static const int bias = getenv("BPP_MSM_C_BIAS") ? atoi(getenv("BPP_MSM_C_BIAS")) : 3;
+  const char *fb = getenv("BPP_MSM_C_BIAS");  // read per plan: tests run the narrow windows as well
+  const int bias = fb ? atoi(fb) : 3;
   if (all_terms <= 20000u) c = (uint32_t)std::max(4, std::min(11, (int)c + bias));
   return c;
 }

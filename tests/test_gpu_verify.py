@@ -180,6 +180,29 @@ def test_both_table_kernels(bpp, engine, monkeypatch, wave, n, ms):
     rb.close()
 
 
+@pytest.mark.parametrize("bias", ["0", "1", "3", "7"])
+def test_small_call_window_widths(bpp, engine, monkeypatch, bias):
+    """small calls take wider MSM windows than the throughput rule gives (BPP_MSM_C_BIAS, default 3): every width from 4 to 11
+    bits goes through the quad bucket kernels here, on multiscalar products of 1..300 terms and on small proof batches"""
+    monkeypatch.setenv("BPP_MSM_C_BIAS", bias)
+    for n in (1, 2, 5, 40, 300):
+        pts = [C.from_uniform_bytes(_h(b"cw-p", i, 64)) for i in range(min(n, 24))]
+        pts = [pts[i % len(pts)] for i in range(n)]
+        scalars = [int.from_bytes(_h(b"cw-s%s" % bias.encode(), i), "little") % C.L for i in range(n)]
+        got = engine.msm_vartime([sb(s_) for s_ in scalars], [p_.compress() for p_ in pts])
+        assert got == C.multiscalar_mul(scalars, pts).compress(), (bias, n)
+    case = make_batch(bpp, engine, 16, [1, 2, 1], 1, seed=b"window-widths")
+    rb = bpp.ResidentBatch(case.transcripts(), case.statements_public, case.proofs)
+    assert rb.verify(bpp.VerifyAction.VerifyOnly, chunk=0) == [None] * 3
+    assert rb.trace(6) == bytes(32)
+    rb.close()
+    bumped = [bpp.RangeStatement.init(case.params, s_.commitments_compressed, [(v or 0) + 1 for v in s_.minimum_value_promises], None)
+              for s_ in case.statements_public]
+    with pytest.raises(bpp.ProofError) as e:
+        bpp.RangeProof.verify_batch(case.transcripts(), bumped, case.proofs, bpp.VerifyAction.VerifyOnly)
+    assert e.value.kind == bpp.ProofErrorKind.VerificationFailed
+
+
 @pytest.mark.parametrize("side", ["0", "1"])
 def test_decompression_beside_pass1(bpp, engine, monkeypatch, side):
     """small inputs decompress on a second stream while PASS 1 runs; force each form: same dynamic points, same verdicts, and an
