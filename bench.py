@@ -48,6 +48,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # SIMD (tools/microbench/valu_rates.hip): 57.3 lanes / clock / CU at the 2.37 GHz the chip holds = 34.7 T/s
 VALU_PEAK_TMAD = 39.3
 LABEL = b"BatchedRangeProofTest"  # benches/range_proof.rs:49
+FAIL_STEP = int(os.environ.get("BPP_BENCH_FAIL_STEP", "0"))  # harness self-test: the n-th step of a leg raises
 
 
 def parse_args():
@@ -68,7 +69,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per cpu_baseline leg")
     ap.add_argument("--wide-steps", type=int, default=40)
     ap.add_argument("--no-traffic", action="store_true",
-                    help="skip the two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) that fill roofline.traffic")
+                    help="skip the rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE, SQ_*) that fill roofline.traffic")
+    ap.add_argument("--only", choices=("headline", "cfg3", "prover"), default=None,
+                    help="run just this leg, no roofline post-processing: what the rocprofv3 child passes of measure_traffic() run")
+    ap.add_argument("--host-in-calls", type=int, default=48, help="calls per timed region of the host-buffers-in leg")
     return ap.parse_args()
 
 
@@ -134,45 +138,87 @@ def make_inputs(np, packed, params, count, seed, chunk=8192):
             "values": values, "blindings": blindings, "seeds": seeds, "ext": ext}
 
 
-def measure_traffic(kernel="k_msm_accumulate"):
-    """HBM-side bytes of one launch of the roofline kernel, measured NOW: two child runs of this script under rocprofv3
-    (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: the TCC block cannot hold both in one pass; kernel trace only, no other
-    trace domain), one step in flight so that the kernel's dispatches do not share the chip.  Children, not exec: this
-    process has initialised the GPU.  Returns None (traffic stays null) if the profiler is missing or a pass fails."""
+def _profiler_usable():
+    import shutil
+    if not shutil.which("rocprofv3"):
+        return False
+    # already running under a profiler (the driver's, or tools/profile_round.sh): no nested profiler runs
+    return not (any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""))
+
+
+def _counter_pass(only, counters, extra_args=()):
+    """one child run of this script's `--only <leg>` under rocprofv3 --kernel-trace --pmc <counters> (kernel trace only, no
+    other trace domain; the program directly after `--`; a child, not an exec: this process has initialised the GPU).
+    Returns {kernel: {counter: sum, "dispatches": n, "dur_ns": total}} or None."""
     import shutil
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    d = tempfile.mkdtemp(prefix="bpp_pmc_", dir="/tmp")
     try:
-        import pmc_summary
-        if not shutil.which("rocprofv3"):
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.abspath(__file__), "--only", only, "--no-extra", "--no-cpu-baseline", "--no-traffic", "--concurrency", "1",
+               "--steps", "4", "--warmup", "1"] + list(extra_args)
+        r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        if r.returncode != 0:
             return None
-        # already running under a profiler (the driver's, or tools/profile_round.sh): no nested profiler runs
-        if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return pmc_summary.counters(d)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _kernel_row(acc, sub):
+    for k, e in (acc or {}).items():
+        if sub in k and e.get("dispatches"):
+            return e
+    return None
+
+
+def measure_traffic(kernel="k_msm_accumulate", only="headline"):
+    """HBM-side bytes of one launch of `kernel`, measured NOW: two child runs of this script (`--only <leg>`) under rocprofv3
+    (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: the TCC block cannot hold both in one pass), one step in flight so that the
+    kernel's dispatches do not share the chip.  Returns None (traffic stays null) if the profiler is missing or a pass fails."""
+    try:
+        if not _profiler_usable():
             return None
         raw = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = tempfile.mkdtemp(prefix="bpp_pmc_", dir="/tmp")
-            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
-                   os.path.abspath(__file__), "--no-extra", "--no-cpu-baseline", "--no-traffic", "--concurrency", "1", "--steps", "4",
-                   "--warmup", "1"]
-            r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
-            if r.returncode != 0:
+            e = _kernel_row(_counter_pass(only, [counter]), kernel)
+            if not e or not e.get(counter):
                 return None
-            kb, n, name = pmc_summary._per_launch(d, counter, kernel)
-            raw[counter] = (kb * 1024.0, n)
-            shutil.rmtree(d, ignore_errors=True)
-        # calibration of the two counters for this kernel's access patterns (tools/microbench/fetch_calib.hip on the same
-        # hardware, profiles/r02_v4_fetch_calib.json): FETCH_SIZE tallies a full 128-byte line request at 64 bytes (x0.500 for
+            raw[counter] = (e[counter] * 1024.0 / e["dispatches"], int(e["dispatches"]))
+        # calibration of the two counters for this engine's access patterns (tools/microbench/fetch_calib.hip on the same
+        # hardware, profiles/r02_v18_fetch_calib.json): FETCH_SIZE tallies a full 128-byte line request at 64 bytes (x0.500 for
         # gathers of aligned 128-byte table entries, as for the documented wide-stream case), WRITE_SIZE reads x1.19 for
         # scattered 160-byte stores
         f, w = raw["FETCH_SIZE"][0], raw["WRITE_SIZE"][0]
         return {"traffic": f / 0.5 + w / 1.19, "traffic_raw_counters": {"FETCH_SIZE_bytes": f, "WRITE_SIZE_bytes": w,
                                                                        "dispatches": [raw["FETCH_SIZE"][1], raw["WRITE_SIZE"][1]]},
-                "traffic_method": "two rocprofv3 child passes of this command (--pmc FETCH_SIZE / --pmc WRITE_SIZE, kernel trace only, one "
-                                  "step in flight), per launch; corrected FETCH / 0.500 + WRITE / 1.19 (profiles/r02_v4_fetch_calib.json); "
-                                  "bytes leaving the XCD L2s, served by the 256 MB Infinity Cache"}
+                "traffic_method": "two rocprofv3 child passes of `bench.py --only %s` (--pmc FETCH_SIZE / --pmc WRITE_SIZE, kernel trace "
+                                  "only, one step in flight), per launch; corrected FETCH / 0.500 + WRITE / 1.19 "
+                                  "(profiles/r02_v18_fetch_calib.json); bytes leaving the XCD L2s, served by the 256 MB Infinity Cache" % only}
     except (Exception, SystemExit):  # noqa: BLE001 - the headline number must not depend on the profiler
         return None
+
+
+def measure_sq(kernels, only="headline"):
+    """issue-side counters of `kernels` from one more child pass (SQ_INSTS_VALU, SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY,
+    SQ_ACTIVE_INST_VALU), one step in flight: VALU instructions per launch, fraction of wave cycles spent waiting"""
+    try:
+        if not _profiler_usable():
+            return {}
+        acc = _counter_pass(only, ["SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"])
+        out = {}
+        for k in kernels:
+            e = _kernel_row(acc, k)
+            if e and e.get("SQ_WAVE_CYCLES"):
+                n = e["dispatches"]
+                out[k] = {"valu_instr_per_launch": e.get("SQ_INSTS_VALU", 0.0) / n, "kernel_ms_alone": e["dur_ns"] / n / 1e6,
+                          "wait_inst_frac": e.get("SQ_WAIT_INST_ANY", 0.0) / e["SQ_WAVE_CYCLES"],
+                          "active_valu_frac": e.get("SQ_ACTIVE_INST_VALU", 0.0) / e["SQ_WAVE_CYCLES"], "dispatches": int(n)}
+        return out
+    except (Exception, SystemExit):  # noqa: BLE001
+        return {}
 
 
 class Leg:
@@ -181,6 +227,7 @@ class Leg:
     def __init__(self, bpp, packed, torch, device, params0, data, batch_proofs, batches, slots, chunk, profile=True):
         import numpy as np
         self.bpp, self.chunk, self.slots = bpp, chunk, []
+        self.calls = self.ok_steps = 0
         self.proofs_per_step = batch_proofs * batches
         nb = data["proofs"].shape[0] // batch_proofs
         self.upload_s = self.marshal_s = 0.0
@@ -205,31 +252,45 @@ class Leg:
 
     def one_step(self, slot):
         _, eng, _, rb = self.slots[slot]
+        self.calls += 1
+        if self.calls == FAIL_STEP:  # BPP_BENCH_FAIL_STEP: the harness' own failure path (tests/test_bench_harness.py)
+            raise RuntimeError("forced failure of step %d (BPP_BENCH_FAIL_STEP)" % FAIL_STEP)
         t0 = time.perf_counter()
         rb.verify_only(self.chunk)  # raises on an invalid batch
         return time.perf_counter() - t0, eng.last_profile()
 
     def run_steps(self, count):
-        """`count` complete steps, at most len(slots) in flight; returns (latencies, stage profiles)"""
+        """`count` complete steps, at most len(slots) in flight; returns (latencies, stage profiles).  A step that raises
+        (invalid batch, engine fault) stops the leg: the first exception of any worker is re-raised here, and the number of
+        completed steps is checked against `count` -- a number is never reported for steps that did not run."""
         S = min(len(self.slots), max(count, 1))
         if S == 1:
             res = [self.one_step(0) for _ in range(count)]
         else:
-            nxt, lock, out = [0], threading.Lock(), [[] for _ in range(S)]
+            nxt, lock, out, errors = [0], threading.Lock(), [[] for _ in range(S)], []
 
             def worker(slot):
-                while True:
+                try:
+                    while True:
+                        with lock:
+                            if nxt[0] >= count or errors:
+                                return
+                            nxt[0] += 1
+                        out[slot].append(self.one_step(slot))
+                except BaseException as e:  # noqa: BLE001 - re-raised on the calling thread
                     with lock:
-                        if nxt[0] >= count:
-                            return
-                        nxt[0] += 1
-                    out[slot].append(self.one_step(slot))
+                        errors.append(e)
             ths = [threading.Thread(target=worker, args=(s,)) for s in range(S)]
             for th in ths:
                 th.start()
             for th in ths:
                 th.join()
+            if errors:
+                raise errors[0]
             res = [r for part in out for r in part]
+        if len(res) != count:
+            raise RuntimeError("%d of %d steps completed" % (len(res), count))
+        self.ok_steps += len(res)
         return [r[0] for r in res], [r[1] for r in res]
 
     def close(self):
@@ -253,8 +314,7 @@ def kernel_roofline(profs, alone_ms=None):
     buckets = min(int(avg["msm_groups"]) * K * (1 << (int(avg["msm_window_bits"]) - 1)), terms * K)
     mads = (terms * K - buckets) * 700.0 + buckets * 100.0
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-           # filled in by measure_traffic() (two rocprofv3 child passes) for the headline leg; else see the file
-           "traffic": None, "traffic_profile": "profiles/r02_v4_traffic.json (FETCH_SIZE / WRITE_SIZE passes of this command)",
+           "traffic": None,  # filled in by measure_traffic() (two rocprofv3 child passes of this leg's own command) or left null
            "kernel": "k_msm_accumulate (Pippenger bucket accumulation of the final MSM)", "kernel_ms": acc_ms,
            "algorithmic_bytes": msm_bytes, "msm_terms_per_launch": terms, "msm_window_bits": int(avg["msm_window_bits"]),
            "msm_windows": K, "msm_groups": int(avg["msm_groups"]),
@@ -285,6 +345,164 @@ def timed(leg, steps, warmup, sync, clock=None):
         th.join()
         return el, lat, profs, (ghz[0] if ghz else None)
     return el, lat, profs
+
+
+def decompress_roofline(stages, n_points, sq, clock_ghz):
+    """roofline object of k_decompress, the verifier's other dominant kernel (ristretto255 decoding of the proofs' points,
+    src/range_proof.rs:1067-1109): 32 B in per point; one inverse square root = 254 squarings (55 multiply-adds each) and
+    25 multiplications (100) per point"""
+    ms = stages.get("decompress_ms")
+    if not ms:
+        return None
+    mads = n_points * (254 * 55 + 25 * 100.0)
+    out = {"bound": "hbm", "kernel": "k_decompress (ristretto255 -> affine-Niels, one lane per point)", "kernel_ms": ms,
+           "points_per_launch": n_points, "algorithmic_bytes": 32 * n_points, "achieved": 32 * n_points / (ms * 1e-3) / 1e9,
+           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 32 * n_points / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+           "note": "integer-VALU bound (254 squarings + 25 multiplications per 32 bytes): see valu; kernel_ms is the stage interval of "
+                   "the timed region (several steps share the chip) and includes the 32 B/proof copy of the transcript-RNG bytes",
+           "valu": {"achieved_Tmad_per_s": mads / (ms * 1e-3) / 1e12, "peak_Tmad_per_s": VALU_PEAK_TMAD,
+                    "frac": mads / (ms * 1e-3) / (VALU_PEAK_TMAD * 1e12)}}
+    if clock_ghz:
+        out["valu"]["frac_at_clock"] = out["valu"]["achieved_Tmad_per_s"] / (64 * 256 * clock_ghz * 1e9 / 1e12)
+    e = (sq or {}).get("k_decompress")
+    if e:  # one step in flight, from the SQ counter pass
+        out["alone"] = {"kernel_ms": e["kernel_ms_alone"], "valu_instr_per_point": 64.0 * e["valu_instr_per_launch"] / n_points,
+                        "wait_inst_frac": e["wait_inst_frac"], "active_valu_frac": e["active_valu_frac"],
+                        "valu_frac": mads / (e["kernel_ms_alone"] * 1e-3) / (VALU_PEAK_TMAD * 1e12),
+                        "note": "kernel_ms under the counter pass (slower than a plain launch); instructions counted per wavefront x 64 lanes"}
+    return out
+
+
+def host_in_leg(bpp, packed, np, device_index, params0, data, R, calls, sync):
+    """host buffers in -> verdict out, what RangeProof::verify_batch(&[RangeStatement], &[RangeProof]) delivers
+    (src/range_proof.rs:712-717): every call hands the engine R x 1024 proofs and statements in pageable host memory
+    (bpp_packed_batch), the engine validates, packs, uploads, verifies (chunk = 1024) and releases.  Never `value`."""
+    n = 1024 * R
+    nb = data["proofs"].shape[0] // 1024
+    inputs = []
+    for k in range(4):  # four distinct call inputs (the same 64 batches in another order), rotated
+        order = [(k * 17 + j) % nb for j in range(R)]
+        idx = np.concatenate([np.arange(b * 1024, (b + 1) * 1024) for b in order])
+        inputs.append(packed.PackedInput(data["proofs"][idx], data["commitments"][idx], data["min_values"][idx],
+                                         data["min_present"][idx], None, LABEL))
+    bytes_per_call = inputs[0].proofs.nbytes + inputs[0].commitments.nbytes + inputs[0].min_values.nbytes + inputs[0].min_present.nbytes
+    out = {"workload": "BASELINE configs[1] with the inputs in HOST memory on every call: %d x 1024 proofs + statements as one "
+                       "bpp_packed_batch (%.1f MB) -> validate, pack, DMA, verify (chunk = 1024), release; C-ABI calls, "
+                       "ctypes marshalling of ONE struct per call" % (R, bytes_per_call / 1e6),
+           "proofs_per_call": n, "host_bytes_per_call": bytes_per_call}
+
+    def run(contexts, depth, calls):
+        engs = [bpp.Engine(device_index) for _ in range(contexts)]
+        pars = [params0.share(e) for e in engs]
+        pipes = [packed.Pipeline(p, depth=depth) for p in pars]
+        errors = []
+
+        def worker(c, count):
+            try:
+                q = []
+                for i in range(count):
+                    q.append(pipes[c].submit(inputs[(i + c) % len(inputs)], bpp.VerifyAction.VerifyOnly, 1024))
+                    if len(q) >= depth:
+                        pipes[c].collect(q.pop(0))
+                while q:
+                    pipes[c].collect(q.pop(0))
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+
+        def region(count):
+            ths = [threading.Thread(target=worker, args=(c, count)) for c in range(contexts)]
+            t0 = time.perf_counter()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            if errors:
+                raise errors[0]
+            return time.perf_counter() - t0
+        region(max(2 * depth, 6))  # lanes, staging and work buffers exist; clocks up
+        sync()
+        el = region(calls)
+        sync()
+        for p in pars:
+            p.close()
+        for e in engs:
+            e.close()
+        return {"contexts": contexts, "pipeline_depth": depth, "calls": contexts * calls, "proofs_per_s": contexts * calls * n / el,
+                "ms_per_call": 1e3 * el / calls / contexts, "host_to_device_GBps": contexts * calls * bytes_per_call / el / 1e9}
+    out["one_context"] = run(1, 4, calls)
+    out["four_contexts"] = run(4, 2, max(8, calls // 4))
+    out["one_context_blocking"] = run(1, 1, max(8, calls // 4))  # bpp_verify_batch_packed's schedule: nothing overlaps
+    return out
+
+
+def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, params2, data2, args, sync):
+    """BASELINE configs[3]: 4096 proofs as ONE reference batch sharded over the ranks, through the C ABI
+    (bpp_verify_sharded_wave: RCCL all_gathers on device buffers).  W waves of K batches are in flight per rank: a wave's
+    K batches run their kernels side by side and share ONE all_gather per exchange; the waves (own communicator, own host
+    thread each) overlap one wave's weight chains and exchanges with the other's kernels."""
+    dmod = importlib.import_module("bulletproofs-plus_amd.dist")
+    K = int(os.environ.get("BPP_BENCH_WAVE_BATCHES", "8"))
+    W = int(os.environ.get("BPP_BENCH_WAVES", "2"))
+    n_local = 4096 // world
+    counts = [n_local] * world
+    nb = data2["proofs"].shape[0] // n_local
+    waves = []
+    for w in range(W):  # communicators are built collectively, in the same order on every rank
+        engs = [bpp.Engine(local_rank) for _ in range(K)]
+        pars = [params2.share(e) for e in engs]
+        rbs = []
+        for i, p in enumerate(pars):  # ranks were seeded differently: any n_local of this rank's proofs are a shard
+            sl = slice(((w * K + i) % nb) * n_local, ((w * K + i) % nb + 1) * n_local)
+            rbs.append(packed.ResidentBatch(p, data2["proofs"][sl], data2["commitments"][sl], data2["min_values"][sl],
+                                            data2["min_present"][sl], None, LABEL))
+            rbs[-1].prepare(0)
+        comm = dmod.ShardComm.from_process_group(engs[0])
+        waves.append((engs, pars, rbs, comm))
+    errors = []
+
+    def worker(w, rounds):
+        try:
+            _, _, rbs, comm = waves[w]
+            for _ in range(rounds):
+                res = comm.verify_wave(rbs, counts)
+                if any(r["code"] != 0 for r in res):
+                    raise RuntimeError("sharded batch failed: %r" % (res,))
+        except BaseException as e:  # noqa: BLE001 - NOTE: the other ranks' collectives of this wave are stranded; the run is lost
+            errors.append(e)
+
+    def region(rounds):
+        ths = [threading.Thread(target=worker, args=(w, rounds)) for w in range(W)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        if errors:
+            raise errors[0]
+        return time.perf_counter() - t0
+    rounds = max(1, args.wide_steps)
+    region(max(3, rounds // 4))
+    sync()
+    wel = region(rounds)
+    sync()
+    tt = torch.tensor([wel], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    wel = float(tt.item())
+    batches = W * K * rounds
+    for engs, pars, rbs, comm in waves:
+        comm.close()
+        for x in rbs:
+            x.close()
+        for p in pars:
+            p.close()
+        for e in engs:
+            e.close()
+    return {"workload": "BASELINE configs[3]: 4096 non-aggregated 64-bit proofs as ONE reference batch, %d per rank, through "
+                        "bpp_verify_sharded_wave: RCCL all_gather of 32 B/proof transcript-RNG bytes (device buffers), weight chain "
+                        "replayed on every rank, RCCL all_gather of the 128-byte accumulators, sum + identity test on the device; "
+                        "%d waves x %d batches in flight per rank" % (n_local, W, K),
+            "rccl_ranks": world, "proofs_per_s": 4096 * batches / wel, "ms_per_batch": 1e3 * wel / batches,
+            "batches": batches, "in_flight": W * K, "waves": W, "batches_per_wave": K}
 
 
 def main():
@@ -319,6 +537,52 @@ def main():
     eng0.profile(True)
     t_setup = time.perf_counter()
 
+    # ------------------------------------------------------------------ legs other than the headline, as functions
+    def cfg3_leg(steps=48, warmup=8, only=False):
+        p3 = bpp.RangeParameters.init(64, 8, G(1), engine=eng0)
+        R3 = int(os.environ.get("BPP_BENCH_CFG3_BATCHES", "64"))
+        S3 = 1 if only else int(os.environ.get("BPP_BENCH_CFG3_INFLIGHT", "4"))
+        d3 = make_inputs(np, packed, p3, 256 * R3, seed=8675309 + 3)
+        leg3 = Leg(bpp, packed, torch, device, p3, d3, 256, R3, S3, 256)
+        el3, lat3, pr3 = timed(leg3, steps, warmup, sync)
+        sync()
+        al3 = [leg3.one_step(0)[1].get("msm_accumulate_ms", 0.0) for _ in range(3)]
+        roof3, st3 = kernel_roofline(pr3, sum(al3) / 3 if min(al3) > 0 else None)
+        leg3.close()
+        p3.close()
+        return {"workload": "BASELINE configs[2]: reference batches of 256 x aggregation-8 64-bit proofs, extension degree 1; "
+                            "one step = %d such batches, %d steps in flight" % (R3, S3),
+                "proofs_per_s": 256 * R3 * steps / el3, "ms_per_step": 1e3 * el3 / steps, "steps": steps, "roofline": roof3,
+                "stages_ms": st3}
+
+    def prover_leg(iters5=6):
+        p5 = bpp.RangeParameters.init(64, 4, G(3), engine=eng0)
+        d5 = make_inputs(np, packed, p5, 1024, seed=8675309 + 5)  # also builds the fixed-base tables (warm-up)
+        t0 = time.perf_counter()
+        for _ in range(iters5):
+            packed.prove(p5, d5["values"], d5["blindings"], d5["commitments"], d5["min_values"], d5["min_present"], None, LABEL,
+                         d5["ext"])
+        el5 = time.perf_counter() - t0
+        pp = eng0.last_prove_profile()
+        fb_bytes = 64 * pp["fb_terms"]
+        p5.close()
+        return {"workload": "BASELINE configs[4]: bpp_prove_batch over 1024 x aggregation-4 64-bit proofs, extension "
+                            "degree 3; host witness buffers in, proof bytes out (PCIe-inclusive)",
+                "proofs_per_s": 1024 * iters5 / el5, "ms_per_call": 1e3 * el5 / iters5, "calls": iters5,
+                "roofline": {"bound": "hbm", "kernel": "k_fb_msm (fixed-base MSM of every L/R/A1/B and the witness check)",
+                             "kernel_ms": pp["fb_msm_ms"], "launches": pp["fb_launches"], "algorithmic_bytes": fb_bytes,
+                             "achieved": fb_bytes / (pp["fb_msm_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": fb_bytes / (pp["fb_msm_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                             "fb_window_bits": pp["fb_window_bits"], "fb_terms": pp["fb_terms"],
+                             "note": "achieved / algorithmic_bytes / kernel_ms are sums over the %d launches of ONE call (both "
+                                     "sub-batch streams); 64 B per term" % pp["fb_launches"]}}
+
+    if args.only in ("cfg3", "prover"):  # a rocprofv3 child pass of measure_traffic(): just the kernels, a short line
+        res = cfg3_leg(args.steps, args.warmup, only=True) if args.only == "cfg3" else prover_leg(2)
+        print(json.dumps({"only": args.only, "proofs_per_s": res["proofs_per_s"]}))
+        eng0.close()
+        return
+
     # ------------------------------------------------------------------ headline: BASELINE configs[1]
     R, S = max(1, args.batches_per_step), max(1, args.concurrency)
     params2 = bpp.RangeParameters.init(64, 1, G(1), engine=eng0)
@@ -333,12 +597,17 @@ def main():
     # 2.3+ GHz it then sustains (tools/clock_ramp.py); 5 warm-up steps are 15 ms.  Without this a 20-step timed region (55 ms)
     # runs mostly at the ramp's clock and reads 10-15 % low; `shader_clock_ghz` in the line is what the timed region held.
     sync()  # under torch.distributed the first barrier builds the communicator (100s of ms): not between warm-up and timing
-    if args.preheat_ms > 0:
-        leg.run_steps(max(1, int(args.preheat_ms / 2.7)))
-    elapsed, lat, profs, clock_ghz = timed(leg, args.steps, args.warmup, sync,
-                                           clock=lambda: bpp.shader_clock_ghz(clk_eng, int(1e3 * max(5.0, min(200.0, 0.6 * est_ms)))))
+    step_error, elapsed, lat, profs, clock_ghz = None, 0.0, [], [], None
+    try:
+        if args.preheat_ms > 0 and not args.only:
+            leg.run_steps(max(1, int(args.preheat_ms / 2.7)))
+        elapsed, lat, profs, clock_ghz = timed(leg, args.steps, args.warmup, sync,
+                                               clock=lambda: bpp.shader_clock_ghz(clk_eng, int(1e3 * max(5.0, min(200.0, 0.6 * est_ms)))))
+    except Exception as e:  # noqa: BLE001 - a failed step: no number; the other ranks still get their collective
+        step_error = e
     clk_eng.close()
-    ok_all = 1  # every step raised nothing: all batches of all steps verified
+    # every timed step ran and raised nothing (each step verifies all its batches or raises)
+    ok_all = 1 if (step_error is None and len(lat) == args.steps) else 0
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -346,7 +615,17 @@ def main():
         flag = torch.tensor([ok_all], dtype=torch.int32, device=device)  # verdicts of the independent shards
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok_all = int(flag.item())
-    assert ok_all == 1
+    if ok_all != 1:
+        sys.stderr.write("bench.py: the timed region did not complete on every rank: %r\n" % (step_error,))
+        if use_dist:
+            dist.destroy_process_group()
+        raise SystemExit(3)
+    if args.only == "headline":
+        print(json.dumps({"only": "headline", "proofs_per_s": 1024 * R * args.steps / elapsed}))
+        leg.close()
+        params2.close()
+        eng0.close()
+        return
     # calibration after the timed region: the roofline kernel with nothing co-running (in the timed region several steps
     # share the chip, so each launch of it is stretched by its neighbours)
     sync()
@@ -372,71 +651,45 @@ def main():
                    "steps_in_flight_per_gpu": len(leg.slots), "parallelism": "proof-sharded x%d" % world,
                    "inputs": "%d distinct proofs per rank, proved on the box by bpp_prove_batch (recipe of "
                              "benches/range_proof.rs:206-262), %.1f s" % (1024 * R, gen_s)},
-        "step_latency_ms": 1e3 * sum(lat) / len(lat),
+        "step_latency_ms": 1e3 * sum(lat) / len(lat), "steps_completed": len(lat), "all_steps_verified": bool(ok_all),
         "host_threads": bpp.host_threads(), "nproc": os.cpu_count(), "usable_cpus": usable_cpus(),
         "shader_clock_ghz": clock_ghz,
     }
+    profiler_legs = rank == 0 and world == 1 and not use_dist and not args.no_traffic
     if roof:
-        if rank == 0 and world == 1 and not use_dist and not args.no_traffic:
-            tr = measure_traffic()
+        sq = {}
+        if profiler_legs:
+            tr = measure_traffic("k_msm_accumulate", "headline")
             if tr:
                 roof.update(tr)
-                roof.pop("traffic_profile", None)
+            sq = measure_sq(["k_decompress", "k_msm_accumulate"], "headline")
+            if sq.get("k_msm_accumulate"):
+                roof.setdefault("alone", {}).update({"wait_inst_frac": sq["k_msm_accumulate"]["wait_inst_frac"],
+                                                     "valu_instr_per_launch": sq["k_msm_accumulate"]["valu_instr_per_launch"]})
         out["roofline"] = roof
         out["stages_ms"] = stages
-    # bpp_batch_upload alone: host proof/statement buffers -> parsed, packed and resident (R batches of 1024); never `value`
+        # the verifier's other dominant kernel: 15 proof points per non-aggregated 64-bit proof (A, A1, B, 6 L, 6 R)
+        out["roofline_decompress"] = decompress_roofline(stages, 15 * 1024 * R, sq, clock_ghz)
+    # bpp_batch_upload_packed alone: host proof/statement buffers -> parsed, packed and resident (R batches of 1024); never `value`
     out["pcie_inclusive_upload_ms"] = 1e3 * leg.upload_s
     leg.close()
 
     extra = {}
+    # ------------------------------------------------------------------ host buffers in -> verdict out (what verify_batch receives)
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra["host_in"] = host_in_leg(bpp, packed, np, local_rank, params2, data2, R, args.host_in_calls, sync)
+        out["pcie_inclusive_value"] = extra["host_in"]["one_context"]["proofs_per_s"]
     # ------------------------------------------------------------------ N > 1: BASELINE configs[3], one batch over all ranks
     if use_dist:
-        dmod = importlib.import_module("bulletproofs-plus_amd.dist")
-        n_local = 4096 // world
-        stream = torch.cuda.Stream(device=device)
-        weng = bpp.Engine(local_rank, stream=stream.cuda_stream)
-        wparams = params2.share(weng)
-        lo = n_local * rank  # ranks were seeded differently: any n_local of this rank's proofs are its shard
-        rb = packed.ResidentBatch(wparams, data2["proofs"][:n_local], data2["commitments"][:n_local],
-                                  data2["min_values"][:n_local], data2["min_present"][:n_local], None, LABEL)
-        ops = dmod.LocalEngineOps(rb)
-        for _ in range(5):
-            dmod.verify_sharded(ops, n_local, device, mode="wide")
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.wide_steps):
-            dmod.verify_sharded(ops, n_local, device, mode="wide")
-        sync()
-        wel = time.perf_counter() - t0
-        tt = torch.tensor([wel], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wel = float(tt.item())
-        extra["wide"] = {"workload": "BASELINE configs[3]: 4096 non-aggregated 64-bit proofs as ONE reference batch, %d per rank; "
-                                     "all_gather of 32 B/proof transcript-RNG bytes, weight chain replayed on every rank, "
-                                     "all_gather of the 128-byte accumulators, rank-local sum + identity test" % n_local,
-                         "rccl_ranks": world, "proofs_per_s": 4096 * args.wide_steps / wel, "ms_per_batch": 1e3 * wel / args.wide_steps,
-                         "steps": args.wide_steps, "in_flight": 1, "first_proof_of_shard": lo}
-        rb.close()
-        wparams.close()
-        weng.close()
+        extra["wide"] = wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, params2, data2, args, sync)
 
     if rank == 0 and world == 1 and not args.no_extra:
         # -------------------------------------------------------------- configs[2]: 256 x aggregation-8
-        p3 = bpp.RangeParameters.init(64, 8, G(1), engine=eng0)
-        R3 = int(os.environ.get("BPP_BENCH_CFG3_BATCHES", "64"))
-        S3 = int(os.environ.get("BPP_BENCH_CFG3_INFLIGHT", "4"))
-        d3 = make_inputs(np, packed, p3, 256 * R3, seed=8675309 + 3)
-        leg3 = Leg(bpp, packed, torch, device, p3, d3, 256, R3, S3, 256)
-        el3, lat3, pr3 = timed(leg3, 48, 8, sync)
-        sync()
-        al3 = [leg3.one_step(0)[1].get("msm_accumulate_ms", 0.0) for _ in range(3)]
-        roof3, st3 = kernel_roofline(pr3, sum(al3) / 3 if min(al3) > 0 else None)
-        extra["cfg3"] = {"workload": "BASELINE configs[2]: reference batches of 256 x aggregation-8 64-bit proofs, extension degree 1; "
-                                     "one step = %d such batches, %d steps in flight" % (R3, S3),
-                         "proofs_per_s": 256 * R3 * 48 / el3, "ms_per_step": 1e3 * el3 / 48, "steps": 48, "roofline": roof3,
-                         "stages_ms": st3}
-        leg3.close()
-        p3.close()
+        extra["cfg3"] = cfg3_leg()
+        if profiler_legs and extra["cfg3"].get("roofline"):
+            tr = measure_traffic("k_msm_accumulate", "cfg3")
+            if tr:
+                extra["cfg3"]["roofline"].update(tr)
         # -------------------------------------------------------------- one 4096-proof reference batch (north_star's sentence)
         Sw = int(os.environ.get("BPP_BENCH_WIDE_INFLIGHT", "12"))
         legw = Leg(bpp, packed, torch, device, params2, data2, 4096, 1, Sw, 0, profile=False)
@@ -471,26 +724,14 @@ def main():
         extra["latency"] = dict(lat_out, workload="BASELINE configs[0]'s shape through the engine: ONE call at a time, 1 and 256 "
                                                   "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input")
         # -------------------------------------------------------------- configs[4]: batch prover
-        p5 = bpp.RangeParameters.init(64, 4, G(3), engine=eng0)
-        d5 = make_inputs(np, packed, p5, 1024, seed=8675309 + 5)  # also builds the fixed-base tables (warm-up)
-        t0 = time.perf_counter()
-        iters5 = 6
-        for _ in range(iters5):
-            packed.prove(p5, d5["values"], d5["blindings"], d5["commitments"], d5["min_values"], d5["min_present"], None, LABEL,
-                         d5["ext"])
-        el5 = time.perf_counter() - t0
-        pp = eng0.last_prove_profile()
-        fb_bytes = 64 * pp["fb_terms"]
-        extra["prover"] = {"workload": "BASELINE configs[4]: bpp_prove_batch over 1024 x aggregation-4 64-bit proofs, extension "
-                                       "degree 3; host witness buffers in, proof bytes out (PCIe-inclusive)",
-                           "proofs_per_s": 1024 * iters5 / el5, "ms_per_call": 1e3 * el5 / iters5, "calls": iters5,
-                           "roofline": {"bound": "hbm", "kernel": "k_fb_msm (fixed-base MSM of every L/R/A1/B and the witness check)",
-                                        "kernel_ms": pp["fb_msm_ms"], "launches": pp["fb_launches"], "algorithmic_bytes": fb_bytes,
-                                        "achieved": fb_bytes / (pp["fb_msm_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                        "frac": fb_bytes / (pp["fb_msm_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                                        "fb_window_bits": pp["fb_window_bits"], "fb_terms": pp["fb_terms"],
-                                        "note": "sum of the launches' event times over both sub-batch streams; 64 B per term"}}
-        p5.close()
+        extra["prover"] = prover_leg()
+        if profiler_legs:
+            tr = measure_traffic("k_fb_msm", "prover")
+            if tr:  # the counters are per dispatch: scaled to the launches of one call, like achieved / algorithmic_bytes
+                rp = extra["prover"]["roofline"]
+                tr["traffic_per_launch_avg"] = tr["traffic"]
+                tr["traffic"] = tr["traffic"] * rp["launches"]
+                rp.update(tr)
     if extra and rank == 0:
         out["extra"] = extra
 

@@ -22,6 +22,19 @@ class ProveItem(Structure):
                 ("rng_bytes", c_void_p), ("rng_len", c_size_t)]
 
 
+class PackedBatch(Structure):
+    """bpp_packed_batch: a homogeneous batch as contiguous arrays"""
+    _fields_ = [("n_items", c_size_t), ("proofs", c_void_p), ("proof_len", c_size_t), ("proof_stride", c_size_t),
+                ("commitments32", c_void_p), ("m", c_uint32), ("min_values", c_void_p), ("min_present", c_void_p),
+                ("seed_nonces32", c_void_p), ("seed_present", c_void_p), ("transcript_state", c_void_p),
+                ("transcript_label", c_void_p), ("label_len", c_size_t)]
+
+
+class ShardResult(Structure):
+    """bpp_shard_result: outcome of one batch of a sharded wave"""
+    _fields_ = [("code", c_int), ("tier", c_int), ("rank", c_int), ("index", c_uint32), ("msg", ctypes.c_char * 160)]
+
+
 class Profile(Structure):
     _fields_ = [(n, c_float) for n in ("transcripts_ms", "decompress_ms", "chain_host_ms", "scalars_ms", "reduce_ms",
                                        "msm_digits_ms", "msm_sort_ms", "msm_accumulate_ms", "msm_bucket_reduce_ms",
@@ -57,6 +70,13 @@ SYMBOLS = [
                                                  c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t]),
     ("bpp_batch_upload", c_int, [c_void_p, c_uint64, POINTER(VerifyItem), c_size_t, POINTER(c_uint64), c_void_p,
                                  c_size_t]),
+    ("bpp_batch_upload_packed", c_int, [c_void_p, c_uint64, POINTER(PackedBatch), POINTER(c_uint64), c_void_p, c_size_t]),
+    ("bpp_verify_batch_packed", c_int, [c_void_p, c_uint64, POINTER(PackedBatch), c_int, c_size_t, c_void_p, c_void_p,
+                                        c_void_p, c_size_t]),
+    ("bpp_ctx_pipeline_depth", c_int, [c_void_p, c_uint32]),
+    ("bpp_verify_submit_packed", c_int, [c_void_p, c_uint64, POINTER(PackedBatch), c_int, c_size_t, POINTER(c_uint64),
+                                         c_void_p, c_size_t]),
+    ("bpp_verify_collect", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t]),
     ("bpp_batch_destroy", c_int, [c_void_p, c_uint64]),
     ("bpp_verify_resident", c_int, [c_void_p, c_uint64, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t]),
     ("bpp_verify_phase1", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_size_t]),
@@ -64,6 +84,19 @@ SYMBOLS = [
     ("bpp_weights_from_chains", c_int, [c_void_p, c_size_t, c_size_t, c_void_p]),
     ("bpp_verify_phase2", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t]),
     ("bpp_accumulators_sum_is_identity", c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_int)]),
+    ("bpp_comm_unique_id", c_int, [c_void_p]),
+    ("bpp_comm_create", c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    ("bpp_comm_adopt", c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    ("bpp_comm_destroy", None, [c_void_p]),
+    ("bpp_comm_last_error", c_char_p, [c_void_p]),
+    ("bpp_verify_sharded", c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint32), POINTER(c_int), POINTER(c_int), c_void_p,
+                                   c_size_t]),
+    ("bpp_verify_sharded_wave", c_int, [c_void_p, POINTER(c_void_p), POINTER(c_uint64), c_size_t, POINTER(c_uint32),
+                                        POINTER(ShardResult)]),
+    ("bpp_shard_local_trailer", c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_uint32, c_void_p]),
+    ("bpp_shard_trailer", c_int, [c_int, c_int, c_uint32, c_char_p, c_void_p]),
+    ("bpp_shard_resolve", c_int, [c_void_p, c_size_t, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_uint32), c_void_p,
+                                  c_size_t]),
     ("bpp_prove_batch", c_int, [c_void_p, c_uint64, POINTER(ProveItem), c_size_t, c_void_p, c_size_t, POINTER(c_size_t),
                                 c_void_p, c_size_t]),
     ("bpp_batch_trace", c_int, [c_void_p, c_uint64, c_int, c_void_p, c_size_t, POINTER(c_size_t)]),
@@ -76,6 +109,7 @@ SYMBOLS = [
     ("bpp_host_threads", c_int, []),
     ("bpp_shader_clock", c_int, [c_void_p, c_uint32, POINTER(c_double)]),
     ("bpp_transcript_new", c_int, [c_void_p, c_size_t, c_void_p]),
+    ("bpp_batch_secret_bytes", c_int, [c_void_p, c_uint64, POINTER(c_uint64)]),
 ]
 
 _lib = None

@@ -287,6 +287,7 @@ struct Batch {
   PinnedBuf<uint8_t> h_rng, h_weights;
   PinnedBuf<uint32_t> h_status, h_ident;
   bool have_trace = false, phase1_done = false;
+  bool seeds_dirty = false, masks_dirty = false;  // device copies of seed nonces / recovered masks not yet wiped
 };
 
 // A destroyed batch leaves its device and pinned allocations to the next upload on the same context (a caller that
@@ -304,7 +305,45 @@ void adopt_buffers(Batch &dst, Batch &src) {
 #undef BPP_ADOPT
 }
 
+void wipe_batch_secrets(Batch &b, hipStream_t s);
+
 }  // namespace
+
+// pipelined host-buffers-in form (bpp_verify_submit_packed / bpp_verify_collect), implemented further down
+struct PipeJob {
+  uint64_t ticket = 0;
+  int action = 0;
+  size_t chunk = 0;
+  std::shared_ptr<Params> Pp;
+  uint64_t params = 0;
+  UploadPlan pl;
+  size_t n_items = 0;
+  uint32_t t = 0;
+  int rc = 0;
+  std::string err;
+  std::vector<uint8_t> masks, present;
+  bool done = false;
+};
+
+struct PipeLane {
+  bpp_ctx *child = nullptr;
+  std::thread th;
+  std::shared_ptr<PipeJob> job;  // posted by submit, taken by the worker
+  bool busy = false;             // from the moment submit claims the lane until its job is done
+};
+
+struct Pipeline {
+  std::mutex mu;                  // lanes' state, tickets
+  std::condition_variable cv;
+  std::mutex submit_mu;           // one submit at a time: lanes are claimed in ticket order
+  std::vector<std::unique_ptr<PipeLane>> lanes;
+  std::map<uint64_t, std::shared_ptr<PipeJob>> tickets;
+  uint64_t next_ticket = 1;
+  uint32_t next_lane = 0;
+  bool quit = false;
+};
+
+void pipeline_shutdown(bpp_ctx *ctx);
 
 struct bpp_ctx {
   int device = 0;
@@ -335,6 +374,9 @@ struct bpp_ctx {
   std::vector<hipStream_t> prove_streams;
   std::vector<hipEvent_t> prove_events;  // pairs around every k_fb_msm launch of the last bpp_prove_batch (profiling only)
   bpp_prove_profile pprof{};
+  std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
+  std::mutex pipe_init_mu;
+  uint32_t pipe_depth = 3;
 };
 
 namespace {
@@ -588,6 +630,9 @@ int bpp_ctx_create(bpp_ctx **out, int device_id) { return bpp_ctx_create_on_stre
 void bpp_ctx_destroy(bpp_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  pipeline_shutdown(ctx);  // waits for the calls in flight on the lanes, joins their threads, destroys their contexts
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &kv : ctx->batches) wipe_batch_secrets(*kv.second, ctx->stream);  // seed nonces / masks of batches never destroyed
   (void)hipStreamSynchronize(ctx->stream);
   ctx->batches.clear();
   ctx->spare_batch.reset();
@@ -912,36 +957,71 @@ int bpp_weights_from_chain(const uint8_t *rng32_all, size_t n_total, uint8_t *we
 }  // extern "C"
 
 namespace {
-int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, uint64_t *batch,
-                const uint8_t *const *challenges32, const uint8_t *rng_out32, char *errbuf, size_t errbuf_len) {
-  try {
-    const std::shared_ptr<Params> Pp = params_registry().get(params);
-    if (!Pp || Pp->device != ctx->device) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle", errbuf, errbuf_len);
+
+// Secrets a resident batch holds on the device: the statements' seed nonces and the recovered masks (the reference wipes
+// both on drop: src/range_statement.rs:76-81 `Zeroize for RangeStatement`, src/extended_mask.rs:14 `ZeroizeOnDrop`).
+// Enqueued on `s`; the caller synchronises before the buffers change hands.
+void wipe_batch_secrets(Batch &b, hipStream_t s) {
+  if (b.seeds.p && b.seeds_dirty) (void)hipMemsetAsync(b.seeds.p, 0, b.seeds.n, s);
+  if (b.masks.p && b.masks_dirty) (void)hipMemsetAsync(b.masks.p, 0, b.masks.n, s);
+  b.seeds_dirty = b.masks_dirty = false;
+}
+
+// ---- host half of an upload: everything that reads the caller's buffers.  Validates and packs into ctx->pin_upload
+// (proof and commitment bytes) and `pl` (descriptors, promises, seed nonces, transcript states).  Pure host work: the
+// pipelined entry runs it on the submitting thread while the context's lanes are busy with earlier calls.
+void upload_host_pack(bpp_ctx *ctx, const Params &P, const bpp_verify_item *items, size_t n_items, const bpp_packed_batch *packed,
+                      UploadPlan &pl) {
+  const ParallelFor pf = [](uint32_t n, const std::function<void(uint32_t)> &fn) { host_parallel_for(n, fn); };
+  const ParamShape shape{P.n_bits, P.m_max, P.t};
+  std::vector<bpp_verify_item> synth;  // packed input that is not uniform after all (hostile / mixed): the item form
+  const bool arithmetic = packed && upload_pass_a_packed(*packed, pl, pf);
+  if (packed && !arithmetic) {
+    upload_packed_as_items(*packed, synth);
+    items = synth.data();
+    n_items = synth.size();
+  }
+  if (!arithmetic) upload_pass_a(items, n_items, pl);
+  // Proof and commitment bytes are assembled directly in page-locked staging: a pageable source makes hipMemcpyAsync
+  // return early and the 40 MB transfer trickle on at ~2.4 GB/s behind the call (it showed up as 23 ms in the first
+  // verification of every freshly uploaded batch)
+  ctx->pin_upload.resize(pl.bytes_total + BPP_BYTES_SLACK);
+  uint8_t *bytes = ctx->pin_upload.data();
+  memset(bytes + pl.bytes_total, 0, BPP_BYTES_SLACK);
+  if (arithmetic) upload_pass_b_packed(*packed, shape, pl, bytes, pf);
+  else upload_pass_b(items, shape, pl, bytes, pf);
+}
+
+// ---- device half: staging -> HBM, slot lists, statement commitments decoded; consumes `pl`
+uint64_t upload_device(bpp_ctx *ctx, const std::shared_ptr<Params> &Pp, uint64_t params, UploadPlan &pl,
+                       const uint8_t *const *challenges32, const uint8_t *rng_out32) {
     Params &P = *Pp;
-    // verify_batch: by definition an empty batch fails (src/range_proof.rs:719-723)
-    if (!items || n_items == 0 || !batch)
-      return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "Range statements or proofs length empty", errbuf, errbuf_len);
-    if (n_items > (1u << 24)) return fail(ctx, BPP_ERR_SIZE_OVERFLOW, "batch too large", errbuf, errbuf_len);
+    const size_t n_items = pl.n_items;
     auto B = std::make_unique<Batch>();
     if (ctx->spare_batch) {
       adopt_buffers(*B, *ctx->spare_batch);
       ctx->spare_batch.reset();
     }
+    hipStream_t s = ctx->stream;
+    // seed nonces pass through page-locked staging and reach the device: both are wiped on EVERY way out of here
+    SmallStaging L;
+    bool registered = false;
+    ScopeExit wipe_secrets{[&] {
+      if (L.n_seed) {
+        (void)hipStreamSynchronize(s);  // the copy out of the staging may still be running
+        upload_wipe_small(ctx->pin_upload2.data(), L);
+      }
+      secure_wipe(pl.seeds.data(), pl.seeds.size());
+      if (!registered && B) {  // an error exit: the half-built batch dies here and must not leave nonces behind
+        wipe_batch_secrets(*B, s);
+        (void)hipStreamSynchronize(s);
+      }
+    }};
     B->params = Pp;
     B->params_handle = params;
     B->B = (uint32_t)n_items;
-    // host planner (upload_host.h): pass A sizes the layout, pass B validates and packs on the host pool.  Proof and
-    // commitment bytes are assembled directly in page-locked staging: a pageable source makes hipMemcpyAsync return early
-    // and the 40 MB transfer trickle on at ~2.4 GB/s behind the call (it showed up as 23 ms in the first verification of
-    // every freshly uploaded batch)
-    UploadPlan pl;
-    upload_pass_a(items, n_items, pl);
-    ctx->pin_upload.resize(pl.bytes_total + BPP_BYTES_SLACK);
-    uint8_t *bytes = ctx->pin_upload.data();
-    memset(bytes + pl.bytes_total, 0, BPP_BYTES_SLACK);
+    const uint8_t *bytes = ctx->pin_upload.data();
     const size_t bytes_len = pl.bytes_total + BPP_BYTES_SLACK;
-    upload_pass_b(items, ParamShape{P.n_bits, P.m_max, P.t}, pl, bytes,
-                  [](uint32_t n, const std::function<void(uint32_t)> &fn) { host_parallel_for(n, fn); });
     B->desc.swap(pl.desc);
     B->rounds_bad.swap(pl.rounds_bad);
     B->defer.swap(pl.defer);
@@ -963,10 +1043,9 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
     B->cs = std::min(B->rmax, (uint32_t)BPP_MAX_ROUNDS - 1) + 3;
     B->cols = 2 * B->max_mn + P.t + 1;
     // device copies (all sources page-locked: the copies are real stream-ordered DMA)
-    hipStream_t s = ctx->stream;
     B->bytes.alloc(bytes_len);
     B->states.alloc(states.size());
-    B->seeds.alloc(seeds.size());
+    B->seeds.alloc(B->any_seed ? seeds.size() : 0);
     B->d_desc.alloc(n_items);
     B->minvals.alloc(minvals.size());
     B->src_off.alloc(dyn);
@@ -974,19 +1053,19 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
     B->idx_commit.alloc(sum_m);
     B->idx_proof.alloc(dyn - sum_m);
     {
-      const size_t o_desc = 0, o_min = o_desc + n_items * sizeof(ProofDesc), o_seed = o_min + minvals.size() * 8,
-                   o_state = o_seed + seeds.size(), total = o_state + states.size();
-      ctx->pin_upload2.resize(total + 64);
+      const SmallStaging Lp = upload_small_layout(pl, n_items);
+      ctx->pin_upload2.resize(Lp.total + 64);
       uint8_t *st = ctx->pin_upload2.data();
-      memcpy(st + o_desc, B->desc.data(), n_items * sizeof(ProofDesc));
-      memcpy(st + o_min, minvals.data(), minvals.size() * 8);
-      memcpy(st + o_seed, seeds.data(), seeds.size());
-      memcpy(st + o_state, states.data(), states.size());
+      L = Lp;  // from here on the staging holds nonces (if any)
+      upload_fill_small(pl, B->desc.data(), n_items, st, L);
       HIP_CHECK(hipMemcpyAsync(B->bytes.p, bytes, bytes_len, hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(B->d_desc.p, st + o_desc, n_items * sizeof(ProofDesc), hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(B->minvals.p, st + o_min, minvals.size() * 8, hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(B->seeds.p, st + o_seed, seeds.size(), hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(B->states.p, st + o_state, states.size(), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(B->d_desc.p, st + L.o_desc, n_items * sizeof(ProofDesc), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(B->minvals.p, st + L.o_min, minvals.size() * 8, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(B->states.p, st + L.o_state, states.size(), hipMemcpyHostToDevice, s));
+      if (L.n_seed) {
+        B->seeds_dirty = true;
+        HIP_CHECK(hipMemcpyAsync(B->seeds.p, st + L.o_seed, L.n_seed, hipMemcpyHostToDevice, s));
+      }
     }
     // point sources in dynamic-slot order C_j.., A1, B, A, L.., R.. and the two slot lists, written by one lane per proof
     hipLaunchKernelGGL(k_build_slots, dim3(cdiv((uint32_t)n_items, 64)), dim3(64), 0, s, B->d_desc.p, (uint32_t)n_items, P.t,
@@ -1027,7 +1106,7 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
         }
         // validate_and_append_point (transcript_protocol.rs:48-61): A, A1, B, L_j, R_j must not be the identity encoding
         if (B->defer[i] & BPP_DEFER_DEGREE) continue;  // other layout: its chunk fails before PASS 1 is looked at
-        const uint8_t *pA = items[i].proof + 1 + 32 * P.t;
+        const uint8_t *pA = bytes + d.proof_off + 1 + 32 * P.t;  // the staged copy of the proof
         auto zero32 = [](const uint8_t *p) {
           uint8_t r = 0;
           for (int k = 0; k < 32; k++) r |= p[k];
@@ -1057,7 +1136,24 @@ int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, siz
     HIP_CHECK(hipStreamSynchronize(s));
     const uint64_t h = g_next_handle.fetch_add(1);
     ctx->batches[h] = std::move(B);
-    *batch = h;
+    registered = true;
+    return h;
+}
+
+int upload_impl(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, const bpp_packed_batch *packed,
+                uint64_t *batch, const uint8_t *const *challenges32, const uint8_t *rng_out32, char *errbuf, size_t errbuf_len) {
+  try {
+    const std::shared_ptr<Params> Pp = params_registry().get(params);
+    if (!Pp || Pp->device != ctx->device) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle", errbuf, errbuf_len);
+    if (packed) n_items = packed->n_items;
+    // verify_batch: by definition an empty batch fails (src/range_proof.rs:719-723)
+    if ((!items && !packed) || n_items == 0 || !batch)
+      return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "Range statements or proofs length empty", errbuf, errbuf_len);
+    if (n_items > (1u << 24)) return fail(ctx, BPP_ERR_SIZE_OVERFLOW, "batch too large", errbuf, errbuf_len);
+    UploadPlan pl;
+    PlanWipe wipe_plan{pl};
+    upload_host_pack(ctx, *Pp, items, n_items, packed, pl);
+    *batch = upload_device(ctx, Pp, params, pl, challenges32, rng_out32);
     return BPP_OK;
   }
   BPP_CATCH(ctx, errbuf, errbuf_len)
@@ -1069,7 +1165,14 @@ extern "C" {
 int bpp_batch_upload(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, uint64_t *batch,
                      char *errbuf, size_t errbuf_len) {
   BPP_ENTRY(ctx);
-  return upload_impl(ctx, params, items, n_items, batch, nullptr, nullptr, errbuf, errbuf_len);
+  return upload_impl(ctx, params, items, n_items, nullptr, batch, nullptr, nullptr, errbuf, errbuf_len);
+}
+
+int bpp_batch_upload_packed(bpp_ctx *ctx, uint64_t params, const bpp_packed_batch *in, uint64_t *batch, char *errbuf,
+                            size_t errbuf_len) {
+  BPP_ENTRY(ctx);
+  if (!in) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "Range statements or proofs length empty", errbuf, errbuf_len);
+  return upload_impl(ctx, params, nullptr, 0, in, batch, nullptr, nullptr, errbuf, errbuf_len);
 }
 
 int bpp_host_threads(void) { return (int)host_pool_size(); }
@@ -1097,6 +1200,8 @@ int bpp_batch_destroy(bpp_ctx *ctx, uint64_t batch) {
   (void)hipStreamSynchronize(ctx->stream);
   auto it = ctx->batches.find(batch);
   if (it == ctx->batches.end()) return BPP_ERR_BAD_HANDLE;
+  wipe_batch_secrets(*it->second, ctx->stream);  // seed nonces, recovered masks: gone before the buffers change hands
+  (void)hipStreamSynchronize(ctx->stream);
   ctx->spare_batch = std::move(it->second);  // nothing of it is in flight any more; its allocations serve the next upload
   ctx->batches.erase(it);
   return BPP_OK;
@@ -1109,7 +1214,7 @@ namespace {
 // Weight-independent device work for the whole resident batch: PASS 1, decompression and -- unless `pass1_only` --
 // the per-proof scalar block (k_scalars_shared).  Returns after the transcript-RNG bytes have reached the host (h_rng); the rest is
 // still running on the stream (it overlaps the host weight chain).
-void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
+void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, bool fetch_rng = true) {
   Params &P = *b.params;
   hipStream_t s = ctx->stream;
   if (!ctx->ev_rng_ready) {
@@ -1156,8 +1261,10 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
                          P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p);
   }
   tm.mark(M_TRANSCRIPTS);
-  HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
+  if (fetch_rng) {  // (the sharded form gathers the device copy over RCCL instead)
+    HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
+  }
   if (!side) launch_decompress(s);
   tm.mark(M_DECOMPRESS);
   if (!pass1_only) {  // the weight-independent part of the PASS-2 scalars; the rest (k_scalars_lanes) takes the weights
@@ -1173,7 +1280,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only) {
   }
   if (side) HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_join, 0));
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipEventSynchronize(ctx->ev_rng));
+  if (fetch_rng) HIP_CHECK(hipEventSynchronize(ctx->ev_rng));
 }
 
 // Weight chains of all groups (src/range_proof.rs:811,849,853,894).  Chunks are independent reference batches: groups of
@@ -1329,25 +1436,9 @@ void fetch_status(bpp_ctx *ctx, Batch &b) {
   HIP_CHECK(hipMemcpyAsync(b.h_status.data(), b.status.p, (size_t)b.B * 4, hipMemcpyDeviceToHost, ctx->stream));
 }
 
-// reference error precedence for proofs [p0, p1) treated as one verify() call
+// reference error precedence for proofs [p0, p1) treated as one verify() call (upload_host.h: check_chunk_errors)
 void check_chunk_errors(const Batch &b, uint32_t p0, uint32_t p1) {
-  // a statement whose commitment does not decode could never have been constructed (RangeStatement holds points)
-  for (uint32_t p = p0; p < p1; p++)
-    if (b.h_status[p] & BPP_ST_COMMIT_FAIL)
-      throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Statement commitment is not the canonical encoding of a point"};
-  // PASS 1 over all proofs of the chunk first (src/range_proof.rs:816-850)
-  for (uint32_t p = p0; p < p1; p++)
-    if (b.h_status[p] & BPP_ST_TRANSCRIPT_FAIL)
-      throw ProofErr{BPP_ERR_VERIFICATION_FAILED,
-                     "Identity element cannot be added to the transcript / transcript challenge cannot be zero"};
-  // PASS 2 in proof order (:859-888)
-  for (uint32_t p = p0; p < p1; p++) {
-    if (b.h_status[p] & BPP_ST_DECOMPRESS_FAIL)
-      throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "A proof member was not the canonical encoding of a point"};
-    if (b.rounds_bad[p] == BPP_ERR_SIZE_OVERFLOW) throw ProofErr{BPP_ERR_SIZE_OVERFLOW, "Internal size overflow"};
-    if (b.rounds_bad[p] == BPP_ERR_INVALID_LENGTH)
-      throw ProofErr{BPP_ERR_INVALID_LENGTH, "Vector L/R length not adequate"};
-  }
+  bpp::check_chunk_errors(b.h_status.data(), b.rounds_bad.data(), p0, p1);
 }
 
 // (re)build the group layout + MSM term lists for `chunk`
@@ -1488,7 +1579,8 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
     enqueue_phase1(ctx, b, tm, pass1_only || action == BPP_RECOVER_ONLY);
 
     float chain_ms = 0;
-    std::vector<uint8_t> h_masks;
+    std::vector<uint8_t> h_masks;  // recovered masks on their way to the caller: wiped on every exit (src/extended_mask.rs:14)
+    ScopeExit wipe_masks{[&] { wipe(h_masks.data(), h_masks.size()); }};
     b.h_ident.resize(b.G);
     for (uint32_t g = 0; g < b.G; g++) b.h_ident[g] = 1;
     auto &h_ident = b.h_ident;
@@ -1502,6 +1594,7 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
       if (action != BPP_VERIFY_ONLY && b.any_seed) {  // masks (:941-969)
         hipLaunchKernelGGL(k_masks, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.chal.p, b.seeds.p,
                            P.n_bits, P.t, b.cs, b.B, b.masks.p);
+        b.masks_dirty = true;
         h_masks.resize((size_t)b.B * P.t * 32);
         HIP_CHECK(hipMemcpyAsync(h_masks.data(), b.masks.p, h_masks.size(), hipMemcpyDeviceToHost, s));
       }
@@ -1520,7 +1613,7 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
     for (uint32_t g = 0; g < b.G; g++) {
       if (b.any_defer) check_deferred(b.defer, b.h_group_first[g], b.h_group_first[g + 1]);  // :637-682
       check_chunk_errors(b, b.h_group_first[g], b.h_group_first[g + 1]);
-      if (want_msm && !h_ident[g]) throw ProofErr{BPP_ERR_VERIFICATION_FAILED, "Range proof batch not valid"};
+      if (want_msm && !h_ident[g]) throw ProofErr{BPP_ERR_VERIFICATION_FAILED, "Range proof batch not valid", BPP_TIER_MSM, b.h_group_first[g]};
     }
     // outputs: Vec<Option<ExtendedMask>>
     for (uint32_t p = 0; p < b.B; p++) {
@@ -1546,7 +1639,7 @@ int bpp_verify_batch_with_challenges(bpp_ctx *ctx, uint64_t params, const bpp_ve
   {
     BPP_ENTRY(ctx);
     if (!challenges32 || !rng_out32) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument", errbuf, errbuf_len);
-    rc = upload_impl(ctx, params, items, n_items, &h, challenges32, rng_out32, errbuf, errbuf_len);
+    rc = upload_impl(ctx, params, items, n_items, nullptr, &h, challenges32, rng_out32, errbuf, errbuf_len);
   }
   if (rc != BPP_OK) return rc;
   rc = bpp_verify_resident(ctx, h, action, chunk, masks_out, mask_present, errbuf, errbuf_len);
@@ -1562,6 +1655,213 @@ int bpp_verify_batch(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items
   rc = bpp_verify_resident(ctx, h, action, chunk, masks_out, mask_present, errbuf, errbuf_len);
   (void)bpp_batch_destroy(ctx, h);
   return rc;
+}
+
+int bpp_verify_batch_packed(bpp_ctx *ctx, uint64_t params, const bpp_packed_batch *in, int action, size_t chunk,
+                            uint8_t *masks_out, uint8_t *mask_present, char *errbuf, size_t errbuf_len) {
+  uint64_t h = 0;
+  int rc = bpp_batch_upload_packed(ctx, params, in, &h, errbuf, errbuf_len);
+  if (rc != BPP_OK) return rc;
+  rc = bpp_verify_resident(ctx, h, action, chunk, masks_out, mask_present, errbuf, errbuf_len);
+  (void)bpp_batch_destroy(ctx, h);
+  return rc;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- pipelined host-buffers-in form
+// One context, `depth` lanes.  A lane is a private child context (own stream, page-locked staging, recycled work buffers)
+// plus a worker thread.  submit packs the caller's buffers into the next lane's staging ON THE CALLING THREAD -- the lanes
+// of earlier tickets are busy with DMA, kernels and weight chains meanwhile -- and hands the plan to the lane's worker,
+// which runs the device half of the upload, the verification and the release exactly as bpp_verify_batch_packed does.
+namespace {
+
+void pipe_worker(bpp_ctx *owner, Pipeline *pp, PipeLane *lane) {
+  (void)hipSetDevice(owner->device);
+  for (;;) {
+    std::shared_ptr<PipeJob> job;
+    {
+      std::unique_lock<std::mutex> lk(pp->mu);
+      pp->cv.wait(lk, [&] { return pp->quit || lane->job; });
+      if (!lane->job) return;  // quit with nothing posted
+      job = std::move(lane->job);
+      lane->job.reset();
+    }
+    bpp_ctx *c = lane->child;
+    char err[256];
+    err[0] = 0;
+    uint64_t h = 0;
+    int rc = BPP_OK;
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      try {
+        h = upload_device(c, job->Pp, job->params, job->pl, nullptr, nullptr);
+      } catch (const EngineError &e) {
+        rc = fail(c, e.code, e.msg, err, sizeof(err));
+      } catch (const ProofErr &e) {
+        rc = fail(c, e.code, e.msg, err, sizeof(err));
+      } catch (const std::exception &e) {
+        rc = fail(c, BPP_ERR_ENGINE, e.what(), err, sizeof(err));
+      }
+    }
+    if (rc == BPP_OK) {
+      const bool want_masks = job->action != BPP_VERIFY_ONLY;
+      if (want_masks) {
+        job->masks.assign(job->n_items * job->t * 32, 0);
+        job->present.assign(job->n_items, 0);
+      }
+      rc = bpp_verify_resident(c, h, job->action, job->chunk, want_masks ? job->masks.data() : nullptr,
+                               want_masks ? job->present.data() : nullptr, err, sizeof(err));
+      (void)bpp_batch_destroy(c, h);
+    }
+    {
+      std::lock_guard<std::mutex> lk(pp->mu);
+      job->rc = rc;
+      job->err = err;
+      job->done = true;
+      lane->busy = false;
+    }
+    pp->cv.notify_all();
+  }
+}
+
+Pipeline *pipeline_get(bpp_ctx *ctx) {
+  std::lock_guard<std::mutex> lk(ctx->pipe_init_mu);
+  if (ctx->pipe) return ctx->pipe.get();
+  auto pp = std::make_unique<Pipeline>();
+  for (uint32_t i = 0; i < ctx->pipe_depth; i++) {
+    auto lane = std::make_unique<PipeLane>();
+    if (bpp_ctx_create(&lane->child, ctx->device) != BPP_OK) throw EngineError{BPP_ERR_ENGINE, "pipeline lane: context creation failed"};
+    pp->lanes.push_back(std::move(lane));
+  }
+  for (auto &lane : pp->lanes) lane->th = std::thread(pipe_worker, ctx, pp.get(), lane.get());
+  ctx->pipe = std::move(pp);
+  return ctx->pipe.get();
+}
+
+}  // namespace
+
+void pipeline_shutdown(bpp_ctx *ctx) {
+  std::unique_ptr<Pipeline> pp;
+  {
+    std::lock_guard<std::mutex> lk(ctx->pipe_init_mu);
+    pp = std::move(ctx->pipe);
+  }
+  if (!pp) return;
+  {
+    std::unique_lock<std::mutex> lk(pp->mu);
+    pp->cv.wait(lk, [&] {  // calls in flight finish first (their results are simply dropped)
+      for (auto &l : pp->lanes)
+        if (l->busy) return false;
+      return true;
+    });
+    pp->quit = true;
+  }
+  pp->cv.notify_all();
+  for (auto &l : pp->lanes) {
+    if (l->th.joinable()) l->th.join();
+    bpp_ctx_destroy(l->child);
+  }
+  for (auto &kv : pp->tickets) wipe(kv.second->masks.data(), kv.second->masks.size());
+}
+
+extern "C" {
+
+int bpp_ctx_pipeline_depth(bpp_ctx *ctx, uint32_t depth) {
+  if (!ctx) return BPP_ERR_BAD_HANDLE;
+  std::lock_guard<std::mutex> lk(ctx->pipe_init_mu);
+  if (ctx->pipe) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "the pipeline is already running");
+  if (depth < 1 || depth > 16) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "pipeline depth must be 1..16");
+  ctx->pipe_depth = depth;
+  return BPP_OK;
+}
+
+int bpp_verify_submit_packed(bpp_ctx *ctx, uint64_t params, const bpp_packed_batch *in, int action, size_t chunk,
+                             uint64_t *ticket, char *errbuf, size_t errbuf_len) {
+  if (!ctx) return BPP_ERR_BAD_HANDLE;
+  if (hipSetDevice(ctx->device) != hipSuccess) return BPP_ERR_NO_DEVICE;
+  try {
+    if (!in || !ticket || in->n_items == 0)
+      return fail(nullptr, BPP_ERR_INVALID_ARGUMENT, "Range statements or proofs length empty", errbuf, errbuf_len);
+    if (action < 0 || action > 2) return fail(nullptr, BPP_ERR_INVALID_ARGUMENT, "unknown verify action", errbuf, errbuf_len);
+    if (in->n_items > (1u << 24)) return fail(nullptr, BPP_ERR_SIZE_OVERFLOW, "batch too large", errbuf, errbuf_len);
+    const std::shared_ptr<Params> Pp = params_registry().get(params);
+    if (!Pp || Pp->device != ctx->device) return fail(nullptr, BPP_ERR_BAD_HANDLE, "unknown params handle", errbuf, errbuf_len);
+    Pipeline *pp = pipeline_get(ctx);
+    std::lock_guard<std::mutex> submit_lock(pp->submit_mu);
+    PipeLane *lane;
+    {
+      std::unique_lock<std::mutex> lk(pp->mu);
+      lane = pp->lanes[pp->next_lane].get();
+      pp->cv.wait(lk, [&] { return !lane->busy; });  // its previous call is done: staging and work buffers are free
+      lane->busy = true;
+      pp->next_lane = (pp->next_lane + 1) % (uint32_t)pp->lanes.size();
+    }
+    auto job = std::make_shared<PipeJob>();
+    job->action = action;
+    job->chunk = chunk;
+    job->Pp = Pp;
+    job->params = params;
+    job->n_items = in->n_items;
+    job->t = Pp->t;
+    try {
+      upload_host_pack(lane->child, *Pp, nullptr, 0, in, job->pl);  // into the lane's staging; throws construction errors
+    } catch (...) {
+      secure_wipe(job->pl.seeds.data(), job->pl.seeds.size());
+      {
+        std::lock_guard<std::mutex> lk(pp->mu);
+        lane->busy = false;
+      }
+      pp->cv.notify_all();
+      throw;
+    }
+    {
+      std::lock_guard<std::mutex> lk(pp->mu);
+      job->ticket = pp->next_ticket++;
+      pp->tickets[job->ticket] = job;
+      lane->job = job;
+      *ticket = job->ticket;
+    }
+    pp->cv.notify_all();
+    return BPP_OK;
+  }
+  BPP_CATCH(nullptr, errbuf, errbuf_len)
+}
+
+int bpp_verify_collect(bpp_ctx *ctx, uint64_t ticket, uint8_t *masks_out, uint8_t *mask_present, char *errbuf,
+                       size_t errbuf_len) {
+  if (!ctx) return BPP_ERR_BAD_HANDLE;
+  Pipeline *pp;
+  {
+    std::lock_guard<std::mutex> lk(ctx->pipe_init_mu);
+    pp = ctx->pipe.get();
+  }
+  if (!pp) return fail(nullptr, BPP_ERR_BAD_HANDLE, "unknown ticket", errbuf, errbuf_len);
+  std::shared_ptr<PipeJob> job;
+  {
+    std::unique_lock<std::mutex> lk(pp->mu);
+    auto it = pp->tickets.find(ticket);
+    if (it == pp->tickets.end()) return fail(nullptr, BPP_ERR_BAD_HANDLE, "unknown ticket", errbuf, errbuf_len);
+    job = it->second;
+    pp->cv.wait(lk, [&] { return job->done; });
+    pp->tickets.erase(it);
+  }
+  ScopeExit wipe_masks{[&] { wipe(job->masks.data(), job->masks.size()); }};
+  if (job->rc != BPP_OK) {
+    set_err(errbuf, errbuf_len, job->err);
+    return job->rc;
+  }
+  const size_t n = job->n_items, t = job->t;
+  const bool have = job->action != BPP_VERIFY_ONLY;
+  if (mask_present) {
+    if (have) memcpy(mask_present, job->present.data(), n);
+    else memset(mask_present, 0, n);
+  }
+  if (masks_out) {
+    if (have) memcpy(masks_out, job->masks.data(), n * t * 32);
+    else memset(masks_out, 0, n * t * 32);
+  }
+  return BPP_OK;
 }
 
 // ---------------------------------------------------------------- phased form
@@ -1699,6 +1999,35 @@ int bpp_batch_trace(bpp_ctx *ctx, uint64_t batch, int what, uint8_t *out, size_t
   BPP_CATCH(ctx, nullptr, 0)
 }
 
+int bpp_batch_secret_bytes(bpp_ctx *ctx, uint64_t batch, uint64_t *nonzero) {
+  BPP_ENTRY(ctx);
+  try {
+    if (!nonzero) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument");
+    Batch *b = nullptr;
+    if (batch == 0) {
+      b = ctx->spare_batch.get();
+    } else {
+      auto it = ctx->batches.find(batch);
+      if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle");
+      b = it->second.get();
+    }
+    uint64_t cnt = 0;
+    if (b) {
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      for (DevBuf<uint8_t> *buf : {&b->seeds, &b->masks}) {
+        if (!buf->p || !buf->n) continue;
+        std::vector<uint8_t> h(buf->n);
+        HIP_CHECK(hipMemcpy(h.data(), buf->p, buf->n, hipMemcpyDeviceToHost));
+        for (uint8_t v : h) cnt += v != 0;
+        wipe(h.data(), h.size());
+      }
+    }
+    *nonzero = cnt;
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, nullptr, 0)
+}
+
 int bpp_profile_enable(bpp_ctx *ctx, int on) {
   if (!ctx) return BPP_ERR_BAD_HANDLE;
   ctx->profile = on != 0;
@@ -1718,6 +2047,8 @@ int bpp_profile_get(bpp_ctx *ctx, bpp_profile *out) {
 }
 
 }  // extern "C"
+
+#include "engine_shard.h"
 
 // ================================================================= batch prover
 extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_item *items, size_t n_items, uint8_t *proofs_out,

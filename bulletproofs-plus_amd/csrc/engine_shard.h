@@ -1,0 +1,403 @@
+// ONE reference batch sharded over the GPUs of a node, behind the C ABI (include/bpp.h: bpp_comm_*, bpp_verify_sharded,
+// bpp_verify_sharded_wave).  Part of engine.hip's translation unit (it drives the same phase functions as
+// bpp_verify_resident); the collectives are RCCL calls on device buffers, issued from here -- no framework in between.
+//
+// Reference coupling points (src/range_proof.rs): the batch weights come from ONE transcript over all proofs in order
+// (:811,:849,:853,:894) and the final check is one group equation (:1050-1062).  SURVEY 8(e).
+//
+// RCCL is loaded lazily (dlopen) so that libbpp_hip.so itself does not depend on a 570 MB library its single-GPU callers
+// never touch; a process that already has librccl.so.1 loaded (e.g. through torch.distributed) gets that same copy.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct RcclApi {
+  void *lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string err;
+};
+
+namespace {
+
+RcclApi &rccl_api() {
+  static RcclApi *api = [] {
+    RcclApi *a = new RcclApi();
+    const char *names[] = {getenv("BPP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+      if (!n || !*n) continue;
+      a->lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (a->lib) break;
+    }
+    if (!a->lib) {
+      a->err = std::string("RCCL not loadable: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+      return a;
+    }
+#define BPP_RCCL_SYM(field, name)                              \
+  a->field = (decltype(a->field))dlsym(a->lib, name);          \
+  if (!a->field && a->err.empty()) a->err = std::string("RCCL symbol missing: ") + name;
+    BPP_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    BPP_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    BPP_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    BPP_RCCL_SYM(CommAbort, "ncclCommAbort");
+    BPP_RCCL_SYM(AllGather, "ncclAllGather");
+    BPP_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef BPP_RCCL_SYM
+    return a;
+  }();
+  return *api;
+}
+
+struct CommError {
+  std::string msg;
+};
+#define RCCL_CHECK(expr)                                                                            \
+  do {                                                                                              \
+    ncclResult_t _r = (expr);                                                                       \
+    if (_r != ncclSuccess) {                                                                        \
+      char _b[256];                                                                                 \
+      snprintf(_b, sizeof(_b), "%s failed: %s", #expr, rccl_api().GetErrorString(_r));              \
+      throw CommError{_b};                                                                          \
+    }                                                                                               \
+  } while (0)
+
+// sum over ranks of batch i's accumulators -> identity flag.  in: [rank][per_rank bytes], batch i's 128 bytes at i * 128.
+// One lane per batch (a handful of additions: the exchange is latency, not work).
+__global__ void k_sum_accumulators_wave(const uint8_t *__restrict__ in, uint32_t world, uint32_t per_rank, uint32_t k,
+                                        uint32_t *__restrict__ is_identity) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  ge acc;
+  ge_identity(acc);
+  for (uint32_t r = 0; r < world; r++) {
+    const uint8_t *src = in + (size_t)r * per_rank + (size_t)i * 128;
+    ge p;
+    uint8_t b[32];
+    for (int c = 0; c < 4; c++) {
+      for (int j = 0; j < 32; j++) b[j] = src[32 * c + j];
+      fe_frombytes(c == 0 ? p.X : c == 1 ? p.Y : c == 2 ? p.Z : p.T, b);
+    }
+    ge_add(acc, acc, p);
+  }
+  is_identity[i] = ge_is_ristretto_identity(acc) ? 1u : 0u;
+}
+
+}  // namespace
+
+struct bpp_comm {
+  int device = 0, rank = 0, world = 1;
+  ncclComm_t comm = nullptr;
+  bool own_comm = false;
+  hipStream_t stream = nullptr;  // collectives and their staging copies
+  DevBuf<uint8_t> send1, recv1, send2, recv2;
+  DevBuf<uint32_t> d_flags;
+  PinnedBuf<uint8_t> h_tr, h_recv1, h_recv2;
+  PinnedBuf<uint32_t> h_flags;
+  std::vector<uint8_t> rng_all, weights_all;
+  std::mutex mu;
+  std::string err;
+};
+
+namespace {
+
+int comm_fail(bpp_comm *c, int code, const std::string &m, char *errbuf = nullptr, size_t len = 0) {
+  if (c) c->err = m;
+  set_err(errbuf, len, m);
+  return code;
+}
+
+int comm_new(bpp_ctx *ctx, ncclComm_t nc, bool own, int rank, int world, bpp_comm **out) {
+  auto c = std::make_unique<bpp_comm>();
+  c->device = ctx->device;
+  c->rank = rank;
+  c->world = world;
+  c->comm = nc;
+  c->own_comm = own;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return BPP_ERR_ENGINE;
+  *out = c.release();
+  return BPP_OK;
+}
+
+void shard_result_set(bpp_shard_result &r, int code, int tier, int rank, uint32_t index, const std::string &msg) {
+  r.code = code;
+  r.tier = tier;
+  r.rank = rank;
+  r.index = index;
+  snprintf(r.msg, sizeof(r.msg), "%s", msg.c_str());
+}
+
+}  // namespace
+
+extern "C" {
+
+int bpp_comm_unique_id(uint8_t id128[128]) {
+  if (!id128) return BPP_ERR_INVALID_ARGUMENT;
+  RcclApi &R = rccl_api();
+  if (!R.err.empty()) return BPP_ERR_COMM;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  if (R.GetUniqueId(&id) != ncclSuccess) return BPP_ERR_COMM;
+  memcpy(id128, &id, 128);
+  return BPP_OK;
+}
+
+int bpp_comm_create(bpp_ctx *ctx, const uint8_t id128[128], int rank, int world, bpp_comm **out) {
+  BPP_ENTRY(ctx);
+  if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "bad communicator arguments");
+  *out = nullptr;
+  RcclApi &R = rccl_api();
+  if (!R.err.empty()) return fail(ctx, BPP_ERR_COMM, R.err);
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  ncclComm_t nc = nullptr;
+  const ncclResult_t r = R.CommInitRank(&nc, world, id, rank);  // collective over the ranks; binds to the current device
+  if (r != ncclSuccess) return fail(ctx, BPP_ERR_COMM, std::string("ncclCommInitRank failed: ") + R.GetErrorString(r));
+  const int rc = comm_new(ctx, nc, true, rank, world, out);
+  if (rc != BPP_OK) (void)R.CommDestroy(nc);
+  return rc;
+}
+
+int bpp_comm_adopt(bpp_ctx *ctx, void *nccl_comm, int rank, int world, bpp_comm **out) {
+  BPP_ENTRY(ctx);
+  if (!out || !nccl_comm || world < 1 || rank < 0 || rank >= world) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "bad communicator arguments");
+  *out = nullptr;
+  RcclApi &R = rccl_api();
+  if (!R.err.empty()) return fail(ctx, BPP_ERR_COMM, R.err);
+  return comm_new(ctx, (ncclComm_t)nccl_comm, false, rank, world, out);
+}
+
+void bpp_comm_destroy(bpp_comm *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->own_comm && c->comm) (void)rccl_api().CommDestroy(c->comm);
+    (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+const char *bpp_comm_last_error(bpp_comm *c) { return c ? c->err.c_str() : "null comm"; }
+
+int bpp_shard_trailer(int tier, int code, uint32_t index, const char *msg, uint8_t trailer_out[BPP_SHARD_TRAILER_BYTES]) {
+  if (!trailer_out || tier < 0 || tier > 255) return BPP_ERR_INVALID_ARGUMENT;
+  shard_trailer_encode(trailer_out, tier, code, index, msg);
+  return BPP_OK;
+}
+
+int bpp_shard_local_trailer(const uint8_t *defer, const uint32_t *status, const uint8_t *rounds_bad, uint32_t n,
+                            uint32_t first_index, uint8_t trailer_out[BPP_SHARD_TRAILER_BYTES]) {
+  if (!trailer_out || ((!status || !rounds_bad) && n)) return BPP_ERR_INVALID_ARGUMENT;
+  shard_local_trailer(defer, status, rounds_bad, n, first_index, trailer_out);
+  return BPP_OK;
+}
+
+int bpp_shard_resolve(const uint8_t *trailers, size_t stride, int world, int *tier_out, int *rank_out, uint32_t *index_out,
+                      char *errbuf, size_t errbuf_len) {
+  if (!trailers || world < 1 || stride < BPP_SHARD_TRAILER_BYTES) return BPP_ERR_INVALID_ARGUMENT;
+  const ShardFinding f = shard_resolve(trailers, stride, world);
+  if (tier_out) *tier_out = f.tier;
+  if (rank_out) *rank_out = f.rank;
+  if (index_out) *index_out = f.index;
+  if (f.tier == BPP_TIER_NONE) return BPP_OK;
+  set_err(errbuf, errbuf_len, f.msg + " (rank " + std::to_string(f.rank) + ")");
+  return f.code;
+}
+
+int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t *batches, size_t k_in, const uint32_t *counts,
+                            bpp_shard_result *results) {
+  if (!comm) return BPP_ERR_BAD_HANDLE;
+  if (!ctxs || !batches || !counts || !results || k_in == 0 || k_in > 64) return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "bad wave arguments");
+  if (hipSetDevice(comm->device) != hipSuccess) return BPP_ERR_NO_DEVICE;
+  const uint32_t K = (uint32_t)k_in, world = (uint32_t)comm->world, rank = (uint32_t)comm->rank;
+  std::lock_guard<std::mutex> comm_lock(comm->mu);
+  std::vector<std::unique_lock<std::mutex>> ctx_locks;
+  for (uint32_t i = 0; i < K; i++) {
+    if (!ctxs[i] || ctxs[i]->device != comm->device) return comm_fail(comm, BPP_ERR_BAD_HANDLE, "context of another device (or null) in the wave");
+    for (uint32_t j = 0; j < i; j++)
+      if (ctxs[j] == ctxs[i]) return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "every batch of a wave needs its own context (stream)");
+    ctx_locks.emplace_back(ctxs[i]->mu);
+  }
+  RcclApi &R = rccl_api();
+  uint32_t maxc = 0, first_index = 0;
+  uint64_t n_total = 0;
+  for (uint32_t r = 0; r < world; r++) {
+    maxc = std::max(maxc, counts[r]);
+    if (r < rank) first_index += counts[r];
+    n_total += counts[r];
+  }
+  if (n_total == 0 || n_total > (1u << 24)) return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "Range statements or proofs length empty");
+  // buffers: first exchange per rank = K slots of maxc x 32 RNG bytes + K trailers; second = K accumulators + K fault words
+  const size_t slot = (size_t)maxc * 32, per1 = K * slot + (size_t)K * BPP_SHARD_TRAILER_BYTES, per2 = (size_t)K * 128 + (size_t)K * 4;
+  std::vector<Batch *> B(K, nullptr);
+  std::vector<int> fault(K, 0);           // engine fault on THIS rank, per batch
+  std::vector<std::string> fault_msg(K);
+  std::vector<uint8_t> skip(K, 0);        // batch decided by the first exchange: no phase 2
+  try {
+    comm->send1.alloc(per1);
+    comm->recv1.alloc(per1 * world);
+    comm->send2.alloc(per2);
+    comm->recv2.alloc(per2 * world);
+    comm->d_flags.alloc(K);
+    comm->h_tr.resize((size_t)K * BPP_SHARD_TRAILER_BYTES + (size_t)K * 4);
+    comm->h_recv1.resize(per1 * world);
+    comm->h_recv2.resize(per2 * world);
+    comm->h_flags.resize(K);
+    // ---------------------------------------------------------------- phase 1 on every context's own stream
+    for (uint32_t i = 0; i < K; i++) {
+      try {
+        auto it = ctxs[i]->batches.find(batches[i]);
+        if (it == ctxs[i]->batches.end()) throw EngineError{BPP_ERR_BAD_HANDLE, "unknown batch handle"};
+        Batch &b = *it->second;
+        if (b.B != counts[rank]) throw EngineError{BPP_ERR_ENGINE, "counts[rank] differs from the resident shard's size"};
+        B[i] = &b;
+        StageTimer tm(ctxs[i]);
+        hipStream_t s = ctxs[i]->stream;
+        uint8_t *dst = comm->send1.p + (size_t)i * slot;
+        if (b.any_defer) {
+          // verify()'s consistency loops (:637-682) fail this batch before anything is computed: nothing runs on items
+          // whose layout differs from the parameters'; the rank still sends a (zero) payload and its finding
+          HIP_CHECK(hipMemsetAsync(dst, 0, slot, s));
+          continue;
+        }
+        layout_groups(ctxs[i], b, 0);
+        enqueue_phase1(ctxs[i], b, tm, b.any_rounds_bad, /*fetch_rng=*/false);
+        HIP_CHECK(hipMemcpyAsync(dst, b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToDevice, s));
+        if (b.B < maxc) HIP_CHECK(hipMemsetAsync(dst + (size_t)b.B * 32, 0, (size_t)(maxc - b.B) * 32, s));
+        fetch_status(ctxs[i], b);
+      } catch (const EngineError &e) {
+        fault[i] = e.code;
+        fault_msg[i] = e.msg;
+      }
+    }
+    for (uint32_t i = 0; i < K; i++) {
+      uint8_t *tr = comm->h_tr.data() + (size_t)i * BPP_SHARD_TRAILER_BYTES;
+      if (!fault[i] && hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) {
+        fault[i] = BPP_ERR_ENGINE;
+        fault_msg[i] = "phase 1 failed on the device";
+      }
+      if (fault[i]) {
+        shard_trailer_encode(tr, BPP_TIER_ENGINE, fault[i], first_index, fault_msg[i].c_str());
+      } else {
+        Batch &b = *B[i];
+        shard_local_trailer(b.any_defer ? b.defer.data() : nullptr, b.h_status.data(), b.rounds_bad.data(), b.B, first_index, tr);
+      }
+    }
+    hipStream_t cs = comm->stream;
+    HIP_CHECK(hipMemcpyAsync(comm->send1.p + K * slot, comm->h_tr.data(), (size_t)K * BPP_SHARD_TRAILER_BYTES, hipMemcpyHostToDevice, cs));
+    RCCL_CHECK(R.AllGather(comm->send1.p, comm->recv1.p, per1, ncclUint8, comm->comm, cs));
+    HIP_CHECK(hipMemcpyAsync(comm->h_recv1.data(), comm->recv1.p, per1 * world, hipMemcpyDeviceToHost, cs));
+    HIP_CHECK(hipStreamSynchronize(cs));
+    // ---------------------------------------------------------------- every rank reads the same findings
+    std::vector<uint32_t> active;
+    for (uint32_t i = 0; i < K; i++) {
+      const ShardFinding f = shard_resolve(comm->h_recv1.data() + K * slot + (size_t)i * BPP_SHARD_TRAILER_BYTES, per1, (int)world);
+      if (f.tier != BPP_TIER_NONE) {
+        skip[i] = 1;
+        shard_result_set(results[i], f.code, f.tier, f.rank, f.index, f.msg + " (rank " + std::to_string(f.rank) + ")");
+      } else {
+        active.push_back(i);
+      }
+    }
+    // ---------------------------------------------------------------- weight transcripts over ALL proofs of each batch
+    if (!active.empty()) {
+      const size_t A = active.size();
+      comm->rng_all.resize(A * n_total * 32);
+      comm->weights_all.resize(A * n_total * 32);
+      std::vector<uint32_t> gfirst(A + 1);
+      for (size_t a = 0; a < A; a++) {
+        gfirst[a] = (uint32_t)(a * n_total);
+        uint8_t *dst = comm->rng_all.data() + a * n_total * 32;
+        for (uint32_t r = 0; r < world; r++) {
+          memcpy(dst, comm->h_recv1.data() + (size_t)r * per1 + (size_t)active[a] * slot, (size_t)counts[r] * 32);
+          dst += (size_t)counts[r] * 32;
+        }
+      }
+      gfirst[A] = (uint32_t)(A * n_total);
+      run_weight_chains_generic(comm->rng_all.data(), comm->weights_all.data(), gfirst.data(), (uint32_t)A);
+      for (size_t a = 0; a < A; a++) {
+        const uint32_t i = active[a];
+        try {
+          Batch &b = *B[i];
+          StageTimer tm(ctxs[i]);
+          hipStream_t s = ctxs[i]->stream;
+          memcpy(b.h_weights.data(), comm->weights_all.data() + (a * n_total + first_index) * 32, (size_t)b.B * 32);
+          enqueue_phase2(ctxs[i], b, tm);
+          hipLaunchKernelGGL(k_ge_to_bytes, dim3(1), dim3(64), 0, s, b.msm.R.p, 1u, comm->send2.p + (size_t)i * 128);
+          HIP_CHECK(hipGetLastError());
+          b.have_trace = true;
+        } catch (const EngineError &e) {
+          fault[i] = e.code;
+          fault_msg[i] = e.msg;
+        }
+      }
+    }
+    uint32_t *fw = (uint32_t *)(comm->h_tr.data() + (size_t)K * BPP_SHARD_TRAILER_BYTES);
+    for (uint32_t i = 0; i < K; i++) {
+      if (!skip[i] && !fault[i] && hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) {
+        fault[i] = BPP_ERR_ENGINE;
+        fault_msg[i] = "phase 2 failed on the device";
+      }
+      fw[i] = skip[i] ? 0u : (uint32_t)fault[i];
+    }
+    for (uint32_t i = 0; i < K; i++)
+      if (skip[i]) HIP_CHECK(hipMemsetAsync(comm->send2.p + (size_t)i * 128, 0, 128, cs));
+    HIP_CHECK(hipMemcpyAsync(comm->send2.p + (size_t)K * 128, fw, (size_t)K * 4, hipMemcpyHostToDevice, cs));
+    RCCL_CHECK(R.AllGather(comm->send2.p, comm->recv2.p, per2, ncclUint8, comm->comm, cs));
+    hipLaunchKernelGGL(k_sum_accumulators_wave, dim3(cdiv(K, 64)), dim3(64), 0, cs, comm->recv2.p, world, (uint32_t)per2, K, comm->d_flags.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(comm->h_flags.data(), comm->d_flags.p, (size_t)K * 4, hipMemcpyDeviceToHost, cs));
+    HIP_CHECK(hipMemcpyAsync(comm->h_recv2.data(), comm->recv2.p, per2 * world, hipMemcpyDeviceToHost, cs));
+    HIP_CHECK(hipStreamSynchronize(cs));
+    for (uint32_t i = 0; i < K; i++) {
+      if (skip[i]) continue;
+      int bad_rank = -1, bad_code = 0;
+      for (uint32_t r = 0; r < world && bad_rank < 0; r++) {
+        uint32_t w;
+        memcpy(&w, comm->h_recv2.data() + (size_t)r * per2 + (size_t)K * 128 + (size_t)i * 4, 4);
+        if (w) {
+          bad_rank = (int)r;
+          bad_code = (int)w;
+        }
+      }
+      if (bad_rank >= 0)
+        shard_result_set(results[i], bad_code < 0 ? bad_code : BPP_ERR_ENGINE, BPP_TIER_ENGINE, bad_rank, 0,
+                         (bad_rank == (int)rank ? fault_msg[i] : std::string("engine fault")) + " (rank " + std::to_string(bad_rank) + ")");
+      else if (!comm->h_flags[i])
+        shard_result_set(results[i], BPP_ERR_VERIFICATION_FAILED, BPP_TIER_MSM, -1, 0, "Range proof batch not valid");
+      else
+        shard_result_set(results[i], BPP_OK, BPP_TIER_NONE, -1, 0, "");
+    }
+    return BPP_OK;
+  } catch (const CommError &e) {
+    return comm_fail(comm, BPP_ERR_COMM, e.msg);
+  } catch (const EngineError &e) {
+    // a HIP failure around the collectives themselves: this rank cannot promise to reach the next collective
+    return comm_fail(comm, e.code, e.msg);
+  } catch (const std::exception &e) {
+    return comm_fail(comm, BPP_ERR_ENGINE, e.what());
+  }
+}
+
+int bpp_verify_sharded(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, const uint32_t *counts, int *tier_out, int *rank_out,
+                       char *errbuf, size_t errbuf_len) {
+  bpp_shard_result r;
+  memset(&r, 0, sizeof(r));
+  bpp_ctx *ctxs[1] = {ctx};
+  const int rc = bpp_verify_sharded_wave(comm, ctxs, &batch, 1, counts, &r);
+  if (rc != BPP_OK) {
+    set_err(errbuf, errbuf_len, comm ? comm->err : "null comm");
+    return rc;
+  }
+  if (tier_out) *tier_out = r.tier;
+  if (rank_out) *rank_out = r.rank;
+  if (r.code != BPP_OK) set_err(errbuf, errbuf_len, r.msg);
+  return r.code;
+}
+
+}  // extern "C"

@@ -237,6 +237,148 @@ int main() {
     UploadPlan pl2;
     EXPECT("null_commitments", plan(vvv, P64, pl2) == BPP_ERR_INVALID_ARGUMENT);
   }
+  {  // packed form (bpp_packed_batch) == item form: same plan, same staged bytes; strided input; a proof whose first byte
+     // differs (another extension degree claimed) sends the batch through the item form with the same deferred finding
+    const uint32_t n = 37, t = 1, rounds = 6, m = 1;
+    std::vector<Item> its;
+    for (uint32_t i = 0; i < n; i++) its.push_back(make_item(t, rounds, m, 1000 + i, (i & 1) != 0, (i % 3) == 0));
+    const size_t plen = its[0].proof_len;
+    for (int variant = 0; variant < 3; variant++) {
+      const size_t stride = variant == 1 ? plen + 7 : plen;
+      if (variant == 2) its[20] = make_item(3, 5, m, 5, true, false);  // extension degree 3 in the SAME 577 bytes: one round less
+      // exact-size packed arrays
+      std::unique_ptr<uint8_t[]> proofs(new uint8_t[stride * (n - 1) + plen]), commits(new uint8_t[32 * n]), pres(new uint8_t[n]),
+          seeds(new uint8_t[32 * n]), seedp(new uint8_t[n]);
+      std::unique_ptr<uint64_t[]> minv(new uint64_t[n]);
+      memset(proofs.get(), 0xee, stride * (n - 1) + plen);
+      for (uint32_t i = 0; i < n; i++) {
+        memcpy(proofs.get() + stride * i, its[i].proof.get(), plen);
+        memcpy(commits.get() + 32 * i, its[i].commits.get(), 32);
+        minv[i] = its[i].minv[0];
+        pres[i] = its[i].present[0];
+        seedp[i] = its[i].seed ? 1 : 0;
+        if (its[i].seed) memcpy(seeds.get() + 32 * i, its[i].seed.get(), 32);
+        else memset(seeds.get() + 32 * i, 0x55, 32);
+      }
+      bpp_packed_batch pk;
+      memset(&pk, 0, sizeof(pk));
+      pk.n_items = n;
+      pk.proofs = proofs.get();
+      pk.proof_len = plen;
+      pk.proof_stride = stride;
+      pk.commitments32 = commits.get();
+      pk.m = m;
+      pk.min_values = minv.get();
+      pk.min_present = pres.get();
+      pk.seed_nonces32 = seeds.get();
+      pk.seed_present = seedp.get();
+      pk.transcript_label = (const uint8_t *)"harness";
+      pk.label_len = 7;
+      std::vector<bpp_verify_item> v;
+      for (auto &i : its) v.push_back(i.view("harness"));
+      UploadPlan pa, pb;
+      bool same = false, arithmetic = false;
+      try {
+        upload_pass_a(v.data(), v.size(), pa);
+        std::unique_ptr<uint8_t[]> ba(new uint8_t[pa.bytes_total + BPP_BYTES_SLACK]), bb;
+        upload_pass_b(v.data(), P64, pa, ba.get(), serial_for);
+        std::vector<bpp_verify_item> synth;
+        arithmetic = upload_pass_a_packed(pk, pb, serial_for);
+        if (!arithmetic) {
+          upload_packed_as_items(pk, synth);
+          upload_pass_a(synth.data(), synth.size(), pb);
+        }
+        bb.reset(new uint8_t[pb.bytes_total + BPP_BYTES_SLACK]);
+        if (arithmetic) upload_pass_b_packed(pk, P64, pb, bb.get(), serial_for);
+        else upload_pass_b(synth.data(), P64, pb, bb.get(), serial_for);
+        same = pa.bytes_total == pb.bytes_total && memcmp(ba.get(), bb.get(), pa.bytes_total) == 0 &&
+               pa.desc.size() == pb.desc.size() && memcmp(pa.desc.data(), pb.desc.data(), n * sizeof(ProofDesc)) == 0 &&
+               pa.minvals == pb.minvals && pa.seeds == pb.seeds && pa.states == pb.states && pa.defer == pb.defer &&
+               pa.rounds_bad == pb.rounds_bad && pa.total_dyn == pb.total_dyn && pa.rmax == pb.rmax && pa.max_mn == pb.max_mn &&
+               pa.any_seed == pb.any_seed && pa.any_defer == pb.any_defer && pa.any_rounds_bad == pb.any_rounds_bad &&
+               pa.uniform_rounds == pb.uniform_rounds && pa.sum_m == pb.sum_m;
+      } catch (const ProofErr &e) {
+        same = false;
+      }
+      EXPECT(variant == 0 ? "packed_equals_items" : variant == 1 ? "packed_strided_equals_items" : "packed_mixed_degree_falls_back",
+             same && arithmetic == (variant != 2) && (variant != 2 || pb.any_defer));
+    }
+    // construction errors: same kind and same (lowest) index from either form
+    its[20] = make_item(t, rounds, m, 5, true, false);
+    its[9].proof[1 + 32 * 4 + 31] = 0xff;   // r1 of item 9 not canonical
+    its[30].proof[1 + 31] = 0xff;           // d1 of item 30 not canonical
+    std::unique_ptr<uint8_t[]> proofs(new uint8_t[plen * n]), commits(new uint8_t[32 * n]);
+    for (uint32_t i = 0; i < n; i++) {
+      memcpy(proofs.get() + plen * i, its[i].proof.get(), plen);
+      memcpy(commits.get() + 32 * i, its[i].commits.get(), 32);
+    }
+    bpp_packed_batch pk;
+    memset(&pk, 0, sizeof(pk));
+    pk.n_items = n;
+    pk.proofs = proofs.get();
+    pk.proof_len = pk.proof_stride = plen;
+    pk.commitments32 = commits.get();
+    pk.m = m;
+    pk.transcript_label = (const uint8_t *)"harness";
+    pk.label_len = 7;
+    UploadPlan pb;
+    int code = 0;
+    uint32_t index = 0;
+    try {
+      upload_pass_a_packed(pk, pb, serial_for);
+      std::unique_ptr<uint8_t[]> bb(new uint8_t[pb.bytes_total + BPP_BYTES_SLACK]);
+      upload_pass_b_packed(pk, P64, pb, bb.get(), serial_for);
+    } catch (const ProofErr &e) {
+      code = e.code;
+      index = e.index;
+    }
+    EXPECT("packed_construction_error_lowest_index", code == BPP_ERR_INVALID_ARGUMENT && index == 9);
+  }
+  {  // seed nonces on the host side are wiped on both ways out (src/range_statement.rs:76-81): after a successful
+     // staging (plan + the seed range of the small staging buffer, nothing else of it) and after a failed plan
+    std::vector<Item> its;
+    for (int i = 0; i < 5; i++) its.push_back(make_item(1, 6, 1, 7, true, true));
+    std::vector<bpp_verify_item> v;
+    for (auto &i : its) v.push_back(i.view("harness"));
+    UploadPlan pl;
+    std::vector<uint8_t> st;
+    SmallStaging L;
+    bool staged_ok = false;
+    {
+      PlanWipe guard{pl};
+      upload_pass_a(v.data(), v.size(), pl);
+      std::unique_ptr<uint8_t[]> bytes(new uint8_t[pl.bytes_total + BPP_BYTES_SLACK]);
+      upload_pass_b(v.data(), P64, pl, bytes.get(), serial_for);
+      L = upload_small_layout(pl, v.size());
+      st.assign(L.total, 0xcc);
+      upload_fill_small(pl, pl.desc.data(), v.size(), st.data(), L);
+      staged_ok = L.n_seed == 5 * 32 && memcmp(st.data() + L.o_seed, its[0].seed.get(), 32) == 0 &&
+                  memcmp(st.data() + L.o_seed + 4 * 32, its[4].seed.get(), 32) == 0;
+      upload_wipe_small(st.data(), L);
+    }
+    bool zero = true;
+    for (size_t i = 0; i < L.n_seed; i++) zero = zero && st[L.o_seed + i] == 0;
+    for (uint8_t b : pl.seeds) zero = zero && b == 0;
+    EXPECT("seed_nonces_wiped_after_success", staged_ok && zero && pl.seeds.size() == 5 * 32 &&
+                                                  memcmp(st.data(), pl.desc.data(), sizeof(ProofDesc)) == 0);
+    // failure: item 3 does not parse; items 0..2 had their nonces copied into the plan already
+    its[3].proof[1 + 32 * 5 + 31] = 0xff;
+    UploadPlan pf;
+    int code = 0;
+    {
+      PlanWipe guard{pf};
+      try {
+        upload_pass_a(v.data(), v.size(), pf);
+        std::unique_ptr<uint8_t[]> bytes(new uint8_t[pf.bytes_total + BPP_BYTES_SLACK]);
+        upload_pass_b(v.data(), P64, pf, bytes.get(), serial_for);
+      } catch (const ProofErr &e) {
+        code = e.code;
+      }
+    }
+    bool fz = pf.seeds.size() == 5 * 32;
+    for (uint8_t b : pf.seeds) fz = fz && b == 0;
+    EXPECT("seed_nonces_wiped_after_failure", code == BPP_ERR_INVALID_ARGUMENT && fz);
+  }
   {  // the arithmetic probes under UBSan/ASan: field, scalar, point, merlin, blake2b, weight chain, recodings
     uint8_t a[64], b[32], o[32], o2[32];
     for (int iter = 0; iter < 200; iter++) {

@@ -1,4 +1,5 @@
-"""Sharding one reference batch across ranks (one process per GPU, torch.distributed; backend "nccl" = RCCL on ROCm).
+"""Sharding one reference batch across ranks: a thin caller of the C ABI (include/bpp.h: bpp_comm_*, bpp_verify_sharded,
+bpp_verify_sharded_wave).  One process per GPU; the collectives are RCCL calls on device buffers made by libbpp_hip.so.
 
 The path partitions by proof.  Two couplings exist in RangeProof::verify (src/range_proof.rs:756-1065):
   1. the batch weights come from ONE transcript over all proofs in order (:811,:849,:853,:894)
@@ -6,34 +7,140 @@ The path partitions by proof.  Two couplings exist in RangeProof::verify (src/ra
           keeps the weights of its own proofs;
   2. the final check is one group equation (:1050-1062)
        -> every rank reduces its proofs to ONE accumulator point; all_gather of the 128-byte accumulators
-          (RCCL has no group-law reduction), rank-local sum in rank order, identity test.
-`mode="shard"` instead treats each rank's proofs as an independent reference batch (what verify_batch's chunking
-does): no data-path collective, only the verdicts are combined.
+          (RCCL has no group-law reduction), the same sum on every rank, identity test.
+Errors: every rank reaches both collectives and every rank raises the same error, the one the single-process verify()
+would have hit first, decided by NUMERIC tier (bpp.h BPP_TIER_*) then rank -- the rule lives in the C library
+(csrc/upload_host.h: shard_local_trailer / shard_resolve) and is what `rehearse_sharded` below drives on CPU.
+
+torch.distributed is used here for one thing only: handing the 128-byte ncclUniqueId of rank 0 to the other ranks
+(any channel would do; a Rust caller uses its own).
 """
+import ctypes
+from ctypes import POINTER, byref, c_int, c_uint32, c_uint64, c_void_p
+
 import torch
 import torch.distributed as dist
 
-from . import api
+from . import _lib, api
+
+TRAILER = 128  # BPP_SHARD_TRAILER_BYTES
 
 
-class LocalEngineOps:
-    """phase interface of one rank, backed by the C ABI (bpp_verify_phase1/2, bpp_accumulators_sum_is_identity)"""
+class ShardComm:
+    """bpp_comm: one RCCL communicator + the staging of the two exchanges.  `engine` fixes the device."""
 
-    def __init__(self, resident_batch):
-        self.rb = resident_batch
+    def __init__(self, engine, rank, world, unique_id):
+        self.engine, self.rank, self.world, self.lib = engine, rank, world, engine.lib
+        self.handle = c_void_p()
+        rc = self.lib.bpp_comm_create(engine.ctx, _lib_buf(unique_id), rank, world, byref(self.handle))
+        api._check(rc, engine.ctx)
 
-    def phase1(self):
-        return self.rb.phase1()
+    @staticmethod
+    def unique_id():
+        out = (ctypes.c_uint8 * 128)()
+        rc = _lib.load().bpp_comm_unique_id(out)
+        if rc != 0:
+            raise api.EngineError("bpp_comm_unique_id failed (%d): RCCL not loadable" % rc)
+        return bytes(out)
 
-    def phase2(self, weights32):
-        return self.rb.phase2(weights32)
+    @classmethod
+    def from_process_group(cls, engine, group=None):
+        """collective over `group`: rank 0's ncclUniqueId travels through torch.distributed, then ncclCommInitRank"""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(engine, rank, world, box[0])
 
-    def sum_is_identity(self, accumulators128):
-        return api.accumulators_sum_is_identity(self.rb.engine, accumulators128)
+    def _err(self):
+        m = self.lib.bpp_comm_last_error(self.handle)
+        return m.decode(errors="replace") if m else ""
 
-    def verify_local(self):
-        self.rb.verify(api.VerifyAction.VerifyOnly, chunk=0)
+    def verify(self, rb, counts):
+        """bpp_verify_sharded: this rank's resident shard `rb` of ONE reference batch; counts[r] = proofs on rank r.
+        Returns True or raises the ProofError every rank raises."""
+        res = self.verify_wave([rb], counts)[0]
+        return _raise(res)
+
+    def verify_wave(self, rbs, counts):
+        """bpp_verify_sharded_wave over k resident shards (each on its OWN engine / stream) -> list of result dicts"""
+        k = len(rbs)
+        ctxs = (c_void_p * k)(*[rb.engine.ctx for rb in rbs])
+        hs = (c_uint64 * k)(*[rb.handle.value for rb in rbs])
+        cn = (c_uint32 * self.world)(*counts)
+        out = (_lib.ShardResult * k)()
+        rc = self.lib.bpp_verify_sharded_wave(self.handle, ctxs, hs, k, cn, out)
+        if rc != 0:
+            raise api.EngineError("bpp_verify_sharded_wave failed (%d): %s" % (rc, self._err()))
+        return [{"code": r.code, "tier": r.tier, "rank": r.rank, "index": r.index, "msg": r.msg.decode(errors="replace")} for r in out]
+
+    def close(self):
+        if self.handle:
+            self.lib.bpp_comm_destroy(self.handle)
+            self.handle = c_void_p()
+
+
+def _lib_buf(data):
+    return (ctypes.c_uint8 * len(data)).from_buffer_copy(data)
+
+
+def _raise(res):
+    if res["code"] == 0:
         return True
+    if res["code"] > 0:
+        e = api.ProofError(res["code"], res["msg"])
+        e.tier, e.rank, e.index = res["tier"], res["rank"], res["index"]
+        raise e
+    raise api.EngineError("bpp engine error %d: %s" % (res["code"], res["msg"]))
+
+
+def verify_shard_mode(rb, device, group=None):
+    """each rank's proofs as an independent reference batch (what verify_batch's chunking does): no
+    data-path collective, only the verdicts are combined"""
+    ok, err = 1, None
+    try:
+        rb.verify(api.VerifyAction.VerifyOnly, chunk=0)
+    except api.ProofError as e:
+        ok, err = 0, e
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if err is not None:
+        raise err
+    if int(flag.item()) == 0:
+        raise api.ProofError(api.ProofErrorKind.VerificationFailed, "Range proof batch not valid (another shard)")
+    return True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU rehearsal of the same protocol (tests/test_dist_gloo.py, world size 2 over gloo): the per-rank kernels need a GPU, so
+# a stand-in supplies their OUTPUTS (per-proof status words, RNG bytes, accumulator); everything that decides -- which
+# finding a rank reports, which one wins, the weight chain -- is the product's C code, and the transport is
+# torch.distributed instead of RCCL.  Not a product path: bpp_verify_sharded is.
+
+def local_trailer(defer, status, rounds_bad, first_index):
+    """bpp_shard_local_trailer: the engine's own order of checks over a rank's per-proof facts -> 128-byte finding"""
+    n = len(status)
+    out = (ctypes.c_uint8 * TRAILER)()
+    d = (ctypes.c_uint8 * max(n, 1))(*defer) if defer is not None else None
+    st = (c_uint32 * max(n, 1))(*status)
+    rb = (ctypes.c_uint8 * max(n, 1))(*rounds_bad)
+    rc = _lib.load().bpp_shard_local_trailer(d, st, rb, n, first_index, out)
+    assert rc == 0
+    return bytes(out)
+
+
+def fault_trailer(code, first_index, msg):
+    out = (ctypes.c_uint8 * TRAILER)()
+    assert _lib.load().bpp_shard_trailer(255, code, first_index, msg.encode()[:110], out) == 0
+    return bytes(out)
+
+
+def resolve(trailers):
+    """bpp_shard_resolve over the ranks' trailers -> result dict (code 0 = all clean)"""
+    world = len(trailers)
+    tier, rank, index = c_int(), c_int(), c_uint32()
+    err = ctypes.create_string_buffer(160)
+    code = _lib.load().bpp_shard_resolve(_lib_buf(b"".join(trailers)), TRAILER, world, byref(tier), byref(rank), byref(index), err, 160)
+    return {"code": code, "tier": tier.value, "rank": rank.value, "index": index.value, "msg": err.value.decode(errors="replace")}
 
 
 def _all_gather_bytes(data, device, group=None):
@@ -41,87 +148,42 @@ def _all_gather_bytes(data, device, group=None):
     world = dist.get_world_size(group)
     src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
     out = torch.empty(world * src.numel(), dtype=torch.uint8, device=device)
-    dist.all_gather_into_tensor(out, src, group=group) if device.type == "cuda" else \
-        dist.all_gather(list(out.chunk(world)), src, group=group)
+    dist.all_gather(list(out.chunk(world)), src, group=group)
     return out.cpu().numpy().tobytes()
 
 
-def verify_sharded(ops, n_local, device, mode="wide", group=None, weights_fn=api.weights_from_chain):
-    """Verify the union of all ranks' resident batches.  Returns True (valid) or raises api.ProofError.
-
-    ops: LocalEngineOps-like object for this rank's shard; every rank must hold the same number of proofs."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    if mode == "shard":
-        ok = 1
-        err = None
-        try:
-            ops.verify_local()
-        except api.ProofError as e:
-            ok, err = 0, e
-        flag = torch.tensor([ok], dtype=torch.int32, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if err is not None:
-            raise err
-        if int(flag.item()) == 0:
-            raise api.ProofError(api.ProofErrorKind.VerificationFailed, "Range proof batch not valid (another shard)")
-        return True
-    # ---- wide: one reference batch over all ranks ----
-    # Every rank enters BOTH collectives whatever happens locally: a rank whose phase raised sends a placeholder plus a
-    # 32-byte status trailer, and all ranks raise the same error afterwards (a rank that raised before the all_gather
-    # would leave the others blocked in it, or -- if the caller carried on -- pair collectives of different batches).
-    err = None
+def rehearse_sharded(ops, n_local, device, group=None, weights_fn=api.weights_from_chain):
+    """the two exchanges of bpp_verify_sharded with `ops` standing in for the kernels:
+         ops.phase1_facts() -> (rng bytes, defer | None, status words, rounds_bad)     ops.phase2(weights32) -> 128-byte accumulator
+         ops.sum_is_identity(accumulators128) -> bool
+    Whatever a rank's stand-in raises, the rank still reaches both collectives (an engine-fault finding travels instead)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    first = n_local * rank
     try:
-        rng_local = ops.phase1()
+        rng_local, defer, status, rounds_bad = ops.phase1_facts()
         assert len(rng_local) == 32 * n_local
-    except api.ProofError as e:
-        err, rng_local = e, bytes(32 * n_local)
-    gathered = _all_gather_bytes(rng_local + _status_trailer(err), device, group)
-    stride = 32 * n_local + 32
-    _raise_first([gathered[stride * r + 32 * n_local:stride * (r + 1)] for r in range(world)])
+        tr = local_trailer(defer, status, rounds_bad, first)
+    except Exception as e:  # noqa: BLE001 - anything at all: the collective below must still be entered
+        rng_local, tr = bytes(32 * n_local), fault_trailer(-1, first, "%s: %s" % (type(e).__name__, e))
+    stride = 32 * n_local + TRAILER
+    gathered = _all_gather_bytes(rng_local + tr, device, group)
+    res = resolve([gathered[stride * r + 32 * n_local:stride * (r + 1)] for r in range(world)])
+    if res["code"] != 0:
+        return _raise(res)
     rng_all = b"".join(gathered[stride * r:stride * r + 32 * n_local] for r in range(world))
     weights_all = weights_fn(rng_all)  # sequential sponge: replayed by every rank, no broadcast needed
+    fault = 0
     try:
         acc = ops.phase2(weights_all[32 * n_local * rank:32 * n_local * (rank + 1)])
         assert len(acc) == 128
-    except api.ProofError as e:
-        err, acc = e, bytes(128)
-    accs = _all_gather_bytes(acc + _status_trailer(err), device, group)
-    assert len(accs) == 160 * world
-    _raise_first([accs[160 * r + 128:160 * (r + 1)] for r in range(world)])
-    if not ops.sum_is_identity(b"".join(accs[160 * r:160 * r + 128] for r in range(world))):
-        raise api.ProofError(api.ProofErrorKind.VerificationFailed, "Range proof batch not valid")
+    except Exception:  # noqa: BLE001
+        acc, fault = bytes(128), 1
+    accs = _all_gather_bytes(acc + bytes([fault]) + bytes(15), device, group)
+    for r in range(world):
+        if accs[144 * r + 128]:
+            raise api.EngineError("bpp engine error -1: engine fault (rank %d)" % r)
+    if not ops.sum_is_identity(b"".join(accs[144 * r:144 * r + 128] for r in range(world))):
+        e = api.ProofError(api.ProofErrorKind.VerificationFailed, "Range proof batch not valid")
+        e.tier, e.rank, e.index = 7, -1, 0
+        raise e
     return True
-
-
-def _tier(err):
-    """position of the failing check inside RangeProof::verify (src/range_proof.rs:756-1065): the consistency loops
-    (:637-659 degree, :674-682 promises), statement points, PASS 1 over ALL proofs (:816-850), then PASS 2 in proof order"""
-    if "Inconsistent extension degree" in err.msg:
-        return 0
-    if "Minimum value promise" in err.msg:
-        return 1
-    if "Statement commitment" in err.msg:
-        return 2
-    if err.kind == api.ProofErrorKind.VerificationFailed:
-        return 3
-    return 4
-
-
-def _status_trailer(err):
-    """32 bytes: [0] = 0 ok / 1 + tier, [1] = ProofError kind, [2] = message length, [3..] message"""
-    if err is None:
-        return bytes(32)
-    msg = err.msg.encode()[:29]
-    return (bytes([1 + _tier(err), int(err.kind), len(msg)]) + msg).ljust(32, b"\0")
-
-
-def _raise_first(trailers):
-    """the error the single-process verify() would have hit first: lowest tier, then lowest rank (shards are contiguous
-    in proof order); identical on every rank"""
-    failed = [(t[0], r) for r, t in enumerate(trailers) if t[0]]
-    if not failed:
-        return
-    _, r = min(failed)
-    t = trailers[r]
-    raise api.ProofError(t[1], t[3:3 + t[2]].decode(errors="replace") + " (rank %d)" % r)

@@ -94,10 +94,91 @@ def prove(params, values, blindings, commitments, min_values, min_present, seed_
     return out
 
 
-class ResidentBatch(api.ResidentBatch):
-    """api.ResidentBatch (bpp_batch_upload / bpp_verify_resident / traces) uploaded from arrays"""
+class PackedInput:
+    """A homogeneous batch as contiguous arrays + the bpp_packed_batch that describes it (include/bpp.h).  Holds the
+    arrays alive; `.struct` can be passed to any *_packed entry point any number of times."""
 
-    def __init__(self, params, proofs, commitments, min_values, min_present, seed_nonces, label):
+    def __init__(self, proofs, commitments, min_values, min_present, seed_nonces, label, seed_present=None, state=None):
+        self.proofs = np.ascontiguousarray(proofs, dtype=np.uint8)
+        n, plen = self.proofs.shape
+        commitments = np.ascontiguousarray(commitments, dtype=np.uint8)
+        m = commitments.shape[1]
+        self.commitments = _c(commitments, np.uint8, (n, m, 32))
+        self.min_values = None if min_values is None else _c(min_values, np.uint64, (n, m))
+        self.min_present = None if min_present is None else _c(min_present, np.uint8, (n, m))
+        self.seed_nonces = None if seed_nonces is None else _c(seed_nonces, np.uint8, (n, 32))
+        self.seed_present = None if seed_present is None else _c(seed_present, np.uint8, (n,))
+        self.label = np.frombuffer(bytes(label), dtype=np.uint8).copy() if len(label) else np.zeros(1, dtype=np.uint8)
+        self.state = None if state is None else np.frombuffer(bytes(state), dtype=np.uint8).copy()
+        self.n, self.m = n, m
+        ptr = lambda a: None if a is None else a.ctypes.data  # noqa: E731
+        self.struct = _lib.PackedBatch(n, ptr(self.proofs), plen, self.proofs.strides[0], ptr(self.commitments), m,
+                                       ptr(self.min_values), ptr(self.min_present), ptr(self.seed_nonces),
+                                       ptr(self.seed_present), ptr(self.state), ptr(self.label), len(label))
+
+
+def verify_batch(params, inp, action=api.VerifyAction.VerifyOnly, chunk=api.MAX_RANGE_PROOF_BATCH_SIZE):
+    """RangeProof::verify_batch over a PackedInput in ONE C call (bpp_verify_batch_packed: upload, verify, release).
+    Returns (masks uint8 [n, t, 32], present uint8 [n])."""
+    eng, t = params.engine, int(params.extension_degree())
+    masks = np.zeros((inp.n, t, 32), dtype=np.uint8)
+    present = np.zeros(inp.n, dtype=np.uint8)
+    err = ctypes.create_string_buffer(256)
+    rc = eng.lib.bpp_verify_batch_packed(eng.ctx, params.handle, byref(inp.struct), int(action), chunk, masks.ctypes.data,
+                                         present.ctypes.data, err, 256)
+    api._check(rc, eng.ctx, err)
+    return masks, present
+
+
+class Pipeline:
+    """bpp_verify_submit_packed / bpp_verify_collect on one engine: upload k+1 overlaps verify k inside ONE context"""
+
+    def __init__(self, params, depth=None):
+        self.params, self.engine, self.t = params, params.engine, int(params.extension_degree())
+        if depth is not None:
+            api._check(self.engine.lib.bpp_ctx_pipeline_depth(self.engine.ctx, int(depth)), self.engine.ctx)
+        self._n = {}
+
+    def submit(self, inp, action=api.VerifyAction.VerifyOnly, chunk=api.MAX_RANGE_PROOF_BATCH_SIZE):
+        ticket = c_uint64()
+        err = ctypes.create_string_buffer(256)
+        rc = self.engine.lib.bpp_verify_submit_packed(self.engine.ctx, self.params.handle, byref(inp.struct), int(action), chunk,
+                                                      byref(ticket), err, 256)
+        api._check(rc, None, err)
+        self._n[ticket.value] = (inp.n, int(action))
+        return ticket.value
+
+    def collect(self, ticket):
+        n, action = self._n.pop(ticket)
+        err = ctypes.create_string_buffer(256)
+        if action == int(api.VerifyAction.VerifyOnly):
+            api._check(self.engine.lib.bpp_verify_collect(self.engine.ctx, ticket, None, None, err, 256), None, err)
+            return None, None
+        masks = np.zeros((n, self.t, 32), dtype=np.uint8)
+        present = np.zeros(n, dtype=np.uint8)
+        api._check(self.engine.lib.bpp_verify_collect(self.engine.ctx, ticket, masks.ctypes.data, present.ctypes.data, err, 256),
+                   None, err)
+        return masks, present
+
+
+class ResidentBatch(api.ResidentBatch):
+    """api.ResidentBatch (bpp_batch_upload / bpp_verify_resident / traces) uploaded from arrays.  form="packed": through
+    bpp_batch_upload_packed (one bpp_packed_batch, no per-item structs); form="items": a bpp_verify_item array built with
+    numpy pointer arithmetic.  Both end in the same resident batch (tests/test_gpu_packed.py)."""
+
+    def __init__(self, params, proofs, commitments, min_values, min_present, seed_nonces, label, form="packed"):
+        self.params, self.engine, self.t = params, params.engine, int(params.extension_degree())
+        self.handle = c_uint64()
+        err = ctypes.create_string_buffer(256)
+        if form == "packed":
+            t0 = time.perf_counter()
+            inp = PackedInput(proofs, commitments, min_values, min_present, seed_nonces, label)
+            self.n = inp.n
+            t1 = time.perf_counter()
+            rc = self.engine.lib.bpp_batch_upload_packed(self.engine.ctx, params.handle, byref(inp.struct), byref(self.handle), err, 256)
+            api._check(rc, self.engine.ctx, err)
+            self.marshal_seconds, self.upload_seconds = t1 - t0, time.perf_counter() - t1
+            return
         t0 = time.perf_counter()
         proofs = np.ascontiguousarray(proofs, dtype=np.uint8)
         n, plen = proofs.shape
@@ -120,9 +201,7 @@ class ResidentBatch(api.ResidentBatch):
         items["transcript_label"] = lbl.ctypes.data
         items["label_len"] = len(label)
         t1 = time.perf_counter()
-        self.params, self.engine, self.n, self.t = params, params.engine, n, int(params.extension_degree())
-        self.handle = c_uint64()
-        err = ctypes.create_string_buffer(256)
+        self.n = n
         rc = self.engine.lib.bpp_batch_upload(self.engine.ctx, params.handle, items.ctypes.data_as(POINTER(_lib.VerifyItem)), n,
                                               byref(self.handle), err, 256)
         api._check(rc, self.engine.ctx, err)

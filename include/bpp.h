@@ -39,6 +39,19 @@ extern "C" {
 #define BPP_ERR_ENGINE (-1)    /* HIP runtime error, see bpp_ctx_last_error */
 #define BPP_ERR_NO_DEVICE (-2) /* no usable gfx950 device */
 #define BPP_ERR_BAD_HANDLE (-3)
+#define BPP_ERR_COMM (-4)      /* RCCL failure (library missing, communicator error): sharded entry points only */
+
+/* Where inside RangeProof::verify (src/range_proof.rs:756-1065) a check failed.  Lower = earlier in the reference's order
+ * of checks; shards of one reference batch combine their findings by (tier, rank) -- see bpp_verify_sharded. */
+#define BPP_TIER_NONE 0
+#define BPP_TIER_CONSTRUCTION 1     /* RangeStatement::init / RangeProof::from_bytes: before verify() is entered */
+#define BPP_TIER_DEGREE 2           /* extension degree of every item (:637-659) */
+#define BPP_TIER_PROMISE 3          /* minimum-value promises (:674-682) */
+#define BPP_TIER_STATEMENT_POINT 4  /* a commitment does not decode (a RangeStatement holds points) */
+#define BPP_TIER_PASS1 5            /* transcript replay of ANY proof (:816-850) */
+#define BPP_TIER_PASS2 6            /* per proof, in proof order: decompression, L/R count (:859-888) */
+#define BPP_TIER_MSM 7              /* the final multiscalar check (:1057-1062) */
+#define BPP_TIER_ENGINE 255         /* an engine fault (negative code) on some rank */
 
 /* VerifyAction (src/range_proof.rs:46-54) */
 #define BPP_VERIFY_ONLY 0
@@ -142,6 +155,45 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
  * the allocation of every work buffer of that plan (~15 hipMallocs) -- so that no verification call pays for it */
 int bpp_batch_prepare(bpp_ctx *ctx, uint64_t batch, size_t chunk);
 
+/* ---- packed form of a homogeneous batch: what a caller of RangeProof::verify_batch(&[Transcript], &[RangeStatement],
+ * &[RangeProof]) (src/range_proof.rs:712-717) holding statements and proofs of ONE shape serialises them into -- no
+ * per-item pointer structs.  All proofs have the same length, all statements the same aggregation factor, one transcript
+ * serves every item (benches/range_proof.rs:98, tests/ristretto.rs:225).  Same checks, same error kinds and precedence as
+ * the item form (one routine checks both); results are bit-identical (tests/test_gpu_packed.py). */
+typedef struct {
+  size_t n_items;
+  const uint8_t *proofs;           /* proof i = RangeProof::to_bytes() at proofs + i * proof_stride */
+  size_t proof_len;                /* length of every proof */
+  size_t proof_stride;             /* >= proof_len; == proof_len when the proofs lie back to back */
+  const uint8_t *commitments32;    /* n_items x m x 32 */
+  uint32_t m;                      /* aggregation factor of every statement */
+  const uint64_t *min_values;      /* n_items x m */
+  const uint8_t *min_present;      /* n_items x m, Option<u64>::is_some; NULL = all None */
+  const uint8_t *seed_nonces32;    /* n_items x 32; NULL = all None */
+  const uint8_t *seed_present;     /* n_items; NULL = every item has a nonce (when seed_nonces32 != NULL) */
+  const uint8_t *transcript_state; /* 203-byte STROBE state, or NULL: Transcript::new(transcript_label) */
+  const uint8_t *transcript_label;
+  size_t label_len;
+} bpp_packed_batch;
+int bpp_batch_upload_packed(bpp_ctx *ctx, uint64_t params, const bpp_packed_batch *in, uint64_t *batch, char *errbuf,
+                            size_t errbuf_len);
+int bpp_verify_batch_packed(bpp_ctx *ctx, uint64_t params, const bpp_packed_batch *in, int action, size_t chunk,
+                            uint8_t *masks_out, uint8_t *mask_present, char *errbuf, size_t errbuf_len);
+
+/* Pipelined host-buffers-in verification inside ONE context.  submit parses, validates and packs `in` into page-locked
+ * staging on the calling thread (construction errors are returned by submit itself, as RangeStatement::init /
+ * RangeProof::from_bytes would raise them before verify_batch is entered) and returns; the caller's buffers are free again.
+ * DMA, kernels and the weight chain of that call then run on one of the context's `depth` internal lanes (own stream, own
+ * staging, own work buffers; default depth 3, bpp_ctx_pipeline_depth before the first submit changes it) while the caller
+ * submits the next batch: upload k+1 overlaps verify k.  collect blocks until the ticket's call is done and returns exactly
+ * what bpp_verify_batch_packed would have returned.  Tickets may be collected in any order; every ticket must be collected
+ * (bpp_ctx_destroy waits for the ones in flight).  submit blocks while all lanes are busy. */
+int bpp_ctx_pipeline_depth(bpp_ctx *ctx, uint32_t depth);
+int bpp_verify_submit_packed(bpp_ctx *ctx, uint64_t params, const bpp_packed_batch *in, int action, size_t chunk,
+                             uint64_t *ticket, char *errbuf, size_t errbuf_len);
+int bpp_verify_collect(bpp_ctx *ctx, uint64_t ticket, uint8_t *masks_out, uint8_t *mask_present, char *errbuf,
+                       size_t errbuf_len);
+
 /* ---- phased form of the same verification, for sharding one reference batch across GPUs ----
  * phase1: PASS 1 of verify (src/range_proof.rs:816-850) for this rank's proofs -> the 32 transcript-RNG bytes per
  *         proof that feed the weight transcript (:845-849).
@@ -161,6 +213,60 @@ int bpp_weights_from_chains(const uint8_t *rng32_all, size_t n_groups, size_t n_
 int bpp_verify_phase2(bpp_ctx *ctx, uint64_t batch, const uint8_t *weights32 /* n_items x 32 */,
                       uint8_t accumulator128[128], char *errbuf, size_t errbuf_len);
 int bpp_accumulators_sum_is_identity(bpp_ctx *ctx, const uint8_t *accumulators128, size_t n, int *is_identity);
+
+/* ---- ONE reference batch sharded over the GPUs of a node, behind the C ABI (BASELINE configs[3]) ----
+ * One process (or thread) per GPU; rank r holds `counts[r]` consecutive proofs of the batch as a resident batch on its own
+ * context.  bpp_verify_sharded runs RangeProof::verify (src/range_proof.rs:756-1065) over the union:
+ *   PASS 1 + decompression + weight-free scalars on every rank's own proofs
+ *   -> RCCL all_gather of the 32 transcript-RNG bytes per proof (device buffers, no host hop) + one 128-byte finding per rank
+ *   -> the batch-weight transcript (:811,:849,:853,:894) replayed by every rank over ALL proofs in order (a sequential
+ *      sponge: cheaper to replay than to broadcast), each rank keeps the weights of its own proofs
+ *   -> PASS 2 + the rank's share of the final MSM (:1050) -> one accumulator point per rank
+ *   -> RCCL all_gather of the 128-byte accumulators (RCCL has no group-law reduction, so the north star's "all-reduce of
+ *      the accumulator" is gather + the same sum on every rank), sum and identity test (:1057) on the device.
+ * EVERY rank reaches both collectives whatever it found locally, and every rank returns the same result: the error the
+ * single-process verify() would have raised first, decided by numeric tier (BPP_TIER_*), then lowest rank.
+ * Return value: 0 Ok, 1..5 ProofError kind (same on every rank), BPP_ERR_COMM when RCCL fails (library missing,
+ * communicator error: the communicator must then be destroyed), other negatives = engine fault on some rank.
+ * VerifyOnly semantics (masks are per proof and need no exchange: recover them with bpp_verify_resident on the shard).
+ *
+ * Communicators: bpp_comm_unique_id (rank 0) -> the caller ships the 128 bytes to the other ranks over its own channel ->
+ * bpp_comm_create on every rank (ncclCommInitRank: collective); or bpp_comm_adopt of an ncclComm_t the caller already
+ * has.  A communicator serialises its own calls; use one per thread that verifies concurrently. */
+typedef struct bpp_comm bpp_comm;
+int bpp_comm_unique_id(uint8_t id128[128]);
+int bpp_comm_create(bpp_ctx *ctx, const uint8_t id128[128], int rank, int world, bpp_comm **out);
+int bpp_comm_adopt(bpp_ctx *ctx, void *nccl_comm, int rank, int world, bpp_comm **out);
+void bpp_comm_destroy(bpp_comm *comm);
+const char *bpp_comm_last_error(bpp_comm *comm);
+int bpp_verify_sharded(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, const uint32_t *counts /* world entries */,
+                       int *tier_out, int *rank_out, char *errbuf, size_t errbuf_len);
+/* A WAVE of k independent sharded batches (batch i resident on ctxs[i], every rank passes its shards of the same k batches
+ * in the same order, all with the same `counts`): their PASS-1 work runs concurrently on the k contexts' streams, ONE
+ * coalesced all_gather carries the RNG bytes of all k, the k weight chains run side by side on the host pool, ONE all_gather
+ * carries the k accumulators.  results[i] receives batch i's outcome (code as bpp_verify_sharded returns it, tier, rank,
+ * message).  Return value: 0 = the wave ran (look at results), BPP_ERR_COMM / negative = the wave itself failed. */
+typedef struct {
+  int code, tier, rank;
+  uint32_t index;       /* position in the whole batch of the proof the finding belongs to (tiers checked per proof) */
+  char msg[160];
+} bpp_shard_result;
+int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t *batches, size_t k, const uint32_t *counts,
+                            bpp_shard_result *results);
+/* host-only pieces of the above, exported for callers that bring their own transport and for the CPU tests
+ * (tests/test_dist_gloo.py): the 128-byte finding a rank contributes, and the rule every rank applies to the gathered ones.
+ *   bpp_shard_local_trailer: first finding of a rank's n proofs from the per-proof facts -- defer[i] (bit 0: extension
+ *     degree differs, bit 1: promise too large; may be NULL), status[i] (bit 0 PASS-1 failure, bit 1 proof point does not
+ *     decode, bit 2 commitment does not decode), rounds_bad[i] (0, 3 = InvalidLength, 5 = SizeOverflow) -- in the
+ *     reference's order of checks; first_index = position of the rank's first proof in the whole batch
+ *   bpp_shard_trailer: a finding given directly (tier, code, index, message)
+ *   bpp_shard_resolve: trailer of rank r at trailers + r * stride -> the winning finding; returns its code (0: all clean) */
+#define BPP_SHARD_TRAILER_BYTES 128
+int bpp_shard_local_trailer(const uint8_t *defer, const uint32_t *status, const uint8_t *rounds_bad, uint32_t n,
+                            uint32_t first_index, uint8_t trailer_out[BPP_SHARD_TRAILER_BYTES]);
+int bpp_shard_trailer(int tier, int code, uint32_t index, const char *msg, uint8_t trailer_out[BPP_SHARD_TRAILER_BYTES]);
+int bpp_shard_resolve(const uint8_t *trailers, size_t stride, int world, int *tier_out, int *rank_out, uint32_t *index_out,
+                      char *errbuf, size_t errbuf_len);
 
 /* ---- B2: batch prover = RangeProof::prove_with_rng (src/range_proof.rs:232-608), one call for n independent proofs ----
  * Every item is one (statement, witness, transcript, rng) quadruple of the reference API:
@@ -231,6 +337,12 @@ int bpp_host_threads(void);
  * verifier's load the chip holds 2.0-2.2 GHz, not the 2.4 GHz of a light kernel: issue-rate peaks have to be priced at
  * the clock measured (bench.py reports it as shader_clock_ghz). */
 int bpp_shader_clock(bpp_ctx *ctx, uint32_t window_us, double *ghz);
+
+/* diagnostics (tests/test_gpu_round3.py): number of non-zero bytes in the device copies of the secrets a resident batch
+ * holds -- the statements' seed nonces and the recovered masks (zeroized on drop by the reference: src/range_statement.rs:76-81,
+ * src/extended_mask.rs:14).  batch == 0 looks at the buffers the context kept from the last destroyed batch, which the
+ * next upload will adopt: must read 0. */
+int bpp_batch_secret_bytes(bpp_ctx *ctx, uint64_t batch, uint64_t *nonzero);
 
 /* Transcript::new(label) -> 203-byte STROBE state (host helper for callers that keep merlin on their side) */
 int bpp_transcript_new(const uint8_t *label, size_t label_len, uint8_t state203[203]);

@@ -16,6 +16,18 @@ pub const BPP_ERR_SIZE_OVERFLOW: c_int = 5;
 pub const BPP_ERR_ENGINE: c_int = -1;
 pub const BPP_ERR_NO_DEVICE: c_int = -2;
 pub const BPP_ERR_BAD_HANDLE: c_int = -3;
+pub const BPP_ERR_COMM: c_int = -4;
+// where inside RangeProof::verify a check failed (src/range_proof.rs:756-1065): orders findings across shards
+pub const BPP_TIER_NONE: c_int = 0;
+pub const BPP_TIER_CONSTRUCTION: c_int = 1;
+pub const BPP_TIER_DEGREE: c_int = 2;
+pub const BPP_TIER_PROMISE: c_int = 3;
+pub const BPP_TIER_STATEMENT_POINT: c_int = 4;
+pub const BPP_TIER_PASS1: c_int = 5;
+pub const BPP_TIER_PASS2: c_int = 6;
+pub const BPP_TIER_MSM: c_int = 7;
+pub const BPP_TIER_ENGINE: c_int = 255;
+pub const BPP_SHARD_TRAILER_BYTES: usize = 128;
 pub const BPP_REFERENCE_CHUNK: usize = 256;
 
 /// bpp_verify_item: one (transcript, statement, proof) triple of `RangeProof::verify_batch` (src/range_proof.rs:712-717)
@@ -48,6 +60,40 @@ pub struct bpp_prove_item {
     pub label_len: usize,
     pub rng_bytes: *const u8,
     pub rng_len: usize,
+}
+
+/// bpp_packed_batch: a homogeneous batch (`&[RangeStatement]`, `&[RangeProof]` of one shape) as contiguous arrays
+#[repr(C)]
+pub struct bpp_packed_batch {
+    pub n_items: usize,
+    pub proofs: *const u8,
+    pub proof_len: usize,
+    pub proof_stride: usize,
+    pub commitments32: *const u8,
+    pub m: u32,
+    pub min_values: *const u64,
+    pub min_present: *const u8,
+    pub seed_nonces32: *const u8,
+    pub seed_present: *const u8,
+    pub transcript_state: *const u8,
+    pub transcript_label: *const u8,
+    pub label_len: usize,
+}
+
+#[repr(C)]
+pub struct bpp_comm {
+    _p: [u8; 0],
+}
+
+/// outcome of one batch of a sharded wave (bpp_verify_sharded_wave)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct bpp_shard_result {
+    pub code: c_int,
+    pub tier: c_int,
+    pub rank: c_int,
+    pub index: u32,
+    pub msg: [c_char; 160],
 }
 
 #[repr(C)]
@@ -116,7 +162,32 @@ extern "C" {
     pub fn bpp_batch_prepare(ctx: *mut bpp_ctx, batch: u64, chunk: usize) -> c_int;
     pub fn bpp_verify_resident(ctx: *mut bpp_ctx, batch: u64, action: c_int, chunk: usize, masks_out: *mut u8, mask_present: *mut u8,
                                errbuf: *mut c_char, errbuf_len: usize) -> c_int;
-    // sharded form (one reference batch over several GPUs)
+    // packed form + pipelined host-buffers-in form (upload k+1 overlaps verify k inside one context)
+    pub fn bpp_batch_upload_packed(ctx: *mut bpp_ctx, params: u64, input: *const bpp_packed_batch, batch: *mut u64, errbuf: *mut c_char,
+                                   errbuf_len: usize) -> c_int;
+    pub fn bpp_verify_batch_packed(ctx: *mut bpp_ctx, params: u64, input: *const bpp_packed_batch, action: c_int, chunk: usize,
+                                   masks_out: *mut u8, mask_present: *mut u8, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    pub fn bpp_ctx_pipeline_depth(ctx: *mut bpp_ctx, depth: u32) -> c_int;
+    pub fn bpp_verify_submit_packed(ctx: *mut bpp_ctx, params: u64, input: *const bpp_packed_batch, action: c_int, chunk: usize,
+                                    ticket: *mut u64, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    pub fn bpp_verify_collect(ctx: *mut bpp_ctx, ticket: u64, masks_out: *mut u8, mask_present: *mut u8, errbuf: *mut c_char,
+                              errbuf_len: usize) -> c_int;
+    // ONE reference batch sharded over the GPUs of a node: RCCL all_gathers on device buffers inside the library
+    pub fn bpp_comm_unique_id(id128: *mut u8) -> c_int;
+    pub fn bpp_comm_create(ctx: *mut bpp_ctx, id128: *const u8, rank: c_int, world: c_int, out: *mut *mut bpp_comm) -> c_int;
+    pub fn bpp_comm_adopt(ctx: *mut bpp_ctx, nccl_comm: *mut c_void, rank: c_int, world: c_int, out: *mut *mut bpp_comm) -> c_int;
+    pub fn bpp_comm_destroy(comm: *mut bpp_comm);
+    pub fn bpp_comm_last_error(comm: *mut bpp_comm) -> *const c_char;
+    pub fn bpp_verify_sharded(comm: *mut bpp_comm, ctx: *mut bpp_ctx, batch: u64, counts: *const u32, tier_out: *mut c_int,
+                              rank_out: *mut c_int, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    pub fn bpp_verify_sharded_wave(comm: *mut bpp_comm, ctxs: *const *mut bpp_ctx, batches: *const u64, k: usize, counts: *const u32,
+                                   results: *mut bpp_shard_result) -> c_int;
+    pub fn bpp_shard_local_trailer(defer: *const u8, status: *const u32, rounds_bad: *const u8, n: u32, first_index: u32,
+                                   trailer_out: *mut u8) -> c_int;
+    pub fn bpp_shard_trailer(tier: c_int, code: c_int, index: u32, msg: *const c_char, trailer_out: *mut u8) -> c_int;
+    pub fn bpp_shard_resolve(trailers: *const u8, stride: usize, world: c_int, tier_out: *mut c_int, rank_out: *mut c_int,
+                             index_out: *mut u32, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    // phased form of the same (callers that bring their own transport)
     pub fn bpp_verify_phase1(ctx: *mut bpp_ctx, batch: u64, rng_out32: *mut u8, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
     pub fn bpp_weights_from_chain(rng32_all: *const u8, n_total: usize, weights32_out: *mut u8) -> c_int;
     pub fn bpp_weights_from_chains(rng32_all: *const u8, n_groups: usize, n_per_group: usize, weights32_out: *mut u8) -> c_int;
@@ -135,4 +206,6 @@ extern "C" {
     pub fn bpp_prove_profile_get(ctx: *mut bpp_ctx, out: *mut bpp_prove_profile) -> c_int;
     pub fn bpp_host_threads() -> c_int;
     pub fn bpp_transcript_new(label: *const u8, label_len: usize, state203: *mut u8) -> c_int;
+    pub fn bpp_batch_secret_bytes(ctx: *mut bpp_ctx, batch: u64, nonzero: *mut u64) -> c_int;
+    pub fn bpp_shader_clock(ctx: *mut bpp_ctx, window_us: u32, ghz: *mut f64) -> c_int;
 }

@@ -7,7 +7,7 @@
 pub mod ffi;
 
 use core::ffi::c_int;
-use std::{ffi::CStr, ptr, sync::Mutex};
+use std::{collections::HashMap, ffi::CStr, ptr, sync::{Arc, Mutex, OnceLock}};
 
 /// Mirror of `tari_bulletproofs_plus::errors::ProofError` (src/errors.rs:11-28) plus engine faults.
 #[derive(Debug, Clone, PartialEq, Eq)]
@@ -60,7 +60,9 @@ impl Engine {
         unsafe { CStr::from_ptr(ffi::bpp_ctx_last_error(self.ctx)).to_string_lossy().into_owned() }
     }
 
-    /// RangeParameters::init (src/range_parameters.rs:32-58); `h_base` / `g_bases` = None: the reference's defaults
+    /// RangeParameters::init (src/range_parameters.rs:32-58); `h_base` / `g_bases` = None: the reference's defaults.
+    /// Derives the generators and builds the device tables: expensive (milliseconds).  Callers go through
+    /// `cached_params`, which does it once per parameter set and process.
     pub fn params(&self, bit_length: usize, max_aggregation: usize, extension_degree: usize, h_base: Option<&[u8; 32]>,
                   g_bases: Option<&[u8]>) -> Result<Params, GpuError> {
         let mut handle = 0u64;
@@ -69,7 +71,64 @@ impl Engine {
                                    h_base.map_or(ptr::null(), |h| h.as_ptr()), g_bases.map_or(ptr::null(), |g| g.as_ptr()), &mut handle)
         };
         map_rc(rc, self.last_error())?;
-        Ok(Params { handle, extension_degree })
+        Ok(Params { handle, extension_degree, owner: self.ctx })
+    }
+
+    /// `RangeProof::verify_batch` over a homogeneous batch handed over as contiguous arrays (bpp_verify_batch_packed): what
+    /// the in-crate patch uses whenever all statements share the aggregation factor and all proofs the length.
+    pub fn verify_batch_packed(&self, params: &Params, input: &PackedBatch<'_>, action: Action, chunk: usize)
+                               -> Result<Vec<Option<Vec<[u8; 32]>>>, GpuError> {
+        let t = params.extension_degree;
+        let raw = input.raw();
+        let mut masks = vec![0u8; input.n_items * t * 32];
+        let mut present = vec![0u8; input.n_items];
+        let mut err = [0 as core::ffi::c_char; 256];
+        let rc = unsafe {
+            ffi::bpp_verify_batch_packed(self.ctx, params.handle, &raw, action as c_int, chunk, masks.as_mut_ptr(), present.as_mut_ptr(),
+                                         err.as_mut_ptr(), err.len())
+        };
+        let out = map_rc(rc, unsafe { CStr::from_ptr(err.as_ptr()) }.to_string_lossy().into_owned()).map(|_| unpack_masks(&masks, &present, t));
+        masks.iter_mut().for_each(|b| *b = 0); // recovered masks are secrets (src/extended_mask.rs:14)
+        out
+    }
+
+    /// Pipelined form: returns at once with a ticket; `collect` blocks for the verdict.  Upload k+1 overlaps verify k
+    /// inside this one context (bpp_verify_submit_packed / bpp_verify_collect).
+    pub fn submit_packed(&self, params: &Params, input: &PackedBatch<'_>, action: Action, chunk: usize) -> Result<Ticket, GpuError> {
+        let raw = input.raw();
+        let mut ticket = 0u64;
+        let mut err = [0 as core::ffi::c_char; 256];
+        let rc = unsafe {
+            ffi::bpp_verify_submit_packed(self.ctx, params.handle, &raw, action as c_int, chunk, &mut ticket, err.as_mut_ptr(), err.len())
+        };
+        map_rc(rc, unsafe { CStr::from_ptr(err.as_ptr()) }.to_string_lossy().into_owned())?;
+        Ok(Ticket { id: ticket, n_items: input.n_items, t: params.extension_degree })
+    }
+
+    pub fn collect(&self, ticket: Ticket) -> Result<Vec<Option<Vec<[u8; 32]>>>, GpuError> {
+        let mut masks = vec![0u8; ticket.n_items * ticket.t * 32];
+        let mut present = vec![0u8; ticket.n_items];
+        let mut err = [0 as core::ffi::c_char; 256];
+        let rc = unsafe { ffi::bpp_verify_collect(self.ctx, ticket.id, masks.as_mut_ptr(), present.as_mut_ptr(), err.as_mut_ptr(), err.len()) };
+        let out = map_rc(rc, unsafe { CStr::from_ptr(err.as_ptr()) }.to_string_lossy().into_owned()).map(|_| unpack_masks(&masks, &present, ticket.t));
+        masks.iter_mut().for_each(|b| *b = 0);
+        out
+    }
+
+    /// This rank's shard of ONE reference batch spread over `counts.len()` GPUs: uploads `input` (counts[rank] proofs) and
+    /// runs bpp_verify_sharded on `comm`.  Every rank returns the same result; `ShardError` carries the numeric tier.
+    pub fn verify_sharded(&self, comm: &ShardComm, params: &Params, input: &PackedBatch<'_>, counts: &[u32]) -> Result<(), ShardError> {
+        let raw = input.raw();
+        let mut batch = 0u64;
+        let mut err = [0 as core::ffi::c_char; 256];
+        let up = unsafe { ffi::bpp_batch_upload_packed(self.ctx, params.handle, &raw, &mut batch, err.as_mut_ptr(), err.len()) };
+        // NOTE: a construction error here is rank-local: the caller must still let the other ranks know (they would wait in
+        // the first all_gather).  RangeStatement / RangeProof objects that exist have passed these checks already.
+        map_rc(up, unsafe { CStr::from_ptr(err.as_ptr()) }.to_string_lossy().into_owned()).map_err(|e| ShardError { error: e, tier: ffi::BPP_TIER_CONSTRUCTION, rank: comm.rank })?;
+        let (mut tier, mut rank) = (0 as c_int, -1 as c_int);
+        let rc = unsafe { ffi::bpp_verify_sharded(comm.raw, self.ctx, batch, counts.as_ptr(), &mut tier, &mut rank, err.as_mut_ptr(), err.len()) };
+        unsafe { ffi::bpp_batch_destroy(self.ctx, batch) };
+        map_rc(rc, unsafe { CStr::from_ptr(err.as_ptr()) }.to_string_lossy().into_owned()).map_err(|e| ShardError { error: e, tier, rank })
     }
 
     /// `RangeProof::verify_batch`: every `chunk` consecutive items are one reference batch (256 = MAX_RANGE_PROOF_BATCH_SIZE,
@@ -136,12 +195,14 @@ impl Engine {
     /// Arc::clone of a parameter set created on another context of the same device
     pub fn retain(&self, params: &Params) -> Result<Params, GpuError> {
         map_rc(unsafe { ffi::bpp_params_retain(self.ctx, params.handle) }, self.last_error())?;
-        Ok(Params { handle: params.handle, extension_degree: params.extension_degree })
+        Ok(Params { handle: params.handle, extension_degree: params.extension_degree, owner: self.ctx })
     }
+}
 
-    pub fn release(&self, params: Params) {
-        unsafe { ffi::bpp_params_destroy(self.ctx, params.handle) };
-    }
+fn unpack_masks(masks: &[u8], present: &[u8], t: usize) -> Vec<Option<Vec<[u8; 32]>>> {
+    (0..present.len()).map(|k| if present[k] != 0 {
+        Some((0..t).map(|j| { let mut b = [0u8; 32]; b.copy_from_slice(&masks[(k * t + j) * 32..(k * t + j + 1) * 32]); b }).collect())
+    } else { None }).collect()
 }
 
 impl Drop for Engine {
@@ -151,9 +212,118 @@ impl Drop for Engine {
 }
 
 /// Device-resident generator tables of one `RangeParameters` (src/range_parameters.rs:20-30): process-wide, shared.
+/// Dropping it drops this holder's reference (bpp_params_destroy = Arc drop) -- on every path, including `?` returns.
 pub struct Params {
     handle: u64,
     extension_degree: usize,
+    owner: *mut ffi::bpp_ctx, // the context that holds this reference (must outlive it: the cache below lives for the process)
+}
+unsafe impl Send for Params {}
+unsafe impl Sync for Params {}
+impl Drop for Params {
+    fn drop(&mut self) {
+        unsafe { ffi::bpp_params_destroy(self.owner, self.handle) };
+    }
+}
+
+/// key of the process-wide parameter cache: (bit length, max aggregation, extension degree, H, G bases)
+type ParamsKey = (usize, usize, usize, [u8; 32], Vec<u8>);
+
+/// `RangeParameters` -> device tables, created ONCE per parameter set and process (the reference shares its generators
+/// through Arc: src/range_parameters.rs:20-30): bpp_params_create derives every generator and builds the tables, which
+/// must not happen per verify call, and a handle created per call would leak on every early return.
+pub fn cached_params(bit_length: usize, max_aggregation: usize, extension_degree: usize, h_base: &[u8; 32], g_bases: &[u8])
+                     -> Result<Arc<Params>, GpuError> {
+    static CACHE: OnceLock<Mutex<HashMap<ParamsKey, Arc<Params>>>> = OnceLock::new();
+    let key: ParamsKey = (bit_length, max_aggregation, extension_degree, *h_base, g_bases.to_vec());
+    let mut cache = CACHE.get_or_init(|| Mutex::new(HashMap::new())).lock().unwrap();
+    if let Some(p) = cache.get(&key) {
+        return Ok(p.clone());
+    }
+    let p = Arc::new(default_engine().lock().unwrap().params(bit_length, max_aggregation, extension_degree, Some(h_base), Some(g_bases))?);
+    cache.insert(key, p.clone());
+    Ok(p)
+}
+
+/// A homogeneous batch as contiguous arrays (bpp_packed_batch)
+pub struct PackedBatch<'a> {
+    pub n_items: usize,
+    /// n_items proofs of `proof_len` bytes each, back to back
+    pub proofs: &'a [u8],
+    pub proof_len: usize,
+    /// n_items x m x 32
+    pub commitments: &'a [u8],
+    pub m: usize,
+    /// n_items x m
+    pub min_values: &'a [u64],
+    pub min_present: &'a [u8],
+    /// n_items x 32 + n_items presence flags, or None
+    pub seed_nonces: Option<(&'a [u8], &'a [u8])>,
+    /// the label of the callers' fresh `Transcript::new(label)` ...
+    pub transcript_label: &'a [u8],
+    /// ... or the 203-byte STROBE state all their transcripts are in
+    pub transcript_state: Option<&'a [u8; 203]>,
+}
+impl PackedBatch<'_> {
+    fn raw(&self) -> ffi::bpp_packed_batch {
+        assert!(self.proofs.len() == self.n_items * self.proof_len && self.commitments.len() == self.n_items * self.m * 32);
+        assert!(self.min_values.len() == self.n_items * self.m && self.min_present.len() == self.n_items * self.m);
+        ffi::bpp_packed_batch {
+            n_items: self.n_items,
+            proofs: self.proofs.as_ptr(),
+            proof_len: self.proof_len,
+            proof_stride: self.proof_len,
+            commitments32: self.commitments.as_ptr(),
+            m: self.m as u32,
+            min_values: self.min_values.as_ptr(),
+            min_present: self.min_present.as_ptr(),
+            seed_nonces32: self.seed_nonces.map_or(ptr::null(), |s| s.0.as_ptr()),
+            seed_present: self.seed_nonces.map_or(ptr::null(), |s| s.1.as_ptr()),
+            transcript_state: self.transcript_state.map_or(ptr::null(), |s| s.as_ptr()),
+            transcript_label: self.transcript_label.as_ptr(),
+            label_len: self.transcript_label.len(),
+        }
+    }
+}
+
+pub struct Ticket {
+    id: u64,
+    n_items: usize,
+    t: usize,
+}
+
+/// One RCCL communicator for sharded verification (bpp_comm).  `unique_id` on rank 0, shipped to the other ranks by the
+/// caller's own channel, then `create` on every rank (collective).
+pub struct ShardComm {
+    raw: *mut ffi::bpp_comm,
+    pub rank: i32,
+}
+unsafe impl Send for ShardComm {}
+impl ShardComm {
+    pub fn unique_id() -> Result<[u8; 128], GpuError> {
+        let mut id = [0u8; 128];
+        map_rc(unsafe { ffi::bpp_comm_unique_id(id.as_mut_ptr()) }, "RCCL not loadable".into())?;
+        Ok(id)
+    }
+    pub fn create(engine: &Engine, id: &[u8; 128], rank: i32, world: i32) -> Result<Self, GpuError> {
+        let mut raw = ptr::null_mut();
+        map_rc(unsafe { ffi::bpp_comm_create(engine.ctx, id.as_ptr(), rank, world, &mut raw) }, engine.last_error())?;
+        Ok(ShardComm { raw, rank })
+    }
+}
+impl Drop for ShardComm {
+    fn drop(&mut self) {
+        unsafe { ffi::bpp_comm_destroy(self.raw) }
+    }
+}
+
+/// a sharded verification's error: the same on every rank; `tier` = where in the reference's order of checks
+/// (ffi::BPP_TIER_*), `rank` = whose proofs (-1: the final check over all of them)
+#[derive(Debug)]
+pub struct ShardError {
+    pub error: GpuError,
+    pub tier: i32,
+    pub rank: i32,
 }
 
 pub struct VerifyItem<'a> {
@@ -183,7 +353,6 @@ pub struct ProveItem<'a> {
 
 /// Process-wide default engine on device 0 for the in-crate patch (one context; callers that want concurrency hold their own).
 pub fn default_engine() -> &'static Mutex<Engine> {
-    use std::sync::OnceLock;
     static ENGINE: OnceLock<Mutex<Engine>> = OnceLock::new();
     ENGINE.get_or_init(|| Mutex::new(Engine::new(0).expect("bpp-gpu-shim: no usable gfx950 device")))
 }

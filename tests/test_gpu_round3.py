@@ -1,0 +1,272 @@
+"""GPU tests of round 3's ABI additions, all through the C ABI:
+  * bpp_batch_upload_packed / bpp_verify_batch_packed == the item form (traces 1-6, masks, error kinds and precedence)
+  * bpp_verify_submit_packed / bpp_verify_collect (upload k+1 under verify k inside one context) == the blocking call
+  * verifier-side secrets (seed nonces, recovered masks) are gone from the device once a batch is destroyed
+    (src/range_statement.rs:76-81, src/extended_mask.rs:14)
+Inputs come from the engine's own batch prover with the recipe of benches/range_proof.rs:206-262 (its bytes are pinned to
+the oracle by tests/test_gpu_prove.py); the masks are additionally compared with what the prover was given."""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+
+from tests.helpers import LABEL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def packed():
+    return importlib.import_module("bulletproofs-plus_amd.packed")
+
+
+def _inputs(bpp, packed, engine, m, t, count, seed):
+    import bench
+    params = bpp.RangeParameters.init(64, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=engine)
+    return params, bench.make_inputs(np, packed, params, count, seed=seed)
+
+
+def _resident(packed, params, d, form, seeds=None, sl=slice(None)):
+    return packed.ResidentBatch(params, d["proofs"][sl], d["commitments"][sl], d["min_values"][sl], d["min_present"][sl],
+                                None if seeds is None else seeds[sl], LABEL, form=form)
+
+
+@pytest.mark.parametrize("m,t,count,chunk", [(1, 1, 300, 128), (8, 1, 20, 0), (2, 3, 33, 16)])
+def test_packed_upload_equals_item_form(bpp, packed, engine, m, t, count, chunk):
+    params, d = _inputs(bpp, packed, engine, m, t, count, 7000 + m)
+    seeds = d["seeds"]
+    ra, rb = _resident(packed, params, d, "items", seeds), _resident(packed, params, d, "packed", seeds)
+    action = bpp.VerifyAction.RecoverAndVerify
+    ma, mb = ra.verify(action, chunk), rb.verify(action, chunk)
+    assert [x.blindings() if x else None for x in ma] == [x.blindings() if x else None for x in mb]
+    if m == 1:  # the blinding the prover was given comes back (benches/range_proof.rs:74: one blinding, t times)
+        assert [x.blindings() for x in mb] == [[bytes(d["blindings"][i, 0, k]) for k in range(t)] for i in range(count)]
+    assert ra.shape() == rb.shape()
+    for what in (1, 2, 3, 4, 5, 6):
+        assert ra.trace(what) == rb.trace(what), what
+    assert rb.trace(6) == bytes(32) * rb.shape()["groups"]
+    ra.close()
+    rb.close()
+    # one blocking call: upload, verify, release
+    inp = packed.PackedInput(d["proofs"], d["commitments"], d["min_values"], d["min_present"], seeds, LABEL)
+    masks, present = packed.verify_batch(params, inp, action, chunk or 256)
+    assert present.tolist() == [1 if m == 1 else 0] * count
+    if m == 1:
+        assert masks.tobytes() == d["blindings"][:, 0].tobytes()
+    params.close()
+
+
+def test_packed_error_kinds_and_precedence_equal_the_item_form(bpp, packed, engine):
+    params, d = _inputs(bpp, packed, engine, 1, 1, 40, 7100)
+    K = bpp.ProofErrorKind
+
+    def both(mut, chunk=0, stage="verify"):
+        """the same mutated input through both forms: (kind, message) must agree"""
+        out = []
+        for form in ("items", "packed"):
+            dd = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+            mut(dd)
+            try:
+                rb = _resident(packed, params, dd, form)
+                try:
+                    rb.verify_only(chunk)
+                    out.append(None)
+                finally:
+                    rb.close()
+            except bpp.ProofError as e:
+                out.append((int(e.kind), e.msg))
+        assert out[0] == out[1], out
+        return out[0]
+
+    def r1_bit(dd):
+        dd["proofs"][17, 1 + 32 + 96] ^= 1  # r1: still canonical, the MSM notices
+
+    def bad_point(dd):
+        dd["proofs"][5, 1 + 32:1 + 64] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)  # A does not decode
+
+    def identity(dd):
+        dd["proofs"][30, 1 + 32:1 + 64] = 0  # identity appended to the transcript: PASS 1
+
+    def noncanonical(dd):
+        dd["proofs"][9, 1 + 32 * 4:1 + 32 * 5] = 0xff  # r1 >= l: from_bytes fails (construction, lowest index wins)
+        dd["proofs"][3, 1 + 32:1 + 64] = 0
+
+    def other_degree(dd):
+        dd["proofs"][12, 0] = 3  # claims extension degree 3 in the same 577 bytes: no longer a uniform batch
+        dd["proofs"][12, 1:1 + 96] = 0  # three canonical d1
+
+    def commitment(dd):
+        dd["commitments"][0, 0] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)  # statement commitment does not decode
+
+    assert both(lambda dd: None) is None
+    assert both(r1_bit)[0] == K.VerificationFailed
+    assert both(bad_point)[0] == K.InvalidArgument
+    assert both(identity)[0] == K.VerificationFailed
+    assert both(lambda dd: (bad_point(dd), identity(dd)))[0] == K.VerificationFailed  # PASS 1 of any proof first
+    assert both(lambda dd: (r1_bit(dd), bad_point(dd)), chunk=8)[0] == K.InvalidArgument  # chunk 0 has the bad point
+    assert both(noncanonical)[0] == K.InvalidArgument
+    assert both(other_degree)[0] == K.InvalidArgument
+    assert both(commitment)[0] == K.InvalidArgument
+    params.close()
+
+
+def test_pipeline_equals_blocking_calls(bpp, packed, engine):
+    params, d = _inputs(bpp, packed, engine, 1, 1, 1536, 7200)
+    K = bpp.ProofErrorKind
+    eng2 = bpp.Engine(0)
+    p2 = params.share(eng2)
+    pipe = packed.Pipeline(p2, depth=3)
+    # six batches of 256: two of them tampered
+    views = []
+    for b in range(6):
+        sl = slice(256 * b, 256 * (b + 1))
+        proofs = d["proofs"][sl].copy()
+        if b == 2:
+            proofs[100, 1 + 32 + 96] ^= 1
+        if b == 4:
+            proofs[7, 1 + 32:1 + 64] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)
+        views.append(packed.PackedInput(proofs, d["commitments"][sl], d["min_values"][sl], d["min_present"][sl], d["seeds"][sl], LABEL))
+    want = []
+    for v in views:
+        try:
+            masks, present = packed.verify_batch(params, v, bpp.VerifyAction.RecoverAndVerify, 128)
+            want.append((masks.tobytes(), present.tobytes()))
+        except bpp.ProofError as e:
+            want.append(int(e.kind))
+    assert want[2] == K.VerificationFailed and want[4] == K.InvalidArgument and isinstance(want[0], tuple)
+    for rounds in range(2):  # lanes are reused
+        tickets = [pipe.submit(v, bpp.VerifyAction.RecoverAndVerify, 128) for v in views]  # more tickets than lanes
+        got = {}
+        for i in (5, 0, 3, 1, 4, 2):  # any order
+            try:
+                masks, present = pipe.collect(tickets[i])
+                got[i] = (masks.tobytes(), present.tobytes())
+            except bpp.ProofError as e:
+                got[i] = int(e.kind)
+        assert [got[i] for i in range(6)] == want
+    # VerifyOnly tickets; a construction error is submit's own return value and leaves the lane usable
+    t0 = pipe.submit(views[0], bpp.VerifyAction.VerifyOnly, 256)
+    bad = d["proofs"][:256].copy()
+    bad[200, 1 + 32 * 4:1 + 32 * 5] = 0xff
+    vb = packed.PackedInput(bad, d["commitments"][:256], d["min_values"][:256], d["min_present"][:256], None, LABEL)
+    with pytest.raises(bpp.ProofError) as e:
+        pipe.submit(vb, bpp.VerifyAction.VerifyOnly, 256)
+    assert e.value.kind == K.InvalidArgument
+    t1 = pipe.submit(views[1], bpp.VerifyAction.VerifyOnly, 256)
+    assert pipe.collect(t1) == (None, None) and pipe.collect(t0) == (None, None)
+    err = ctypes.create_string_buffer(64)
+    assert eng2.lib.bpp_verify_collect(eng2.ctx, 987654, None, None, err, 64) == -3  # unknown ticket
+    assert eng2.lib.bpp_ctx_pipeline_depth(eng2.ctx, 2) != 0  # already running
+    t2 = pipe.submit(views[3], bpp.VerifyAction.VerifyOnly, 256)  # still in flight when the context goes: destroy waits
+    assert t2
+    p2.close()
+    eng2.close()
+    params.close()
+
+
+def test_verifier_secrets_are_wiped(bpp, packed, engine):
+    """seed nonces and recovered masks: present on the device while the batch lives, zero in the buffers the context
+    keeps for the next upload once it is destroyed -- after a successful and after a failing verification"""
+    eng = bpp.Engine(0)
+    params, d = _inputs(bpp, packed, eng, 1, 1, 64, 7300)
+
+    def secret_bytes(handle):
+        n = ctypes.c_uint64()
+        assert eng.lib.bpp_batch_secret_bytes(eng.ctx, handle, ctypes.byref(n)) == 0
+        return n.value
+
+    for tamper in (False, True):
+        proofs = d["proofs"].copy()
+        if tamper:
+            proofs[3, 1 + 32 + 96] ^= 1
+        rb = packed.ResidentBatch(params, proofs, d["commitments"], d["min_values"], d["min_present"], d["seeds"], LABEL)
+        assert secret_bytes(rb.handle) > 64 * 24  # the nonces arrived
+        if tamper:
+            with pytest.raises(bpp.ProofError):
+                rb.verify(bpp.VerifyAction.RecoverAndVerify, 0)
+        else:
+            masks = rb.verify(bpp.VerifyAction.RecoverAndVerify, 0)
+            assert masks[0].blindings() == [bytes(d["blindings"][0, 0, 0])]
+        assert secret_bytes(rb.handle) > 2 * 64 * 24  # nonces + masks
+        rb.close()
+        assert secret_bytes(0) == 0  # what the next upload adopts holds nothing
+    # the one-call form leaves nothing behind either
+    inp = packed.PackedInput(d["proofs"], d["commitments"], d["min_values"], d["min_present"], d["seeds"], LABEL)
+    packed.verify_batch(params, inp, bpp.VerifyAction.RecoverAndVerify, 256)
+    assert secret_bytes(0) == 0
+    params.close()
+    eng.close()
+
+
+def test_sharded_entry_over_rccl_one_rank(bpp, packed, engine):
+    """bpp_verify_sharded / bpp_verify_sharded_wave with a real RCCL communicator of ONE rank (what a 1-GPU box can run; the
+    multi-rank rule is covered on CPU by tests/test_dist_gloo.py): both all_gathers run on device buffers, the verdicts,
+    tiers and intermediates equal those of the single-call form on the same proofs"""
+    dmod = importlib.import_module("bulletproofs-plus_amd.dist")
+    params, d = _inputs(bpp, packed, engine, 1, 1, 600, 7400)
+    K = bpp.ProofErrorKind
+    comm = dmod.ShardComm(engine, 0, 1, dmod.ShardComm.unique_id())
+    rb = _resident(packed, params, d, "packed", sl=slice(0, 300))
+    assert comm.verify(rb, [300]) is True
+    w_sharded, s_sharded, acc = rb.trace(3), rb.trace(4), rb.trace(6)
+    rb.verify_only(0)  # the single-call form over the same 300 proofs: same weights, same scalars, same (identity) result
+    assert (w_sharded, s_sharded, acc) == (rb.trace(3), rb.trace(4), rb.trace(6)) and acc == bytes(32)
+    with pytest.raises(bpp.EngineError):
+        comm.verify(rb, [299])  # counts[rank] must be the shard's size
+    rb.close()
+
+    def outcome(mut):
+        pr = d["proofs"][:300].copy()
+        mut(pr)
+        r = packed.ResidentBatch(params, pr, d["commitments"][:300], d["min_values"][:300], d["min_present"][:300], None, LABEL)
+        try:
+            comm.verify(r, [300])
+            return None
+        except bpp.ProofError as e:
+            return (int(e.kind), e.tier, e.rank, e.index)
+        finally:
+            r.close()
+
+    def r1_bit(pr):
+        pr[17, 1 + 32 + 96] ^= 1
+
+    def bad_point(pr):
+        pr[5, 1 + 32:1 + 64] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)
+
+    def identity(pr):
+        pr[30, 1 + 32:1 + 64] = 0
+
+    def degree(pr):
+        pr[12, 0] = 3
+        pr[12, 1:1 + 32 * 8] = 0
+
+    assert outcome(lambda pr: None) is None
+    assert outcome(r1_bit) == (K.VerificationFailed, 7, -1, 0)
+    assert outcome(bad_point) == (K.InvalidArgument, 6, 0, 5)
+    assert outcome(identity) == (K.VerificationFailed, 5, 0, 30)
+    assert outcome(lambda pr: (bad_point(pr), identity(pr))) == (K.VerificationFailed, 5, 0, 30)
+    assert outcome(degree) == (K.InvalidArgument, 2, 0, 12)
+    # a wave: three batches on three contexts, the middle one tampered; ONE all_gather per exchange for all three
+    engs = [bpp.Engine(0) for _ in range(3)]
+    pars = [params.share(e) for e in engs]
+    rbs = []
+    for i in range(3):
+        pr = d["proofs"][200 * i:200 * (i + 1)].copy()
+        if i == 1:
+            pr[100, 1 + 32 + 96] ^= 1
+        sl = slice(200 * i, 200 * (i + 1))
+        rbs.append(packed.ResidentBatch(pars[i], pr, d["commitments"][sl], d["min_values"][sl], d["min_present"][sl], None, LABEL))
+    for _ in range(2):
+        res = comm.verify_wave(rbs, [200])
+        assert [r["code"] for r in res] == [0, int(K.VerificationFailed), 0] and res[1]["tier"] == 7
+    with pytest.raises(bpp.EngineError):
+        comm.verify_wave([rbs[0], rbs[0]], [200])  # one context twice
+    for x in rbs:
+        x.close()
+    for p in pars:
+        p.close()
+    for e in engs:
+        e.close()
+    comm.close()
+    params.close()
