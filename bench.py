@@ -489,6 +489,7 @@ def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, para
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     wel = float(tt.item())
     batches = W * K * rounds
+    wave_ms = waves[0][3].last_timing()
     for engs, pars, rbs, comm in waves:
         comm.close()
         for x in rbs:
@@ -502,7 +503,8 @@ def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, para
                         "replayed on every rank, RCCL all_gather of the 128-byte accumulators, sum + identity test on the device; "
                         "%d waves x %d batches in flight per rank" % (n_local, W, K),
             "rccl_ranks": world, "proofs_per_s": 4096 * batches / wel, "ms_per_batch": 1e3 * wel / batches,
-            "batches": batches, "in_flight": W * K, "waves": W, "batches_per_wave": K}
+            "batches": batches, "in_flight": W * K, "waves": W, "batches_per_wave": K,
+            "last_wave_host_ms": {k: round(v, 3) for k, v in wave_ms.items()}}
 
 
 def main():

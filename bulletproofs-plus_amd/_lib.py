@@ -35,6 +35,11 @@ class ShardResult(Structure):
     _fields_ = [("code", c_int), ("tier", c_int), ("rank", c_int), ("index", c_uint32), ("msg", ctypes.c_char * 160)]
 
 
+class ShardTiming(Structure):
+    _fields_ = [(n, c_float) for n in ("enqueue1_ms", "wait1_ms", "gather1_ms", "chains_ms", "enqueue2_ms", "wait2_ms",
+                                       "gather2_ms")] + [("batches", c_uint32)]
+
+
 class Profile(Structure):
     _fields_ = [(n, c_float) for n in ("transcripts_ms", "decompress_ms", "chain_host_ms", "scalars_ms", "reduce_ms",
                                        "msm_digits_ms", "msm_sort_ms", "msm_accumulate_ms", "msm_bucket_reduce_ms",
@@ -53,6 +58,7 @@ SYMBOLS = [
     ("bpp_ctx_create_on_stream", c_int, [POINTER(c_void_p), c_int, c_void_p]),
     ("bpp_ctx_destroy", None, [c_void_p]),
     ("bpp_ctx_last_error", c_char_p, [c_void_p]),
+    ("bpp_ctx_set_option", c_int, [c_void_p, c_char_p, c_int]),
     ("bpp_precomp_create", c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_uint64)]),
     ("bpp_precomp_destroy", c_int, [c_void_p, c_uint64]),
     ("bpp_precomp_retain", c_int, [c_void_p, c_uint64]),
@@ -89,6 +95,7 @@ SYMBOLS = [
     ("bpp_comm_adopt", c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
     ("bpp_comm_destroy", None, [c_void_p]),
     ("bpp_comm_last_error", c_char_p, [c_void_p]),
+    ("bpp_comm_last_timing", c_int, [c_void_p, POINTER(ShardTiming)]),
     ("bpp_verify_sharded", c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint32), POINTER(c_int), POINTER(c_int), c_void_p,
                                    c_size_t]),
     ("bpp_verify_sharded_wave", c_int, [c_void_p, POINTER(c_void_p), POINTER(c_uint64), c_size_t, POINTER(c_uint32),

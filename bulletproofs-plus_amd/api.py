@@ -141,6 +141,10 @@ class Engine:
     def profile(self, on=True):
         self.lib.bpp_profile_enable(self.ctx, 1 if on else 0)
 
+    def set_option(self, name, value):
+        """bpp_ctx_set_option: per-context knob (tests, A/B timing); -1 restores the engine's own rule"""
+        _check(self.lib.bpp_ctx_set_option(self.ctx, name.encode(), int(value)), self.ctx)
+
     def last_profile(self):
         p = _lib.Profile()
         self.lib.bpp_profile_get(self.ctx, byref(p))

@@ -374,6 +374,13 @@ struct bpp_ctx {
   std::vector<hipStream_t> prove_streams;
   std::vector<hipEvent_t> prove_events;  // pairs around every k_fb_msm launch of the last bpp_prove_batch (profiling only)
   bpp_prove_profile pprof{};
+  // knobs (tests, A/B timing).  -1 = the engine's own rule.  The BPP_* environment variables of the same names are read
+  // ONCE, when the context is created (no getenv on any verification path: a host that calls setenv from another thread
+  // would race with it); bpp_ctx_set_option changes them afterwards.
+  struct Options {
+    int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_quad = -1, msm_final_quad = -1,
+        fb_threads = -1, prove_subs = -1;
+  } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
   uint32_t pipe_depth = 3;
@@ -382,10 +389,29 @@ struct bpp_ctx {
 namespace {
 
 // lanes per output point of k_fb_msm: enough (term, window) items per lane to outweigh the log2(lanes) reduction tree
-static uint32_t fb_threads(uint32_t terms, const FbGeom &g) {
-  if (const char *e = getenv("BPP_FB_THREADS")) return (uint32_t)atoi(e);
+static uint32_t fb_threads(const bpp_ctx *ctx, uint32_t terms, const FbGeom &g) {
+  if (ctx->opt.fb_threads > 0) return (uint32_t)ctx->opt.fb_threads;
   const uint32_t items = terms * g.windows;
   return items >= 4096 ? 256u : (items >= 1024 ? 128u : 64u);
+}
+
+struct OptionName {
+  const char *name, *env;
+  int bpp_ctx::Options::*field;
+};
+const OptionName kOptions[] = {
+    {"transcripts_wave", "BPP_TRANSCRIPTS_WAVE", &bpp_ctx::Options::transcripts_wave},
+    {"tables_wave", "BPP_TABLES_WAVE", &bpp_ctx::Options::tables_wave},
+    {"side_decompress", "BPP_SIDE_DECOMPRESS", &bpp_ctx::Options::side_decompress},
+    {"msm_c_bias", "BPP_MSM_C_BIAS", &bpp_ctx::Options::msm_c_bias},
+    {"msm_quad", "BPP_MSM_QUAD", &bpp_ctx::Options::msm_quad},
+    {"msm_final_quad", "BPP_MSM_FINAL_QUAD", &bpp_ctx::Options::msm_final_quad},
+    {"fb_threads", "BPP_FB_THREADS", &bpp_ctx::Options::fb_threads},
+    {"prove_subs", "BPP_PROVE_SUBS", &bpp_ctx::Options::prove_subs},
+};
+void options_from_env(bpp_ctx *c) {
+  for (const OptionName &o : kOptions)
+    if (const char *e = getenv(o.env)) c->opt.*(o.field) = atoi(e);
 }
 
 int fail(bpp_ctx *ctx, int code, const std::string &m, char *errbuf = nullptr, size_t len = 0) {
@@ -431,15 +457,14 @@ static bool decompress_spill_enabled() {
 
 
 // ------------------------------------------------------------------ MSM driver
-uint32_t choose_window(uint32_t group_terms, uint32_t all_terms) {
+uint32_t choose_window(const bpp_ctx *ctx, uint32_t group_terms, uint32_t all_terms) {
   // buckets per window ~ terms / 12  (bucket lists of ~12 points keep the per-lane chains short)
   uint32_t c = 4;
   while (c < 14 && (1u << c) * 12u <= group_terms) c++;  // nb = 2^(c-1)
   // A small call has the chip to itself: its time is the length of the dependency chains, not the number of additions.
   // Wider windows shorten the bucket lists (accumulation) and the Horner step (fewer windows to add) for a longer
   // row / column reduction: three more bits are worth 0.07-0.1 ms up to a few hundred proofs (one proof 0.79 -> 0.68 ms).
-  const char *fb = getenv("BPP_MSM_C_BIAS");  // read per plan: tests run the narrow windows as well
-  const int bias = fb ? atoi(fb) : 3;
+  const int bias = ctx->opt.msm_c_bias >= 0 ? ctx->opt.msm_c_bias : 3;  // (tests run the narrow windows as well)
   if (all_terms <= 20000u) c = (uint32_t)std::max(4, std::min(11, (int)c + bias));
   return c;
 }
@@ -450,7 +475,7 @@ void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff)
   const uint32_t G = (uint32_t)goff.size() - 1, n = goff[G];
   uint32_t maxg = 0;
   for (uint32_t g = 0; g < G; g++) maxg = std::max(maxg, goff[g + 1] - goff[g]);
-  const MsmPlan plan = msm_make_plan(choose_window(maxg, n), G, n);
+  const MsmPlan plan = msm_make_plan(choose_window(ctx, maxg, n), G, n);
   w.plan = plan;
   w.max_group_terms = maxg;
   const size_t nbk = (size_t)G * plan.K * plan.nb;
@@ -507,8 +532,7 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
                      w.order_hist.p + (size_t)plan.G * 256, w.order.p);
   if (tm) tm->mark(M_ORDER);  // msm_accumulate_ms brackets k_msm_accumulate alone (the roofline kernel)
   // few buckets on an idle chip (one batch per call): quad forms, ~3x shorter dependency chains (tests force either form)
-  const char *fq2 = getenv("BPP_MSM_QUAD");
-  const bool small = fq2 ? atoi(fq2) != 0 : (size_t)plan.G * per_group <= 100000;
+  const bool small = ctx->opt.msm_quad >= 0 ? ctx->opt.msm_quad != 0 : (size_t)plan.G * per_group <= 100000;
   if (small)
     hipLaunchKernelGGL(k_msm_accumulate_quad, dim3(cdiv(plan.G * per_group, 16)), dim3(64), 0, s, w.sorted.p, w.starts.p,
                        w.counts.p, w.order.p, tabs, plan.G * per_group, w.buckets.p);
@@ -526,8 +550,7 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
   }
   if (tm) tm->mark(M_BUCKET);
   {
-    const char *fq = getenv("BPP_MSM_FINAL_QUAD");  // tests force either kernel
-    if (fq ? atoi(fq) != 0 : true)
+    if (ctx->opt.msm_final_quad != 0)  // (tests force either kernel)
       hipLaunchKernelGGL(k_msm_final_quad, dim3(cdiv(plan.G, 16)), dim3(64), 0, s, w.W.p, plan, w.R.p, w.is_identity.p);
     else
       hipLaunchKernelGGL(k_msm_final, dim3(cdiv(plan.G, 64)), dim3(64), 0, s, w.W.p, plan, w.R.p, w.is_identity.p);
@@ -612,6 +635,7 @@ int bpp_ctx_create_on_stream(bpp_ctx **out, int device_id, void *hip_stream) {
   if (hipSetDevice(device_id) != hipSuccess) return BPP_ERR_NO_DEVICE;
   bpp_ctx *c = new bpp_ctx();
   c->device = device_id;
+  options_from_env(c);
   if (hip_stream) {
     c->stream = (hipStream_t)hip_stream;
   } else {
@@ -659,6 +683,17 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
 }
 
 const char *bpp_ctx_last_error(bpp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int bpp_ctx_set_option(bpp_ctx *ctx, const char *name, int value) {
+  if (!ctx || !name) return BPP_ERR_BAD_HANDLE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  for (const OptionName &o : kOptions)
+    if (strcmp(name, o.name) == 0) {
+      ctx->opt.*(o.field) = value;
+      return BPP_OK;
+    }
+  return fail(ctx, BPP_ERR_INVALID_ARGUMENT, std::string("unknown option: ") + name);
+}
 
 #define BPP_ENTRY(ctx)                         \
   if (!(ctx)) return BPP_ERR_BAD_HANDLE;       \
@@ -918,7 +953,7 @@ int bpp_pedersen_commit(bpp_ctx *ctx, uint64_t params, const uint64_t *values, c
     HIP_CHECK(hipMemcpyAsync(d_c.p, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, s));
     DevBuf<ge> d_ge;
     d_ge.alloc(count);
-    hipLaunchKernelGGL(k_fb_msm, dim3((uint32_t)count), dim3(fb_threads(per, P.fb_ped_geo)), 0, s, d_sc.p, d_g.p, d_c.p, per, P.fb_ped.p, P.fb_ped_geo,
+    hipLaunchKernelGGL(k_fb_msm, dim3((uint32_t)count), dim3(fb_threads(ctx, per, P.fb_ped_geo)), 0, s, d_sc.p, d_g.p, d_c.p, per, P.fb_ped.p, P.fb_ped_geo,
                        d_ge.p);
     hipLaunchKernelGGL(k_compress_ge, dim3(cdiv((uint32_t)count, 64)), dim3(64), 0, s, d_ge.p, (uint32_t)count, d_out.p);
     HIP_CHECK(hipGetLastError());
@@ -1226,8 +1261,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, boo
   // idle, so its decompression runs beside PASS 1 and the weight-free scalars on a second stream and joins before the
   // weights are needed (one 256-proof call 0.84 -> 0.79 ms).  Large inputs fill the chip either way: one stream, less
   // bookkeeping (measured: no gain).  Stage profiling keeps the serial order so that its intervals mean something.
-  const char *fs = getenv("BPP_SIDE_DECOMPRESS");  // tests force either form
-  const bool side = (fs ? atoi(fs) != 0 : b.B <= BPP_SIDE_DECOMPRESS_MAX) && !ctx->profile;
+  const bool side = (ctx->opt.side_decompress >= 0 ? ctx->opt.side_decompress != 0 : b.B <= BPP_SIDE_DECOMPRESS_MAX) && !ctx->profile;
   const uint32_t n_proof_pts = b.total_dyn - b.sum_m;
   auto launch_decompress = [&](hipStream_t st) {
     hipLaunchKernelGGL(k_decompress, dim3(cdiv(n_proof_pts, 64)), dim3(64), 0, st, b.bytes.p, b.src_off.p, b.owner.p,
@@ -1250,8 +1284,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, boo
     if (!b.uniform_rounds) HIP_CHECK(hipMemsetAsync(b.chal.p, 0, (size_t)b.B * b.cs * sizeof(sc), s));  // trace padding only
     tm.mark(M_START);
     // small inputs: one proof per wavefront (latency); large inputs: one proof per lane (issue slots)
-    const char *fw = getenv("BPP_TRANSCRIPTS_WAVE");  // tests force either kernel
-    const int force_wave = fw ? atoi(fw) : -1;
+    const int force_wave = ctx->opt.transcripts_wave;  // (tests force either kernel)
     const bool wave = force_wave >= 0 ? force_wave != 0 : b.B <= BPP_TRANSCRIPTS_WAVE_MAX;
     if (wave)
       hipLaunchKernelGGL(k_transcripts_wave, dim3(b.B), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.states.p,
@@ -1269,8 +1302,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, boo
   tm.mark(M_DECOMPRESS);
   if (!pass1_only) {  // the weight-independent part of the PASS-2 scalars; the rest (k_scalars_lanes) takes the weights
     // tables of the generator-row kernel: by the same lane for large inputs, one wavefront per proof for small ones
-    const char *ft = getenv("BPP_TABLES_WAVE");  // tests force either form
-    const bool tw = ft ? atoi(ft) != 0 : b.B <= BPP_TABLES_WAVE_MAX;
+    const bool tw = ctx->opt.tables_wave >= 0 ? ctx->opt.tables_wave != 0 : b.B <= BPP_TABLES_WAVE_MAX;  // (tests force either form)
     hipLaunchKernelGGL(k_scalars_shared, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.chal.p,
                        P.n_bits, P.t, b.cs, b.B, b.shr.p, b.lanes_nhi_max(P.n_bits), tw ? (sc *)nullptr : b.tab.p);
     if (tw)
@@ -1492,8 +1524,8 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
   sc *dyn_scal = b.scal.p + (size_t)b.G * b.cols;
   {
     const uint32_t nhi_max = b.lanes_nhi_max(P.n_bits);
-    const char *ft = getenv("BPP_TABLES_WAVE");  // as in enqueue_phase1: small inputs take the one-wavefront-per-proof forms
-    const bool tw = ft ? atoi(ft) != 0 : b.B <= BPP_TABLES_WAVE_MAX;
+    // as in enqueue_phase1: small inputs take the one-wavefront-per-proof forms
+    const bool tw = ctx->opt.tables_wave >= 0 ? ctx->opt.tables_wave != 0 : b.B <= BPP_TABLES_WAVE_MAX;
     if (tw)
       hipLaunchKernelGGL(k_scalars_weighted_wave, dim3(b.B), dim3(64), 0, s, b.d_desc.p, b.shr.p, b.weights.p, P.n_bits, P.t,
                          b.max_mn, b.cols, b.B, nhi_max, b.tab.p, b.rows.p, dyn_scal);
@@ -1732,6 +1764,7 @@ Pipeline *pipeline_get(bpp_ctx *ctx) {
   for (uint32_t i = 0; i < ctx->pipe_depth; i++) {
     auto lane = std::make_unique<PipeLane>();
     if (bpp_ctx_create(&lane->child, ctx->device) != BPP_OK) throw EngineError{BPP_ERR_ENGINE, "pipeline lane: context creation failed"};
+    lane->child->opt = ctx->opt;
     pp->lanes.push_back(std::move(lane));
   }
   for (auto &lane : pp->lanes) lane->th = std::thread(pipe_worker, ctx, pp.get(), lane.get());
@@ -2170,7 +2203,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     // Fiat-Shamir latency, a handful of wavefronts) -> wave step -> fixed-base MSM (fills the chip), so one sub-batch's
     // lane step overlaps another's MSM.  All device buffers come out of one arena allocation per call.
     uint32_t PROVE_SUBS = 2;
-    if (const char *e = getenv("BPP_PROVE_SUBS")) PROVE_SUBS = std::max(1, std::min(16, atoi(e)));
+    if (ctx->opt.prove_subs > 0) PROVE_SUBS = (uint32_t)std::min(16, ctx->opt.prove_subs);
     const uint32_t sub_size = std::max<uint32_t>(64, cdiv(B, PROVE_SUBS));
     const uint32_t n_sub = cdiv(B, sub_size);
     while (ctx->prove_streams.size() < n_sub) {
@@ -2293,7 +2326,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_bytes, u.d_desc, t, n_gen, nb, m, 1 + t, u.d_cts,
                          u.d_ctg, u.d_ctc);
       fb_mark(s);
-      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(1 + t, P.fb_geo)), 0, s, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, P.fb_geo,
+      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(ctx, 1 + t, P.fb_geo)), 0, s, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, P.fb_geo,
                          u.d_ge);
       fb_mark(s);
       hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_ge, nb * m, u.d_commit32);
@@ -2308,7 +2341,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
                            stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
         uint8_t *out = (j < rounds) ? u.d_lr + (size_t)j * nb * 64 : u.d_a1b;
         fb_mark(s);
-        hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(fb_threads(mn + t + 1, P.fb_geo)), 0, s, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, P.fb_geo,
+        hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(fb_threads(ctx, mn + t + 1, P.fb_geo)), 0, s, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, P.fb_geo,
                            u.d_ge);
         fb_mark(s);
         hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);

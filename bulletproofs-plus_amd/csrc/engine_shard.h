@@ -100,6 +100,7 @@ struct bpp_comm {
   std::vector<uint8_t> rng_all, weights_all;
   std::mutex mu;
   std::string err;
+  bpp_shard_timing timing{};  // host wall-clock split of the last wave
 };
 
 namespace {
@@ -184,6 +185,13 @@ void bpp_comm_destroy(bpp_comm *c) {
 
 const char *bpp_comm_last_error(bpp_comm *c) { return c ? c->err.c_str() : "null comm"; }
 
+int bpp_comm_last_timing(bpp_comm *c, bpp_shard_timing *out) {
+  if (!c || !out) return BPP_ERR_BAD_HANDLE;
+  std::lock_guard<std::mutex> lk(c->mu);
+  *out = c->timing;
+  return BPP_OK;
+}
+
 int bpp_shard_trailer(int tier, int code, uint32_t index, const char *msg, uint8_t trailer_out[BPP_SHARD_TRAILER_BYTES]) {
   if (!trailer_out || tier < 0 || tier > 255) return BPP_ERR_INVALID_ARGUMENT;
   shard_trailer_encode(trailer_out, tier, code, index, msg);
@@ -238,6 +246,15 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
   std::vector<int> fault(K, 0);           // engine fault on THIS rank, per batch
   std::vector<std::string> fault_msg(K);
   std::vector<uint8_t> skip(K, 0);        // batch decided by the first exchange: no phase 2
+  auto t_mark = std::chrono::steady_clock::now();
+  bpp_shard_timing &tmg = comm->timing;
+  memset(&tmg, 0, sizeof(tmg));
+  tmg.batches = K;
+  auto lap = [&](float &slot) {
+    const auto now = std::chrono::steady_clock::now();
+    slot += std::chrono::duration<float, std::milli>(now - t_mark).count();
+    t_mark = now;
+  };
   try {
     comm->send1.alloc(per1);
     comm->recv1.alloc(per1 * world);
@@ -275,6 +292,7 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
         fault_msg[i] = e.msg;
       }
     }
+    lap(tmg.enqueue1_ms);
     for (uint32_t i = 0; i < K; i++) {
       uint8_t *tr = comm->h_tr.data() + (size_t)i * BPP_SHARD_TRAILER_BYTES;
       if (!fault[i] && hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) {
@@ -288,11 +306,13 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
         shard_local_trailer(b.any_defer ? b.defer.data() : nullptr, b.h_status.data(), b.rounds_bad.data(), b.B, first_index, tr);
       }
     }
+    lap(tmg.wait1_ms);
     hipStream_t cs = comm->stream;
     HIP_CHECK(hipMemcpyAsync(comm->send1.p + K * slot, comm->h_tr.data(), (size_t)K * BPP_SHARD_TRAILER_BYTES, hipMemcpyHostToDevice, cs));
     RCCL_CHECK(R.AllGather(comm->send1.p, comm->recv1.p, per1, ncclUint8, comm->comm, cs));
     HIP_CHECK(hipMemcpyAsync(comm->h_recv1.data(), comm->recv1.p, per1 * world, hipMemcpyDeviceToHost, cs));
     HIP_CHECK(hipStreamSynchronize(cs));
+    lap(tmg.gather1_ms);
     // ---------------------------------------------------------------- every rank reads the same findings
     std::vector<uint32_t> active;
     for (uint32_t i = 0; i < K; i++) {
@@ -320,6 +340,7 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
       }
       gfirst[A] = (uint32_t)(A * n_total);
       run_weight_chains_generic(comm->rng_all.data(), comm->weights_all.data(), gfirst.data(), (uint32_t)A);
+      lap(tmg.chains_ms);
       for (size_t a = 0; a < A; a++) {
         const uint32_t i = active[a];
         try {
@@ -337,6 +358,7 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
         }
       }
     }
+    lap(tmg.enqueue2_ms);
     uint32_t *fw = (uint32_t *)(comm->h_tr.data() + (size_t)K * BPP_SHARD_TRAILER_BYTES);
     for (uint32_t i = 0; i < K; i++) {
       if (!skip[i] && !fault[i] && hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) {
@@ -345,6 +367,7 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
       }
       fw[i] = skip[i] ? 0u : (uint32_t)fault[i];
     }
+    lap(tmg.wait2_ms);
     for (uint32_t i = 0; i < K; i++)
       if (skip[i]) HIP_CHECK(hipMemsetAsync(comm->send2.p + (size_t)i * 128, 0, 128, cs));
     HIP_CHECK(hipMemcpyAsync(comm->send2.p + (size_t)K * 128, fw, (size_t)K * 4, hipMemcpyHostToDevice, cs));
@@ -354,6 +377,7 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
     HIP_CHECK(hipMemcpyAsync(comm->h_flags.data(), comm->d_flags.p, (size_t)K * 4, hipMemcpyDeviceToHost, cs));
     HIP_CHECK(hipMemcpyAsync(comm->h_recv2.data(), comm->recv2.p, per2 * world, hipMemcpyDeviceToHost, cs));
     HIP_CHECK(hipStreamSynchronize(cs));
+    lap(tmg.gather2_ms);
     for (uint32_t i = 0; i < K; i++) {
       if (skip[i]) continue;
       int bad_rank = -1, bad_code = 0;

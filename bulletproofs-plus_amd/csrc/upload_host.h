@@ -63,7 +63,7 @@ inline void parse_proof(const uint8_t *p, size_t len, ParsedItem &out) {
   size_t rest = nchunks - (t + 5);
   if (rest / 2 == 0) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Serialized proof is too short"};
   if ((rest % 2) || rem) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Unused data after deserialization"};
-  if (rest / 2 > BPP_MAX_WIRE_ROUNDS) throw ProofErr{BPP_ERR_SIZE_OVERFLOW, "Internal size overflow (proof larger than 64 MB)"};
+  if (rest / 2 > BPP_MAX_WIRE_ROUNDS) throw ProofErr{BPP_ERR_SIZE_OVERFLOW, "Internal size overflow (more than 64 (L, R) pairs)"};
   out.t = t;
   out.rounds = (uint32_t)(rest / 2);
 }

@@ -73,6 +73,12 @@ class ShardComm:
             raise api.EngineError("bpp_verify_sharded_wave failed (%d): %s" % (rc, self._err()))
         return [{"code": r.code, "tier": r.tier, "rank": r.rank, "index": r.index, "msg": r.msg.decode(errors="replace")} for r in out]
 
+    def last_timing(self):
+        """host wall-clock split of the last wave (ms)"""
+        t = _lib.ShardTiming()
+        self.lib.bpp_comm_last_timing(self.handle, byref(t))
+        return {n: getattr(t, n) for n, _ in _lib.ShardTiming._fields_}
+
     def close(self):
         if self.handle:
             self.lib.bpp_comm_destroy(self.handle)

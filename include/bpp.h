@@ -69,6 +69,11 @@ int bpp_ctx_create(bpp_ctx **out, int device_id);
 int bpp_ctx_create_on_stream(bpp_ctx **out, int device_id, void *hip_stream);
 void bpp_ctx_destroy(bpp_ctx *ctx);
 const char *bpp_ctx_last_error(bpp_ctx *ctx);
+/* per-context knobs for tests and A/B timing; value -1 restores the engine's own rule.  Names: "transcripts_wave",
+ * "tables_wave", "side_decompress", "msm_quad", "msm_final_quad" (0 / 1: force the one-lane or the latency form of that stage),
+ * "msm_c_bias" (extra MSM window bits of small calls), "fb_threads", "prove_subs".  The environment variables BPP_<NAME> give
+ * the initial values and are read ONCE, when the context is created: no verification path calls getenv. */
+int bpp_ctx_set_option(bpp_ctx *ctx, const char *name, int value);
 
 /* ---- B1: multiscalar traits ----
  * bpp_precomp_create  = VartimePrecomputedMultiscalarMul::new(static_points)   (src/generators/bulletproof_gens.rs:103)
@@ -253,6 +258,14 @@ typedef struct {
 } bpp_shard_result;
 int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t *batches, size_t k, const uint32_t *counts,
                             bpp_shard_result *results);
+/* host wall-clock split of the last wave on `comm` (ms): enqueueing phase 1 on the k streams, waiting for it, the first
+ * exchange (trailers up, all_gather, everything down), the k weight chains, enqueueing phase 2, waiting for it, the second
+ * exchange with the sum and identity test */
+typedef struct {
+  float enqueue1_ms, wait1_ms, gather1_ms, chains_ms, enqueue2_ms, wait2_ms, gather2_ms;
+  uint32_t batches;
+} bpp_shard_timing;
+int bpp_comm_last_timing(bpp_comm *comm, bpp_shard_timing *out);
 /* host-only pieces of the above, exported for callers that bring their own transport and for the CPU tests
  * (tests/test_dist_gloo.py): the 128-byte finding a rank contributes, and the rule every rank applies to the gathered ones.
  *   bpp_shard_local_trailer: first finding of a rank's n proofs from the per-proof facts -- defer[i] (bit 0: extension

@@ -25,3 +25,16 @@ def engine(bpp):
     eng = bpp.Engine(0)
     yield eng
     eng.close()
+
+
+@pytest.fixture
+def opt(engine):
+    """set per-context knobs of the session engine for one test (bpp_ctx_set_option); restored afterwards"""
+    touched = []
+
+    def set_option(name, value):
+        engine.set_option(name, value)
+        touched.append(name)
+    yield set_option
+    for name in touched:
+        engine.set_option(name, -1)

@@ -183,6 +183,21 @@ def test_oversized_proof_does_not_inflate_the_batch(bpp, engine):
         assert _kind(bpp, lambda: rb.verify(A.VerifyOnly, chunk=1)) == want
         assert len(rb.trace(1)) == 4 * (rb.shape()["max_rounds"] + 3) * 32
         rb.close()
+    # the engine's own cap (layout.h BPP_MAX_WIRE_ROUNDS = 64 pairs): at the cap the proof is still replayed and reported with
+    # PASS-2 precedence (an identity member of a LATER proof, a PASS-1 finding, comes first); one pair more is refused at
+    # upload, same error kind, and quickly: no kernel ever walks a proof longer than the cap
+    import time
+    at_cap = bpp.RangeProof.from_bytes(raw + lr * 61)
+    r3 = bytearray(c.proofs[3].to_bytes())
+    r3[1 + 32:1 + 64] = bytes(32)
+    ident = bpp.RangeProof.from_bytes(bytes(r3))
+    V = lambda proofs: bpp.RangeProof.verify_batch(c.transcripts(), c.statements_public, proofs, A.VerifyOnly, chunk=0)
+    assert _kind(bpp, lambda: V([c.proofs[0], at_cap, c.proofs[2], c.proofs[3]])) == K.SizeOverflow
+    assert _kind(bpp, lambda: V([c.proofs[0], at_cap, c.proofs[2], ident])) == K.VerificationFailed
+    t0 = time.perf_counter()
+    assert _kind(bpp, lambda: V([c.proofs[0], raw + lr * 62, c.proofs[2], ident])) == K.SizeOverflow
+    assert _kind(bpp, lambda: V([c.proofs[0], raw + lr * 100000, c.proofs[2], ident])) == K.SizeOverflow  # a 6.4 MB "proof"
+    assert time.perf_counter() - t0 < 2.0
     # the same proofs without the oversized one still verify on the same engine
     assert bpp.RangeProof.verify_batch(c.transcripts(), c.statements_public, c.proofs, A.VerifyOnly, chunk=2) == [None] * 4
 

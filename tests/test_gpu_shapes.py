@@ -36,7 +36,7 @@ def _product(bpp, engine, n, m_max, t, items, private=True):
 
 
 @pytest.mark.parametrize("n,m,t,count", [(64, 32, 1, 2), (64, 16, 6, 2), (2, 1, 1, 3), (1, 2, 2, 2), (16, 8, 3, 3), (64, 1, 6, 4)])
-def test_verifier_edge_shapes(bpp, engine, n, m, t, count, monkeypatch):
+def test_verifier_edge_shapes(bpp, engine, n, m, t, count, opt):
     cp, items, raw = _make(n, m, t, count, b"edge-%d-%d-%d" % (n, m, t))
     params, sts, proofs, trs = _product(bpp, engine, n, m, t, items)
     rc, want_masks, tr = cp.verify(items, action=1, want_trace=True)
@@ -45,8 +45,8 @@ def test_verifier_edge_shapes(bpp, engine, n, m, t, count, monkeypatch):
     # one-lane-per-proof kernels of the throughput path (LDS-resident sponge, lane-built tables) onto the same shapes
     for force_lane_kernels in (False, True):
         if force_lane_kernels:
-            monkeypatch.setenv("BPP_TRANSCRIPTS_WAVE", "0")
-            monkeypatch.setenv("BPP_TABLES_WAVE", "0")
+            opt("transcripts_wave", 0)
+            opt("tables_wave", 0)
         rb = bpp.ResidentBatch(trs, sts, proofs)
         masks = rb.verify(bpp.VerifyAction.RecoverAndVerify, chunk=0)
         assert [mk.blindings() if mk else None for mk in masks] == want_masks
@@ -54,8 +54,8 @@ def test_verifier_edge_shapes(bpp, engine, n, m, t, count, monkeypatch):
         assert rb.trace(4) == tr["static_scalars"] and rb.trace(5) == tr["dynamic_scalars"]
         assert rb.trace(6) == tr["msm_result"] == bytes(32)
         rb.close()
-    monkeypatch.delenv("BPP_TRANSCRIPTS_WAVE", raising=False)
-    monkeypatch.delenv("BPP_TABLES_WAVE", raising=False)
+    opt("transcripts_wave", -1)
+    opt("tables_wave", -1)
     cp.close()
     # the engine's prover reproduces the same bytes at this shape
     wits = [bpp.RangeWitness.init([bpp.CommitmentOpening.new(r["vals"][j], r["blinds"][j]) for j in range(m)]) for r in raw]

@@ -142,11 +142,11 @@ def test_intermediates_bit_exact(bpp, engine, n, batch, t):
 
 
 @pytest.mark.parametrize("wave", ["0", "1"])
-def test_both_pass1_kernels(bpp, engine, monkeypatch, wave):
+def test_both_pass1_kernels(bpp, engine, opt, wave):
     """PASS 1 has a one-lane-per-proof kernel (large inputs) and a one-wavefront-per-proof kernel on the cooperative
     sponge (small inputs); force each: challenges and transcript-RNG bytes must equal the oracle's, identity members must
     be reported by both"""
-    monkeypatch.setenv("BPP_TRANSCRIPTS_WAVE", wave)
+    opt("transcripts_wave", int(wave))
     case = make_batch(bpp, engine, 16, [1, 2, 1, 4], 2, seed=b"pass1-kernels")
     _, tr = oracle_verify_trace(case, action=0)
     rb = bpp.ResidentBatch(case.transcripts(), case.statements_public, case.proofs)
@@ -165,10 +165,10 @@ def test_both_pass1_kernels(bpp, engine, monkeypatch, wave):
 
 @pytest.mark.parametrize("wave", ["0", "1"])
 @pytest.mark.parametrize("n,ms", [(16, [1, 2, 1, 4]), (2, [1, 4, 2]), (64, [8, 1])])
-def test_both_table_kernels(bpp, engine, monkeypatch, wave, n, ms):
+def test_both_table_kernels(bpp, engine, opt, wave, n, ms):
     """the tables of the generator-row kernel are built by one lane per proof (large inputs) or one wavefront per proof (small
     inputs); force each: static and dynamic MSM scalars must equal the oracle's for mixed aggregation and small bit lengths"""
-    monkeypatch.setenv("BPP_TABLES_WAVE", wave)
+    opt("tables_wave", int(wave))
     case = make_batch(bpp, engine, n, ms, 2, seed=b"table-kernels-%d" % n)
     _, tr = oracle_verify_trace(case, action=0)
     rb = bpp.ResidentBatch(case.transcripts(), case.statements_public, case.proofs)
@@ -181,10 +181,10 @@ def test_both_table_kernels(bpp, engine, monkeypatch, wave, n, ms):
 
 
 @pytest.mark.parametrize("bias", ["0", "1", "3", "7"])
-def test_small_call_window_widths(bpp, engine, monkeypatch, bias):
+def test_small_call_window_widths(bpp, engine, opt, bias):
     """small calls take wider MSM windows than the throughput rule gives (BPP_MSM_C_BIAS, default 3): every width from 4 to 11
     bits goes through the quad bucket kernels here, on multiscalar products of 1..300 terms and on small proof batches"""
-    monkeypatch.setenv("BPP_MSM_C_BIAS", bias)
+    opt("msm_c_bias", int(bias))
     for n in (1, 2, 5, 40, 300):
         pts = [C.from_uniform_bytes(_h(b"cw-p", i, 64)) for i in range(min(n, 24))]
         pts = [pts[i % len(pts)] for i in range(n)]
@@ -204,10 +204,10 @@ def test_small_call_window_widths(bpp, engine, monkeypatch, bias):
 
 
 @pytest.mark.parametrize("side", ["0", "1"])
-def test_decompression_beside_pass1(bpp, engine, monkeypatch, side):
+def test_decompression_beside_pass1(bpp, engine, opt, side):
     """small inputs decompress on a second stream while PASS 1 runs; force each form: same dynamic points, same verdicts, and an
     undecodable point plus a transcript failure in one batch still surface in the reference's order"""
-    monkeypatch.setenv("BPP_SIDE_DECOMPRESS", side)
+    opt("side_decompress", int(side))
     case = make_batch(bpp, engine, 16, [1, 2, 4, 1, 1], 1, seed=b"side-decompress")
     _, tr = oracle_verify_trace(case, action=0)
     for _ in range(3):  # the streams are reused call after call
@@ -236,10 +236,10 @@ def test_decompression_beside_pass1(bpp, engine, monkeypatch, side):
 
 
 @pytest.mark.parametrize("quad", ["0", "1"])
-def test_both_bucket_kernel_forms(bpp, engine, monkeypatch, quad):
+def test_both_bucket_kernel_forms(bpp, engine, opt, quad):
     """bucket accumulation / row-column reduction exist in a one-lane-per-bucket form (many buckets) and a quad form (few
     buckets, latency); force each on the same input: MSM result, accept / reject and the B1 multiscalar API must agree"""
-    monkeypatch.setenv("BPP_MSM_QUAD", quad)
+    opt("msm_quad", int(quad))
     case = make_batch(bpp, engine, 32, [1, 2, 1, 1, 4, 1], 1, seed=b"bucket-forms")
     rb = bpp.ResidentBatch(case.transcripts(), case.statements_public, case.proofs)
     assert rb.verify(bpp.VerifyAction.VerifyOnly, chunk=0) == [None] * 6

@@ -3,7 +3,7 @@ bytes) and the shared arithmetic headers under AddressSanitizer + UBSan (SURVEY 
 
 Cases (csrc/hosttest_upload.cpp): reference error kinds of from_bytes on every truncation, random mutations, the
 two-loop precedence of verify_statements_and_generators_consistency (src/range_proof.rs:637-682), the layout count ==
-kernel count invariant for a proof with 2^20 (L, R) pairs, refusal above that."""
+kernel count invariant for a proof with the largest accepted number of (L, R) pairs (BPP_MAX_WIRE_ROUNDS), refusal above that."""
 import importlib
 import os
 import subprocess

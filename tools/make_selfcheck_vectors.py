@@ -61,11 +61,15 @@ def case(name, n, batch, t, strategy):
                        "bumped_promise_verify_only": res(lambda: O.verify_batch(T(), bumped, proofs, 0))}}
 
 
-if __name__ == "__main__":
-    out = sys.argv[1] if len(sys.argv) > 1 else "/tmp/selfcheck_ref_vectors.json"
+def build_doc():
     cases = [case("single_n8_t1", 8, [1], 1, "none"), case("aggregated4_n4_t2", 4, [4], 2, "third"), case("mixed_1_2_n8_t3", 8, [1, 2], 3, "eq")]
     p = O.RangeParameters(64, 2, O.PedersenGens(6))
     anchors = {"h_base": p.pc_gens.h_base_compressed.hex(), "g_bases": [g.hex() for g in p.pc_gens.g_base_compressed_vec],
                "gi": [g.compress().hex() for g in p.gi_base()], "hi": [g.compress().hex() for g in p.hi_base()]}
-    json.dump({"source": "ORACLE self-check (not the reference)", "cases": cases, "anchors_n64_m2_t6": anchors}, open(out, "w"))
+    return {"source": "ORACLE self-check (not the reference)", "cases": cases, "anchors_n64_m2_t6": anchors}
+
+
+if __name__ == "__main__":
+    out = sys.argv[1] if len(sys.argv) > 1 else "/tmp/selfcheck_ref_vectors.json"
+    json.dump(build_doc(), open(out, "w"))
     print("wrote", out)
