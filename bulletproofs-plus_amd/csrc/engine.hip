@@ -238,8 +238,7 @@ SharedRegistry<Precomp> &precomp_registry() {
 }
 
 struct MsmWork {
-  DevBuf<int16_t> digits;
-  DevBuf<uint32_t> counts, starts, sorted, order, order_hist;
+  DevBuf<uint32_t> counts, starts, sorted, order;
   DevBuf<ge> buckets, Q, W, R;
   DevBuf<uint8_t> comp32;
   DevBuf<uint32_t> is_identity;
@@ -298,8 +297,8 @@ void adopt_buffers(Batch &dst, Batch &src) {
   BPP_ADOPT(src_off); BPP_ADOPT(owner); BPP_ADOPT(idx_commit); BPP_ADOPT(idx_proof); BPP_ADOPT(status0); BPP_ADOPT(chal);
   BPP_ADOPT(rows); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(tab); BPP_ADOPT(rng_out); BPP_ADOPT(weights);
   BPP_ADOPT(masks); BPP_ADOPT(chal_bytes); BPP_ADOPT(status); BPP_ADOPT(group_first); BPP_ADOPT(group_dlo); BPP_ADOPT(dynpts); BPP_ADOPT(dec_spill);
-  BPP_ADOPT(msm.digits); BPP_ADOPT(msm.counts); BPP_ADOPT(msm.starts); BPP_ADOPT(msm.sorted); BPP_ADOPT(msm.order);
-  BPP_ADOPT(msm.order_hist); BPP_ADOPT(msm.buckets); BPP_ADOPT(msm.Q); BPP_ADOPT(msm.W); BPP_ADOPT(msm.R); BPP_ADOPT(msm.comp32);
+  BPP_ADOPT(msm.counts); BPP_ADOPT(msm.starts); BPP_ADOPT(msm.sorted); BPP_ADOPT(msm.order);
+  BPP_ADOPT(msm.buckets); BPP_ADOPT(msm.Q); BPP_ADOPT(msm.W); BPP_ADOPT(msm.R); BPP_ADOPT(msm.comp32);
   BPP_ADOPT(msm.is_identity); BPP_ADOPT(msm.term_sidx); BPP_ADOPT(msm.term_pidx); BPP_ADOPT(msm.group_off);
   BPP_ADOPT(h_rng); BPP_ADOPT(h_weights); BPP_ADOPT(h_status); BPP_ADOPT(h_ident);
 #undef BPP_ADOPT
@@ -479,12 +478,10 @@ void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff)
   w.plan = plan;
   w.max_group_terms = maxg;
   const size_t nbk = (size_t)G * plan.K * plan.nb;
-  w.digits.alloc((size_t)n * plan.K);
   w.counts.alloc(nbk);
   w.starts.alloc(nbk);
   w.sorted.alloc((size_t)n * plan.K);
   w.order.alloc(nbk);
-  w.order_hist.alloc((size_t)G * 512);
   w.buckets.alloc(nbk);
   w.Q.alloc((size_t)G * plan.K * plan.c);
   w.W.alloc((size_t)G * plan.K);
@@ -516,20 +513,12 @@ void msm_prepare(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &sidx, co
 
 void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, StageTimer *tm) {
   const MsmPlan plan = w.plan;
-  const size_t nbk = (size_t)plan.G * plan.K * plan.nb;
   hipStream_t s = ctx->stream;
-  dim3 gt(cdiv(w.max_group_terms, 256), plan.G);
-  hipLaunchKernelGGL(k_msm_digits, gt, dim3(256), 0, s, scalars, w.term_sidx.p, w.group_off.p, plan, w.digits.p);
-  if (tm) tm->mark(M_DIGITS);
-  hipLaunchKernelGGL(k_msm_sort, dim3(plan.K, plan.G), dim3(BPP_SORT_THREADS), 2 * plan.nb * sizeof(uint32_t), s, w.digits.p, w.group_off.p,
-                     w.term_pidx.p, plan, w.counts.p, w.starts.p, w.sorted.p);
-  if (tm) tm->mark(M_SORT);
+  // digits + counting sort + size ordering: one launch (msm.h: k_msm_prelude)
   const uint32_t per_group = plan.K * plan.nb;
-  HIP_CHECK(hipMemsetAsync(w.order_hist.p, 0, (size_t)plan.G * 512 * 4, s));
-  dim3 og(cdiv(per_group, 1024), plan.G);
-  hipLaunchKernelGGL(k_order_hist, og, dim3(1024), 0, s, w.counts.p, per_group, w.order_hist.p);
-  hipLaunchKernelGGL(k_order_scatter, og, dim3(1024), 0, s, w.counts.p, per_group, w.order_hist.p,
-                     w.order_hist.p + (size_t)plan.G * 256, w.order.p);
+  const uint32_t dig_cap = msm_prelude_dig_cap(plan, w.max_group_terms);
+  hipLaunchKernelGGL(k_msm_prelude, dim3(8 * cdiv(plan.G, 8) * plan.K), dim3(BPP_SORT_THREADS), msm_prelude_lds(plan, dig_cap), s, scalars,
+                     w.term_sidx.p, w.term_pidx.p, w.group_off.p, plan, dig_cap, w.counts.p, w.starts.p, w.sorted.p, w.order.p);
   if (tm) tm->mark(M_ORDER);  // msm_accumulate_ms brackets k_msm_accumulate alone (the roofline kernel)
   // few buckets on an idle chip (one batch per call): quad forms, ~3x shorter dependency chains (tests force either form)
   const bool small = ctx->opt.msm_quad >= 0 ? ctx->opt.msm_quad != 0 : (size_t)plan.G * per_group <= 100000;
@@ -1524,18 +1513,11 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
   sc *dyn_scal = b.scal.p + (size_t)b.G * b.cols;
   {
     const uint32_t nhi_max = b.lanes_nhi_max(P.n_bits);
-    // as in enqueue_phase1: small inputs take the one-wavefront-per-proof forms
-    const bool tw = ctx->opt.tables_wave >= 0 ? ctx->opt.tables_wave != 0 : b.B <= BPP_TABLES_WAVE_MAX;
-    if (tw)
-      hipLaunchKernelGGL(k_scalars_weighted_wave, dim3(b.B), dim3(64), 0, s, b.d_desc.p, b.shr.p, b.weights.p, P.n_bits, P.t,
-                         b.max_mn, b.cols, b.B, nhi_max, b.tab.p, b.rows.p, dyn_scal);
-    else
-      hipLaunchKernelGGL(k_scalars_weighted, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.d_desc.p, b.shr.p, b.weights.p, P.n_bits, P.t,
-                         b.max_mn, b.cols, b.B, nhi_max, b.tab.p, b.rows.p, dyn_scal);
-    // proofs per workgroup: enough (proof, generator pair) items for four passes of the 64 lanes
+    // proofs per workgroup: enough (proof, generator pair) items for four passes of the 64 lanes.  The weighted part of the
+    // scalar block (dynamic scalars, base columns, w into the low tables) is this kernel's prologue.
     const uint32_t ppw = std::max<uint32_t>(1, std::min<uint32_t>(BPP_LANES_MAX_PPW, 256 / std::max<uint32_t>(1, b.max_mn)));
-    hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s, b.d_desc.p, b.tab.p,
-                       P.n_bits, b.max_mn, b.cols, b.B, nhi_max, ppw, b.rows.p);
+    hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s, b.d_desc.p, b.tab.p, b.shr.p,
+                       b.weights.p, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, b.rows.p, dyn_scal);
   }
   tm.mark(M_LANES);
   hipLaunchKernelGGL(k_reduce_static, dim3(cdiv(b.cols, BPP_REDUCE_TILE), b.G), dim3(64), 0, s, b.rows.p, b.group_first.p, b.cols,
@@ -1555,8 +1537,8 @@ void collect_profile(bpp_ctx *ctx, Batch &b, StageTimer &tm, float chain_ms, flo
   pf.scalars_ms = tm.between(M_DECOMPRESS, M_SCALARS) + tm.between(M_WEIGHTS_IN, M_LANES);  // shared + lanes
   pf.chain_host_ms = chain_ms;
   pf.reduce_ms = tm.between(M_LANES, M_REDUCE);
-  pf.msm_digits_ms = tm.between(M_REDUCE, M_DIGITS);
-  pf.msm_sort_ms = tm.between(M_DIGITS, M_ORDER);  // counting sort + size ordering of the buckets
+  pf.msm_digits_ms = 0;                             // (digits are part of the sort kernel since round 3)
+  pf.msm_sort_ms = tm.between(M_REDUCE, M_ORDER);   // k_msm_prelude: digits + counting sort + size ordering of the buckets
   pf.msm_accumulate_ms = tm.between(M_ORDER, M_ACC);
   pf.msm_bucket_reduce_ms = tm.between(M_ACC, M_BUCKET);
   pf.msm_final_ms = tm.between(M_BUCKET, M_FINAL);

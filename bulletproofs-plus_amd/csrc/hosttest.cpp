@@ -98,6 +98,8 @@ int ht_msm_recode(const uint8_t a[32], uint32_t c, int16_t *digits /* K */, uint
   sc x; sc_load_words(x, a);
   const MsmPlan plan = msm_make_plan(c, 1, 1);
   msm_recode(digits, 1, x, plan);
+  for (uint32_t k = 0; k < plan.K; k++)  // the one-window form must give the same digit (msm.h: k_msm_prelude uses it)
+    if (msm_digit_at(x.v, plan, k) != (int32_t)digits[k]) return -1;
   for (uint32_t k = 0; k < plan.K; k++) widths[k] = k < plan.K_wide ? plan.c : plan.c - 1;
   return (int)plan.K; }
 int ht_fb_recode(const uint8_t a[32], uint32_t n_gens, int16_t *digits /* 32 */, uint32_t *wbits) {

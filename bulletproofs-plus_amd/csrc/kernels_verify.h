@@ -248,12 +248,12 @@ __global__ void __launch_bounds__(64) k_from_uniform(const uint8_t *__restrict__
 
 // ---------------------------------------------------------------------------------------------
 // PASS 2 scalar block (src/range_proof.rs:894-1033).  The host weight chain (1.3 ms per 64 x 1024 proofs) runs while
-// PASS 1, decompression and k_scalars_shared execute; the weights enter in k_scalars_weighted:
+// PASS 1, decompression and k_scalars_shared execute; the weights enter in k_scalars_lanes' prologue:
 //   k_scalars_shared    1 lane / proof : batch inversion (divsteps), powers, sums -> shr[p][*], and the weight-free
 //                                        low / high tables of k_scalars_lanes -> tab[p][*]              (no weight)
-//   k_scalars_weighted  1 lane / proof : w x (low tables, e^2 z) in place, the dynamic scalars (canonical) and the
-//                                        g / h base columns of the proof's row
-//   k_scalars_lanes     1 wave / ppw proofs : tables -> LDS, lanes over (proof, generator index) -> WEIGHTED rows
+//   k_scalars_lanes     1 wave / ppw proofs : w x (low tables, e^2 z) while the tables go to LDS, the dynamic scalars
+//                                        (canonical) and the g / h base columns, one product per lane and job; then lanes
+//                                        over (proof, generator index) -> WEIGHTED rows
 //   k_reduce_static                    : per group, column sums of the rows (additions only)
 // A product costs the same ~270 instructions whether one lane of the wavefront needs it or all 64: everything that exists
 // once per proof or once per table entry is therefore computed with one lane per PROOF (64 proofs per wavefront), and
@@ -567,159 +567,6 @@ __global__ void __launch_bounds__(64) k_scalars_tables_wave(const ProofDesc *__r
   }
 }
 
-// The weighted part of the scalar block, one lane per proof (src/range_proof.rs:894, :1006-1032): w into the three low
-// tables and e^2 z (in place in tab[]), the proof's dynamic scalars and its g / h base columns.  A Montgomery product with
-// one CANONICAL operand is the canonical product, so the dynamic scalars (which k_msm_digits wants canonical) take the
-// weight as it arrives and need no conversion:
-//   C_j: (-e^2 y^{mn+1} w) z^{2(j+1)};  A1: -e w;  B: -w;  A: -e^2 w;  L_j: (-e^2 w) e_j^2;  R_j: (-e^2 w) e_j^-2
-__global__ void __launch_bounds__(64) k_scalars_weighted(const ProofDesc *__restrict__ desc, const sc *__restrict__ shr,
-                                                         const uint8_t *__restrict__ weights32, uint32_t n_bits, uint32_t t,
-                                                         uint32_t max_mn, uint32_t cols, uint32_t B, uint32_t nhi_max,
-                                                         sc *tab, sc *__restrict__ rows, sc *__restrict__ dyn_out) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= B) return;
-  const ProofDesc d = desc[p];
-  const uint32_t r = d.rounds, m = d.m;
-  const uint32_t LB = lanes_lb(n_bits), nlo = 1u << LB;
-  if (!lanes_shape_ok(r, m, nhi_max, LB)) return;
-  const sc *S = shr + (size_t)p * SH_STRIDE;
-  sc *T = tab + (size_t)p * lanes_tab_stride(nhi_max);
-  sc *glo = T, *yn2lo = T + 8, *hlo = T + 16, *e2z = T + 24 + 3 * nhi_max;
-  sc wc, w, ne2w_m;
-  sc_load_words(wc, weights32 + (size_t)p * 32);
-  sc_to_mont(w, wc);
-  sc_montmul(ne2w_m, S[SH_NEG_E2], w);  // -w e^2, Montgomery
-  for (uint32_t v = 0; v < nlo; v++) {
-    sc x = glo[v];
-    sc_montmul(x, x, w);
-    glo[v] = x;
-    x = hlo[v];
-    sc_montmul(x, x, w);
-    hlo[v] = x;
-    x = yn2lo[v];
-    sc_montmul(x, x, ne2w_m);  // -w e^2 y^mn y^-lo 2^klo
-    yn2lo[v] = x;
-  }
-  {
-    sc x;
-    sc_montmul(x, S[SH_E2Z], w);
-    *e2z = x;
-  }
-  sc *dyn = dyn_out + d.dyn_off;
-  {
-    const sc z_square = S[SH_Z2];
-    sc nyw, zz = z_square;
-    sc_montmul(nyw, S[SH_NEG_E2_YNM1], wc);
-    for (uint32_t j = 0; j < m; j++) {
-      sc x;
-      sc_montmul(x, zz, nyw);
-      dyn[j] = x;
-      if (j + 1 < m) sc_montmul(zz, zz, z_square);
-    }
-  }
-  {
-    sc x, ne;
-    sc_neg(ne, S[SH_E]);
-    sc_montmul(x, ne, wc);
-    dyn[m] = x;
-    sc_neg(x, wc);
-    dyn[m + 1] = x;
-    sc ne2w;
-    sc_montmul(ne2w, S[SH_NEG_E2], wc);
-    dyn[m + 2] = ne2w;
-    for (uint32_t j = 0; j < r; j++) {
-      sc_montmul(x, ne2w, S[SH_ESQ(j)]);
-      dyn[m + 3 + j] = x;
-      sc_montmul(x, ne2w, S[SH_ESQINV(j)]);
-      dyn[m + 3 + r + j] = x;
-    }
-  }
-  sc *row = rows + (size_t)p * cols;
-  {
-    sc x;
-    sc_montmul(x, S[SH_HS], w);
-    row[2 * max_mn + t] = x;
-    for (uint32_t k = 0; k < t; k++) {
-      sc_montmul(x, S[SH_D1(k)], w);
-      row[2 * max_mn + k] = x;
-    }
-  }
-}
-
-// The same for SMALL inputs, one wavefront per proof: every product above is one job (3 * 2^LB table entries, e^2 z, the
-// m + 3 + 2r dynamic scalars, the t + 1 base columns: 43 jobs for a 64-bit proof), and all of them are "one stored value
-// times one of five multipliers" once w, -w e^2 (both forms) and -w e^2 y^(mn+1) exist.  Each lane derives the multipliers
-// (4 products) and does its own job: 5-6 products deep instead of 45 (0.029 -> 0.008 ms at 256 proofs).  Same products on the
-// same operands as k_scalars_weighted, so the same bits.
-__global__ void __launch_bounds__(64) k_scalars_weighted_wave(const ProofDesc *__restrict__ desc, const sc *__restrict__ shr,
-                                                              const uint8_t *__restrict__ weights32, uint32_t n_bits, uint32_t t,
-                                                              uint32_t max_mn, uint32_t cols, uint32_t B, uint32_t nhi_max,
-                                                              sc *tab, sc *__restrict__ rows, sc *__restrict__ dyn_out) {
-  const uint32_t p = blockIdx.x, lane = threadIdx.x;
-  if (p >= B) return;
-  const ProofDesc d = desc[p];
-  const uint32_t r = d.rounds, m = d.m;
-  const uint32_t LB = lanes_lb(n_bits), nlo = 1u << LB;
-  if (!lanes_shape_ok(r, m, nhi_max, LB)) return;
-  const sc *S = shr + (size_t)p * SH_STRIDE;
-  sc *T = tab + (size_t)p * lanes_tab_stride(nhi_max);
-  sc *glo = T, *yn2lo = T + 8, *hlo = T + 16, *e2z = T + 24 + 3 * nhi_max;
-  sc *dyn = dyn_out + d.dyn_off;
-  sc *row = rows + (size_t)p * cols;
-  sc wc, w, ne2w_m, ne2w, nyw;
-  sc_load_words(wc, weights32 + (size_t)p * 32);
-  sc_to_mont(w, wc);
-  sc_montmul(ne2w_m, S[SH_NEG_E2], w);       // -w e^2, Montgomery
-  sc_montmul(ne2w, S[SH_NEG_E2], wc);        // -w e^2, canonical
-  sc_montmul(nyw, S[SH_NEG_E2_YNM1], wc);    // -w e^2 y^(mn+1), canonical
-  const uint32_t j_e2z = 3 * nlo, j_c = j_e2z + 1, j_a1 = j_c + m, j_lr = j_a1 + 3, j_row = j_lr + 2 * r, n_jobs = j_row + 1 + t;
-  for (uint32_t job = lane; job < n_jobs; job += 64) {
-    const sc *src;
-    sc *dst;
-    uint32_t sel;  // multiplier: 0 w, 1 -w e^2 (Montgomery), 2 -w e^2 (canonical), 3 -w e^2 y^(mn+1), 4 the weight as it came
-    uint32_t zpow = 0;  // C_j: z^(2(j+1)) from z^2 by j more products
-    bool neg = false, plain_neg = false;
-    if (job < nlo) src = dst = glo + job, sel = 0;
-    else if (job < 2 * nlo) src = dst = hlo + (job - nlo), sel = 0;
-    else if (job < 3 * nlo) src = dst = yn2lo + (job - 2 * nlo), sel = 1;
-    else if (job == j_e2z) src = S + SH_E2Z, dst = e2z, sel = 0;
-    else if (job < j_a1) src = S + SH_Z2, dst = dyn + (job - j_c), sel = 3, zpow = job - j_c;
-    else if (job == j_a1) src = S + SH_E, dst = dyn + m, sel = 4, neg = true;               // A1: -e w
-    else if (job == j_a1 + 1) src = S + SH_E, dst = dyn + m + 1, sel = 4, plain_neg = true;  // B: -w
-    else if (job == j_a1 + 2) src = S + SH_NEG_E2, dst = dyn + m + 2, sel = 4;               // A: -e^2 w
-    else if (job < j_row) {
-      const uint32_t k = job - j_lr;
-      src = k < r ? S + SH_ESQ(k) : S + SH_ESQINV(k - r);
-      dst = dyn + m + 3 + k;
-      sel = 2;
-    } else {
-      const uint32_t k = job - j_row;  // 0: the h base, 1 + k: g base k
-      src = k == 0 ? S + SH_HS : S + SH_D1(k - 1);
-      dst = row + 2 * max_mn + (k == 0 ? t : k - 1);
-      sel = 0;
-    }
-    sc a = *src, x;
-    if (zpow) {
-      const sc z2 = a;
-      for (uint32_t i = 0; i < zpow; i++) sc_montmul(a, a, z2);
-    }
-    if (neg) sc_neg(a, a);
-    sc mult = w;
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      uint32_t v = w.v[q];
-      v = sel == 1 ? ne2w_m.v[q] : v;
-      v = sel == 2 ? ne2w.v[q] : v;
-      v = sel == 3 ? nyw.v[q] : v;
-      v = sel == 4 ? wc.v[q] : v;
-      mult.v[q] = v;
-    }
-    sc_montmul(x, a, mult);
-    if (plain_neg) sc_neg(x, wc);
-    *dst = x;
-  }
-}
-
 // Generator scalars.  With i = (hi << LB) | lo, s[i] = slo[lo]*shi[hi] and y^-i = ylo[lo]*yhi[hi] (products over the bits of
 // i), so every per-index quantity is ONE product of a "low" and a "high" table entry:
 //   g[i]                     = w r1e y^-i s[i]                 = glo[lo]   * ghi[hi]    glo = w*r1e*ylo*slo,  ghi = yhi*shi
@@ -732,51 +579,131 @@ __global__ void __launch_bounds__(64) k_scalars_weighted_wave(const ProofDesc *_
 // (hlo*shi + yn2lo*y2hi) - e2z with both products accumulated in the same columns (sc9_montmul2); e2z = w e^2 z.  The proof's
 // batch weight w (src/range_proof.rs:894) sits in the three low tables and e2z, so the rows come out WEIGHTED and the
 // per-group column sums need no product at all (round 1: 5 products per pair here and 2 more in k_reduce_static).  The tables
-// come from tab[] (k_scalars_shared, k_scalars_weighted) and are unpacked ONCE per entry into nine 29-bit limbs in LDS
+// come from tab[] (k_scalars_shared / k_scalars_tables_wave; the weight is folded in on the way) and are unpacked ONCE per entry into nine 29-bit limbs in LDS
 // (sc9) instead of once per use.  Dynamic LDS per proof:
-//   sc9: glo[8] yn2lo[8] hlo[8] | ghi[nhi_max] y2hi[nhi_max] shi[nhi_max]      sc: e2z
+//   sc9: glo[8] yn2lo[8] hlo[8] (weighted) | ghi[nhi_max] y2hi[nhi_max] shi[nhi_max]      sc: e2z (weighted)
 BPP_HD constexpr uint32_t lanes_lds_bytes(uint32_t nhi_max) {
   return (lanes_tab_stride(nhi_max) - 1u) * (uint32_t)sizeof(sc9) + (uint32_t)sizeof(sc);
 }
 
 // One workgroup serves `ppw` consecutive proofs (a 64-bit single-commitment proof has 64 generator pairs: four proofs
-// make four full passes of the 64 lanes); both phases run over flattened (proof, index) items.
+// make four full passes of the 64 lanes); all phases run over flattened (proof, item) items.
+//
+// The WEIGHTED part of the scalar block (src/range_proof.rs:894, :1006-1032) is this kernel's prologue (until round 3 a
+// launch of its own, k_scalars_weighted: one lane per proof, 45 products deep, one more kernel queueing behind the other
+// steps' work): the proof's batch weight w goes into the three low tables and e^2 z while they are unpacked into LDS
+// (nothing is written back: tab[] stays weight-free), and the proof's m + 3 + 2r dynamic scalars and t + 1 base columns are
+// one product each, spread over the lanes:
+//   C_j: (-e^2 y^{mn+1} w) z^{2(j+1)};  A1: -e w;  B: -w;  A: -e^2 w;  L_j: (-e^2 w) e_j^2;  R_j: (-e^2 w) e_j^-2
+// A Montgomery product with one CANONICAL operand is the canonical product, so the dynamic scalars (which the MSM wants
+// canonical) take the weight as it arrives and need no conversion.  Same products on the same operands as the old kernels.
 #define BPP_LANES_MAX_PPW 8
 __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restrict__ desc, const sc *__restrict__ tab,
-                                                      uint32_t n_bits, uint32_t max_mn, uint32_t cols, uint32_t B,
+                                                      const sc *__restrict__ shr, const uint8_t *__restrict__ weights32,
+                                                      uint32_t n_bits, uint32_t t, uint32_t max_mn, uint32_t cols, uint32_t B,
                                                       uint32_t nhi_max, uint32_t ppw,
-                                                      sc *__restrict__ rows /* weighted, Montgomery */) {
+                                                      sc *__restrict__ rows /* weighted, Montgomery */,
+                                                      sc *__restrict__ dyn_out /* canonical */) {
   const uint32_t p0 = blockIdx.x * ppw;
   const uint32_t lane = threadIdx.x;
   extern __shared__ uint32_t lanes_lds_raw[];
-  __shared__ uint32_t s_r[BPP_LANES_MAX_PPW], s_m[BPP_LANES_MAX_PPW];
+  __shared__ uint32_t s_r[BPP_LANES_MAX_PPW], s_m[BPP_LANES_MAX_PPW], s_dyn[BPP_LANES_MAX_PPW];
+  __shared__ sc s_mult[BPP_LANES_MAX_PPW][5];  // w, -w e^2 (Montgomery), -w e^2 (canonical), -w e^2 y^(mn+1) (canonical), the weight as it came
   const uint32_t ts = lanes_tab_stride(nhi_max), n9 = ts - 1u;  // entries per proof: n9 as limbs, then e2z packed
   const uint32_t per_bytes = lanes_lds_bytes(nhi_max);
   const uint32_t LB = lanes_lb(n_bits), nlo = 1u << LB;
   if (lane < ppw) {
     const uint32_t p = p0 + lane;
-    uint32_t r = ~0u, m = 0;
+    uint32_t r = ~0u, m = 0, dyn_off = 0;
     if (p < B) {
       const ProofDesc d = desc[p];
       if (lanes_shape_ok(d.rounds, d.m, nhi_max, LB)) r = d.rounds;
       m = d.m;
+      dyn_off = d.dyn_off;
     }
     s_r[lane] = r;  // ~0: nothing to do for this slot (past the end, or a shape rejected on the host before PASS 2)
     s_m[lane] = m;
+    s_dyn[lane] = dyn_off;
+    if (r != ~0u) {
+      const sc *S = shr + (size_t)p * SH_STRIDE;
+      sc wc, w, x;
+      sc_load_words(wc, weights32 + (size_t)p * 32);
+      sc_to_mont(w, wc);
+      s_mult[lane][0] = w;
+      sc_montmul(x, S[SH_NEG_E2], w);
+      s_mult[lane][1] = x;
+      sc_montmul(x, S[SH_NEG_E2], wc);
+      s_mult[lane][2] = x;
+      sc_montmul(x, S[SH_NEG_E2_YNM1], wc);
+      s_mult[lane][3] = x;
+      s_mult[lane][4] = wc;
+    }
   }
   __syncthreads();
-  // ---- tables -> LDS (entries a proof's shape does not use are never read)
+  // ---- tables -> LDS, the low ones and e^2 z times the weight (entries a proof's shape does not use are never read)
   for (uint32_t it = lane; it < ppw * ts; it += 64) {
     const uint32_t sub = it / ts, idx = it - sub * ts;
     if (s_r[sub] == ~0u) continue;
-    const sc v = tab[(size_t)(p0 + sub) * ts + idx];
+    const size_t p = p0 + sub;
     uint8_t *base = reinterpret_cast<uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes;
     if (idx < n9) {
+      sc v = tab[p * ts + idx];
+      if (idx < 24u && (idx & 7u) < nlo) {  // glo [0,8), yn2lo [8,16), hlo [16,24)
+        const sc mult = s_mult[sub][(idx >> 3) == 1u ? 1 : 0];
+        sc_montmul(v, v, mult);
+      }
       sc9 o9;
       sc9_from(o9, v);
       reinterpret_cast<sc9 *>(base)[idx] = o9;
     } else {
+      sc v;
+      sc_montmul(v, shr[p * SH_STRIDE + SH_E2Z], s_mult[sub][0]);  // w e^2 z
       *reinterpret_cast<sc *>(base + (size_t)n9 * sizeof(sc9)) = v;
+    }
+  }
+  // ---- dynamic scalars and base columns: one product per job
+  {
+    uint32_t jmax = 0;
+    for (uint32_t sub = 0; sub < ppw; sub++)
+      if (s_r[sub] != ~0u) jmax = max(jmax, s_m[sub] + 3u + 2u * s_r[sub] + t + 1u);
+    for (uint32_t it = lane; it < ppw * jmax; it += 64) {
+      const uint32_t sub = it / jmax, job = it - sub * jmax;
+      const uint32_t r = s_r[sub], m = s_m[sub];
+      if (r == ~0u || job >= m + 3u + 2u * r + t + 1u) continue;
+      const size_t p = p0 + sub;
+      const sc *S = shr + p * SH_STRIDE;
+      sc *dyn = dyn_out + s_dyn[sub];
+      sc *row = rows + p * cols;
+      const uint32_t j_a1 = m, j_lr = m + 3u, j_row = j_lr + 2u * r;
+      const sc *src;
+      sc *dst;
+      uint32_t sel, zpow = 0;  // multiplier index into s_mult; C_j: z^(2(j+1)) from z^2 by j more products
+      bool neg = false, plain_neg = false;
+      if (job < j_a1) src = S + SH_Z2, dst = dyn + job, sel = 3, zpow = job;
+      else if (job == j_a1) src = S + SH_E, dst = dyn + m, sel = 4, neg = true;               // A1: -e w
+      else if (job == j_a1 + 1) src = S + SH_E, dst = dyn + m + 1, sel = 4, plain_neg = true;  // B: -w
+      else if (job == j_a1 + 2) src = S + SH_NEG_E2, dst = dyn + m + 2, sel = 4;               // A: -e^2 w
+      else if (job < j_row) {
+        const uint32_t k = job - j_lr;
+        src = k < r ? S + SH_ESQ(k) : S + SH_ESQINV(k - r);
+        dst = dyn + m + 3 + k;
+        sel = 2;
+      } else {
+        const uint32_t k = job - j_row;  // 0: the h base, 1 + k: g base k
+        src = k == 0 ? S + SH_HS : S + SH_D1(k - 1);
+        dst = row + 2 * max_mn + (k == 0 ? t : k - 1);
+        sel = 0;
+      }
+      sc a = *src, x;
+      if (zpow) {
+        const sc z2 = a;
+        for (uint32_t i = 0; i < zpow; i++) sc_montmul(a, a, z2);
+      }
+      if (neg) sc_neg(a, a);
+      const sc mult = s_mult[sub][sel];
+      sc_montmul(x, a, mult);
+      if (plain_neg) sc_neg(x, mult);
+      *dst = x;
     }
   }
   __syncthreads();

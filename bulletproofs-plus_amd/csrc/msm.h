@@ -7,9 +7,9 @@
 //
 // One launch sequence serves G independent MSMs ("groups").  A term is (scalar index, point index); group g owns
 // terms [group_off[g], group_off[g+1]).  Pipeline:
-//   k_msm_digits      scalar -> K signed c-bit digits (window-major per group)
-//   k_msm_sort        LDS-staged counting sort, one workgroup per (group, window): bucket histogram + offsets in LDS,
-//                     term ids (sign in bit 31) grouped by |digit|; no global atomics
+//   k_msm_prelude     one workgroup per (group, window): digits of that window, LDS-staged counting sort (bucket histogram +
+//                     offsets in LDS, term ids with the sign in bit 31 grouped by |digit|; no global atomics), buckets
+//                     ordered by size
 //   k_msm_accumulate  one lane per bucket: sum of its points (mixed additions, 7M each)
 //   k_msm_bitsum      Q[g][k][b] = sum of buckets whose digit has bit b set   (wave tree reduction in LDS)
 //   k_msm_window      W[g][k]    = sum_b 2^b Q[g][k][b]
@@ -34,56 +34,67 @@ __device__ __forceinline__ const niels *point_ptr(const PointTables &t, uint32_t
 // (Non-temporal loads of the sorted lists and non-temporal 16-byte stores of the buckets were measured: FETCH_SIZE of
 // this kernel went from 389 to 1039 MB per launch, WRITE_SIZE from 240 to 595 MB, its duration from 0.84 to 0.98 ms.)
 
-// ---- signed digits.  grid = (ceil(maxGroupTerms/256), G), block 256.
-// Layout digitsT[goff[g]*K + k*ng + i] (window-major inside a group): the sort kernel reads one window contiguously ----
-__global__ void __launch_bounds__(256) k_msm_digits(const sc *__restrict__ scalars, const uint32_t *__restrict__ term_sidx,
-                                                    const uint32_t *__restrict__ group_off, MsmPlan plan,
-                                                    int16_t *__restrict__ digitsT) {
-  const uint32_t g = blockIdx.y;
-  const uint32_t t0 = group_off[g], t1 = group_off[g + 1], ng = t1 - t0;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ng) return;
-  const sc s = scalars[term_sidx[t0 + i]];
-  msm_recode(digitsT + (size_t)t0 * plan.K + i, ng, s, plan);
-}
-
-// ---- LDS-staged counting sort: one workgroup per (window, group) keeps that window's bucket table in LDS.
-// Pass 1 histograms the window's digits with LDS atomics, an in-LDS scan turns counts into offsets, pass 2 scatters
-// term ids (sign in bit 31) into sorted[] -- no global atomics, no global scan.  grid = (K, G), block 1024.
-// Region of (g, k) in sorted[]: [goff[g]*K + k*ng, +ng).  Dynamic LDS: 2 * nb u32. ----
+// ---- The MSM's prelude in ONE launch: digits, counting sort and size ordering of one window of one group per workgroup.
+// (Until round 3 these were four dependent launches -- k_msm_digits, k_msm_sort, k_order_hist, k_order_scatter -- plus a
+// memset, each queueing behind the other steps' 15 000-wavefront kernels: 1.3 ms of summed in-flight time for 0.3 ms of
+// work.)  Workgroup (g, k):
+//   pass 1  every term's digit of window k straight from its scalar (msm_digit_at: the two words around the window, the
+//           carry decided by the window below), kept in LDS as int16 for pass 2 (as many as fit), histogram by |digit| with
+//           LDS atomics
+//   scan    counts -> offsets (in LDS); counts[] / starts[] of the window's 2^(c-1) buckets
+//   pass 2  term ids (sign in bit 31) scattered into sorted[]: region of (g, k) = [goff[g]*K + k*ng, +ng)
+//   order   this window's buckets by descending size (counting sort over the counts clamped to 255) into
+//           order[(g*K + k)*nb ..]: the 64 lanes of an accumulation wavefront get equally long lists.  Ordering per
+//           window balances a wavefront as well as the per-group ordering did (a wavefront takes 64 consecutive slots).
+// XCD-aware mapping (blockIdx % 8 = XCD, as in k_msm_accumulate): all windows of group g run on XCD g % 8, so the group's
+// scalars are fetched into ONE L2 once and the lists written here are in the L2 that k_msm_accumulate reads them from.
+// grid = 8 * ceil(G/8) * K workgroups of 1024.  Dynamic LDS: 2 * nb u32 + dig_cap int16.
 #ifndef BPP_SORT_THREADS
 #define BPP_SORT_THREADS 1024
 #endif
-__global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_sort(const int16_t *__restrict__ digitsT, const uint32_t *__restrict__ group_off,
-                                                   const uint32_t *__restrict__ term_pidx, MsmPlan plan,
-                                                   uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
-                                                   uint32_t *__restrict__ sorted) {
+__global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__restrict__ scalars, const uint32_t *__restrict__ term_sidx,
+                                                      const uint32_t *__restrict__ term_pidx, const uint32_t *__restrict__ group_off,
+                                                      MsmPlan plan, uint32_t dig_cap, uint32_t *__restrict__ counts,
+                                                      uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
+                                                      uint32_t *__restrict__ order) {
   extern __shared__ uint32_t lds[];
-  const uint32_t k = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, nb = plan.nb, K = plan.K;
-  uint32_t *hist = lds, *cur = lds + nb;
-  __shared__ uint32_t part[BPP_SORT_THREADS];
   constexpr uint32_t T = BPP_SORT_THREADS;
+  const uint32_t tid = threadIdx.x, nb = plan.nb, K = plan.K;
+  const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+  const uint32_t g = xcd + 8u * (j / K), k = j % K;
+  if (g >= plan.G) return;
+  uint32_t *hist = lds, *cur = lds + nb;
+  int16_t *dcache = (int16_t *)(lds + 2 * nb);
+  __shared__ uint32_t part[T];
+  __shared__ uint32_t cls_n[256], cls_start[256], cls_cur[256];
   const uint32_t t0 = group_off[g], ng = group_off[g + 1] - t0;
-  const int16_t *dg = digitsT + (size_t)t0 * K + (size_t)k * ng;
   const uint32_t region = t0 * K + k * ng;
-  for (uint32_t j = tid; j < nb; j += T) hist[j] = 0;
+  for (uint32_t q = tid; q < nb; q += T) hist[q] = 0;
+  if (tid < 256) cls_n[tid] = cls_cur[tid] = 0;
   __syncthreads();
-  // eight independent loads in flight per lane before the first atomic (one load per trip left every trip a full memory
-  // round trip long: the kernel's blocks of sixteen wavefronts sat on their wave slots for 80 us doing nothing)
+  // pass 1: eight scalars in flight per lane before the first atomic
   for (uint32_t i0 = tid; i0 < ng; i0 += 8 * T) {
+    uint32_t si[8];
     int32_t d[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) d[u] = (i0 + u * T < ng) ? (int32_t)dg[i0 + u * T] : 0;
+    for (int u = 0; u < 8; u++) si[u] = (i0 + u * T < ng) ? term_sidx[t0 + i0 + u * T] : 0xffffffffu;
 #pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (d[u]) atomicAdd(&hist[(uint32_t)(d[u] < 0 ? -d[u] : d[u]) - 1], 1u);
+    for (int u = 0; u < 8; u++) d[u] = si[u] != 0xffffffffu ? msm_digit_at(scalars[si[u]].v, plan, k) : 0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t i = i0 + u * T;
+      if (i < ng) {
+        if (i < dig_cap) dcache[i] = (int16_t)d[u];
+        if (d[u]) atomicAdd(&hist[(uint32_t)(d[u] < 0 ? -d[u] : d[u]) - 1], 1u);
+      }
+    }
   }
   __syncthreads();
   // exclusive scan of hist[0..nb): thread t owns a contiguous run of `per` bins
   const uint32_t per = (nb + T - 1u) / T;
   const uint32_t a = tid * per < nb ? tid * per : nb, b = (a + per < nb) ? a + per : nb;
   uint32_t sum = 0;
-  for (uint32_t j = a; j < b; j++) sum += hist[j];
+  for (uint32_t q = a; q < b; q++) sum += hist[q];
   part[tid] = sum;
   __syncthreads();
   for (uint32_t off = 1; off < T; off <<= 1) {
@@ -94,22 +105,25 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_sort(const int16_t *__
   }
   uint32_t run = (tid == 0) ? 0 : part[tid - 1];
   const size_t bbase = ((size_t)g * K + k) * nb;
-  for (uint32_t j = a; j < b; j++) {
-    const uint32_t cnt = hist[j];
-    counts[bbase + j] = cnt;
-    starts[bbase + j] = region + run;
-    cur[j] = run;
+  for (uint32_t q = a; q < b; q++) {
+    const uint32_t cnt = hist[q];
+    counts[bbase + q] = cnt;
+    starts[bbase + q] = region + run;
+    cur[q] = run;
     run += cnt;
+    atomicAdd(&cls_n[cnt < 255u ? cnt : 255u], 1u);  // size classes of this window's buckets
   }
   __syncthreads();
+  // pass 2: scatter
   for (uint32_t i0 = tid; i0 < ng; i0 += 8 * T) {
     int32_t d[8];
     uint32_t pi[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const bool in = i0 + u * T < ng;
-      d[u] = in ? (int32_t)dg[i0 + u * T] : 0;
-      pi[u] = in ? term_pidx[t0 + i0 + u * T] : 0u;
+      const uint32_t i = i0 + u * T;
+      const bool in = i < ng;
+      pi[u] = in ? term_pidx[t0 + i] : 0u;
+      d[u] = !in ? 0 : (i < dig_cap ? (int32_t)dcache[i] : msm_digit_at(scalars[term_sidx[t0 + i]].v, plan, k));
     }
 #pragma unroll
     for (int u = 0; u < 8; u++)
@@ -118,53 +132,26 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_sort(const int16_t *__
         sorted[region + pos] = pi[u] | (d[u] < 0 ? 0x80000000u : 0u);  // point index, sign in bit 31
       }
   }
-}
-
-// ---- order each group's buckets by size (descending) so that the 64 lanes of a wavefront run equally long chains,
-// while a group's buckets stay together (its ~2 MB point set is meant to live in ONE XCD's L2, see k_msm_accumulate).
-// Counting sort over the bucket counts (clamped to 255), per group: k_order_hist builds hist[g][256] with LDS-aggregated
-// atomics, k_order_scatter reserves one range per (block, size class).  grid = (ceil(K*nb/1024), G). ----
-__global__ void __launch_bounds__(1024) k_order_hist(const uint32_t *__restrict__ counts, uint32_t per_group,
-                                                     uint32_t *__restrict__ hist /* [G][256] */) {
-  __shared__ uint32_t h[256];
-  const uint32_t tid = threadIdx.x, g = blockIdx.y;
-  if (tid < 256) h[tid] = 0;
-  __syncthreads();
-  const uint32_t i = blockIdx.x * 1024 + tid;
-  if (i < per_group) {
-    const uint32_t c = counts[(size_t)g * per_group + i];
-    atomicAdd(&h[c < 255u ? c : 255u], 1u);
+  // order: descending start offsets of the 256 size classes, then one slot per bucket
+  if (tid < 256) {
+    uint32_t before = 0;
+    for (uint32_t c2 = tid + 1; c2 < 256; c2++) before += cls_n[c2];
+    cls_start[tid] = before;
   }
   __syncthreads();
-  if (tid < 256 && h[tid]) atomicAdd(&hist[g * 256 + tid], h[tid]);
-}
-__global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t *__restrict__ counts, uint32_t per_group,
-                                                        const uint32_t *__restrict__ hist, uint32_t *__restrict__ cursor,
-                                                        uint32_t *__restrict__ order) {
-  __shared__ uint32_t h[256], base[256], start[256];
-  const uint32_t tid = threadIdx.x, g = blockIdx.y;
-  if (tid < 256) h[tid] = 0;
-  __syncthreads();
-  const uint32_t i = blockIdx.x * 1024 + tid;
-  uint32_t cls = 0, local = 0;
-  if (i < per_group) {
-    const uint32_t c = counts[(size_t)g * per_group + i];
-    cls = c < 255u ? c : 255u;
-    local = atomicAdd(&h[cls], 1u);
+  for (uint32_t q = a; q < b; q++) {
+    const uint32_t cnt = hist[q], cls = cnt < 255u ? cnt : 255u;
+    const uint32_t pos = cls_start[cls] + atomicAdd(&cls_cur[cls], 1u);
+    order[bbase + pos] = (uint32_t)(bbase + q);
   }
-  __syncthreads();
-  if (tid == 0) {  // descending start offsets of the size classes of this group
-    uint32_t run = 0;
-    for (int c = 255; c >= 0; c--) {
-      start[c] = run;
-      run += hist[g * 256 + c];
-    }
-  }
-  __syncthreads();
-  if (tid < 256 && h[tid]) base[tid] = start[tid] + atomicAdd(&cursor[g * 256 + tid], h[tid]);
-  __syncthreads();
-  if (i < per_group) order[(size_t)g * per_group + base[cls] + local] = g * per_group + i;
 }
+// dynamic LDS of k_msm_prelude: the two bucket tables + as many cached digits as keep the workgroup under 64 KB
+inline uint32_t msm_prelude_dig_cap(const MsmPlan &plan, uint32_t max_group_terms) {
+  const uint32_t fixed = 2u * plan.nb * 4u + (BPP_SORT_THREADS + 3u * 256u) * 4u;
+  const uint32_t room = fixed + 1024u < 65536u ? (65536u - 1024u - fixed) / 2u : 0u;
+  return max_group_terms < room ? max_group_terms : room;
+}
+inline size_t msm_prelude_lds(const MsmPlan &plan, uint32_t dig_cap) { return (size_t)2 * plan.nb * 4 + (size_t)((dig_cap + 1u) & ~1u) * 2; }
 
 // ---- bucket sums: one lane per bucket.  XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs
 // (blockIdx % 8), so XCD x takes the groups x, x+8, x+16, ... one after the other; a group's buckets (in size order)

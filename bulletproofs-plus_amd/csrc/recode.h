@@ -46,6 +46,35 @@ BPP_HD void msm_recode(int16_t *out, size_t stride, const sc &s, const MsmPlan &
   }
 }
 
+// The same digit for ONE window, computed from the words around it (what the fused sort kernel does: it owns one window of
+// every term and never sees the whole digit string).  The carry into window k is decided by window k-1 alone unless that
+// window's raw value is exactly half its range, in which case it is the carry into k-1 (and so on down): carry(j+1) =
+// raw_j > half_j, or raw_j == half_j and carry(j).  `w` = the scalar's eight 32-bit words, read on demand.
+BPP_HD uint32_t msm_window_bit(const MsmPlan &plan, uint32_t k) {
+  return k <= plan.K_wide ? k * plan.c : plan.K_wide * plan.c + (k - plan.K_wide) * (plan.c - 1);
+}
+BPP_HD uint32_t msm_window_raw(const uint32_t *w, uint32_t bit, uint32_t wd) {
+  const uint32_t wi = bit >> 5, sh = bit & 31;
+  if (wi >= 8) return 0;
+  uint32_t v = w[wi] >> sh;
+  if (sh + wd > 32 && wi + 1 < 8) v |= w[wi + 1] << (32 - sh);
+  return v & ((1u << wd) - 1u);
+}
+BPP_HD int32_t msm_digit_at(const uint32_t *w, const MsmPlan &plan, uint32_t k) {
+  uint32_t carry = 0;
+  for (uint32_t j = k; j-- > 0;) {
+    const uint32_t wdj = j < plan.K_wide ? plan.c : plan.c - 1;
+    const uint32_t rawj = msm_window_raw(w, msm_window_bit(plan, j), wdj), half = 1u << (wdj - 1);
+    if (rawj != half) {
+      carry = rawj > half ? 1u : 0u;
+      break;
+    }
+  }
+  const uint32_t wd = k < plan.K_wide ? plan.c : plan.c - 1;
+  const uint32_t v = msm_window_raw(w, msm_window_bit(plan, k), wd) + carry;
+  return v > (1u << (wd - 1)) ? (int32_t)v - (int32_t)(1u << wd) : (int32_t)v;
+}
+
 // plan for a group of `terms` terms with window width c
 inline MsmPlan msm_make_plan(uint32_t c, uint32_t G, uint32_t n_terms) {
   MsmPlan plan;

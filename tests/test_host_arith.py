@@ -195,7 +195,11 @@ def test_scalar_recodings(ht, monkeypatch):
     vals = [int.from_bytes(_r(b"rec", i), "little") % L for i in range(40)]
     vals += [0, 1, L - 1, L - 2, 2**252, 2**252 - 1, 2**252 + 1, (1 << 252) - (1 << 200), 0x8080808080808080 << 64]
     for c in range(4, 15):
-        for a in vals:
+        # windows whose raw value is exactly half their range pass the carry of the window below on: chains of them, with
+        # and without a carry coming in at the bottom (the one-window digit function has to walk down them)
+        half_chain = sum(1 << (c * k + c - 1) for k in range(9))
+        chains = [half_chain, half_chain + (1 << (c - 1)) - 1, (half_chain << c) + (1 << (c - 1)) + 1, (half_chain << (2 * c)) + (1 << c) - 1]
+        for a in vals + [x % L for x in chains]:
             dig = (ctypes.c_int16 * 64)()
             wid = (ctypes.c_uint32 * 64)()
             K = ht.ht_msm_recode(a.to_bytes(32, "little"), c, dig, wid)
