@@ -43,9 +43,11 @@ __device__ __forceinline__ const niels *point_ptr(const PointTables &t, uint32_t
 //           LDS atomics
 //   scan    counts -> offsets (in LDS); counts[] / starts[] of the window's 2^(c-1) buckets
 //   pass 2  term ids (sign in bit 31) scattered into sorted[]: region of (g, k) = [goff[g]*K + k*ng, +ng)
-//   order   this window's buckets by descending size (counting sort over the counts clamped to 255) into
-//           order[(g*K + k)*nb ..]: the 64 lanes of an accumulation wavefront get equally long lists.  Ordering per
-//           window balances a wavefront as well as the per-group ordering did (a wavefront takes 64 consecutive slots).
+//   order   this window's buckets by descending size (counting sort over the counts clamped to 255); the last workgroup of
+//           a group to finish merges the K window orders into the group's: order[g*K*nb ..] = all buckets of the group by
+//           descending size, so that the 64 lanes of an accumulation wavefront get equally long lists and the kernel's
+//           last wavefronts the shortest ones.  (Ordering per window only was measured: outliers of every window spread
+//           over the grid, k_msm_accumulate 0.82 -> 0.96 ms alone, + 5 % instructions.)
 // XCD-aware mapping (blockIdx % 8 = XCD, as in k_msm_accumulate): all windows of group g run on XCD g % 8, so the group's
 // scalars are fetched into ONE L2 once and the lists written here are in the L2 that k_msm_accumulate reads them from.
 // grid = 8 * ceil(G/8) * K workgroups of 1024.  Dynamic LDS: 2 * nb u32 + dig_cap int16.
@@ -56,6 +58,7 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__re
                                                       const uint32_t *__restrict__ term_pidx, const uint32_t *__restrict__ group_off,
                                                       MsmPlan plan, uint32_t dig_cap, uint32_t *__restrict__ counts,
                                                       uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
+                                                      uint32_t *order_win, uint32_t *cls_hist, uint32_t *done,
                                                       uint32_t *__restrict__ order) {
   extern __shared__ uint32_t lds[];
   constexpr uint32_t T = BPP_SORT_THREADS;
@@ -132,17 +135,60 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__re
         sorted[region + pos] = pi[u] | (d[u] < 0 ? 0x80000000u : 0u);  // point index, sign in bit 31
       }
   }
-  // order: descending start offsets of the 256 size classes, then one slot per bucket
+  // order, step 1: this window's buckets by descending size class into order_win[] (positions local to the window)
   if (tid < 256) {
     uint32_t before = 0;
     for (uint32_t c2 = tid + 1; c2 < 256; c2++) before += cls_n[c2];
     cls_start[tid] = before;
+    cls_hist[((size_t)g * K + k) * 256 + tid] = cls_n[tid];
   }
   __syncthreads();
   for (uint32_t q = a; q < b; q++) {
     const uint32_t cnt = hist[q], cls = cnt < 255u ? cnt : 255u;
     const uint32_t pos = cls_start[cls] + atomicAdd(&cls_cur[cls], 1u);
-    order[bbase + pos] = (uint32_t)(bbase + q);
+    order_win[bbase + pos] = (uint32_t)(bbase + q);
+  }
+  // order, step 2: the LAST workgroup of the group to get here merges the K per-window orders into the group's order: all
+  // buckets of the group by descending size class (windows of c - 1 bits hold twice as many terms per bucket as the wide
+  // ones, so equal positions of different windows are NOT equal sizes).  The position of a bucket inside its (window, class)
+  // run is kept: a pure gather, no atomics.  `done[g]` counts finished workgroups and is never reset: every launch adds
+  // exactly K per group.
+  __shared__ uint32_t s_last;
+  __threadfence();  // counts[], order_win[], cls_hist[] of this window are out before the ticket is taken
+  __syncthreads();
+  if (tid == 0) s_last = (atomicAdd(&done[g], 1u) % K) == K - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const uint32_t *gh = cls_hist + (size_t)g * K * 256;
+  const size_t gbase = (size_t)g * K * nb;
+  uint32_t running = 0;  // lane cls < 256: first group-level slot of the NEXT window's run of class cls
+  if (tid < 256) {
+    uint32_t tot = 0;
+    for (uint32_t kk = 0; kk < K; kk++) tot += __hip_atomic_load(&gh[kk * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cls_n[tid] = tot;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    for (uint32_t c2 = tid + 1; c2 < 256; c2++) running += cls_n[c2];
+  }
+  __syncthreads();
+  for (uint32_t kk = 0; kk < K; kk++) {
+    if (tid < 256) cls_cur[tid] = __hip_atomic_load(&gh[kk * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // n[kk][cls]
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t before = 0;  // where the class starts inside window kk's own order
+      for (uint32_t c2 = tid + 1; c2 < 256; c2++) before += cls_cur[c2];
+      cls_start[tid] = running - before;  // group slot = local position + this (may wrap: unsigned arithmetic)
+      running += cls_cur[tid];
+    }
+    __syncthreads();
+    for (uint32_t q = tid; q < nb; q += T) {
+      const uint32_t bkt = __hip_atomic_load(&order_win[gbase + (size_t)kk * nb + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t cnt = __hip_atomic_load(&counts[bkt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      order[gbase + (uint32_t)(q + cls_start[cnt < 255u ? cnt : 255u])] = bkt;
+    }
+    __syncthreads();
   }
 }
 // dynamic LDS of k_msm_prelude: the two bucket tables + as many cached digits as keep the workgroup under 64 KB
