@@ -484,7 +484,7 @@ void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff)
   w.sorted.alloc((size_t)n * plan.K);
   w.order.alloc(nbk);
   w.order_win.alloc(nbk);
-  w.cls_hist.alloc((size_t)G * plan.K * 256);
+  w.cls_hist.alloc((size_t)G * plan.K * 768);
   // finished-workgroup tickets of k_msm_prelude: zeroed with every new plan (here), never per launch: every launch adds
   // exactly K per group and the kernel looks at the count modulo K
   w.done.alloc(G);

@@ -135,12 +135,21 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__re
         sorted[region + pos] = pi[u] | (d[u] < 0 ? 0x80000000u : 0u);  // point index, sign in bit 31
       }
   }
-  // order, step 1: this window's buckets by descending size class into order_win[] (positions local to the window)
+  // order, step 1: this window's buckets by descending size class into order_win[] (positions local to the window);
+  // cls_hist[g][k] = [how many buckets per class | where each class starts in this window's order]
+  uint32_t *gh = cls_hist + (size_t)g * K * 768;  // per window: 256 counts, 256 class starts, 256 offsets (step 2)
+  if (tid < 256) part[tid] = cls_n[tid];
+  __syncthreads();
+  for (uint32_t off = 1; off < 256; off <<= 1) {  // suffix sums over the classes: part[c] = sum_{c2 >= c} n[c2]
+    uint32_t v = (tid < 256 && tid + off < 256) ? part[tid + off] : 0;
+    __syncthreads();
+    if (tid < 256) part[tid] += v;
+    __syncthreads();
+  }
   if (tid < 256) {
-    uint32_t before = 0;
-    for (uint32_t c2 = tid + 1; c2 < 256; c2++) before += cls_n[c2];
-    cls_start[tid] = before;
-    cls_hist[((size_t)g * K + k) * 256 + tid] = cls_n[tid];
+    cls_start[tid] = part[tid] - cls_n[tid];
+    gh[k * 768 + tid] = cls_n[tid];
+    gh[k * 768 + 256 + tid] = cls_start[tid];
   }
   __syncthreads();
   for (uint32_t q = a; q < b; q++) {
@@ -150,45 +159,51 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__re
   }
   // order, step 2: the LAST workgroup of the group to get here merges the K per-window orders into the group's order: all
   // buckets of the group by descending size class (windows of c - 1 bits hold twice as many terms per bucket as the wide
-  // ones, so equal positions of different windows are NOT equal sizes).  The position of a bucket inside its (window, class)
-  // run is kept: a pure gather, no atomics.  `done[g]` counts finished workgroups and is never reset: every launch adds
-  // exactly K per group.
+  // ones, so equal positions of different windows are NOT equal sizes).  A bucket keeps its position inside its
+  // (window, class) run: group slot = local position + offs[window][class], a pure gather without atomics.  `done[g]` counts
+  // finished workgroups and is never reset: every launch adds exactly K per group.
   __shared__ uint32_t s_last;
   __threadfence();  // counts[], order_win[], cls_hist[] of this window are out before the ticket is taken
   __syncthreads();
   if (tid == 0) s_last = (atomicAdd(&done[g], 1u) % K) == K - 1u ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
-  const uint32_t *gh = cls_hist + (size_t)g * K * 256;
+  __threadfence();  // acquire: what the other workgroups of the group wrote is read from L2, not from a stale L1 line
   const size_t gbase = (size_t)g * K * nb;
-  uint32_t running = 0;  // lane cls < 256: first group-level slot of the NEXT window's run of class cls
+  uint32_t tot = 0;
   if (tid < 256) {
-    uint32_t tot = 0;
-    for (uint32_t kk = 0; kk < K; kk++) tot += __hip_atomic_load(&gh[kk * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    cls_n[tid] = tot;
+    for (uint32_t kk = 0; kk < K; kk++) tot += gh[kk * 768 + tid];
+    part[tid] = tot;
   }
   __syncthreads();
-  if (tid < 256) {
-    for (uint32_t c2 = tid + 1; c2 < 256; c2++) running += cls_n[c2];
+  for (uint32_t off = 1; off < 256; off <<= 1) {
+    uint32_t v = (tid < 256 && tid + off < 256) ? part[tid + off] : 0;
+    __syncthreads();
+    if (tid < 256) part[tid] += v;
+    __syncthreads();
   }
+  if (tid < 256) {
+    uint32_t running = part[tid] - tot;  // first group-level slot of class tid
+    for (uint32_t kk = 0; kk < K; kk++) {
+      gh[kk * 768 + 512 + tid] = running - gh[kk * 768 + 256 + tid];  // (may wrap: unsigned arithmetic, undone by + position)
+      running += gh[kk * 768 + tid];
+    }
+  }
+  __threadfence();
   __syncthreads();
-  for (uint32_t kk = 0; kk < K; kk++) {
-    if (tid < 256) cls_cur[tid] = __hip_atomic_load(&gh[kk * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // n[kk][cls]
-    __syncthreads();
-    if (tid < 256) {
-      uint32_t before = 0;  // where the class starts inside window kk's own order
-      for (uint32_t c2 = tid + 1; c2 < 256; c2++) before += cls_cur[c2];
-      cls_start[tid] = running - before;  // group slot = local position + this (may wrap: unsigned arithmetic)
-      running += cls_cur[tid];
-    }
-    __syncthreads();
-    for (uint32_t q = tid; q < nb; q += T) {
-      const uint32_t bkt = __hip_atomic_load(&order_win[gbase + (size_t)kk * nb + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t cnt = __hip_atomic_load(&counts[bkt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      order[gbase + (uint32_t)(q + cls_start[cnt < 255u ? cnt : 255u])] = bkt;
-    }
-    __syncthreads();
+  const uint32_t n_all = K * nb;
+  for (uint32_t i0 = tid; i0 < n_all; i0 += 4 * T) {
+    uint32_t bk[4], cn[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) bk[u] = i0 + u * T < n_all ? order_win[gbase + i0 + u * T] : 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < 4; u++) cn[u] = bk[u] != 0xffffffffu ? counts[bk[u]] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (bk[u] != 0xffffffffu) {
+        const uint32_t i = i0 + u * T, kk = i >> (plan.c - 1u), q = i & (nb - 1u);
+        order[gbase + (uint32_t)(q + gh[kk * 768 + 512 + (cn[u] < 255u ? cn[u] : 255u)])] = bk[u];
+      }
   }
 }
 // dynamic LDS of k_msm_prelude: the two bucket tables + as many cached digits as keep the workgroup under 64 KB

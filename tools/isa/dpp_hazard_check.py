@@ -15,7 +15,26 @@ import subprocess
 import sys
 import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
+def llvm_bin(hipcc=None):
+    """directory holding llvm-objdump / llvm-objcopy: next to the hipcc in use (<rocm>/bin/hipcc -> <rocm>/lib/llvm/bin), then
+    the usual prefixes, then PATH; None if nowhere"""
+    import shutil
+    cands = []
+    for h in (hipcc, os.environ.get("HIPCC"), shutil.which("hipcc")):
+        if h and os.path.isabs(h):
+            root = os.path.dirname(os.path.dirname(os.path.realpath(h)))
+            cands += [os.path.join(root, "lib", "llvm", "bin"), os.path.join(root, "llvm", "bin")]
+    cands += ["/opt/rocm/lib/llvm/bin", "/opt/rocm/llvm/bin"]
+    w = shutil.which("llvm-objdump")
+    if w:
+        cands.append(os.path.dirname(w))
+    for c in cands:
+        if os.path.exists(os.path.join(c, "llvm-objdump")) and os.path.exists(os.path.join(c, "llvm-objcopy")):
+            return c
+    return None
+
+
+LLVM = llvm_bin() or "/opt/rocm/lib/llvm/bin"
 STORES = ("scratch_store", "global_store", "flat_store", "buffer_store", "ds_write", "ds_bpermute", "ds_permute", "ds_swizzle")
 
 
