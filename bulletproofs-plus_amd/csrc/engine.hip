@@ -238,7 +238,7 @@ SharedRegistry<Precomp> &precomp_registry() {
 }
 
 struct MsmWork {
-  DevBuf<uint32_t> counts, starts, sorted, order, order_win, cls_hist, done;
+  DevBuf<uint32_t> counts, starts, sorted, order, order_win, cls_hist;
   DevBuf<ge> buckets, Q, W, R;
   DevBuf<uint8_t> comp32;
   DevBuf<uint32_t> is_identity;
@@ -298,7 +298,7 @@ void adopt_buffers(Batch &dst, Batch &src) {
   BPP_ADOPT(rows); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(tab); BPP_ADOPT(rng_out); BPP_ADOPT(weights);
   BPP_ADOPT(masks); BPP_ADOPT(chal_bytes); BPP_ADOPT(status); BPP_ADOPT(group_first); BPP_ADOPT(group_dlo); BPP_ADOPT(dynpts); BPP_ADOPT(dec_spill);
   BPP_ADOPT(msm.counts); BPP_ADOPT(msm.starts); BPP_ADOPT(msm.sorted); BPP_ADOPT(msm.order); BPP_ADOPT(msm.order_win);
-  BPP_ADOPT(msm.cls_hist); BPP_ADOPT(msm.done);
+  BPP_ADOPT(msm.cls_hist);
   BPP_ADOPT(msm.buckets); BPP_ADOPT(msm.Q); BPP_ADOPT(msm.W); BPP_ADOPT(msm.R); BPP_ADOPT(msm.comp32);
   BPP_ADOPT(msm.is_identity); BPP_ADOPT(msm.term_sidx); BPP_ADOPT(msm.term_pidx); BPP_ADOPT(msm.group_off);
   BPP_ADOPT(h_rng); BPP_ADOPT(h_weights); BPP_ADOPT(h_status); BPP_ADOPT(h_ident);
@@ -485,10 +485,6 @@ void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff)
   w.order.alloc(nbk);
   w.order_win.alloc(nbk);
   w.cls_hist.alloc((size_t)G * plan.K * 768);
-  // finished-workgroup tickets of k_msm_prelude: zeroed with every new plan (here), never per launch: every launch adds
-  // exactly K per group and the kernel looks at the count modulo K
-  w.done.alloc(G);
-  HIP_CHECK(hipMemsetAsync(w.done.p, 0, (size_t)w.done.n * 4, ctx->stream));
   w.buckets.alloc(nbk);
   w.Q.alloc((size_t)G * plan.K * plan.c);
   w.W.alloc((size_t)G * plan.K);
@@ -521,12 +517,12 @@ void msm_prepare(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &sidx, co
 void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, StageTimer *tm) {
   const MsmPlan plan = w.plan;
   hipStream_t s = ctx->stream;
-  // digits + counting sort + size ordering: one launch (msm.h: k_msm_prelude)
+  // digits + counting sort + per-window size ordering in one launch (msm.h: k_msm_prelude), then the group-level order
   const uint32_t per_group = plan.K * plan.nb;
   const uint32_t dig_cap = msm_prelude_dig_cap(plan, w.max_group_terms);
   hipLaunchKernelGGL(k_msm_prelude, dim3(8 * cdiv(plan.G, 8) * plan.K), dim3(BPP_SORT_THREADS), msm_prelude_lds(plan, dig_cap), s, scalars,
-                     w.term_sidx.p, w.term_pidx.p, w.group_off.p, plan, dig_cap, w.counts.p, w.starts.p, w.sorted.p, w.order_win.p, w.cls_hist.p,
-                     w.done.p, w.order.p);
+                     w.term_sidx.p, w.term_pidx.p, w.group_off.p, plan, dig_cap, w.counts.p, w.starts.p, w.sorted.p, w.order_win.p, w.cls_hist.p);
+  hipLaunchKernelGGL(k_msm_order, dim3(plan.G), dim3(BPP_SORT_THREADS), 0, s, w.counts.p, w.order_win.p, w.cls_hist.p, plan, w.order.p);
   if (tm) tm->mark(M_ORDER);  // msm_accumulate_ms brackets k_msm_accumulate alone (the roofline kernel)
   // few buckets on an idle chip (one batch per call): quad forms, ~3x shorter dependency chains (tests force either form)
   const bool small = ctx->opt.msm_quad >= 0 ? ctx->opt.msm_quad != 0 : (size_t)plan.G * per_group <= 100000;

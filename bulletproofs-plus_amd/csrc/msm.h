@@ -43,11 +43,8 @@ __device__ __forceinline__ const niels *point_ptr(const PointTables &t, uint32_t
 //           LDS atomics
 //   scan    counts -> offsets (in LDS); counts[] / starts[] of the window's 2^(c-1) buckets
 //   pass 2  term ids (sign in bit 31) scattered into sorted[]: region of (g, k) = [goff[g]*K + k*ng, +ng)
-//   order   this window's buckets by descending size (counting sort over the counts clamped to 255); the last workgroup of
-//           a group to finish merges the K window orders into the group's: order[g*K*nb ..] = all buckets of the group by
-//           descending size, so that the 64 lanes of an accumulation wavefront get equally long lists and the kernel's
-//           last wavefronts the shortest ones.  (Ordering per window only was measured: outliers of every window spread
-//           over the grid, k_msm_accumulate 0.82 -> 0.96 ms alone, + 5 % instructions.)
+//   order   this window's buckets by descending size (counting sort over the counts clamped to 255) into order_win[], with
+//           the class histogram in cls_hist[]; k_msm_order merges the K window orders into the group's
 // XCD-aware mapping (blockIdx % 8 = XCD, as in k_msm_accumulate): all windows of group g run on XCD g % 8, so the group's
 // scalars are fetched into ONE L2 once and the lists written here are in the L2 that k_msm_accumulate reads them from.
 // grid = 8 * ceil(G/8) * K workgroups of 1024.  Dynamic LDS: 2 * nb u32 + dig_cap int16.
@@ -58,8 +55,7 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__re
                                                       const uint32_t *__restrict__ term_pidx, const uint32_t *__restrict__ group_off,
                                                       MsmPlan plan, uint32_t dig_cap, uint32_t *__restrict__ counts,
                                                       uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
-                                                      uint32_t *order_win, uint32_t *cls_hist, uint32_t *done,
-                                                      uint32_t *__restrict__ order) {
+                                                      uint32_t *__restrict__ order_win, uint32_t *__restrict__ cls_hist) {
   extern __shared__ uint32_t lds[];
   constexpr uint32_t T = BPP_SORT_THREADS;
   const uint32_t tid = threadIdx.x, nb = plan.nb, K = plan.K;
@@ -157,18 +153,23 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__re
     const uint32_t pos = cls_start[cls] + atomicAdd(&cls_cur[cls], 1u);
     order_win[bbase + pos] = (uint32_t)(bbase + q);
   }
-  // order, step 2: the LAST workgroup of the group to get here merges the K per-window orders into the group's order: all
-  // buckets of the group by descending size class (windows of c - 1 bits hold twice as many terms per bucket as the wide
-  // ones, so equal positions of different windows are NOT equal sizes).  A bucket keeps its position inside its
-  // (window, class) run: group slot = local position + offs[window][class], a pure gather without atomics.  `done[g]` counts
-  // finished workgroups and is never reset: every launch adds exactly K per group.
-  __shared__ uint32_t s_last;
-  __threadfence();  // counts[], order_win[], cls_hist[] of this window are out before the ticket is taken
-  __syncthreads();
-  if (tid == 0) s_last = (atomicAdd(&done[g], 1u) % K) == K - 1u ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();  // acquire: what the other workgroups of the group wrote is read from L2, not from a stale L1 line
+}
+
+// ---- order, step 2: one workgroup per group merges the K per-window orders into the group's order: all buckets of the
+// group by descending size class, so that the 64 lanes of an accumulation wavefront get equally long lists and the kernel's
+// last wavefronts the shortest ones (windows of c - 1 bits hold twice as many terms per bucket as the wide ones, so equal
+// positions of different windows are NOT equal sizes; ordering per window only was measured: the outliers of every window
+// spread over the grid, k_msm_accumulate 0.82 -> 0.96 ms alone, + 5 % instructions).  A bucket keeps its position inside
+// its (window, class) run: group slot = local position + offs[window][class] -- a pure gather, no atomics.
+// (A launch of its own on purpose.  Done by the last workgroup of k_msm_prelude to finish, it needs device-scope fences
+// between workgroups, and on this chip those write back and invalidate a whole XCD's L2 each time: every kernel in flight
+// lost its cached lines, the step went from 2.5 to 3.8 ms.)  grid = G workgroups of 1024.
+__global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_order(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ order_win,
+                                                    uint32_t *cls_hist, MsmPlan plan, uint32_t *__restrict__ order) {
+  constexpr uint32_t T = BPP_SORT_THREADS;
+  const uint32_t tid = threadIdx.x, g = blockIdx.x, nb = plan.nb, K = plan.K;
+  __shared__ uint32_t part[256];
+  uint32_t *gh = cls_hist + (size_t)g * K * 768;
   const size_t gbase = (size_t)g * K * nb;
   uint32_t tot = 0;
   if (tid < 256) {
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__re
     part[tid] = tot;
   }
   __syncthreads();
-  for (uint32_t off = 1; off < 256; off <<= 1) {
+  for (uint32_t off = 1; off < 256; off <<= 1) {  // suffix sums over the classes
     uint32_t v = (tid < 256 && tid + off < 256) ? part[tid + off] : 0;
     __syncthreads();
     if (tid < 256) part[tid] += v;
@@ -189,8 +190,7 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__re
       running += gh[kk * 768 + tid];
     }
   }
-  __threadfence();
-  __syncthreads();
+  __syncthreads();  // (the offsets are read back by the same workgroup: same CU, same L1, written through)
   const uint32_t n_all = K * nb;
   for (uint32_t i0 = tid; i0 < n_all; i0 += 4 * T) {
     uint32_t bk[4], cn[4];
