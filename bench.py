@@ -167,10 +167,12 @@ def _counter_pass(only, counters, extra_args=()):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def _kernel_row(acc, sub):
-    for k, e in (acc or {}).items():
-        if sub in k and e.get("dispatches"):
-            return e
+def _kernel_row(acc, name):
+    """the row of kernel `name` (exact short name; k_decompress must not pick k_decompress_plain), else a substring match"""
+    for exact in (True, False):
+        for k, e in (acc or {}).items():
+            if (k == name if exact else name in k) and e.get("dispatches"):
+                return e
     return None
 
 
@@ -365,7 +367,12 @@ def decompress_roofline(stages, n_points, sq, clock_ghz):
     if clock_ghz:
         out["valu"]["frac_at_clock"] = out["valu"]["achieved_Tmad_per_s"] / (64 * 256 * clock_ghz * 1e9 / 1e12)
     e = (sq or {}).get("k_decompress")
-    if e:  # one step in flight, from the SQ counter pass
+    if e:  # one step in flight, from the SQ counter pass.  The kernel's dispatches there: one per verification (n_points proof
+        # points) and ONE at upload over the statements' commitments (n_points / 15): per-launch averages are scaled to a
+        # verification launch by points
+        nd = e["dispatches"]
+        scale = nd * n_points / ((nd - 1) * n_points + n_points / 15.0) if nd > 1 else 1.0
+        e = dict(e, kernel_ms_alone=e["kernel_ms_alone"] * scale, valu_instr_per_launch=e["valu_instr_per_launch"] * scale)
         out["alone"] = {"kernel_ms": e["kernel_ms_alone"], "valu_instr_per_point": 64.0 * e["valu_instr_per_launch"] / n_points,
                         "wait_inst_frac": e["wait_inst_frac"], "active_valu_frac": e["active_valu_frac"],
                         "valu_frac": mads / (e["kernel_ms_alone"] * 1e-3) / (VALU_PEAK_TMAD * 1e12),

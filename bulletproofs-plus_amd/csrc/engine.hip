@@ -1519,7 +1519,10 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
     const uint32_t nhi_max = b.lanes_nhi_max(P.n_bits);
     // proofs per workgroup: enough (proof, generator pair) items for four passes of the 64 lanes.  The weighted part of the
     // scalar block (dynamic scalars, base columns, w into the low tables) is this kernel's prologue.
-    const uint32_t ppw = std::max<uint32_t>(1, std::min<uint32_t>(BPP_LANES_MAX_PPW, 256 / std::max<uint32_t>(1, b.max_mn)));
+    // Large inputs take sixteen 64-bit proofs per workgroup: the prologue's product jobs (43 per proof) then fill whole
+    // wavefronts; small inputs keep four (more workgroups, shorter chains: the chip is idle anyway).
+    const uint32_t per_wg = b.B <= BPP_TABLES_WAVE_MAX ? 256u : 1024u;
+    const uint32_t ppw = std::max<uint32_t>(1, std::min<uint32_t>(BPP_LANES_MAX_PPW, per_wg / std::max<uint32_t>(1, b.max_mn)));
     hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s, b.d_desc.p, b.tab.p, b.shr.p,
                        b.weights.p, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, b.rows.p, dyn_scal);
   }

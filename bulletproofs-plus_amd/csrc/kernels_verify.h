@@ -597,7 +597,7 @@ BPP_HD constexpr uint32_t lanes_lds_bytes(uint32_t nhi_max) {
 //   C_j: (-e^2 y^{mn+1} w) z^{2(j+1)};  A1: -e w;  B: -w;  A: -e^2 w;  L_j: (-e^2 w) e_j^2;  R_j: (-e^2 w) e_j^-2
 // A Montgomery product with one CANONICAL operand is the canonical product, so the dynamic scalars (which the MSM wants
 // canonical) take the weight as it arrives and need no conversion.  Same products on the same operands as the old kernels.
-#define BPP_LANES_MAX_PPW 8
+#define BPP_LANES_MAX_PPW 16
 __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restrict__ desc, const sc *__restrict__ tab,
                                                       const sc *__restrict__ shr, const uint8_t *__restrict__ weights32,
                                                       uint32_t n_bits, uint32_t t, uint32_t max_mn, uint32_t cols, uint32_t B,
@@ -612,6 +612,10 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
   const uint32_t ts = lanes_tab_stride(nhi_max), n9 = ts - 1u;  // entries per proof: n9 as limbs, then e2z packed
   const uint32_t per_bytes = lanes_lds_bytes(nhi_max);
   const uint32_t LB = lanes_lb(n_bits), nlo = 1u << LB;
+  // A product costs the same ~250 instructions whether one lane of the wavefront needs it or all 64, so the prologue is laid
+  // out for full wavefronts: (1) w = weight in Montgomery form, one lane per proof; (2) the three derived multipliers, one
+  // lane per (proof, multiplier); (3) ONE flat list of product jobs over all proofs of the workgroup -- 3 * 2^LB low-table
+  // entries, e^2 z, the dynamic scalars, the base columns: 43 per 64-bit proof; (4) the high tables are copied without a product.
   if (lane < ppw) {
     const uint32_t p = p0 + lane;
     uint32_t r = ~0u, m = 0, dyn_off = 0;
@@ -625,61 +629,50 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     s_m[lane] = m;
     s_dyn[lane] = dyn_off;
     if (r != ~0u) {
-      const sc *S = shr + (size_t)p * SH_STRIDE;
-      sc wc, w, x;
+      sc wc, w;
       sc_load_words(wc, weights32 + (size_t)p * 32);
       sc_to_mont(w, wc);
       s_mult[lane][0] = w;
-      sc_montmul(x, S[SH_NEG_E2], w);
-      s_mult[lane][1] = x;
-      sc_montmul(x, S[SH_NEG_E2], wc);
-      s_mult[lane][2] = x;
-      sc_montmul(x, S[SH_NEG_E2_YNM1], wc);
-      s_mult[lane][3] = x;
       s_mult[lane][4] = wc;
     }
   }
   __syncthreads();
-  // ---- tables -> LDS, the low ones and e^2 z times the weight (entries a proof's shape does not use are never read)
-  for (uint32_t it = lane; it < ppw * ts; it += 64) {
-    const uint32_t sub = it / ts, idx = it - sub * ts;
+  for (uint32_t it = lane; it < 3u * ppw; it += 64) {
+    const uint32_t sub = it / 3u, which = it - 3u * sub;
     if (s_r[sub] == ~0u) continue;
-    const size_t p = p0 + sub;
-    uint8_t *base = reinterpret_cast<uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes;
-    if (idx < n9) {
-      sc v = tab[p * ts + idx];
-      if (idx < 24u && (idx & 7u) < nlo) {  // glo [0,8), yn2lo [8,16), hlo [16,24)
-        const sc mult = s_mult[sub][(idx >> 3) == 1u ? 1 : 0];
-        sc_montmul(v, v, mult);
-      }
-      sc9 o9;
-      sc9_from(o9, v);
-      reinterpret_cast<sc9 *>(base)[idx] = o9;
-    } else {
-      sc v;
-      sc_montmul(v, shr[p * SH_STRIDE + SH_E2Z], s_mult[sub][0]);  // w e^2 z
-      *reinterpret_cast<sc *>(base + (size_t)n9 * sizeof(sc9)) = v;
-    }
+    const sc *S = shr + (size_t)(p0 + sub) * SH_STRIDE;
+    const sc a = which == 2u ? S[SH_NEG_E2_YNM1] : S[SH_NEG_E2];
+    const sc b2 = which == 0u ? s_mult[sub][0] : s_mult[sub][4];
+    sc x;
+    sc_montmul(x, a, b2);
+    s_mult[sub][1 + which] = x;  // 1: -w e^2 Montgomery, 2: -w e^2 canonical, 3: -w e^2 y^(mn+1) canonical
   }
-  // ---- dynamic scalars and base columns: one product per job
+  __syncthreads();
   {
-    uint32_t jmax = 0;
+    uint32_t jmax = 0;  // product jobs per proof (the largest of the workgroup: jobs past a proof's own count are skipped)
     for (uint32_t sub = 0; sub < ppw; sub++)
-      if (s_r[sub] != ~0u) jmax = max(jmax, s_m[sub] + 3u + 2u * s_r[sub] + t + 1u);
+      if (s_r[sub] != ~0u) jmax = max(jmax, 3u * nlo + 1u + s_m[sub] + 3u + 2u * s_r[sub] + t + 1u);
     for (uint32_t it = lane; it < ppw * jmax; it += 64) {
       const uint32_t sub = it / jmax, job = it - sub * jmax;
       const uint32_t r = s_r[sub], m = s_m[sub];
-      if (r == ~0u || job >= m + 3u + 2u * r + t + 1u) continue;
+      const uint32_t j_e2z = 3u * nlo, j_c = j_e2z + 1u, j_a1 = j_c + m, j_lr = j_a1 + 3u, j_row = j_lr + 2u * r, n_jobs = j_row + t + 1u;
+      if (r == ~0u || job >= n_jobs) continue;
       const size_t p = p0 + sub;
       const sc *S = shr + p * SH_STRIDE;
+      const sc *T = tab + p * ts;
       sc *dyn = dyn_out + s_dyn[sub];
       sc *row = rows + p * cols;
-      const uint32_t j_a1 = m, j_lr = m + 3u, j_row = j_lr + 2u * r;
+      uint8_t *base = reinterpret_cast<uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes;
       const sc *src;
-      sc *dst;
+      sc *dst = nullptr;
+      uint32_t lds_idx = ~0u;  // destination in LDS (sc9 entry), else `dst` in global memory
       uint32_t sel, zpow = 0;  // multiplier index into s_mult; C_j: z^(2(j+1)) from z^2 by j more products
       bool neg = false, plain_neg = false;
-      if (job < j_a1) src = S + SH_Z2, dst = dyn + job, sel = 3, zpow = job;
+      if (job < nlo) src = T + job, lds_idx = job, sel = 0;                                // glo
+      else if (job < 2u * nlo) src = T + 16 + (job - nlo), lds_idx = 16u + (job - nlo), sel = 0;      // hlo
+      else if (job < 3u * nlo) src = T + 8 + (job - 2u * nlo), lds_idx = 8u + (job - 2u * nlo), sel = 1;  // yn2lo
+      else if (job == j_e2z) src = S + SH_E2Z, lds_idx = n9, sel = 0;                      // w e^2 z
+      else if (job < j_a1) src = S + SH_Z2, dst = dyn + (job - j_c), sel = 3, zpow = job - j_c;
       else if (job == j_a1) src = S + SH_E, dst = dyn + m, sel = 4, neg = true;               // A1: -e w
       else if (job == j_a1 + 1) src = S + SH_E, dst = dyn + m + 1, sel = 4, plain_neg = true;  // B: -w
       else if (job == j_a1 + 2) src = S + SH_NEG_E2, dst = dyn + m + 2, sel = 4;               // A: -e^2 w
@@ -703,8 +696,25 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
       const sc mult = s_mult[sub][sel];
       sc_montmul(x, a, mult);
       if (plain_neg) sc_neg(x, mult);
-      *dst = x;
+      if (lds_idx == ~0u) {
+        *dst = x;
+      } else if (lds_idx < n9) {
+        sc9 o9;
+        sc9_from(o9, x);
+        reinterpret_cast<sc9 *>(base)[lds_idx] = o9;
+      } else {
+        *reinterpret_cast<sc *>(base + (size_t)n9 * sizeof(sc9)) = x;
+      }
     }
+  }
+  // ---- the high tables -> LDS as they are (entries a proof's shape does not use are never read)
+  for (uint32_t it = lane; it < ppw * (n9 - 24u); it += 64) {
+    const uint32_t sub = it / (n9 - 24u), idx = 24u + (it - sub * (n9 - 24u));
+    if (s_r[sub] == ~0u) continue;
+    const sc v = tab[(size_t)(p0 + sub) * ts + idx];
+    sc9 o9;
+    sc9_from(o9, v);
+    reinterpret_cast<sc9 *>(reinterpret_cast<uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes)[idx] = o9;
   }
   __syncthreads();
   // ---- generator rows
