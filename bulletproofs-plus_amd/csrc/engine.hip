@@ -171,6 +171,7 @@ struct Params {
   std::mutex fb_mu;  // serialises the one-off build of the prover's fixed-base table
   uint32_t n_bits, m_max, t;
   DevBuf<niels> table;  // [2*n*m_max interleaved G,H | t g_bases | h_base]
+  DevBuf<niels> table_hi;  // the same points times 2^127: the half-scalar MSM plan of small calls (msm.h)
   uint32_t table_len;
   DevBuf<uint8_t> d_hg32;           // compressed H, G_0..G_{t-1}
   std::vector<uint8_t> hg32;        // host copy
@@ -245,6 +246,7 @@ struct MsmWork {
   DevBuf<uint32_t> term_sidx, term_pidx, group_off;
   MsmPlan plan{};
   uint32_t max_group_terms = 0;
+  bool split = false;  // half-scalar plan (small verifier calls): every term twice, 128-bit windows
 };
 
 struct Batch {
@@ -278,6 +280,7 @@ struct Batch {
   DevBuf<uint32_t> status, group_first, group_dlo;
   DevBuf<uint32_t> dec_spill;  // k_decompress parks three field elements per proof point here across its squaring chain
   DevBuf<niels> dynpts;
+  DevBuf<ge> dyn_hi;  // 2^127 x dynpts (half-scalar plan only)
   MsmWork msm;
   // layout of the last verify
   size_t last_chunk = (size_t)-1;
@@ -296,7 +299,7 @@ void adopt_buffers(Batch &dst, Batch &src) {
   BPP_ADOPT(d_ext_status); BPP_ADOPT(bytes); BPP_ADOPT(states); BPP_ADOPT(seeds); BPP_ADOPT(d_desc); BPP_ADOPT(minvals);
   BPP_ADOPT(src_off); BPP_ADOPT(owner); BPP_ADOPT(idx_commit); BPP_ADOPT(idx_proof); BPP_ADOPT(status0); BPP_ADOPT(chal);
   BPP_ADOPT(rows); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(tab); BPP_ADOPT(rng_out); BPP_ADOPT(weights);
-  BPP_ADOPT(masks); BPP_ADOPT(chal_bytes); BPP_ADOPT(status); BPP_ADOPT(group_first); BPP_ADOPT(group_dlo); BPP_ADOPT(dynpts); BPP_ADOPT(dec_spill);
+  BPP_ADOPT(masks); BPP_ADOPT(chal_bytes); BPP_ADOPT(status); BPP_ADOPT(group_first); BPP_ADOPT(group_dlo); BPP_ADOPT(dynpts); BPP_ADOPT(dyn_hi); BPP_ADOPT(dec_spill);
   BPP_ADOPT(msm.counts); BPP_ADOPT(msm.starts); BPP_ADOPT(msm.sorted); BPP_ADOPT(msm.order); BPP_ADOPT(msm.order_win);
   BPP_ADOPT(msm.cls_hist);
   BPP_ADOPT(msm.buckets); BPP_ADOPT(msm.Q); BPP_ADOPT(msm.W); BPP_ADOPT(msm.R); BPP_ADOPT(msm.comp32);
@@ -379,7 +382,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1;
+        fb_threads = -1, prove_subs = -1, msm_split = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -408,6 +411,7 @@ const OptionName kOptions[] = {
     {"msm_final_quad", "BPP_MSM_FINAL_QUAD", &bpp_ctx::Options::msm_final_quad},
     {"fb_threads", "BPP_FB_THREADS", &bpp_ctx::Options::fb_threads},
     {"prove_subs", "BPP_PROVE_SUBS", &bpp_ctx::Options::prove_subs},
+    {"msm_split", "BPP_MSM_SPLIT", &bpp_ctx::Options::msm_split},
 };
 void options_from_env(bpp_ctx *c) {
   for (const OptionName &o : kOptions)
@@ -457,6 +461,8 @@ static bool decompress_spill_enabled() {
 
 
 // ------------------------------------------------------------------ MSM driver
+// A call of up to this many MSM terms is "small": it has the chip to itself, its time is the length of its dependency chains
+#define BPP_SMALL_CALL_TERMS 20000u
 uint32_t choose_window(const bpp_ctx *ctx, uint32_t group_terms, uint32_t all_terms) {
   // buckets per window ~ terms / 12  (bucket lists of ~12 points keep the per-lane chains short)
   uint32_t c = 4;
@@ -465,18 +471,25 @@ uint32_t choose_window(const bpp_ctx *ctx, uint32_t group_terms, uint32_t all_te
   // Wider windows shorten the bucket lists (accumulation) and the Horner step (fewer windows to add) for a longer
   // row / column reduction: three more bits are worth 0.07-0.1 ms up to a few hundred proofs (one proof 0.79 -> 0.68 ms).
   const int bias = ctx->opt.msm_c_bias >= 0 ? ctx->opt.msm_c_bias : 3;  // (tests run the narrow windows as well)
-  if (all_terms <= 20000u) c = (uint32_t)std::max(4, std::min(11, (int)c + bias));
+  if (all_terms <= BPP_SMALL_CALL_TERMS) c = (uint32_t)std::max(4, std::min(11, (int)c + bias));
   return c;
 }
 
 // plan + work buffers for G groups with term offsets goff[0..G]; the term lists (term_sidx / term_pidx) are filled by
 // the caller, from host vectors (msm_prepare) or by a kernel (layout_groups)
-void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff) {
+// half-scalar plan (msm.h: k_shift127_quad): small verifier calls, unless the one-lane kernels are forced
+bool msm_wants_split(const bpp_ctx *ctx, uint32_t n_terms) {
+  if (ctx->opt.msm_split >= 0) return ctx->opt.msm_split != 0 && ctx->opt.msm_quad != 0;
+  return n_terms <= BPP_SMALL_CALL_TERMS && ctx->opt.msm_quad != 0;
+}
+// goff: term offsets of the groups as the kernels will see them (already doubled for a split plan)
+void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff, bool split = false) {
   const uint32_t G = (uint32_t)goff.size() - 1, n = goff[G];
   uint32_t maxg = 0;
   for (uint32_t g = 0; g < G; g++) maxg = std::max(maxg, goff[g + 1] - goff[g]);
-  const MsmPlan plan = msm_make_plan(choose_window(ctx, maxg, n), G, n);
+  const MsmPlan plan = msm_make_plan(choose_window(ctx, maxg, split ? n / 2 : n), G, n, split ? 128u : 253u);
   w.plan = plan;
+  w.split = split;
   w.max_group_terms = maxg;
   const size_t nbk = (size_t)G * plan.K * plan.nb;
   w.counts.alloc(nbk);
@@ -525,7 +538,7 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
   hipLaunchKernelGGL(k_msm_order, dim3(plan.G), dim3(BPP_SORT_THREADS), 0, s, w.counts.p, w.order_win.p, w.cls_hist.p, plan, w.order.p);
   if (tm) tm->mark(M_ORDER);  // msm_accumulate_ms brackets k_msm_accumulate alone (the roofline kernel)
   // few buckets on an idle chip (one batch per call): quad forms, ~3x shorter dependency chains (tests force either form)
-  const bool small = ctx->opt.msm_quad >= 0 ? ctx->opt.msm_quad != 0 : (size_t)plan.G * per_group <= 100000;
+  const bool small = w.split || (ctx->opt.msm_quad >= 0 ? ctx->opt.msm_quad != 0 : (size_t)plan.G * per_group <= 100000);
   if (small)
     hipLaunchKernelGGL(k_msm_accumulate_quad, dim3(cdiv(plan.G * per_group, 16)), dim3(64), 0, s, w.sorted.p, w.starts.p,
                        w.counts.p, w.order.p, tabs, plan.G * per_group, w.buckets.p);
@@ -604,7 +617,7 @@ int msm_host_entry(bpp_ctx *ctx, const niels *tab_a, uint32_t n_a, const uint8_t
   }
   MsmWork w;
   msm_prepare(ctx, w, sidx, pidx, goff);
-  PointTables tabs{tab_a, d_dyn.p, n_a};
+  PointTables tabs{tab_a, d_dyn.p, n_a, nullptr, nullptr};
   msm_run(ctx, w, d_sc.p, tabs, nullptr);
   hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(w.plan.G, 64)), dim3(64), 0, ctx->stream, w.R.p, w.plan.G, w.comp32.p);
   HIP_CHECK(hipMemcpyAsync(out32, w.comp32.p, 32 * (goff.size() - 1), hipMemcpyDeviceToHost, ctx->stream));
@@ -847,6 +860,8 @@ int bpp_params_create(bpp_ctx *ctx, uint32_t bit_length, uint32_t max_aggregatio
       for (int i = 0; i < 32; i++) z = z && P->hg32[(size_t)k * 32 + i] == 0;
       if (z) return fail(ctx, BPP_ERR_VERIFICATION_FAILED, "Identity element cannot be added to the transcript");
     }
+    P->table_hi.alloc(P->table_len);
+    hipLaunchKernelGGL(k_shift127_table, dim3(cdiv(P->table_len, 64)), dim3(64), 0, ctx->stream, P->table.p, P->table_len, P->table_hi.p);
     P->fb_ped_geo = fb_geometry(t + 1);
     P->fb_ped.alloc((size_t)(t + 1) * fb_stride(P->fb_ped_geo));
     hipLaunchKernelGGL(k_fb_build,
@@ -1259,6 +1274,11 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, boo
   auto launch_decompress = [&](hipStream_t st) {
     hipLaunchKernelGGL(k_decompress, dim3(cdiv(n_proof_pts, 64)), dim3(64), 0, st, b.bytes.p, b.src_off.p, b.owner.p,
                        b.idx_proof.p, n_proof_pts, b.dynpts.p, b.status.p, b.dec_spill.p);
+    // half-scalar plan of small calls: the 2^127 multiples of every dynamic point (the statements' commitments were decoded
+    // at upload), 127 doublings each, right behind the decompression and -- for small inputs -- beside PASS 1 and the scalars.
+    // A point that did not decode left an arbitrary entry: its multiple is never looked at (the call fails on the status).
+    if (b.msm.split && !pass1_only)
+      hipLaunchKernelGGL(k_shift127_quad, dim3(cdiv(b.total_dyn, 16)), dim3(64), 0, st, b.dynpts.p, b.total_dyn, b.dyn_hi.p);
   };
   if (side) {
     if (!ctx->side_stream) {
@@ -1493,15 +1513,21 @@ void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk) {
   }
   goff[G] = run;
   dlo[G] = b.total_dyn;
-  msm_plan_alloc(ctx, b.msm, goff);  // leaves goff in pin_small[0 .. G]
+  const bool split = msm_wants_split(ctx, run);
+  if (split) {  // every term twice: (low half, P), (high half, 2^127 P)
+    for (uint32_t g = 0; g <= G; g++) goff[g] *= 2;
+    maxg *= 2;
+    b.dyn_hi.alloc(b.total_dyn);
+  }
+  msm_plan_alloc(ctx, b.msm, goff, split);  // leaves goff in pin_small[0 .. G]
   b.group_dlo.alloc(G + 1);
   uint32_t *pin = ctx->pin_small.data();
   memcpy(pin + (G + 1), b.h_group_first.data(), (G + 1) * 4);
   memcpy(pin + 2 * (size_t)(G + 1), dlo.data(), (G + 1) * 4);
   HIP_CHECK(hipMemcpyAsync(b.group_first.p, pin + (G + 1), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
   HIP_CHECK(hipMemcpyAsync(b.group_dlo.p, pin + 2 * (size_t)(G + 1), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_layout_terms, dim3(cdiv(maxg, 256), G), dim3(256), 0, ctx->stream, b.msm.group_off.p, b.group_dlo.p, G,
-                     b.cols, b.max_mn, n_gen, P.table_len, b.msm.term_sidx.p, b.msm.term_pidx.p);
+  hipLaunchKernelGGL(k_layout_terms, dim3(cdiv(split ? maxg / 2 : maxg, 256), G), dim3(256), 0, ctx->stream, b.msm.group_off.p, b.group_dlo.p, G,
+                     b.cols, b.max_mn, n_gen, P.table_len, split ? 1u : 0u, b.msm.term_sidx.p, b.msm.term_pidx.p);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(ctx->stream));  // goff / dlo are locals
   b.last_chunk = chunk;
@@ -1530,7 +1556,7 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
   hipLaunchKernelGGL(k_reduce_static, dim3(cdiv(b.cols, BPP_REDUCE_TILE), b.G), dim3(64), 0, s, b.rows.p, b.group_first.p, b.cols,
                      b.scal.p);
   tm.mark(M_REDUCE);
-  PointTables tabs{P.table.p, b.dynpts.p, P.table_len};
+  PointTables tabs{P.table.p, b.dynpts.p, P.table_len, P.table_hi.p, b.dyn_hi.p};
   msm_run(ctx, b.msm, b.scal.p, tabs, &tm);
   HIP_CHECK(hipGetLastError());
 }

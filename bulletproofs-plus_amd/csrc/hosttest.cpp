@@ -102,6 +102,19 @@ int ht_msm_recode(const uint8_t a[32], uint32_t c, int16_t *digits /* K */, uint
     if (msm_digit_at(x.v, plan, k) != (int32_t)digits[k]) return -1;
   for (uint32_t k = 0; k < plan.K; k++) widths[k] = k < plan.K_wide ? plan.c : plan.c - 1;
   return (int)plan.K; }
+// half-scalar plan: digits of the two halves (128-bit windows) -> out_lo[K], out_hi[K]; returns K
+int ht_msm_recode_split(const uint8_t a[32], uint32_t c, int16_t *out_lo, int16_t *out_hi, uint32_t *widths) {
+  sc x; sc_load_words(x, a);
+  const MsmPlan plan = msm_make_plan(c, 1, 2, 128);
+  uint32_t lo[8], hi[8];
+  msm_half_words(lo, x.v, false);
+  msm_half_words(hi, x.v, true);
+  for (uint32_t k = 0; k < plan.K; k++) {
+    out_lo[k] = (int16_t)msm_digit_at(lo, plan, k);
+    out_hi[k] = (int16_t)msm_digit_at(hi, plan, k);
+    widths[k] = k < plan.K_wide ? plan.c : plan.c - 1;
+  }
+  return (int)plan.K; }
 int ht_fb_recode(const uint8_t a[32], uint32_t n_gens, int16_t *digits /* 32 */, uint32_t *wbits) {
   sc x; sc_load_words(x, a);
   const FbGeom g = fb_geometry(n_gens);

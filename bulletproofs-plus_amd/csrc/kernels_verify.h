@@ -16,6 +16,7 @@
 #include "wstrobe.h"
 #include "lstrobe.h"
 #include "point.h"
+#include "recode.h"
 #include "scalar.h"
 
 namespace bpp {
@@ -785,18 +786,25 @@ __global__ void __launch_bounds__(64) k_build_slots(const ProofDesc *__restrict_
 // term_sidx -> index into scal[] (static part G*cols first, then dynamic), term_pidx -> index into the point tables
 // (generator table first, then dynpts).  grid = (ceil(max terms per group / 256), G).
 __global__ void __launch_bounds__(256) k_layout_terms(const uint32_t *__restrict__ goff, const uint32_t *__restrict__ dlo, uint32_t G,
-                                                      uint32_t cols, uint32_t max_mn, uint32_t n_gen, uint32_t table_len,
+                                                      uint32_t cols, uint32_t max_mn, uint32_t n_gen, uint32_t table_len, uint32_t split,
                                                       uint32_t *__restrict__ term_sidx, uint32_t *__restrict__ term_pidx) {
   const uint32_t g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t t0 = goff[g], ng = goff[g + 1] - t0;
+  const uint32_t t0 = goff[g], ng = (goff[g + 1] - t0) >> split;  // half-scalar plan: ng low-half terms, then ng high-half ones
   if (i >= ng) return;
+  uint32_t si, pi;
   if (i < cols) {
-    term_sidx[t0 + i] = g * cols + i;
-    term_pidx[t0 + i] = i < 2 * max_mn ? i : n_gen + (i - 2 * max_mn);
+    si = g * cols + i;
+    pi = i < 2 * max_mn ? i : n_gen + (i - 2 * max_mn);
   } else {
     const uint32_t q = dlo[g] + (i - cols);
-    term_sidx[t0 + i] = G * cols + q;
-    term_pidx[t0 + i] = table_len + q;
+    si = G * cols + q;
+    pi = table_len + q;
+  }
+  term_sidx[t0 + i] = si;
+  term_pidx[t0 + i] = pi;
+  if (split) {
+    term_sidx[t0 + ng + i] = si | BPP_TERM_HI;
+    term_pidx[t0 + ng + i] = pi | BPP_POINT_HI;
   }
 }
 

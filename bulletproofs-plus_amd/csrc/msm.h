@@ -26,6 +26,10 @@ struct PointTables {
   const niels *tab_a;
   const niels *tab_b;
   uint32_t n_a;
+  // half-scalar plans only (MsmPlan::split): the 2^127 multiples -- of the generators as affine-Niels entries (built once per
+  // parameter set), of the batch's dynamic points in extended coordinates (k_shift127_quad, every verification)
+  const niels *tab_a_hi;
+  const ge *tab_b_hi;
 };
 __device__ __forceinline__ const niels *point_ptr(const PointTables &t, uint32_t idx) {
   return idx < t.n_a ? (t.tab_a + idx) : (t.tab_b + (idx - t.n_a));
@@ -51,6 +55,15 @@ __device__ __forceinline__ const niels *point_ptr(const PointTables &t, uint32_t
 #ifndef BPP_SORT_THREADS
 #define BPP_SORT_THREADS 1024
 #endif
+// digit of window k of the term whose term_sidx entry is `si`: the whole scalar, or -- half-scalar plan -- the half the
+// entry's top bit selects
+__device__ __forceinline__ int32_t msm_term_digit(const sc *__restrict__ scalars, uint32_t si, const MsmPlan &plan, uint32_t k) {
+  if (!plan.split) return msm_digit_at(scalars[si].v, plan, k);
+  const sc s = scalars[si & ~BPP_TERM_HI];
+  uint32_t h[8];
+  msm_half_words(h, s.v, (si & BPP_TERM_HI) != 0);
+  return msm_digit_at(h, plan, k);
+}
 __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__restrict__ scalars, const uint32_t *__restrict__ term_sidx,
                                                       const uint32_t *__restrict__ term_pidx, const uint32_t *__restrict__ group_off,
                                                       MsmPlan plan, uint32_t dig_cap, uint32_t *__restrict__ counts,
@@ -78,7 +91,7 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__re
 #pragma unroll
     for (int u = 0; u < 8; u++) si[u] = (i0 + u * T < ng) ? term_sidx[t0 + i0 + u * T] : 0xffffffffu;
 #pragma unroll
-    for (int u = 0; u < 8; u++) d[u] = si[u] != 0xffffffffu ? msm_digit_at(scalars[si[u]].v, plan, k) : 0;
+    for (int u = 0; u < 8; u++) d[u] = si[u] != 0xffffffffu ? msm_term_digit(scalars, si[u], plan, k) : 0;
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const uint32_t i = i0 + u * T;
@@ -122,7 +135,7 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__re
       const uint32_t i = i0 + u * T;
       const bool in = i < ng;
       pi[u] = in ? term_pidx[t0 + i] : 0u;
-      d[u] = !in ? 0 : (i < dig_cap ? (int32_t)dcache[i] : msm_digit_at(scalars[term_sidx[t0 + i]].v, plan, k));
+      d[u] = !in ? 0 : (i < dig_cap ? (int32_t)dcache[i] : msm_term_digit(scalars, term_sidx[t0 + i], plan, k));
     }
 #pragma unroll
     for (int u = 0; u < 8; u++)
@@ -588,27 +601,97 @@ __global__ void __launch_bounds__(64) k_msm_accumulate_quad(const uint32_t *__re
   const uint32_t bkt = order[slot];
   const uint32_t a = starts[bkt], n = counts[bkt];
   if (n == 0) return;
-  fe m;
+  fe m, d2, one;
+  fe_const(d2, FE_D2);
+  fe_1(one);
   {
     ge id;
     ge_identity(id);
     quad_load(m, q, id);
   }
+  // An entry is (sign | high-multiple flag | point index).  Low entries and the generators' 2^127 multiples are affine-Niels
+  // table lines (mixed addition); the 2^127 multiples of the batch's own points exist in extended coordinates only
+  // (k_shift127_quad: normalising them would cost an inversion each) and take the full addition.
   uint32_t e = sorted[a];
-  niels pt = *point_ptr(tabs, e & 0x7fffffffu);
+  niels pn;
+  ge pg;
+  auto fetch = [&](uint32_t ent, niels &dn, ge &dg) {
+    const uint32_t pi = ent & 0x3fffffffu;
+    if (!(ent & BPP_POINT_HI)) dn = *point_ptr(tabs, pi);
+    else if (pi < tabs.n_a) dn = tabs.tab_a_hi[pi];
+    else dg = tabs.tab_b_hi[pi - tabs.n_a];
+  };
+  fetch(e, pn, pg);
   for (uint32_t i = 0; i < n; i++) {
     const uint32_t e_cur = e;
-    niels cur = pt;
+    niels cur = pn;
+    ge curg = pg;
     if (i + 1 < n) {
       e = sorted[a + i + 1];
-      pt = *point_ptr(tabs, e & 0x7fffffffu);
+      fetch(e, pn, pg);
     }
-    niels_cneg(cur, (e_cur >> 31) != 0);
-    quad_ge_madd(m, q, cur);
+    const bool neg = (e_cur >> 31) != 0;
+    if ((e_cur & BPP_POINT_HI) && (e_cur & 0x3fffffffu) >= tabs.n_a) {
+      if (neg) {  // -(X : Y : Z : T) = (-X : Y : Z : -T), brought back to reduced limbs for the products
+        ge_neg(curg, curg);
+        fe_carry(curg.X);
+        fe_carry(curg.T);
+      }
+      quad_ge_add(m, q, curg, d2, one);
+    } else {
+      niels_cneg(cur, neg);
+      quad_ge_madd(m, q, cur);
+    }
   }
   // lane q writes coordinate q
   fe *dst = (fe *)(buckets + bkt);
   dst[qi] = m;
+}
+
+// ---- 2^127 multiples for the half-scalar plan of small calls.  The final Horner step is 253 DEPENDENT doublings, 0.3 ms of
+// a 0.65 ms call whatever the batch size; with s = s_lo + 2^127 s_hi the MSM runs over twice the terms, (s_lo, P) and
+// (s_hi, 2^127 P), on 128-bit windows: the same number of additions, half the doublings.  2^127 P of a batch's own points is
+// 127 doublings per point, but those depend on the decompression only and run beside PASS 1 and the scalar stage.
+// One quad per point (the doubling's four squarings / products side by side, as in k_msm_final_quad): (a, b, .) = (y+x, y-x)
+// gives the point as (a - b : a + b : 2); T is not an input of a doubling.
+__global__ void __launch_bounds__(64) k_shift127_quad(const niels *__restrict__ pts, uint32_t n, ge *__restrict__ out) {
+  const uint32_t lane = threadIdx.x, qi = lane & 3u;
+  const QuadMask q = quad_mask(qi);
+  const uint32_t i = blockIdx.x * 16u + (lane >> 2);
+  if (i >= n) return;  // whole quads leave together
+  const niels p = pts[i];
+  ge g;
+  fe_sub(g.X, p.yplusx, p.yminusx);
+  fe_carry(g.X);
+  fe_add(g.Y, p.yplusx, p.yminusx);
+  fe_carry(g.Y);
+  fe_1(g.Z);
+  g.Z.v[0] = 2;
+  fe_0(g.T);
+  fe m;
+  quad_load(m, q, g);
+#pragma unroll 1
+  for (uint32_t k = 0; k < BPP_MSM_SPLIT_BIT; k++) quad_ge_dbl(m, q);
+  fe *dst = (fe *)(out + i);
+  dst[qi] = m;
+}
+// the generators' 2^127 multiples as table entries: one lane per generator, once per parameter set
+__global__ void __launch_bounds__(64) k_shift127_table(const niels *__restrict__ tab, uint32_t n, niels *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ge g;
+  ge_identity(g);
+  const niels p = tab[i];
+  ge_madd(g, g, p);
+  ge_dbl_n(g, g, (int)BPP_MSM_SPLIT_BIT);
+  fe zi, x, y;
+  fe_invert(zi, g.Z);
+  fe_mul(x, g.X, zi);
+  fe_mul(y, g.Y, zi);
+  niels e;
+  niels_from_affine(e, x, y);
+  fe_carry(e.yminusx);
+  out[i] = e;
 }
 
 // one workgroup of 1024 lanes per (group, window): 256 quads.  Quad (seg, i) adds a quarter of the buckets of row / column i

@@ -19,7 +19,12 @@ struct MsmPlan {
   uint32_t nb;       // buckets per window = 2^(c-1)
   uint32_t G;        // groups
   uint32_t n_terms;  // total terms
+  uint32_t split;    // 1: half-scalar plan -- every term appears twice, (s mod 2^127, P) and (s >> 127, 2^127 P), the windows
+                     // cover 128 bits: half the doublings in the final Horner step (small calls, msm.h)
 };
+#define BPP_MSM_SPLIT_BIT 127u
+#define BPP_TERM_HI 0x80000000u   // term_sidx: take the high half of the scalar
+#define BPP_POINT_HI 0x40000000u  // term_pidx / sorted[]: the point's 2^127 multiple (bit 31 of sorted[] is the sign)
 
 // digits of one canonical scalar, written with stride `stride` (window-major layout of k_msm_digits: stride = terms of the group)
 BPP_HD void msm_recode(int16_t *out, size_t stride, const sc &s, const MsmPlan &plan) {
@@ -76,15 +81,30 @@ BPP_HD int32_t msm_digit_at(const uint32_t *w, const MsmPlan &plan, uint32_t k) 
 }
 
 // plan for a group of `terms` terms with window width c
-inline MsmPlan msm_make_plan(uint32_t c, uint32_t G, uint32_t n_terms) {
+// bits = 253 (canonical scalars), or 128 for the half-scalar plan: the low half has 127 bits and the spare top bit keeps
+// the top window's raw value under half its range, so nothing carries out (the high half has 126 bits)
+inline MsmPlan msm_make_plan(uint32_t c, uint32_t G, uint32_t n_terms, uint32_t bits = 253) {
   MsmPlan plan;
   plan.c = c;
-  plan.K = (253 + c - 1) / c;
-  plan.K_wide = plan.K - (plan.K * c - 253);  // 253 = K_wide * c + (K - K_wide) * (c - 1)
+  plan.K = (bits + c - 1) / c;
+  plan.K_wide = plan.K - (plan.K * c - bits);  // bits = K_wide * c + (K - K_wide) * (c - 1)
   plan.nb = 1u << (c - 1);
   plan.G = G;
   plan.n_terms = n_terms;
+  plan.split = bits == 253 ? 0u : 1u;
   return plan;
+}
+// the half of a canonical scalar a split plan's term stands for, as eight words (upper ones zero)
+BPP_HD void msm_half_words(uint32_t h[8], const uint32_t *w, bool hi) {
+  if (!hi) {
+    h[0] = w[0];
+    h[1] = w[1];
+    h[2] = w[2];
+    h[3] = w[3] & 0x7fffffffu;
+  } else {
+    for (int i = 0; i < 4; i++) h[i] = (w[3 + i] >> 31) | ((i + 4 < 8 ? w[4 + i] : 0u) << 1);
+  }
+  h[4] = h[5] = h[6] = h[7] = 0;
 }
 
 // Window width is chosen per parameter set (fb_geometry): the widest window whose table stays under ~1.8 GB, because

@@ -270,3 +270,36 @@ def test_sharded_entry_over_rccl_one_rank(bpp, packed, engine):
         e.close()
     comm.close()
     params.close()
+
+
+@pytest.mark.parametrize("m,t,count,chunk", [(1, 1, 1, 0), (1, 1, 300, 0), (1, 1, 300, 64), (8, 1, 20, 0), (2, 3, 33, 16), (1, 1, 1100, 0)])
+def test_half_scalar_plan_equals_the_full_one(bpp, packed, engine, opt, m, t, count, chunk):
+    """small calls run the final MSM as a half-scalar plan: s = s_lo + 2^127 s_hi over (P, 2^127 P), 128-bit windows, half the
+    doublings of the final Horner step (msm.h: k_shift127_quad).  Forced on and off on the same resident batch: same accept /
+    reject, and where the check fails the same (non-identity) group element comes out of both plans"""
+    params, d = _inputs(bpp, packed, engine, m, t, count, 7500 + m + count)
+    K = bpp.ProofErrorKind
+    for tamper in (False, True):
+        proofs = d["proofs"].copy()
+        if tamper:
+            proofs[count // 2, 1 + 32 * t + 96] ^= 1  # r1
+        results = []
+        for split in (0, 1):
+            opt("msm_split", split)
+            rb = packed.ResidentBatch(params, proofs, d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+            try:
+                rb.verify_only(chunk)
+                verdict = None
+            except bpp.ProofError as e:
+                verdict = int(e.kind)
+            results.append((verdict, rb.trace(6), rb.trace(4), rb.trace(5)))
+            rb.close()
+        assert results[0] == results[1]
+        assert results[0][0] == (K.VerificationFailed if tamper else None)
+        groups = len(results[0][1]) // 32
+        if not tamper:
+            assert results[0][1] == bytes(32) * groups
+        else:
+            assert results[0][1] != bytes(32) * groups  # some group's sum is a real point, the same from both plans
+    opt("msm_split", -1)
+    params.close()
