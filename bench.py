@@ -448,7 +448,7 @@ def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, para
     K batches run their kernels side by side and share ONE all_gather per exchange; the waves (own communicator, own host
     thread each) overlap one wave's weight chains and exchanges with the other's kernels."""
     dmod = importlib.import_module("bulletproofs-plus_amd.dist")
-    K = int(os.environ.get("BPP_BENCH_WAVE_BATCHES", "8"))
+    K = int(os.environ.get("BPP_BENCH_WAVE_BATCHES", "12"))
     W = int(os.environ.get("BPP_BENCH_WAVES", "2"))
     n_local = 4096 // world
     counts = [n_local] * world
@@ -716,7 +716,7 @@ def main():
         legw.close()
         # -------------------------------------------------------------- single-call latency (configs[0]'s shape)
         lat_out = {}
-        for nb in (1, 256):
+        for nb in (1, 64, 256):
             legl = Leg(bpp, packed, torch, device, params2, data2, nb, 1, 1, 0, profile=False)
             legl.run_steps(10)
             ls, _ = legl.run_steps(50)  # the latency: no stage events
@@ -730,8 +730,9 @@ def main():
                                         "ms_per_call_median_with_stage_events": 1e3 * lsp[len(lsp) // 2],
                                         "proofs_per_s": nb / ls[len(ls) // 2], "roofline": rl, "stages_ms": sl}
             legl.close()
-        extra["latency"] = dict(lat_out, workload="BASELINE configs[0]'s shape through the engine: ONE call at a time, 1 and 256 "
-                                                  "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input")
+        extra["latency"] = dict(lat_out, workload="BASELINE configs[0]'s shape through the engine: ONE call at a time, 1, 64 and 256 "
+                                                  "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input; calls of up to ~128 proofs "
+                                                  "run the final MSM as a half-scalar plan (s = s_lo + 2^127 s_hi: half the Horner doublings)")
         # -------------------------------------------------------------- configs[4]: batch prover
         extra["prover"] = prover_leg()
         if profiler_legs:
