@@ -6,7 +6,7 @@
 // (:811,:849,:853,:894) and the final check is one group equation (:1050-1062).  SURVEY 8(e).
 //
 // RCCL is loaded lazily (dlopen) so that libbpp_hip.so itself does not depend on a 570 MB library its single-GPU callers
-// never touch; a process that already has librccl.so.1 loaded (e.g. through torch.distributed) gets that same copy.
+// never touch; the copy next to the HIP runtime in use is preferred (see rccl_api).
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -27,10 +27,28 @@ namespace {
 RcclApi &rccl_api() {
   static RcclApi *api = [] {
     RcclApi *a = new RcclApi();
-    const char *names[] = {getenv("BPP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
-      if (!n || !*n) continue;
-      a->lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    // RCCL must sit on the SAME HIP / HSA runtime this library is running on: RCCL opens the HSA runtime by name on its own,
+    // and a copy from another ROCm tree (say PyTorch's bundled librccl.so, already in the process, while this library was
+    // loaded first and bound to /opt/rocm's libamdhip64) finds an HSA runtime nobody initialised: "no ROCm-capable device".
+    // So the first candidates are the librccl files NEXT TO the libamdhip64 that hipGetDeviceCount resolves to; only then
+    // the bare names (which return whatever copy the process already holds).
+    std::vector<std::string> names;
+    if (const char *e = getenv("BPP_RCCL_LIB")) names.push_back(e);
+    Dl_info info;
+    if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+      std::string dir(info.dli_fname);
+      const size_t slash = dir.rfind('/');
+      if (slash != std::string::npos) {
+        dir.resize(slash + 1);
+        names.push_back(dir + "librccl.so.1");
+        names.push_back(dir + "librccl.so");
+      }
+    }
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    for (const std::string &n : names) {
+      if (n.empty()) continue;
+      a->lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (a->lib) break;
     }
     if (!a->lib) {

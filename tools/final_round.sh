@@ -1,14 +1,20 @@
 #!/bin/bash
-# On the GPU box: every number the docs quote, for one build (TAG = e.g. r02_v7): profile set, bench lines, tool benches.
-TAG=${1:-r02}
+# On the GPU box: every file tools/results_table.py reads, for one build (TAG = e.g. r03_v2): profile set, bench lines, tool
+# benches.  Steps are joined so that a failing GPU step stops the script (no further GPU work after a failure).
+set -e -o pipefail
+TAG=${1:-r03}
 O=gpurun_out
 mkdir -p $O
-tools/profile_round.sh $TAG > $O/${TAG}_profile.log 2>&1 || echo "profile_round failed"
-python3 bench.py > $O/${TAG}_bench_cfg2_default.json 2> $O/${TAG}_bench.err
-python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_steps20.json 2>> $O/${TAG}_bench.err
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_torchrun1.json 2>> $O/${TAG}_bench.err
-for T in 2 4 8 16; do BPP_HOST_THREADS=$T python3 bench.py --no-extra --no-cpu-baseline --no-traffic 2>/dev/null | tail -1; done > $O/${TAG}_host_threads.jsonl
-python3 tools/bench_upload.py --threads 1,4 > $O/${TAG}_bench_upload.jsonl 2>> $O/${TAG}_bench.err
-python3 tools/bench_latency.py > $O/${TAG}_bench_latency.jsonl 2>> $O/${TAG}_bench.err
-python3 tools/bench_prove.py > $O/${TAG}_bench_prove.jsonl 2>> $O/${TAG}_bench.err
+export TMPDIR=/tmp
+(cd tools/microbench && (test -x fetch_calib || hipcc -O3 --offload-arch=gfx950 fetch_calib.hip -o fetch_calib))
+timeout -k 10 700 bash tools/profile_round.sh $TAG > $O/${TAG}_profile.log 2>&1
+echo "profile set done"
+timeout -k 10 700 python3 bench.py > $O/${TAG}_bench_full.json 2> $O/${TAG}_bench.err
+echo "full bench done"
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline --no-traffic > $O/${TAG}_bench_steps20.json 2>> $O/${TAG}_bench.err
+timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/${TAG}_bench_torchrun1.json 2>> $O/${TAG}_bench.err
+echo "bench lines done"
+timeout -k 10 300 python3 tools/wave_probe.py "1x1,1x8,2x8,4x4,2x12,3x8" 30 > $O/${TAG}_wave_probe.jsonl 2>> $O/${TAG}_bench.err
+timeout -k 10 300 python3 tools/bench_latency.py > $O/${TAG}_bench_latency.jsonl 2>> $O/${TAG}_bench.err
+BPP_MSM_SPLIT=0 timeout -k 10 300 python3 tools/bench_latency.py --no-cpu > $O/${TAG}_bench_latency_nosplit.jsonl 2>> $O/${TAG}_bench.err
 echo "final_round $TAG done"
