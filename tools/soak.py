@@ -5,8 +5,13 @@ compared with the CPU oracle's (oracle/c: accept / reject and the error kind) fo
 the mixed, overlapping conditions of the throughput path with inputs no unit test enumerates.  Test infrastructure (uses the
 oracle as the checker), not part of the product.
 
+Every call goes through one of the engine's entry paths, picked at random (--paths): the item form (bpp_verify_batch), the
+packed blocking form (bpp_verify_batch_packed), the pipelined form (bpp_verify_submit_packed / collect, several tickets
+outstanding, collected in random order) and the sharded form over a one-rank RCCL communicator (bpp_verify_sharded: the whole
+call is one reference batch).  Small calls take the half-scalar MSM plan, larger ones the full plan.
+
     python tools/soak.py --seconds 120 --threads 4
-prints one JSON line: calls, rejected inputs, mismatches (must be 0)."""
+prints one JSON line: calls (per path), rejected inputs, mismatches (must be 0)."""
 import argparse
 import importlib
 import json
@@ -25,8 +30,13 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--seed", type=int, default=20260704)
+    ap.add_argument("--paths", default="items,packed,pipeline,sharded")
     args = ap.parse_args()
+    import numpy as np
     bpp = importlib.import_module("bulletproofs-plus_amd")
+    packed = importlib.import_module("bulletproofs-plus_amd.packed")
+    dmod = importlib.import_module("bulletproofs-plus_amd.dist")
+    paths = args.paths.split(",")
     from oracle import cport
     from tests.golden.loader import load_bench
     data = load_bench("bench_cfg2.bin")
@@ -34,17 +44,51 @@ def main():
     n_bits, m, t, label = data["bit_length"], data["m"], data["t"], data["label"]
     stop = time.time() + args.seconds
     stats = {"calls": 0, "rejected": 0, "mismatch": 0, "proofs": 0}
+    stats.update({"calls_" + p: 0 for p in paths})
     lock = threading.Lock()
     problems = []
+
+    def packed_input(sub):
+        n = len(sub)
+        proofs = np.frombuffer(b"".join(it["proof"] for it in sub), dtype=np.uint8).reshape(n, -1)
+        comm = np.frombuffer(b"".join(it["commitments"][0] for it in sub), dtype=np.uint8).reshape(n, 1, 32)
+        mins = np.array([[it["min_values"][0] or 0] for it in sub], dtype=np.uint64)
+        pres = np.array([[0 if it["min_values"][0] is None else 1] for it in sub], dtype=np.uint8)
+        return packed.PackedInput(proofs, comm, mins, pres, None, label)
 
     def worker(k):
         rng = random.Random(args.seed + k)
         eng = bpp.Engine(0)
         params = bpp.RangeParameters.init(n_bits, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=eng)
+        pipe = packed.Pipeline(params, depth=3) if "pipeline" in paths else None
+        comm = dmod.ShardComm(eng, 0, 1, dmod.ShardComm.unique_id()) if "sharded" in paths else None
         cp = cport.Params(n_bits, m, t)
+        pending = []  # pipeline tickets: (ticket, expected code, record)
+
+        def record(path, cnt, chunk, mutated, want, got):
+            with lock:
+                stats["calls"] += 1
+                stats["calls_" + path] += 1
+                stats["proofs"] += cnt
+                stats["rejected"] += 1 if want else 0
+                if got != want:
+                    stats["mismatch"] += 1
+                    if len(problems) < 5:
+                        problems.append({"thread": k, "path": path, "count": cnt, "chunk": chunk, "mutated": mutated, "oracle": want, "engine": got})
+
+        def collect(entry):
+            ticket, want, rec = entry
+            got = 0
+            try:
+                pipe.collect(ticket)
+            except bpp.ProofError as e:
+                got = int(e.kind)
+            record(*rec, want, got)
+
         while time.time() < stop:
+            path = rng.choice(paths)
             cnt = rng.choice([1, 2, 3, 7, 16, 64, 200, 256])
-            chunk = rng.choice([0, 0, 8, 64])
+            chunk = 0 if path == "sharded" else rng.choice([0, 0, 8, 64])
             sub = [dict(items[i]) for i in rng.sample(range(len(items)), cnt)]
             mutated = rng.random() < 0.5
             if mutated:
@@ -68,20 +112,35 @@ def main():
                     break
             got = 0
             try:
-                sts = [bpp.RangeStatement.init(params, it["commitments"], it["min_values"], None) for it in sub]
-                proofs = [bpp.RangeProof.from_bytes(it["proof"]) for it in sub]
-                trs = [bpp.Transcript.new(label) for _ in sub]
-                bpp.RangeProof.verify_batch(trs, sts, proofs, bpp.VerifyAction.VerifyOnly, chunk=chunk)
+                if path == "items":
+                    sts = [bpp.RangeStatement.init(params, it["commitments"], it["min_values"], None) for it in sub]
+                    proofs = [bpp.RangeProof.from_bytes(it["proof"]) for it in sub]
+                    trs = [bpp.Transcript.new(label) for _ in sub]
+                    bpp.RangeProof.verify_batch(trs, sts, proofs, bpp.VerifyAction.VerifyOnly, chunk=chunk)
+                elif path == "packed":
+                    packed.verify_batch(params, packed_input(sub), bpp.VerifyAction.VerifyOnly, chunk)
+                elif path == "pipeline":
+                    ticket = pipe.submit(packed_input(sub), bpp.VerifyAction.VerifyOnly, chunk)  # construction errors raise here
+                    pending.append((ticket, want, ("pipeline", cnt, chunk, mutated)))
+                    if len(pending) >= 3:
+                        collect(pending.pop(rng.randrange(len(pending))))
+                    continue
+                else:
+                    rb = packed.ResidentBatch(params, *[getattr(packed_input(sub), a) for a in ("proofs", "commitments", "min_values", "min_present")],
+                                              None, label)
+                    try:
+                        comm.verify(rb, [cnt])
+                    finally:
+                        rb.close()
             except bpp.ProofError as e:
                 got = int(e.kind)
-            with lock:
-                stats["calls"] += 1
-                stats["proofs"] += cnt
-                stats["rejected"] += 1 if want else 0
-                if got != want:
-                    stats["mismatch"] += 1
-                    if len(problems) < 5:
-                        problems.append({"thread": k, "count": cnt, "chunk": chunk, "mutated": mutated, "oracle": want, "engine": got})
+            record(path, cnt, chunk, mutated, want, got)
+        while pending:
+            collect(pending.pop())
+        if comm is not None:
+            comm.close()
+        params.close()
+        eng.close()
         cp.close()
 
     th = [threading.Thread(target=worker, args=(k,)) for k in range(args.threads)]
