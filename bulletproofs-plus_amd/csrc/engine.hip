@@ -1261,7 +1261,10 @@ namespace {
 // Weight-independent device work for the whole resident batch: PASS 1, decompression and -- unless `pass1_only` --
 // the per-proof scalar block (k_scalars_shared).  Returns after the transcript-RNG bytes have reached the host (h_rng); the rest is
 // still running on the stream (it overlaps the host weight chain).
-void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, bool fetch_rng = true) {
+// rng_dev_dst != nullptr (the sharded form): the transcript-RNG bytes are copied device -> device right behind PASS 1 and
+// ev_rng is recorded there; nothing comes to the host and the function does not wait
+void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uint8_t *rng_dev_dst = nullptr) {
+  const bool fetch_rng = rng_dev_dst == nullptr;
   Params &P = *b.params;
   hipStream_t s = ctx->stream;
   if (!ctx->ev_rng_ready) {
@@ -1311,10 +1314,9 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, boo
                          P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p);
   }
   tm.mark(M_TRANSCRIPTS);
-  if (fetch_rng) {  // (the sharded form gathers the device copy over RCCL instead)
-    HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
-  }
+  if (fetch_rng) HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));
+  else HIP_CHECK(hipMemcpyAsync(rng_dev_dst, b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToDevice, s));  // gathered over RCCL
+  HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
   if (!side) launch_decompress(s);
   tm.mark(M_DECOMPRESS);
   if (!pass1_only) {  // the weight-independent part of the PASS-2 scalars; the rest (k_scalars_lanes) takes the weights

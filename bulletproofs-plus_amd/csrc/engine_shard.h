@@ -258,8 +258,8 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
     n_total += counts[r];
   }
   if (n_total == 0 || n_total > (1u << 24)) return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "Range statements or proofs length empty");
-  // buffers: first exchange per rank = K slots of maxc x 32 RNG bytes + K trailers; second = K accumulators + K fault words
-  const size_t slot = (size_t)maxc * 32, per1 = K * slot + (size_t)K * BPP_SHARD_TRAILER_BYTES, per2 = (size_t)K * 128 + (size_t)K * 4;
+  // buffers: first exchange per rank = K slots of maxc x 32 RNG bytes; second = K accumulators + K findings (trailers)
+  const size_t slot = (size_t)maxc * 32, per1 = K * slot, per2 = (size_t)K * 128 + (size_t)K * BPP_SHARD_TRAILER_BYTES;
   std::vector<Batch *> B(K, nullptr);
   std::vector<int> fault(K, 0);           // engine fault on THIS rank, per batch
   std::vector<std::string> fault_msg(K);
@@ -279,11 +279,16 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
     comm->send2.alloc(per2);
     comm->recv2.alloc(per2 * world);
     comm->d_flags.alloc(K);
-    comm->h_tr.resize((size_t)K * BPP_SHARD_TRAILER_BYTES + (size_t)K * 4);
+    comm->h_tr.resize((size_t)K * BPP_SHARD_TRAILER_BYTES);
     comm->h_recv1.resize(per1 * world);
     comm->h_recv2.resize(per2 * world);
     comm->h_flags.resize(K);
     // ---------------------------------------------------------------- phase 1 on every context's own stream
+    // Only the transcript-RNG bytes cross before the weights exist: they leave PASS 1, the first kernel of the phase, so the
+    // exchange (and the weight chains behind it) overlap the decompression and the weight-free scalars of the same wave.
+    // What a rank FOUND travels with the second exchange, next to its accumulator.
+    hipStream_t cs = comm->stream;
+    std::vector<uint8_t> no_kernels(K, 0);  // nothing runs on this batch's items here (deferred consistency finding)
     for (uint32_t i = 0; i < K; i++) {
       try {
         auto it = ctxs[i]->batches.find(batches[i]);
@@ -294,28 +299,82 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
         StageTimer tm(ctxs[i]);
         hipStream_t s = ctxs[i]->stream;
         uint8_t *dst = comm->send1.p + (size_t)i * slot;
+        if (!ctxs[i]->ev_rng_ready) {
+          HIP_CHECK(hipEventCreateWithFlags(&ctxs[i]->ev_rng, hipEventDisableTiming));
+          ctxs[i]->ev_rng_ready = true;
+        }
         if (b.any_defer) {
           // verify()'s consistency loops (:637-682) fail this batch before anything is computed: nothing runs on items
-          // whose layout differs from the parameters'; the rank still sends a (zero) payload and its finding
+          // whose layout differs from the parameters'; the rank still sends a (zero) payload and, later, its finding
+          no_kernels[i] = 1;
           HIP_CHECK(hipMemsetAsync(dst, 0, slot, s));
-          continue;
+          HIP_CHECK(hipEventRecord(ctxs[i]->ev_rng, s));
+        } else {
+          layout_groups(ctxs[i], b, 0);
+          if (b.B < maxc) HIP_CHECK(hipMemsetAsync(dst + (size_t)b.B * 32, 0, (size_t)(maxc - b.B) * 32, s));
+          enqueue_phase1(ctxs[i], b, tm, b.any_rounds_bad, dst);
         }
-        layout_groups(ctxs[i], b, 0);
-        enqueue_phase1(ctxs[i], b, tm, b.any_rounds_bad, /*fetch_rng=*/false);
-        HIP_CHECK(hipMemcpyAsync(dst, b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToDevice, s));
-        if (b.B < maxc) HIP_CHECK(hipMemsetAsync(dst + (size_t)b.B * 32, 0, (size_t)(maxc - b.B) * 32, s));
-        fetch_status(ctxs[i], b);
+        HIP_CHECK(hipStreamWaitEvent(cs, ctxs[i]->ev_rng, 0));
       } catch (const EngineError &e) {
         fault[i] = e.code;
         fault_msg[i] = e.msg;
+        (void)hipMemsetAsync(comm->send1.p + (size_t)i * slot, 0, slot, cs);  // this rank's slot still has defined bytes
       }
     }
     lap(tmg.enqueue1_ms);
+    RCCL_CHECK(R.AllGather(comm->send1.p, comm->recv1.p, per1, ncclUint8, comm->comm, cs));
+    HIP_CHECK(hipMemcpyAsync(comm->h_recv1.data(), comm->recv1.p, per1 * world, hipMemcpyDeviceToHost, cs));
+    HIP_CHECK(hipStreamSynchronize(cs));
+    lap(tmg.gather1_ms);
+    // ---------------------------------------------------------------- weight transcripts over ALL proofs of each batch
+    {
+      comm->rng_all.resize((size_t)K * n_total * 32);
+      comm->weights_all.resize((size_t)K * n_total * 32);
+      std::vector<uint32_t> gfirst(K + 1);
+      for (uint32_t i = 0; i < K; i++) {
+        gfirst[i] = (uint32_t)(i * n_total);
+        uint8_t *dst = comm->rng_all.data() + (size_t)i * n_total * 32;
+        for (uint32_t r = 0; r < world; r++) {
+          memcpy(dst, comm->h_recv1.data() + (size_t)r * per1 + (size_t)i * slot, (size_t)counts[r] * 32);
+          dst += (size_t)counts[r] * 32;
+        }
+      }
+      gfirst[K] = (uint32_t)(K * n_total);
+      run_weight_chains_generic(comm->rng_all.data(), comm->weights_all.data(), gfirst.data(), K);
+      lap(tmg.chains_ms);
+      // PASS 2 + this rank's share of the MSM wherever the kernels ran and the shapes allow it (a batch with an L/R count
+      // that does not fit its statement has a PASS-2 finding coming and no scalars to run on)
+      for (uint32_t i = 0; i < K; i++) {
+        if (fault[i]) continue;
+        Batch &b = *B[i];
+        try {
+          StageTimer tm(ctxs[i]);
+          hipStream_t s = ctxs[i]->stream;
+          if (no_kernels[i] || b.any_rounds_bad) {
+            skip[i] = 1;
+            HIP_CHECK(hipMemsetAsync(comm->send2.p + (size_t)i * 128, 0, 128, s));
+            if (no_kernels[i]) HIP_CHECK(hipMemsetAsync(b.status.p, 0, (size_t)b.B * 4, s));
+          } else {
+            memcpy(b.h_weights.data(), comm->weights_all.data() + ((size_t)i * n_total + first_index) * 32, (size_t)b.B * 32);
+            enqueue_phase2(ctxs[i], b, tm);
+            hipLaunchKernelGGL(k_ge_to_bytes, dim3(1), dim3(64), 0, s, b.msm.R.p, 1u, comm->send2.p + (size_t)i * 128);
+            HIP_CHECK(hipGetLastError());
+            b.have_trace = true;
+          }
+          fetch_status(ctxs[i], b);
+        } catch (const EngineError &e) {
+          fault[i] = e.code;
+          fault_msg[i] = e.msg;
+        }
+      }
+    }
+    lap(tmg.enqueue2_ms);
+    // ---------------------------------------------------------------- findings: one trailer per batch, next to the accumulator
     for (uint32_t i = 0; i < K; i++) {
       uint8_t *tr = comm->h_tr.data() + (size_t)i * BPP_SHARD_TRAILER_BYTES;
       if (!fault[i] && hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) {
         fault[i] = BPP_ERR_ENGINE;
-        fault_msg[i] = "phase 1 failed on the device";
+        fault_msg[i] = "a kernel of this rank failed on the device";
       }
       if (fault[i]) {
         shard_trailer_encode(tr, BPP_TIER_ENGINE, fault[i], first_index, fault_msg[i].c_str());
@@ -324,71 +383,8 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
         shard_local_trailer(b.any_defer ? b.defer.data() : nullptr, b.h_status.data(), b.rounds_bad.data(), b.B, first_index, tr);
       }
     }
-    lap(tmg.wait1_ms);
-    hipStream_t cs = comm->stream;
-    HIP_CHECK(hipMemcpyAsync(comm->send1.p + K * slot, comm->h_tr.data(), (size_t)K * BPP_SHARD_TRAILER_BYTES, hipMemcpyHostToDevice, cs));
-    RCCL_CHECK(R.AllGather(comm->send1.p, comm->recv1.p, per1, ncclUint8, comm->comm, cs));
-    HIP_CHECK(hipMemcpyAsync(comm->h_recv1.data(), comm->recv1.p, per1 * world, hipMemcpyDeviceToHost, cs));
-    HIP_CHECK(hipStreamSynchronize(cs));
-    lap(tmg.gather1_ms);
-    // ---------------------------------------------------------------- every rank reads the same findings
-    std::vector<uint32_t> active;
-    for (uint32_t i = 0; i < K; i++) {
-      const ShardFinding f = shard_resolve(comm->h_recv1.data() + K * slot + (size_t)i * BPP_SHARD_TRAILER_BYTES, per1, (int)world);
-      if (f.tier != BPP_TIER_NONE) {
-        skip[i] = 1;
-        shard_result_set(results[i], f.code, f.tier, f.rank, f.index, f.msg + " (rank " + std::to_string(f.rank) + ")");
-      } else {
-        active.push_back(i);
-      }
-    }
-    // ---------------------------------------------------------------- weight transcripts over ALL proofs of each batch
-    if (!active.empty()) {
-      const size_t A = active.size();
-      comm->rng_all.resize(A * n_total * 32);
-      comm->weights_all.resize(A * n_total * 32);
-      std::vector<uint32_t> gfirst(A + 1);
-      for (size_t a = 0; a < A; a++) {
-        gfirst[a] = (uint32_t)(a * n_total);
-        uint8_t *dst = comm->rng_all.data() + a * n_total * 32;
-        for (uint32_t r = 0; r < world; r++) {
-          memcpy(dst, comm->h_recv1.data() + (size_t)r * per1 + (size_t)active[a] * slot, (size_t)counts[r] * 32);
-          dst += (size_t)counts[r] * 32;
-        }
-      }
-      gfirst[A] = (uint32_t)(A * n_total);
-      run_weight_chains_generic(comm->rng_all.data(), comm->weights_all.data(), gfirst.data(), (uint32_t)A);
-      lap(tmg.chains_ms);
-      for (size_t a = 0; a < A; a++) {
-        const uint32_t i = active[a];
-        try {
-          Batch &b = *B[i];
-          StageTimer tm(ctxs[i]);
-          hipStream_t s = ctxs[i]->stream;
-          memcpy(b.h_weights.data(), comm->weights_all.data() + (a * n_total + first_index) * 32, (size_t)b.B * 32);
-          enqueue_phase2(ctxs[i], b, tm);
-          hipLaunchKernelGGL(k_ge_to_bytes, dim3(1), dim3(64), 0, s, b.msm.R.p, 1u, comm->send2.p + (size_t)i * 128);
-          HIP_CHECK(hipGetLastError());
-          b.have_trace = true;
-        } catch (const EngineError &e) {
-          fault[i] = e.code;
-          fault_msg[i] = e.msg;
-        }
-      }
-    }
-    lap(tmg.enqueue2_ms);
-    uint32_t *fw = (uint32_t *)(comm->h_tr.data() + (size_t)K * BPP_SHARD_TRAILER_BYTES);
-    for (uint32_t i = 0; i < K; i++) {
-      if (!skip[i] && !fault[i] && hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) {
-        fault[i] = BPP_ERR_ENGINE;
-        fault_msg[i] = "phase 2 failed on the device";
-      }
-      fw[i] = skip[i] ? 0u : (uint32_t)fault[i];
-    }
     lap(tmg.wait2_ms);
-    for (uint32_t i = 0; i < K; i++)
-      if (skip[i]) HIP_CHECK(hipMemsetAsync(comm->send2.p + (size_t)i * 128, 0, 128, cs));
-    HIP_CHECK(hipMemcpyAsync(comm->send2.p + (size_t)K * 128, fw, (size_t)K * 4, hipMemcpyHostToDevice, cs));
+    HIP_CHECK(hipMemcpyAsync(comm->send2.p + (size_t)K * 128, comm->h_tr.data(), (size_t)K * BPP_SHARD_TRAILER_BYTES, hipMemcpyHostToDevice, cs));
     RCCL_CHECK(R.AllGather(comm->send2.p, comm->recv2.p, per2, ncclUint8, comm->comm, cs));
     hipLaunchKernelGGL(k_sum_accumulators_wave, dim3(cdiv(K, 64)), dim3(64), 0, cs, comm->recv2.p, world, (uint32_t)per2, K, comm->d_flags.p);
     HIP_CHECK(hipGetLastError());
@@ -396,20 +392,12 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
     HIP_CHECK(hipMemcpyAsync(comm->h_recv2.data(), comm->recv2.p, per2 * world, hipMemcpyDeviceToHost, cs));
     HIP_CHECK(hipStreamSynchronize(cs));
     lap(tmg.gather2_ms);
+    // every rank reads the same findings and decides alike: a finding of any rank (lowest tier, then lowest rank) comes
+    // before the final check, exactly as in the single-process verify(); an engine fault only counts when nothing was found
     for (uint32_t i = 0; i < K; i++) {
-      if (skip[i]) continue;
-      int bad_rank = -1, bad_code = 0;
-      for (uint32_t r = 0; r < world && bad_rank < 0; r++) {
-        uint32_t w;
-        memcpy(&w, comm->h_recv2.data() + (size_t)r * per2 + (size_t)K * 128 + (size_t)i * 4, 4);
-        if (w) {
-          bad_rank = (int)r;
-          bad_code = (int)w;
-        }
-      }
-      if (bad_rank >= 0)
-        shard_result_set(results[i], bad_code < 0 ? bad_code : BPP_ERR_ENGINE, BPP_TIER_ENGINE, bad_rank, 0,
-                         (bad_rank == (int)rank ? fault_msg[i] : std::string("engine fault")) + " (rank " + std::to_string(bad_rank) + ")");
+      const ShardFinding f = shard_resolve(comm->h_recv2.data() + (size_t)K * 128 + (size_t)i * BPP_SHARD_TRAILER_BYTES, per2, (int)world);
+      if (f.tier != BPP_TIER_NONE)
+        shard_result_set(results[i], f.code > 0 || f.code < 0 ? f.code : BPP_ERR_ENGINE, f.tier, f.rank, f.index, f.msg + " (rank " + std::to_string(f.rank) + ")");
       else if (!comm->h_flags[i])
         shard_result_set(results[i], BPP_ERR_VERIFICATION_FAILED, BPP_TIER_MSM, -1, 0, "Range proof batch not valid");
       else

@@ -162,7 +162,9 @@ def rehearse_sharded(ops, n_local, device, group=None, weights_fn=api.weights_fr
     """the two exchanges of bpp_verify_sharded with `ops` standing in for the kernels:
          ops.phase1_facts() -> (rng bytes, defer | None, status words, rounds_bad)     ops.phase2(weights32) -> 128-byte accumulator
          ops.sum_is_identity(accumulators128) -> bool
-    Whatever a rank's stand-in raises, the rank still reaches both collectives (an engine-fault finding travels instead)."""
+    As in the library: only the RNG bytes cross before the weights exist; what a rank found travels with its accumulator,
+    and a finding of any rank (lowest tier, then lowest rank) comes before the final check.  Whatever a rank's stand-in
+    raises, the rank still reaches both collectives (an engine-fault finding travels instead)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     first = n_local * rank
     try:
@@ -171,24 +173,21 @@ def rehearse_sharded(ops, n_local, device, group=None, weights_fn=api.weights_fr
         tr = local_trailer(defer, status, rounds_bad, first)
     except Exception as e:  # noqa: BLE001 - anything at all: the collective below must still be entered
         rng_local, tr = bytes(32 * n_local), fault_trailer(-1, first, "%s: %s" % (type(e).__name__, e))
-    stride = 32 * n_local + TRAILER
-    gathered = _all_gather_bytes(rng_local + tr, device, group)
-    res = resolve([gathered[stride * r + 32 * n_local:stride * (r + 1)] for r in range(world)])
+    gathered = _all_gather_bytes(rng_local, device, group)
+    weights_all = weights_fn(gathered)  # sequential sponge over ALL proofs: replayed by every rank, no broadcast needed
+    acc = bytes(128)
+    if tr == bytes(TRAILER):  # nothing found here: this rank's share of the final sum (the library runs it regardless;
+        try:                  # the stand-in cannot compute on proofs it has already rejected)
+            acc = ops.phase2(weights_all[32 * n_local * rank:32 * n_local * (rank + 1)])
+            assert len(acc) == 128
+        except Exception as e:  # noqa: BLE001
+            acc, tr = bytes(128), fault_trailer(-1, first, "%s: %s" % (type(e).__name__, e))
+    both = _all_gather_bytes(acc + tr, device, group)
+    stride = 128 + TRAILER
+    res = resolve([both[stride * r + 128:stride * (r + 1)] for r in range(world)])
     if res["code"] != 0:
         return _raise(res)
-    rng_all = b"".join(gathered[stride * r:stride * r + 32 * n_local] for r in range(world))
-    weights_all = weights_fn(rng_all)  # sequential sponge: replayed by every rank, no broadcast needed
-    fault = 0
-    try:
-        acc = ops.phase2(weights_all[32 * n_local * rank:32 * n_local * (rank + 1)])
-        assert len(acc) == 128
-    except Exception:  # noqa: BLE001
-        acc, fault = bytes(128), 1
-    accs = _all_gather_bytes(acc + bytes([fault]) + bytes(15), device, group)
-    for r in range(world):
-        if accs[144 * r + 128]:
-            raise api.EngineError("bpp engine error -1: engine fault (rank %d)" % r)
-    if not ops.sum_is_identity(b"".join(accs[144 * r:144 * r + 128] for r in range(world))):
+    if not ops.sum_is_identity(b"".join(both[stride * r:stride * r + 128] for r in range(world))):
         e = api.ProofError(api.ProofErrorKind.VerificationFailed, "Range proof batch not valid")
         e.tier, e.rank, e.index = 7, -1, 0
         raise e

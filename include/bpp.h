@@ -222,13 +222,14 @@ int bpp_accumulators_sum_is_identity(bpp_ctx *ctx, const uint8_t *accumulators12
 /* ---- ONE reference batch sharded over the GPUs of a node, behind the C ABI (BASELINE configs[3]) ----
  * One process (or thread) per GPU; rank r holds `counts[r]` consecutive proofs of the batch as a resident batch on its own
  * context.  bpp_verify_sharded runs RangeProof::verify (src/range_proof.rs:756-1065) over the union:
- *   PASS 1 + decompression + weight-free scalars on every rank's own proofs
- *   -> RCCL all_gather of the 32 transcript-RNG bytes per proof (device buffers, no host hop) + one 128-byte finding per rank
+ *   PASS 1 on every rank's own proofs, decompression and the weight-free scalars right behind it
+ *   -> RCCL all_gather of the 32 transcript-RNG bytes per proof (device buffers, no host hop) as soon as PASS 1 is done
  *   -> the batch-weight transcript (:811,:849,:853,:894) replayed by every rank over ALL proofs in order (a sequential
  *      sponge: cheaper to replay than to broadcast), each rank keeps the weights of its own proofs
  *   -> PASS 2 + the rank's share of the final MSM (:1050) -> one accumulator point per rank
- *   -> RCCL all_gather of the 128-byte accumulators (RCCL has no group-law reduction, so the north star's "all-reduce of
- *      the accumulator" is gather + the same sum on every rank), sum and identity test (:1057) on the device.
+ *   -> RCCL all_gather of the 128-byte accumulators, each with the 128-byte finding of its rank (RCCL has no group-law
+ *      reduction, so the north star's "all-reduce of the accumulator" is gather + the same sum on every rank), sum and
+ *      identity test (:1057) on the device; a finding of any rank comes before the final check, as in verify().
  * EVERY rank reaches both collectives whatever it found locally, and every rank returns the same result: the error the
  * single-process verify() would have raised first, decided by numeric tier (BPP_TIER_*), then lowest rank.
  * Return value: 0 Ok, 1..5 ProofError kind (same on every rank), BPP_ERR_COMM when RCCL fails (library missing,
@@ -258,9 +259,9 @@ typedef struct {
 } bpp_shard_result;
 int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t *batches, size_t k, const uint32_t *counts,
                             bpp_shard_result *results);
-/* host wall-clock split of the last wave on `comm` (ms): enqueueing phase 1 on the k streams, waiting for it, the first
- * exchange (trailers up, all_gather, everything down), the k weight chains, enqueueing phase 2, waiting for it, the second
- * exchange with the sum and identity test */
+/* host wall-clock split of the last wave on `comm` (ms): enqueueing phase 1 on the k streams, the first exchange (waits for
+ * PASS 1 only: all_gather, RNG bytes down), the k weight chains, enqueueing phase 2, waiting for the k streams, the second
+ * exchange with the sum and identity test (wait1_ms is always 0 since the first exchange no longer waits for all of phase 1) */
 typedef struct {
   float enqueue1_ms, wait1_ms, gather1_ms, chains_ms, enqueue2_ms, wait2_ms, gather2_ms;
   uint32_t batches;
