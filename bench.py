@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "4")),
+    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "6")),
                     help="steps in flight per GPU (one engine/stream + one host thread each)")
     ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_step", type=int,
                     default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "64")),
@@ -448,12 +448,12 @@ def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, para
     K batches run their kernels side by side and share ONE all_gather per exchange; the waves (own communicator, own host
     thread each) overlap one wave's weight chains and exchanges with the other's kernels."""
     dmod = importlib.import_module("bulletproofs-plus_amd.dist")
-    # One rank: two waves of twelve (one wave's weight chains and exchanges under the other's kernels).  Several ranks: ONE
+    # One rank: three waves of twelve (one wave's weight chains and exchanges under the others' kernels).  Several ranks: ONE
     # wave of sixteen -- two communicators progressing from two host threads per rank can reach their collectives in
     # different orders on different ranks; that is legal for RCCL as long as both kernels can be resident at once, but this
     # leg cannot be rehearsed on a multi-GPU node here, so it takes the form that cannot interleave at all.
     K = int(os.environ.get("BPP_BENCH_WAVE_BATCHES", "12" if world == 1 else "16"))
-    W = int(os.environ.get("BPP_BENCH_WAVES", "2" if world == 1 else "1"))
+    W = int(os.environ.get("BPP_BENCH_WAVES", "3" if world == 1 else "1"))
     n_local = 4096 // world
     counts = [n_local] * world
     nb = data2["proofs"].shape[0] // n_local
