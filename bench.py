@@ -68,6 +68,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per cpu_baseline leg")
     ap.add_argument("--wide-steps", type=int, default=40)
+    ap.add_argument("--wide-timeout", type=int, default=240, help="seconds after which the sharded leg (N > 1 / torchrun) is abandoned")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE, SQ_*) that fill roofline.traffic")
     ap.add_argument("--only", choices=("headline", "cfg3", "prover"), default=None,
@@ -724,7 +725,24 @@ def main():
         out["pcie_inclusive_value"] = extra["host_in"]["one_context"]["proofs_per_s"]
     # ------------------------------------------------------------------ N > 1: BASELINE configs[3], one batch over all ranks
     if use_dist:
-        extra["wide"] = wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, params2, data2, args, sync)
+        # The headline above is complete; this leg must not be able to take it down.  An exception is reported inside the
+        # object; a collective that never returns (this leg cannot be rehearsed on a multi-GPU node by the builder) is cut
+        # short by a watchdog: after --wide-timeout seconds every rank gives up at once, rank 0 prints the line it has
+        # (extra.wide = the timeout) and the process ends without waiting for the stuck communicator.
+        def give_up():
+            if rank == 0:
+                out["extra"] = dict(extra, wide={"error": "the sharded leg did not finish within %d s; headline unaffected" % args.wide_timeout,
+                                                 "rccl_ranks": world})
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.wide_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            extra["wide"] = wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, params2, data2, args, sync)
+        except Exception as e:  # noqa: BLE001
+            extra["wide"] = {"error": "%s: %s" % (type(e).__name__, e), "rccl_ranks": world}
+        dog.cancel()
 
     if rank == 0 and world == 1 and not args.no_extra:
         # -------------------------------------------------------------- configs[2]: 256 x aggregation-8
@@ -779,7 +797,7 @@ def main():
     if extra and rank == 0:
         out["extra"] = extra
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (the contract: on rank 0 at N = 1 only)
         from oracle import cport  # cpu_baseline leg only: the oracle is the thing timed here, never the product path
         cp = cport.Params(64, 1, 1)
         ncpu = usable_cpus()
