@@ -93,6 +93,7 @@ SYMBOLS = [
     ("bpp_comm_unique_id", c_int, [c_void_p]),
     ("bpp_comm_create", c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
     ("bpp_comm_adopt", c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    ("bpp_comm_create_local", c_int, [c_void_p, c_uint64, c_int, c_int, POINTER(c_void_p)]),
     ("bpp_comm_destroy", None, [c_void_p]),
     ("bpp_comm_last_error", c_char_p, [c_void_p]),
     ("bpp_comm_last_timing", c_int, [c_void_p, POINTER(ShardTiming)]),

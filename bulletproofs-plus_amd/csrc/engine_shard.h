@@ -106,8 +106,32 @@ __global__ void k_sum_accumulators_wave(const uint8_t *__restrict__ in, uint32_t
 
 }  // namespace
 
+// In-process stand-in for the communicator (bpp_comm_create_local): the "ranks" are threads of ONE process on ONE device,
+// each with its own context; an all_gather is a rendezvous plus device-to-device copies.  It exists so that the sharded
+// entry points can be driven with several ranks -- ragged shard sizes, findings on any rank, the slicing of the replayed
+// weight chain -- on a box with a single GPU, through exactly the code the RCCL form runs (tests/test_gpu_round3.py).
+struct LocalGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  int world = 1, arrived = 0;
+  uint64_t generation = 0;
+  std::vector<const uint8_t *> send;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t gen = generation;
+    if (++arrived == world) {
+      arrived = 0;
+      generation++;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+
 struct bpp_comm {
   int device = 0, rank = 0, world = 1;
+  std::shared_ptr<LocalGroup> local;  // set: in-process transport instead of RCCL
   ncclComm_t comm = nullptr;
   bool own_comm = false;
   hipStream_t stream = nullptr;  // collectives and their staging copies
@@ -140,6 +164,27 @@ int comm_new(bpp_ctx *ctx, ncclComm_t nc, bool own, int rank, int world, bpp_com
   *out = c.release();
   return BPP_OK;
 }
+
+// all_gather of `bytes` per rank on the communicator's stream: RCCL, or the in-process rendezvous
+void comm_allgather(bpp_comm *c, const uint8_t *send, uint8_t *recv, size_t bytes, hipStream_t cs) {
+  if (!c->local) {
+    RCCL_CHECK(rccl_api().AllGather(send, recv, bytes, ncclUint8, c->comm, cs));
+    return;
+  }
+  HIP_CHECK(hipStreamSynchronize(cs));  // everything this rank sends is in place
+  {
+    std::lock_guard<std::mutex> lk(c->local->mu);
+    c->local->send[c->rank] = send;
+  }
+  c->local->barrier();
+  for (int r = 0; r < c->world; r++)
+    HIP_CHECK(hipMemcpyAsync(recv + (size_t)r * bytes, c->local->send[r], bytes, hipMemcpyDeviceToDevice, cs));
+  HIP_CHECK(hipStreamSynchronize(cs));
+  c->local->barrier();  // nobody reuses a send buffer before every rank has read it
+}
+
+std::mutex g_local_groups_mu;
+std::map<uint64_t, std::weak_ptr<LocalGroup>> g_local_groups;
 
 void shard_result_set(bpp_shard_result &r, int code, int tier, int rank, uint32_t index, const std::string &msg) {
   r.code = code;
@@ -187,6 +232,27 @@ int bpp_comm_adopt(bpp_ctx *ctx, void *nccl_comm, int rank, int world, bpp_comm 
   RcclApi &R = rccl_api();
   if (!R.err.empty()) return fail(ctx, BPP_ERR_COMM, R.err);
   return comm_new(ctx, (ncclComm_t)nccl_comm, false, rank, world, out);
+}
+
+int bpp_comm_create_local(bpp_ctx *ctx, uint64_t group_id, int rank, int world, bpp_comm **out) {
+  BPP_ENTRY(ctx);
+  if (!out || world < 1 || rank < 0 || rank >= world) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "bad communicator arguments");
+  *out = nullptr;
+  std::shared_ptr<LocalGroup> g;
+  {
+    std::lock_guard<std::mutex> lk(g_local_groups_mu);
+    g = g_local_groups[group_id].lock();
+    if (!g) {
+      g = std::make_shared<LocalGroup>();
+      g->world = world;
+      g->send.assign(world, nullptr);
+      g_local_groups[group_id] = g;
+    }
+  }
+  if (g->world != world) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "this group id exists with another world size");
+  const int rc = comm_new(ctx, nullptr, false, rank, world, out);
+  if (rc == BPP_OK) (*out)->local = g;
+  return rc;
 }
 
 void bpp_comm_destroy(bpp_comm *c) {
@@ -249,7 +315,6 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
       if (ctxs[j] == ctxs[i]) return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "every batch of a wave needs its own context (stream)");
     ctx_locks.emplace_back(ctxs[i]->mu);
   }
-  RcclApi &R = rccl_api();
   uint32_t maxc = 0, first_index = 0;
   uint64_t n_total = 0;
   for (uint32_t r = 0; r < world; r++) {
@@ -322,7 +387,7 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
       }
     }
     lap(tmg.enqueue1_ms);
-    RCCL_CHECK(R.AllGather(comm->send1.p, comm->recv1.p, per1, ncclUint8, comm->comm, cs));
+    comm_allgather(comm, comm->send1.p, comm->recv1.p, per1, cs);
     HIP_CHECK(hipMemcpyAsync(comm->h_recv1.data(), comm->recv1.p, per1 * world, hipMemcpyDeviceToHost, cs));
     HIP_CHECK(hipStreamSynchronize(cs));
     lap(tmg.gather1_ms);
@@ -385,7 +450,7 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
     }
     lap(tmg.wait2_ms);
     HIP_CHECK(hipMemcpyAsync(comm->send2.p + (size_t)K * 128, comm->h_tr.data(), (size_t)K * BPP_SHARD_TRAILER_BYTES, hipMemcpyHostToDevice, cs));
-    RCCL_CHECK(R.AllGather(comm->send2.p, comm->recv2.p, per2, ncclUint8, comm->comm, cs));
+    comm_allgather(comm, comm->send2.p, comm->recv2.p, per2, cs);
     hipLaunchKernelGGL(k_sum_accumulators_wave, dim3(cdiv(K, 64)), dim3(64), 0, cs, comm->recv2.p, world, (uint32_t)per2, K, comm->d_flags.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(comm->h_flags.data(), comm->d_flags.p, (size_t)K * 4, hipMemcpyDeviceToHost, cs));

@@ -29,10 +29,13 @@ TRAILER = 128  # BPP_SHARD_TRAILER_BYTES
 class ShardComm:
     """bpp_comm: one RCCL communicator + the staging of the two exchanges.  `engine` fixes the device."""
 
-    def __init__(self, engine, rank, world, unique_id):
+    def __init__(self, engine, rank, world, unique_id=None, local_group=None):
         self.engine, self.rank, self.world, self.lib = engine, rank, world, engine.lib
         self.handle = c_void_p()
-        rc = self.lib.bpp_comm_create(engine.ctx, _lib_buf(unique_id), rank, world, byref(self.handle))
+        if local_group is not None:  # bpp_comm_create_local: ranks = threads of this process on one device (tests)
+            rc = self.lib.bpp_comm_create_local(engine.ctx, int(local_group), rank, world, byref(self.handle))
+        else:
+            rc = self.lib.bpp_comm_create(engine.ctx, _lib_buf(unique_id), rank, world, byref(self.handle))
         api._check(rc, engine.ctx)
 
     @staticmethod

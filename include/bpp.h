@@ -243,6 +243,10 @@ typedef struct bpp_comm bpp_comm;
 int bpp_comm_unique_id(uint8_t id128[128]);
 int bpp_comm_create(bpp_ctx *ctx, const uint8_t id128[128], int rank, int world, bpp_comm **out);
 int bpp_comm_adopt(bpp_ctx *ctx, void *nccl_comm, int rank, int world, bpp_comm **out);
+/* In-process stand-in for tests on a single GPU: the `world` ranks are threads of one process, each with its own context on
+ * the same device; an all_gather is a rendezvous of the threads plus device-to-device copies.  Everything else of
+ * bpp_verify_sharded(_wave) is the code the RCCL form runs.  Ranks of one group pass the same (arbitrary) group_id. */
+int bpp_comm_create_local(bpp_ctx *ctx, uint64_t group_id, int rank, int world, bpp_comm **out);
 void bpp_comm_destroy(bpp_comm *comm);
 const char *bpp_comm_last_error(bpp_comm *comm);
 int bpp_verify_sharded(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, const uint32_t *counts /* world entries */,

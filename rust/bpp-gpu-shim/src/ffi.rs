@@ -98,6 +98,19 @@ pub struct bpp_shard_result {
 
 #[repr(C)]
 #[derive(Default, Clone, Copy, Debug)]
+pub struct bpp_shard_timing {
+    pub enqueue1_ms: f32,
+    pub wait1_ms: f32,
+    pub gather1_ms: f32,
+    pub chains_ms: f32,
+    pub enqueue2_ms: f32,
+    pub wait2_ms: f32,
+    pub gather2_ms: f32,
+    pub batches: u32,
+}
+
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
 pub struct bpp_profile {
     pub transcripts_ms: f32,
     pub decompress_ms: f32,
@@ -133,6 +146,7 @@ extern "C" {
     pub fn bpp_ctx_create_on_stream(out: *mut *mut bpp_ctx, device_id: c_int, hip_stream: *mut c_void) -> c_int;
     pub fn bpp_ctx_destroy(ctx: *mut bpp_ctx);
     pub fn bpp_ctx_last_error(ctx: *mut bpp_ctx) -> *const c_char;
+    pub fn bpp_ctx_set_option(ctx: *mut bpp_ctx, name: *const c_char, value: c_int) -> c_int;
     // B1: VartimePrecomputedMultiscalarMul / VartimeMultiscalarMul / MultiscalarMul (src/traits.rs:40-43, src/ristretto.rs:28-64)
     pub fn bpp_precomp_create(ctx: *mut bpp_ctx, points32: *const u8, count: usize, handle: *mut u64) -> c_int;
     pub fn bpp_precomp_destroy(ctx: *mut bpp_ctx, handle: u64) -> c_int;
@@ -176,8 +190,10 @@ extern "C" {
     pub fn bpp_comm_unique_id(id128: *mut u8) -> c_int;
     pub fn bpp_comm_create(ctx: *mut bpp_ctx, id128: *const u8, rank: c_int, world: c_int, out: *mut *mut bpp_comm) -> c_int;
     pub fn bpp_comm_adopt(ctx: *mut bpp_ctx, nccl_comm: *mut c_void, rank: c_int, world: c_int, out: *mut *mut bpp_comm) -> c_int;
+    pub fn bpp_comm_create_local(ctx: *mut bpp_ctx, group_id: u64, rank: c_int, world: c_int, out: *mut *mut bpp_comm) -> c_int;
     pub fn bpp_comm_destroy(comm: *mut bpp_comm);
     pub fn bpp_comm_last_error(comm: *mut bpp_comm) -> *const c_char;
+    pub fn bpp_comm_last_timing(comm: *mut bpp_comm, out: *mut bpp_shard_timing) -> c_int;
     pub fn bpp_verify_sharded(comm: *mut bpp_comm, ctx: *mut bpp_ctx, batch: u64, counts: *const u32, tier_out: *mut c_int,
                               rank_out: *mut c_int, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
     pub fn bpp_verify_sharded_wave(comm: *mut bpp_comm, ctxs: *const *mut bpp_ctx, batches: *const u64, k: usize, counts: *const u32,

@@ -303,3 +303,87 @@ def test_half_scalar_plan_equals_the_full_one(bpp, packed, engine, opt, m, t, co
             assert results[0][1] != bytes(32) * groups  # some group's sum is a real point, the same from both plans
     opt("msm_split", -1)
     params.close()
+
+
+def test_sharded_entry_with_three_ranks_in_process(bpp, packed, engine):
+    """bpp_verify_sharded with THREE ranks on one GPU: the ranks are threads of this process, each with its own context and a
+    communicator of the in-process transport (bpp_comm_create_local: the all_gather is a rendezvous + device copies; everything
+    else is the code the RCCL form runs).  Ragged shards (100 + 37 + 163 proofs): every rank must return the same outcome, the
+    one the single-call form gives on the union -- verdict, tier, and for per-proof findings the rank and the index in the
+    whole batch -- and each rank's weights must be its slice of the one weight chain over all 300 proofs."""
+    import threading
+    dmod = importlib.import_module("bulletproofs-plus_amd.dist")
+    params, d = _inputs(bpp, packed, engine, 1, 1, 300, 7600)
+    K = bpp.ProofErrorKind
+    counts, world = [100, 37, 163], 3
+    first = [0, 100, 137]
+    engs = [bpp.Engine(0) for _ in range(world)]
+    pars = [params.share(e) for e in engs]
+    comms = [dmod.ShardComm(engs[r], r, world, local_group=4242) for r in range(world)]
+
+    def run(proofs, commitments=None):
+        comm_arr = d["commitments"] if commitments is None else commitments
+        out, weights = [None] * world, [None] * world
+
+        def rank_main(r):
+            sl = slice(first[r], first[r] + counts[r])
+            rb = packed.ResidentBatch(pars[r], proofs[sl], comm_arr[sl], d["min_values"][sl], d["min_present"][sl], None, LABEL)
+            try:
+                comms[r].verify(rb, counts)
+                out[r] = None
+                weights[r] = rb.trace(3)
+            except bpp.ProofError as e:
+                out[r] = (int(e.kind), e.tier, e.rank, e.index)
+            except BaseException as e:  # noqa: BLE001
+                out[r] = ("exception", repr(e))
+            finally:
+                rb.close()
+        ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in ths), "a rank is stuck in a collective"
+        assert out[0] == out[1] == out[2], out
+        # the single-call form over the union
+        rb = packed.ResidentBatch(params, proofs, comm_arr, d["min_values"], d["min_present"], None, LABEL)
+        try:
+            rb.verify_only(0)
+            want = None
+        except bpp.ProofError as e:
+            want = int(e.kind)
+        w_all = rb.trace(3)
+        rb.close()
+        assert (out[0][0] if out[0] else None) == want, (out[0], want)
+        if out[0] is None:
+            assert b"".join(weights) == w_all  # every rank used its slice of the one chain
+        return out[0]
+
+    def mut(*edits):
+        pr = d["proofs"].copy()
+        for i, what in edits:
+            if what == "r1":
+                pr[i, 1 + 32 + 96] ^= 1
+            elif what == "badpoint":
+                pr[i, 1 + 32:1 + 64] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)
+            elif what == "identity":
+                pr[i, 1 + 32:1 + 64] = 0
+        return pr
+
+    assert run(d["proofs"]) is None
+    assert run(mut((120, "r1"))) == (K.VerificationFailed, 7, -1, 0)                      # only the sum notices
+    assert run(mut((120, "badpoint"))) == (K.InvalidArgument, 6, 1, 120)                   # rank 1, proof 120 of the batch
+    assert run(mut((250, "identity"))) == (K.VerificationFailed, 5, 2, 250)                # PASS 1 on rank 2
+    assert run(mut((5, "badpoint"), (250, "identity"))) == (K.VerificationFailed, 5, 2, 250)   # PASS 1 of any proof first
+    assert run(mut((136, "badpoint"), (20, "badpoint"))) == (K.InvalidArgument, 6, 0, 20)   # same tier: the earlier proof
+    bad_comm = d["commitments"].copy()
+    bad_comm[299, 0] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)
+    assert run(mut((3, "identity")), bad_comm) == (K.InvalidArgument, 4, 2, 299)            # a statement point before PASS 1
+    assert run(d["proofs"]) is None                                                          # still in step afterwards
+    for c in comms:
+        c.close()
+    for p in pars:
+        p.close()
+    for e in engs:
+        e.close()
+    params.close()
