@@ -418,11 +418,21 @@ __global__ void __launch_bounds__(64) k_msm_final(const ge *__restrict__ W, MsmP
 // into the consumer, and for `x - broadcast(y)` it emits v_subrev_u32_dpp, which on this toolchain / chip computes
 // broadcast(x) - y: `v_subrev_u32_dpp d, A, B quad_perm:[3,3,3,3]` returns B[lane 3] - A[lane] instead of B[lane] - A[lane 3]
 // (v_sub_u32_dpp and v_add_u32_dpp behave as documented; tools/isa/dpp_hazard_check.py refuses the opcode in any build).
+// The ten moves and ONE trailing wait state are a single asm statement: the compiler can neither fold a broadcast into its
+// consumer (the subrev problem above) nor put a store of the last result right behind it (the stale-store-data problem:
+// a DPP result read as store DATA by the very next instruction; every earlier result already has the following move as its
+// wait state).  Correctness then does not depend on what the scheduler or the register allocator happen to do; the
+// build-time disassembly check (tools/isa/dpp_hazard_check.py) stays as the net under compiler-generated DPP.
 template <int S>
 __device__ __forceinline__ void quad_bcast(fe &r, const fe &v) {
-#pragma unroll
-  for (int i = 0; i < 10; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.v[i], S * 0x55, 0xf, 0xf, false);
-  fe_fence(r);
+  static_assert(S >= 0 && S < 4, "quad position");
+#define BPP_QB(i) "v_mov_b32_dpp %" #i ", %1" #i " quad_perm:[%20,%20,%20,%20] row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile(BPP_QB(0) BPP_QB(1) BPP_QB(2) BPP_QB(3) BPP_QB(4) BPP_QB(5) BPP_QB(6) BPP_QB(7) BPP_QB(8) BPP_QB(9) "s_nop 0"
+               : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]),
+                 "=&v"(r.v[8]), "=&v"(r.v[9])
+               : "v"(v.v[0]), "v"(v.v[1]), "v"(v.v[2]), "v"(v.v[3]), "v"(v.v[4]), "v"(v.v[5]), "v"(v.v[6]), "v"(v.v[7]), "v"(v.v[8]),
+                 "v"(v.v[9]), "n"(S));
+#undef BPP_QB
 }
 // per-lane choice among four field elements: three v_cndmask per limb under wavefront-wide lane masks held in scalar
 // registers (ternaries get turned into divergent branches with the multiplication duplicated in every arm, which serialises
