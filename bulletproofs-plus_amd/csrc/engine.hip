@@ -280,7 +280,7 @@ struct Batch {
   DevBuf<uint32_t> status, group_first, group_dlo;
   DevBuf<uint32_t> dec_spill;  // k_decompress parks three field elements per proof point here across its squaring chain
   DevBuf<niels> dynpts;
-  DevBuf<ge> dyn_hi;  // 2^127 x dynpts (half-scalar plan only)
+  DevBuf<pniels> dyn_hi;  // 2^127 x dynpts as projective Niels entries (half-scalar plan only)
   MsmWork msm;
   // layout of the last verify
   size_t last_chunk = (size_t)-1;

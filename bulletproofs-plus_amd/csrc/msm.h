@@ -27,9 +27,16 @@ struct PointTables {
   const niels *tab_b;
   uint32_t n_a;
   // half-scalar plans only (MsmPlan::split): the 2^127 multiples -- of the generators as affine-Niels entries (built once per
-  // parameter set), of the batch's dynamic points in extended coordinates (k_shift127_quad, every verification)
+  // parameter set), of the batch's dynamic points as PROJECTIVE Niels entries (k_shift127_quad, every verification)
   const niels *tab_a_hi;
-  const ge *tab_b_hi;
+  const struct pniels *tab_b_hi;
+};
+// (Y+X, Y-X, 2dT, 2Z): a point that is not normalised to Z = 1, in the form the mixed addition consumes.  An affine-Niels
+// entry is the special case 2Z = 2, so ONE addition routine (and one instruction stream: no divergence inside a
+// wavefront) serves table lines and the 2^127 multiples of a batch's own points, which exist in projective form only
+// (normalising them would cost an inversion each).
+struct pniels {
+  fe yplusx, yminusx, xy2d, z2;
 };
 __device__ __forceinline__ const niels *point_ptr(const PointTables &t, uint32_t idx) {
   return idx < t.n_a ? (t.tab_a + idx) : (t.tab_b + (idx - t.n_a));
@@ -507,19 +514,18 @@ __device__ __forceinline__ void quad_ge_add(fe &m, const QuadMask &q, const ge &
   quad_efgh(m, q, e, f, gg, h);
 }
 // acc += pt (affine Niels, already sign-adjusted): the seven products of ge_madd in two rounds
-__device__ __forceinline__ void quad_ge_madd(fe &m, const QuadMask &q, const niels &pt) {
+// (zz = 2 Z' of the entry: the constant 2 for an affine table line, pniels::z2 for a projective one)
+__device__ __forceinline__ void quad_ge_madd(fe &m, const QuadMask &q, const niels &pt, const fe &zz) {
   fe X, Y, Z, T;
   quad_bcast<0>(X, m);
   quad_bcast<1>(Y, m);
   quad_bcast<2>(Z, m);
   quad_bcast<3>(T, m);
-  fe l0, l1, l, r, s2, zz;
+  fe l0, l1, l, r, s2;
   fe_add(l0, Y, X);
   fe_sub(l1, Y, X);
   fe_sel4(l, q, l0, l1, T, Z);
-  fe_1(zz);
-  zz.v[0] = 2;  // lane 3: d = 2 Z
-  fe_sel4(r, q, pt.yplusx, pt.yminusx, pt.xy2d, zz);
+  fe_sel4(r, q, pt.yplusx, pt.yminusx, pt.xy2d, zz);  // lane 3: d = Z * 2Z'
   fe_mul(s2, l, r);  // a, b, c, d
   fe a, b, c, d, e, f, gg, h;
   quad_bcast<0>(a, s2);
@@ -611,47 +617,45 @@ __global__ void __launch_bounds__(64) k_msm_accumulate_quad(const uint32_t *__re
   const uint32_t bkt = order[slot];
   const uint32_t a = starts[bkt], n = counts[bkt];
   if (n == 0) return;
-  fe m, d2, one;
-  fe_const(d2, FE_D2);
-  fe_1(one);
+  fe m;
   {
     ge id;
     ge_identity(id);
     quad_load(m, q, id);
   }
   // An entry is (sign | high-multiple flag | point index).  Low entries and the generators' 2^127 multiples are affine-Niels
-  // table lines (mixed addition); the 2^127 multiples of the batch's own points exist in extended coordinates only
-  // (k_shift127_quad: normalising them would cost an inversion each) and take the full addition.
+  // table lines (2Z = 2); the 2^127 multiples of the batch's own points are projective Niels entries with their own 2Z.
+  // Both run through the same mixed addition.
+  fe two;
+  fe_1(two);
+  two.v[0] = 2;
   uint32_t e = sorted[a];
   niels pn;
-  ge pg;
-  auto fetch = [&](uint32_t ent, niels &dn, ge &dg) {
+  fe pz;
+  auto fetch = [&](uint32_t ent, niels &dn, fe &dz) {
     const uint32_t pi = ent & 0x3fffffffu;
+    dz = two;
     if (!(ent & BPP_POINT_HI)) dn = *point_ptr(tabs, pi);
     else if (pi < tabs.n_a) dn = tabs.tab_a_hi[pi];
-    else dg = tabs.tab_b_hi[pi - tabs.n_a];
+    else {
+      const pniels *src = tabs.tab_b_hi + (pi - tabs.n_a);
+      dn.yplusx = src->yplusx;
+      dn.yminusx = src->yminusx;
+      dn.xy2d = src->xy2d;
+      dz = src->z2;
+    }
   };
-  fetch(e, pn, pg);
+  fetch(e, pn, pz);
   for (uint32_t i = 0; i < n; i++) {
     const uint32_t e_cur = e;
     niels cur = pn;
-    ge curg = pg;
+    const fe curz = pz;
     if (i + 1 < n) {
       e = sorted[a + i + 1];
-      fetch(e, pn, pg);
+      fetch(e, pn, pz);
     }
-    const bool neg = (e_cur >> 31) != 0;
-    if ((e_cur & BPP_POINT_HI) && (e_cur & 0x3fffffffu) >= tabs.n_a) {
-      if (neg) {  // -(X : Y : Z : T) = (-X : Y : Z : -T), brought back to reduced limbs for the products
-        ge_neg(curg, curg);
-        fe_carry(curg.X);
-        fe_carry(curg.T);
-      }
-      quad_ge_add(m, q, curg, d2, one);
-    } else {
-      niels_cneg(cur, neg);
-      quad_ge_madd(m, q, cur);
-    }
+    niels_cneg(cur, (e_cur >> 31) != 0);
+    quad_ge_madd(m, q, cur, curz);
   }
   // lane q writes coordinate q
   fe *dst = (fe *)(buckets + bkt);
@@ -663,8 +667,8 @@ __global__ void __launch_bounds__(64) k_msm_accumulate_quad(const uint32_t *__re
 // (s_hi, 2^127 P), on 128-bit windows: the same number of additions, half the doublings.  2^127 P of a batch's own points is
 // 127 doublings per point, but those depend on the decompression only and run beside PASS 1 and the scalar stage.
 // One quad per point (the doubling's four squarings / products side by side, as in k_msm_final_quad): (a, b, .) = (y+x, y-x)
-// gives the point as (a - b : a + b : 2); T is not an input of a doubling.
-__global__ void __launch_bounds__(64) k_shift127_quad(const niels *__restrict__ pts, uint32_t n, ge *__restrict__ out) {
+// gives the point as (a - b : a + b : 2); T is not an input of a doubling.  The result leaves as a projective Niels entry.
+__global__ void __launch_bounds__(64) k_shift127_quad(const niels *__restrict__ pts, uint32_t n, pniels *__restrict__ out) {
   const uint32_t lane = threadIdx.x, qi = lane & 3u;
   const QuadMask q = quad_mask(qi);
   const uint32_t i = blockIdx.x * 16u + (lane >> 2);
@@ -682,8 +686,20 @@ __global__ void __launch_bounds__(64) k_shift127_quad(const niels *__restrict__ 
   quad_load(m, q, g);
 #pragma unroll 1
   for (uint32_t k = 0; k < BPP_MSM_SPLIT_BIT; k++) quad_ge_dbl(m, q);
+  // (X, Y, Z, T) over the quad -> (Y + X, Y - X, 2d T, 2 Z): lanes 0 and 1 take the sum and the difference, lane 2 its own
+  // coordinate times 2d, lane 3 its own doubled; every lane stores one reduced field element
+  fe X, Y, s0, s1, md, m2, d2, o;
+  quad_bcast<0>(X, m);
+  quad_bcast<1>(Y, m);
+  fe_add(s0, Y, X);
+  fe_sub(s1, Y, X);
+  fe_const(d2, FE_D2);
+  fe_mul(md, m, d2);
+  fe_add(m2, m, m);
+  fe_sel4(o, q, s0, s1, md, m2);
+  fe_carry(o);
   fe *dst = (fe *)(out + i);
-  dst[qi] = m;
+  dst[qi] = o;
 }
 // the generators' 2^127 multiples as table entries: one lane per generator, once per parameter set
 __global__ void __launch_bounds__(64) k_shift127_table(const niels *__restrict__ tab, uint32_t n, niels *__restrict__ out) {
