@@ -686,16 +686,18 @@ __global__ void __launch_bounds__(64) k_shift127_quad(const niels *__restrict__ 
   quad_load(m, q, g);
 #pragma unroll 1
   for (uint32_t k = 0; k < BPP_MSM_SPLIT_BIT; k++) quad_ge_dbl(m, q);
-  // (X, Y, Z, T) over the quad -> (Y + X, Y - X, 2d T, 2 Z): lanes 0 and 1 take the sum and the difference, lane 2 its own
-  // coordinate times 2d, lane 3 its own doubled; every lane stores one reduced field element
-  fe X, Y, s0, s1, md, m2, d2, o;
+  // (X, Y, Z, T) over the quad (lane q holds coordinate q) -> (Y + X, Y - X, 2d T, 2 Z): every lane stores one reduced
+  // field element of the entry
+  fe X, Y, Z, T, s0, s1, md, m2, d2, o;
   quad_bcast<0>(X, m);
   quad_bcast<1>(Y, m);
+  quad_bcast<2>(Z, m);
+  quad_bcast<3>(T, m);
   fe_add(s0, Y, X);
   fe_sub(s1, Y, X);
   fe_const(d2, FE_D2);
-  fe_mul(md, m, d2);
-  fe_add(m2, m, m);
+  fe_mul(md, T, d2);
+  fe_add(m2, Z, Z);
   fe_sel4(o, q, s0, s1, md, m2);
   fe_carry(o);
   fe *dst = (fe *)(out + i);
