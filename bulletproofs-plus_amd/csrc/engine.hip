@@ -477,11 +477,11 @@ uint32_t choose_window(const bpp_ctx *ctx, uint32_t group_terms, uint32_t all_te
 
 // plan + work buffers for G groups with term offsets goff[0..G]; the term lists (term_sidx / term_pidx) are filled by
 // the caller, from host vectors (msm_prepare) or by a kernel (layout_groups)
-// half-scalar plan (msm.h: k_shift127_quad): the smallest verifier calls, unless the one-lane kernels are forced.  It halves
-// the final Horner step (0.30 -> 0.15 ms) and doubles every bucket's list: measured on 64-bit proofs it wins up to ~128
-// proofs per call (1 proof 0.64 -> 0.51 ms, 64 proofs 0.67 -> 0.59) and loses from 256 on (0.69 -> 0.73 ms, 1024: 1.09 -> 1.44:
-// the lists of the 12 x 1024 buckets are then 8+ additions deep, a third of them full additions of the 2^127 multiples)
-#define BPP_SPLIT_CALL_TERMS 2400u
+// half-scalar plan (msm.h: k_shift127_quad): small verifier calls, unless the one-lane kernels are forced.  It halves the
+// final Horner step (0.27 -> 0.13 ms) and doubles every bucket's list (quad accumulation: 0.035 -> 0.105 ms at 256 proofs,
+// 0.07 -> 0.38 at 1024).  Measured on non-aggregated 64-bit proofs (profiles/r03_v3_bench_latency*.jsonl): 1 proof 0.62 -> 0.48
+// ms, 64: 0.68 -> 0.54, 256: 0.70 -> 0.67, 512: 0.79 -> 0.80, 1024: 0.99 -> 1.20: it pays up to about 300 proofs per call.
+#define BPP_SPLIT_CALL_TERMS 5000u
 bool msm_wants_split(const bpp_ctx *ctx, uint32_t n_terms) {
   if (ctx->opt.msm_split >= 0) return ctx->opt.msm_split != 0 && ctx->opt.msm_quad != 0;
   return n_terms <= BPP_SPLIT_CALL_TERMS && ctx->opt.msm_quad != 0;
