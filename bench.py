@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "6")),
+    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "4")),
                     help="steps in flight per GPU (one engine/stream + one host thread each)")
     ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_step", type=int,
                     default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "64")),

@@ -629,9 +629,6 @@ __global__ void __launch_bounds__(64) k_msm_accumulate_quad(const uint32_t *__re
   fe two;
   fe_1(two);
   two.v[0] = 2;
-  uint32_t e = sorted[a];
-  niels pn;
-  fe pz;
   auto fetch = [&](uint32_t ent, niels &dn, fe &dz) {
     const uint32_t pi = ent & 0x3fffffffu;
     dz = two;
@@ -645,17 +642,31 @@ __global__ void __launch_bounds__(64) k_msm_accumulate_quad(const uint32_t *__re
       dz = src->z2;
     }
   };
-  fetch(e, pn, pz);
-  for (uint32_t i = 0; i < n; i++) {
-    const uint32_t e_cur = e;
-    niels cur = pn;
-    const fe curz = pz;
-    if (i + 1 < n) {
-      e = sorted[a + i + 1];
-      fetch(e, pn, pz);
+  // Four entries per trip: their list words are already in registers (loaded during the previous trip), their four points are
+  // requested together and only then added one after the other.  With one entry in flight per trip (the first form) every
+  // addition waited for two dependent memory round trips of a nearly idle chip (~3 us against ~1.2 us of arithmetic): the
+  // kernel took 0.1 ms for the 8-deep lists of a 256-proof half-scalar call.
+  uint32_t ew[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) ew[u] = (uint32_t)u < n ? sorted[a + u] : 0u;
+  for (uint32_t i0 = 0; i0 < n; i0 += 4) {
+    uint32_t ec[4];
+    niels pt[4];
+    fe pzz[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      ec[u] = ew[u];
+      if (i0 + u < n) fetch(ec[u], pt[u], pzz[u]);
     }
-    niels_cneg(cur, (e_cur >> 31) != 0);
-    quad_ge_madd(m, q, cur, curz);
+#pragma unroll
+    for (int u = 0; u < 4; u++) ew[u] = i0 + 4 + u < n ? sorted[a + i0 + 4 + u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (i0 + u < n) {
+        niels_cneg(pt[u], (ec[u] >> 31) != 0);
+        quad_ge_madd(m, q, pt[u], pzz[u]);
+      }
+    }
   }
   // lane q writes coordinate q
   fe *dst = (fe *)(buckets + bkt);
