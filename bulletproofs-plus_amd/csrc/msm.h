@@ -38,6 +38,7 @@ struct PointTables {
 struct pniels {
   fe yplusx, yminusx, xy2d, z2;
 };
+__device__ const uint32_t BPP_FE_TWO[10] = {2, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // the 2Z of an affine table line
 __device__ __forceinline__ const niels *point_ptr(const PointTables &t, uint32_t idx) {
   return idx < t.n_a ? (t.tab_a + idx) : (t.tab_b + (idx - t.n_a));
 }
@@ -626,21 +627,20 @@ __global__ void __launch_bounds__(64) k_msm_accumulate_quad(const uint32_t *__re
   // An entry is (sign | high-multiple flag | point index).  Low entries and the generators' 2^127 multiples are affine-Niels
   // table lines (2Z = 2); the 2^127 multiples of the batch's own points are projective Niels entries with their own 2Z.
   // Both run through the same mixed addition.
-  fe two;
-  fe_1(two);
-  two.v[0] = 2;
+  // Branch-free fetch: the three Niels fields sit at the same offsets in a table line and in a projective entry, and 2Z is
+  // read either from the entry or from a constant in memory -- every load of the four entries of a trip is unconditional, so
+  // all of them are in flight together (with a branch per entry kind the loads of one entry were waited for at the end of
+  // its branch before the next entry's were issued).
   auto fetch = [&](uint32_t ent, niels &dn, fe &dz) {
     const uint32_t pi = ent & 0x3fffffffu;
-    dz = two;
-    if (!(ent & BPP_POINT_HI)) dn = *point_ptr(tabs, pi);
-    else if (pi < tabs.n_a) dn = tabs.tab_a_hi[pi];
-    else {
-      const pniels *src = tabs.tab_b_hi + (pi - tabs.n_a);
-      dn.yplusx = src->yplusx;
-      dn.yminusx = src->yminusx;
-      dn.xy2d = src->xy2d;
-      dz = src->z2;
-    }
+    const bool hi = (ent & BPP_POINT_HI) != 0, proj = hi && pi >= tabs.n_a;
+    const pniels *pp = tabs.tab_b_hi + (proj ? pi - tabs.n_a : 0u);
+    const niels *np = hi ? (pi < tabs.n_a ? tabs.tab_a_hi + pi : (const niels *)pp) : point_ptr(tabs, pi);
+    const fe *zp = proj ? &pp->z2 : (const fe *)BPP_FE_TWO;
+    dn.yplusx = np->yplusx;
+    dn.yminusx = np->yminusx;
+    dn.xy2d = np->xy2d;
+    dz = *zp;
   };
   // Four entries per trip: their list words are already in registers (loaded during the previous trip), their four points are
   // requested together and only then added one after the other.  With one entry in flight per trip (the first form) every
