@@ -171,7 +171,7 @@ struct Params {
   std::mutex fb_mu;  // serialises the one-off build of the prover's fixed-base table
   uint32_t n_bits, m_max, t;
   DevBuf<niels> table;  // [2*n*m_max interleaved G,H | t g_bases | h_base]
-  DevBuf<niels> table_hi;  // the same points times 2^127: the half-scalar MSM plan of small calls (msm.h)
+  DevBuf<niels> table_hi;  // the same points times 2^126: the half-scalar MSM plan of small calls (msm.h)
   uint32_t table_len;
   DevBuf<uint8_t> d_hg32;           // compressed H, G_0..G_{t-1}
   std::vector<uint8_t> hg32;        // host copy
@@ -246,7 +246,7 @@ struct MsmWork {
   DevBuf<uint32_t> term_sidx, term_pidx, group_off;
   MsmPlan plan{};
   uint32_t max_group_terms = 0;
-  bool split = false;  // half-scalar plan (small verifier calls): every term twice, 128-bit windows
+  bool split = false;  // half-scalar plan (small verifier calls): every term twice, 127-bit windows
 };
 
 struct Batch {
@@ -280,7 +280,7 @@ struct Batch {
   DevBuf<uint32_t> status, group_first, group_dlo;
   DevBuf<uint32_t> dec_spill;  // k_decompress parks three field elements per proof point here across its squaring chain
   DevBuf<niels> dynpts;
-  DevBuf<pniels> dyn_hi;  // 2^127 x dynpts as projective Niels entries (half-scalar plan only)
+  DevBuf<pniels> dyn_hi;  // 2^126 x dynpts as projective Niels entries (half-scalar plan only)
   MsmWork msm;
   // layout of the last verify
   size_t last_chunk = (size_t)-1;
@@ -477,7 +477,7 @@ uint32_t choose_window(const bpp_ctx *ctx, uint32_t group_terms, uint32_t all_te
 
 // plan + work buffers for G groups with term offsets goff[0..G]; the term lists (term_sidx / term_pidx) are filled by
 // the caller, from host vectors (msm_prepare) or by a kernel (layout_groups)
-// half-scalar plan (msm.h: k_shift127_quad): small verifier calls, unless the one-lane kernels are forced.  It halves the
+// half-scalar plan (msm.h: k_split_shift_quad): small verifier calls, unless the one-lane kernels are forced.  It halves the
 // final Horner step (0.27 -> 0.13 ms) and doubles every bucket's list (quad accumulation: 0.035 -> 0.105 ms at 256 proofs,
 // 0.07 -> 0.38 at 1024).  Measured on non-aggregated 64-bit proofs (profiles/r03_v3_bench_latency*.jsonl): 1 proof 0.62 -> 0.48
 // ms, 64: 0.68 -> 0.54, 256: 0.70 -> 0.67, 512: 0.79 -> 0.80, 1024: 0.99 -> 1.20: it pays up to about 300 proofs per call.
@@ -491,7 +491,7 @@ void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff,
   const uint32_t G = (uint32_t)goff.size() - 1, n = goff[G];
   uint32_t maxg = 0;
   for (uint32_t g = 0; g < G; g++) maxg = std::max(maxg, goff[g + 1] - goff[g]);
-  const MsmPlan plan = msm_make_plan(choose_window(ctx, maxg, split ? n / 2 : n), G, n, split ? 128u : 253u);
+  const MsmPlan plan = msm_make_plan(choose_window(ctx, maxg, split ? n / 2 : n), G, n, split ? BPP_MSM_SPLIT_BITS : 253u);
   w.plan = plan;
   w.split = split;
   w.max_group_terms = maxg;
@@ -865,7 +865,7 @@ int bpp_params_create(bpp_ctx *ctx, uint32_t bit_length, uint32_t max_aggregatio
       if (z) return fail(ctx, BPP_ERR_VERIFICATION_FAILED, "Identity element cannot be added to the transcript");
     }
     P->table_hi.alloc(P->table_len);
-    hipLaunchKernelGGL(k_shift127_table, dim3(cdiv(P->table_len, 64)), dim3(64), 0, ctx->stream, P->table.p, P->table_len, P->table_hi.p);
+    hipLaunchKernelGGL(k_split_shift_table, dim3(cdiv(P->table_len, 64)), dim3(64), 0, ctx->stream, P->table.p, P->table_len, P->table_hi.p);
     P->fb_ped_geo = fb_geometry(t + 1);
     P->fb_ped.alloc((size_t)(t + 1) * fb_stride(P->fb_ped_geo));
     hipLaunchKernelGGL(k_fb_build,
@@ -1281,11 +1281,11 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
   auto launch_decompress = [&](hipStream_t st) {
     hipLaunchKernelGGL(k_decompress, dim3(cdiv(n_proof_pts, 64)), dim3(64), 0, st, b.bytes.p, b.src_off.p, b.owner.p,
                        b.idx_proof.p, n_proof_pts, b.dynpts.p, b.status.p, b.dec_spill.p);
-    // half-scalar plan of small calls: the 2^127 multiples of every dynamic point (the statements' commitments were decoded
-    // at upload), 127 doublings each, right behind the decompression and -- for small inputs -- beside PASS 1 and the scalars.
+    // half-scalar plan of small calls: the 2^126 multiples of every dynamic point (the statements' commitments were decoded
+    // at upload), 126 doublings each, right behind the decompression and -- for small inputs -- beside PASS 1 and the scalars.
     // A point that did not decode left an arbitrary entry: its multiple is never looked at (the call fails on the status).
     if (b.msm.split && !pass1_only)
-      hipLaunchKernelGGL(k_shift127_quad, dim3(cdiv(b.total_dyn, 16)), dim3(64), 0, st, b.dynpts.p, b.total_dyn, b.dyn_hi.p);
+      hipLaunchKernelGGL(k_split_shift_quad, dim3(cdiv(b.total_dyn, 16)), dim3(64), 0, st, b.dynpts.p, b.total_dyn, b.dyn_hi.p);
   };
   if (side) {
     if (!ctx->side_stream) {
@@ -1520,7 +1520,7 @@ void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk) {
   goff[G] = run;
   dlo[G] = b.total_dyn;
   const bool split = msm_wants_split(ctx, run);
-  if (split) {  // every term twice: (low half, P), (high half, 2^127 P)
+  if (split) {  // every term twice: (low half, P), (high half, 2^126 P)
     for (uint32_t g = 0; g <= G; g++) goff[g] *= 2;
     maxg *= 2;
     b.dyn_hi.alloc(b.total_dyn);

@@ -105,7 +105,7 @@ int ht_msm_recode(const uint8_t a[32], uint32_t c, int16_t *digits /* K */, uint
 // half-scalar plan: digits of the two halves (128-bit windows) -> out_lo[K], out_hi[K]; returns K
 int ht_msm_recode_split(const uint8_t a[32], uint32_t c, int16_t *out_lo, int16_t *out_hi, uint32_t *widths) {
   sc x; sc_load_words(x, a);
-  const MsmPlan plan = msm_make_plan(c, 1, 2, 128);
+  const MsmPlan plan = msm_make_plan(c, 1, 2, BPP_MSM_SPLIT_BITS);
   uint32_t lo[8], hi[8];
   msm_half_words(lo, x.v, false);
   msm_half_words(hi, x.v, true);

@@ -26,14 +26,14 @@ struct PointTables {
   const niels *tab_a;
   const niels *tab_b;
   uint32_t n_a;
-  // half-scalar plans only (MsmPlan::split): the 2^127 multiples -- of the generators as affine-Niels entries (built once per
-  // parameter set), of the batch's dynamic points as PROJECTIVE Niels entries (k_shift127_quad, every verification)
+  // half-scalar plans only (MsmPlan::split): the 2^126 multiples -- of the generators as affine-Niels entries (built once per
+  // parameter set), of the batch's dynamic points as PROJECTIVE Niels entries (k_split_shift_quad, every verification)
   const niels *tab_a_hi;
   const struct pniels *tab_b_hi;
 };
 // (Y+X, Y-X, 2dT, 2Z): a point that is not normalised to Z = 1, in the form the mixed addition consumes.  An affine-Niels
 // entry is the special case 2Z = 2, so ONE addition routine (and one instruction stream: no divergence inside a
-// wavefront) serves table lines and the 2^127 multiples of a batch's own points, which exist in projective form only
+// wavefront) serves table lines and the 2^126 multiples of a batch's own points, which exist in projective form only
 // (normalising them would cost an inversion each).
 struct pniels {
   fe yplusx, yminusx, xy2d, z2;
@@ -624,8 +624,8 @@ __global__ void __launch_bounds__(64) k_msm_accumulate_quad(const uint32_t *__re
     ge_identity(id);
     quad_load(m, q, id);
   }
-  // An entry is (sign | high-multiple flag | point index).  Low entries and the generators' 2^127 multiples are affine-Niels
-  // table lines (2Z = 2); the 2^127 multiples of the batch's own points are projective Niels entries with their own 2Z.
+  // An entry is (sign | high-multiple flag | point index).  Low entries and the generators' 2^126 multiples are affine-Niels
+  // table lines (2Z = 2); the 2^126 multiples of the batch's own points are projective Niels entries with their own 2Z.
   // Both run through the same mixed addition.
   // Branch-free fetch: the three Niels fields sit at the same offsets in a table line and in a projective entry, and 2Z is
   // read either from the entry or from a constant in memory -- every load of the four entries of a trip is unconditional, so
@@ -673,13 +673,13 @@ __global__ void __launch_bounds__(64) k_msm_accumulate_quad(const uint32_t *__re
   dst[qi] = m;
 }
 
-// ---- 2^127 multiples for the half-scalar plan of small calls.  The final Horner step is 253 DEPENDENT doublings, 0.3 ms of
-// a 0.65 ms call whatever the batch size; with s = s_lo + 2^127 s_hi the MSM runs over twice the terms, (s_lo, P) and
-// (s_hi, 2^127 P), on 128-bit windows: the same number of additions, half the doublings.  2^127 P of a batch's own points is
-// 127 doublings per point, but those depend on the decompression only and run beside PASS 1 and the scalar stage.
+// ---- 2^126 multiples for the half-scalar plan of small calls.  The final Horner step is 253 DEPENDENT doublings, 0.3 ms of
+// a 0.65 ms call whatever the batch size; with s = s_lo + 2^126 s_hi the MSM runs over twice the terms, (s_lo, P) and
+// (s_hi, 2^126 P), on 127-bit windows: the same number of additions, half the doublings.  2^126 P of a batch's own points is
+// 126 doublings per point, but those depend on the decompression only and run beside PASS 1 and the scalar stage.
 // One quad per point (the doubling's four squarings / products side by side, as in k_msm_final_quad): (a, b, .) = (y+x, y-x)
 // gives the point as (a - b : a + b : 2); T is not an input of a doubling.  The result leaves as a projective Niels entry.
-__global__ void __launch_bounds__(64) k_shift127_quad(const niels *__restrict__ pts, uint32_t n, pniels *__restrict__ out) {
+__global__ void __launch_bounds__(64) k_split_shift_quad(const niels *__restrict__ pts, uint32_t n, pniels *__restrict__ out) {
   const uint32_t lane = threadIdx.x, qi = lane & 3u;
   const QuadMask q = quad_mask(qi);
   const uint32_t i = blockIdx.x * 16u + (lane >> 2);
@@ -714,8 +714,8 @@ __global__ void __launch_bounds__(64) k_shift127_quad(const niels *__restrict__ 
   fe *dst = (fe *)(out + i);
   dst[qi] = o;
 }
-// the generators' 2^127 multiples as table entries: one lane per generator, once per parameter set
-__global__ void __launch_bounds__(64) k_shift127_table(const niels *__restrict__ tab, uint32_t n, niels *__restrict__ out) {
+// the generators' 2^126 multiples as table entries: one lane per generator, once per parameter set
+__global__ void __launch_bounds__(64) k_split_shift_table(const niels *__restrict__ tab, uint32_t n, niels *__restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   ge g;

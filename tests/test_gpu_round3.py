@@ -274,8 +274,8 @@ def test_sharded_entry_over_rccl_one_rank(bpp, packed, engine):
 
 @pytest.mark.parametrize("m,t,count,chunk", [(1, 1, 1, 0), (1, 1, 300, 0), (1, 1, 300, 64), (8, 1, 20, 0), (2, 3, 33, 16), (1, 1, 1100, 0)])
 def test_half_scalar_plan_equals_the_full_one(bpp, packed, engine, opt, m, t, count, chunk):
-    """small calls run the final MSM as a half-scalar plan: s = s_lo + 2^127 s_hi over (P, 2^127 P), 128-bit windows, half the
-    doublings of the final Horner step (msm.h: k_shift127_quad).  Forced on and off on the same resident batch: same accept /
+    """small calls run the final MSM as a half-scalar plan: s = s_lo + 2^126 s_hi over (P, 2^126 P), 127-bit windows, half the
+    doublings of the final Horner step (msm.h: k_split_shift_quad).  Forced on and off on the same resident batch: same accept /
     reject, and where the check fails the same (non-identity) group element comes out of both plans"""
     params, d = _inputs(bpp, packed, engine, m, t, count, 7500 + m + count)
     K = bpp.ProofErrorKind

@@ -210,13 +210,16 @@ def test_scalar_recodings(ht, monkeypatch):
                 total += dig[k] << off
                 off += wid[k]
             assert total == a, (c, hex(a))
-    # half-scalar plan of small calls: s = lo + 2^127 hi, both halves recoded over 128-bit windows
+    # half-scalar plan of small calls: s = lo + 2^126 hi, both halves recoded over 127-bit windows (one spare bit: nothing
+    # carries out of the top window; s >= 2^252 makes the high half exactly 2^126: the top window's digit is +half)
     for c in range(4, 12):
-        for a in vals + [(1 << 127) - 1, 1 << 127, (1 << 127) + 1, L - 1, ((1 << 126) - 1) << 127]:
+        edge = [(1 << 126) - 1, 1 << 126, (1 << 126) + 1, L - 1, L - 2, 1 << 252, (1 << 252) + 1, (1 << 252) - 1,
+                ((1 << 126) - 1) << 126, (((1 << 126) - 1) << 126) | ((1 << 126) - 1)]
+        for a in vals + edge:
             a %= L
             lo, hi, wid = (ctypes.c_int16 * 64)(), (ctypes.c_int16 * 64)(), (ctypes.c_uint32 * 64)()
             K = ht.ht_msm_recode_split(a.to_bytes(32, "little"), c, lo, hi, wid)
-            assert sum(wid[:K]) == 128 and K == -(-128 // c)
+            assert sum(wid[:K]) == 127 and K == -(-127 // c)
             tot_lo = tot_hi = off = 0
             for k in range(K):
                 for d in (lo[k], hi[k]):
@@ -224,7 +227,7 @@ def test_scalar_recodings(ht, monkeypatch):
                 tot_lo += lo[k] << off
                 tot_hi += hi[k] << off
                 off += wid[k]
-            assert tot_lo == a % (1 << 127) and tot_hi == a >> 127 and tot_lo + (tot_hi << 127) == a
+            assert tot_lo == a % (1 << 126) and tot_hi == a >> 126 and tot_lo + (tot_hi << 126) == a
     for forced, n_gens in [(None, 5), (None, 516), (None, 1026), (None, 5000), ("8", 5), ("9", 5), ("10", 5), ("11", 5)]:
         if forced:
             monkeypatch.setenv("BPP_FB_WBITS", forced)
