@@ -783,7 +783,7 @@ def main():
                                         "proofs_per_s": nb / ls[len(ls) // 2], "roofline": rl, "stages_ms": sl}
             legl.close()
         extra["latency"] = dict(lat_out, workload="BASELINE configs[0]'s shape through the engine: ONE call at a time, 1, 64 and 256 "
-                                                  "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input; calls of up to ~300 proofs "
+                                                  "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input; calls of up to ~1200 proofs "
                                                   "run the final MSM as a half-scalar plan (s = s_lo + 2^126 s_hi: half the Horner doublings)")
         # -------------------------------------------------------------- configs[4]: batch prover
         extra["prover"] = prover_leg()
