@@ -524,6 +524,11 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)
 
+    # Several ranks on one host share its cores: each process's pool of weight-chain workers (default: up to 32) is sized to
+    # its share before the library is loaded, so that eight ranks do not put 256 runnable threads on the node.
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env > 1 and "BPP_HOST_THREADS" not in os.environ:
+        os.environ["BPP_HOST_THREADS"] = str(max(4, min(32, usable_cpus() // world_env)))
     import numpy as np
     import torch
     import torch.distributed as dist

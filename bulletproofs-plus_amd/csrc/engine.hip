@@ -393,7 +393,10 @@ namespace {
 
 // lanes per output point of k_fb_msm: enough (term, window) items per lane to outweigh the log2(lanes) reduction tree
 static uint32_t fb_threads(const bpp_ctx *ctx, uint32_t terms, const FbGeom &g) {
-  if (ctx->opt.fb_threads > 0) return (uint32_t)ctx->opt.fb_threads;
+  if (ctx->opt.fb_threads > 0) {  // any whole number of wavefronts up to the kernel's launch bound
+    const uint32_t t = ((uint32_t)ctx->opt.fb_threads + 63u) & ~63u;
+    return t > FB_THREADS ? FB_THREADS : t;
+  }
   const uint32_t items = terms * g.windows;
   return items >= 4096 ? 256u : (items >= 1024 ? 128u : 64u);
 }
@@ -2332,6 +2335,9 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     };
     const auto t_begin = std::chrono::steady_clock::now();
     arena_clean = false;
+    // The sub-batches advance together: every phase is enqueued for all of them before the next one (enqueued one
+    // sub-batch after the other, the second stream started ~60 launches late and the call ended with one stream running
+    // alone: its latency-bound Fiat-Shamir kernels with nothing beside them).
     for (uint32_t q = 0; q < n_sub; q++) {
       Sub &u = subs[q];
       hipStream_t s = ctx->prove_streams[q];
@@ -2355,7 +2361,12 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       hipLaunchKernelGGL(kp_check_commitments, lane_grid, b64, 0, s, u.d_bytes, u.d_desc, u.d_commit32, nb, u.d_ps);
       hipLaunchKernelGGL(kp_A, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, P.table.p, P.fb_table.p, P.fb_geo, n_gen, n,
                          t, u.d_ps, u.d_a32);
-      for (uint32_t j = 0; j <= rounds; j++) {
+    }
+    for (uint32_t j = 0; j <= rounds; j++)
+      for (uint32_t q = 0; q < n_sub; q++) {
+        Sub &u = subs[q];
+        hipStream_t s = ctx->prove_streams[q];
+        const uint32_t nb = u.nb;
         const uint8_t *lr_prev = j ? u.d_lr + (size_t)(j - 1) * nb * 64 : nullptr;
         hipLaunchKernelGGL(kp_lane, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
         hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
@@ -2367,7 +2378,11 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         fb_mark(s);
         hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);
       }
-      hipLaunchKernelGGL(kp_finish, lane_grid, b64, 0, s, u.d_desc, n, t, nb, rounds, u.d_a32, u.d_lr, u.d_a1b, u.d_vec, u.d_ps,
+    for (uint32_t q = 0; q < n_sub; q++) {
+      Sub &u = subs[q];
+      hipStream_t s = ctx->prove_streams[q];
+      const uint32_t nb = u.nb;
+      hipLaunchKernelGGL(kp_finish, dim3(cdiv(nb, 64)), b64, 0, s, u.d_desc, n, t, nb, rounds, u.d_a32, u.d_lr, u.d_a1b, u.d_vec, u.d_ps,
                          u.d_proofs, (uint32_t)plen);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipMemcpyAsync(pin_proofs + (size_t)u.lo * plen, u.d_proofs, (size_t)nb * plen, hipMemcpyDeviceToHost, s));

@@ -129,7 +129,13 @@ BPP_D void fb_fetch(niels &q, int &d, const FbStage &st, const fbent *__restrict
 __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx,
                                                        const uint32_t *__restrict__ count, uint32_t stride,
                                                        const fbent *__restrict__ tbl, FbGeom geo, ge *__restrict__ out) {
-  const uint32_t o = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;  // 64, 128 or 256 lanes per output
+  // Outputs are dealt to the workgroups even ones first, then the odd ones.  The prover's last launch pairs a long output
+  // (A1: 2mn + t + 1 terms) with a short one (B: t + 1 terms) per proof; with o = blockIdx.x every long output sat on an even
+  // workgroup index, i.e. (workgroups go round the 8 XCDs) on four of the eight XCDs, and that launch took 1.35 ms against
+  // the 0.33 ms of a round with as many additions.  Equal outputs (every other launch) do not care.
+  const uint32_t n_even = (gridDim.x + 1u) >> 1;
+  const uint32_t o = blockIdx.x < n_even ? 2u * blockIdx.x : 2u * (blockIdx.x - n_even) + 1u;
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;  // a whole number of wavefronts per output, at most FB_THREADS
   const uint32_t n = count[o];
   __shared__ FbShared sh;
   ge acc;
@@ -159,7 +165,20 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ sc
   __syncthreads();
   sh.red[tid] = acc;
   __syncthreads();
-  for (uint32_t off = nthr / 2; off >= 1; off >>= 1) {
+  // nthr is a multiple of 64, not necessarily a power of two (192 lanes = three wavefronts per output fill the chip's
+  // 3-wavefronts-per-SIMD slots with exactly two rounds of 1024 proofs' L and R): the lanes above the largest power of
+  // two fold into the low ones first
+  uint32_t p2 = 64;
+  while (p2 * 2 <= nthr) p2 *= 2;
+  if (nthr > p2) {
+    if (tid + p2 < nthr) {
+      ge x = sh.red[tid], y2 = sh.red[tid + p2];
+      ge_add(x, x, y2);
+      sh.red[tid] = x;
+    }
+    __syncthreads();
+  }
+  for (uint32_t off = p2 / 2; off >= 1; off >>= 1) {
     if (tid < off) {
       ge x = sh.red[tid], y2 = sh.red[tid + off];
       ge_add(x, x, y2);

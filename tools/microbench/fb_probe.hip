@@ -1,0 +1,209 @@
+// Microbenchmark (gfx950): the prover's fixed-base MSM (k_fb_msm) on the shape of one round of BASELINE configs[4]
+// (outputs = 2 x proofs, 260 terms each, 516 generators, 11-bit windows: 24 x 1024 entries of 128 bytes = 1.6 GB of table,
+// filled with pseudo-random field elements: the arithmetic does not care) against two other ways of cutting the same work:
+//   A  k_fb_msm as shipped: one workgroup of 256 lanes per output, (term, window) items dealt round the lanes, 8-level tree
+//      through LDS at the end (one busy wavefront, three idle ones holding their registers)
+//   B  A without the tree (wrong result: the price of the tree and its barriers, a lower bound for any restructuring)
+//   C  k_fb_part + k_fb_sum: one independent wavefront per (output, slice of <= PER terms), no barrier beyond its own staging,
+//      64 partial sums per wavefront written to memory; a second launch sums an output's partials (one wavefront per output:
+//      lane-wise over the slices at full width, then the 6-level tree)
+// usage: fb_probe [proofs=1024]     build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I bulletproofs-plus_amd/csrc -I include ...
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <random>
+#include <vector>
+#include "kernels_prove.h"
+using namespace bpp;
+
+__global__ void k_fill_tbl(fbent *t, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  niels q;
+  const uint32_t a = (uint32_t)i * 2654435761u, b = (uint32_t)(i >> 7) * 40503u;
+  for (int k = 0; k < 10; k++) {
+    q.yplusx.v[k] = (a + k * 40503u + b) & 0x1ffffff;
+    q.yminusx.v[k] = (a * 3u + k * 2654435761u) & 0x1ffffff;
+    q.xy2d.v[k] = (a ^ (b + k * 977u)) & 0x1ffffff;
+  }
+  t[i].q = q;
+}
+
+// ---- B: k_fb_msm without its reduction tree
+__global__ void __launch_bounds__(FB_THREADS) k_fb_msm_notree(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx,
+                                                              const uint32_t *__restrict__ count, uint32_t stride, const fbent *__restrict__ tbl,
+                                                              FbGeom geo, ge *__restrict__ out) {
+  const uint32_t o = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t n = count[o];
+  __shared__ FbShared sh;
+  ge acc;
+  ge_identity(acc);
+  for (uint32_t base = 0; base < n; base += FB_CHUNK) {
+    const uint32_t cn = n - base < FB_CHUNK ? n - base : FB_CHUNK;
+    __syncthreads();
+    for (uint32_t i = tid; i < cn; i += nthr) {
+      const sc s = scal[(size_t)o * stride + base + i];
+      fb_recode(sh.st.dig + (size_t)i * geo.windows, s, geo);
+      sh.st.gi[i] = gidx[(size_t)o * stride + base + i];
+    }
+    __syncthreads();
+    const uint32_t items = cn * geo.windows;
+    uint32_t it = tid;
+    niels nxt;
+    int nd = 0;
+    if (it < items) fb_fetch(nxt, nd, sh.st, tbl, geo, it);
+    while (it < items) {
+      niels cur = nxt;
+      const int cd = nd;
+      it += nthr;
+      if (it < items) fb_fetch(nxt, nd, sh.st, tbl, geo, it);
+      if (cd != 0) ge_madd_swapped(acc, acc, cur, cd < 0);
+    }
+  }
+  if (acc.X.v[0] == 0x7fffffffu) out[o] = acc;  // never true: keeps the loop alive
+}
+
+// ---- C: one wavefront per (output, slice)
+#define FBP_MAX_PER 128
+struct FbPartStage {
+  int16_t dig[FBP_MAX_PER * FB_MAX_WINDOWS];
+  uint32_t gi[FBP_MAX_PER];
+};
+__global__ void __launch_bounds__(64) k_fb_part(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx, const uint32_t *__restrict__ count,
+                                                uint32_t stride, uint32_t parts, const fbent *__restrict__ tbl, FbGeom geo,
+                                                ge *__restrict__ partial /* [outputs][parts][64] */) {
+  const uint32_t o = blockIdx.x / parts, part = blockIdx.x - o * parts, lane = threadIdx.x;
+  const uint32_t n = count[o], per = (n + parts - 1) / parts;
+  const uint32_t lo = part * per < n ? part * per : n, hi = lo + per < n ? lo + per : n, cn = hi - lo;
+  __shared__ FbPartStage st;
+  for (uint32_t i = lane; i < cn; i += 64) {
+    const sc s = scal[(size_t)o * stride + lo + i];
+    fb_recode(st.dig + (size_t)i * geo.windows, s, geo);
+    st.gi[i] = gidx[(size_t)o * stride + lo + i];
+  }
+  __syncthreads();
+  ge acc;
+  ge_identity(acc);
+  const uint32_t items = cn * geo.windows;
+  // item it = (term i, window w), it = lane + 64 k: (i, w) advance without a division
+  const uint32_t di = 64u / geo.windows, dw = 64u - di * geo.windows;
+  uint32_t it = lane, i = lane / geo.windows, w = lane - i * geo.windows;
+  auto fetch = [&](niels &q, int &d) {
+    d = st.dig[it];
+    const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+    niels_load_swapped(q, &tbl[((size_t)st.gi[i] * geo.windows + w) * geo.entries + (mag ? mag - 1u : 0u)].q, d < 0);
+  };
+  auto step = [&]() {
+    it += 64u;
+    i += di;
+    w += dw;
+    if (w >= geo.windows) {
+      w -= geo.windows;
+      i++;
+    }
+  };
+  niels nxt;
+  int nd = 0;
+  if (it < items) fetch(nxt, nd);
+  while (it < items) {
+    niels cur = nxt;
+    const int cd = nd;
+    step();
+    if (it < items) fetch(nxt, nd);
+    if (cd != 0) ge_madd_swapped(acc, acc, cur, cd < 0);
+  }
+  partial[(size_t)blockIdx.x * 64u + lane] = acc;
+}
+__global__ void __launch_bounds__(64) k_fb_sum(const ge *__restrict__ partial, uint32_t parts, ge *__restrict__ out) {
+  const uint32_t o = blockIdx.x, lane = threadIdx.x;
+  __shared__ ge red[64];
+  ge acc = partial[((size_t)o * parts) * 64u + lane];
+  for (uint32_t p = 1; p < parts; p++) {
+    const ge x = partial[((size_t)o * parts + p) * 64u + lane];
+    ge_add(acc, acc, x);
+  }
+  red[lane] = acc;
+  __syncthreads();
+  for (uint32_t off = 32; off >= 1; off >>= 1) {
+    if (lane < off) {
+      ge x = red[lane], y2 = red[lane + off];
+      ge_add(x, x, y2);
+      red[lane] = x;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) out[o] = red[0];
+}
+
+int main(int argc, char **argv) {
+  const uint32_t proofs = argc > 1 ? (uint32_t)atoi(argv[1]) : 1024u;
+  const uint32_t n_gen = 516, terms = 260, outputs = 2 * proofs, stride = 2 * 256 + 4;
+  const FbGeom geo = fb_geometry(n_gen);
+  const size_t tbl_n = (size_t)n_gen * fb_stride(geo);
+  printf("fb_probe: %u outputs x %u terms, %u-bit windows (%u x %u entries), table %.2f GB\n", outputs, terms, geo.wbits, geo.windows, geo.entries,
+         tbl_n * 128.0 / 1e9);
+  fbent *d_tbl;
+  if (hipMalloc(&d_tbl, tbl_n * sizeof(fbent)) != hipSuccess) return 1;
+  hipLaunchKernelGGL(k_fill_tbl, dim3((uint32_t)((tbl_n + 255) / 256)), dim3(256), 0, 0, d_tbl, tbl_n);
+  std::mt19937 rng(777);
+  std::vector<sc> h_s((size_t)outputs * stride);
+  std::vector<uint32_t> h_g((size_t)outputs * stride), h_c(outputs, terms);
+  for (size_t k = 0; k < h_s.size(); k++) {
+    for (int j = 0; j < 8; j++) h_s[k].v[j] = rng();
+    h_s[k].v[7] &= 0x0fffffffu;
+    h_g[k] = rng() % n_gen;
+  }
+  sc *d_s;
+  uint32_t *d_g, *d_c;
+  ge *d_out, *d_part;
+  const uint32_t max_parts = 8;
+  (void)hipMalloc(&d_s, h_s.size() * sizeof(sc));
+  (void)hipMalloc(&d_g, h_g.size() * 4);
+  (void)hipMalloc(&d_c, h_c.size() * 4);
+  (void)hipMalloc(&d_out, (size_t)outputs * sizeof(ge));
+  (void)hipMalloc(&d_part, (size_t)outputs * max_parts * 64 * sizeof(ge));
+  (void)hipMemcpy(d_s, h_s.data(), h_s.size() * sizeof(sc), hipMemcpyHostToDevice);
+  (void)hipMemcpy(d_g, h_g.data(), h_g.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(d_c, h_c.data(), h_c.size() * 4, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1, e2;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventCreate(&e2);
+  auto best_of = [&](auto &&launch) {
+    float best = 1e9f;
+    for (int r = 0; r < 6; r++) {
+      (void)hipEventRecord(e0);
+      launch();
+      (void)hipEventRecord(e1);
+      (void)hipEventSynchronize(e1);
+      float ms;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (r) best = std::min(best, ms);
+    }
+    return best;
+  };
+  const double adds = (double)outputs * terms * geo.windows;
+  for (uint32_t thr : {256u, 192u, 128u}) {
+    const float a = best_of([&] { hipLaunchKernelGGL(k_fb_msm, dim3(outputs), dim3(thr), 0, 0, d_s, d_g, d_c, stride, d_tbl, geo, d_out); });
+    printf("A k_fb_msm, %3u lanes per output        : %.3f ms  (%.1f G additions/s)\n", thr, a, adds / a / 1e6);
+  }
+  std::vector<ge> ref(outputs), got(outputs);
+  (void)hipMemcpy(ref.data(), d_out, (size_t)outputs * sizeof(ge), hipMemcpyDeviceToHost);
+  const float b = best_of([&] { hipLaunchKernelGGL(k_fb_msm_notree, dim3(outputs), dim3(256), 0, 0, d_s, d_g, d_c, stride, d_tbl, geo, d_out); });
+  printf("B the same without the tree (256 lanes)  : %.3f ms  (%.1f G additions/s)\n", b, adds / b / 1e6);
+  for (uint32_t parts : {3u, 4u, 5u, 6u, 8u}) {
+    float sum_ms = 0;
+    const float c = best_of([&] {
+      hipLaunchKernelGGL(k_fb_part, dim3(outputs * parts), dim3(64), 0, 0, d_s, d_g, d_c, stride, parts, d_tbl, geo, d_part);
+      (void)hipEventRecord(e2);
+      hipLaunchKernelGGL(k_fb_sum, dim3(outputs), dim3(64), 0, 0, d_part, parts, d_out);
+    });
+    (void)hipEventElapsedTime(&sum_ms, e2, e1);
+    printf("C k_fb_part + k_fb_sum, %u slices (%3u terms): %.3f ms  (%.1f G additions/s; the sum %.3f ms)\n", parts, (terms + parts - 1) / parts, c,
+           adds / c / 1e6, sum_ms);
+  }
+  printf("[%s]\n", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
