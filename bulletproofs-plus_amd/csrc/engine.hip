@@ -2406,7 +2406,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       pp.fb_terms = (uint64_t)B * ((uint64_t)m * (1 + t) + (uint64_t)rounds * 2 * (mn + t + 1) + 3 + 2 * t);
       pp.fb_launches = (uint32_t)(ev_used / 2);
       pp.fb_window_bits = P.fb_geo.wbits;
-      pp.fb_windows = P.fb_geo.windows;
+      pp.fb_windows = P.fb_geo.items;  // additions per term
       pp.sub_batches = n_sub;
     }
     for (uint32_t i = 0; i < B; i++) {  // only the status word of the (secret-bearing) ProveState is looked at

@@ -120,5 +120,5 @@ int ht_fb_recode(const uint8_t a[32], uint32_t n_gens, int16_t *digits /* 32 */,
   const FbGeom g = fb_geometry(n_gens);
   fb_recode(digits, x, g);
   *wbits = g.wbits;
-  return (int)g.windows; }
+  return (int)g.items; }
 }

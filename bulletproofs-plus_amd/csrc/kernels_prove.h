@@ -5,9 +5,9 @@
 //       Gf[i] = sum_{u = i mod len} cG[u] G_u,  Hf[i] = sum cH[u] H_u   (len = mn >> j)
 //     with per-proof coefficient vectors cG/cH that absorb e^-1, e*y^-n, e, e^-1 each round (:511-521);
 //     every G_u / H_u lands in exactly one of L_j, R_j, so a round is two MSMs of mn + t + 1 terms over FIXED bases.
-//   * fixed-base MSM: signed windows over a precomputed table in HBM (per generator ceil(254/w) windows x 2^(w-1)
+//   * fixed-base MSM: signed windows over a precomputed table in HBM (per generator ceil(254/w) slots x 2^(w-1)
 //     multiples, affine Niels padded to one 128-byte line; w = 8..11 chosen by fb_geometry) -> 23 additions per term
-//     at w = 11, no doublings, no buckets.
+//     at w = 11 (the full top window stays unsigned and uses the spare slot, recode.h), no doublings, no buckets.
 //   * per proof and round: one lane for the Fiat-Shamir / RNG / inversion step (kp_lane), one wavefront for the
 //     scalar-vector work (kp_wave), one wavefront per output point for the MSM (k_fb_msm).
 // All scalars are Montgomery form in HBM; canonical only in MSM inputs, transcript bytes and the proof.
@@ -70,15 +70,18 @@ __global__ void __launch_bounds__(64) k_fb_build(const niels *__restrict__ gens,
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_gens * geo.windows * blocks) return;
   const uint32_t blk = i % blocks, gw = i / blocks, g = gw / geo.windows, w = gw % geo.windows;
+  // the last slot of a geometry with an unsigned top window continues the slot before it: entries + 1 .. 2 * entries
+  const bool ext = fb_top_unsigned(geo) && w + 1 == geo.windows;
+  const uint32_t wexp = ext ? w - 1 : w;
   ge base;
   ge_identity(base);
   const niels q = gens[g];
   ge_madd(base, base, q);
-  if (w) ge_dbl_n(base, base, (int)(geo.wbits * w));
+  if (wexp) ge_dbl_n(base, base, (int)(geo.wbits * wexp));
   cached cb;
   ge_to_cached(cb, base);
-  // acc = (blk * FB_BUILD_BLOCK + 1) * base by double-and-add from the top bit
-  const uint32_t first = blk * FB_BUILD_BLOCK + 1;
+  // acc = first * base by double-and-add from the top bit
+  const uint32_t pos = blk * FB_BUILD_BLOCK, first = pos + 1 + (ext ? geo.entries : 0u);
   ge acc;
   ge_identity(acc);
   for (int bit = 31; bit >= 0; bit--) {
@@ -86,8 +89,8 @@ __global__ void __launch_bounds__(64) k_fb_build(const niels *__restrict__ gens,
     ge_dbl(acc, acc);
     if ((first >> bit) & 1u) ge_add_cached(acc, acc, cb);
   }
-  fbent *out = tbl + ((size_t)g * geo.windows + w) * geo.entries + (first - 1);
-  const uint32_t cnt = geo.entries - (first - 1) < FB_BUILD_BLOCK ? geo.entries - (first - 1) : FB_BUILD_BLOCK;
+  fbent *out = tbl + ((size_t)g * geo.windows + w) * geo.entries + pos;
+  const uint32_t cnt = geo.entries - pos < FB_BUILD_BLOCK ? geo.entries - pos : FB_BUILD_BLOCK;
   for (uint32_t d = 0; d < cnt; d++) {
     fe zi, x, y;
     fe_invert(zi, acc.Z);
@@ -119,7 +122,7 @@ union FbShared {
 };
 
 BPP_D void fb_fetch(niels &q, int &d, const FbStage &st, const fbent *__restrict__ tbl, const FbGeom &geo, uint32_t it) {
-  const uint32_t i = it / geo.windows, w = it - i * geo.windows;
+  const uint32_t i = it / geo.items, w = it - i * geo.items;
   d = st.dig[it];
   const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
   // y+x / y-x exchanged by address for a negative digit (ge_madd_swapped does the rest of the negation)
@@ -145,11 +148,11 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ sc
     __syncthreads();  // the previous chunk's digits are no longer read
     for (uint32_t i = tid; i < cn; i += nthr) {
       const sc s = scal[(size_t)o * stride + base + i];
-      fb_recode(sh.st.dig + (size_t)i * geo.windows, s, geo);
+      fb_recode(sh.st.dig + (size_t)i * geo.items, s, geo);
       sh.st.gi[i] = gidx[(size_t)o * stride + base + i];
     }
     __syncthreads();
-    const uint32_t items = cn * geo.windows;
+    const uint32_t items = cn * geo.items;
     uint32_t it = tid;
     niels nxt;
     int nd = 0;
@@ -361,7 +364,7 @@ __global__ void __launch_bounds__(64) kp_A(const uint8_t *__restrict__ bytes, co
     const fbent *row = tbl + (size_t)(n_gen + lane) * fb_stride(geo);
     int16_t dig[FB_MAX_WINDOWS];
     fb_recode(dig, s, geo);
-    for (uint32_t w = 0; w < geo.windows; w++) {
+    for (uint32_t w = 0; w < geo.items; w++) {
       const int dgt = dig[w];
       if (dgt != 0) {
         const uint32_t mag = (uint32_t)(dgt < 0 ? -dgt : dgt);

@@ -116,11 +116,18 @@ BPP_HD void msm_half_words(uint32_t h[8], const uint32_t *w, bool hi) {
 
 // Window width is chosen per parameter set (fb_geometry): the widest window whose table stays under ~1.8 GB, because
 // random 128-byte lines come at 21 G lines/s out of <= 2 GB but only ~10 G lines/s out of larger tables (TLB reach,
-// tools/microbench/rand_lines.hip).  11 bits (<= 600 generators) = 24 windows of 1024 entries, 23 additions per term.
+// tools/microbench/rand_lines.hip).  11 bits (<= 600 generators) = 23 additions per term out of 24 slots of 1024 entries.
+//
+// A canonical scalar has 253 bits.  Signed digits need one position more than ceil(253 / wbits) only when the top window is
+// full (253 = 23 x 11): its carry would be a 24th digit that is 0 or 1 -- a whole addition per term for one bit.  In that
+// case the top window is kept UNSIGNED instead (digit 0 .. 2^wbits, no carry out) and its entries 2^(wbits-1)+1 .. 2^wbits
+// live in the table slot the carry digit would have used: same table size, same addressing (slot w, entry digit - 1 simply
+// runs on into slot w + 1), one addition per term fewer.  `items` = digit positions, `windows` = table slots per generator.
 struct FbGeom {
   uint32_t wbits;    // window width
-  uint32_t windows;  // ceil(254 / wbits): the top window never carries out
-  uint32_t entries;  // 2^(wbits-1) signed multiples 1..2^(wbits-1)
+  uint32_t windows;  // table slots per generator: ceil(254 / wbits)
+  uint32_t entries;  // entries per slot: 2^(wbits-1) signed multiples 1..2^(wbits-1)
+  uint32_t items;    // digit positions per scalar: windows, or windows - 1 with the unsigned top window
 };
 #define FB_MAX_WINDOWS 32
 #define FB_BUILD_BLOCK 128  // entries per lane of k_fb_build
@@ -139,14 +146,16 @@ inline FbGeom fb_geometry(uint32_t n_gens) {  // host side
   g.wbits = w;
   g.windows = (254 + w - 1) / w;
   g.entries = 1u << (w - 1);
+  g.items = (253u % w == 0u) ? 253u / w : g.windows;
   return g;
 }
 BPP_HD size_t fb_stride(const FbGeom &g) { return (size_t)g.windows * g.entries; }  // entries per generator
+BPP_HD bool fb_top_unsigned(const FbGeom &g) { return g.items < g.windows; }
 
-// signed digits of a canonical scalar, digit in [-(2^(w-1) - 1), 2^(w-1)]
+// digits of a canonical scalar: signed, in [-(2^(w-1) - 1), 2^(w-1)]; the top one in [0, 2^w] when fb_top_unsigned
 BPP_HD void fb_recode(int16_t *dig, const sc &s, const FbGeom &g) {
   uint32_t carry = 0;
-  for (uint32_t w = 0; w < g.windows; w++) {
+  for (uint32_t w = 0; w < g.items; w++) {
     const uint32_t bit = w * g.wbits, wi = bit >> 5, sh = bit & 31u;
     uint32_t raw = 0;
     if (wi < 8) {
@@ -154,7 +163,7 @@ BPP_HD void fb_recode(int16_t *dig, const sc &s, const FbGeom &g) {
       raw = (uint32_t)(two >> sh) & ((1u << g.wbits) - 1u);
     }
     const uint32_t v = raw + carry;
-    carry = v > g.entries ? 1u : 0u;
+    carry = (v > g.entries && !(fb_top_unsigned(g) && w + 1 == g.items)) ? 1u : 0u;
     dig[w] = (int16_t)((int32_t)v - (int32_t)(carry << g.wbits));
   }
 }

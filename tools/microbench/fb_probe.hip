@@ -45,11 +45,11 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm_notree(const sc *__restri
     __syncthreads();
     for (uint32_t i = tid; i < cn; i += nthr) {
       const sc s = scal[(size_t)o * stride + base + i];
-      fb_recode(sh.st.dig + (size_t)i * geo.windows, s, geo);
+      fb_recode(sh.st.dig + (size_t)i * geo.items, s, geo);
       sh.st.gi[i] = gidx[(size_t)o * stride + base + i];
     }
     __syncthreads();
-    const uint32_t items = cn * geo.windows;
+    const uint32_t items = cn * geo.items;
     uint32_t it = tid;
     niels nxt;
     int nd = 0;
@@ -80,16 +80,16 @@ __global__ void __launch_bounds__(64) k_fb_part(const sc *__restrict__ scal, con
   __shared__ FbPartStage st;
   for (uint32_t i = lane; i < cn; i += 64) {
     const sc s = scal[(size_t)o * stride + lo + i];
-    fb_recode(st.dig + (size_t)i * geo.windows, s, geo);
+    fb_recode(st.dig + (size_t)i * geo.items, s, geo);
     st.gi[i] = gidx[(size_t)o * stride + lo + i];
   }
   __syncthreads();
   ge acc;
   ge_identity(acc);
-  const uint32_t items = cn * geo.windows;
+  const uint32_t items = cn * geo.items;
   // item it = (term i, window w), it = lane + 64 k: (i, w) advance without a division
-  const uint32_t di = 64u / geo.windows, dw = 64u - di * geo.windows;
-  uint32_t it = lane, i = lane / geo.windows, w = lane - i * geo.windows;
+  const uint32_t di = 64u / geo.items, dw = 64u - di * geo.items;
+  uint32_t it = lane, i = lane / geo.items, w = lane - i * geo.items;
   auto fetch = [&](niels &q, int &d) {
     d = st.dig[it];
     const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
@@ -99,8 +99,8 @@ __global__ void __launch_bounds__(64) k_fb_part(const sc *__restrict__ scal, con
     it += 64u;
     i += di;
     w += dw;
-    if (w >= geo.windows) {
-      w -= geo.windows;
+    if (w >= geo.items) {
+      w -= geo.items;
       i++;
     }
   };
@@ -184,7 +184,7 @@ int main(int argc, char **argv) {
     }
     return best;
   };
-  const double adds = (double)outputs * terms * geo.windows;
+  const double adds = (double)outputs * terms * geo.items;
   for (uint32_t thr : {256u, 192u, 128u}) {
     const float a = best_of([&] { hipLaunchKernelGGL(k_fb_msm, dim3(outputs), dim3(thr), 0, 0, d_s, d_g, d_c, stride, d_tbl, geo, d_out); });
     printf("A k_fb_msm, %3u lanes per output        : %.3f ms  (%.1f G additions/s)\n", thr, a, adds / a / 1e6);
