@@ -445,41 +445,40 @@ def host_in_leg(bpp, packed, np, device_index, params0, data, R, calls, sync):
 
 def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, params2, data2, args, sync):
     """BASELINE configs[3]: 4096 proofs as ONE reference batch sharded over the ranks, through the C ABI
-    (bpp_verify_sharded_wave: RCCL all_gathers on device buffers).  W waves of K batches are in flight per rank: a wave's
-    K batches run their kernels side by side and share ONE all_gather per exchange; the waves (own communicator, own host
-    thread each) overlap one wave's weight chains and exchanges with the other's kernels."""
+    (bpp_verify_sharded_groups: RCCL all_gathers on device buffers).  A rank's shards of G such batches are ONE resident
+    batch on one context: every verifier kernel is launched once for all G, each of the two all_gathers carries all G, the G
+    weight chains (each over all 4096 proofs, replayed on every rank) run side by side on the host pool.  W such calls are in
+    flight per rank (own communicator, own host thread each): one call's chains and exchanges under the others' kernels."""
     dmod = importlib.import_module("bulletproofs-plus_amd.dist")
-    # One rank: three waves of twelve (one wave's weight chains and exchanges under the others' kernels).  Several ranks: ONE
-    # wave of sixteen -- two communicators progressing from two host threads per rank can reach their collectives in
-    # different orders on different ranks; that is legal for RCCL as long as both kernels can be resident at once, but this
-    # leg cannot be rehearsed on a multi-GPU node here, so it takes the form that cannot interleave at all.
-    K = int(os.environ.get("BPP_BENCH_WAVE_BATCHES", "12" if world == 1 else "16"))
+    # One rank: three calls of 32 batches.  Several ranks: ONE call of 64 -- two communicators progressing from two host
+    # threads per rank can reach their collectives in different orders on different ranks; that is legal for RCCL as long as
+    # both kernels can be resident at once, but this leg cannot be rehearsed on a multi-GPU node here, so it takes the form
+    # that cannot interleave at all.
+    G = int(os.environ.get("BPP_BENCH_WAVE_BATCHES", "32" if world == 1 else "64"))
     W = int(os.environ.get("BPP_BENCH_WAVES", "3" if world == 1 else "1"))
     n_local = 4096 // world
     counts = [n_local] * world
     nb = data2["proofs"].shape[0] // n_local
-    waves = []
+    calls = []
     for w in range(W):  # communicators are built collectively, in the same order on every rank
-        engs = [bpp.Engine(local_rank) for _ in range(K)]
-        pars = [params2.share(e) for e in engs]
-        rbs = []
-        for i, p in enumerate(pars):  # ranks were seeded differently: any n_local of this rank's proofs are a shard
-            sl = slice(((w * K + i) % nb) * n_local, ((w * K + i) % nb + 1) * n_local)
-            rbs.append(packed.ResidentBatch(p, data2["proofs"][sl], data2["commitments"][sl], data2["min_values"][sl],
-                                            data2["min_present"][sl], None, LABEL))
-            rbs[-1].prepare(0)
-        comm = dmod.ShardComm.from_process_group(engs[0])
-        waves.append((engs, pars, rbs, comm))
+        eng = bpp.Engine(local_rank)
+        par = params2.share(eng)
+        # ranks were seeded differently: any n_local of this rank's proofs are a shard
+        idx = np.concatenate([np.arange(((w * G + i) % nb) * n_local, ((w * G + i) % nb + 1) * n_local) for i in range(G)])
+        rb = packed.ResidentBatch(par, data2["proofs"][idx], data2["commitments"][idx], data2["min_values"][idx],
+                                  data2["min_present"][idx], None, LABEL)
+        rb.prepare(n_local if G > 1 else 0)
+        calls.append((eng, par, rb, dmod.ShardComm.from_process_group(eng)))
     errors = []
 
     def worker(w, rounds):
         try:
-            _, _, rbs, comm = waves[w]
+            _, _, rb, comm = calls[w]
             for _ in range(rounds):
-                res = comm.verify_wave(rbs, counts)
+                res = comm.verify_groups(rb, G, counts)
                 if any(r["code"] != 0 for r in res):
-                    raise RuntimeError("sharded batch failed: %r" % (res,))
-        except BaseException as e:  # noqa: BLE001 - NOTE: the other ranks' collectives of this wave are stranded; the run is lost
+                    raise RuntimeError("sharded batch failed: %r" % ([r for r in res if r["code"] != 0][:2],))
+        except BaseException as e:  # noqa: BLE001 - NOTE: the other ranks' collectives of this call are stranded; the run is lost
             errors.append(e)
 
     def region(rounds):
@@ -500,22 +499,19 @@ def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, para
     tt = torch.tensor([wel], dtype=torch.float64, device=device)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     wel = float(tt.item())
-    batches = W * K * rounds
-    wave_ms = waves[0][3].last_timing()
-    for engs, pars, rbs, comm in waves:
+    batches = W * G * rounds
+    wave_ms = calls[0][3].last_timing()
+    for eng, par, rb, comm in calls:
         comm.close()
-        for x in rbs:
-            x.close()
-        for p in pars:
-            p.close()
-        for e in engs:
-            e.close()
+        rb.close()
+        par.close()
+        eng.close()
     return {"workload": "BASELINE configs[3]: 4096 non-aggregated 64-bit proofs as ONE reference batch, %d per rank, through "
-                        "bpp_verify_sharded_wave: RCCL all_gather of 32 B/proof transcript-RNG bytes (device buffers), weight chain "
+                        "bpp_verify_sharded_groups: RCCL all_gather of 32 B/proof transcript-RNG bytes (device buffers), weight chain "
                         "replayed on every rank, RCCL all_gather of the 128-byte accumulators, sum + identity test on the device; "
-                        "%d waves x %d batches in flight per rank" % (n_local, W, K),
+                        "%d calls in flight per rank, each over %d batches resident as one" % (n_local, W, G),
             "rccl_ranks": world, "proofs_per_s": 4096 * batches / wel, "ms_per_batch": 1e3 * wel / batches,
-            "batches": batches, "in_flight": W * K, "waves": W, "batches_per_wave": K,
+            "batches": batches, "in_flight": W * G, "waves": W, "batches_per_wave": G,
             "last_wave_host_ms": {k: round(v, 3) for k, v in wave_ms.items()}}
 
 

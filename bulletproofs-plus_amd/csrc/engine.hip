@@ -1266,7 +1266,8 @@ namespace {
 // still running on the stream (it overlaps the host weight chain).
 // rng_dev_dst != nullptr (the sharded form): the transcript-RNG bytes are copied device -> device right behind PASS 1 and
 // ev_rng is recorded there; nothing comes to the host and the function does not wait
-void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uint8_t *rng_dev_dst = nullptr) {
+void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uint8_t *rng_dev_dst = nullptr, size_t rng_row_bytes = 0,
+                    size_t rng_dst_pitch = 0) {
   const bool fetch_rng = rng_dev_dst == nullptr;
   Params &P = *b.params;
   hipStream_t s = ctx->stream;
@@ -1318,6 +1319,9 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
   }
   tm.mark(M_TRANSCRIPTS);
   if (fetch_rng) HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));
+  else if (rng_dst_pitch && rng_dst_pitch != rng_row_bytes)  // rows of one group each, padded to the widest rank's shard
+    HIP_CHECK(hipMemcpy2DAsync(rng_dev_dst, rng_dst_pitch, b.rng_out.p, rng_row_bytes, rng_row_bytes, ((size_t)b.B * 32) / rng_row_bytes,
+                               hipMemcpyDeviceToDevice, s));
   else HIP_CHECK(hipMemcpyAsync(rng_dev_dst, b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToDevice, s));  // gathered over RCCL
   HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
   if (!side) launch_decompress(s);

@@ -479,6 +479,172 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
   }
 }
 
+// The grouped form: this rank's shards of `n_groups` reference batches live in ONE resident batch (group g = proofs
+// [g c, (g + 1) c) with c = counts[rank]) on ONE context, so every kernel of the verifier is launched once for all of them,
+// as the chunked single-process form does (bpp_verify_resident with chunk = c), and the two exchanges carry all groups.
+// What a wave of k contexts pays per batch -- a dozen launches, a stream, a host thread's attention -- is paid once here;
+// it is the form for many batches with small shards (eight ranks x 512 proofs of a 4096-proof batch).
+int bpp_verify_sharded_groups(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, size_t n_groups, const uint32_t *counts,
+                              bpp_shard_result *results) {
+  if (!comm) return BPP_ERR_BAD_HANDLE;
+  if (!ctx || !counts || !results || n_groups == 0 || n_groups > 4096) return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "bad group arguments");
+  if (ctx->device != comm->device) return comm_fail(comm, BPP_ERR_BAD_HANDLE, "context of another device");
+  if (hipSetDevice(comm->device) != hipSuccess) return BPP_ERR_NO_DEVICE;
+  const uint32_t G = (uint32_t)n_groups, world = (uint32_t)comm->world, rank = (uint32_t)comm->rank;
+  std::lock_guard<std::mutex> comm_lock(comm->mu);
+  std::unique_lock<std::mutex> ctx_lock(ctx->mu);
+  uint32_t maxc = 0, first_index = 0;
+  uint64_t n_total = 0;
+  for (uint32_t r = 0; r < world; r++) {
+    maxc = std::max(maxc, counts[r]);
+    if (r < rank) first_index += counts[r];
+    n_total += counts[r];
+  }
+  const uint32_t c = counts[rank];
+  if (n_total == 0 || n_total > (1u << 24)) return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "Range statements or proofs length empty");
+  if (c == 0) return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "the grouped form needs a non-empty shard on every rank");
+  const size_t slot = (size_t)maxc * 32, per1 = G * slot, per2 = (size_t)G * 128 + (size_t)G * BPP_SHARD_TRAILER_BYTES;
+  int fault = 0;  // engine fault on THIS rank: it still reaches both collectives, with zero payloads and an ENGINE finding
+  std::string fault_msg;
+  Batch *bp = nullptr;
+  auto t_mark = std::chrono::steady_clock::now();
+  bpp_shard_timing &tmg = comm->timing;
+  memset(&tmg, 0, sizeof(tmg));
+  tmg.batches = G;
+  auto lap = [&](float &slot_ms) {
+    const auto now = std::chrono::steady_clock::now();
+    slot_ms += std::chrono::duration<float, std::milli>(now - t_mark).count();
+    t_mark = now;
+  };
+  try {
+    comm->send1.alloc(per1);
+    comm->recv1.alloc(per1 * world);
+    comm->send2.alloc(per2);
+    comm->recv2.alloc(per2 * world);
+    comm->d_flags.alloc(G);
+    comm->h_tr.resize((size_t)G * BPP_SHARD_TRAILER_BYTES);
+    comm->h_recv1.resize(per1 * world);
+    comm->h_recv2.resize(per2 * world);
+    comm->h_flags.resize(G);
+    hipStream_t cs = comm->stream, s = ctx->stream;
+    try {
+      auto it = ctx->batches.find(batch);
+      if (it == ctx->batches.end()) throw EngineError{BPP_ERR_BAD_HANDLE, "unknown batch handle"};
+      Batch &b = *it->second;
+      if ((uint64_t)b.B != (uint64_t)G * c) throw EngineError{BPP_ERR_ENGINE, "the resident batch does not hold n_groups x counts[rank] proofs"};
+      bp = &b;
+      StageTimer tm(ctx);
+      if (!ctx->ev_rng_ready) {
+        HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_rng, hipEventDisableTiming));
+        ctx->ev_rng_ready = true;
+      }
+      layout_groups(ctx, b, G == 1 ? 0 : c);
+      if (b.G != G) throw EngineError{BPP_ERR_ENGINE, "group layout differs from n_groups"};
+      if (c < maxc) HIP_CHECK(hipMemsetAsync(comm->send1.p, 0, per1, s));
+      // several groups: the kernels tolerate odd shapes and run on everything (as bpp_verify_resident does with chunks), the
+      // findings are raised per group afterwards; one group: the wave form's rules (nothing runs on a deferred finding)
+      if (G == 1 && b.any_defer) {
+        HIP_CHECK(hipMemsetAsync(comm->send1.p, 0, per1, s));
+        HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
+      } else {
+        enqueue_phase1(ctx, b, tm, G == 1 && b.any_rounds_bad, comm->send1.p, (size_t)c * 32, slot);
+      }
+      HIP_CHECK(hipStreamWaitEvent(cs, ctx->ev_rng, 0));
+    } catch (const EngineError &e) {
+      fault = e.code;
+      fault_msg = e.msg;
+      (void)hipMemsetAsync(comm->send1.p, 0, per1, cs);
+    }
+    lap(tmg.enqueue1_ms);
+    comm_allgather(comm, comm->send1.p, comm->recv1.p, per1, cs);
+    HIP_CHECK(hipMemcpyAsync(comm->h_recv1.data(), comm->recv1.p, per1 * world, hipMemcpyDeviceToHost, cs));
+    HIP_CHECK(hipStreamSynchronize(cs));
+    lap(tmg.gather1_ms);
+    // weight transcripts over ALL proofs of each reference batch, replayed on every rank
+    comm->rng_all.resize((size_t)G * n_total * 32);
+    comm->weights_all.resize((size_t)G * n_total * 32);
+    {
+      std::vector<uint32_t> gfirst(G + 1);
+      for (uint32_t g = 0; g < G; g++) {
+        gfirst[g] = (uint32_t)(g * n_total);
+        uint8_t *dst = comm->rng_all.data() + (size_t)g * n_total * 32;
+        for (uint32_t r = 0; r < world; r++) {
+          memcpy(dst, comm->h_recv1.data() + (size_t)r * per1 + (size_t)g * slot, (size_t)counts[r] * 32);
+          dst += (size_t)counts[r] * 32;
+        }
+      }
+      gfirst[G] = (uint32_t)(G * n_total);
+      run_weight_chains_generic(comm->rng_all.data(), comm->weights_all.data(), gfirst.data(), G);
+    }
+    lap(tmg.chains_ms);
+    bool ran2 = false;
+    if (!fault) {
+      Batch &b = *bp;
+      try {
+        StageTimer tm(ctx);
+        if (G == 1 && (b.any_defer || b.any_rounds_bad)) {
+          HIP_CHECK(hipMemsetAsync(comm->send2.p, 0, 128, s));
+          if (b.any_defer) HIP_CHECK(hipMemsetAsync(b.status.p, 0, (size_t)b.B * 4, s));
+        } else {
+          for (uint32_t g = 0; g < G; g++)
+            memcpy(b.h_weights.data() + (size_t)g * c * 32, comm->weights_all.data() + ((size_t)g * n_total + first_index) * 32, (size_t)c * 32);
+          enqueue_phase2(ctx, b, tm);
+          hipLaunchKernelGGL(k_ge_to_bytes, dim3(cdiv(G, 64)), dim3(64), 0, s, b.msm.R.p, G, comm->send2.p);
+          HIP_CHECK(hipGetLastError());
+          b.have_trace = true;
+          ran2 = true;
+        }
+        fetch_status(ctx, b);
+      } catch (const EngineError &e) {
+        fault = e.code;
+        fault_msg = e.msg;
+      }
+    }
+    (void)ran2;
+    lap(tmg.enqueue2_ms);
+    if (!fault && hipStreamSynchronize(s) != hipSuccess) {
+      fault = BPP_ERR_ENGINE;
+      fault_msg = "a kernel of this rank failed on the device";
+    }
+    if (fault) (void)hipMemsetAsync(comm->send2.p, 0, (size_t)G * 128, cs);
+    for (uint32_t g = 0; g < G; g++) {
+      uint8_t *tr = comm->h_tr.data() + (size_t)g * BPP_SHARD_TRAILER_BYTES;
+      if (fault) {
+        shard_trailer_encode(tr, BPP_TIER_ENGINE, fault, first_index, fault_msg.c_str());
+      } else {
+        Batch &b = *bp;
+        const size_t o = (size_t)g * c;
+        shard_local_trailer(b.any_defer ? b.defer.data() + o : nullptr, b.h_status.data() + o, b.rounds_bad.data() + o, c, first_index, tr);
+      }
+    }
+    lap(tmg.wait2_ms);
+    HIP_CHECK(hipMemcpyAsync(comm->send2.p + (size_t)G * 128, comm->h_tr.data(), (size_t)G * BPP_SHARD_TRAILER_BYTES, hipMemcpyHostToDevice, cs));
+    comm_allgather(comm, comm->send2.p, comm->recv2.p, per2, cs);
+    hipLaunchKernelGGL(k_sum_accumulators_wave, dim3(cdiv(G, 64)), dim3(64), 0, cs, comm->recv2.p, world, (uint32_t)per2, G, comm->d_flags.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(comm->h_flags.data(), comm->d_flags.p, (size_t)G * 4, hipMemcpyDeviceToHost, cs));
+    HIP_CHECK(hipMemcpyAsync(comm->h_recv2.data(), comm->recv2.p, per2 * world, hipMemcpyDeviceToHost, cs));
+    HIP_CHECK(hipStreamSynchronize(cs));
+    lap(tmg.gather2_ms);
+    for (uint32_t g = 0; g < G; g++) {
+      const ShardFinding f = shard_resolve(comm->h_recv2.data() + (size_t)G * 128 + (size_t)g * BPP_SHARD_TRAILER_BYTES, per2, (int)world);
+      if (f.tier != BPP_TIER_NONE)
+        shard_result_set(results[g], f.code > 0 || f.code < 0 ? f.code : BPP_ERR_ENGINE, f.tier, f.rank, f.index, f.msg + " (rank " + std::to_string(f.rank) + ")");
+      else if (!comm->h_flags[g])
+        shard_result_set(results[g], BPP_ERR_VERIFICATION_FAILED, BPP_TIER_MSM, -1, 0, "Range proof batch not valid");
+      else
+        shard_result_set(results[g], BPP_OK, BPP_TIER_NONE, -1, 0, "");
+    }
+    return BPP_OK;
+  } catch (const CommError &e) {
+    return comm_fail(comm, BPP_ERR_COMM, e.msg);
+  } catch (const EngineError &e) {
+    return comm_fail(comm, e.code, e.msg);
+  } catch (const std::exception &e) {
+    return comm_fail(comm, BPP_ERR_ENGINE, e.what());
+  }
+}
+
 int bpp_verify_sharded(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, const uint32_t *counts, int *tier_out, int *rank_out,
                        char *errbuf, size_t errbuf_len) {
   bpp_shard_result r;

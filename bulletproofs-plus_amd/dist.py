@@ -76,6 +76,16 @@ class ShardComm:
             raise api.EngineError("bpp_verify_sharded_wave failed (%d): %s" % (rc, self._err()))
         return [{"code": r.code, "tier": r.tier, "rank": r.rank, "index": r.index, "msg": r.msg.decode(errors="replace")} for r in out]
 
+    def verify_groups(self, rb, n_groups, counts):
+        """bpp_verify_sharded_groups: ONE resident batch holding this rank's shards of n_groups reference batches (group g =
+        proofs [g c, (g+1) c), c = counts[rank]) -> list of n_groups result dicts"""
+        cn = (c_uint32 * self.world)(*counts)
+        out = (_lib.ShardResult * n_groups)()
+        rc = self.lib.bpp_verify_sharded_groups(self.handle, rb.engine.ctx, rb.handle, n_groups, cn, out)
+        if rc != 0:
+            raise api.EngineError("bpp_verify_sharded_groups failed (%d): %s" % (rc, self._err()))
+        return [{"code": r.code, "tier": r.tier, "rank": r.rank, "index": r.index, "msg": r.msg.decode(errors="replace")} for r in out]
+
     def last_timing(self):
         """host wall-clock split of the last wave (ms)"""
         t = _lib.ShardTiming()

@@ -263,6 +263,14 @@ typedef struct {
 } bpp_shard_result;
 int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t *batches, size_t k, const uint32_t *counts,
                             bpp_shard_result *results);
+/* The GROUPED form: this rank's shards of n_groups independent reference batches (same `counts` for all) are ONE resident
+ * batch on ONE context -- group g = proofs [g c, (g+1) c) of it, c = counts[rank] > 0 -- so every verifier kernel is
+ * launched once for all groups (as bpp_verify_resident does with chunk = c) and each of the two all_gathers carries all
+ * groups.  results[g] = group g's outcome, exactly as a bpp_verify_sharded call on that batch alone would give it.  The form
+ * for many batches with small shards: a wave of k contexts pays a dozen launches and a stream per batch, this pays them
+ * once.  src/range_proof.rs:712-752 (one reference batch per group), :811-853 (its weight chain over all ranks' proofs). */
+int bpp_verify_sharded_groups(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, size_t n_groups, const uint32_t *counts,
+                              bpp_shard_result *results /* n_groups */);
 /* host wall-clock split of the last wave on `comm` (ms): enqueueing phase 1 on the k streams, the first exchange (waits for
  * PASS 1 only: all_gather, RNG bytes down), the k weight chains, enqueueing phase 2, waiting for the k streams, the second
  * exchange with the sum and identity test (wait1_ms is always 0 since the first exchange no longer waits for all of phase 1) */

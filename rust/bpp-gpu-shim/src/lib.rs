@@ -131,6 +131,26 @@ impl Engine {
         map_rc(rc, unsafe { CStr::from_ptr(err.as_ptr()) }.to_string_lossy().into_owned()).map_err(|e| ShardError { error: e, tier, rank })
     }
 
+    /// This rank's shards of `n_groups` reference batches at once: `input` holds n_groups x counts[rank] proofs, group g =
+    /// proofs [g c, (g + 1) c).  One set of kernel launches and two all_gathers for all groups (bpp_verify_sharded_groups);
+    /// per group the result a `verify_sharded` call on that batch alone would give.
+    pub fn verify_sharded_groups(&self, comm: &ShardComm, params: &Params, input: &PackedBatch<'_>, n_groups: usize, counts: &[u32])
+                                 -> Result<Vec<Result<(), ShardError>>, GpuError> {
+        let raw = input.raw();
+        let mut batch = 0u64;
+        let mut err = [0 as core::ffi::c_char; 256];
+        let up = unsafe { ffi::bpp_batch_upload_packed(self.ctx, params.handle, &raw, &mut batch, err.as_mut_ptr(), err.len()) };
+        map_rc(up, unsafe { CStr::from_ptr(err.as_ptr()) }.to_string_lossy().into_owned())?;  // rank-local: see verify_sharded
+        let mut res: Vec<ffi::bpp_shard_result> = (0..n_groups).map(|_| unsafe { core::mem::zeroed() }).collect();
+        let rc = unsafe { ffi::bpp_verify_sharded_groups(comm.raw, self.ctx, batch, n_groups, counts.as_ptr(), res.as_mut_ptr()) };
+        unsafe { ffi::bpp_batch_destroy(self.ctx, batch) };
+        map_rc(rc, unsafe { CStr::from_ptr(ffi::bpp_comm_last_error(comm.raw)) }.to_string_lossy().into_owned())?;
+        Ok(res.iter().map(|r| {
+            let msg = unsafe { CStr::from_ptr(r.msg.as_ptr()) }.to_string_lossy().into_owned();
+            map_rc(r.code, msg).map_err(|e| ShardError { error: e, tier: r.tier, rank: r.rank })
+        }).collect())
+    }
+
     /// `RangeProof::verify_batch`: every `chunk` consecutive items are one reference batch (256 = MAX_RANGE_PROOF_BATCH_SIZE,
     /// 0 = the whole input).  Returns per item `Some(mask blindings, t x 32 bytes)` or `None`.
     pub fn verify_batch(&self, params: &Params, items: &[VerifyItem<'_>], action: Action, chunk: usize)

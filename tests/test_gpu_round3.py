@@ -387,3 +387,89 @@ def test_sharded_entry_with_three_ranks_in_process(bpp, packed, engine):
     for e in engs:
         e.close()
     params.close()
+
+
+def test_sharded_groups_with_three_ranks_in_process(bpp, packed, engine):
+    """bpp_verify_sharded_groups: FOUR reference batches of 90 proofs sharded raggedly (30 + 20 + 40) over three in-process
+    ranks, each rank's four shards resident as ONE batch on ONE context (every kernel launched once for all four, both
+    exchanges carrying all four).  Per group every rank must report what bpp_verify_sharded reports for that batch alone
+    (= what the single-call form says about the 90 proofs): verdict, tier, rank and index of the finding; untouched groups
+    stay accepted next to failing ones; each rank's weights are its slices of the four chains."""
+    import threading
+    dmod = importlib.import_module("bulletproofs-plus_amd.dist")
+    params, d = _inputs(bpp, packed, engine, 1, 1, 360, 7700)
+    K = bpp.ProofErrorKind
+    counts, world, G, n = [30, 20, 40], 3, 4, 90
+    first = [0, 30, 50]
+    engs = [bpp.Engine(0) for _ in range(world)]
+    pars = [params.share(e) for e in engs]
+    comms = [dmod.ShardComm(engs[r], r, world, local_group=4343) for r in range(world)]
+
+    def run(proofs):
+        out, weights = [None] * world, [None] * world
+
+        def rank_main(r):
+            idx = np.concatenate([np.arange(n * g + first[r], n * g + first[r] + counts[r]) for g in range(G)])
+            rb = packed.ResidentBatch(pars[r], proofs[idx], d["commitments"][idx], d["min_values"][idx], d["min_present"][idx], None, LABEL)
+            try:
+                res = comms[r].verify_groups(rb, G, counts)
+                out[r] = [(x["code"], x["tier"], x["rank"], x["index"]) for x in res]
+                weights[r] = rb.trace(3)
+            except BaseException as e:  # noqa: BLE001
+                out[r] = ("exception", repr(e))
+            finally:
+                rb.close()
+        ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in ths), "a rank is stuck in a collective"
+        assert out[0] == out[1] == out[2], out
+        # every group against the single-call form on its 90 proofs
+        for g in range(G):
+            sl = slice(n * g, n * (g + 1))
+            rb = packed.ResidentBatch(params, proofs[sl], d["commitments"][sl], d["min_values"][sl], d["min_present"][sl], None, LABEL)
+            try:
+                rb.verify_only(0)
+                want = 0
+            except bpp.ProofError as e:
+                want = int(e.kind)
+            w_all = rb.trace(3)
+            rb.close()
+            assert out[0][g][0] == want, (g, out[0][g], want)
+            if want == 0:
+                c0 = 0
+                for r in range(world):  # rank r's weights of group g = its slice of the chain over the group's 90 proofs
+                    got = weights[r][32 * g * counts[r]:32 * (g + 1) * counts[r]]
+                    assert got == w_all[32 * c0:32 * (c0 + counts[r])], (g, r)
+                    c0 += counts[r]
+        return out[0]
+
+    ok = (0, 0, -1, 0)
+    assert run(d["proofs"]) == [ok] * G
+    pr = d["proofs"].copy()
+    pr[n * 1 + 45, 1 + 32 + 96] ^= 1                                                    # group 1: r1 of a proof on rank 1
+    pr[n * 2 + 35, 1 + 32:1 + 64] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)   # group 2: non-canonical A on rank 1
+    pr[n * 3 + 70, 1 + 32:1 + 64] = 0                                                    # group 3: identity A on rank 2
+    pr[n * 3 + 2, 1 + 32:1 + 64] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)    # ... and a later-tier finding on rank 0
+    assert run(pr) == [ok, (int(K.VerificationFailed), 7, -1, 0), (int(K.InvalidArgument), 6, 1, 35), (int(K.VerificationFailed), 5, 2, 70)]
+    assert run(d["proofs"]) == [ok] * G
+    # one rank, one group: the grouped entry is bpp_verify_sharded
+    c1 = dmod.ShardComm(engine, 0, 1, local_group=4344)
+    sl = slice(0, 200)
+    rb = packed.ResidentBatch(params, d["proofs"][sl], d["commitments"][sl], d["min_values"][sl], d["min_present"][sl], None, LABEL)
+    assert [x["code"] for x in c1.verify_groups(rb, 1, [200])] == [0]
+    assert [x["code"] for x in c1.verify_groups(rb, 4, [50])] == [0] * 4
+    bad = c1.verify_groups(rb, 3, [50])  # 3 x 50 is not the batch: an engine fault of this rank, reported for every group
+    assert all(x["code"] < 0 and x["tier"] == 255 for x in bad)
+    assert [x["code"] for x in c1.verify_groups(rb, 2, [100])] == [0] * 2  # and the communicator is still in step
+    rb.close()
+    c1.close()
+    for c in comms:
+        c.close()
+    for p in pars:
+        p.close()
+    for e in engs:
+        e.close()
+    params.close()

@@ -8,7 +8,9 @@ oracle as the checker), not part of the product.
 Every call goes through one of the engine's entry paths, picked at random (--paths): the item form (bpp_verify_batch), the
 packed blocking form (bpp_verify_batch_packed), the pipelined form (bpp_verify_submit_packed / collect, several tickets
 outstanding, collected in random order) and the sharded form over a one-rank RCCL communicator (bpp_verify_sharded: the whole
-call is one reference batch).  Small calls take the half-scalar MSM plan, larger ones the full plan.
+call is one reference batch) and the grouped sharded form (bpp_verify_sharded_groups: the call cut into equal groups, each its
+own reference batch, every group's outcome compared with the oracle's).  Small calls take the half-scalar MSM plan, larger
+ones the full plan.
 
     python tools/soak.py --seconds 120 --threads 4
 prints one JSON line: calls (per path), rejected inputs, mismatches (must be 0)."""
@@ -30,7 +32,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--seed", type=int, default=20260704)
-    ap.add_argument("--paths", default="items,packed,pipeline,sharded")
+    ap.add_argument("--paths", default="items,packed,pipeline,sharded,groups")
     args = ap.parse_args()
     import numpy as np
     bpp = importlib.import_module("bulletproofs-plus_amd")
@@ -61,7 +63,7 @@ def main():
         eng = bpp.Engine(0)
         params = bpp.RangeParameters.init(n_bits, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=eng)
         pipe = packed.Pipeline(params, depth=3) if "pipeline" in paths else None
-        comm = dmod.ShardComm(eng, 0, 1, dmod.ShardComm.unique_id()) if "sharded" in paths else None
+        comm = dmod.ShardComm(eng, 0, 1, dmod.ShardComm.unique_id()) if ("sharded" in paths or "groups" in paths) else None
         cp = cport.Params(n_bits, m, t)
         pending = []  # pipeline tickets: (ticket, expected code, record)
 
@@ -89,6 +91,9 @@ def main():
             path = rng.choice(paths)
             cnt = rng.choice([1, 2, 3, 7, 16, 64, 200, 256])
             chunk = 0 if path == "sharded" else rng.choice([0, 0, 8, 64])
+            if path == "groups":  # bpp_verify_sharded_groups: `cnt` proofs as equal groups, every group its own reference batch
+                groups = rng.choice([g for g in (1, 2, 4, 8, 16) if cnt % g == 0 and cnt // g >= 1])
+                chunk = cnt // groups
             sub = [dict(items[i]) for i in rng.sample(range(len(items)), cnt)]
             mutated = rng.random() < 0.5
             if mutated:
@@ -125,6 +130,21 @@ def main():
                     if len(pending) >= 3:
                         collect(pending.pop(rng.randrange(len(pending))))
                     continue
+                elif path == "groups":
+                    rb = packed.ResidentBatch(params, *[getattr(packed_input(sub), a) for a in ("proofs", "commitments", "min_values", "min_present")],
+                                              None, label)
+                    try:
+                        res = comm.verify_groups(rb, cnt // chunk, [chunk])
+                    finally:
+                        rb.close()
+                    # per group the oracle's verdict on that group; the call's outcome for the record: the first failing group's
+                    for gi, r in enumerate(res):
+                        rc_g, _, _ = cp.verify(sub[gi * chunk:(gi + 1) * chunk], action=0)
+                        if r["code"] != rc_g:
+                            got = -1000 - gi  # a per-group mismatch shows up as a mismatch of the call
+                            break
+                    else:
+                        got = next((r["code"] for r in res if r["code"] != 0), 0)
                 else:
                     rb = packed.ResidentBatch(params, *[getattr(packed_input(sub), a) for a in ("proofs", "commitments", "min_values", "min_present")],
                                               None, label)
