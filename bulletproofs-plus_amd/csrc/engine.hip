@@ -1548,10 +1548,11 @@ void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk) {
 
 // Weight-dependent tail: h_weights -> device, the weighted generator rows and dynamic scalars (k_scalars_lanes), the
 // per-group column sums, final MSM.
-void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm) {
+void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool weights_resident = false) {
   Params &P = *b.params;
   hipStream_t s = ctx->stream;
-  HIP_CHECK(hipMemcpyAsync(b.weights.p, b.h_weights.data(), (size_t)b.B * 32, hipMemcpyHostToDevice, s));
+  // (weights_resident: the grouped sharded form has put them into b.weights device -> device already)
+  if (!weights_resident) HIP_CHECK(hipMemcpyAsync(b.weights.p, b.h_weights.data(), (size_t)b.B * 32, hipMemcpyHostToDevice, s));
   tm.mark(M_WEIGHTS_IN);
   sc *dyn_scal = b.scal.p + (size_t)b.G * b.cols;
   {

@@ -135,7 +135,7 @@ struct bpp_comm {
   ncclComm_t comm = nullptr;
   bool own_comm = false;
   hipStream_t stream = nullptr;  // collectives and their staging copies
-  DevBuf<uint8_t> send1, recv1, send2, recv2;
+  DevBuf<uint8_t> send1, recv1, send2, recv2, send3, recv3;
   DevBuf<uint32_t> d_flags;
   PinnedBuf<uint8_t> h_tr, h_recv1, h_recv2;
   PinnedBuf<uint32_t> h_flags;
@@ -560,23 +560,41 @@ int bpp_verify_sharded_groups(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, size
     HIP_CHECK(hipMemcpyAsync(comm->h_recv1.data(), comm->recv1.p, per1 * world, hipMemcpyDeviceToHost, cs));
     HIP_CHECK(hipStreamSynchronize(cs));
     lap(tmg.gather1_ms);
-    // weight transcripts over ALL proofs of each reference batch, replayed on every rank
-    comm->rng_all.resize((size_t)G * n_total * 32);
-    comm->weights_all.resize((size_t)G * n_total * 32);
+    // Weight transcripts over ALL proofs of each reference batch.  One rank replays all of them.  Several ranks share them out:
+    // rank r replays the chains of groups r, r + world, ... and a third all_gather hands every rank every group's weights
+    // (32 B per proof: 8 MB for 64 batches of 4096) -- the replay is a sequential sponge per batch on a host core, and with
+    // every rank replaying every chain it, not the GPUs, bounded the rate (64 chains: 3.4 - 4.7 ms per call on sixteen
+    // workers against 3 ms of kernels for a rank's 64 shards of 512 proofs).
+    const bool share_chains = world > 1;
+    const uint32_t n_own = share_chains ? (G > rank ? (G - rank + world - 1) / world : 0u) : G;
+    const uint32_t slots3 = cdiv(G, world);
+    const size_t per3 = (size_t)slots3 * n_total * 32;
+    comm->rng_all.resize((size_t)std::max(n_own, 1u) * n_total * 32);
+    comm->weights_all.resize((size_t)std::max(n_own, 1u) * n_total * 32);
     {
-      std::vector<uint32_t> gfirst(G + 1);
-      for (uint32_t g = 0; g < G; g++) {
-        gfirst[g] = (uint32_t)(g * n_total);
-        uint8_t *dst = comm->rng_all.data() + (size_t)g * n_total * 32;
+      std::vector<uint32_t> gfirst(n_own + 1);
+      for (uint32_t j = 0; j < n_own; j++) {
+        const uint32_t g = share_chains ? rank + j * world : j;
+        gfirst[j] = (uint32_t)(j * n_total);
+        uint8_t *dst = comm->rng_all.data() + (size_t)j * n_total * 32;
         for (uint32_t r = 0; r < world; r++) {
           memcpy(dst, comm->h_recv1.data() + (size_t)r * per1 + (size_t)g * slot, (size_t)counts[r] * 32);
           dst += (size_t)counts[r] * 32;
         }
       }
-      gfirst[G] = (uint32_t)(G * n_total);
-      run_weight_chains_generic(comm->rng_all.data(), comm->weights_all.data(), gfirst.data(), G);
+      gfirst[n_own] = (uint32_t)(n_own * n_total);
+      if (n_own) run_weight_chains_generic(comm->rng_all.data(), comm->weights_all.data(), gfirst.data(), n_own);
     }
     lap(tmg.chains_ms);
+    if (share_chains) {
+      comm->send3.alloc(per3);
+      comm->recv3.alloc(per3 * world);
+      if (n_own < slots3) HIP_CHECK(hipMemsetAsync(comm->send3.p, 0, per3, cs));
+      if (n_own) HIP_CHECK(hipMemcpyAsync(comm->send3.p, comm->weights_all.data(), (size_t)n_own * n_total * 32, hipMemcpyHostToDevice, cs));
+      comm_allgather(comm, comm->send3.p, comm->recv3.p, per3, cs);
+      HIP_CHECK(hipStreamSynchronize(cs));
+      lap(tmg.gather1_ms);  // (counted with the first exchange: the timing struct is part of the ABI)
+    }
     bool ran2 = false;
     if (!fault) {
       Batch &b = *bp;
@@ -586,9 +604,19 @@ int bpp_verify_sharded_groups(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, size
           HIP_CHECK(hipMemsetAsync(comm->send2.p, 0, 128, s));
           if (b.any_defer) HIP_CHECK(hipMemsetAsync(b.status.p, 0, (size_t)b.B * 4, s));
         } else {
-          for (uint32_t g = 0; g < G; g++)
-            memcpy(b.h_weights.data() + (size_t)g * c * 32, comm->weights_all.data() + ((size_t)g * n_total + first_index) * 32, (size_t)c * 32);
-          enqueue_phase2(ctx, b, tm);
+          if (!share_chains) {
+            for (uint32_t g = 0; g < G; g++)
+              memcpy(b.h_weights.data() + (size_t)g * c * 32, comm->weights_all.data() + ((size_t)g * n_total + first_index) * 32, (size_t)c * 32);
+            enqueue_phase2(ctx, b, tm);
+          } else {
+            // this rank's slice of every group's weights, device -> device: the groups replayed by rank o sit n_total * 32 bytes
+            // apart in o's part of recv3 and `world` groups apart in the batch
+            for (uint32_t o = 0; o < world && o < G; o++)
+              HIP_CHECK(hipMemcpy2DAsync(b.weights.p + (size_t)o * c * 32, (size_t)world * c * 32,
+                                         comm->recv3.p + (size_t)o * per3 + (size_t)first_index * 32, (size_t)n_total * 32, (size_t)c * 32,
+                                         (G - o + world - 1) / world, hipMemcpyDeviceToDevice, s));
+            enqueue_phase2(ctx, b, tm, true);
+          }
           hipLaunchKernelGGL(k_ge_to_bytes, dim3(cdiv(G, 64)), dim3(64), 0, s, b.msm.R.p, G, comm->send2.p);
           HIP_CHECK(hipGetLastError());
           b.have_trace = true;

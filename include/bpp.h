@@ -268,7 +268,9 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
  * launched once for all groups (as bpp_verify_resident does with chunk = c) and each of the two all_gathers carries all
  * groups.  results[g] = group g's outcome, exactly as a bpp_verify_sharded call on that batch alone would give it.  The form
  * for many batches with small shards: a wave of k contexts pays a dozen launches and a stream per batch, this pays them
- * once.  src/range_proof.rs:712-752 (one reference batch per group), :811-853 (its weight chain over all ranks' proofs). */
+ * once.  With several ranks the weight chains are shared out (rank r replays those of groups r, r + world, ...) and a third
+ * all_gather hands every rank all weights: the sequential replay, not the GPUs, bounds the rate when every rank replays
+ * every chain.  src/range_proof.rs:712-752 (one reference batch per group), :811-853 (its weight chain over all ranks' proofs). */
 int bpp_verify_sharded_groups(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, size_t n_groups, const uint32_t *counts,
                               bpp_shard_result *results /* n_groups */);
 /* host wall-clock split of the last wave on `comm` (ms): enqueueing phase 1 on the k streams, the first exchange (waits for

@@ -390,17 +390,17 @@ def test_sharded_entry_with_three_ranks_in_process(bpp, packed, engine):
 
 
 def test_sharded_groups_with_three_ranks_in_process(bpp, packed, engine):
-    """bpp_verify_sharded_groups: FOUR reference batches of 90 proofs sharded raggedly (30 + 20 + 40) over three in-process
-    ranks, each rank's four shards resident as ONE batch on ONE context (every kernel launched once for all four, both
-    exchanges carrying all four).  Per group every rank must report what bpp_verify_sharded reports for that batch alone
-    (= what the single-call form says about the 90 proofs): verdict, tier, rank and index of the finding; untouched groups
-    stay accepted next to failing ones; each rank's weights are its slices of the four chains."""
+    """bpp_verify_sharded_groups: SEVEN reference batches of 60 proofs sharded raggedly (20 + 12 + 28) over three in-process
+    ranks, each rank's seven shards resident as ONE batch on ONE context (every kernel launched once for all seven, the
+    exchanges carrying all seven; the seven weight chains shared out 3 + 2 + 2 over the ranks and their weights gathered).  Per group every rank must report what bpp_verify_sharded reports for that batch alone
+    (= what the single-call form says about the 60 proofs): verdict, tier, rank and index of the finding; untouched groups
+    stay accepted next to failing ones; each rank's weights are its slices of the seven chains."""
     import threading
     dmod = importlib.import_module("bulletproofs-plus_amd.dist")
-    params, d = _inputs(bpp, packed, engine, 1, 1, 360, 7700)
+    params, d = _inputs(bpp, packed, engine, 1, 1, 420, 7700)
     K = bpp.ProofErrorKind
-    counts, world, G, n = [30, 20, 40], 3, 4, 90
-    first = [0, 30, 50]
+    counts, world, G, n = [20, 12, 28], 3, 7, 60
+    first = [0, 20, 32]
     engs = [bpp.Engine(0) for _ in range(world)]
     pars = [params.share(e) for e in engs]
     comms = [dmod.ShardComm(engs[r], r, world, local_group=4343) for r in range(world)]
@@ -426,7 +426,7 @@ def test_sharded_groups_with_three_ranks_in_process(bpp, packed, engine):
             t.join(timeout=120)
         assert not any(t.is_alive() for t in ths), "a rank is stuck in a collective"
         assert out[0] == out[1] == out[2], out
-        # every group against the single-call form on its 90 proofs
+        # every group against the single-call form on its 60 proofs
         for g in range(G):
             sl = slice(n * g, n * (g + 1))
             rb = packed.ResidentBatch(params, proofs[sl], d["commitments"][sl], d["min_values"][sl], d["min_present"][sl], None, LABEL)
@@ -440,7 +440,7 @@ def test_sharded_groups_with_three_ranks_in_process(bpp, packed, engine):
             assert out[0][g][0] == want, (g, out[0][g], want)
             if want == 0:
                 c0 = 0
-                for r in range(world):  # rank r's weights of group g = its slice of the chain over the group's 90 proofs
+                for r in range(world):  # rank r's weights of group g = its slice of the chain over the group's 60 proofs
                     got = weights[r][32 * g * counts[r]:32 * (g + 1) * counts[r]]
                     assert got == w_all[32 * c0:32 * (c0 + counts[r])], (g, r)
                     c0 += counts[r]
@@ -449,11 +449,13 @@ def test_sharded_groups_with_three_ranks_in_process(bpp, packed, engine):
     ok = (0, 0, -1, 0)
     assert run(d["proofs"]) == [ok] * G
     pr = d["proofs"].copy()
-    pr[n * 1 + 45, 1 + 32 + 96] ^= 1                                                    # group 1: r1 of a proof on rank 1
-    pr[n * 2 + 35, 1 + 32:1 + 64] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)   # group 2: non-canonical A on rank 1
-    pr[n * 3 + 70, 1 + 32:1 + 64] = 0                                                    # group 3: identity A on rank 2
+    pr[n * 1 + 25, 1 + 32 + 96] ^= 1                                                    # group 1: r1 of a proof on rank 1
+    pr[n * 2 + 25, 1 + 32:1 + 64] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)   # group 2: non-canonical A on rank 1
+    pr[n * 3 + 50, 1 + 32:1 + 64] = 0                                                    # group 3: identity A on rank 2
     pr[n * 3 + 2, 1 + 32:1 + 64] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)    # ... and a later-tier finding on rank 0
-    assert run(pr) == [ok, (int(K.VerificationFailed), 7, -1, 0), (int(K.InvalidArgument), 6, 1, 35), (int(K.VerificationFailed), 5, 2, 70)]
+    pr[n * 6 + 59, 1 + 32 + 96] ^= 1                                                    # group 6 (replayed by rank 0): the last proof
+    assert run(pr) == [ok, (int(K.VerificationFailed), 7, -1, 0), (int(K.InvalidArgument), 6, 1, 25), (int(K.VerificationFailed), 5, 2, 50),
+                       ok, ok, (int(K.VerificationFailed), 7, -1, 0)]
     assert run(d["proofs"]) == [ok] * G
     # one rank, one group: the grouped entry is bpp_verify_sharded
     c1 = dmod.ShardComm(engine, 0, 1, local_group=4344)
