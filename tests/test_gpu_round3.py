@@ -456,6 +456,14 @@ def test_sharded_groups_with_three_ranks_in_process(bpp, packed, engine):
     pr[n * 6 + 59, 1 + 32 + 96] ^= 1                                                    # group 6 (replayed by rank 0): the last proof
     assert run(pr) == [ok, (int(K.VerificationFailed), 7, -1, 0), (int(K.InvalidArgument), 6, 1, 25), (int(K.VerificationFailed), 5, 2, 50),
                        ok, ok, (int(K.VerificationFailed), 7, -1, 0)]
+    # verify()'s own consistency loop (a proof of another extension degree) precedes everything else of its group, whichever
+    # rank holds it; the kernels still run on every item of the resident batch, the other groups keep their verdicts
+    pr = d["proofs"].copy()
+    pr[n * 4 + 40, 0] = 3
+    pr[n * 4 + 40, 1:1 + 32 * 8] = 0                 # group 4, rank 2
+    pr[n * 4 + 5, 1 + 32:1 + 64] = 0                 # ... and an identity A on rank 0 (a later tier)
+    pr[n * 5 + 31, 1 + 32 + 96] ^= 1                 # group 5 fails in its sum
+    assert run(pr) == [ok, ok, ok, ok, (int(K.InvalidArgument), 2, 2, 40), (int(K.VerificationFailed), 7, -1, 0), ok]
     assert run(d["proofs"]) == [ok] * G
     # one rank, one group: the grouped entry is bpp_verify_sharded
     c1 = dmod.ShardComm(engine, 0, 1, local_group=4344)
