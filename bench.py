@@ -445,37 +445,43 @@ def host_in_leg(bpp, packed, np, device_index, params0, data, R, calls, sync):
 
 def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, params2, data2, args, sync):
     """BASELINE configs[3]: 4096 proofs as ONE reference batch sharded over the ranks, through the C ABI
-    (bpp_verify_sharded_groups: RCCL all_gathers on device buffers).  A rank's shards of G such batches are ONE resident
-    batch on one context: every verifier kernel is launched once for all G, each of the two all_gathers carries all G, the G
-    weight chains (each over all 4096 proofs, replayed on every rank) run side by side on the host pool.  W such calls are in
-    flight per rank (own communicator, own host thread each): one call's chains and exchanges under the others' kernels."""
+    (bpp_verify_sharded_groups_wave: RCCL all_gathers on device buffers).  A rank's shards of G such batches are ONE resident
+    batch on one context: every verifier kernel is launched once for all G, each all_gather carries all G, the weight chains
+    (each over all 4096 proofs; shared out over the ranks and their weights gathered when there are several) run side by side on
+    the host pool.  One call runs S such batches as a software pipeline of one host thread; W calls are in flight per rank
+    (own communicator, own host thread each)."""
     dmod = importlib.import_module("bulletproofs-plus_amd.dist")
-    # One rank: three calls of 32 batches.  Several ranks: ONE call of 64 -- two communicators progressing from two host
-    # threads per rank can reach their collectives in different orders on different ranks; that is legal for RCCL as long as
-    # both kernels can be resident at once, but this leg cannot be rehearsed on a multi-GPU node here, so it takes the form
-    # that cannot interleave at all.
-    G = int(os.environ.get("BPP_BENCH_WAVE_BATCHES", "32" if world == 1 else "64"))
-    W = int(os.environ.get("BPP_BENCH_WAVES", "3" if world == 1 else "1"))
+    # ONE call per rank, a pipeline of two times 64 batches, at every N.  (Several calls from several host threads, each with its
+    # own communicator, do as well on one rank -- three times 32: the same rate -- but two communicators progressing from two
+    # threads can reach their collectives in different orders on different ranks; that is legal for RCCL only while every
+    # kernel involved can be resident at once, and this leg cannot be rehearsed on a multi-GPU node here: it takes the form
+    # whose collectives are issued in one order on every rank by construction.)
+    G = int(os.environ.get("BPP_BENCH_WAVE_BATCHES", "64"))
+    W = int(os.environ.get("BPP_BENCH_WAVES", "1"))
+    S = int(os.environ.get("BPP_BENCH_WAVE_SLOTS", "2"))
     n_local = 4096 // world
     counts = [n_local] * world
     nb = data2["proofs"].shape[0] // n_local
     calls = []
     for w in range(W):  # communicators are built collectively, in the same order on every rank
-        eng = bpp.Engine(local_rank)
-        par = params2.share(eng)
-        # ranks were seeded differently: any n_local of this rank's proofs are a shard
-        idx = np.concatenate([np.arange(((w * G + i) % nb) * n_local, ((w * G + i) % nb + 1) * n_local) for i in range(G)])
-        rb = packed.ResidentBatch(par, data2["proofs"][idx], data2["commitments"][idx], data2["min_values"][idx],
-                                  data2["min_present"][idx], None, LABEL)
-        rb.prepare(n_local if G > 1 else 0)
-        calls.append((eng, par, rb, dmod.ShardComm.from_process_group(eng)))
+        engs = [bpp.Engine(local_rank) for _ in range(S)]
+        pars = [params2.share(e) for e in engs]
+        rbs = []
+        for sl in range(S):
+            # ranks were seeded differently: any n_local of this rank's proofs are a shard
+            first = (w * S + sl) * G
+            idx = np.concatenate([np.arange(((first + i) % nb) * n_local, ((first + i) % nb + 1) * n_local) for i in range(G)])
+            rbs.append(packed.ResidentBatch(pars[sl], data2["proofs"][idx], data2["commitments"][idx], data2["min_values"][idx],
+                                            data2["min_present"][idx], None, LABEL))
+            rbs[-1].prepare(n_local if G > 1 else 0)
+        calls.append((engs, pars, rbs, dmod.ShardComm.from_process_group(engs[0])))
     errors = []
 
     def worker(w, rounds):
         try:
-            _, _, rb, comm = calls[w]
+            _, _, rbs, comm = calls[w]
             for _ in range(rounds):
-                res = comm.verify_groups(rb, G, counts)
+                res = [r for part in comm.verify_groups_wave(rbs, G, counts) for r in part]
                 if any(r["code"] != 0 for r in res):
                     raise RuntimeError("sharded batch failed: %r" % ([r for r in res if r["code"] != 0][:2],))
         except BaseException as e:  # noqa: BLE001 - NOTE: the other ranks' collectives of this call are stranded; the run is lost
@@ -499,19 +505,23 @@ def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, para
     tt = torch.tensor([wel], dtype=torch.float64, device=device)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     wel = float(tt.item())
-    batches = W * G * rounds
+    batches = W * S * G * rounds
     wave_ms = calls[0][3].last_timing()
-    for eng, par, rb, comm in calls:
+    for engs, pars, rbs, comm in calls:
         comm.close()
-        rb.close()
-        par.close()
-        eng.close()
+        for rb in rbs:
+            rb.close()
+        for par in pars:
+            par.close()
+        for eng in engs:
+            eng.close()
     return {"workload": "BASELINE configs[3]: 4096 non-aggregated 64-bit proofs as ONE reference batch, %d per rank, through "
-                        "bpp_verify_sharded_groups: RCCL all_gather of 32 B/proof transcript-RNG bytes (device buffers), weight chain "
-                        "replayed on every rank, RCCL all_gather of the 128-byte accumulators, sum + identity test on the device; "
-                        "%d calls in flight per rank, each over %d batches resident as one" % (n_local, W, G),
+                        "bpp_verify_sharded_groups_wave: RCCL all_gather of 32 B/proof transcript-RNG bytes (device buffers), weight "
+                        "chains replayed (shared out over the ranks and gathered when there are several), RCCL all_gather of the "
+                        "128-byte accumulators, sum + identity test on the device; %d calls in flight per rank, each a pipeline of %d "
+                        "times %d batches resident as one" % (n_local, W, S, G),
             "rccl_ranks": world, "proofs_per_s": 4096 * batches / wel, "ms_per_batch": 1e3 * wel / batches,
-            "batches": batches, "in_flight": W * G, "waves": W, "batches_per_wave": G,
+            "batches": batches, "in_flight": W * S * G, "waves": W, "slots_per_call": S, "batches_per_wave": G,
             "last_wave_host_ms": {k: round(v, 3) for k, v in wave_ms.items()}}
 
 

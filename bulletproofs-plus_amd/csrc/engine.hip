@@ -1353,6 +1353,11 @@ class HostPool {
     return *p;
   }
   uint32_t size() const { return (uint32_t)workers_.size() + 1; }
+  // calls that have work queued on the pool right now (a hint for the chain scheduler, nothing is promised)
+  uint32_t busy() {
+    std::lock_guard<std::mutex> lk(mu_);
+    return (uint32_t)jobs_.size();
+  }
   // run fn(i) for i in [0, n) on the pool + the calling thread; returns when all are done
   void parallel_for(uint32_t n, const std::function<void(uint32_t)> &fn) {
     if (n == 0) return;
@@ -1441,9 +1446,14 @@ void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const u
   // One scalar chain per worker has the lowest latency when workers are plentiful; lock-step vector bundles
   // (chain_host.h) need ~5x less CPU time per chain and keep the GPU fed when several calls / ranks share few cores
   // (measured, 64 groups x 4 calls in flight: 4 host threads 14.9 M proofs/s lock-step vs 12.5 M scalar; 32 threads
-  // 15.3 M vs 15.5 M).  Used as soon as the groups outnumber half the workers.
+  // 15.3 M vs 15.5 M).  Used as soon as the groups outnumber half the workers -- unless the pool is idle and two rounds of
+  // scalar chains cover the call: a bundle of eight takes three times as long as one scalar chain, and a lone call of 16 or
+  // 32 chains (a sharded call's share of the replay) is waited for by its caller with the GPU idle (32 chains of 4096
+  // proofs on 16 workers: 3.4 ms as four bundles, 2.2 ms as scalar chains).
   static const int force = getenv("BPP_CHAIN_LOCKSTEP") ? atoi(getenv("BPP_CHAIN_LOCKSTEP")) : -1;
-  const uint32_t W = force >= 0 ? (force ? (uint32_t)simd : 1u) : ((G >= 2u * (uint32_t)simd && 2 * G > pool.size()) ? (uint32_t)simd : 1u);
+  const bool crowded = G > 2u * pool.size() || pool.busy() > 0;
+  const uint32_t W = force >= 0 ? (force ? (uint32_t)simd : 1u)
+                                : ((G >= 2u * (uint32_t)simd && 2 * G > pool.size() && crowded) ? (uint32_t)simd : 1u);
   struct Unit {
     uint32_t g0, cnt;
   };

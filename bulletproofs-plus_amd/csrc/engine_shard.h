@@ -135,7 +135,15 @@ struct bpp_comm {
   ncclComm_t comm = nullptr;
   bool own_comm = false;
   hipStream_t stream = nullptr;  // collectives and their staging copies
-  DevBuf<uint8_t> send1, recv1, send2, recv2, send3, recv3;
+  DevBuf<uint8_t> send1, recv1, send2, recv2;
+  struct GroupSlot {  // exchange buffers of one batch of bpp_verify_sharded_groups_wave's pipeline
+    DevBuf<uint8_t> send1, recv1, send2, recv2, send3, recv3;
+    DevBuf<uint32_t> d_flags;
+    PinnedBuf<uint8_t> h_tr, h_recv1, h_recv2;
+    PinnedBuf<uint32_t> h_flags;
+    std::vector<uint8_t> rng_all, weights_all;
+  };
+  std::vector<std::unique_ptr<GroupSlot>> slots;
   DevBuf<uint32_t> d_flags;
   PinnedBuf<uint8_t> h_tr, h_recv1, h_recv2;
   PinnedBuf<uint32_t> h_flags;
@@ -481,18 +489,31 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
 
 // The grouped form: this rank's shards of `n_groups` reference batches live in ONE resident batch (group g = proofs
 // [g c, (g + 1) c) with c = counts[rank]) on ONE context, so every kernel of the verifier is launched once for all of them,
-// as the chunked single-process form does (bpp_verify_resident with chunk = c), and the two exchanges carry all groups.
+// as the chunked single-process form does (bpp_verify_resident with chunk = c), and the exchanges carry all groups.
 // What a wave of k contexts pays per batch -- a dozen launches, a stream, a host thread's attention -- is paid once here;
 // it is the form for many batches with small shards (eight ranks x 512 proofs of a 4096-proof batch).
-int bpp_verify_sharded_groups(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, size_t n_groups, const uint32_t *counts,
-                              bpp_shard_result *results) {
+//
+// k such batches (each on its own context) run as a software pipeline of ONE host thread on ONE communicator:
+//   phase 1 of every slot is enqueued; then, slot by slot: first exchange (waits for that slot's PASS 1 only), weight chains
+//   (while the later slots' phase 1 and the earlier slots' phase 2 keep the GPU busy), phase 2 enqueued; then, slot by slot:
+//   findings, second exchange, verdicts.
+// The order of the collectives is the same on every rank by construction -- what several calls from several host threads
+// on several communicators cannot promise.
+int bpp_verify_sharded_groups_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t *batches, size_t k_in, size_t n_groups,
+                                   const uint32_t *counts, bpp_shard_result *results) {
   if (!comm) return BPP_ERR_BAD_HANDLE;
-  if (!ctx || !counts || !results || n_groups == 0 || n_groups > 4096) return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "bad group arguments");
-  if (ctx->device != comm->device) return comm_fail(comm, BPP_ERR_BAD_HANDLE, "context of another device");
+  if (!ctxs || !batches || !counts || !results || k_in == 0 || k_in > 16 || n_groups == 0 || n_groups > 4096)
+    return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "bad group arguments");
   if (hipSetDevice(comm->device) != hipSuccess) return BPP_ERR_NO_DEVICE;
-  const uint32_t G = (uint32_t)n_groups, world = (uint32_t)comm->world, rank = (uint32_t)comm->rank;
+  const uint32_t K = (uint32_t)k_in, G = (uint32_t)n_groups, world = (uint32_t)comm->world, rank = (uint32_t)comm->rank;
   std::lock_guard<std::mutex> comm_lock(comm->mu);
-  std::unique_lock<std::mutex> ctx_lock(ctx->mu);
+  std::vector<std::unique_lock<std::mutex>> ctx_locks;
+  for (uint32_t i = 0; i < K; i++) {
+    if (!ctxs[i] || ctxs[i]->device != comm->device) return comm_fail(comm, BPP_ERR_BAD_HANDLE, "context of another device (or null)");
+    for (uint32_t j = 0; j < i; j++)
+      if (ctxs[j] == ctxs[i]) return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "every batch of a wave needs its own context (stream)");
+    ctx_locks.emplace_back(ctxs[i]->mu);
+  }
   uint32_t maxc = 0, first_index = 0;
   uint64_t n_total = 0;
   for (uint32_t r = 0; r < world; r++) {
@@ -504,164 +525,185 @@ int bpp_verify_sharded_groups(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, size
   if (n_total == 0 || n_total > (1u << 24)) return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "Range statements or proofs length empty");
   if (c == 0) return comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "the grouped form needs a non-empty shard on every rank");
   const size_t slot = (size_t)maxc * 32, per1 = G * slot, per2 = (size_t)G * 128 + (size_t)G * BPP_SHARD_TRAILER_BYTES;
-  int fault = 0;  // engine fault on THIS rank: it still reaches both collectives, with zero payloads and an ENGINE finding
-  std::string fault_msg;
-  Batch *bp = nullptr;
+  // Weight transcripts over ALL proofs of each reference batch.  One rank replays all of them.  Several ranks share them out:
+  // rank r replays the chains of groups r, r + world, ... and a third all_gather hands every rank every group's weights
+  // (32 B per proof: 8 MB for 64 batches of 4096) -- the replay is a sequential sponge per batch on a host core, and with
+  // every rank replaying every chain it, not the GPUs, bounded the rate (64 chains: 3.4 - 4.7 ms per call on sixteen
+  // workers against 3 ms of kernels for a rank's 64 shards of 512 proofs).
+  const bool share_chains = world > 1;
+  const uint32_t n_own = share_chains ? (G > rank ? (G - rank + world - 1) / world : 0u) : G;
+  const uint32_t slots3 = cdiv(G, world);
+  const size_t per3 = (size_t)slots3 * n_total * 32;
+  std::vector<int> fault(K, 0);  // engine fault on THIS rank: it still reaches every collective, with zero payloads and an ENGINE finding
+  std::vector<std::string> fault_msg(K);
+  std::vector<Batch *> B(K, nullptr);
   auto t_mark = std::chrono::steady_clock::now();
   bpp_shard_timing &tmg = comm->timing;
   memset(&tmg, 0, sizeof(tmg));
-  tmg.batches = G;
+  tmg.batches = K * G;
   auto lap = [&](float &slot_ms) {
     const auto now = std::chrono::steady_clock::now();
     slot_ms += std::chrono::duration<float, std::milli>(now - t_mark).count();
     t_mark = now;
   };
   try {
-    comm->send1.alloc(per1);
-    comm->recv1.alloc(per1 * world);
-    comm->send2.alloc(per2);
-    comm->recv2.alloc(per2 * world);
-    comm->d_flags.alloc(G);
-    comm->h_tr.resize((size_t)G * BPP_SHARD_TRAILER_BYTES);
-    comm->h_recv1.resize(per1 * world);
-    comm->h_recv2.resize(per2 * world);
-    comm->h_flags.resize(G);
-    hipStream_t cs = comm->stream, s = ctx->stream;
-    try {
-      auto it = ctx->batches.find(batch);
-      if (it == ctx->batches.end()) throw EngineError{BPP_ERR_BAD_HANDLE, "unknown batch handle"};
-      Batch &b = *it->second;
-      if ((uint64_t)b.B != (uint64_t)G * c) throw EngineError{BPP_ERR_ENGINE, "the resident batch does not hold n_groups x counts[rank] proofs"};
-      bp = &b;
-      StageTimer tm(ctx);
-      if (!ctx->ev_rng_ready) {
-        HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_rng, hipEventDisableTiming));
-        ctx->ev_rng_ready = true;
+    while (comm->slots.size() < K) comm->slots.emplace_back(new bpp_comm::GroupSlot());
+    hipStream_t cs = comm->stream;
+    for (uint32_t i = 0; i < K; i++) {
+      bpp_comm::GroupSlot &S = *comm->slots[i];
+      S.send1.alloc(per1);
+      S.recv1.alloc(per1 * world);
+      S.send2.alloc(per2);
+      S.recv2.alloc(per2 * world);
+      S.d_flags.alloc(G);
+      S.h_tr.resize((size_t)G * BPP_SHARD_TRAILER_BYTES);
+      S.h_recv1.resize(per1 * world);
+      S.h_recv2.resize(per2 * world);
+      S.h_flags.resize(G);
+      if (share_chains) {
+        S.send3.alloc(per3);
+        S.recv3.alloc(per3 * world);
       }
-      layout_groups(ctx, b, G == 1 ? 0 : c);
-      if (b.G != G) throw EngineError{BPP_ERR_ENGINE, "group layout differs from n_groups"};
-      if (c < maxc) HIP_CHECK(hipMemsetAsync(comm->send1.p, 0, per1, s));
-      // several groups: the kernels tolerate odd shapes and run on everything (as bpp_verify_resident does with chunks), the
-      // findings are raised per group afterwards; one group: the wave form's rules (nothing runs on a deferred finding)
-      if (G == 1 && b.any_defer) {
-        HIP_CHECK(hipMemsetAsync(comm->send1.p, 0, per1, s));
-        HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
-      } else {
-        enqueue_phase1(ctx, b, tm, G == 1 && b.any_rounds_bad, comm->send1.p, (size_t)c * 32, slot);
+    }
+    // ---------------------------------------------------------------- phase 1 of every slot
+    for (uint32_t i = 0; i < K; i++) {
+      bpp_comm::GroupSlot &S = *comm->slots[i];
+      bpp_ctx *ctx = ctxs[i];
+      hipStream_t s = ctx->stream;
+      try {
+        auto it = ctx->batches.find(batches[i]);
+        if (it == ctx->batches.end()) throw EngineError{BPP_ERR_BAD_HANDLE, "unknown batch handle"};
+        Batch &b = *it->second;
+        if ((uint64_t)b.B != (uint64_t)G * c) throw EngineError{BPP_ERR_ENGINE, "the resident batch does not hold n_groups x counts[rank] proofs"};
+        B[i] = &b;
+        StageTimer tm(ctx);
+        if (!ctx->ev_rng_ready) {
+          HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_rng, hipEventDisableTiming));
+          ctx->ev_rng_ready = true;
+        }
+        layout_groups(ctx, b, G == 1 ? 0 : c);
+        if (b.G != G) throw EngineError{BPP_ERR_ENGINE, "group layout differs from n_groups"};
+        if (c < maxc) HIP_CHECK(hipMemsetAsync(S.send1.p, 0, per1, s));
+        // several groups: the kernels tolerate odd shapes and run on everything (as bpp_verify_resident does with chunks), the
+        // findings are raised per group afterwards; one group: the wave form's rules (nothing runs on a deferred finding)
+        if (G == 1 && b.any_defer) {
+          HIP_CHECK(hipMemsetAsync(S.send1.p, 0, per1, s));
+          HIP_CHECK(hipEventRecord(ctx->ev_rng, s));
+        } else {
+          enqueue_phase1(ctx, b, tm, G == 1 && b.any_rounds_bad, S.send1.p, (size_t)c * 32, slot);
+        }
+        HIP_CHECK(hipStreamWaitEvent(cs, ctx->ev_rng, 0));
+      } catch (const EngineError &e) {
+        fault[i] = e.code;
+        fault_msg[i] = e.msg;
+        (void)hipMemsetAsync(S.send1.p, 0, per1, cs);
       }
-      HIP_CHECK(hipStreamWaitEvent(cs, ctx->ev_rng, 0));
-    } catch (const EngineError &e) {
-      fault = e.code;
-      fault_msg = e.msg;
-      (void)hipMemsetAsync(comm->send1.p, 0, per1, cs);
     }
     lap(tmg.enqueue1_ms);
-    comm_allgather(comm, comm->send1.p, comm->recv1.p, per1, cs);
-    HIP_CHECK(hipMemcpyAsync(comm->h_recv1.data(), comm->recv1.p, per1 * world, hipMemcpyDeviceToHost, cs));
-    HIP_CHECK(hipStreamSynchronize(cs));
-    lap(tmg.gather1_ms);
-    // Weight transcripts over ALL proofs of each reference batch.  One rank replays all of them.  Several ranks share them out:
-    // rank r replays the chains of groups r, r + world, ... and a third all_gather hands every rank every group's weights
-    // (32 B per proof: 8 MB for 64 batches of 4096) -- the replay is a sequential sponge per batch on a host core, and with
-    // every rank replaying every chain it, not the GPUs, bounded the rate (64 chains: 3.4 - 4.7 ms per call on sixteen
-    // workers against 3 ms of kernels for a rank's 64 shards of 512 proofs).
-    const bool share_chains = world > 1;
-    const uint32_t n_own = share_chains ? (G > rank ? (G - rank + world - 1) / world : 0u) : G;
-    const uint32_t slots3 = cdiv(G, world);
-    const size_t per3 = (size_t)slots3 * n_total * 32;
-    comm->rng_all.resize((size_t)std::max(n_own, 1u) * n_total * 32);
-    comm->weights_all.resize((size_t)std::max(n_own, 1u) * n_total * 32);
-    {
-      std::vector<uint32_t> gfirst(n_own + 1);
-      for (uint32_t j = 0; j < n_own; j++) {
-        const uint32_t g = share_chains ? rank + j * world : j;
-        gfirst[j] = (uint32_t)(j * n_total);
-        uint8_t *dst = comm->rng_all.data() + (size_t)j * n_total * 32;
-        for (uint32_t r = 0; r < world; r++) {
-          memcpy(dst, comm->h_recv1.data() + (size_t)r * per1 + (size_t)g * slot, (size_t)counts[r] * 32);
-          dst += (size_t)counts[r] * 32;
-        }
-      }
-      gfirst[n_own] = (uint32_t)(n_own * n_total);
-      if (n_own) run_weight_chains_generic(comm->rng_all.data(), comm->weights_all.data(), gfirst.data(), n_own);
-    }
-    lap(tmg.chains_ms);
-    if (share_chains) {
-      comm->send3.alloc(per3);
-      comm->recv3.alloc(per3 * world);
-      if (n_own < slots3) HIP_CHECK(hipMemsetAsync(comm->send3.p, 0, per3, cs));
-      if (n_own) HIP_CHECK(hipMemcpyAsync(comm->send3.p, comm->weights_all.data(), (size_t)n_own * n_total * 32, hipMemcpyHostToDevice, cs));
-      comm_allgather(comm, comm->send3.p, comm->recv3.p, per3, cs);
+    // ---------------------------------------------------------------- per slot: first exchange, chains, phase 2
+    for (uint32_t i = 0; i < K; i++) {
+      bpp_comm::GroupSlot &S = *comm->slots[i];
+      bpp_ctx *ctx = ctxs[i];
+      hipStream_t s = ctx->stream;
+      comm_allgather(comm, S.send1.p, S.recv1.p, per1, cs);
+      HIP_CHECK(hipMemcpyAsync(S.h_recv1.data(), S.recv1.p, per1 * world, hipMemcpyDeviceToHost, cs));
       HIP_CHECK(hipStreamSynchronize(cs));
-      lap(tmg.gather1_ms);  // (counted with the first exchange: the timing struct is part of the ABI)
-    }
-    bool ran2 = false;
-    if (!fault) {
-      Batch &b = *bp;
-      try {
-        StageTimer tm(ctx);
-        if (G == 1 && (b.any_defer || b.any_rounds_bad)) {
-          HIP_CHECK(hipMemsetAsync(comm->send2.p, 0, 128, s));
-          if (b.any_defer) HIP_CHECK(hipMemsetAsync(b.status.p, 0, (size_t)b.B * 4, s));
-        } else {
-          if (!share_chains) {
-            for (uint32_t g = 0; g < G; g++)
-              memcpy(b.h_weights.data() + (size_t)g * c * 32, comm->weights_all.data() + ((size_t)g * n_total + first_index) * 32, (size_t)c * 32);
-            enqueue_phase2(ctx, b, tm);
-          } else {
-            // this rank's slice of every group's weights, device -> device: the groups replayed by rank o sit n_total * 32 bytes
-            // apart in o's part of recv3 and `world` groups apart in the batch
-            for (uint32_t o = 0; o < world && o < G; o++)
-              HIP_CHECK(hipMemcpy2DAsync(b.weights.p + (size_t)o * c * 32, (size_t)world * c * 32,
-                                         comm->recv3.p + (size_t)o * per3 + (size_t)first_index * 32, (size_t)n_total * 32, (size_t)c * 32,
-                                         (G - o + world - 1) / world, hipMemcpyDeviceToDevice, s));
-            enqueue_phase2(ctx, b, tm, true);
+      lap(tmg.gather1_ms);
+      S.rng_all.resize((size_t)std::max(n_own, 1u) * n_total * 32);
+      S.weights_all.resize((size_t)std::max(n_own, 1u) * n_total * 32);
+      {
+        std::vector<uint32_t> gfirst(n_own + 1);
+        for (uint32_t j = 0; j < n_own; j++) {
+          const uint32_t g = share_chains ? rank + j * world : j;
+          gfirst[j] = (uint32_t)(j * n_total);
+          uint8_t *dst = S.rng_all.data() + (size_t)j * n_total * 32;
+          for (uint32_t r = 0; r < world; r++) {
+            memcpy(dst, S.h_recv1.data() + (size_t)r * per1 + (size_t)g * slot, (size_t)counts[r] * 32);
+            dst += (size_t)counts[r] * 32;
           }
-          hipLaunchKernelGGL(k_ge_to_bytes, dim3(cdiv(G, 64)), dim3(64), 0, s, b.msm.R.p, G, comm->send2.p);
-          HIP_CHECK(hipGetLastError());
-          b.have_trace = true;
-          ran2 = true;
         }
-        fetch_status(ctx, b);
-      } catch (const EngineError &e) {
-        fault = e.code;
-        fault_msg = e.msg;
+        gfirst[n_own] = (uint32_t)(n_own * n_total);
+        if (n_own) run_weight_chains_generic(S.rng_all.data(), S.weights_all.data(), gfirst.data(), n_own);
       }
-    }
-    (void)ran2;
-    lap(tmg.enqueue2_ms);
-    if (!fault && hipStreamSynchronize(s) != hipSuccess) {
-      fault = BPP_ERR_ENGINE;
-      fault_msg = "a kernel of this rank failed on the device";
-    }
-    if (fault) (void)hipMemsetAsync(comm->send2.p, 0, (size_t)G * 128, cs);
-    for (uint32_t g = 0; g < G; g++) {
-      uint8_t *tr = comm->h_tr.data() + (size_t)g * BPP_SHARD_TRAILER_BYTES;
-      if (fault) {
-        shard_trailer_encode(tr, BPP_TIER_ENGINE, fault, first_index, fault_msg.c_str());
-      } else {
-        Batch &b = *bp;
-        const size_t o = (size_t)g * c;
-        shard_local_trailer(b.any_defer ? b.defer.data() + o : nullptr, b.h_status.data() + o, b.rounds_bad.data() + o, c, first_index, tr);
+      lap(tmg.chains_ms);
+      if (share_chains) {
+        if (n_own < slots3) HIP_CHECK(hipMemsetAsync(S.send3.p, 0, per3, cs));
+        if (n_own) HIP_CHECK(hipMemcpyAsync(S.send3.p, S.weights_all.data(), (size_t)n_own * n_total * 32, hipMemcpyHostToDevice, cs));
+        comm_allgather(comm, S.send3.p, S.recv3.p, per3, cs);
+        HIP_CHECK(hipStreamSynchronize(cs));
+        lap(tmg.gather1_ms);  // (counted with the first exchange: the timing struct is part of the ABI)
       }
+      if (!fault[i]) {
+        Batch &b = *B[i];
+        try {
+          StageTimer tm(ctx);
+          if (G == 1 && (b.any_defer || b.any_rounds_bad)) {
+            HIP_CHECK(hipMemsetAsync(S.send2.p, 0, 128, s));
+            if (b.any_defer) HIP_CHECK(hipMemsetAsync(b.status.p, 0, (size_t)b.B * 4, s));
+          } else {
+            if (!share_chains) {
+              for (uint32_t g = 0; g < G; g++)
+                memcpy(b.h_weights.data() + (size_t)g * c * 32, S.weights_all.data() + ((size_t)g * n_total + first_index) * 32, (size_t)c * 32);
+              enqueue_phase2(ctx, b, tm);
+            } else {
+              // this rank's slice of every group's weights, device -> device: the groups replayed by rank o sit n_total * 32
+              // bytes apart in o's part of recv3 and `world` groups apart in the batch
+              for (uint32_t o = 0; o < world && o < G; o++)
+                HIP_CHECK(hipMemcpy2DAsync(b.weights.p + (size_t)o * c * 32, (size_t)world * c * 32,
+                                           S.recv3.p + (size_t)o * per3 + (size_t)first_index * 32, (size_t)n_total * 32, (size_t)c * 32,
+                                           (G - o + world - 1) / world, hipMemcpyDeviceToDevice, s));
+              enqueue_phase2(ctx, b, tm, true);
+            }
+            hipLaunchKernelGGL(k_ge_to_bytes, dim3(cdiv(G, 64)), dim3(64), 0, s, b.msm.R.p, G, S.send2.p);
+            HIP_CHECK(hipGetLastError());
+            b.have_trace = true;
+          }
+          fetch_status(ctx, b);
+        } catch (const EngineError &e) {
+          fault[i] = e.code;
+          fault_msg[i] = e.msg;
+        }
+      }
+      lap(tmg.enqueue2_ms);
     }
-    lap(tmg.wait2_ms);
-    HIP_CHECK(hipMemcpyAsync(comm->send2.p + (size_t)G * 128, comm->h_tr.data(), (size_t)G * BPP_SHARD_TRAILER_BYTES, hipMemcpyHostToDevice, cs));
-    comm_allgather(comm, comm->send2.p, comm->recv2.p, per2, cs);
-    hipLaunchKernelGGL(k_sum_accumulators_wave, dim3(cdiv(G, 64)), dim3(64), 0, cs, comm->recv2.p, world, (uint32_t)per2, G, comm->d_flags.p);
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(comm->h_flags.data(), comm->d_flags.p, (size_t)G * 4, hipMemcpyDeviceToHost, cs));
-    HIP_CHECK(hipMemcpyAsync(comm->h_recv2.data(), comm->recv2.p, per2 * world, hipMemcpyDeviceToHost, cs));
-    HIP_CHECK(hipStreamSynchronize(cs));
-    lap(tmg.gather2_ms);
-    for (uint32_t g = 0; g < G; g++) {
-      const ShardFinding f = shard_resolve(comm->h_recv2.data() + (size_t)G * 128 + (size_t)g * BPP_SHARD_TRAILER_BYTES, per2, (int)world);
-      if (f.tier != BPP_TIER_NONE)
-        shard_result_set(results[g], f.code > 0 || f.code < 0 ? f.code : BPP_ERR_ENGINE, f.tier, f.rank, f.index, f.msg + " (rank " + std::to_string(f.rank) + ")");
-      else if (!comm->h_flags[g])
-        shard_result_set(results[g], BPP_ERR_VERIFICATION_FAILED, BPP_TIER_MSM, -1, 0, "Range proof batch not valid");
-      else
-        shard_result_set(results[g], BPP_OK, BPP_TIER_NONE, -1, 0, "");
+    // ---------------------------------------------------------------- per slot: findings, second exchange, verdicts
+    for (uint32_t i = 0; i < K; i++) {
+      bpp_comm::GroupSlot &S = *comm->slots[i];
+      bpp_ctx *ctx = ctxs[i];
+      if (!fault[i] && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        fault[i] = BPP_ERR_ENGINE;
+        fault_msg[i] = "a kernel of this rank failed on the device";
+      }
+      if (fault[i]) (void)hipMemsetAsync(S.send2.p, 0, (size_t)G * 128, cs);
+      for (uint32_t g = 0; g < G; g++) {
+        uint8_t *tr = S.h_tr.data() + (size_t)g * BPP_SHARD_TRAILER_BYTES;
+        if (fault[i]) {
+          shard_trailer_encode(tr, BPP_TIER_ENGINE, fault[i], first_index, fault_msg[i].c_str());
+        } else {
+          Batch &b = *B[i];
+          const size_t o = (size_t)g * c;
+          shard_local_trailer(b.any_defer ? b.defer.data() + o : nullptr, b.h_status.data() + o, b.rounds_bad.data() + o, c, first_index, tr);
+        }
+      }
+      lap(tmg.wait2_ms);
+      HIP_CHECK(hipMemcpyAsync(S.send2.p + (size_t)G * 128, S.h_tr.data(), (size_t)G * BPP_SHARD_TRAILER_BYTES, hipMemcpyHostToDevice, cs));
+      comm_allgather(comm, S.send2.p, S.recv2.p, per2, cs);
+      hipLaunchKernelGGL(k_sum_accumulators_wave, dim3(cdiv(G, 64)), dim3(64), 0, cs, S.recv2.p, world, (uint32_t)per2, G, S.d_flags.p);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(S.h_flags.data(), S.d_flags.p, (size_t)G * 4, hipMemcpyDeviceToHost, cs));
+      HIP_CHECK(hipMemcpyAsync(S.h_recv2.data(), S.recv2.p, per2 * world, hipMemcpyDeviceToHost, cs));
+      HIP_CHECK(hipStreamSynchronize(cs));
+      lap(tmg.gather2_ms);
+      for (uint32_t g = 0; g < G; g++) {
+        bpp_shard_result &out = results[(size_t)i * G + g];
+        const ShardFinding f = shard_resolve(S.h_recv2.data() + (size_t)G * 128 + (size_t)g * BPP_SHARD_TRAILER_BYTES, per2, (int)world);
+        if (f.tier != BPP_TIER_NONE)
+          shard_result_set(out, f.code > 0 || f.code < 0 ? f.code : BPP_ERR_ENGINE, f.tier, f.rank, f.index, f.msg + " (rank " + std::to_string(f.rank) + ")");
+        else if (!S.h_flags[g])
+          shard_result_set(out, BPP_ERR_VERIFICATION_FAILED, BPP_TIER_MSM, -1, 0, "Range proof batch not valid");
+        else
+          shard_result_set(out, BPP_OK, BPP_TIER_NONE, -1, 0, "");
+      }
     }
     return BPP_OK;
   } catch (const CommError &e) {
@@ -671,6 +713,13 @@ int bpp_verify_sharded_groups(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, size
   } catch (const std::exception &e) {
     return comm_fail(comm, BPP_ERR_ENGINE, e.what());
   }
+}
+
+int bpp_verify_sharded_groups(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, size_t n_groups, const uint32_t *counts,
+                              bpp_shard_result *results) {
+  if (!ctx) return comm ? comm_fail(comm, BPP_ERR_INVALID_ARGUMENT, "bad group arguments") : BPP_ERR_BAD_HANDLE;
+  bpp_ctx *ctxs[1] = {ctx};
+  return bpp_verify_sharded_groups_wave(comm, ctxs, &batch, 1, n_groups, counts, results);
 }
 
 int bpp_verify_sharded(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, const uint32_t *counts, int *tier_out, int *rank_out,

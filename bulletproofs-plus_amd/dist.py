@@ -86,6 +86,20 @@ class ShardComm:
             raise api.EngineError("bpp_verify_sharded_groups failed (%d): %s" % (rc, self._err()))
         return [{"code": r.code, "tier": r.tier, "rank": r.rank, "index": r.index, "msg": r.msg.decode(errors="replace")} for r in out]
 
+    def verify_groups_wave(self, rbs, n_groups, counts):
+        """bpp_verify_sharded_groups_wave: k grouped resident batches (each on its OWN engine) as a software pipeline of this
+        one thread -> list (k) of lists (n_groups) of result dicts"""
+        k = len(rbs)
+        ctxs = (c_void_p * k)(*[rb.engine.ctx for rb in rbs])
+        hs = (c_uint64 * k)(*[rb.handle.value for rb in rbs])
+        cn = (c_uint32 * self.world)(*counts)
+        out = (_lib.ShardResult * (k * n_groups))()
+        rc = self.lib.bpp_verify_sharded_groups_wave(self.handle, ctxs, hs, k, n_groups, cn, out)
+        if rc != 0:
+            raise api.EngineError("bpp_verify_sharded_groups_wave failed (%d): %s" % (rc, self._err()))
+        res = [{"code": r.code, "tier": r.tier, "rank": r.rank, "index": r.index, "msg": r.msg.decode(errors="replace")} for r in out]
+        return [res[i * n_groups:(i + 1) * n_groups] for i in range(k)]
+
     def last_timing(self):
         """host wall-clock split of the last wave (ms)"""
         t = _lib.ShardTiming()

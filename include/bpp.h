@@ -273,6 +273,13 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
  * every chain.  src/range_proof.rs:712-752 (one reference batch per group), :811-853 (its weight chain over all ranks' proofs). */
 int bpp_verify_sharded_groups(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, size_t n_groups, const uint32_t *counts,
                               bpp_shard_result *results /* n_groups */);
+/* k grouped batches (batch i resident on ctxs[i], every one holding n_groups x counts[rank] proofs) as a software pipeline of
+ * ONE host thread on ONE communicator: phase 1 of all k is enqueued; then, batch by batch, the first exchange, the weight
+ * chains and the enqueueing of phase 2 (while the other batches' kernels keep the GPU busy); then, batch by batch, the findings
+ * and the second exchange.  Every rank issues its collectives in the same order by construction, which calls from several
+ * host threads on several communicators cannot promise.  results: k x n_groups, batch-major. */
+int bpp_verify_sharded_groups_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t *batches, size_t k, size_t n_groups,
+                                   const uint32_t *counts, bpp_shard_result *results /* k x n_groups */);
 /* host wall-clock split of the last wave on `comm` (ms): enqueueing phase 1 on the k streams, the first exchange (waits for
  * PASS 1 only: all_gather, RNG bytes down), the k weight chains, enqueueing phase 2, waiting for the k streams, the second
  * exchange with the sum and identity test (wait1_ms is always 0 since the first exchange no longer waits for all of phase 1) */

@@ -200,6 +200,8 @@ extern "C" {
                                    results: *mut bpp_shard_result) -> c_int;
     pub fn bpp_verify_sharded_groups(comm: *mut bpp_comm, ctx: *mut bpp_ctx, batch: u64, n_groups: usize, counts: *const u32,
                                      results: *mut bpp_shard_result) -> c_int;
+    pub fn bpp_verify_sharded_groups_wave(comm: *mut bpp_comm, ctxs: *const *mut bpp_ctx, batches: *const u64, k: usize, n_groups: usize,
+                                          counts: *const u32, results: *mut bpp_shard_result) -> c_int;
     pub fn bpp_shard_local_trailer(defer: *const u8, status: *const u32, rounds_bad: *const u8, n: u32, first_index: u32,
                                    trailer_out: *mut u8) -> c_int;
     pub fn bpp_shard_trailer(tier: c_int, code: c_int, index: u32, msg: *const c_char, trailer_out: *mut u8) -> c_int;

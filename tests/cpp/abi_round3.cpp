@@ -3,7 +3,8 @@
 //   bpp_verify_batch_packed == bpp_verify_batch on the same proofs, bpp_verify_submit_packed / bpp_verify_collect with three
 //   tickets collected out of order, bpp_batch_secret_bytes, bpp_ctx_set_option, and the sharded entries over the in-process
 //   communicator (bpp_comm_create_local, one rank): bpp_verify_sharded, bpp_verify_sharded_wave (two contexts),
-//   bpp_verify_sharded_groups (four groups, one tampered) with their bpp_shard_result records.
+//   bpp_verify_sharded_groups (four groups, one tampered), bpp_verify_sharded_groups_wave (two slots) with their
+//   bpp_shard_result records.
 // Proofs come from the engine's own prover through the C++ mirror (include/bpp.hpp).  Built and run by
 // tests/test_gpu_cpp_mirror.py on the GPU box.
 #include <cstdio>
@@ -188,6 +189,11 @@ int main() {
     CHECK(wres[0].code == BPP_OK && wres[1].code == BPP_ERR_VERIFICATION_FAILED && wres[1].tier == BPP_TIER_MSM);
     bpp_shard_timing tm;
     CHECK(bpp_comm_last_timing(comm, &tm) == BPP_OK && tm.batches == 2);
+    // the same two batches as two slots of one pipelined grouped call, two groups of 50 each
+    bpp_shard_result gres[4];
+    CHECK(bpp_verify_sharded_groups_wave(comm, ctxs, hs, 2, 2, c50, gres) == BPP_OK);
+    CHECK(gres[0].code == BPP_OK && gres[1].code == BPP_OK);                                       // slot 0: clean
+    CHECK(gres[2].code == BPP_OK && gres[3].code == BPP_ERR_VERIFICATION_FAILED && gres[3].tier == BPP_TIER_MSM);  // slot 1: proof 77
     CHECK(bpp_batch_destroy(ctx, h1) == BPP_OK && bpp_batch_destroy(eng2.ctx(), h2) == BPP_OK);
     bpp_comm_destroy(comm);
   }

@@ -465,6 +465,36 @@ def test_sharded_groups_with_three_ranks_in_process(bpp, packed, engine):
     pr[n * 5 + 31, 1 + 32 + 96] ^= 1                 # group 5 fails in its sum
     assert run(pr) == [ok, ok, ok, ok, (int(K.InvalidArgument), 2, 2, 40), (int(K.VerificationFailed), 7, -1, 0), ok]
     assert run(d["proofs"]) == [ok] * G
+    want_bad = [ok, ok, ok, ok, (int(K.InvalidArgument), 2, 2, 40), (int(K.VerificationFailed), 7, -1, 0), ok]
+    # the pipelined form: every rank runs the tampered and the clean input as two slots of ONE call (two contexts, one host
+    # thread, one communicator): the same per-group outcomes, in slot order
+    engs_b = [bpp.Engine(0) for _ in range(world)]
+    pars_b = [params.share(e) for e in engs_b]
+    out2 = [None] * world
+
+    def rank_wave(r):
+        idx = np.concatenate([np.arange(n * g + first[r], n * g + first[r] + counts[r]) for g in range(G)])
+        rbs = [packed.ResidentBatch(pp, arr[idx], d["commitments"][idx], d["min_values"][idx], d["min_present"][idx], None, LABEL)
+               for pp, arr in ((pars[r], pr), (pars_b[r], d["proofs"]))]
+        try:
+            res = comms[r].verify_groups_wave(rbs, G, counts)
+            out2[r] = [[(x["code"], x["tier"], x["rank"], x["index"]) for x in part] for part in res]
+        except BaseException as e:  # noqa: BLE001
+            out2[r] = ("exception", repr(e))
+        finally:
+            for rb in rbs:
+                rb.close()
+    ths = [threading.Thread(target=rank_wave, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ths), "a rank is stuck in a collective"
+    assert out2[0] == out2[1] == out2[2] == [want_bad, [ok] * G], out2
+    for p in pars_b:
+        p.close()
+    for e in engs_b:
+        e.close()
     # one rank, one group: the grouped entry is bpp_verify_sharded
     c1 = dmod.ShardComm(engine, 0, 1, local_group=4344)
     sl = slice(0, 200)

@@ -14,8 +14,8 @@ echo "full bench done"
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline --no-traffic > $O/${TAG}_bench_steps20.json 2>> $O/${TAG}_bench.err
 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/${TAG}_bench_torchrun1.json 2>> $O/${TAG}_bench.err
 echo "bench lines done"
-timeout -k 10 300 python3 tools/wave_probe.py "1x1,1x16,3x12,1g16,1g64,2g32,3g32" 20 4096 2>> $O/${TAG}_bench.err | grep "^{" > $O/${TAG}_wave_probe.jsonl
-timeout -k 10 300 python3 tools/wave_probe.py "1x16,1g16,1g64,3g32" 20 512 2>> $O/${TAG}_bench.err | grep "^{" >> $O/${TAG}_wave_probe.jsonl
+timeout -k 10 300 python3 tools/wave_probe.py "1x1,1x16,3x12,1g16,1g64,3g32,1p2g64" 20 4096 2>> $O/${TAG}_bench.err | grep "^{" > $O/${TAG}_wave_probe.jsonl
+timeout -k 10 300 python3 tools/wave_probe.py "1x16,1g16,1g64,3g32,1p2g64" 20 512 2>> $O/${TAG}_bench.err | grep "^{" >> $O/${TAG}_wave_probe.jsonl
 timeout -k 10 300 python3 tools/bench_latency.py > $O/${TAG}_bench_latency.jsonl 2>> $O/${TAG}_bench.err
 BPP_MSM_SPLIT=0 timeout -k 10 300 python3 tools/bench_latency.py --no-cpu > $O/${TAG}_bench_latency_nosplit.jsonl 2>> $O/${TAG}_bench.err
 echo "final_round $TAG done"
