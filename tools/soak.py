@@ -9,7 +9,8 @@ Every call goes through one of the engine's entry paths, picked at random (--pat
 packed blocking form (bpp_verify_batch_packed), the pipelined form (bpp_verify_submit_packed / collect, several tickets
 outstanding, collected in random order) and the sharded form over a one-rank RCCL communicator (bpp_verify_sharded: the whole
 call is one reference batch) and the grouped sharded form (bpp_verify_sharded_groups: the call cut into equal groups, each its
-own reference batch, every group's outcome compared with the oracle's).  Small calls take the half-scalar MSM plan, larger
+own reference batch, every group's outcome compared with the oracle's; half of the even splits as two slots of one pipelined
+call, bpp_verify_sharded_groups_wave).  Small calls take the half-scalar MSM plan, larger
 ones the full plan.
 
     python tools/soak.py --seconds 120 --threads 4
@@ -64,6 +65,8 @@ def main():
         params = bpp.RangeParameters.init(n_bits, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=eng)
         pipe = packed.Pipeline(params, depth=3) if "pipeline" in paths else None
         comm = dmod.ShardComm(eng, 0, 1, dmod.ShardComm.unique_id()) if ("sharded" in paths or "groups" in paths) else None
+        eng_b = bpp.Engine(0) if "groups" in paths else None  # second slot of the pipelined grouped form
+        params_b = params.share(eng_b) if eng_b else None
         cp = cport.Params(n_bits, m, t)
         pending = []  # pipeline tickets: (ticket, expected code, record)
 
@@ -131,12 +134,23 @@ def main():
                         collect(pending.pop(rng.randrange(len(pending))))
                     continue
                 elif path == "groups":
-                    rb = packed.ResidentBatch(params, *[getattr(packed_input(sub), a) for a in ("proofs", "commitments", "min_values", "min_present")],
-                                              None, label)
-                    try:
-                        res = comm.verify_groups(rb, cnt // chunk, [chunk])
-                    finally:
-                        rb.close()
+                    n_groups = cnt // chunk
+                    if n_groups % 2 == 0 and rng.random() < 0.5:  # two slots of one pipelined call (bpp_verify_sharded_groups_wave)
+                        half = n_groups // 2 * chunk
+                        rbs = [packed.ResidentBatch(pp, *[getattr(packed_input(part), a) for a in ("proofs", "commitments", "min_values", "min_present")],
+                                                    None, label) for pp, part in ((params, sub[:half]), (params_b, sub[half:]))]
+                        try:
+                            res = [r for part in comm.verify_groups_wave(rbs, n_groups // 2, [chunk]) for r in part]
+                        finally:
+                            for rb in rbs:
+                                rb.close()
+                    else:
+                        rb = packed.ResidentBatch(params, *[getattr(packed_input(sub), a) for a in ("proofs", "commitments", "min_values", "min_present")],
+                                                  None, label)
+                        try:
+                            res = comm.verify_groups(rb, n_groups, [chunk])
+                        finally:
+                            rb.close()
                     # per group the oracle's verdict on that group; the call's outcome for the record: the first failing group's
                     for gi, r in enumerate(res):
                         rc_g, _, _ = cp.verify(sub[gi * chunk:(gi + 1) * chunk], action=0)
@@ -159,6 +173,9 @@ def main():
             collect(pending.pop())
         if comm is not None:
             comm.close()
+        if params_b is not None:
+            params_b.close()
+            eng_b.close()
         params.close()
         eng.close()
         cp.close()
