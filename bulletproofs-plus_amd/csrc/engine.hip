@@ -2417,8 +2417,8 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       }
       pp.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
       // terms handed to k_fb_msm: witness check m x (1 + t); per round L and R of mn + t + 1 terms each (every generator
-      // lands in exactly one of the two); A1 and B: 3 + 2t terms together
-      pp.fb_terms = (uint64_t)B * ((uint64_t)m * (1 + t) + (uint64_t)rounds * 2 * (mn + t + 1) + 3 + 2 * t);
+      // lands in exactly one of the two); the final step's A1 (every generator once more: 2 mn + t + 1 terms) and B (t + 1)
+      pp.fb_terms = (uint64_t)B * ((uint64_t)m * (1 + t) + (uint64_t)rounds * 2 * (mn + t + 1) + 2 * mn + 2 * t + 2);
       pp.fb_launches = (uint32_t)(ev_used / 2);
       pp.fb_window_bits = P.fb_geo.wbits;
       pp.fb_windows = P.fb_geo.items;  // additions per term
