@@ -65,6 +65,51 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm_notree(const sc *__restri
   if (acc.X.v[0] == 0x7fffffffu) out[o] = acc;  // never true: keeps the loop alive
 }
 
+// ---- D: the shipped kernel's body bounded for four wavefronts per SIMD (<= 128 VGPRs)
+__global__ void __launch_bounds__(FB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_fb_msm_w4(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx, const uint32_t *__restrict__ count, uint32_t stride,
+            const fbent *__restrict__ tbl, FbGeom geo, ge *__restrict__ out) {
+  const uint32_t o = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t n = count[o];
+  __shared__ FbShared sh;
+  ge acc;
+  ge_identity(acc);
+  for (uint32_t base = 0; base < n; base += FB_CHUNK) {
+    const uint32_t cn = n - base < FB_CHUNK ? n - base : FB_CHUNK;
+    __syncthreads();
+    for (uint32_t i = tid; i < cn; i += nthr) {
+      const sc s = scal[(size_t)o * stride + base + i];
+      fb_recode(sh.st.dig + (size_t)i * geo.items, s, geo);
+      sh.st.gi[i] = gidx[(size_t)o * stride + base + i];
+    }
+    __syncthreads();
+    const uint32_t items = cn * geo.items;
+    uint32_t it = tid;
+    niels nxt;
+    int nd = 0;
+    if (it < items) fb_fetch(nxt, nd, sh.st, tbl, geo, it);
+    while (it < items) {
+      niels cur = nxt;
+      const int cd = nd;
+      it += nthr;
+      if (it < items) fb_fetch(nxt, nd, sh.st, tbl, geo, it);
+      if (cd != 0) ge_madd_swapped(acc, acc, cur, cd < 0);
+    }
+  }
+  __syncthreads();
+  sh.red[tid] = acc;
+  __syncthreads();
+  for (uint32_t off = nthr / 2; off >= 1; off >>= 1) {
+    if (tid < off) {
+      ge x = sh.red[tid], y2 = sh.red[tid + off];
+      ge_add(x, x, y2);
+      sh.red[tid] = x;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) out[o] = sh.red[0];
+}
+
 // ---- C: one wavefront per (output, slice)
 #define FBP_MAX_PER 128
 struct FbPartStage {
@@ -193,7 +238,9 @@ int main(int argc, char **argv) {
   (void)hipMemcpy(ref.data(), d_out, (size_t)outputs * sizeof(ge), hipMemcpyDeviceToHost);
   const float b = best_of([&] { hipLaunchKernelGGL(k_fb_msm_notree, dim3(outputs), dim3(256), 0, 0, d_s, d_g, d_c, stride, d_tbl, geo, d_out); });
   printf("B the same without the tree (256 lanes)  : %.3f ms  (%.1f G additions/s)\n", b, adds / b / 1e6);
-  for (uint32_t parts : {3u, 4u, 5u, 6u, 8u}) {
+  const float dd = best_of([&] { hipLaunchKernelGGL(k_fb_msm_w4, dim3(outputs), dim3(256), 0, 0, d_s, d_g, d_c, stride, d_tbl, geo, d_out); });
+  printf("D k_fb_msm bounded for 4 wavefronts per SIMD: %.3f ms  (%.1f G additions/s)\n", dd, adds / dd / 1e6);
+  for (uint32_t parts : {3u, 5u}) {
     float sum_ms = 0;
     const float c = best_of([&] {
       hipLaunchKernelGGL(k_fb_part, dim3(outputs * parts), dim3(64), 0, 0, d_s, d_g, d_c, stride, parts, d_tbl, geo, d_part);
