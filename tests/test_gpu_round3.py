@@ -513,3 +513,48 @@ def test_sharded_groups_with_three_ranks_in_process(bpp, packed, engine):
     for e in engs:
         e.close()
     params.close()
+
+
+def test_sharded_groups_equal_the_chunked_form_at_baseline_size(bpp, packed, engine):
+    """sixteen reference batches of 1024 proofs (BASELINE configs[1]'s batch) as ONE resident batch: bpp_verify_sharded_groups
+    over a one-rank RCCL communicator and the single-process chunked form (verify_only(chunk = 1024)) must agree on every
+    intermediate of every group -- weights, static and dynamic scalars, the groups' MSM results -- and on which groups fail
+    when two of them are tampered with; the same through the pipelined entry with the batch cut in two slots"""
+    dmod = importlib.import_module("bulletproofs-plus_amd.dist")
+    G, n = 16, 1024
+    params, d = _inputs(bpp, packed, engine, 1, 1, G * n, 7800)
+    K = bpp.ProofErrorKind
+    comm = dmod.ShardComm(engine, 0, 1, dmod.ShardComm.unique_id())
+    pr = d["proofs"].copy()
+    pr[5 * n + 1000, 1 + 32 + 96] ^= 1    # r1 of a proof of group 5
+    pr[11 * n + 3, 1 + 32 + 128] ^= 2     # s1 of a proof of group 11
+    for proofs, bad in ((d["proofs"], set()), (pr, {5, 11})):
+        rb = packed.ResidentBatch(params, proofs, d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+        res = comm.verify_groups(rb, G, [n])
+        assert {g for g, r in enumerate(res) if r["code"] != 0} == bad
+        assert all(r["code"] == int(K.VerificationFailed) and r["tier"] == 7 for g, r in enumerate(res) if g in bad)
+        sharded = [rb.trace(w) for w in (3, 4, 5, 6)]
+        try:
+            rb.verify_only(n)
+            assert not bad
+        except bpp.ProofError as e:
+            assert bad and e.kind == K.VerificationFailed
+        assert sharded == [rb.trace(w) for w in (3, 4, 5, 6)]
+        acc = sharded[3]
+        assert {g for g in range(G) if acc[32 * g:32 * g + 32] != bytes(32)} == bad
+        rb.close()
+        # two slots of eight groups on two contexts, one pipelined call
+        eng_b = bpp.Engine(0)
+        par_b = params.share(eng_b)
+        h = G // 2 * n
+        rbs = [packed.ResidentBatch(pp, proofs[sl], d["commitments"][sl], d["min_values"][sl], d["min_present"][sl], None, LABEL)
+               for pp, sl in ((params, slice(0, h)), (par_b, slice(h, 2 * h)))]
+        res2 = [r for part in comm.verify_groups_wave(rbs, G // 2, [n]) for r in part]
+        assert [r["code"] for r in res2] == [r["code"] for r in res]
+        assert rbs[0].trace(3) + rbs[1].trace(3) == sharded[0]
+        for x in rbs:
+            x.close()
+        par_b.close()
+        eng_b.close()
+    comm.close()
+    params.close()
