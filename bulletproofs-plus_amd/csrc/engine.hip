@@ -381,7 +381,7 @@ struct bpp_ctx {
   // ONCE, when the context is created (no getenv on any verification path: a host that calls setenv from another thread
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
-    int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_quad = -1, msm_final_quad = -1,
+    int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_quad = -1, msm_final_quad = -1,
         fb_threads = -1, prove_subs = -1, msm_split = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
@@ -410,6 +410,7 @@ const OptionName kOptions[] = {
     {"tables_wave", "BPP_TABLES_WAVE", &bpp_ctx::Options::tables_wave},
     {"side_decompress", "BPP_SIDE_DECOMPRESS", &bpp_ctx::Options::side_decompress},
     {"msm_c_bias", "BPP_MSM_C_BIAS", &bpp_ctx::Options::msm_c_bias},
+    {"msm_c_max", "BPP_MSM_C_MAX", &bpp_ctx::Options::msm_c_max},
     {"msm_quad", "BPP_MSM_QUAD", &bpp_ctx::Options::msm_quad},
     {"msm_final_quad", "BPP_MSM_FINAL_QUAD", &bpp_ctx::Options::msm_final_quad},
     {"fb_threads", "BPP_FB_THREADS", &bpp_ctx::Options::fb_threads},
@@ -470,6 +471,11 @@ uint32_t choose_window(const bpp_ctx *ctx, uint32_t group_terms, uint32_t all_te
   // buckets per window ~ terms / 12  (bucket lists of ~12 points keep the per-lane chains short)
   uint32_t c = 4;
   while (c < 14 && (1u << c) * 12u <= group_terms) c++;  // nb = 2^(c-1)
+  // Above 11 bits the buckets of a window no longer fit the row / column reduction (2.1 additions per bucket, k_msm_window_rc)
+  // and go through the bit-plane one (c / 2 per bucket): 13 bits for a 4096-proof batch (61 k terms) is 20 x 61 k + 20 x 4096
+  // x 6.5 = 1.76 M additions, 11 bits 23 x 61 k + 23 x 1024 x 2.1 = 1.47 M.  The wider windows only pay from ~200 k terms on.
+  const uint32_t c_max = ctx->opt.msm_c_max >= 0 ? (uint32_t)ctx->opt.msm_c_max : (group_terms < 200000u ? 11u : 14u);
+  if (c > c_max && c_max >= 4) c = c_max;
   // A small call has the chip to itself: its time is the length of the dependency chains, not the number of additions.
   // Wider windows shorten the bucket lists (accumulation) and the Horner step (fewer windows to add) for a longer
   // row / column reduction: three more bits are worth 0.07-0.1 ms up to a few hundred proofs (one proof 0.79 -> 0.68 ms).

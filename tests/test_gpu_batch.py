@@ -343,17 +343,21 @@ def test_concurrent_contexts(bpp):
     assert results[3] == [("ok", True)] * 4
 
 
-def test_baseline_cfg4_one_gpu(bpp, engine):
+@pytest.mark.parametrize("c_max", [-1, 12, 14])
+def test_baseline_cfg4_one_gpu(bpp, engine, opt, c_max):
     """BASELINE configs[3] is 4096 x m=1 proofs over 8 GPUs; on one GPU the same input is one reference batch of 4096
-    (chunk = 0): a 65 667-term MSM, i.e. 13-bit windows (uneven: 13 wide + 7 narrow) and the bit-plane bucket reduction
-    that only windows above 11 bits use.  Properties: accept; one flipped bit anywhere rejects; chunked at 1024 the same
-    input is four independent batches with four identity results."""
+    (chunk = 0): a 65 667-term MSM.  The engine's own rule keeps 11-bit windows below 200 000 terms per group (the row /
+    column bucket reduction); "msm_c_max" 12 and 14 bring back the plans the size alone would pick -- 12- and 13-bit windows
+    (uneven: 13 wide + 7 narrow) with the bit-plane bucket reduction that only windows above 11 bits use.  Properties, for
+    every plan: accept; one flipped bit anywhere rejects; chunked at 1024 the same input is four independent batches with four
+    identity results; and a tampered batch leaves the same (non-identity) group element whatever the plan."""
     data, items, params, sts, pub, proofs, trs = _bench_case(bpp, engine, "bench_cfg2.bin")
     A = bpp.VerifyAction
     rot = lambda xs, k: xs[k:] + xs[:k]
     pub4 = pub + rot(pub, 131) + rot(pub, 262) + rot(pub, 393)
     proofs4 = proofs + rot(proofs, 131) + rot(proofs, 262) + rot(proofs, 393)
     trs4 = [bpp.Transcript.new(data["label"]) for _ in proofs4]
+    opt("msm_c_max", c_max)
     rb = bpp.ResidentBatch(trs4, pub4, proofs4)
     assert rb.verify(A.VerifyOnly, chunk=0) == [None] * 4096
     assert rb.shape()["groups"] == 1 and rb.trace(6) == bytes(32)
@@ -361,11 +365,20 @@ def test_baseline_cfg4_one_gpu(bpp, engine):
     assert rb.shape()["groups"] == 4 and rb.trace(6) == bytes(32) * 4
     rb.close()
     raw = bytearray(proofs4[3000].to_bytes())
-    raw[200] ^= 0x04
+    raw[1 + 32 + 96] ^= 0x04  # r1: the batch fails in its sum only
     bad = list(proofs4)
     bad[3000] = bpp.RangeProof.from_bytes(bytes(raw))
-    k = _kind(bpp, lambda: bpp.RangeProof.verify_batch(trs4, pub4, bad, A.VerifyOnly, chunk=0))
-    assert k in (bpp.ProofErrorKind.VerificationFailed, bpp.ProofErrorKind.InvalidArgument)
+    rb = bpp.ResidentBatch(trs4, pub4, bad)
+    assert _kind(bpp, lambda: rb.verify(A.VerifyOnly, chunk=0)) == bpp.ProofErrorKind.VerificationFailed
+    point = rb.trace(6)
+    rb.close()
+    assert point != bytes(32)
+    _CFG4_POINTS.setdefault("p", point)
+    assert _CFG4_POINTS["p"] == point  # the same sum from the 11-, 12- and 13-bit plans
+    opt("msm_c_max", -1)
+
+
+_CFG4_POINTS = {}
 
 
 def test_bench_step_full_size_properties(bpp, engine):
