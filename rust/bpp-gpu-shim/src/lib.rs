@@ -151,6 +151,36 @@ impl Engine {
         }).collect())
     }
 
+    /// k grouped inputs as ONE pipelined call (bpp_verify_sharded_groups_wave): `inputs[i]` is uploaded to `engines[i]` (distinct
+    /// contexts of the communicator's device; `self` is not used beyond being one of them) and the k batches advance as a
+    /// software pipeline of this one thread -- one batch's weight chains and exchanges under the other batches' kernels, every
+    /// rank issuing its collectives in the same order.  Result: per input, per group, as `verify_sharded_groups`.
+    pub fn verify_sharded_groups_wave(comm: &ShardComm, engines: &[&Engine], params: &[&Params], inputs: &[PackedBatch<'_>], n_groups: usize,
+                                      counts: &[u32]) -> Result<Vec<Vec<Result<(), ShardError>>>, GpuError> {
+        let k = inputs.len();
+        assert!(k > 0 && engines.len() == k && params.len() == k);
+        let mut err = [0 as core::ffi::c_char; 256];
+        let mut batches = vec![0u64; k];
+        let ctxs: Vec<*mut ffi::bpp_ctx> = engines.iter().map(|e| e.ctx).collect();
+        let release = |upto: usize, batches: &[u64]| for i in 0..upto { unsafe { ffi::bpp_batch_destroy(ctxs[i], batches[i]) }; };
+        for i in 0..k {
+            let raw = inputs[i].raw();
+            let up = unsafe { ffi::bpp_batch_upload_packed(ctxs[i], params[i].handle, &raw, &mut batches[i], err.as_mut_ptr(), err.len()) };
+            if let Err(e) = map_rc(up, unsafe { CStr::from_ptr(err.as_ptr()) }.to_string_lossy().into_owned()) {
+                release(i, &batches);
+                return Err(e);  // rank-local: see verify_sharded
+            }
+        }
+        let mut res: Vec<ffi::bpp_shard_result> = (0..k * n_groups).map(|_| unsafe { core::mem::zeroed() }).collect();
+        let rc = unsafe { ffi::bpp_verify_sharded_groups_wave(comm.raw, ctxs.as_ptr(), batches.as_ptr(), k, n_groups, counts.as_ptr(), res.as_mut_ptr()) };
+        release(k, &batches);
+        map_rc(rc, unsafe { CStr::from_ptr(ffi::bpp_comm_last_error(comm.raw)) }.to_string_lossy().into_owned())?;
+        Ok(res.chunks(n_groups).map(|part| part.iter().map(|r| {
+            let msg = unsafe { CStr::from_ptr(r.msg.as_ptr()) }.to_string_lossy().into_owned();
+            map_rc(r.code, msg).map_err(|e| ShardError { error: e, tier: r.tier, rank: r.rank })
+        }).collect()).collect())
+    }
+
     /// `RangeProof::verify_batch`: every `chunk` consecutive items are one reference batch (256 = MAX_RANGE_PROOF_BATCH_SIZE,
     /// 0 = the whole input).  Returns per item `Some(mask blindings, t x 32 bytes)` or `None`.
     pub fn verify_batch(&self, params: &Params, items: &[VerifyItem<'_>], action: Action, chunk: usize)
