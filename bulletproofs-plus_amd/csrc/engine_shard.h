@@ -1,5 +1,7 @@
 // ONE reference batch sharded over the GPUs of a node, behind the C ABI (include/bpp.h: bpp_comm_*, bpp_verify_sharded,
-// bpp_verify_sharded_wave).  Part of engine.hip's translation unit (it drives the same phase functions as
+// bpp_verify_sharded_wave: k batches on k contexts; bpp_verify_sharded_groups(_wave): a rank's shards of many batches as one
+// resident batch -- one set of kernel launches --, k of those as a software pipeline of one host thread, the weight-chain
+// replay shared out over the ranks).  Part of engine.hip's translation unit (it drives the same phase functions as
 // bpp_verify_resident); the collectives are RCCL calls on device buffers, issued from here -- no framework in between.
 //
 // Reference coupling points (src/range_proof.rs): the batch weights come from ONE transcript over all proofs in order
