@@ -495,6 +495,28 @@ def test_sharded_groups_with_three_ranks_in_process(bpp, packed, engine):
         p.close()
     for e in engs_b:
         e.close()
+    # an engine fault on ONE rank (its resident batch does not hold n_groups x counts[rank] proofs) strands nobody: the rank
+    # still reaches every collective with empty payloads, and every rank reports the fault (tier 255, rank 1) for every group
+    out3 = [None] * world
+
+    def rank_fault(r):
+        groups_here = G - 1 if r == 1 else G
+        idx = np.concatenate([np.arange(n * g + first[r], n * g + first[r] + counts[r]) for g in range(groups_here)])
+        rb = packed.ResidentBatch(pars[r], d["proofs"][idx], d["commitments"][idx], d["min_values"][idx], d["min_present"][idx], None, LABEL)
+        try:
+            out3[r] = [(x["code"] < 0, x["tier"], x["rank"]) for x in comms[r].verify_groups(rb, G, counts)]
+        except BaseException as e:  # noqa: BLE001
+            out3[r] = ("exception", repr(e))
+        finally:
+            rb.close()
+    ths = [threading.Thread(target=rank_fault, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ths), "a rank is stuck in a collective"
+    assert out3[0] == out3[1] == out3[2] == [(True, 255, 1)] * G, out3
+    assert run(d["proofs"]) == [ok] * G  # and the communicators are still in step
     # one rank, one group: the grouped entry is bpp_verify_sharded
     c1 = dmod.ShardComm(engine, 0, 1, local_group=4344)
     sl = slice(0, 200)
