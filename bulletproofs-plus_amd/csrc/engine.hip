@@ -489,8 +489,9 @@ uint32_t choose_window(const bpp_ctx *ctx, uint32_t group_terms, uint32_t all_te
 // half-scalar plan (msm.h: k_split_shift_quad): small verifier calls, unless the one-lane kernels are forced.  It halves the
 // final Horner step (0.26 -> 0.13 ms) and doubles every bucket's list (quad accumulation: 0.034 -> 0.066 ms at 256 proofs,
 // 0.07 -> 0.18 at 1024).  Measured on non-aggregated 64-bit proofs (profiles/r03_v4_bench_latency*.jsonl): 1 proof 0.63 -> 0.47
-// ms, 64: 0.65 -> 0.52, 256: 0.67 -> 0.62, 512: 0.79 -> 0.73, 1024: 1.08 -> 1.05: it pays over the whole range of "small" calls.
-#define BPP_SPLIT_CALL_TERMS BPP_SMALL_CALL_TERMS
+// ms, 64: 0.65 -> 0.52, 256: 0.67 -> 0.62, 512: 0.79 -> 0.73.  The two plans cross at about 900 proofs (896: 0.94 / 0.96 ms with /
+// without, 1024: 1.00-1.03 / 0.98-1.00, 1280: 1.16-1.21 / 1.11-1.12; same box, alternating): up to 14 000 terms.
+#define BPP_SPLIT_CALL_TERMS 14000u
 bool msm_wants_split(const bpp_ctx *ctx, uint32_t n_terms) {
   if (ctx->opt.msm_split >= 0) return ctx->opt.msm_split != 0 && ctx->opt.msm_quad != 0;
   return n_terms <= BPP_SPLIT_CALL_TERMS && ctx->opt.msm_quad != 0;
