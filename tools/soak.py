@@ -10,8 +10,8 @@ packed blocking form (bpp_verify_batch_packed), the pipelined form (bpp_verify_s
 outstanding, collected in random order) and the sharded form over a one-rank RCCL communicator (bpp_verify_sharded: the whole
 call is one reference batch) and the grouped sharded form (bpp_verify_sharded_groups: the call cut into equal groups, each its
 own reference batch, every group's outcome compared with the oracle's; half of the even splits as two slots of one pipelined
-call, bpp_verify_sharded_groups_wave).  Small calls take the half-scalar MSM plan, larger
-ones the full plan.
+call, bpp_verify_sharded_groups_wave).  Most calls are small (half-scalar MSM plan); about one in twenty-five has 1000 or 1500 proofs (full plan with
+the latency kernels / the throughput kernels).
 
     python tools/soak.py --seconds 120 --threads 4
 prints one JSON line: calls (per path), rejected inputs, mismatches (must be 0)."""
@@ -93,11 +93,13 @@ def main():
         while time.time() < stop:
             path = rng.choice(paths)
             cnt = rng.choice([1, 2, 3, 7, 16, 64, 200, 256])
+            if rng.random() < 0.04:  # now and then a call beyond the half-scalar plan (1000 proofs) and beyond the small-call plan (1500)
+                cnt = rng.choice([1000, 1500])
             chunk = 0 if path == "sharded" else rng.choice([0, 0, 8, 64])
             if path == "groups":  # bpp_verify_sharded_groups: `cnt` proofs as equal groups, every group its own reference batch
-                groups = rng.choice([g for g in (1, 2, 4, 8, 16) if cnt % g == 0 and cnt // g >= 1])
+                groups = rng.choice([g for g in (1, 2, 4, 8, 16) if cnt % g == 0 and cnt // g >= 1] if cnt < 1000 else [1, 2, 4])
                 chunk = cnt // groups
-            sub = [dict(items[i]) for i in rng.sample(range(len(items)), cnt)]
+            sub = [dict(items[i]) for i in (rng.sample(range(len(items)), cnt) if cnt <= len(items) else rng.choices(range(len(items)), k=cnt))]
             mutated = rng.random() < 0.5
             if mutated:
                 j = rng.randrange(cnt)
