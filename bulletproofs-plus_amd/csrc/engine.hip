@@ -381,7 +381,7 @@ struct bpp_ctx {
   // ONCE, when the context is created (no getenv on any verification path: a host that calls setenv from another thread
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
-    int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_quad = -1, msm_final_quad = -1,
+    int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_quad = -1, msm_final_quad = -1,
         fb_threads = -1, prove_subs = -1, msm_split = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
@@ -411,6 +411,7 @@ const OptionName kOptions[] = {
     {"side_decompress", "BPP_SIDE_DECOMPRESS", &bpp_ctx::Options::side_decompress},
     {"msm_c_bias", "BPP_MSM_C_BIAS", &bpp_ctx::Options::msm_c_bias},
     {"msm_c_max", "BPP_MSM_C_MAX", &bpp_ctx::Options::msm_c_max},
+    {"msm_c_add", "BPP_MSM_C_ADD", &bpp_ctx::Options::msm_c_add},
     {"msm_quad", "BPP_MSM_QUAD", &bpp_ctx::Options::msm_quad},
     {"msm_final_quad", "BPP_MSM_FINAL_QUAD", &bpp_ctx::Options::msm_final_quad},
     {"fb_threads", "BPP_FB_THREADS", &bpp_ctx::Options::fb_threads},
@@ -475,6 +476,7 @@ uint32_t choose_window(const bpp_ctx *ctx, uint32_t group_terms, uint32_t all_te
   // and go through the bit-plane one (c / 2 per bucket): 13 bits for a 4096-proof batch (61 k terms) is 20 x 61 k + 20 x 4096
   // x 6.5 = 1.76 M additions, 11 bits 23 x 61 k + 23 x 1024 x 2.1 = 1.47 M.  The wider windows only pay from ~200 k terms on.
   const uint32_t c_max = ctx->opt.msm_c_max >= 0 ? (uint32_t)ctx->opt.msm_c_max : (group_terms < 200000u ? 11u : 14u);
+  if (ctx->opt.msm_c_add > 0 && all_terms > BPP_SMALL_CALL_TERMS) c += (uint32_t)ctx->opt.msm_c_add;  // (A/B timing of wider windows)
   if (c > c_max && c_max >= 4) c = c_max;
   // A small call has the chip to itself: its time is the length of the dependency chains, not the number of additions.
   // Wider windows shorten the bucket lists (accumulation) and the Horner step (fewer windows to add) for a longer
@@ -546,13 +548,23 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
   hipStream_t s = ctx->stream;
   // digits + counting sort + per-window size ordering in one launch (msm.h: k_msm_prelude), then the group-level order
   const uint32_t per_group = plan.K * plan.nb;
-  const uint32_t dig_cap = msm_prelude_dig_cap(plan, w.max_group_terms);
-  hipLaunchKernelGGL(k_msm_prelude, dim3(8 * cdiv(plan.G, 8) * plan.K), dim3(BPP_SORT_THREADS), msm_prelude_lds(plan, dig_cap), s, scalars,
-                     w.term_sidx.p, w.term_pidx.p, w.group_off.p, plan, dig_cap, w.counts.p, w.starts.p, w.sorted.p, w.order_win.p, w.cls_hist.p);
-  hipLaunchKernelGGL(k_msm_order, dim3(plan.G), dim3(BPP_SORT_THREADS), 0, s, w.counts.p, w.order_win.p, w.cls_hist.p, plan, w.order.p);
-  if (tm) tm->mark(M_ORDER);  // msm_accumulate_ms brackets k_msm_accumulate alone (the roofline kernel)
+  // many small groups of a throughput call: four-wavefront workgroups (msm.h); a small call (latency) and large groups: sixteen
   // few buckets on an idle chip (one batch per call): quad forms, ~3x shorter dependency chains (tests force either form)
   const bool small = w.split || (ctx->opt.msm_quad >= 0 ? ctx->opt.msm_quad != 0 : (size_t)plan.G * per_group <= 100000);
+  const bool narrow = !small && w.max_group_terms <= BPP_SORT_SMALL_GROUP_TERMS;
+  if (narrow) {
+    const uint32_t dig_cap = msm_prelude_dig_cap(plan, w.max_group_terms, BPP_SORT_THREADS_SMALL);
+    hipLaunchKernelGGL(k_msm_prelude<BPP_SORT_THREADS_SMALL>, dim3(8 * cdiv(plan.G, 8) * plan.K), dim3(BPP_SORT_THREADS_SMALL), msm_prelude_lds(plan, dig_cap), s,
+                       scalars, w.term_sidx.p, w.term_pidx.p, w.group_off.p, plan, dig_cap, w.counts.p, w.starts.p, w.sorted.p, w.order_win.p, w.cls_hist.p);
+    hipLaunchKernelGGL(k_msm_order<BPP_SORT_THREADS_SMALL>, dim3(plan.G), dim3(BPP_SORT_THREADS_SMALL), 0, s, w.counts.p, w.order_win.p, w.cls_hist.p, plan,
+                       w.order.p);
+  } else {
+    const uint32_t dig_cap = msm_prelude_dig_cap(plan, w.max_group_terms);
+    hipLaunchKernelGGL(k_msm_prelude<BPP_SORT_THREADS>, dim3(8 * cdiv(plan.G, 8) * plan.K), dim3(BPP_SORT_THREADS), msm_prelude_lds(plan, dig_cap), s, scalars,
+                       w.term_sidx.p, w.term_pidx.p, w.group_off.p, plan, dig_cap, w.counts.p, w.starts.p, w.sorted.p, w.order_win.p, w.cls_hist.p);
+    hipLaunchKernelGGL(k_msm_order<BPP_SORT_THREADS>, dim3(plan.G), dim3(BPP_SORT_THREADS), 0, s, w.counts.p, w.order_win.p, w.cls_hist.p, plan, w.order.p);
+  }
+  if (tm) tm->mark(M_ORDER);  // msm_accumulate_ms brackets k_msm_accumulate alone (the roofline kernel)
   if (small)
     hipLaunchKernelGGL(k_msm_accumulate_quad, dim3(cdiv(plan.G * per_group, 16)), dim3(64), 0, s, w.sorted.p, w.starts.p,
                        w.counts.p, w.order.p, tabs, plan.G * per_group, w.buckets.p);

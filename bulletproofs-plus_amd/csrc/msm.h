@@ -59,10 +59,16 @@ __device__ __forceinline__ const niels *point_ptr(const PointTables &t, uint32_t
 //           the class histogram in cls_hist[]; k_msm_order merges the K window orders into the group's
 // XCD-aware mapping (blockIdx % 8 = XCD, as in k_msm_accumulate): all windows of group g run on XCD g % 8, so the group's
 // scalars are fetched into ONE L2 once and the lists written here are in the L2 that k_msm_accumulate reads them from.
-// grid = 8 * ceil(G/8) * K workgroups of 1024.  Dynamic LDS: 2 * nb u32 + dig_cap int16.
+// grid = 8 * ceil(G/8) * K workgroups of T lanes.  Dynamic LDS: 2 * nb u32 + dig_cap int16.
+// T: 1024 lanes per (group, window); 256 when the groups are small (the reference's own 256-proof batches: 4 k terms per
+// group, 256 such groups x 29 windows per 65 536 proofs).  Sixteen-wavefront workgroups with four terms per lane mostly wait
+// for a CU with sixteen free wavefront slots: with four-wavefront ones the stage shrinks from 5.6 to 1.8 ms of a step in
+// flight and the step gains 4 % (128-proof batches 7 %, 512: 2 %; at 1024 proofs per batch the wide form is 1-2 % ahead).
 #ifndef BPP_SORT_THREADS
 #define BPP_SORT_THREADS 1024
 #endif
+#define BPP_SORT_THREADS_SMALL 256
+#define BPP_SORT_SMALL_GROUP_TERMS 9000u
 // digit of window k of the term whose term_sidx entry is `si`: the whole scalar, or -- half-scalar plan -- the half the
 // entry's top bit selects
 __device__ __forceinline__ int32_t msm_term_digit(const sc *__restrict__ scalars, uint32_t si, const MsmPlan &plan, uint32_t k) {
@@ -72,13 +78,13 @@ __device__ __forceinline__ int32_t msm_term_digit(const sc *__restrict__ scalars
   msm_half_words(h, s.v, (si & BPP_TERM_HI) != 0);
   return msm_digit_at(h, plan, k);
 }
-__global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__restrict__ scalars, const uint32_t *__restrict__ term_sidx,
-                                                      const uint32_t *__restrict__ term_pidx, const uint32_t *__restrict__ group_off,
-                                                      MsmPlan plan, uint32_t dig_cap, uint32_t *__restrict__ counts,
-                                                      uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
-                                                      uint32_t *__restrict__ order_win, uint32_t *__restrict__ cls_hist) {
+template <uint32_t T>
+__global__ void __launch_bounds__(T) k_msm_prelude(const sc *__restrict__ scalars, const uint32_t *__restrict__ term_sidx,
+                                                   const uint32_t *__restrict__ term_pidx, const uint32_t *__restrict__ group_off,
+                                                   MsmPlan plan, uint32_t dig_cap, uint32_t *__restrict__ counts,
+                                                   uint32_t *__restrict__ starts, uint32_t *__restrict__ sorted,
+                                                   uint32_t *__restrict__ order_win, uint32_t *__restrict__ cls_hist) {
   extern __shared__ uint32_t lds[];
-  constexpr uint32_t T = BPP_SORT_THREADS;
   const uint32_t tid = threadIdx.x, nb = plan.nb, K = plan.K;
   const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
   const uint32_t g = xcd + 8u * (j / K), k = j % K;
@@ -185,9 +191,9 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_prelude(const sc *__re
 // (A launch of its own on purpose.  Done by the last workgroup of k_msm_prelude to finish, it needs device-scope fences
 // between workgroups, and on this chip those write back and invalidate a whole XCD's L2 each time: every kernel in flight
 // lost its cached lines, the step went from 2.5 to 3.8 ms.)  grid = G workgroups of 1024.
-__global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_order(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ order_win,
-                                                    uint32_t *cls_hist, MsmPlan plan, uint32_t *__restrict__ order) {
-  constexpr uint32_t T = BPP_SORT_THREADS;
+template <uint32_t T>
+__global__ void __launch_bounds__(T) k_msm_order(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ order_win,
+                                                 uint32_t *cls_hist, MsmPlan plan, uint32_t *__restrict__ order) {
   const uint32_t tid = threadIdx.x, g = blockIdx.x, nb = plan.nb, K = plan.K;
   __shared__ uint32_t part[256];
   uint32_t *gh = cls_hist + (size_t)g * K * 768;
@@ -228,8 +234,8 @@ __global__ void __launch_bounds__(BPP_SORT_THREADS) k_msm_order(const uint32_t *
   }
 }
 // dynamic LDS of k_msm_prelude: the two bucket tables + as many cached digits as keep the workgroup under 64 KB
-inline uint32_t msm_prelude_dig_cap(const MsmPlan &plan, uint32_t max_group_terms) {
-  const uint32_t fixed = 2u * plan.nb * 4u + (BPP_SORT_THREADS + 3u * 256u) * 4u;
+inline uint32_t msm_prelude_dig_cap(const MsmPlan &plan, uint32_t max_group_terms, uint32_t threads = BPP_SORT_THREADS) {
+  const uint32_t fixed = 2u * plan.nb * 4u + (threads + 3u * 256u) * 4u;
   const uint32_t room = fixed + 1024u < 65536u ? (65536u - 1024u - fixed) / 2u : 0u;
   return max_group_terms < room ? max_group_terms : room;
 }
