@@ -381,7 +381,7 @@ struct bpp_ctx {
   // ONCE, when the context is created (no getenv on any verification path: a host that calls setenv from another thread
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
-    int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_quad = -1, msm_final_quad = -1,
+    int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
         fb_threads = -1, prove_subs = -1, msm_split = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
@@ -412,6 +412,7 @@ const OptionName kOptions[] = {
     {"msm_c_bias", "BPP_MSM_C_BIAS", &bpp_ctx::Options::msm_c_bias},
     {"msm_c_max", "BPP_MSM_C_MAX", &bpp_ctx::Options::msm_c_max},
     {"msm_c_add", "BPP_MSM_C_ADD", &bpp_ctx::Options::msm_c_add},
+    {"msm_rc2", "BPP_MSM_RC2", &bpp_ctx::Options::msm_rc2},
     {"msm_quad", "BPP_MSM_QUAD", &bpp_ctx::Options::msm_quad},
     {"msm_final_quad", "BPP_MSM_FINAL_QUAD", &bpp_ctx::Options::msm_final_quad},
     {"fb_threads", "BPP_FB_THREADS", &bpp_ctx::Options::fb_threads},
@@ -574,6 +575,8 @@ void msm_run(bpp_ctx *ctx, MsmWork &w, const sc *scalars, PointTables tabs, Stag
   if (tm) tm->mark(M_ACC);
   if (plan.c <= 11 && small) {
     hipLaunchKernelGGL(k_msm_window_rc_quad, dim3(plan.G * plan.K), dim3(1024), 0, s, w.buckets.p, w.counts.p, plan, w.W.p);
+  } else if (plan.nb <= 256 && ctx->opt.msm_rc2 != 0) {  // two windows per wavefront (msm.h)
+    hipLaunchKernelGGL(k_msm_window_rc2, dim3(cdiv(plan.G * plan.K, 2)), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, plan.G * plan.K, w.W.p);
   } else if (plan.c <= 11) {
     hipLaunchKernelGGL(k_msm_window_rc, dim3(plan.G * plan.K), dim3(64), 0, s, w.buckets.p, w.counts.p, plan, w.W.p);
   } else {

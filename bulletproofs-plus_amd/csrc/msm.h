@@ -364,6 +364,67 @@ __global__ void __launch_bounds__(64) k_msm_window_rc(const ge *__restrict__ buc
   }
 }
 
+// The same for windows of at most 256 buckets (A, Bc <= 16: the many small groups of a throughput call, e.g. the reference's
+// own 256-proof batches at 9-bit windows): TWO windows per wavefront, 16 lanes per row / column set instead of 32 with half of
+// them idle -- half the wavefronts and half the issued instructions of the stage (a fifth of such a step's VALU work).
+// lanes 0-15 rows of window 2 b, 16-31 rows of window 2 b + 1, 32-47 / 48-63 their columns.  grid = ceil(G K / 2) blocks of 64.
+__global__ void __launch_bounds__(64) k_msm_window_rc2(const ge *__restrict__ buckets, const uint32_t *__restrict__ counts, MsmPlan plan,
+                                                       uint32_t n_windows, ge *__restrict__ W) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t nb = plan.nb, lb = plan.c - 1;
+  const uint32_t lBc = lb / 2, Bc = 1u << lBc, A = nb >> lBc;  // Bc <= A <= 16
+  const bool is_row = lane < 32;
+  const uint32_t sub = (lane >> 4) & 1u, idx = lane & 15u;
+  const uint32_t gk = blockIdx.x * 2u + sub;
+  const bool live = gk < n_windows;
+  const size_t base = (size_t)gk * nb;
+  __shared__ ge red[64];
+  ge acc;
+  ge_identity(acc);
+  if (live && (is_row ? (idx < A) : (idx < Bc))) {
+    const uint32_t cnt = is_row ? Bc : A;
+    for (uint32_t q = 0; q < cnt; q++) {
+      const uint32_t j0 = is_row ? (Bc * idx + q) : (Bc * q + idx);  // bucket index j-1 with j = Bc*a + b, b in [1, Bc]
+      if (counts[base + j0]) {
+        const ge x = buckets[base + j0];
+        ge_add(acc, acc, x);
+      }
+    }
+  }
+  red[lane] = acc;
+  __syncthreads();
+  const uint32_t half_n = is_row ? A : Bc;
+  for (uint32_t off = 1; off < 16; off <<= 1) {  // suffix scan inside each 16-lane set
+    ge y2;
+    const bool act = idx + off < half_n;
+    if (act) y2 = red[lane + off];
+    __syncthreads();
+    if (act) {
+      ge_add(acc, acc, y2);
+      red[lane] = acc;
+    }
+    __syncthreads();
+  }
+  if (is_row ? (idx == 0 || idx >= A) : (idx >= Bc)) ge_identity(acc);
+  red[lane] = acc;
+  __syncthreads();
+  for (uint32_t off = 8; off >= 1; off >>= 1) {
+    if (idx < off) {
+      ge x = red[lane], y2 = red[lane + off];
+      ge_add(x, x, y2);
+      red[lane] = x;
+    }
+    __syncthreads();
+  }
+  if (is_row && idx == 0 && live) {
+    ge rows = red[lane];
+    const ge cols = red[lane + 32];
+    if (lBc) ge_dbl_n(rows, rows, (int)lBc);
+    ge_add(rows, rows, cols);
+    W[gk] = rows;
+  }
+}
+
 // ---- Q[g][k][b] = sum over buckets j (digit j+1) with bit b of (j+1) set.  grid = (c, K, G), block 64 ----
 __global__ void __launch_bounds__(64) k_msm_bitsum(const ge *__restrict__ buckets, const uint32_t *__restrict__ counts,
                                                    MsmPlan plan, ge *__restrict__ Q /* [G][K][c] */) {

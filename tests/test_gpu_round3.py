@@ -580,3 +580,48 @@ def test_sharded_groups_equal_the_chunked_form_at_baseline_size(bpp, packed, eng
         eng_b.close()
     comm.close()
     params.close()
+
+
+@pytest.mark.parametrize("chunk", [128, 256])
+def test_many_small_groups_through_the_throughput_kernels(bpp, packed, engine, opt, chunk):
+    """16 384 proofs cut into reference batches of 128 / 256 (the reference's own batch size): a throughput call (more than
+    100 000 buckets) whose groups are small -- 8- and 9-bit windows, the four-wavefront prelude, two windows per wavefront in
+    the bucket reduction (k_msm_window_rc2).  Against the one-window reduction (msm_rc2 = 0) and against the latency kernels
+    (msm_quad = 1) on the same resident batch: the same scalars, the same per-group results -- identity everywhere, and the
+    same non-identity element in the groups that were tampered with -- and the oracle's verdict on one clean and one bad group."""
+    from oracle import cport
+    n = 16384
+    params, d = _inputs(bpp, packed, engine, 1, 1, n, 7900)
+    K = bpp.ProofErrorKind
+    pr = d["proofs"].copy()
+    bad_groups = {3, n // chunk - 1}
+    for g in bad_groups:
+        pr[g * chunk + 17, 1 + 32 + 96] ^= 1
+    results = {}
+    for name, options in (("rc2", {}), ("rc", {"msm_rc2": 0}), ("quad", {"msm_quad": 1})):
+        for k, v in options.items():
+            opt(k, v)
+        rb = packed.ResidentBatch(params, pr, d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+        with pytest.raises(bpp.ProofError) as e:
+            rb.verify_only(chunk)
+        assert e.value.kind == K.VerificationFailed
+        results[name] = (rb.trace(4), rb.trace(5), rb.trace(6))
+        rb.close()
+        for k in options:
+            opt(k, -1)
+    assert results["rc2"] == results["rc"] == results["quad"]
+    acc = results["rc2"][2]
+    assert {g for g in range(n // chunk) if acc[32 * g:32 * g + 32] != bytes(32)} == bad_groups
+    cp = cport.Params(64, 1, 1)
+    for g, want in ((0, 0), (3, int(K.VerificationFailed))):
+        sl = range(g * chunk, (g + 1) * chunk)
+        items = [{"proof": bytes(pr[i]), "commitments": [bytes(d["commitments"][i, 0])],
+                  "min_values": [int(d["min_values"][i, 0]) if d["min_present"][i, 0] else None], "seed_nonce": None, "label": LABEL} for i in sl]
+        rc, _, _ = cp.verify(items, action=0)
+        assert rc == want
+    cp.close()
+    rb = packed.ResidentBatch(params, d["proofs"], d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+    rb.verify_only(chunk)
+    assert rb.trace(6) == bytes(32) * (n // chunk)
+    rb.close()
+    params.close()
