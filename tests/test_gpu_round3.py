@@ -582,15 +582,14 @@ def test_sharded_groups_equal_the_chunked_form_at_baseline_size(bpp, packed, eng
     params.close()
 
 
-@pytest.mark.parametrize("chunk", [128, 256])
-def test_many_small_groups_through_the_throughput_kernels(bpp, packed, engine, opt, chunk):
+@pytest.mark.parametrize("chunk,n", [(128, 16384), (256, 16384), (256, 16640)])  # the last: 65 groups x 29 windows, an odd number of windows
+def test_many_small_groups_through_the_throughput_kernels(bpp, packed, engine, opt, chunk, n):
     """16 384 proofs cut into reference batches of 128 / 256 (the reference's own batch size): a throughput call (more than
     100 000 buckets) whose groups are small -- 8- and 9-bit windows, the four-wavefront prelude, two windows per wavefront in
     the bucket reduction (k_msm_window_rc2).  Against the one-window reduction (msm_rc2 = 0) and against the latency kernels
     (msm_quad = 1) on the same resident batch: the same scalars, the same per-group results -- identity everywhere, and the
     same non-identity element in the groups that were tampered with -- and the oracle's verdict on one clean and one bad group."""
     from oracle import cport
-    n = 16384
     params, d = _inputs(bpp, packed, engine, 1, 1, n, 7900)
     K = bpp.ProofErrorKind
     pr = d["proofs"].copy()
