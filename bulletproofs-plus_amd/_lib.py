@@ -104,6 +104,11 @@ SYMBOLS = [
     ("bpp_verify_sharded_groups", c_int, [c_void_p, c_void_p, c_uint64, c_size_t, POINTER(c_uint32), POINTER(ShardResult)]),
     ("bpp_verify_sharded_groups_wave", c_int, [c_void_p, POINTER(c_void_p), POINTER(c_uint64), c_size_t, c_size_t, POINTER(c_uint32),
                                                POINTER(ShardResult)]),
+    ("bpp_verify_resident_groups", c_int, [c_void_p, c_uint64, POINTER(c_uint32), c_size_t, POINTER(ShardResult)]),
+    ("bpp_batcher_create", c_int, [c_void_p, c_uint64, c_void_p, c_uint32, c_uint32, c_uint32, POINTER(c_void_p)]),
+    ("bpp_batcher_verify", c_int, [c_void_p, c_void_p, c_char_p, c_size_t]),
+    ("bpp_batcher_stats", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
+    ("bpp_batcher_destroy", None, [c_void_p]),
     ("bpp_shard_local_trailer", c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_uint32, c_void_p]),
     ("bpp_shard_trailer", c_int, [c_int, c_int, c_uint32, c_char_p, c_void_p]),
     ("bpp_shard_resolve", c_int, [c_void_p, c_size_t, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_uint32), c_void_p,

@@ -1532,14 +1532,27 @@ void check_chunk_errors(const Batch &b, uint32_t p0, uint32_t p1) {
 }
 
 // (re)build the group layout + MSM term lists for `chunk`
-void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk) {
-  if (b.last_chunk == chunk && b.G) return;
+// `bounds` (optional): explicit group boundaries first[0..G] (0 = first[0] < ... < first[G] = B) instead of equal chunks --
+// the reference batches of different callers pooled into one call (bpp_verify_resident_groups)
+void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk, const std::vector<uint32_t> *bounds = nullptr) {
+  if (!bounds && chunk == (size_t)-1) chunk = 0;  // ((size_t)-1 marks an explicit layout in last_chunk)
+  if (bounds) {
+    if (b.last_chunk == (size_t)-1 && b.G && b.h_group_first == *bounds) return;
+  } else if (b.last_chunk == chunk && b.G) {
+    return;
+  }
   Params &P = *b.params;
-  const uint32_t cz = (chunk == 0 || chunk >= b.B) ? b.B : (uint32_t)chunk;
-  const uint32_t G = cdiv(b.B, cz);
+  uint32_t G;
+  if (bounds) {
+    G = (uint32_t)bounds->size() - 1;
+    b.h_group_first = *bounds;
+  } else {
+    const uint32_t cz = (chunk == 0 || chunk >= b.B) ? b.B : (uint32_t)chunk;
+    G = cdiv(b.B, cz);
+    b.h_group_first.resize(G + 1);
+    for (uint32_t g = 0; g <= G; g++) b.h_group_first[g] = std::min(g * cz, b.B);
+  }
   b.G = G;
-  b.h_group_first.resize(G + 1);
-  for (uint32_t g = 0; g <= G; g++) b.h_group_first[g] = std::min(g * cz, b.B);
   b.group_first.alloc(G + 1);
   b.scal.alloc((size_t)G * b.cols + b.total_dyn);
   // terms of group g: static columns (first 2*max_mn generators, then g bases, then h) + its proofs' dynamic slots.
@@ -1575,7 +1588,7 @@ void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk) {
                      b.cols, b.max_mn, n_gen, P.table_len, split ? 1u : 0u, b.msm.term_sidx.p, b.msm.term_pidx.p);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(ctx->stream));  // goff / dlo are locals
-  b.last_chunk = chunk;
+  b.last_chunk = bounds ? (size_t)-1 : chunk;
 }
 
 // Weight-dependent tail: h_weights -> device, the weighted generator rows and dynamic scalars (k_scalars_lanes), the
@@ -1722,6 +1735,59 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
     return BPP_OK;
   }
   BPP_CATCH(ctx, errbuf, errbuf_len)
+}
+
+// Reference batches of DIFFERENT sizes in one call: group g = proofs [group_first[g], group_first[g + 1]) of the resident
+// batch, every group verified as its own verify() call (VerifyOnly) by the same kernel launches, with its own outcome --
+// where bpp_verify_resident cuts equal chunks and stops at the first failing one.  What a pool of small calls needs
+// (bpp_batcher below).
+int bpp_verify_resident_groups(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first, size_t n_groups, bpp_shard_result *results) {
+  BPP_ENTRY(ctx);
+  try {
+    auto it = ctx->batches.find(batch);
+    if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle");
+    if (!group_first || !results || n_groups == 0) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument");
+    Batch &b = *it->second;
+    std::vector<uint32_t> bounds(group_first, group_first + n_groups + 1);
+    if (bounds.front() != 0 || bounds.back() != b.B) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "group boundaries must run from 0 to the batch size");
+    for (size_t g = 0; g < n_groups; g++)
+      if (bounds[g] >= bounds[g + 1]) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "empty or unordered group");
+    auto t_begin = std::chrono::steady_clock::now();
+    StageTimer tm(ctx);
+    hipStream_t s = ctx->stream;
+    layout_groups(ctx, b, 0, &bounds);
+    // the kernels tolerate odd shapes and run on every item (as bpp_verify_resident does with several chunks); findings are
+    // raised per group afterwards, in the reference's order
+    enqueue_phase1(ctx, b, tm, false);
+    b.h_ident.resize(b.G);
+    for (uint32_t g = 0; g < b.G; g++) b.h_ident[g] = 1;
+    auto c0 = std::chrono::steady_clock::now();
+    run_weight_chains(b);
+    const float chain_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c0).count();
+    enqueue_phase2(ctx, b, tm);
+    HIP_CHECK(hipMemcpyAsync(b.h_ident.data(), b.msm.is_identity.p, (size_t)b.G * 4, hipMemcpyDeviceToHost, s));
+    b.have_trace = true;
+    fetch_status(ctx, b);
+    HIP_CHECK(hipStreamSynchronize(s));
+    collect_profile(ctx, b, tm, chain_ms, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    for (uint32_t g = 0; g < b.G; g++) {
+      bpp_shard_result &r = results[g];
+      memset(&r, 0, sizeof(r));
+      r.rank = -1;
+      try {
+        if (b.any_defer) check_deferred(b.defer, b.h_group_first[g], b.h_group_first[g + 1]);
+        check_chunk_errors(b, b.h_group_first[g], b.h_group_first[g + 1]);
+        if (!b.h_ident[g]) throw ProofErr{BPP_ERR_VERIFICATION_FAILED, "Range proof batch not valid", BPP_TIER_MSM, b.h_group_first[g]};
+      } catch (const ProofErr &e) {
+        r.code = e.code;
+        r.tier = e.tier;
+        r.index = e.index - b.h_group_first[g];  // position inside the group's own batch
+        snprintf(r.msg, sizeof(r.msg), "%s", e.msg.c_str());
+      }
+    }
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, nullptr, 0)
 }
 
 int bpp_verify_batch_with_challenges(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items,
@@ -2143,6 +2209,7 @@ int bpp_profile_get(bpp_ctx *ctx, bpp_profile *out) {
 }  // extern "C"
 
 #include "engine_shard.h"
+#include "engine_batcher.h"
 
 // ================================================================= batch prover
 extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_item *items, size_t n_items, uint8_t *proofs_out,

@@ -130,6 +130,42 @@ def verify_batch(params, inp, action=api.VerifyAction.VerifyOnly, chunk=api.MAX_
     return masks, present
 
 
+class Batcher:
+    """bpp_batcher: many host threads, each calling verify(inp) with ONE reference batch; the calls that are waiting are pooled
+    into grouped engine calls (bpp_verify_resident_groups), every caller gets the outcome of a call of its own.  `shape`: a
+    PackedInput whose proof length, aggregation factor and label say what can be pooled."""
+
+    def __init__(self, params, shape, lanes=2, max_wait_us=0, max_calls=64):
+        self.params, self.engine = params, params.engine
+        self.handle = ctypes.c_void_p()
+        api._check(self.engine.lib.bpp_batcher_create(self.engine.ctx, params.handle, byref(shape.struct), lanes, max_wait_us, max_calls,
+                                                      byref(self.handle)), self.engine.ctx)
+
+    def verify(self, inp):
+        """blocks; raises ProofError exactly as verify_batch(params, inp, VerifyOnly, chunk=0) would"""
+        err = ctypes.create_string_buffer(256)
+        api._check(self.engine.lib.bpp_batcher_verify(self.handle, byref(inp.struct), err, 256), None, err)
+
+    def stats(self):
+        v = [c_uint64() for _ in range(3)]
+        self.engine.lib.bpp_batcher_stats(self.handle, *[byref(x) for x in v])
+        return dict(zip(("pooled_calls", "engine_calls", "solo_calls"), [x.value for x in v]))
+
+    def close(self):
+        if self.handle:
+            self.engine.lib.bpp_batcher_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
+def verify_groups(rb, bounds):
+    """bpp_verify_resident_groups on a resident batch: group g = proofs [bounds[g], bounds[g+1]) -> list of result dicts"""
+    G = len(bounds) - 1
+    arr = (ctypes.c_uint32 * (G + 1))(*bounds)
+    out = (_lib.ShardResult * G)()
+    api._check(rb.engine.lib.bpp_verify_resident_groups(rb.engine.ctx, rb.handle, arr, G, out), rb.engine.ctx)
+    return [{"code": r.code, "tier": r.tier, "index": r.index, "msg": r.msg.decode(errors="replace")} for r in out]
+
+
 class Pipeline:
     """bpp_verify_submit_packed / bpp_verify_collect on one engine: upload k+1 overlaps verify k inside ONE context"""
 

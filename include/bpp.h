@@ -281,6 +281,26 @@ int bpp_verify_sharded_groups(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, size
  * host threads on several communicators cannot promise.  results: k x n_groups, batch-major. */
 int bpp_verify_sharded_groups_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t *batches, size_t k, size_t n_groups,
                                    const uint32_t *counts, bpp_shard_result *results /* k x n_groups */);
+
+/* ---- pooled small calls ----
+ * Reference batches of different sizes as the groups of ONE engine call: group g = proofs [group_first[g], group_first[g+1])
+ * of the resident batch (group_first[0] = 0, group_first[n_groups] = the batch size), every group verified as its own
+ * verify() (VerifyOnly) with its own outcome in results[g] (code, tier, index inside the group, message; rank = -1). */
+int bpp_verify_resident_groups(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first, size_t n_groups, bpp_shard_result *results);
+/* bpp_batcher: many host threads, each with ONE reference batch per call.  Separate small calls stop at about 5 000 calls per
+ * second whatever the number of callers (a small call is a chain of latency-bound kernels and the chip runs about six of those
+ * side by side); the batcher pools the calls that are waiting into grouped engine calls (bpp_verify_resident_groups) on
+ * `lanes` contexts of its own (the first one is `ctx`), without a thread of its own: whichever caller finds a lane free
+ * leads the next pooled call for everybody queued behind it.  bpp_batcher_verify blocks and returns exactly what
+ * bpp_verify_batch_packed(ctx, params, in, BPP_VERIFY_ONLY, 0, ...) would: 0 or the ProofError kind, message in errbuf.
+ * `shape` fixes what can be pooled (proof_len, m, transcript label; other inputs are verified on their own).  max_wait_us:
+ * how long a leader waits for company (0: takes what is there); max_calls: most batches per pooled call (0: 64). */
+typedef struct bpp_batcher bpp_batcher;
+int bpp_batcher_create(bpp_ctx *ctx, uint64_t params, const bpp_packed_batch *shape, uint32_t lanes, uint32_t max_wait_us, uint32_t max_calls,
+                       bpp_batcher **out);
+int bpp_batcher_verify(bpp_batcher *b, const bpp_packed_batch *in, char *errbuf, size_t errbuf_len);
+int bpp_batcher_stats(bpp_batcher *b, uint64_t *pooled_calls, uint64_t *engine_calls, uint64_t *solo_calls);
+void bpp_batcher_destroy(bpp_batcher *b);
 /* host wall-clock split of the last wave on `comm` (ms): enqueueing phase 1 on the k streams, the first exchange (waits for
  * PASS 1 only: all_gather, RNG bytes down), the k weight chains, enqueueing phase 2, waiting for the k streams, the second
  * exchange with the sum and identity test (wait1_ms is always 0 since the first exchange no longer waits for all of phase 1) */

@@ -64,7 +64,7 @@ int main(int argc, char **argv) {
   in.min_present = min_present.data();
   in.transcript_label = (const uint8_t *)label.data();
   in.label_len = label.size();
-  for (int host = 0; host < 2; host++)
+  for (int host = 0; host < 3; host++)  // 0: resident batches, 1: host buffers in (bpp_verify_batch_packed), 2: the same through ONE bpp_batcher
     for (int S : S_list) {
       std::vector<std::unique_ptr<Engine>> engs;
       std::vector<std::shared_ptr<RangeParameters>> pars;
@@ -75,10 +75,13 @@ int main(int argc, char **argv) {
         pars.push_back(params->share(*engs[k]));
         if (!host && bpp_batch_upload_packed(engs[k]->ctx(), pars[k]->handle(), &in, &handles[k], err, sizeof(err)) != BPP_OK) return 1;
       }
+      bpp_batcher *bat = nullptr;
+      if (host == 2 && bpp_batcher_create(eng.ctx(), params->handle(), &in, getenv("BATCHER_LANES") ? atoi(getenv("BATCHER_LANES")) : 2, getenv("BATCHER_WAIT_US") ? atoi(getenv("BATCHER_WAIT_US")) : 0, 64, &bat) != BPP_OK) return 1;
       auto call = [&](int k) {
         char e2[256];
-        const int rc = host ? bpp_verify_batch_packed(engs[k]->ctx(), pars[k]->handle(), &in, BPP_VERIFY_ONLY, 0, nullptr, nullptr, e2, sizeof(e2))
-                            : bpp_verify_resident(engs[k]->ctx(), handles[k], BPP_VERIFY_ONLY, 0, nullptr, nullptr, e2, sizeof(e2));
+        const int rc = host == 2 ? bpp_batcher_verify(bat, &in, e2, sizeof(e2))
+                       : host  ? bpp_verify_batch_packed(engs[k]->ctx(), pars[k]->handle(), &in, BPP_VERIFY_ONLY, 0, nullptr, nullptr, e2, sizeof(e2))
+                               : bpp_verify_resident(engs[k]->ctx(), handles[k], BPP_VERIFY_ONLY, 0, nullptr, nullptr, e2, sizeof(e2));
         if (rc != BPP_OK) {
           fprintf(stderr, "call failed: %d %s\n", rc, e2);
           exit(1);
@@ -101,8 +104,11 @@ int main(int argc, char **argv) {
         });
       for (auto &t : th) t.join();
       const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      printf("{\"proofs_per_call\": %u, \"host_buffers_in\": %s, \"in_flight\": %d, \"calls_per_s\": %.1f, \"proofs_per_s\": %.0f, \"ms_per_call_per_context\": %.3f}\n", N,
-             host ? "true" : "false", S, total / el, N * (double)total / el, 1e3 * el * S / (double)total);
+      uint64_t pooled = 0, ecalls = 0, solo = 0;
+      if (bat) bpp_batcher_stats(bat, &pooled, &ecalls, &solo);
+      printf("{\"proofs_per_call\": %u, \"form\": \"%s\", \"host_buffers_in\": %s, \"in_flight\": %d, \"calls_per_s\": %.1f, \"proofs_per_s\": %.0f, \"ms_per_call_per_context\": %.3f, \"engine_calls\": %llu}\n", N,
+             host == 2 ? "batcher" : host ? "packed" : "resident", host ? "true" : "false", S, total / el, N * (double)total / el, 1e3 * el * S / (double)total, (unsigned long long)ecalls);
+      if (bat) bpp_batcher_destroy(bat);
       fflush(stdout);
       for (int k = 0; k < S; k++)
         if (!host) bpp_batch_destroy(engs[k]->ctx(), handles[k]);
