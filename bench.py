@@ -443,6 +443,58 @@ def host_in_leg(bpp, packed, np, device_index, params0, data, R, calls, sync):
     return out
 
 
+def small_calls_leg(bpp, packed, np, local_rank, params2, data2, callers=32, seconds=1.2):
+    """The reference's own use: separate callers, each with ONE batch of 256 proofs per verify_batch call (its
+    MAX_RANGE_PROOF_BATCH_SIZE), host buffers in.  (a) every caller on a context of its own (bpp_verify_batch_packed): a small
+    call is a chain of latency-bound kernels and the chip runs about six of them side by side, so the rate stops at about
+    5 000 calls per second whatever the number of callers; (b) the same callers through ONE bpp_batcher, which pools the calls
+    that are waiting into grouped engine calls (bpp_verify_resident_groups)."""
+    sl = slice(0, 256)
+    inp = packed.PackedInput(data2["proofs"][sl], data2["commitments"][sl], data2["min_values"][sl], data2["min_present"][sl], None, LABEL)
+    out = {"workload": "%d host threads, each verifying one 256-proof reference batch per call from host buffers (VerifyOnly), %.1f s per form"
+                       % (callers, seconds)}
+    for form in ("separate_contexts", "batcher"):
+        engs = [bpp.Engine(local_rank) for _ in range(callers if form == "separate_contexts" else 0)]
+        pars = [params2.share(e) for e in engs]
+        bat = packed.Batcher(params2, inp, lanes=2) if form == "batcher" else None
+        errors, cnt = [], [0] * callers
+
+        def call(k):
+            if bat is not None:
+                bat.verify(inp)
+            else:
+                packed.verify_batch(pars[k], inp, bpp.VerifyAction.VerifyOnly, 0)
+        for k in range(callers if bat is None else 4):
+            call(k)
+        stop = time.time() + seconds
+
+        def worker(k):
+            try:
+                while time.time() < stop:
+                    call(k)
+                    cnt[k] += 1
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(callers)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        el = time.perf_counter() - t0
+        if errors:
+            raise errors[0]
+        out[form] = {"calls_per_s": sum(cnt) / el, "proofs_per_s": 256 * sum(cnt) / el, "ms_per_call": 1e3 * el * callers / max(1, sum(cnt))}
+        if bat is not None:
+            out[form]["engine_calls"] = bat.stats()["engine_calls"]
+            bat.close()
+        for p in pars:
+            p.close()
+        for e in engs:
+            e.close()
+    return out
+
+
 def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, params2, data2, args, sync):
     """BASELINE configs[3]: 4096 proofs as ONE reference batch sharded over the ranks, through the C ABI
     (bpp_verify_sharded_groups_wave: RCCL all_gathers on device buffers).  A rank's shards of G such batches are ONE resident
@@ -796,6 +848,8 @@ def main():
         extra["latency"] = dict(lat_out, workload="BASELINE configs[0]'s shape through the engine: ONE call at a time, 1, 64 and 256 "
                                                   "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input; calls of up to ~1200 proofs "
                                                   "run the final MSM as a half-scalar plan (s = s_lo + 2^126 s_hi: half the Horner doublings)")
+        # -------------------------------------------------------------- many callers, one 256-proof verify_batch call each
+        extra["small_calls"] = small_calls_leg(bpp, packed, np, local_rank, params2, data2)
         # -------------------------------------------------------------- configs[4]: batch prover
         extra["prover"] = prover_leg()
         if profiler_legs:

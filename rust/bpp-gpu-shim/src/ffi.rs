@@ -84,6 +84,10 @@ pub struct bpp_packed_batch {
 pub struct bpp_comm {
     _p: [u8; 0],
 }
+#[repr(C)]
+pub struct bpp_batcher {
+    _p: [u8; 0],
+}
 
 /// outcome of one batch of a sharded wave (bpp_verify_sharded_wave)
 #[repr(C)]
@@ -202,6 +206,13 @@ extern "C" {
                                      results: *mut bpp_shard_result) -> c_int;
     pub fn bpp_verify_sharded_groups_wave(comm: *mut bpp_comm, ctxs: *const *mut bpp_ctx, batches: *const u64, k: usize, n_groups: usize,
                                           counts: *const u32, results: *mut bpp_shard_result) -> c_int;
+    // reference batches of different sizes as the groups of one call; the pool of many callers' small calls
+    pub fn bpp_verify_resident_groups(ctx: *mut bpp_ctx, batch: u64, group_first: *const u32, n_groups: usize, results: *mut bpp_shard_result) -> c_int;
+    pub fn bpp_batcher_create(ctx: *mut bpp_ctx, params: u64, shape: *const bpp_packed_batch, lanes: u32, max_wait_us: u32, max_calls: u32,
+                              out: *mut *mut bpp_batcher) -> c_int;
+    pub fn bpp_batcher_verify(b: *mut bpp_batcher, input: *const bpp_packed_batch, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    pub fn bpp_batcher_stats(b: *mut bpp_batcher, pooled_calls: *mut u64, engine_calls: *mut u64, solo_calls: *mut u64) -> c_int;
+    pub fn bpp_batcher_destroy(b: *mut bpp_batcher);
     pub fn bpp_shard_local_trailer(defer: *const u8, status: *const u32, rounds_bad: *const u8, n: u32, first_index: u32,
                                    trailer_out: *mut u8) -> c_int;
     pub fn bpp_shard_trailer(tier: c_int, code: c_int, index: u32, msg: *const c_char, trailer_out: *mut u8) -> c_int;

@@ -406,3 +406,36 @@ pub fn default_engine() -> &'static Mutex<Engine> {
     static ENGINE: OnceLock<Mutex<Engine>> = OnceLock::new();
     ENGINE.get_or_init(|| Mutex::new(Engine::new(0).expect("bpp-gpu-shim: no usable gfx950 device")))
 }
+
+/// `bpp_batcher`: many threads, each with one reference batch per call; the library pools the calls that are waiting into
+/// grouped engine calls (a small call alone is a chain of latency-bound kernels: separate 256-proof calls stop at about 5 000
+/// per second whatever the number of callers).  `verify` blocks and returns what `Engine::verify_batch_packed(.., VerifyOnly,
+/// 0)` would for that input alone.  Shareable between threads (`&self`).
+pub struct Batcher {
+    raw: *mut ffi::bpp_batcher,
+}
+unsafe impl Send for Batcher {}
+unsafe impl Sync for Batcher {}
+
+impl Batcher {
+    /// `shape`: any input of the kind to be pooled (proof length, aggregation factor, transcript label)
+    pub fn new(engine: &Engine, params: &Params, shape: &PackedBatch<'_>, lanes: u32, max_wait_us: u32, max_calls: u32) -> Result<Batcher, GpuError> {
+        let raw_shape = shape.raw();
+        let mut raw = core::ptr::null_mut();
+        let rc = unsafe { ffi::bpp_batcher_create(engine.ctx, params.handle, &raw_shape, lanes, max_wait_us, max_calls, &mut raw) };
+        map_rc(rc, String::from("bpp_batcher_create"))?;
+        Ok(Batcher { raw })
+    }
+    pub fn verify(&self, input: &PackedBatch<'_>) -> Result<(), GpuError> {
+        let raw_in = input.raw();
+        let mut err = [0 as core::ffi::c_char; 256];
+        let rc = unsafe { ffi::bpp_batcher_verify(self.raw, &raw_in, err.as_mut_ptr(), err.len()) };
+        map_rc(rc, unsafe { CStr::from_ptr(err.as_ptr()) }.to_string_lossy().into_owned())
+    }
+}
+
+impl Drop for Batcher {
+    fn drop(&mut self) {
+        unsafe { ffi::bpp_batcher_destroy(self.raw) }
+    }
+}

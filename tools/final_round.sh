@@ -18,7 +18,8 @@ timeout -k 10 300 python3 tools/wave_probe.py "1x1,1x16,3x12,1g16,1g64,3g32,1p2g
 timeout -k 10 300 python3 tools/wave_probe.py "1x16,1g16,1g64,3g32,1p2g64" 20 512 2>> $O/${TAG}_bench.err | grep "^{" >> $O/${TAG}_wave_probe.jsonl
 timeout -k 10 300 python3 tools/chunk_probe.py "128,256,512,1024,2048,4096" 64 2>> $O/${TAG}_bench.err | grep "^{" > $O/${TAG}_chunk_probe.jsonl
 WIDE_PROBE_N=256 WIDE_PROBE_S=1,4,8,16 timeout -k 10 300 python3 tools/wide_probe.py 2>> $O/${TAG}_bench.err | grep "^{" > $O/${TAG}_calls_in_flight.jsonl
-WIDE_PROBE_HOST=1 WIDE_PROBE_N=256 WIDE_PROBE_S=1,4,8,16 timeout -k 10 300 python3 tools/wide_probe.py 2>> $O/${TAG}_bench.err | grep "^{" >> $O/${TAG}_calls_in_flight.jsonl
+WIDE_PROBE_HOST=1 WIDE_PROBE_N=256 WIDE_PROBE_S=1,4,8,16,32,64 timeout -k 10 300 python3 tools/wide_probe.py 2>> $O/${TAG}_bench.err | grep "^{" >> $O/${TAG}_calls_in_flight.jsonl
+WIDE_PROBE_HOST=2 WIDE_PROBE_N=256 WIDE_PROBE_S=1,4,8,16,32,64 timeout -k 10 300 python3 tools/wide_probe.py 2>> $O/${TAG}_bench.err | grep "^{" >> $O/${TAG}_calls_in_flight.jsonl
 timeout -k 10 300 python3 tools/bench_latency.py > $O/${TAG}_bench_latency.jsonl 2>> $O/${TAG}_bench.err
 BPP_MSM_SPLIT=0 timeout -k 10 300 python3 tools/bench_latency.py --no-cpu > $O/${TAG}_bench_latency_nosplit.jsonl 2>> $O/${TAG}_bench.err
 echo "final_round $TAG done"

@@ -10,7 +10,8 @@ packed blocking form (bpp_verify_batch_packed), the pipelined form (bpp_verify_s
 outstanding, collected in random order) and the sharded form over a one-rank RCCL communicator (bpp_verify_sharded: the whole
 call is one reference batch) and the grouped sharded form (bpp_verify_sharded_groups: the call cut into equal groups, each its
 own reference batch, every group's outcome compared with the oracle's; half of the even splits as two slots of one pipelined
-call, bpp_verify_sharded_groups_wave).  Most calls are small (half-scalar MSM plan); about one in twenty-five has 1000 or 1500 proofs (full plan with
+call, bpp_verify_sharded_groups_wave), and through ONE bpp_batcher shared by all threads (the call is pooled with whatever the
+other threads hand in at that moment; its verdict must be that of a call of its own).  Most calls are small (half-scalar MSM plan); about one in twenty-five has 1000 or 1500 proofs (full plan with
 the latency kernels / the throughput kernels).
 
     python tools/soak.py --seconds 120 --threads 4
@@ -33,7 +34,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--seed", type=int, default=20260704)
-    ap.add_argument("--paths", default="items,packed,pipeline,sharded,groups")
+    ap.add_argument("--paths", default="items,packed,pipeline,sharded,groups,batcher")
     args = ap.parse_args()
     import numpy as np
     bpp = importlib.import_module("bulletproofs-plus_amd")
@@ -50,6 +51,8 @@ def main():
     stats.update({"calls_" + p: 0 for p in paths})
     lock = threading.Lock()
     problems = []
+
+    shared = {}  # the one bpp_batcher all worker threads call into (path "batcher")
 
     def packed_input(sub):
         n = len(sub)
@@ -95,7 +98,7 @@ def main():
             cnt = rng.choice([1, 2, 3, 7, 16, 64, 200, 256])
             if rng.random() < 0.04:  # now and then a call beyond the half-scalar plan (1000 proofs) and beyond the small-call plan (1500)
                 cnt = rng.choice([1000, 1500])
-            chunk = 0 if path == "sharded" else rng.choice([0, 0, 8, 64])
+            chunk = 0 if path in ("sharded", "batcher") else rng.choice([0, 0, 8, 64])
             if path == "groups":  # bpp_verify_sharded_groups: `cnt` proofs as equal groups, every group its own reference batch
                 groups = rng.choice([g for g in (1, 2, 4, 8, 16) if cnt % g == 0 and cnt // g >= 1] if cnt < 1000 else [1, 2, 4])
                 chunk = cnt // groups
@@ -135,6 +138,8 @@ def main():
                     if len(pending) >= 3:
                         collect(pending.pop(rng.randrange(len(pending))))
                     continue
+                elif path == "batcher":  # pooled with whatever the other threads are calling at the moment
+                    shared["bat"].verify(packed_input(sub))
                 elif path == "groups":
                     n_groups = cnt // chunk
                     if n_groups % 2 == 0 and rng.random() < 0.5:  # two slots of one pipelined call (bpp_verify_sharded_groups_wave)
@@ -182,6 +187,11 @@ def main():
         eng.close()
         cp.close()
 
+    eng_b = params_b = None
+    if "batcher" in paths:
+        eng_b = bpp.Engine(0)
+        params_b = bpp.RangeParameters.init(n_bits, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=eng_b)
+        shared["bat"] = packed.Batcher(params_b, packed_input(items[:1]), lanes=2)
     th = [threading.Thread(target=worker, args=(k,)) for k in range(args.threads)]
     for x in th:
         x.start()
@@ -192,6 +202,11 @@ def main():
                 print("progress", json.dumps(stats), file=sys.stderr, flush=True)
     for x in th:
         x.join()
+    if eng_b is not None:
+        stats["batcher"] = shared["bat"].stats()
+        shared["bat"].close()
+        params_b.close()
+        eng_b.close()
     print(json.dumps(dict(stats, seconds=args.seconds, threads=args.threads, problems=problems)))
     return 1 if stats["mismatch"] else 0
 
