@@ -191,7 +191,7 @@ def main():
     if "batcher" in paths:
         eng_b = bpp.Engine(0)
         params_b = bpp.RangeParameters.init(n_bits, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=eng_b)
-        shared["bat"] = packed.Batcher(params_b, packed_input(items[:1]), lanes=2)
+        shared["bat"] = packed.Batcher(params_b, packed_input(items[:1]), lanes=2, max_wait_us=5000)  # (the threads spend most of their time in the oracle: a leader waits for company)
     th = [threading.Thread(target=worker, args=(k,)) for k in range(args.threads)]
     for x in th:
         x.start()
