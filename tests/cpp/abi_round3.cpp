@@ -4,12 +4,14 @@
 //   tickets collected out of order, bpp_batch_secret_bytes, bpp_ctx_set_option, and the sharded entries over the in-process
 //   communicator (bpp_comm_create_local, one rank): bpp_verify_sharded, bpp_verify_sharded_wave (two contexts),
 //   bpp_verify_sharded_groups (four groups, one tampered), bpp_verify_sharded_groups_wave (two slots) with their
-//   bpp_shard_result records.
+//   bpp_shard_result records; bpp_verify_resident_groups (ragged groups) and bpp_batcher (six threads).
 // Proofs come from the engine's own prover through the C++ mirror (include/bpp.hpp).  Built and run by
 // tests/test_gpu_cpp_mirror.py on the GPU box.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "bpp.hpp"
 
@@ -196,6 +198,38 @@ int main() {
     CHECK(gres[2].code == BPP_OK && gres[3].code == BPP_ERR_VERIFICATION_FAILED && gres[3].tier == BPP_TIER_MSM);  // slot 1: proof 77
     CHECK(bpp_batch_destroy(ctx, h1) == BPP_OK && bpp_batch_destroy(eng2.ctx(), h2) == BPP_OK);
     bpp_comm_destroy(comm);
+  }
+  // ---- reference batches of different sizes as the groups of one call; the pool of many callers' small calls
+  {
+    uint64_t h = 0;
+    bpp_packed_batch in = packed_of(bad.data(), 0, N, false);  // proof 77 tampered
+    CHECK(bpp_batch_upload_packed(ctx, params->handle(), &in, &h, err, sizeof(err)) == BPP_OK);
+    const uint32_t first[4] = {0, 10, 120, N};  // groups of 10, 110 and 80 proofs
+    bpp_shard_result res[3];
+    CHECK(bpp_verify_resident_groups(ctx, h, first, 3, res) == BPP_OK);
+    CHECK(res[0].code == BPP_OK && res[2].code == BPP_OK && res[1].code == BPP_ERR_VERIFICATION_FAILED && res[1].tier == BPP_TIER_MSM);
+    CHECK(bpp_batch_destroy(ctx, h) == BPP_OK);
+    bpp_batcher *bat = nullptr;
+    bpp_packed_batch shape = packed_of(flat.data(), 0, 1, false);
+    CHECK(bpp_batcher_create(ctx, params->handle(), &shape, 2, 0, 0, &bat) == BPP_OK);
+    std::atomic<int> wrong{0};
+    std::vector<std::thread> th;
+    for (int k = 0; k < 6; k++)
+      th.emplace_back([&, k] {
+        char e2[256];
+        for (int i = 0; i < 25; i++) {
+          const bool use_bad = ((k + i) % 3) == 0;
+          // [60, 100) of `bad` holds proof 77; [100, 140) does not
+          bpp_packed_batch mine = packed_of(use_bad ? bad.data() : flat.data(), use_bad ? 60 : 100, 40, false);
+          const int rc = bpp_batcher_verify(bat, &mine, e2, sizeof(e2));
+          if (rc != (use_bad ? BPP_ERR_VERIFICATION_FAILED : BPP_OK)) wrong++;
+        }
+      });
+    for (auto &t : th) t.join();
+    CHECK(wrong == 0);
+    uint64_t pooled = 0, ecalls = 0, solo = 0;
+    CHECK(bpp_batcher_stats(bat, &pooled, &ecalls, &solo) == BPP_OK && ecalls > 0 && ecalls <= 150);
+    bpp_batcher_destroy(bat);
   }
   printf("abi_round3 ok\n");
   return 0;

@@ -29,6 +29,6 @@ def test_compiled_caller_of_the_round3_entry_points(tmp_path):
     exe = str(tmp_path / "abi_round3")
     libdir = os.path.dirname(lib)
     subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "abi_round3.cpp"),
-                    "-o", exe, "-L", libdir, "-lbpp_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+                    "-o", exe, "-L", libdir, "-lbpp_hip", "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "abi_round3 ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
