@@ -49,8 +49,24 @@ bool batcher_poolable(const bpp_batcher *b, const bpp_packed_batch *in) {
          memcmp(in->transcript_label, b->key_label.data(), in->label_len) == 0 && in->n_items <= b->max_proofs;
 }
 
-// one pooled engine call on `lane` over `reqs`; fills every request's code / msg
+void batcher_run_unchecked(bpp_batcher *b, bpp_batcher::Lane &L, const std::vector<bpp_batcher::Req *> &reqs);
+// one pooled engine call on `lane` over `reqs`; fills every request's code / msg (nothing may escape: callers are waiting)
 void batcher_run(bpp_batcher *b, bpp_batcher::Lane &L, const std::vector<bpp_batcher::Req *> &reqs) {
+  try {
+    batcher_run_unchecked(b, L, reqs);
+  } catch (const std::exception &e) {
+    for (auto *r : reqs) {
+      r->code = BPP_ERR_ENGINE;
+      r->msg = std::string("batcher: ") + e.what();
+    }
+  } catch (...) {
+    for (auto *r : reqs) {
+      r->code = BPP_ERR_ENGINE;
+      r->msg = "batcher: unexpected failure";
+    }
+  }
+}
+void batcher_run_unchecked(bpp_batcher *b, bpp_batcher::Lane &L, const std::vector<bpp_batcher::Req *> &reqs) {
   char err[256];
   auto solo = [&](bpp_batcher::Req *r) {
     err[0] = 0;
