@@ -456,7 +456,7 @@ def small_calls_leg(bpp, packed, np, local_rank, params2, data2, callers=32, sec
     for form in ("separate_contexts", "batcher"):
         engs = [bpp.Engine(local_rank) for _ in range(callers if form == "separate_contexts" else 0)]
         pars = [params2.share(e) for e in engs]
-        bat = packed.Batcher(params2, inp, lanes=2) if form == "batcher" else None
+        bat = packed.Batcher(params2, inp, lanes=0) if form == "batcher" else None
         errors, cnt = [], [0] * callers
 
         def call(k):

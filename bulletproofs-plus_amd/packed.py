@@ -135,7 +135,7 @@ class Batcher:
     into grouped engine calls (bpp_verify_resident_groups), every caller gets the outcome of a call of its own.  `shape`: a
     PackedInput whose proof length, aggregation factor and label say what can be pooled."""
 
-    def __init__(self, params, shape, lanes=2, max_wait_us=0, max_calls=64):
+    def __init__(self, params, shape, lanes=0, max_wait_us=0, max_calls=64):
         self.params, self.engine = params, params.engine
         self.handle = ctypes.c_void_p()
         api._check(self.engine.lib.bpp_batcher_create(self.engine.ctx, params.handle, byref(shape.struct), lanes, max_wait_us, max_calls,

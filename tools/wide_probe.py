@@ -31,7 +31,7 @@ def main():
     for S in [int(x) for x in os.environ.get("WIDE_PROBE_S", "1,4,6,8").split(",")]:
         engs = [bpp.Engine(0) for _ in range(S if mode < 2 else 0)]
         ps = [p0.share(e) for e in engs]
-        bat = packed.Batcher(p0, inp, lanes=2) if mode == 2 else None
+        bat = packed.Batcher(p0, inp, lanes=int(os.environ.get("WIDE_PROBE_LANES", "0"))) if mode == 2 else None
         rbs = [] if host else [packed.ResidentBatch(ps[k], d["proofs"], d["commitments"], d["min_values"], d["min_present"], None, bench.LABEL)
                                for k in range(S)]
 
