@@ -136,7 +136,7 @@ extern "C" {
 int bpp_batcher_create(bpp_ctx *ctx, uint64_t params, const bpp_packed_batch *shape, uint32_t lanes, uint32_t max_wait_us, uint32_t max_calls,
                        bpp_batcher **out) {
   if (!ctx || !out || !shape || !shape->transcript_label || shape->proof_len == 0 || shape->m == 0) return BPP_ERR_INVALID_ARGUMENT;
-  if (lanes == 0) lanes = 3;  // (8...64 callers: 3 lanes are 5-20 % ahead of 2, 128 callers 10 % behind; 4 and 6 lose from 16 callers on)
+  if (lanes == 0) lanes = 2;  // (two pooled calls in flight keep the pools large; three are within run-to-run noise of two, four and six lose)
   if (lanes > 8) lanes = 8;
   auto b = std::make_unique<bpp_batcher>();
   b->params = params;

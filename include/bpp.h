@@ -290,7 +290,7 @@ int bpp_verify_resident_groups(bpp_ctx *ctx, uint64_t batch, const uint32_t *gro
 /* bpp_batcher: many host threads, each with ONE reference batch per call.  Separate small calls stop at about 5 000 calls per
  * second whatever the number of callers (a small call is a chain of latency-bound kernels and the chip runs about six of those
  * side by side); the batcher pools the calls that are waiting into grouped engine calls (bpp_verify_resident_groups) on
- * `lanes` contexts of its own (the first one is `ctx`; 0 = the default of three), without a thread of its own: whichever caller finds a lane free
+ * `lanes` contexts of its own (the first one is `ctx`; 0 = the default of two), without a thread of its own: whichever caller finds a lane free
  * leads the next pooled call for everybody queued behind it.  bpp_batcher_verify blocks and returns exactly what
  * bpp_verify_batch_packed(ctx, params, in, BPP_VERIFY_ONLY, 0, ...) would: 0 or the ProofError kind, message in errbuf.
  * `shape` fixes what can be pooled (proof_len, m, transcript label; other inputs are verified on their own).  max_wait_us:
