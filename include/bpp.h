@@ -300,7 +300,7 @@ int bpp_batcher_create(bpp_ctx *ctx, uint64_t params, const bpp_packed_batch *sh
                        bpp_batcher **out);
 int bpp_batcher_verify(bpp_batcher *b, const bpp_packed_batch *in, char *errbuf, size_t errbuf_len);
 int bpp_batcher_stats(bpp_batcher *b, uint64_t *pooled_calls, uint64_t *engine_calls, uint64_t *solo_calls);
-void bpp_batcher_destroy(bpp_batcher *b);
+void bpp_batcher_destroy(bpp_batcher *b); /* waits for the calls in flight; no call may start once it has been called */
 /* host wall-clock split of the last wave on `comm` (ms): enqueueing phase 1 on the k streams, the first exchange (waits for
  * PASS 1 only: all_gather, RNG bytes down), the k weight chains, enqueueing phase 2, waiting for the k streams, the second
  * exchange with the sum and identity test (wait1_ms is always 0 since the first exchange no longer waits for all of phase 1) */
