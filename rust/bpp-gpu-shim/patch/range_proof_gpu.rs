@@ -71,6 +71,23 @@ pub mod gpu {
         cached_params(g.bit_length(), g.max_aggregation_factor(), g.extension_degree() as usize, g.h_base_compressed().as_fixed_bytes(), &gb)
     }
 
+    /// one bpp_batcher per (parameter set, proof length, aggregation factor, transcript label) and process
+    fn pooled_batcher(params: &Arc<Params>, shape: &PackedBatch<'_>) -> Result<Arc<bpp_gpu_shim::Batcher>, GpuError> {
+        use std::collections::HashMap;
+        use std::sync::{Mutex, OnceLock};
+        static POOL: OnceLock<Mutex<HashMap<(usize, usize, usize, Vec<u8>), Arc<bpp_gpu_shim::Batcher>>>> = OnceLock::new();
+        let key = (Arc::as_ptr(params) as usize, shape.proof_len, shape.m, shape.transcript_label.to_vec());
+        let mut pool = POOL.get_or_init(|| Mutex::new(HashMap::new())).lock().unwrap();
+        if let Some(b) = pool.get(&key) {
+            return Ok(b.clone());
+        }
+        // a context of its own for the batcher's first lane: the default engine stays free for the large calls
+        let engine = Engine::new(0)?;
+        let b = Arc::new(bpp_gpu_shim::Batcher::new_owning(engine, params, shape, 0, 0, 0)?);
+        pool.insert(key, b.clone());
+        Ok(b)
+    }
+
     /// `RangeProof::verify_batch` (src/range_proof.rs:712-752) on the GPU, for transcripts the caller describes.  Verifies
     /// EVERY chunk of MAX_RANGE_PROOF_BATCH_SIZE proofs (the reference stops after the first, :740-751).
     pub fn verify_batch<P>(transcripts: GpuTranscript<'_>, statements: &[RangeStatement<P>], proofs: &[RangeProof<P>], action: VerifyAction)
@@ -107,6 +124,13 @@ pub mod gpu {
                 let input = PackedBatch { n_items: n, proofs: &flat, proof_len: blobs[0].len(), commitments: &comms, m: m0, min_values: &mins,
                                           min_present: &present, seed_nonces: Some((&seeds, &seed_present)),
                                           transcript_label: transcripts.label(), transcript_state: transcripts.state() };
+                if n <= MAX_RANGE_PROOF_BATCH_SIZE && matches!(action, VerifyAction::VerifyOnly) && transcripts.state().is_none() {
+                    // ONE reference batch and nothing to recover: a small call.  Separate threads with such calls stop at about
+                    // 5 000 calls per second on a context each (and at one call at a time behind the engine mutex above); pooled
+                    // with the other threads' calls by a process-wide bpp_batcher they share grouped engine calls.  Same outcome.
+                    drop(engine);
+                    return pooled_batcher(&params, &input)?.verify(&input).map(|_| (0..n).map(|_| None).collect());
+                }
                 engine.verify_batch_packed(&params, &input, act, MAX_RANGE_PROOF_BATCH_SIZE)
             } else {
                 let comms: Vec<Vec<u8>> = statements.iter().map(|s| s.commitments_compressed.iter().flat_map(|c| *c.as_fixed_bytes()).collect()).collect();

@@ -413,6 +413,7 @@ pub fn default_engine() -> &'static Mutex<Engine> {
 /// 0)` would for that input alone.  Shareable between threads (`&self`).
 pub struct Batcher {
     raw: *mut ffi::bpp_batcher,
+    _engine: Option<Engine>,  // the context of the first lane, when the batcher owns it (dropped after the batcher itself)
 }
 unsafe impl Send for Batcher {}
 unsafe impl Sync for Batcher {}
@@ -424,7 +425,14 @@ impl Batcher {
         let mut raw = core::ptr::null_mut();
         let rc = unsafe { ffi::bpp_batcher_create(engine.ctx, params.handle, &raw_shape, lanes, max_wait_us, max_calls, &mut raw) };
         map_rc(rc, String::from("bpp_batcher_create"))?;
-        Ok(Batcher { raw })
+        Ok(Batcher { raw, _engine: None })
+    }
+    /// the same, taking ownership of `engine` (a context that exists for this batcher only); `params` is retained on it first
+    pub fn new_owning(engine: Engine, params: &Params, shape: &PackedBatch<'_>, lanes: u32, max_wait_us: u32, max_calls: u32) -> Result<Batcher, GpuError> {
+        map_rc(unsafe { ffi::bpp_params_retain(engine.ctx, params.handle) }, String::from("bpp_params_retain"))?;
+        let mut b = Batcher::new(&engine, params, shape, lanes, max_wait_us, max_calls)?;
+        b._engine = Some(engine);
+        Ok(b)
     }
     pub fn verify(&self, input: &PackedBatch<'_>) -> Result<(), GpuError> {
         let raw_in = input.raw();
@@ -436,6 +444,6 @@ impl Batcher {
 
 impl Drop for Batcher {
     fn drop(&mut self) {
-        unsafe { ffi::bpp_batcher_destroy(self.raw) }
+        unsafe { ffi::bpp_batcher_destroy(self.raw) }  // (fields drop afterwards: the owned engine outlives the batcher)
     }
 }
