@@ -849,7 +849,10 @@ def main():
                                                   "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input; calls of up to ~1200 proofs "
                                                   "run the final MSM as a half-scalar plan (s = s_lo + 2^126 s_hi: half the Horner doublings)")
         # -------------------------------------------------------------- many callers, one 256-proof verify_batch call each
-        extra["small_calls"] = small_calls_leg(bpp, packed, np, local_rank, params2, data2)
+        try:
+            extra["small_calls"] = small_calls_leg(bpp, packed, np, local_rank, params2, data2)
+        except Exception as e:  # noqa: BLE001 - a side leg: reported, never allowed to take the line down
+            extra["small_calls"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # -------------------------------------------------------------- configs[4]: batch prover
         extra["prover"] = prover_leg()
         if profiler_legs:
