@@ -443,7 +443,7 @@ def host_in_leg(bpp, packed, np, device_index, params0, data, R, calls, sync):
     return out
 
 
-def small_calls_leg(bpp, packed, np, local_rank, params2, data2, callers=32, seconds=1.2):
+def small_calls_leg(bpp, packed, np, local_rank, params2, data2, callers=32, seconds=2.0):
     """The reference's own use: separate callers, each with ONE batch of 256 proofs per verify_batch call (its
     MAX_RANGE_PROOF_BATCH_SIZE), host buffers in.  (a) every caller on a context of its own (bpp_verify_batch_packed): a small
     call is a chain of latency-bound kernels and the chip runs about six of them side by side, so the rate stops at about
