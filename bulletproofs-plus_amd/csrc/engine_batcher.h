@@ -89,7 +89,9 @@ void batcher_run_unchecked(bpp_batcher *b, bpp_batcher::Lane &L, const std::vect
   for (size_t g = 0; g < reqs.size(); g++) {
     const bpp_packed_batch &in = *reqs[g]->in;
     L.bounds[g] = (uint32_t)at;
-    for (size_t i = 0; i < in.n_items; i++) memcpy(&L.proofs[(at + i) * plen], in.proofs + i * in.proof_stride, plen);
+    if (in.proof_stride == plen) memcpy(&L.proofs[at * plen], in.proofs, in.n_items * plen);
+    else
+      for (size_t i = 0; i < in.n_items; i++) memcpy(&L.proofs[(at + i) * plen], in.proofs + i * in.proof_stride, plen);
     memcpy(&L.commitments[at * m * 32], in.commitments32, in.n_items * m * 32);
     if (in.min_values) memcpy(&L.min_values[at * m], in.min_values, in.n_items * m * 8);
     else memset(&L.min_values[at * m], 0, in.n_items * m * 8);
