@@ -227,9 +227,10 @@ def measure_sq(kernels, only="headline"):
 class Leg:
     """S slots (engine + stream + resident copy of the input) verifying `chunk`-proof reference batches"""
 
-    def __init__(self, bpp, packed, torch, device, params0, data, batch_proofs, batches, slots, chunk, profile=True):
+    def __init__(self, bpp, packed, torch, device, params0, data, batch_proofs, batches, slots, chunk, profile=True, action=0):
         import numpy as np
-        self.bpp, self.chunk, self.slots = bpp, chunk, []
+        self.bpp, self.chunk, self.slots, self.action = bpp, chunk, [], int(action)
+        self.data_idx = []
         self.calls = self.ok_steps = 0
         self.proofs_per_step = batch_proofs * batches
         nb = data["proofs"].shape[0] // batch_proofs
@@ -242,12 +243,20 @@ class Leg:
             # the same `nb` distinct batches in another order for every slot
             order = [(i * 11 + k) % nb for k in range(batches)]
             idx = np.concatenate([np.arange(b * batch_proofs, (b + 1) * batch_proofs) for b in order])
+            seeds = data["seeds"][idx] if self.action and data.get("seeds") is not None else None  # (mask recovery needs the nonces)
             rb = packed.ResidentBatch(params, data["proofs"][idx], data["commitments"][idx], data["min_values"][idx],
-                                      data["min_present"][idx], None, LABEL)
+                                      data["min_present"][idx], seeds, LABEL)
             self.upload_s, self.marshal_s = rb.upload_seconds, rb.marshal_seconds
+            self.data_idx.append(idx)
             rb.prepare(chunk)   # group layout, MSM plan, work buffers: not in any timed call
-            rb.verify_only(chunk)  # every slot has run once (events, lazily built state) before anything is timed
+            self._call(rb)  # every slot has run once (events, lazily built state) before anything is timed
             self.slots.append((stream, eng, params, rb))
+
+    def _call(self, rb):
+        if self.action:
+            return rb.verify_arrays(self.action, self.chunk)  # masks as arrays: no per-item Python in the timed call
+        rb.verify_only(self.chunk)  # raises on an invalid batch
+        return None
 
     def set_profile(self, on):
         for _, eng, _, _ in self.slots:
@@ -259,7 +268,7 @@ class Leg:
         if self.calls == FAIL_STEP:  # BPP_BENCH_FAIL_STEP: the harness' own failure path (tests/test_bench_harness.py)
             raise RuntimeError("forced failure of step %d (BPP_BENCH_FAIL_STEP)" % FAIL_STEP)
         t0 = time.perf_counter()
-        rb.verify_only(self.chunk)  # raises on an invalid batch
+        self._call(rb)
         return time.perf_counter() - t0, eng.last_profile()
 
     def run_steps(self, count):
@@ -446,21 +455,35 @@ def host_in_leg(bpp, packed, np, device_index, params0, data, R, calls, sync):
 def small_calls_leg(bpp, packed, np, local_rank, params2, data2, callers=32, seconds=2.0):
     """The reference's own use: separate callers, each with ONE batch of 256 proofs per verify_batch call (its
     MAX_RANGE_PROOF_BATCH_SIZE), host buffers in.  (a) every caller on a context of its own (bpp_verify_batch_packed): a small
-    call is a chain of latency-bound kernels and the chip runs about six of them side by side, so the rate stops at about
-    5 000 calls per second whatever the number of callers; (b) the same callers through ONE bpp_batcher, which pools the calls
-    that are waiting into grouped engine calls (bpp_verify_resident_groups)."""
+    call is a chain of latency-bound kernels and the chip runs about six of them side by side; the library's admission gate
+    (bpp_small_call_limit, default 8) keeps the other callers waiting on the host instead of on the hardware queues -- the same
+    with the gate switched off is measured next to it; (b) the same callers through ONE bpp_batcher, which pools the calls that
+    are waiting into grouped engine calls (bpp_verify_resident_groups_actions); (c) the batcher with RecoverOnly calls (a wallet
+    scanning outputs: seed nonces in, masks out, no final check)."""
     sl = slice(0, 256)
     inp = packed.PackedInput(data2["proofs"][sl], data2["commitments"][sl], data2["min_values"][sl], data2["min_present"][sl], None, LABEL)
-    out = {"workload": "%d host threads, each verifying one 256-proof reference batch per call from host buffers (VerifyOnly), %.1f s per form"
-                       % (callers, seconds)}
-    for form in ("separate_contexts", "batcher"):
-        engs = [bpp.Engine(local_rank) for _ in range(callers if form == "separate_contexts" else 0)]
+    inp_seed = packed.PackedInput(data2["proofs"][sl], data2["commitments"][sl], data2["min_values"][sl], data2["min_present"][sl],
+                                  data2["seeds"][sl], LABEL)
+    want_masks = data2["blindings"][sl, 0, 0, :]
+    eng0 = params2.engine
+    limit0 = eng0.lib.bpp_small_call_limit(eng0.ctx, -1)
+    out = {"workload": "%d host threads, each verifying one 256-proof reference batch per call from host buffers, %.1f s per form"
+                       % (callers, seconds), "small_call_limit": limit0}
+    for form in ("separate_contexts", "separate_contexts_gate_off", "batcher", "batcher_recover_only"):
+        separate = form.startswith("separate")
+        engs = [bpp.Engine(local_rank) for _ in range(callers if separate else 0)]
         pars = [params2.share(e) for e in engs]
-        bat = packed.Batcher(params2, inp, lanes=0) if form == "batcher" else None
+        bat = None if separate else packed.Batcher(params2, inp, lanes=0)
+        eng0.lib.bpp_small_call_limit(eng0.ctx, 0 if form.endswith("gate_off") else limit0)
         errors, cnt = [], [0] * callers
+        info0 = packed.runtime_info(eng0)
 
         def call(k):
-            if bat is not None:
+            if form == "batcher_recover_only":
+                masks, present = bat.verify_action(inp_seed, bpp.VerifyAction.RecoverOnly)
+                if not (present.all() and (masks[:, 0, :] == want_masks).all()):
+                    raise RuntimeError("recovered masks differ from the prover's blindings")
+            elif bat is not None:
                 bat.verify(inp)
             else:
                 packed.verify_batch(pars[k], inp, bpp.VerifyAction.VerifyOnly, 0)
@@ -482,11 +505,16 @@ def small_calls_leg(bpp, packed, np, local_rank, params2, data2, callers=32, sec
         for th in ths:
             th.join()
         el = time.perf_counter() - t0
+        eng0.lib.bpp_small_call_limit(eng0.ctx, limit0)
         if errors:
             raise errors[0]
-        out[form] = {"calls_per_s": sum(cnt) / el, "proofs_per_s": 256 * sum(cnt) / el, "ms_per_call": 1e3 * el * callers / max(1, sum(cnt))}
+        info = packed.runtime_info(eng0)
+        out[form] = {"calls_per_s": sum(cnt) / el, "proofs_per_s": 256 * sum(cnt) / el, "ms_per_call": 1e3 * el * callers / max(1, sum(cnt)),
+                     "contexts": info["contexts"], "hw_queues": info["hw_queues"],
+                     "calls_that_queued_at_the_gate": info["small_calls_queued"] - info0["small_calls_queued"]}
         if bat is not None:
             out[form]["engine_calls"] = bat.stats()["engine_calls"]
+            out[form]["largest_pool"] = dict(zip(("calls", "proofs"), bat.largest_pool()))
             bat.close()
         for p in pars:
             p.close()
@@ -631,6 +659,33 @@ def main():
                             "one step = %d such batches, %d steps in flight" % (R3, S3),
                 "proofs_per_s": 256 * R3 * steps / el3, "ms_per_step": 1e3 * el3 / steps, "steps": steps, "roofline": roof3,
                 "stages_ms": st3}
+
+    def recover_only_leg(data, params, steps=32, warmup=6):
+        """SURVEY 8(f)2 / src/range_proof.rs:941-969,1040-1043: a wallet scanning outputs.  RecoverOnly over the headline's 65 536
+        resident proofs (seed nonces resident too) in 1024-proof reference batches, 4 steps in flight: PASS 1, decompression,
+        k_masks; no weight chains, no PASS 2, no MSM.  Masks come back as arrays and are checked against the prover's blindings."""
+        Rr, Sr = max(1, args.batches_per_step), max(1, args.concurrency)
+        legr = Leg(bpp, packed, torch, device, params, data, 1024, Rr, Sr, 1024, action=int(bpp.VerifyAction.RecoverOnly))
+        elr, latr, prr = timed(legr, steps, warmup, sync)
+        sync()
+        masks, present = legr._call(legr.slots[0][3])
+        ok = bool(present.all()) and bool((masks[:, 0, :] == data["blindings"][legr.data_idx[0], 0, 0, :]).all())
+        avg = {k: sum(p[k] for p in prr) / len(prr) for k in prr[0]}
+        n_pts = 1024 * Rr * 15
+        dec_ms, msk_ms, tr_ms = avg["decompress_ms"], avg["masks_ms"], avg["transcripts_ms"]
+        legr.close()
+        return {"workload": "VerifyAction::RecoverOnly over %d resident 64-bit proofs with seed nonces, as %d reference batches of 1024 per step, "
+                            "%d steps in flight: PASS 1 + decompression + mask recovery (src/range_proof.rs:941-969), no weight chain, no MSM "
+                            "(:1040-1043); masks returned as arrays" % (1024 * Rr, Rr, Sr),
+                "proofs_per_s": 1024 * Rr * steps / elr, "ms_per_step": 1e3 * elr / steps, "steps": steps, "masks_equal_blindings": ok,
+                "stages_ms": {"transcripts_ms": round(tr_ms, 4), "decompress_ms": round(dec_ms, 4), "masks_ms": round(msk_ms, 4)},
+                "roofline": {"bound": "hbm", "kernel": "k_decompress (15 proof points per proof; the dominant kernel without an MSM)",
+                             "kernel_ms": dec_ms, "algorithmic_bytes": 32 * n_pts, "achieved": 32 * n_pts / (dec_ms * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 32 * n_pts / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                             "note": "integer-VALU bound (254 squarings + 25 multiplications per point): see valu",
+                             "valu": {"achieved_Tmad_per_s": n_pts * (254 * 55 + 25 * 100) / (dec_ms * 1e-3) / 1e12,
+                                      "peak_Tmad_per_s": VALU_PEAK_TMAD,
+                                      "frac": n_pts * (254 * 55 + 25 * 100) / (dec_ms * 1e-3) / (VALU_PEAK_TMAD * 1e12)}}}
 
     def prover_leg(iters5=6):
         p5 = bpp.RangeParameters.init(64, 4, G(3), engine=eng0)
@@ -854,6 +909,10 @@ def main():
         except Exception as e:  # noqa: BLE001 - a side leg: reported, never allowed to take the line down
             extra["small_calls"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # -------------------------------------------------------------- configs[4]: batch prover
+        try:
+            extra["recover_only"] = recover_only_leg(data2, params2)
+        except Exception as e:  # noqa: BLE001 - the headline is never held hostage by an extra leg
+            extra["recover_only"] = {"error": "%s: %s" % (type(e).__name__, e)}
         extra["prover"] = prover_leg()
         if profiler_legs:
             tr = measure_traffic("k_fb_msm", "prover")

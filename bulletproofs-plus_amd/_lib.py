@@ -44,12 +44,19 @@ class Profile(Structure):
     _fields_ = [(n, c_float) for n in ("transcripts_ms", "decompress_ms", "chain_host_ms", "scalars_ms", "reduce_ms",
                                        "msm_digits_ms", "msm_sort_ms", "msm_accumulate_ms", "msm_bucket_reduce_ms",
                                        "msm_final_ms", "total_ms")] + \
-               [(n, c_uint32) for n in ("msm_terms", "msm_window_bits", "msm_windows", "msm_groups")]
+               [(n, c_uint32) for n in ("msm_terms", "msm_window_bits", "msm_windows", "msm_groups")] + [("masks_ms", c_float)]
 
 
 class ProveProfile(Structure):
     _fields_ = [("fb_msm_ms", c_float), ("total_ms", c_float), ("fb_terms", c_uint64), ("fb_launches", c_uint32),
                 ("fb_window_bits", c_uint32), ("fb_windows", c_uint32), ("sub_batches", c_uint32)]
+
+
+class RuntimeInfo(Structure):
+    """bpp_runtime_info: what the library sees of its runtime preconditions (hardware queues, contexts, the small-call gate)"""
+    _fields_ = [("device", c_int), ("contexts", c_uint32), ("contexts_peak", c_uint32), ("hw_queues", c_uint32),
+                ("host_threads", c_uint32), ("small_call_limit", c_uint32), ("small_calls_in_flight", c_uint32),
+                ("small_calls", c_uint64), ("small_calls_queued", c_uint64), ("oversubscribed", c_uint32)]
 
 
 # every symbol include/bpp.h declares: (name, restype, argtypes)
@@ -105,6 +112,13 @@ SYMBOLS = [
     ("bpp_verify_sharded_groups_wave", c_int, [c_void_p, POINTER(c_void_p), POINTER(c_uint64), c_size_t, c_size_t, POINTER(c_uint32),
                                                POINTER(ShardResult)]),
     ("bpp_verify_resident_groups", c_int, [c_void_p, c_uint64, POINTER(c_uint32), c_size_t, POINTER(ShardResult)]),
+    ("bpp_verify_resident_groups_actions", c_int, [c_void_p, c_uint64, POINTER(c_uint32), c_size_t, POINTER(c_int), POINTER(ShardResult),
+                                                   c_void_p, c_void_p]),
+    ("bpp_batcher_verify_action", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_char_p, c_size_t]),
+    ("bpp_batcher_set_limits", c_int, [c_void_p, c_uint32, c_uint32]),
+    ("bpp_batcher_largest_pool", c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32)]),
+    ("bpp_runtime_info_get", c_int, [c_void_p, POINTER(RuntimeInfo)]),
+    ("bpp_small_call_limit", c_int, [c_void_p, c_int]),
     ("bpp_batcher_create", c_int, [c_void_p, c_uint64, c_void_p, c_uint32, c_uint32, c_uint32, POINTER(c_void_p)]),
     ("bpp_batcher_verify", c_int, [c_void_p, c_void_p, c_char_p, c_size_t]),
     ("bpp_batcher_stats", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),

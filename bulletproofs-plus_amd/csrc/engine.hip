@@ -78,10 +78,16 @@ struct DevBuf {
   }
 };
 
-// page-locked host memory: asynchronous copies to/from it do not stall other streams or host threads
+// page-locked host memory: asynchronous copies to/from it do not stall other streams or host threads.  It is also MAPPED
+// into the device's address space (coherent, never cached by the GPU): the verifier's kernels write their small results --
+// transcript-RNG bytes, status words, identity flags, masks -- straight into it and read the batch weights from it, so a
+// verification enqueues no copy at all (each hipMemcpyAsync of a few KB ran as a blit kernel of its own that queued behind
+// the other steps' 15 k-wavefront launches: five per step, 0.19 ms each with four steps in flight, two of them on the
+// PASS 1 -> weight chain -> PASS 2 critical path)
 template <typename T>
 struct PinnedBuf {
   T *p = nullptr;
+  T *d = nullptr;  // the same memory as the device sees it
   size_t n = 0;
   PinnedBuf() {}
   PinnedBuf(const PinnedBuf &) = delete;
@@ -93,16 +99,20 @@ struct PinnedBuf {
     if (count <= n && p) return;
     if (p) (void)hipHostFree(p);
     p = nullptr;
+    d = nullptr;
     if (count == 0) count = 1;
-    HIP_CHECK(hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocMapped | hipHostMallocPortable));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&d, p, 0));
     n = count;
   }
+  T *dev() { return d; }
   T *data() { return p; }
   const T *data() const { return p; }
   T &operator[](size_t i) { return p[i]; }
   const T &operator[](size_t i) const { return p[i]; }
   void swap(PinnedBuf &o) {
     std::swap(p, o.p);
+    std::swap(d, o.d);
     std::swap(n, o.n);
   }
 };
@@ -238,6 +248,102 @@ SharedRegistry<Precomp> &precomp_registry() {
   return *r;
 }
 
+// ------------------------------------------------------------------ per-device runtime state: admission gate, bookkeeping
+// A SMALL call (one reference batch of up to a few hundred proofs: what separate callers of RangeProof::verify_batch issue,
+// src/range_proof.rs:73-76,712-752) is a chain of about fifteen latency-bound kernels with tiny grids.  The chip runs about
+// six such chains side by side; more callers than that add nothing, and many more take it away: 8-16 callers with a context
+// each reached 5.3 k calls/s, 32 callers 2.6 k, 64 callers 1.6 k (profiles/r03_v10_calls_in_flight.jsonl) -- every context
+// brings a stream and a side stream, the runtime multiplexes them onto its hardware queues (GPU_MAX_HW_QUEUES, 4 unless the
+// host sets more) and streams that share a queue serialise behind each other's kernels.  So the library admits at most
+// `limit` small calls per device at a time (BPP_SMALL_CALLS_IN_FLIGHT, default 12; bpp_small_call_limit); the others wait
+// their turn in arrival order, on the host, holding nothing.  Large calls (they fill the chip by themselves) pass freely.
+struct DeviceState {
+  std::mutex mu;
+  struct Waiter {
+    std::condition_variable cv;
+    bool go = false;
+  };
+  std::deque<Waiter *> queue;
+  uint32_t limit = 12, in_flight = 0;
+  uint64_t small_calls = 0, small_calls_queued = 0;
+  uint32_t contexts = 0, contexts_peak = 0;
+  bool warned = false;
+};
+DeviceState &device_state(int dev) {
+  static std::mutex mu;
+  static std::map<int, DeviceState *> *all = new std::map<int, DeviceState *>();  // leaked: contexts may outlive static destruction
+  std::lock_guard<std::mutex> lk(mu);
+  DeviceState *&d = (*all)[dev];
+  if (!d) {
+    d = new DeviceState();
+    if (const char *e = getenv("BPP_SMALL_CALLS_IN_FLIGHT")) d->limit = (uint32_t)std::max(0, atoi(e));  // 0: no gate
+  }
+  return *d;
+}
+// hardware queues the HIP runtime multiplexes this process' streams onto: read once at its start-up from GPU_MAX_HW_QUEUES
+uint32_t runtime_hw_queues() {
+  static const uint32_t q = [] {
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? (uint32_t)v : 4u;
+  }();
+  return q;
+}
+thread_local int tl_gate_depth = 0;  // a thread that holds the gate passes it again (upload + verify of one call)
+struct GateHold {
+  DeviceState *d = nullptr;
+  GateHold(int dev, bool small) {
+    if (!small) return;
+    if (tl_gate_depth++ > 0) {
+      d = nullptr;
+      held_outer = true;
+      return;
+    }
+    DeviceState &D = device_state(dev);
+    std::unique_lock<std::mutex> lk(D.mu);
+    D.small_calls++;
+    if (D.limit == 0) {  // gate switched off: counted, never held
+      tl_gate_depth--;
+      return;
+    }
+    d = &D;
+    if (D.in_flight < D.limit && D.queue.empty()) {
+      D.in_flight++;
+      return;
+    }
+    D.small_calls_queued++;
+    DeviceState::Waiter w;
+    D.queue.push_back(&w);
+    w.cv.wait(lk, [&] { return w.go; });  // the releasing thread has already counted this call in
+  }
+  ~GateHold() {
+    if (held_outer) {
+      tl_gate_depth--;
+      return;
+    }
+    if (!d) return;
+    tl_gate_depth--;
+    std::lock_guard<std::mutex> lk(d->mu);
+    d->in_flight--;
+    while (!d->queue.empty() && d->in_flight < d->limit) {
+      DeviceState::Waiter *w = d->queue.front();
+      d->queue.pop_front();
+      d->in_flight++;
+      w->go = true;
+      w->cv.notify_one();
+    }
+  }
+  GateHold(const GateHold &) = delete;
+  GateHold &operator=(const GateHold &) = delete;
+
+ private:
+  bool held_outer = false;
+};
+// calls of up to this many proofs are "small" for the gate (their MSM has at most ~20 000 terms: BPP_SMALL_CALL_TERMS)
+#define BPP_GATE_SMALL_PROOFS 1024u
+// proof + commitment bytes of an upload up to this size travel with the small arrays in k_ingest; above it by DMA
+#define BPP_INGEST_MAX_BYTES (1u << 20)
+
 struct MsmWork {
   DevBuf<uint32_t> counts, starts, sorted, order, order_win, cls_hist;
   DevBuf<ge> buckets, Q, W, R;
@@ -286,9 +392,11 @@ struct Batch {
   size_t last_chunk = (size_t)-1;
   uint32_t G = 0;
   std::vector<uint32_t> h_group_first;
-  PinnedBuf<uint8_t> h_rng, h_weights;
+  PinnedBuf<uint8_t> h_rng, h_weights, h_masks;  // mapped: written / read by the kernels directly (PinnedBuf)
   PinnedBuf<uint32_t> h_status, h_ident;
   bool have_trace = false, phase1_done = false;
+  bool status_clean = false;     // status[] == status0[]: k_results_out resets it behind every verification
+  bool weights_on_host = false;  // the last PASS 2 read its weights from h_weights (b.weights holds them only in the sharded forms)
   bool seeds_dirty = false, masks_dirty = false;  // device copies of seed nonces / recovered masks not yet wiped
 };
 
@@ -304,7 +412,7 @@ void adopt_buffers(Batch &dst, Batch &src) {
   BPP_ADOPT(msm.cls_hist);
   BPP_ADOPT(msm.buckets); BPP_ADOPT(msm.Q); BPP_ADOPT(msm.W); BPP_ADOPT(msm.R); BPP_ADOPT(msm.comp32);
   BPP_ADOPT(msm.is_identity); BPP_ADOPT(msm.term_sidx); BPP_ADOPT(msm.term_pidx); BPP_ADOPT(msm.group_off);
-  BPP_ADOPT(h_rng); BPP_ADOPT(h_weights); BPP_ADOPT(h_status); BPP_ADOPT(h_ident);
+  BPP_ADOPT(h_rng); BPP_ADOPT(h_weights); BPP_ADOPT(h_status); BPP_ADOPT(h_ident); BPP_ADOPT(h_masks);
 #undef BPP_ADOPT
 }
 
@@ -431,7 +539,7 @@ int fail(bpp_ctx *ctx, int code, const std::string &m, char *errbuf = nullptr, s
 }
 
 enum Mark { M_START = 0, M_TRANSCRIPTS, M_DECOMPRESS, M_SCALARS, M_WEIGHTS_IN, M_LANES, M_REDUCE, M_DIGITS, M_SORT, M_ORDER, M_ACC,
-            M_BUCKET, M_FINAL, M_COUNT };
+            M_BUCKET, M_FINAL, M_MASKS0, M_MASKS, M_COUNT };
 
 struct StageTimer {
   bpp_ctx *ctx;
@@ -500,7 +608,9 @@ bool msm_wants_split(const bpp_ctx *ctx, uint32_t n_terms) {
   return n_terms <= BPP_SPLIT_CALL_TERMS && ctx->opt.msm_quad != 0;
 }
 // goff: term offsets of the groups as the kernels will see them (already doubled for a split plan)
-void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff, bool split = false) {
+// copy_goff: the group offsets go to the device by a copy of their own (msm_prepare); layout_groups hands them to
+// k_layout_terms through mapped host memory instead
+void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff, bool split = false, bool copy_goff = true) {
   const uint32_t G = (uint32_t)goff.size() - 1, n = goff[G];
   uint32_t maxg = 0;
   for (uint32_t g = 0; g < G; g++) maxg = std::max(maxg, goff[g + 1] - goff[g]);
@@ -524,10 +634,10 @@ void msm_plan_alloc(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &goff,
   w.term_sidx.alloc(n);
   w.term_pidx.alloc(n);
   w.group_off.alloc(G + 1);
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));  // pin_small may still feed an earlier copy
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));  // pin_small may still feed an earlier copy / kernel
   ctx->pin_small.resize(3 * (size_t)(G + 1));
   memcpy(ctx->pin_small.data(), goff.data(), (G + 1) * 4);
-  HIP_CHECK(hipMemcpyAsync(w.group_off.p, ctx->pin_small.data(), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (copy_goff) HIP_CHECK(hipMemcpyAsync(w.group_off.p, ctx->pin_small.data(), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
 }
 
 void msm_prepare(bpp_ctx *ctx, MsmWork &w, const std::vector<uint32_t> &sidx, const std::vector<uint32_t> &pidx,
@@ -680,6 +790,20 @@ int bpp_ctx_create_on_stream(bpp_ctx **out, int device_id, void *hip_stream) {
     }
     c->own_stream = true;
   }
+  {  // bookkeeping: every context brings a stream (and, for small inputs, a side stream) onto the runtime's hardware queues
+    DeviceState &D = device_state(device_id);
+    std::lock_guard<std::mutex> lk(D.mu);
+    D.contexts++;
+    D.contexts_peak = std::max(D.contexts_peak, D.contexts);
+    const uint32_t q = runtime_hw_queues();
+    if (D.contexts > q) {  // not an error: the call succeeds, the note sits where bpp_ctx_last_error finds it
+      char note[256];
+      snprintf(note, sizeof(note), "note: %u contexts on %u hardware queues (GPU_MAX_HW_QUEUES=%u, read by the HIP runtime at start-up): "
+               "streams beyond that share queues and their kernels serialise; see INTEGRATION.md, runtime preconditions", D.contexts, q, q);
+      c->err = note;
+      D.warned = true;
+    }
+  }
   *out = c;
   return BPP_OK;
 }
@@ -714,7 +838,48 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
   for (auto &e : ctx->prove_events) (void)hipEventDestroy(e);
   ctx->prove_arena.release();
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  {
+    DeviceState &D = device_state(ctx->device);
+    std::lock_guard<std::mutex> lk(D.mu);
+    if (D.contexts) D.contexts--;
+  }
   delete ctx;
+}
+
+int bpp_runtime_info_get(bpp_ctx *ctx, bpp_runtime_info *out) {
+  if (!ctx || !out) return BPP_ERR_BAD_HANDLE;
+  memset(out, 0, sizeof(*out));
+  DeviceState &D = device_state(ctx->device);
+  std::lock_guard<std::mutex> lk(D.mu);
+  out->device = ctx->device;
+  out->contexts = D.contexts;
+  out->contexts_peak = D.contexts_peak;
+  out->hw_queues = runtime_hw_queues();
+  out->host_threads = host_pool_size();
+  out->small_call_limit = D.limit;
+  out->small_calls_in_flight = D.in_flight;
+  out->small_calls = D.small_calls;
+  out->small_calls_queued = D.small_calls_queued;
+  out->oversubscribed = D.contexts > out->hw_queues ? 1u : 0u;
+  return BPP_OK;
+}
+
+int bpp_small_call_limit(bpp_ctx *ctx, int limit) {
+  if (!ctx) return BPP_ERR_BAD_HANDLE;
+  DeviceState &D = device_state(ctx->device);
+  std::lock_guard<std::mutex> lk(D.mu);
+  const int before = (int)D.limit;
+  if (limit >= 0) {
+    D.limit = (uint32_t)limit;
+    while (!D.queue.empty() && (D.limit == 0 || D.in_flight < D.limit)) {  // a wider (or removed) gate lets waiting calls in
+      DeviceState::Waiter *w = D.queue.front();
+      D.queue.pop_front();
+      D.in_flight++;
+      w->go = true;
+      w->cv.notify_one();
+    }
+  }
+  return before;
 }
 
 const char *bpp_ctx_last_error(bpp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
@@ -1130,14 +1295,33 @@ uint64_t upload_device(bpp_ctx *ctx, const std::shared_ptr<Params> &Pp, uint64_t
       uint8_t *st = ctx->pin_upload2.data();
       L = Lp;  // from here on the staging holds nonces (if any)
       upload_fill_small(pl, B->desc.data(), n_items, st, L);
-      HIP_CHECK(hipMemcpyAsync(B->bytes.p, bytes, bytes_len, hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(B->d_desc.p, st + L.o_desc, n_items * sizeof(ProofDesc), hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(B->minvals.p, st + L.o_min, minvals.size() * 8, hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(B->states.p, st + L.o_state, states.size(), hipMemcpyHostToDevice, s));
+      // ONE launch reads the pieces out of the mapped staging (k_ingest) and clears the two status arrays; only the proof
+      // bytes of a large batch (tens of MB) go by DMA.  (Six copies / memsets were six blit kernels in front of every call.)
+      B->status0.alloc(n_items);
+      B->status.alloc(n_items);
+      uint8_t *st_dev = ctx->pin_upload2.dev();
+      IngestArgs ia;
+      memset(&ia, 0, sizeof(ia));
+      auto seg = [&](const uint8_t *src, void *dst, size_t nbytes) {
+        if (nbytes) ia.seg[ia.n_seg++] = IngestSeg{src, (uint8_t *)dst, nbytes};
+      };
+      const bool bytes_by_dma = bytes_len > BPP_INGEST_MAX_BYTES;
+      if (bytes_by_dma) HIP_CHECK(hipMemcpyAsync(B->bytes.p, bytes, bytes_len, hipMemcpyHostToDevice, s));
+      else seg(ctx->pin_upload.dev(), B->bytes.p, bytes_len);
+      seg(st_dev + L.o_desc, B->d_desc.p, n_items * sizeof(ProofDesc));
+      seg(st_dev + L.o_min, B->minvals.p, minvals.size() * 8);
+      seg(st_dev + L.o_state, B->states.p, states.size());
       if (L.n_seed) {
         B->seeds_dirty = true;
-        HIP_CHECK(hipMemcpyAsync(B->seeds.p, st + L.o_seed, L.n_seed, hipMemcpyHostToDevice, s));
+        seg(st_dev + L.o_seed, B->seeds.p, L.n_seed);
       }
+      ia.zero[0] = B->status0.p;
+      ia.zero[1] = B->status.p;
+      ia.zero_words = (uint32_t)n_items;
+      size_t most = n_items * 4;
+      for (uint32_t q = 0; q < ia.n_seg; q++) most = std::max<size_t>(most, ia.seg[q].bytes);
+      hipLaunchKernelGGL(k_ingest, dim3((uint32_t)std::min<size_t>(2048, std::max<size_t>(1, most / (16 * 256)))), dim3(256), 0, s, ia);
+      HIP_CHECK(hipGetLastError());
     }
     // point sources in dynamic-slot order C_j.., A1, B, A, L.., R.. and the two slot lists, written by one lane per proof
     hipLaunchKernelGGL(k_build_slots, dim3(cdiv((uint32_t)n_items, 64)), dim3(64), 0, s, B->d_desc.p, (uint32_t)n_items, P.t,
@@ -1147,7 +1331,6 @@ uint64_t upload_device(bpp_ctx *ctx, const std::shared_ptr<Params> &Pp, uint64_t
     B->chal.alloc((size_t)n_items * B->cs);
     B->rng_out.alloc(n_items * 32);
     B->weights.alloc(n_items * 32);
-    B->status.alloc(n_items);
     B->dynpts.alloc(dyn);
     if (decompress_spill_enabled()) B->dec_spill.alloc((size_t)30 * (dyn - B->sum_m));
     B->rows.alloc((size_t)n_items * B->cols);
@@ -1196,15 +1379,17 @@ uint64_t upload_device(bpp_ctx *ctx, const std::shared_ptr<Params> &Pp, uint64_t
     }
     // initial per-proof status of every verification of this batch: caller-side PASS-1 findings (if any) and the
     // statement's commitments, decoded here once (the reference's RangeStatement holds decompressed points)
-    B->status0.alloc(n_items);
-    if (B->ext_challenges)
+    // (k_ingest cleared status0[] and status[]; commitments that do not decode are recorded in both: every verification finds
+    // status[] == status0[] and leaves it so (k_results_out), no copy in front of PASS 1)
+    if (B->ext_challenges) {
       HIP_CHECK(hipMemcpyAsync(B->status0.p, B->d_ext_status.p, n_items * 4, hipMemcpyDeviceToDevice, s));
-    else
-      HIP_CHECK(hipMemsetAsync(B->status0.p, 0, n_items * 4, s));
+      HIP_CHECK(hipMemcpyAsync(B->status.p, B->d_ext_status.p, n_items * 4, hipMemcpyDeviceToDevice, s));
+    }
     if (B->sum_m)
       hipLaunchKernelGGL(k_decompress, dim3(cdiv(B->sum_m, 64)), dim3(64), 0, s, B->bytes.p, B->src_off.p, B->owner.p,
-                         B->idx_commit.p, B->sum_m, B->dynpts.p, B->status0.p, (uint32_t *)nullptr);
+                         B->idx_commit.p, B->sum_m, B->dynpts.p, B->status0.p, (uint32_t *)nullptr, B->status.p);
     HIP_CHECK(hipGetLastError());
+    B->status_clean = true;
     HIP_CHECK(hipStreamSynchronize(s));
     const uint64_t h = g_next_handle.fetch_add(1);
     ctx->batches[h] = std::move(B);
@@ -1297,7 +1482,10 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
     HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_rng, hipEventDisableTiming));
     ctx->ev_rng_ready = true;
   }
-  HIP_CHECK(hipMemcpyAsync(b.status.p, b.status0.p, (size_t)b.B * 4, hipMemcpyDeviceToDevice, s));
+  // status[] starts as status0[]: the previous verification's last kernel left it so (k_results_out), unless that call died
+  // half way
+  if (!b.status_clean) HIP_CHECK(hipMemcpyAsync(b.status.p, b.status0.p, (size_t)b.B * 4, hipMemcpyDeviceToDevice, s));
+  b.status_clean = false;
   // Decompression needs nothing PASS 1 produces (both only OR bits into status[]).  A small input leaves most of the chip
   // idle, so its decompression runs beside PASS 1 and the weight-free scalars on a second stream and joins before the
   // weights are needed (one 256-proof call 0.84 -> 0.79 ms).  Large inputs fill the chip either way: one stream, less
@@ -1306,7 +1494,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
   const uint32_t n_proof_pts = b.total_dyn - b.sum_m;
   auto launch_decompress = [&](hipStream_t st) {
     hipLaunchKernelGGL(k_decompress, dim3(cdiv(n_proof_pts, 64)), dim3(64), 0, st, b.bytes.p, b.src_off.p, b.owner.p,
-                       b.idx_proof.p, n_proof_pts, b.dynpts.p, b.status.p, b.dec_spill.p);
+                       b.idx_proof.p, n_proof_pts, b.dynpts.p, b.status.p, b.dec_spill.p, (uint32_t *)nullptr);
     // half-scalar plan of small calls: the 2^126 multiples of every dynamic point (the statements' commitments were decoded
     // at upload), 126 doublings each, right behind the decompression and -- for small inputs -- beside PASS 1 and the scalars.
     // A point that did not decode left an arbitrary entry: its multiple is never looked at (the call fails on the status).
@@ -1332,16 +1520,18 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
     // small inputs: one proof per wavefront (latency); large inputs: one proof per lane (issue slots)
     const int force_wave = ctx->opt.transcripts_wave;  // (tests force either kernel)
     const bool wave = force_wave >= 0 ? force_wave != 0 : b.B <= BPP_TRANSCRIPTS_WAVE_MAX;
+    uint8_t *rng_host = fetch_rng ? b.h_rng.dev() : nullptr;  // mapped page-locked memory: no device-to-host copy behind PASS 1
     if (wave)
       hipLaunchKernelGGL(k_transcripts_wave, dim3(b.B), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.states.p,
-                         P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p);
+                         P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p, rng_host);
     else
       hipLaunchKernelGGL(k_transcripts, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.states.p,
-                         P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p);
+                         P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p, rng_host);
   }
   tm.mark(M_TRANSCRIPTS);
-  if (fetch_rng) HIP_CHECK(hipMemcpyAsync(b.h_rng.data(), b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToHost, s));
-  else if (rng_dst_pitch && rng_dst_pitch != rng_row_bytes)  // rows of one group each, padded to the widest rank's shard
+  if (fetch_rng) {
+    // (nothing to copy: PASS 1 wrote the bytes the weight chain reads into h_rng itself; the event below tells the host)
+  } else if (rng_dst_pitch && rng_dst_pitch != rng_row_bytes)  // rows of one group each, padded to the widest rank's shard
     HIP_CHECK(hipMemcpy2DAsync(rng_dev_dst, rng_dst_pitch, b.rng_out.p, rng_row_bytes, rng_row_bytes, ((size_t)b.B * 32) / rng_row_bytes,
                                hipMemcpyDeviceToDevice, s));
   else HIP_CHECK(hipMemcpyAsync(rng_dev_dst, b.rng_out.p, (size_t)b.B * 32, hipMemcpyDeviceToDevice, s));  // gathered over RCCL
@@ -1522,9 +1712,21 @@ void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const u
   pool.parallel_for((uint32_t)units.size(), run_unit);
 }
 
-void fetch_status(bpp_ctx *ctx, Batch &b) {
-  HIP_CHECK(hipMemcpyAsync(b.h_status.data(), b.status.p, (size_t)b.B * 4, hipMemcpyDeviceToHost, ctx->stream));
+// status words (and, where asked for, the groups' identity flags and the recovered masks) -> mapped host memory, status[]
+// back to its initial value: one launch, no copy (kernels_verify.h: k_results_out).  Valid on the host once the stream has
+// been synchronised.
+void fetch_results(bpp_ctx *ctx, Batch &b, bool ident, bool masks) {
+  if (ident) b.h_ident.resize(b.G);
+  const uint32_t pieces = masks ? (uint32_t)(((size_t)b.B * b.params->t * 32) / 16) : 0u;
+  if (masks) b.h_masks.resize((size_t)pieces * 16);
+  const uint32_t items = std::max(b.B, ident ? b.G : 0u);
+  hipLaunchKernelGGL(k_results_out, dim3(cdiv(items, 256)), dim3(256), 0, ctx->stream, b.status.p, b.status0.p, b.h_status.dev(), b.B,
+                     ident ? b.msm.is_identity.p : (const uint32_t *)nullptr, ident ? b.h_ident.dev() : (uint32_t *)nullptr, b.G,
+                     masks ? (const uint4 *)b.masks.p : (const uint4 *)nullptr, masks ? (uint4 *)b.h_masks.dev() : (uint4 *)nullptr, pieces);
+  HIP_CHECK(hipGetLastError());
+  b.status_clean = true;  // (in stream order: whatever is enqueued behind this launch finds status0)
 }
+void fetch_status(bpp_ctx *ctx, Batch &b) { fetch_results(ctx, b, false, false); }
 
 // reference error precedence for proofs [p0, p1) treated as one verify() call (upload_host.h: check_chunk_errors)
 void check_chunk_errors(const Batch &b, uint32_t p0, uint32_t p1) {
@@ -1577,17 +1779,18 @@ void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk, const std::vector<uint3
     maxg *= 2;
     b.dyn_hi.alloc(b.total_dyn);
   }
-  msm_plan_alloc(ctx, b.msm, goff, split);  // leaves goff in pin_small[0 .. G]
+  msm_plan_alloc(ctx, b.msm, goff, split, false);  // leaves goff in pin_small[0 .. G]
   b.group_dlo.alloc(G + 1);
   uint32_t *pin = ctx->pin_small.data();
   memcpy(pin + (G + 1), b.h_group_first.data(), (G + 1) * 4);
   memcpy(pin + 2 * (size_t)(G + 1), dlo.data(), (G + 1) * 4);
-  HIP_CHECK(hipMemcpyAsync(b.group_first.p, pin + (G + 1), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIP_CHECK(hipMemcpyAsync(b.group_dlo.p, pin + 2 * (size_t)(G + 1), (G + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_layout_terms, dim3(cdiv(split ? maxg / 2 : maxg, 256), G), dim3(256), 0, ctx->stream, b.msm.group_off.p, b.group_dlo.p, G,
-                     b.cols, b.max_mn, n_gen, P.table_len, split ? 1u : 0u, b.msm.term_sidx.p, b.msm.term_pidx.p);
+  // the three small arrays are read by k_layout_terms where they are (mapped host memory); it also leaves the device copies
+  const uint32_t *pin_dev = ctx->pin_small.dev();
+  hipLaunchKernelGGL(k_layout_terms, dim3(cdiv(split ? maxg / 2 : maxg, 256), G), dim3(256), 0, ctx->stream, pin_dev, pin_dev + 2 * (size_t)(G + 1),
+                     pin_dev + (G + 1), G, b.cols, b.max_mn, n_gen, P.table_len, split ? 1u : 0u, b.msm.term_sidx.p, b.msm.term_pidx.p,
+                     b.msm.group_off.p, b.group_dlo.p, b.group_first.p);
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));  // goff / dlo are locals
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));  // pin_small is reused by the next plan
   b.last_chunk = bounds ? (size_t)-1 : chunk;
 }
 
@@ -1597,7 +1800,9 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool weights_residen
   Params &P = *b.params;
   hipStream_t s = ctx->stream;
   // (weights_resident: the grouped sharded form has put them into b.weights device -> device already)
-  if (!weights_resident) HIP_CHECK(hipMemcpyAsync(b.weights.p, b.h_weights.data(), (size_t)b.B * 32, hipMemcpyHostToDevice, s));
+  // otherwise k_scalars_lanes reads them where the chains wrote them: h_weights is mapped, each weight is read once
+  b.weights_on_host = !weights_resident;
+  const uint8_t *weights = weights_resident ? b.weights.p : b.h_weights.dev();
   tm.mark(M_WEIGHTS_IN);
   sc *dyn_scal = b.scal.p + (size_t)b.G * b.cols;
   {
@@ -1609,7 +1814,7 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool weights_residen
     const uint32_t per_wg = b.B <= BPP_TABLES_WAVE_MAX ? 256u : 1024u;
     const uint32_t ppw = std::max<uint32_t>(1, std::min<uint32_t>(BPP_LANES_MAX_PPW, per_wg / std::max<uint32_t>(1, b.max_mn)));
     hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s, b.d_desc.p, b.tab.p, b.shr.p,
-                       b.weights.p, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, b.rows.p, dyn_scal);
+                       weights, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, b.rows.p, dyn_scal);
   }
   tm.mark(M_LANES);
   hipLaunchKernelGGL(k_reduce_static, dim3(cdiv(b.cols, BPP_REDUCE_TILE), b.G), dim3(64), 0, s, b.rows.p, b.group_first.p, b.cols,
@@ -1634,6 +1839,7 @@ void collect_profile(bpp_ctx *ctx, Batch &b, StageTimer &tm, float chain_ms, flo
   pf.msm_accumulate_ms = tm.between(M_ORDER, M_ACC);
   pf.msm_bucket_reduce_ms = tm.between(M_ACC, M_BUCKET);
   pf.msm_final_ms = tm.between(M_BUCKET, M_FINAL);
+  pf.masks_ms = tm.between(M_MASKS0, M_MASKS);
   pf.total_ms = total_host_ms;
   pf.msm_terms = b.msm.plan.n_terms;
   pf.msm_window_bits = b.msm.plan.c;
@@ -1662,8 +1868,18 @@ int bpp_batch_prepare(bpp_ctx *ctx, uint64_t batch, size_t chunk) {
   BPP_CATCH(ctx, nullptr, 0)
 }
 
+// proofs of a resident batch (0: unknown handle), read under the context's lock: the gate is always taken BEFORE that lock
+static uint32_t batch_size_peek(bpp_ctx *ctx, uint64_t batch) {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  auto it = ctx->batches.find(batch);
+  return it == ctx->batches.end() ? 0u : it->second->B;
+}
+
 int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, uint8_t *masks_out, uint8_t *mask_present,
                         char *errbuf, size_t errbuf_len) {
+  if (!ctx) return BPP_ERR_BAD_HANDLE;
+  const uint32_t n_peek = batch_size_peek(ctx, batch);
+  GateHold gate(ctx->device, n_peek && n_peek <= BPP_GATE_SMALL_PROOFS);  // small calls queue for the device (DeviceState)
   BPP_ENTRY(ctx);
   try {
     auto it = ctx->batches.find(batch);
@@ -1685,11 +1901,15 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
     enqueue_phase1(ctx, b, tm, pass1_only || action == BPP_RECOVER_ONLY);
 
     float chain_ms = 0;
-    std::vector<uint8_t> h_masks;  // recovered masks on their way to the caller: wiped on every exit (src/extended_mask.rs:14)
-    ScopeExit wipe_masks{[&] { wipe(h_masks.data(), h_masks.size()); }};
+    // recovered masks on their way to the caller (page-locked, written by k_results_out): wiped on every exit (src/extended_mask.rs:14)
+    bool have_masks = false;
+    ScopeExit wipe_masks{[&] {
+      if (have_masks) wipe(b.h_masks.data(), std::min(b.h_masks.n, (size_t)b.B * P.t * 32));
+    }};
     b.h_ident.resize(b.G);
     for (uint32_t g = 0; g < b.G; g++) b.h_ident[g] = 1;
     auto &h_ident = b.h_ident;
+    const uint8_t *h_masks = nullptr;
     if (!pass1_only) {
       // weight chains: one per chunk (src/range_proof.rs:811,849,853,894); the device keeps working meanwhile
       auto c0 = std::chrono::steady_clock::now();
@@ -1698,20 +1918,21 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
       }
       chain_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c0).count();
       if (action != BPP_VERIFY_ONLY && b.any_seed) {  // masks (:941-969)
+        tm.mark(M_MASKS0);
         hipLaunchKernelGGL(k_masks, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.chal.p, b.seeds.p,
                            P.n_bits, P.t, b.cs, b.B, b.masks.p);
+        tm.mark(M_MASKS);
         b.masks_dirty = true;
-        h_masks.resize((size_t)b.B * P.t * 32);
-        HIP_CHECK(hipMemcpyAsync(h_masks.data(), b.masks.p, h_masks.size(), hipMemcpyDeviceToHost, s));
+        have_masks = true;
       }
       if (want_msm) {
         enqueue_phase2(ctx, b, tm);
-        HIP_CHECK(hipMemcpyAsync(h_ident.data(), b.msm.is_identity.p, (size_t)b.G * 4, hipMemcpyDeviceToHost, s));
         b.have_trace = true;
       }
     }
-    fetch_status(ctx, b);
+    fetch_results(ctx, b, want_msm, have_masks);
     HIP_CHECK(hipStreamSynchronize(s));
+    if (have_masks) h_masks = b.h_masks.data();
     auto t_end = std::chrono::steady_clock::now();
     collect_profile(ctx, b, tm, chain_ms, std::chrono::duration<float, std::milli>(t_end - t_begin).count());
 
@@ -1738,61 +1959,115 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
 }
 
 // Reference batches of DIFFERENT sizes in one call: group g = proofs [group_first[g], group_first[g + 1]) of the resident
-// batch, every group verified as its own verify() call (VerifyOnly) by the same kernel launches, with its own outcome --
-// where bpp_verify_resident cuts equal chunks and stops at the first failing one.  What a pool of small calls needs
-// (bpp_batcher below).
-int bpp_verify_resident_groups(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first, size_t n_groups, bpp_shard_result *results) {
-  BPP_ENTRY(ctx);
+// batch, every group verified as its own verify() call by the same kernel launches, with its own outcome and its own
+// VerifyAction (src/range_proof.rs:46-54) -- where bpp_verify_resident cuts equal chunks and stops at the first failing one.
+// What a pool of small calls needs (bpp_batcher below).  actions == nullptr: VerifyOnly for every group.
+// Masks (:941-969): a group whose action recovers them and whose verify() would have returned Ok gets the masks of its items
+// that carry a seed nonce; every other item's slot is zero / absent (an Err returns no masks).  A RecoverOnly group never
+// looks at the final check (:1040-1043); when EVERY group is RecoverOnly the weight chains and PASS 2 are not run at all.
+}  // extern "C"
+namespace {
+int verify_groups_core(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first, size_t n_groups, const int *actions,
+                       bpp_shard_result *results, uint8_t *masks_out, uint8_t *mask_present) {
   try {
     auto it = ctx->batches.find(batch);
     if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle");
     if (!group_first || !results || n_groups == 0) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument");
     Batch &b = *it->second;
+    Params &P = *b.params;
     std::vector<uint32_t> bounds(group_first, group_first + n_groups + 1);
     if (bounds.front() != 0 || bounds.back() != b.B) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "group boundaries must run from 0 to the batch size");
     for (size_t g = 0; g < n_groups; g++)
       if (bounds[g] >= bounds[g + 1]) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "empty or unordered group");
+    bool want_msm = false, want_masks = false;
+    for (size_t g = 0; g < n_groups; g++) {
+      const int a = actions ? actions[g] : BPP_VERIFY_ONLY;
+      if (a < 0 || a > 2) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "unknown verify action");
+      want_msm = want_msm || a != BPP_RECOVER_ONLY;
+      want_masks = want_masks || a != BPP_VERIFY_ONLY;
+    }
+    want_masks = want_masks && b.any_seed;
     auto t_begin = std::chrono::steady_clock::now();
     StageTimer tm(ctx);
     hipStream_t s = ctx->stream;
     layout_groups(ctx, b, 0, &bounds);
     // the kernels tolerate odd shapes and run on every item (as bpp_verify_resident does with several chunks); findings are
     // raised per group afterwards, in the reference's order
-    enqueue_phase1(ctx, b, tm, false);
+    enqueue_phase1(ctx, b, tm, !want_msm);
     b.h_ident.resize(b.G);
     for (uint32_t g = 0; g < b.G; g++) b.h_ident[g] = 1;
-    auto c0 = std::chrono::steady_clock::now();
-    run_weight_chains(b);
-    const float chain_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c0).count();
-    enqueue_phase2(ctx, b, tm);
-    HIP_CHECK(hipMemcpyAsync(b.h_ident.data(), b.msm.is_identity.p, (size_t)b.G * 4, hipMemcpyDeviceToHost, s));
-    b.have_trace = true;
-    fetch_status(ctx, b);
+    ScopeExit wipe_masks{[&] {
+      if (want_masks) wipe(b.h_masks.data(), std::min(b.h_masks.n, (size_t)b.B * P.t * 32));
+    }};
+    float chain_ms = 0;
+    if (want_msm) {
+      auto c0 = std::chrono::steady_clock::now();
+      run_weight_chains(b);
+      chain_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c0).count();
+    }
+    if (want_masks) {
+      hipLaunchKernelGGL(k_masks, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.chal.p, b.seeds.p, P.n_bits, P.t, b.cs, b.B,
+                         b.masks.p);
+      b.masks_dirty = true;
+    }
+    if (want_msm) {
+      enqueue_phase2(ctx, b, tm);
+      b.have_trace = true;
+    }
+    fetch_results(ctx, b, want_msm, want_masks);
     HIP_CHECK(hipStreamSynchronize(s));
     collect_profile(ctx, b, tm, chain_ms, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     for (uint32_t g = 0; g < b.G; g++) {
       bpp_shard_result &r = results[g];
       memset(&r, 0, sizeof(r));
       r.rank = -1;
+      const int a = actions ? actions[g] : BPP_VERIFY_ONLY;
+      const uint32_t p0 = b.h_group_first[g], p1 = b.h_group_first[g + 1];
       try {
-        if (b.any_defer) check_deferred(b.defer, b.h_group_first[g], b.h_group_first[g + 1]);
-        check_chunk_errors(b, b.h_group_first[g], b.h_group_first[g + 1]);
-        if (!b.h_ident[g]) throw ProofErr{BPP_ERR_VERIFICATION_FAILED, "Range proof batch not valid", BPP_TIER_MSM, b.h_group_first[g]};
+        if (b.any_defer) check_deferred(b.defer, p0, p1);
+        check_chunk_errors(b, p0, p1);
+        if (a != BPP_RECOVER_ONLY && !b.h_ident[g]) throw ProofErr{BPP_ERR_VERIFICATION_FAILED, "Range proof batch not valid", BPP_TIER_MSM, p0};
       } catch (const ProofErr &e) {
         r.code = e.code;
         r.tier = e.tier;
-        r.index = e.index - b.h_group_first[g];  // position inside the group's own batch
+        r.index = e.index - p0;  // position inside the group's own batch
         snprintf(r.msg, sizeof(r.msg), "%s", e.msg.c_str());
+      }
+      const bool give = a != BPP_VERIFY_ONLY && r.code == BPP_OK;
+      for (uint32_t p = p0; p < p1; p++) {
+        const bool present = give && (b.desc[p].flags & 1u);
+        if (mask_present) mask_present[p] = present ? 1 : 0;
+        if (masks_out) {
+          if (present) memcpy(masks_out + (size_t)p * P.t * 32, b.h_masks.data() + (size_t)p * P.t * 32, (size_t)P.t * 32);
+          else memset(masks_out + (size_t)p * P.t * 32, 0, (size_t)P.t * 32);
+        }
       }
     }
     return BPP_OK;
   }
   BPP_CATCH(ctx, nullptr, 0)
 }
+}  // namespace
+extern "C" {
+
+int bpp_verify_resident_groups_actions(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first, size_t n_groups, const int *actions,
+                                       bpp_shard_result *results, uint8_t *masks_out, uint8_t *mask_present) {
+  if (!ctx) return BPP_ERR_BAD_HANDLE;
+  const uint32_t n_peek = batch_size_peek(ctx, batch);
+  GateHold gate(ctx->device, n_peek && n_peek <= BPP_GATE_SMALL_PROOFS);  // small calls queue for the device (DeviceState)
+  BPP_ENTRY(ctx);
+  return verify_groups_core(ctx, batch, group_first, n_groups, actions, results, masks_out, mask_present);
+}
+
+int bpp_verify_resident_groups(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first, size_t n_groups, bpp_shard_result *results) {
+  return bpp_verify_resident_groups_actions(ctx, batch, group_first, n_groups, nullptr, results, nullptr, nullptr);
+}
 
 int bpp_verify_batch_with_challenges(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items,
                                      const uint8_t *const *challenges32, const uint8_t *rng_out32, int action, size_t chunk,
                                      uint8_t *masks_out, uint8_t *mask_present, char *errbuf, size_t errbuf_len) {
+  if (!ctx) return BPP_ERR_BAD_HANDLE;
+  GateHold gate(ctx->device, n_items <= BPP_GATE_SMALL_PROOFS);  // held across upload and verification of a small call
   uint64_t h = 0;
   int rc;
   {
@@ -1808,6 +2083,8 @@ int bpp_verify_batch_with_challenges(bpp_ctx *ctx, uint64_t params, const bpp_ve
 
 int bpp_verify_batch(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items, size_t n_items, int action,
                      size_t chunk, uint8_t *masks_out, uint8_t *mask_present, char *errbuf, size_t errbuf_len) {
+  if (!ctx) return BPP_ERR_BAD_HANDLE;
+  GateHold gate(ctx->device, n_items <= BPP_GATE_SMALL_PROOFS);
   uint64_t h = 0;
   int rc = bpp_batch_upload(ctx, params, items, n_items, &h, errbuf, errbuf_len);
   if (rc != BPP_OK) return rc;
@@ -1818,6 +2095,8 @@ int bpp_verify_batch(bpp_ctx *ctx, uint64_t params, const bpp_verify_item *items
 
 int bpp_verify_batch_packed(bpp_ctx *ctx, uint64_t params, const bpp_packed_batch *in, int action, size_t chunk,
                             uint8_t *masks_out, uint8_t *mask_present, char *errbuf, size_t errbuf_len) {
+  if (!ctx) return BPP_ERR_BAD_HANDLE;
+  GateHold gate(ctx->device, in && in->n_items <= BPP_GATE_SMALL_PROOFS);
   uint64_t h = 0;
   int rc = bpp_batch_upload_packed(ctx, params, in, &h, errbuf, errbuf_len);
   if (rc != BPP_OK) return rc;
@@ -1851,6 +2130,7 @@ void pipe_worker(bpp_ctx *owner, Pipeline *pp, PipeLane *lane) {
     err[0] = 0;
     uint64_t h = 0;
     int rc = BPP_OK;
+    GateHold gate(owner->device, job->n_items <= BPP_GATE_SMALL_PROOFS);
     {
       std::lock_guard<std::mutex> lk(c->mu);
       try {
@@ -2132,6 +2412,13 @@ int bpp_batch_trace(bpp_ctx *ctx, uint64_t batch, int what, uint8_t *out, size_t
         break;
       case BPP_TRACE_WEIGHTS:
         need = (size_t)b.B * 32;
+        if (b.weights_on_host) {  // PASS 2 read them from the mapped host buffer the chains wrote
+          if (written) *written = need;
+          if (!out || out_len < need) return fail(ctx, BPP_ERR_INVALID_LENGTH, "trace buffer too small");
+          HIP_CHECK(hipStreamSynchronize(s));
+          memcpy(out, b.h_weights.data(), need);
+          return BPP_OK;
+        }
         src = b.weights.p;
         break;
       case BPP_TRACE_STATIC_SCALARS:

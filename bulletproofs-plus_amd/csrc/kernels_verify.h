@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(64, BPP_TRANSCRIPTS_WAVES) k_transcripts(const
                                                     const uint8_t *__restrict__ states, const uint8_t *__restrict__ hg32,
                                                     uint32_t n_bits, uint32_t t, uint32_t B, uint32_t cs,
                                                     sc *__restrict__ chal, uint8_t *__restrict__ rng_out,
-                                                    uint32_t *__restrict__ status) {
+                                                    uint32_t *__restrict__ status, uint8_t *__restrict__ rng_host) {
   __shared__ uint32_t sponge[BPP_LS_WORDS * BPP_LS_STRIDE];  // word w of lane l at [w * 64 + l] (lstrobe.h)
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B) return;
@@ -105,6 +105,24 @@ __global__ void __launch_bounds__(64, BPP_TRANSCRIPTS_WAVES) k_transcripts(const
 #pragma unroll
   for (int i = 0; i < 8; i++) reinterpret_cast<uint32_t *>(rng_out)[(size_t)p * 8 + i] = out[i];
   if (!ok) atomicOr(&status[p], BPP_ST_TRANSCRIPT_FAIL);
+  // The host's copy (mapped page-locked memory: what the batch-weight chain reads, src/range_proof.rs:845-853) leaves the
+  // kernel as whole 64-byte lines: the wavefront's 2 KB are transposed through the (now dead) sponge and stored 16 bytes per
+  // lane, 1 KB contiguous per store -- a lane's own eight dwords, 32 bytes apart from its neighbour's, would cross the bus as
+  // partial lines.  The workgroup is one wavefront: its LDS operations execute in order.
+  if (rng_host) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) sponge[threadIdx.x * 8 + i] = out[i];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t p0 = blockIdx.x * blockDim.x, live = min(B - p0, 64u) * 2u;  // 16-byte pieces this wavefront owns
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) {
+      const uint32_t q = k * 64u + threadIdx.x;
+      if (q < live) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(&sponge[q * 4u]);
+        *reinterpret_cast<uint4 *>(rng_host + (size_t)p0 * 32 + (size_t)q * 16) = v;
+      }
+    }
+  }
 }
 
 // The same PASS 1 with one proof per WAVEFRONT on the cooperative sponge of wstrobe.h (state in LDS, 25-lane Keccak-f).
@@ -132,7 +150,7 @@ __global__ void __launch_bounds__(64) k_transcripts_wave(const uint8_t *__restri
                                                          const uint8_t *__restrict__ states, const uint8_t *__restrict__ hg32,
                                                          uint32_t n_bits, uint32_t t, uint32_t B, uint32_t cs,
                                                          sc *__restrict__ chal, uint8_t *__restrict__ rng_out,
-                                                         uint32_t *__restrict__ status) {
+                                                         uint32_t *__restrict__ status, uint8_t *__restrict__ rng_host) {
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
   if (p >= B) return;
   __shared__ TranscriptLds L;
@@ -188,6 +206,8 @@ __global__ void __launch_bounds__(64) k_transcripts_wave(const uint8_t *__restri
   wm_rng_finalize(s, K, ZeroAt{});
   wm_rng_fill(s, K, L.buf, 32);
   if (lane < 32) rng_out[(size_t)p * 32 + lane] = L.buf[lane];
+  if (rng_host && lane < 8)  // the host's copy (mapped page-locked memory), one 32-byte write per proof
+    reinterpret_cast<uint32_t *>(rng_host)[(size_t)p * 8 + lane] = reinterpret_cast<const uint32_t *>(L.buf)[lane];
   if (!ok && lane == 0) atomicOr(&status[p], BPP_ST_TRANSCRIPT_FAIL);
 }
 
@@ -199,7 +219,8 @@ __global__ void __launch_bounds__(64) k_transcripts_wave(const uint8_t *__restri
 __global__ void __launch_bounds__(64, BPP_DECOMPRESS_WAVES) k_decompress(const uint8_t *__restrict__ bytes, const uint32_t *__restrict__ src_off,
                                                    const uint32_t *__restrict__ owner, const uint32_t *__restrict__ idx, uint32_t n,
                                                    niels *__restrict__ out, uint32_t *__restrict__ status,
-                                                   uint32_t *__restrict__ spill /* [30][n] words or null */) {
+                                                   uint32_t *__restrict__ spill /* [30][n] words or null */,
+                                                   uint32_t *__restrict__ status_b = nullptr /* upload: the verifications' working copy */) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t e = idx[i];  // dynamic slot: the statement's commitments are decoded once at upload (the reference's
@@ -210,6 +231,7 @@ __global__ void __launch_bounds__(64, BPP_DECOMPRESS_WAVES) k_decompress(const u
     niels_identity(q);
     uint32_t o = owner[e];
     atomicOr(&status[o & 0x7fffffffu], (o >> 31) ? BPP_ST_COMMIT_FAIL : BPP_ST_DECOMPRESS_FAIL);
+    if (status_b) atomicOr(&status_b[o & 0x7fffffffu], (o >> 31) ? BPP_ST_COMMIT_FAIL : BPP_ST_DECOMPRESS_FAIL);
   }
   out[e] = q;
 }
@@ -785,11 +807,27 @@ __global__ void __launch_bounds__(64) k_build_slots(const ProofDesc *__restrict_
 // MSM term lists of a chunked batch: group g = its static columns, then the dynamic slots [dlo[g], dlo[g+1]) of its proofs.
 // term_sidx -> index into scal[] (static part G*cols first, then dynamic), term_pidx -> index into the point tables
 // (generator table first, then dynpts).  grid = (ceil(max terms per group / 256), G).
-__global__ void __launch_bounds__(256) k_layout_terms(const uint32_t *__restrict__ goff, const uint32_t *__restrict__ dlo, uint32_t G,
+// goff / dlo / gfirst arrive in mapped page-locked host memory ([G + 1] words each: three host-to-device copies were three
+// blit kernels per planned call); every workgroup reads the two or three words it needs from there, the first one of a
+// group leaves the device copies the other kernels use.
+__global__ void __launch_bounds__(256) k_layout_terms(const uint32_t *__restrict__ goff, const uint32_t *__restrict__ dlo,
+                                                      const uint32_t *__restrict__ gfirst, uint32_t G,
                                                       uint32_t cols, uint32_t max_mn, uint32_t n_gen, uint32_t table_len, uint32_t split,
-                                                      uint32_t *__restrict__ term_sidx, uint32_t *__restrict__ term_pidx) {
+                                                      uint32_t *__restrict__ term_sidx, uint32_t *__restrict__ term_pidx,
+                                                      uint32_t *__restrict__ goff_dev, uint32_t *__restrict__ dlo_dev,
+                                                      uint32_t *__restrict__ gfirst_dev) {
   const uint32_t g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t t0 = goff[g], ng = (goff[g + 1] - t0) >> split;  // half-scalar plan: ng low-half terms, then ng high-half ones
+  const uint32_t t0 = goff[g], t1 = goff[g + 1], ng = (t1 - t0) >> split;  // half-scalar plan: ng low-half terms, then ng high-half ones
+  if (i == 0) {
+    goff_dev[g] = t0;
+    dlo_dev[g] = dlo[g];
+    gfirst_dev[g] = gfirst[g];
+    if (g + 1 == G) {
+      goff_dev[G] = t1;
+      dlo_dev[G] = dlo[G];
+      gfirst_dev[G] = gfirst[G];
+    }
+  }
   if (i >= ng) return;
   uint32_t si, pi;
   if (i < cols) {
@@ -940,6 +978,58 @@ __global__ void k_chal_canonical(const sc *__restrict__ chal, uint32_t n, uint8_
   uint8_t o[32];
   sc_store_words(o, v);
   for (int k = 0; k < 32; k++) out[(size_t)i * 32 + k] = o[k];
+}
+
+// What an upload brings onto the device arrives in ONE launch as well: up to six pieces (proof bytes of a small batch,
+// descriptors, promises, transcript states, seed nonces) are read out of mapped page-locked staging, 16 bytes per lane, and up
+// to two word arrays are cleared (status0 / status).  Five hipMemcpyAsync + a memset were six blit kernels in front of every
+// small call; the proof bytes of a LARGE batch (tens of MB) still go by DMA.
+struct IngestSeg {
+  const uint8_t *src;
+  uint8_t *dst;
+  uint64_t bytes;
+};
+struct IngestArgs {
+  IngestSeg seg[6];
+  uint32_t n_seg;
+  uint32_t *zero[2];
+  uint32_t zero_words;
+};
+__global__ void __launch_bounds__(256) k_ingest(IngestArgs a) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  for (uint32_t s = 0; s < a.n_seg; s++) {
+    const IngestSeg g = a.seg[s];
+    size_t done = 0;
+    if ((((uintptr_t)g.src | (uintptr_t)g.dst) & 15u) == 0) {
+      const size_t n16 = g.bytes / 16;
+      for (size_t i = tid; i < n16; i += nth) reinterpret_cast<uint4 *>(g.dst)[i] = reinterpret_cast<const uint4 *>(g.src)[i];
+      done = n16 * 16;
+    }
+    for (size_t i = done + tid; i < g.bytes; i += nth) g.dst[i] = g.src[i];
+  }
+  for (int z = 0; z < 2; z++)
+    if (a.zero[z])
+      for (size_t i = tid; i < a.zero_words; i += nth) a.zero[z][i] = 0;
+}
+
+// The results of a verification leave the device in ONE launch, straight into mapped page-locked host memory (no copy
+// engine, no blit kernel per array): the per-proof status words, the per-group identity flags of the final check
+// (src/range_proof.rs:1057-1062) and the recovered masks (:941-969).  status[] is then reset to the batch's initial status
+// (statement commitments that do not decode, caller-side PASS-1 findings), so the next verification of the same resident batch
+// starts clean without a device-to-device copy in front of its first kernel.
+__global__ void __launch_bounds__(256) k_results_out(uint32_t *__restrict__ status, const uint32_t *__restrict__ status0,
+                                                     uint32_t *__restrict__ status_host, uint32_t B,
+                                                     const uint32_t *__restrict__ is_identity, uint32_t *__restrict__ ident_host,
+                                                     uint32_t G, const uint4 *__restrict__ masks, uint4 *__restrict__ masks_host,
+                                                     uint32_t mask_pieces) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) {
+    status_host[i] = status[i];
+    status[i] = status0[i];
+  }
+  if (is_identity && i < G) ident_host[i] = is_identity[i];
+  if (masks)
+    for (uint32_t q = i; q < mask_pieces; q += gridDim.x * blockDim.x) masks_host[q] = masks[q];
 }
 
 }  // namespace bpp

@@ -405,10 +405,12 @@ struct SmallStaging {
 };
 inline SmallStaging upload_small_layout(const UploadPlan &pl, size_t n_items) {
   SmallStaging L;
+  // every piece starts on a 16-byte boundary: k_ingest moves them 16 bytes per lane out of the mapped staging
+  auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
   L.o_desc = 0;
-  L.o_min = L.o_desc + n_items * sizeof(ProofDesc);
-  L.o_state = L.o_min + pl.minvals.size() * 8;
-  L.o_seed = L.o_state + pl.states.size();
+  L.o_min = up16(L.o_desc + n_items * sizeof(ProofDesc));
+  L.o_state = up16(L.o_min + pl.minvals.size() * 8);
+  L.o_seed = up16(L.o_state + pl.states.size());
   L.n_seed = pl.any_seed ? pl.seeds.size() : 0;
   L.total = L.o_seed + L.n_seed;
   return L;

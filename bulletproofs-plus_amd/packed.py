@@ -146,6 +146,25 @@ class Batcher:
         err = ctypes.create_string_buffer(256)
         api._check(self.engine.lib.bpp_batcher_verify(self.handle, byref(inp.struct), err, 256), None, err)
 
+    def verify_action(self, inp, action):
+        """any VerifyAction through the pool: returns (masks uint8 [n, t, 32], present uint8 [n]) exactly as
+        verify_batch(params, inp, action, chunk=0) would, or raises its ProofError"""
+        t = int(self.params.extension_degree())
+        masks = np.zeros((inp.n, t, 32), dtype=np.uint8)
+        present = np.zeros(inp.n, dtype=np.uint8)
+        err = ctypes.create_string_buffer(256)
+        api._check(self.engine.lib.bpp_batcher_verify_action(self.handle, byref(inp.struct), int(action), masks.ctypes.data,
+                                                             present.ctypes.data, err, 256), None, err)
+        return masks, present
+
+    def largest_pool(self):
+        c, p = ctypes.c_uint32(), ctypes.c_uint32()
+        self.engine.lib.bpp_batcher_largest_pool(self.handle, byref(c), byref(p))
+        return c.value, p.value
+
+    def set_limits(self, max_calls=0, max_proofs=0):
+        api._check(self.engine.lib.bpp_batcher_set_limits(self.handle, max_calls, max_proofs), None)
+
     def stats(self):
         v = [c_uint64() for _ in range(3)]
         self.engine.lib.bpp_batcher_stats(self.handle, *[byref(x) for x in v])
@@ -155,6 +174,26 @@ class Batcher:
         if self.handle:
             self.engine.lib.bpp_batcher_destroy(self.handle)
             self.handle = ctypes.c_void_p()
+
+
+def verify_groups_actions(rb, bounds, actions):
+    """bpp_verify_resident_groups_actions: one VerifyAction per group -> (result dicts, masks [n, t, 32], present [n])"""
+    G = len(bounds) - 1
+    arr = (ctypes.c_uint32 * (G + 1))(*bounds)
+    act = (ctypes.c_int * G)(*[int(a) for a in actions])
+    out = (_lib.ShardResult * G)()
+    masks = np.zeros((rb.n, rb.t, 32), dtype=np.uint8)
+    present = np.zeros(rb.n, dtype=np.uint8)
+    api._check(rb.engine.lib.bpp_verify_resident_groups_actions(rb.engine.ctx, rb.handle, arr, G, act, out, masks.ctypes.data,
+                                                                present.ctypes.data), rb.engine.ctx)
+    return [{"code": r.code, "tier": r.tier, "index": r.index, "msg": r.msg.decode(errors="replace")} for r in out], masks, present
+
+
+def runtime_info(engine):
+    """bpp_runtime_info_get as a dict"""
+    info = _lib.RuntimeInfo()
+    api._check(engine.lib.bpp_runtime_info_get(engine.ctx, byref(info)), engine.ctx)
+    return {n: getattr(info, n) for n, _ in _lib.RuntimeInfo._fields_}
 
 
 def verify_groups(rb, bounds):
@@ -242,3 +281,14 @@ class ResidentBatch(api.ResidentBatch):
                                               byref(self.handle), err, 256)
         api._check(rc, self.engine.ctx, err)
         self.marshal_seconds, self.upload_seconds = t1 - t0, time.perf_counter() - t1
+
+    def verify_arrays(self, action, chunk=0):
+        """bpp_verify_resident with the masks as arrays (no per-item Python): (masks uint8 [n, t, 32], present uint8 [n])"""
+        if not hasattr(self, "_masks"):
+            self._masks = np.zeros((self.n, self.t, 32), dtype=np.uint8)
+            self._present = np.zeros(self.n, dtype=np.uint8)
+        err = ctypes.create_string_buffer(256)
+        rc = self.engine.lib.bpp_verify_resident(self.engine.ctx, self.handle, int(action), chunk, self._masks.ctypes.data,
+                                                 self._present.ctypes.data, err, 256)
+        api._check(rc, self.engine.ctx, err)
+        return self._masks, self._present

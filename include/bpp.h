@@ -76,6 +76,29 @@ const char *bpp_ctx_last_error(bpp_ctx *ctx);
  * the initial values and are read ONCE, when the context is created: no verification path calls getenv. */
 int bpp_ctx_set_option(bpp_ctx *ctx, const char *name, int value);
 
+/* ---- runtime preconditions and the admission gate for small calls ("Runtime preconditions") ----
+ * Separate callers of RangeProof::verify_batch hand over at most MAX_RANGE_PROOF_BATCH_SIZE = 256 proofs per call
+ * (src/range_proof.rs:73-76,712-752).  Such a call is a chain of latency-bound kernels; the chip runs about six of them side
+ * by side, and with many more in flight (every context brings a stream and a side stream onto the runtime's hardware queues)
+ * all of them get slower.  The library therefore admits at most `small_call_limit` calls of <= 1024 proofs per device at a
+ * time (default 12, environment BPP_SMALL_CALLS_IN_FLIGHT, 0 = no gate); the others wait their turn on the host in arrival
+ * order.  Large calls pass freely.  bpp_small_call_limit sets the limit (limit < 0: query only) and returns the previous one.
+ * bpp_runtime_info_get reports what the library sees: live contexts of the device, the hardware queues the HIP runtime uses
+ * (GPU_MAX_HW_QUEUES as read at ITS start-up; 4 when unset -- a library cannot change it for its host), the host pool, the
+ * gate's counters.  When a new context makes contexts > hw_queues, bpp_ctx_create still succeeds and leaves a note where
+ * bpp_ctx_last_error finds it. */
+typedef struct {
+  int device;
+  uint32_t contexts, contexts_peak; /* live / most ever: each owns a stream, small inputs use a second one */
+  uint32_t hw_queues;               /* GPU_MAX_HW_QUEUES (4 when unset) */
+  uint32_t host_threads;            /* bpp_host_threads() */
+  uint32_t small_call_limit, small_calls_in_flight;
+  uint64_t small_calls, small_calls_queued; /* gated calls so far; those that had to wait */
+  uint32_t oversubscribed;          /* 1: contexts > hw_queues */
+} bpp_runtime_info;
+int bpp_runtime_info_get(bpp_ctx *ctx, bpp_runtime_info *out);
+int bpp_small_call_limit(bpp_ctx *ctx, int limit);
+
 /* ---- B1: multiscalar traits ----
  * bpp_precomp_create  = VartimePrecomputedMultiscalarMul::new(static_points)   (src/generators/bulletproof_gens.rs:103)
  * bpp_msm_mixed       = ::vartime_mixed_multiscalar_mul(static_scalars, dyn_scalars, dyn_points)
@@ -287,6 +310,13 @@ int bpp_verify_sharded_groups_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const u
  * of the resident batch (group_first[0] = 0, group_first[n_groups] = the batch size), every group verified as its own
  * verify() (VerifyOnly) with its own outcome in results[g] (code, tier, index inside the group, message; rank = -1). */
 int bpp_verify_resident_groups(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first, size_t n_groups, bpp_shard_result *results);
+/* The same with a VerifyAction PER GROUP (src/range_proof.rs:46-54; actions == NULL: VerifyOnly everywhere) and the masks of
+ * the groups that recover them (:941-969): masks_out n_items x extension_degree x 32, mask_present n_items (either may be
+ * NULL).  A group gets its masks only where its own verify() would have returned Ok; every other slot is zero / absent.  A
+ * RecoverOnly group is never held to the final check (:1040-1043); when every group is RecoverOnly neither the weight chains
+ * nor PASS 2 run. */
+int bpp_verify_resident_groups_actions(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first, size_t n_groups, const int *actions,
+                                       bpp_shard_result *results, uint8_t *masks_out, uint8_t *mask_present);
 /* bpp_batcher: many host threads, each with ONE reference batch per call.  Separate small calls stop at about 5 000 calls per
  * second whatever the number of callers (a small call is a chain of latency-bound kernels and the chip runs about six of those
  * side by side); the batcher pools the calls that are waiting into grouped engine calls (bpp_verify_resident_groups) on
@@ -299,6 +329,18 @@ typedef struct bpp_batcher bpp_batcher;
 int bpp_batcher_create(bpp_ctx *ctx, uint64_t params, const bpp_packed_batch *shape, uint32_t lanes, uint32_t max_wait_us, uint32_t max_calls,
                        bpp_batcher **out);
 int bpp_batcher_verify(bpp_batcher *b, const bpp_packed_batch *in, char *errbuf, size_t errbuf_len);
+/* Any VerifyAction through the pool (round 4): returns exactly what bpp_verify_batch_packed(ctx, params, in, action, 0,
+ * masks_out, mask_present, ...) would -- the caller's own seed nonces in (in->seed_nonces32), its own masks out.  Calls pool
+ * whatever their shape (proof length, aggregation factor, transcript label or state: the pooled upload goes through the item
+ * form, out of the callers' buffers); RecoverOnly calls (a wallet scanning outputs: no final check, :1040-1043) pool among
+ * themselves.  `shape` of bpp_batcher_create is no longer needed and may be NULL.  Secrets: nonces are read where the caller
+ * keeps them, masks pass through the lane's buffers, which are wiped before the lane is handed on. */
+int bpp_batcher_verify_action(bpp_batcher *b, const bpp_packed_batch *in, int action, uint8_t *masks_out, uint8_t *mask_present,
+                              char *errbuf, size_t errbuf_len);
+/* most requests (0: keep) and most proofs (0: keep; default 16384) of one pooled call */
+int bpp_batcher_set_limits(bpp_batcher *b, uint32_t max_calls, uint32_t max_proofs);
+/* the largest pooled call so far: requests and proofs in it (never above the limits) */
+int bpp_batcher_largest_pool(bpp_batcher *b, uint32_t *calls, uint32_t *proofs);
 int bpp_batcher_stats(bpp_batcher *b, uint64_t *pooled_calls, uint64_t *engine_calls, uint64_t *solo_calls);
 void bpp_batcher_destroy(bpp_batcher *b); /* waits for the calls in flight; no call may start once it has been called */
 /* host wall-clock split of the last wave on `comm` (ms): enqueueing phase 1 on the k streams, the first exchange (waits for
@@ -371,6 +413,7 @@ typedef struct {
   float msm_digits_ms, msm_sort_ms, msm_accumulate_ms, msm_bucket_reduce_ms, msm_final_ms;
   float total_ms;
   uint32_t msm_terms, msm_window_bits, msm_windows, msm_groups;
+  float masks_ms; /* k_masks (mask recovery, src/range_proof.rs:941-969); 0 for VerifyOnly */
 } bpp_profile;
 int bpp_profile_enable(bpp_ctx *ctx, int on);
 int bpp_profile_get(bpp_ctx *ctx, bpp_profile *out);

@@ -1,0 +1,286 @@
+"""GPU tests of round 4: every VerifyAction through the pooled path (bpp_verify_resident_groups_actions, bpp_batcher_verify_action)
+held to the CPU oracle (verdict, error kind AND recovered masks), pooling across shapes, the batcher's limits and strided inputs,
+the device-wide admission gate for small calls, the runtime-precondition report.
+
+Reference: RangeProof::verify_batch / verify with its three VerifyActions (src/range_proof.rs:46-54, :712-752, :941-969,
+:1040-1043); separate callers hand over at most MAX_RANGE_PROOF_BATCH_SIZE proofs per call (:73-76)."""
+import importlib
+import os
+import random
+import threading
+
+import numpy as np
+import pytest
+
+from tests.helpers import LABEL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def packed():
+    return importlib.import_module("bulletproofs-plus_amd.packed")
+
+
+def _make(bpp, packed, engine, m, count, seed):
+    import bench
+    params = bpp.RangeParameters.init(64, m, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    d = bench.make_inputs(np, packed, params, count, seed=seed)
+    params.close()
+    return d
+
+
+def _oracle_items(pr, d, sl, seeds, label=LABEL):
+    idx = range(*sl.indices(len(d["proofs"])))
+    return [{"proof": bytes(pr[k]), "commitments": [bytes(c) for c in d["commitments"][i]],
+             "min_values": [int(v) if p else None for v, p in zip(d["min_values"][i], d["min_present"][i])],
+             "seed_nonce": bytes(seeds[k]) if seeds is not None else None, "label": label} for k, i in enumerate(idx)]
+
+
+def _masks_as_lists(masks, present):
+    return [[bytes(masks[i, k]) for k in range(masks.shape[1])] if present[i] else None for i in range(masks.shape[0])]
+
+
+def _cases(bpp, packed, engine, n_cases, seed):
+    """(PackedInput, action, oracle rc, oracle masks) tuples: non-aggregated and 2-aggregated statements (two proof lengths),
+    1...48 proofs, every VerifyAction, a third of them tampered (failing sum, non-canonical point, identity point, a scalar that
+    from_bytes would refuse, a commitment that does not decode)"""
+    from oracle import cport
+    d1, d2 = _make(bpp, packed, engine, 1, 400, seed), _make(bpp, packed, engine, 2, 120, seed + 1)
+    cp = cport.Params(64, 2, 1)
+    rng = random.Random(seed)
+    sizes = [1, 2, 5, 16, 33, 48]
+    out = []
+    for i in range(n_cases):
+        d = d2 if i % 4 == 3 else d1
+        n = sizes[i % len(sizes)]
+        lo = rng.randrange(0, len(d["proofs"]) - n)
+        sl = slice(lo, lo + n)
+        pr = d["proofs"][sl].copy()
+        com = d["commitments"][sl].copy()
+        kind, j = i % 11, rng.randrange(n)
+        if kind == 1:
+            pr[j, 1 + 32 + 96] ^= 1                                                   # r1 changed: the final check fails
+        elif kind == 2:
+            pr[j, 1 + 32:1 + 64] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)  # A does not decode
+        elif kind == 3:
+            pr[j, 1 + 32:1 + 64] = 0                                                  # A is the identity encoding: PASS 1 refuses it
+        elif kind == 4:
+            pr[j, 1 + 32 + 96:1 + 32 + 128] = 0xff                                    # r1 >= l: from_bytes refuses the proof
+        elif kind == 5:
+            com[j, 0] = np.frombuffer(b"\x01" + bytes(31), dtype=np.uint8)             # a commitment that does not decode
+        action = (0, 1, 2)[(i // 2) % 3]
+        seeds = d["seeds"][sl] if d["seeds"] is not None else None
+        dd = dict(d, commitments=d["commitments"].copy())
+        dd["commitments"][sl] = com
+        rc, masks, _ = cp.verify(_oracle_items(pr, dd, sl, seeds if action else None), action=action)
+        inp = packed.PackedInput(pr, com, d["min_values"][sl], d["min_present"][sl], seeds, LABEL)
+        out.append((inp, action, rc, masks if rc == 0 else None))
+    cp.close()
+    return out
+
+
+def test_grouped_actions_equal_the_oracle(bpp, packed, engine):
+    """one resident batch, six groups with different VerifyActions (bpp_verify_resident_groups_actions): per group the oracle's
+    verdict and -- where it returns Ok -- the oracle's masks; a RecoverOnly group with a failing sum still returns its masks
+    (src/range_proof.rs:1040-1043), a RecoverAndVerify one does not; an all-RecoverOnly call never runs PASS 2"""
+    from oracle import cport
+    params = bpp.RangeParameters.init(64, 1, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    d = _make(bpp, packed, engine, 1, 300, 4100)
+    K = bpp.ProofErrorKind
+    bounds = [0, 40, 41, 100, 180, 260, 300]
+    actions = [0, 1, 2, 1, 2, 0]
+    pr = d["proofs"].copy()
+    pr[120, 1 + 32 + 96] ^= 1   # group 3 (RecoverAndVerify): failing sum -> Err, no masks
+    pr[200, 1 + 32 + 96] ^= 1   # group 4 (RecoverOnly): not looked at -> Ok, masks (garbage for that one proof, as in the reference)
+    pr[270, 1 + 32:1 + 64] = 0  # group 5 (VerifyOnly): identity A
+    cp = cport.Params(64, 1, 1)
+    rb = packed.ResidentBatch(params, pr, d["commitments"], d["min_values"], d["min_present"], d["seeds"], LABEL)
+    res, masks, present = packed.verify_groups_actions(rb, bounds, actions)
+    got = _masks_as_lists(masks, present)
+    for g, a in enumerate(actions):
+        sl = slice(bounds[g], bounds[g + 1])
+        rc, want, _ = cp.verify(_oracle_items(pr[sl], d, sl, d["seeds"][sl] if a else None), action=a)
+        assert res[g]["code"] == rc, (g, res[g])
+        assert got[sl] == (want if rc == 0 and a else [None] * (bounds[g + 1] - bounds[g])), g
+    assert [r["code"] for r in res] == [0, 0, 0, int(K.VerificationFailed), 0, int(K.VerificationFailed)]
+    assert res[5]["tier"] == 5 and res[5]["index"] == 10
+    # the blinding the prover was given comes back for the clean RecoverAndVerify / RecoverOnly groups
+    assert got[40] == [bytes(d["blindings"][40, 0, 0])] and got[41:100] == [[bytes(d["blindings"][i, 0, 0])] for i in range(41, 100)]
+    # every group RecoverOnly: no weight chains, no PASS 2 (the trace of the final check keeps the previous call's groups)
+    res2, masks2, present2 = packed.verify_groups_actions(rb, [0, 150, 300], [2, 2])
+    assert [r["code"] for r in res2] == [0, int(K.VerificationFailed)]  # (group 1 holds the identity A: PASS 1)
+    # (r1 enters the transcript after the last challenge: proof 120's mask is the prover's blinding all the same)
+    assert _masks_as_lists(masks2, present2)[:150] == [[bytes(d["blindings"][i, 0, 0])] for i in range(150)]
+    assert not present2[150:].any()
+    with pytest.raises(bpp.ProofError):
+        packed.verify_groups_actions(rb, [0, 300], [7])
+    rb.close()
+    cp.close()
+    params.close()
+
+
+def test_batcher_mixed_actions_and_shapes_match_the_oracle(bpp, packed, engine):
+    """sixteen host threads, one batcher: VerifyOnly / RecoverAndVerify / RecoverOnly calls of 1...48 proofs, two statement
+    shapes (aggregation 1 with seed nonces, aggregation 2: another proof length), a third tampered in five ways.  Every call
+    returns the ORACLE's verdict for that input alone and -- where that is Ok and the action recovers -- the oracle's masks;
+    most calls went through pooled engine calls, construction errors did not take their pool down"""
+    cases = _cases(bpp, packed, engine, 66, 4200)
+    assert len({rc for _, _, rc, _ in cases}) >= 3 and {a for _, a, _, _ in cases} == {0, 1, 2}
+    params = bpp.RangeParameters.init(64, 2, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    bat = packed.Batcher(params, cases[0][0], lanes=2)
+    problems = []
+
+    def worker(k):
+        r = random.Random(k)
+        try:
+            for _ in range(30):
+                inp, action, want_rc, want_masks = cases[r.randrange(len(cases))]
+                try:
+                    masks, present = bat.verify_action(inp, action)
+                    got_rc, got = 0, _masks_as_lists(masks, present)
+                except bpp.ProofError as e:
+                    got_rc, got = int(e.kind), None
+                if got_rc != want_rc:
+                    problems.append((k, "rc", want_rc, got_rc))
+                elif got_rc == 0 and action != 0 and got != want_masks:
+                    problems.append((k, "masks", action))
+                elif got_rc == 0 and action == 0 and any(g is not None for g in got):
+                    problems.append((k, "masks from VerifyOnly"))
+        except BaseException as e:  # noqa: BLE001
+            problems.append((k, "exception", repr(e)))
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(16)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in ths), "a caller is stuck in the batcher"
+    assert not problems, problems[:5]
+    st = bat.stats()
+    assert st["pooled_calls"] > 100 and st["engine_calls"] < 16 * 30
+    bat.close()
+    params.close()
+
+
+def test_batcher_limits_and_strided_proofs(bpp, packed, engine):
+    """max_proofs is a hard limit (round 3: the leader's own request was appended after the cut), proofs with a stride larger
+    than their length pool like any others, nothing above the limit is pooled at all"""
+    params = bpp.RangeParameters.init(64, 1, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    d = _make(bpp, packed, engine, 1, 256, 4300)
+    plen = d["proofs"].shape[1]
+    wide = np.zeros((256, plen + 47), dtype=np.uint8)
+    wide[:, :plen] = d["proofs"]
+    wide[:, plen:] = 0xa5  # never read
+    bad = wide.copy()
+    bad[7, 1 + 32 + 96] ^= 1
+
+    class Strided(packed.PackedInput):
+        def __init__(self, arr, sl):
+            super().__init__(d["proofs"][sl], d["commitments"][sl], d["min_values"][sl], d["min_present"][sl], None, LABEL)
+            self.keep = arr
+            self.struct.proofs = arr[sl].ctypes.data
+            self.struct.proof_stride = arr.strides[0]
+    bat = packed.Batcher(params, packed.PackedInput(d["proofs"][:1], d["commitments"][:1], d["min_values"][:1], d["min_present"][:1], None, LABEL),
+                         lanes=1)
+    bat.set_limits(max_proofs=150)
+    inputs = [(Strided(wide, slice(0, 64)), 0), (Strided(bad, slice(0, 64)), 1), (Strided(wide, slice(64, 124)), 0),
+              (Strided(wide, slice(100, 250)), 0), (Strided(wide, slice(0, 200)), 0)]  # the last: above max_proofs, never pooled
+    problems = []
+
+    def worker(k):
+        r = random.Random(k)
+        for _ in range(25):
+            inp, want = inputs[r.randrange(len(inputs))]
+            try:
+                bat.verify(inp)
+                got = 0
+            except bpp.ProofError as e:
+                got = int(e.kind)
+            if got != want:
+                problems.append((k, want, got))
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(12)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ths)
+    assert not problems, problems[:5]
+    calls, proofs = bat.largest_pool()
+    assert 2 <= calls and proofs <= 150, (calls, proofs)
+    assert bat.stats()["pooled_calls"] > 20
+    bat.close()
+    params.close()
+
+
+def test_small_call_gate_and_runtime_report(bpp, packed, engine):
+    """the device admits `limit` small calls at a time, the rest queue in arrival order and all of them get their verdicts;
+    bpp_runtime_info_get reports the hardware queues the HIP runtime was started with, the live contexts, the gate's counters;
+    a context created beyond the hardware queues carries a note where bpp_ctx_last_error finds it"""
+    params = bpp.RangeParameters.init(64, 1, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    d = _make(bpp, packed, engine, 1, 64, 4400)
+    info0 = packed.runtime_info(engine)
+    assert info0["hw_queues"] == int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) or info0["hw_queues"] == 4
+    assert info0["contexts"] >= 1 and info0["host_threads"] == bpp.host_threads() and info0["small_call_limit"] >= 1
+    before = engine.lib.bpp_small_call_limit(engine.ctx, 2)
+    assert before == info0["small_call_limit"]
+    engines = [bpp.Engine(0) for _ in range(8)]
+    pars = [params.share(e) for e in engines]
+    bad = d["proofs"].copy()
+    bad[3, 1 + 32 + 96] ^= 1
+    problems = []
+
+    def worker(k):
+        for i in range(20):
+            pr, want = (bad, 1) if (i + k) % 3 == 0 else (d["proofs"], 0)
+            inp = packed.PackedInput(pr, d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+            try:
+                packed.verify_batch(pars[k], inp, bpp.VerifyAction.VerifyOnly, 0)
+                got = 0
+            except bpp.ProofError as e:
+                got = int(e.kind)
+            if got != want:
+                problems.append((k, want, got))
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ths), "a caller is stuck at the gate"
+    assert not problems, problems[:5]
+    info = packed.runtime_info(engine)
+    assert info["small_call_limit"] == 2 and info["small_calls_in_flight"] == 0
+    assert info["small_calls"] - info0["small_calls"] >= 160 and info["small_calls_queued"] > info0["small_calls_queued"]
+    assert info["contexts"] >= info0["contexts"] + 8 and info["contexts_peak"] >= info["contexts"]
+    assert engine.lib.bpp_small_call_limit(engine.ctx, 0) == 2  # gate off: calls are counted, never held
+    q0 = packed.runtime_info(engine)["small_calls_queued"]
+    worker(0)
+    assert packed.runtime_info(engine)["small_calls_queued"] == q0
+    engine.lib.bpp_small_call_limit(engine.ctx, before)
+    # more contexts than hardware queues: creation succeeds and says so
+    extra = [bpp.Engine(0) for _ in range(max(0, info["hw_queues"] + 1 - packed.runtime_info(engine)["contexts"]))]
+    probe = bpp.Engine(0)
+    note = engine.lib.bpp_ctx_last_error(probe.ctx).decode()
+    assert "hardware queues" in note and "GPU_MAX_HW_QUEUES" in note and packed.runtime_info(engine)["oversubscribed"] == 1
+    for e in extra + [probe]:
+        e.close()
+    for p in pars:
+        p.close()
+    for e in engines:
+        e.close()
+    params.close()
+
+
+def test_recover_only_at_bench_size(bpp, packed, engine):
+    """RecoverOnly over a large resident batch in 1024-proof reference batches (bench.py's extra.recover_only leg at a quarter
+    of its size): the masks are the blindings the prover was given, nothing of PASS 2 runs, the same batch then verifies"""
+    params = bpp.RangeParameters.init(64, 1, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    d = _make(bpp, packed, engine, 1, 16384, 4500)
+    rb = packed.ResidentBatch(params, d["proofs"], d["commitments"], d["min_values"], d["min_present"], d["seeds"], LABEL)
+    masks = rb.verify(bpp.VerifyAction.RecoverOnly, 1024)
+    got = np.frombuffer(b"".join(m.blindings()[0] for m in masks), dtype=np.uint8).reshape(-1, 32)
+    assert (got == d["blindings"][:, 0, 0]).all()
+    rb.verify_only(1024)
+    masks = rb.verify(bpp.VerifyAction.RecoverAndVerify, 1024)
+    assert all(m.blindings()[0] == bytes(d["blindings"][i, 0, 0]) for i, m in enumerate(masks))
+    rb.close()
+    params.close()
