@@ -582,7 +582,7 @@ def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, para
     sync()
     wel = region(rounds)
     sync()
-    tt = torch.tensor([wel], dtype=torch.float64, device=device)
+    tt = torch.tensor([wel], dtype=torch.float64)  # (CPU tensor: the control plane is gloo)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     wel = float(tt.item())
     batches = W * S * G * rounds
@@ -630,7 +630,10 @@ def main():
     device = torch.device("cuda", local_rank)
     use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: exercises the RCCL path)
     if use_dist:
-        dist.init_process_group("nccl", device_id=device)
+        # the harness' own control plane (barriers, the MAX over ranks of the elapsed time, the verdict AND, rank 0's
+        # ncclUniqueId) runs over gloo on the CPU: the ONLY RCCL in this process is the one the engine loads for its data path
+        # (the librccl next to its own HIP runtime, csrc/engine_shard.h) -- torch's bundled copy is never initialised
+        dist.init_process_group("gloo")
 
     def sync():
         torch.cuda.synchronize(device)
@@ -771,10 +774,10 @@ def main():
     # every timed step ran and raised nothing (each step verifies all its batches or raises)
     ok_all = 1 if (step_error is None and len(lat) == args.steps) else 0
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64)  # (CPU tensors: the control plane is gloo)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        flag = torch.tensor([ok_all], dtype=torch.int32, device=device)  # verdicts of the independent shards
+        flag = torch.tensor([ok_all], dtype=torch.int32)  # verdicts of the independent shards
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok_all = int(flag.item())
     if ok_all != 1:

@@ -103,6 +103,7 @@ SYMBOLS = [
     ("bpp_comm_create_local", c_int, [c_void_p, c_uint64, c_int, c_int, POINTER(c_void_p)]),
     ("bpp_comm_destroy", None, [c_void_p]),
     ("bpp_comm_last_error", c_char_p, [c_void_p]),
+    ("bpp_comm_set_timeout", c_int, [c_void_p, c_uint32]),
     ("bpp_comm_last_timing", c_int, [c_void_p, POINTER(ShardTiming)]),
     ("bpp_verify_sharded", c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint32), POINTER(c_int), POINTER(c_int), c_void_p,
                                    c_size_t]),

@@ -34,10 +34,13 @@ RcclApi &rccl_api() {
     // loaded first and bound to /opt/rocm's libamdhip64) finds an HSA runtime nobody initialised: "no ROCm-capable device".
     // So the first candidates are the librccl files NEXT TO the libamdhip64 that hipGetDeviceCount resolves to; only then
     // the bare names (which return whatever copy the process already holds).
+    // BPP_RCCL_LIB names THE library to use: when it cannot be loaded nothing else is tried (an explicit choice that silently
+    // became another copy would be the mismatch above all over again) and every bpp_comm_* call returns BPP_ERR_COMM.
     std::vector<std::string> names;
-    if (const char *e = getenv("BPP_RCCL_LIB")) names.push_back(e);
+    const char *forced = getenv("BPP_RCCL_LIB");
+    if (forced && *forced) names.push_back(forced);
     Dl_info info;
-    if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+    if (!(forced && *forced) && dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
       std::string dir(info.dli_fname);
       const size_t slash = dir.rfind('/');
       if (slash != std::string::npos) {
@@ -46,15 +49,19 @@ RcclApi &rccl_api() {
         names.push_back(dir + "librccl.so");
       }
     }
-    names.push_back("librccl.so.1");
-    names.push_back("librccl.so");
+    if (!(forced && *forced)) {
+      names.push_back("librccl.so.1");
+      names.push_back("librccl.so");
+    }
     for (const std::string &n : names) {
       if (n.empty()) continue;
       a->lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (a->lib) break;
     }
     if (!a->lib) {
-      a->err = std::string("RCCL not loadable: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+      const char *why = dlerror();
+      a->err = std::string("RCCL not loadable") + (forced && *forced ? std::string(" (BPP_RCCL_LIB=") + forced + ")" : std::string()) + ": " +
+               (why ? why : "librccl.so.1 not found");
       return a;
     }
 #define BPP_RCCL_SYM(field, name)                              \
@@ -117,17 +124,26 @@ struct LocalGroup {
   std::condition_variable cv;
   int world = 1, arrived = 0;
   uint64_t generation = 0;
+  bool broken = false;  // a rank gave up waiting: every rendezvous of this group fails from then on (as an aborted ncclComm does)
   std::vector<const uint8_t *> send;
-  void barrier() {
+  // false: the other ranks did not all arrive within timeout_ms (0 = wait for ever), or the group is already broken
+  bool barrier(uint32_t timeout_ms) {
     std::unique_lock<std::mutex> lk(mu);
+    if (broken) return false;
     const uint64_t gen = generation;
     if (++arrived == world) {
       arrived = 0;
       generation++;
       cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return generation != gen; });
+      return true;
     }
+    auto ready = [&] { return generation != gen || broken; };
+    if (timeout_ms == 0) cv.wait(lk, ready);
+    else if (!cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), ready)) {
+      broken = true;
+      cv.notify_all();
+    }
+    return !broken;
   }
 };
 
@@ -153,6 +169,12 @@ struct bpp_comm {
   std::mutex mu;
   std::string err;
   bpp_shard_timing timing{};  // host wall-clock split of the last wave
+  // Every wait for a collective has a deadline (bpp_comm_set_timeout; BPP_COMM_TIMEOUT_MS; default 60 s; 0 = none): a peer that
+  // died or never called leaves an all_gather kernel spinning on this rank's stream for ever.  When the deadline passes the
+  // communicator is aborted (ncclCommAbort: its kernels exit), marked dead, and the call -- like every later call on it --
+  // returns BPP_ERR_COMM: an RCCL failure maps to a C error code on every surviving rank.
+  uint32_t timeout_ms = 60000;
+  bool dead = false;
 };
 
 namespace {
@@ -163,8 +185,40 @@ int comm_fail(bpp_comm *c, int code, const std::string &m, char *errbuf = nullpt
   return code;
 }
 
+// Waits for everything enqueued on the communicator's stream -- a collective and the copies around it -- with the
+// communicator's deadline.  Polls (the wait must be interruptible: hipStreamSynchronize is not).
+void comm_wait(bpp_comm *c, hipStream_t cs) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spins = 0;; spins++) {
+    const hipError_t q = hipStreamQuery(cs);
+    if (q == hipSuccess) return;
+    if (q != hipErrorNotReady) {
+      (void)hipGetLastError();
+      throw EngineError{BPP_ERR_ENGINE, std::string("the communicator's stream failed: ") + hipGetErrorString(q)};
+    }
+    const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (c->timeout_ms && waited >= (long long)c->timeout_ms) {
+      c->dead = true;
+      if (!c->local && c->comm) {
+        (void)rccl_api().CommAbort(c->comm);  // the collective's kernel exits; the handle is gone with it
+        c->comm = nullptr;
+        c->own_comm = false;
+      }
+      const auto t1 = std::chrono::steady_clock::now();  // let the stream drain (bounded: nothing may hang here either)
+      while (hipStreamQuery(cs) == hipErrorNotReady && std::chrono::steady_clock::now() - t1 < std::chrono::seconds(5))
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      (void)hipGetLastError();
+      throw CommError{"a collective did not complete within " + std::to_string(c->timeout_ms) +
+                      " ms (a peer is missing or dead); the communicator was aborted and must be destroyed"};
+    }
+    if (spins < 2000) std::this_thread::yield();  // the exchanges are tens of microseconds when every rank is there
+    else std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
 int comm_new(bpp_ctx *ctx, ncclComm_t nc, bool own, int rank, int world, bpp_comm **out) {
   auto c = std::make_unique<bpp_comm>();
+  if (const char *e = getenv("BPP_COMM_TIMEOUT_MS")) c->timeout_ms = (uint32_t)std::max(0, atoi(e));
   c->device = ctx->device;
   c->rank = rank;
   c->world = world;
@@ -186,11 +240,17 @@ void comm_allgather(bpp_comm *c, const uint8_t *send, uint8_t *recv, size_t byte
     std::lock_guard<std::mutex> lk(c->local->mu);
     c->local->send[c->rank] = send;
   }
-  c->local->barrier();
+  auto rendezvous = [&] {
+    if (c->local->barrier(c->timeout_ms)) return;
+    c->dead = true;
+    throw CommError{"a collective did not complete within " + std::to_string(c->timeout_ms) +
+                    " ms (a peer is missing or dead); the communicator was aborted and must be destroyed"};
+  };
+  rendezvous();
   for (int r = 0; r < c->world; r++)
     HIP_CHECK(hipMemcpyAsync(recv + (size_t)r * bytes, c->local->send[r], bytes, hipMemcpyDeviceToDevice, cs));
   HIP_CHECK(hipStreamSynchronize(cs));
-  c->local->barrier();  // nobody reuses a send buffer before every rank has read it
+  rendezvous();  // nobody reuses a send buffer before every rank has read it
 }
 
 std::mutex g_local_groups_mu;
@@ -279,6 +339,13 @@ void bpp_comm_destroy(bpp_comm *c) {
 
 const char *bpp_comm_last_error(bpp_comm *c) { return c ? c->err.c_str() : "null comm"; }
 
+int bpp_comm_set_timeout(bpp_comm *c, uint32_t timeout_ms) {
+  if (!c) return BPP_ERR_BAD_HANDLE;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->timeout_ms = timeout_ms;
+  return BPP_OK;
+}
+
 int bpp_comm_last_timing(bpp_comm *c, bpp_shard_timing *out) {
   if (!c || !out) return BPP_ERR_BAD_HANDLE;
   std::lock_guard<std::mutex> lk(c->mu);
@@ -318,6 +385,7 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
   if (hipSetDevice(comm->device) != hipSuccess) return BPP_ERR_NO_DEVICE;
   const uint32_t K = (uint32_t)k_in, world = (uint32_t)comm->world, rank = (uint32_t)comm->rank;
   std::lock_guard<std::mutex> comm_lock(comm->mu);
+  if (comm->dead) return comm_fail(comm, BPP_ERR_COMM, "this communicator was aborted after a collective timed out: destroy it");
   std::vector<std::unique_lock<std::mutex>> ctx_locks;
   for (uint32_t i = 0; i < K; i++) {
     if (!ctxs[i] || ctxs[i]->device != comm->device) return comm_fail(comm, BPP_ERR_BAD_HANDLE, "context of another device (or null) in the wave");
@@ -399,7 +467,7 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
     lap(tmg.enqueue1_ms);
     comm_allgather(comm, comm->send1.p, comm->recv1.p, per1, cs);
     HIP_CHECK(hipMemcpyAsync(comm->h_recv1.data(), comm->recv1.p, per1 * world, hipMemcpyDeviceToHost, cs));
-    HIP_CHECK(hipStreamSynchronize(cs));
+    comm_wait(comm, cs);
     lap(tmg.gather1_ms);
     // ---------------------------------------------------------------- weight transcripts over ALL proofs of each batch
     {
@@ -465,7 +533,7 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(comm->h_flags.data(), comm->d_flags.p, (size_t)K * 4, hipMemcpyDeviceToHost, cs));
     HIP_CHECK(hipMemcpyAsync(comm->h_recv2.data(), comm->recv2.p, per2 * world, hipMemcpyDeviceToHost, cs));
-    HIP_CHECK(hipStreamSynchronize(cs));
+    comm_wait(comm, cs);
     lap(tmg.gather2_ms);
     // every rank reads the same findings and decides alike: a finding of any rank (lowest tier, then lowest rank) comes
     // before the final check, exactly as in the single-process verify(); an engine fault only counts when nothing was found
@@ -509,6 +577,7 @@ int bpp_verify_sharded_groups_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const u
   if (hipSetDevice(comm->device) != hipSuccess) return BPP_ERR_NO_DEVICE;
   const uint32_t K = (uint32_t)k_in, G = (uint32_t)n_groups, world = (uint32_t)comm->world, rank = (uint32_t)comm->rank;
   std::lock_guard<std::mutex> comm_lock(comm->mu);
+  if (comm->dead) return comm_fail(comm, BPP_ERR_COMM, "this communicator was aborted after a collective timed out: destroy it");
   std::vector<std::unique_lock<std::mutex>> ctx_locks;
   for (uint32_t i = 0; i < K; i++) {
     if (!ctxs[i] || ctxs[i]->device != comm->device) return comm_fail(comm, BPP_ERR_BAD_HANDLE, "context of another device (or null)");
@@ -609,7 +678,7 @@ int bpp_verify_sharded_groups_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const u
       hipStream_t s = ctx->stream;
       comm_allgather(comm, S.send1.p, S.recv1.p, per1, cs);
       HIP_CHECK(hipMemcpyAsync(S.h_recv1.data(), S.recv1.p, per1 * world, hipMemcpyDeviceToHost, cs));
-      HIP_CHECK(hipStreamSynchronize(cs));
+      comm_wait(comm, cs);
       lap(tmg.gather1_ms);
       S.rng_all.resize((size_t)std::max(n_own, 1u) * n_total * 32);
       S.weights_all.resize((size_t)std::max(n_own, 1u) * n_total * 32);
@@ -632,7 +701,7 @@ int bpp_verify_sharded_groups_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const u
         if (n_own < slots3) HIP_CHECK(hipMemsetAsync(S.send3.p, 0, per3, cs));
         if (n_own) HIP_CHECK(hipMemcpyAsync(S.send3.p, S.weights_all.data(), (size_t)n_own * n_total * 32, hipMemcpyHostToDevice, cs));
         comm_allgather(comm, S.send3.p, S.recv3.p, per3, cs);
-        HIP_CHECK(hipStreamSynchronize(cs));
+        comm_wait(comm, cs);
         lap(tmg.gather1_ms);  // (counted with the first exchange: the timing struct is part of the ABI)
       }
       if (!fault[i]) {
@@ -694,7 +763,7 @@ int bpp_verify_sharded_groups_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const u
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipMemcpyAsync(S.h_flags.data(), S.d_flags.p, (size_t)G * 4, hipMemcpyDeviceToHost, cs));
       HIP_CHECK(hipMemcpyAsync(S.h_recv2.data(), S.recv2.p, per2 * world, hipMemcpyDeviceToHost, cs));
-      HIP_CHECK(hipStreamSynchronize(cs));
+      comm_wait(comm, cs);
       lap(tmg.gather2_ms);
       for (uint32_t g = 0; g < G; g++) {
         bpp_shard_result &out = results[(size_t)i * G + g];

@@ -100,6 +100,10 @@ class ShardComm:
         res = [{"code": r.code, "tier": r.tier, "rank": r.rank, "index": r.index, "msg": r.msg.decode(errors="replace")} for r in out]
         return [res[i * n_groups:(i + 1) * n_groups] for i in range(k)]
 
+    def set_timeout(self, ms):
+        """deadline of every wait for a collective (bpp_comm_set_timeout): past it the call returns BPP_ERR_COMM"""
+        api._check(self.lib.bpp_comm_set_timeout(self.handle, int(ms)), None)
+
     def last_timing(self):
         """host wall-clock split of the last wave (ms)"""
         t = _lib.ShardTiming()
@@ -134,7 +138,8 @@ def verify_shard_mode(rb, device, group=None):
         rb.verify(api.VerifyAction.VerifyOnly, chunk=0)
     except api.ProofError as e:
         ok, err = 0, e
-    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    # (the verdicts travel over whatever backend the caller's group has: a CPU tensor unless that is NCCL / RCCL)
+    flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     if err is not None:
         raise err

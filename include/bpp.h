@@ -273,6 +273,11 @@ int bpp_comm_adopt(bpp_ctx *ctx, void *nccl_comm, int rank, int world, bpp_comm 
 int bpp_comm_create_local(bpp_ctx *ctx, uint64_t group_id, int rank, int world, bpp_comm **out);
 void bpp_comm_destroy(bpp_comm *comm);
 const char *bpp_comm_last_error(bpp_comm *comm);
+/* Deadline of every wait for a collective on this communicator, in ms (default 60 000, or BPP_COMM_TIMEOUT_MS at creation;
+ * 0 = wait for ever).  A peer that died or never made the call would leave the all_gather spinning on this rank for ever: when
+ * the deadline passes the communicator is aborted (ncclCommAbort), the call returns BPP_ERR_COMM on every surviving rank, and so
+ * does every later call on it -- destroy it and build a new one over the ranks that are left. */
+int bpp_comm_set_timeout(bpp_comm *comm, uint32_t timeout_ms);
 int bpp_verify_sharded(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, const uint32_t *counts /* world entries */,
                        int *tier_out, int *rank_out, char *errbuf, size_t errbuf_len);
 /* A WAVE of k independent sharded batches (batch i resident on ctxs[i], every rank passes its shards of the same k batches

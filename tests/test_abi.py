@@ -87,3 +87,17 @@ def test_vectorised_weight_chains_equal_the_scalar_chain():
         wt.append_message(b"proof", rng[32 * i:32 * i + 32])
     r = wt.build_rng().finalize(M.NullRng())
     assert pkg.weights_from_chains(rng, 1) == b"".join(C.scalar_bytes(O.random_not_zero(r)) for _ in range(40))
+
+
+def test_missing_rccl_library_maps_to_the_comm_error_code():
+    """BPP_RCCL_LIB names THE library the sharded entry points load RCCL from; a file that is not there must come back as
+    BPP_ERR_COMM (-4) from bpp_comm_unique_id -- no fallback to another copy, no crash (child process: the binding is resolved
+    once per process; needs no GPU)"""
+    import subprocess
+    import sys
+    code = ("import ctypes, importlib, sys; sys.path.insert(0, %r); pkg = importlib.import_module('bulletproofs-plus_amd'); "
+            "lib = pkg._lib.load(); buf = (ctypes.c_uint8 * 128)(); rc = lib.bpp_comm_unique_id(buf); print('rc', rc); "
+            "sys.exit(0 if rc == -4 else 1)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BPP_RCCL_LIB="/nonexistent/librccl.so"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr[-1000:])

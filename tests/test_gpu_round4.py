@@ -284,3 +284,153 @@ def test_recover_only_at_bench_size(bpp, packed, engine):
     assert all(m.blindings()[0] == bytes(d["blindings"][i, 0, 0]) for i, m in enumerate(masks))
     rb.close()
     params.close()
+
+
+def test_collective_deadline_reaches_every_surviving_rank(bpp, packed, engine):
+    """an RCCL failure maps to a C error code.  Three in-process ranks, the third never makes the call: the other two
+    wait for their first exchange, the deadline (bpp_comm_set_timeout) passes, BOTH get BPP_ERR_COMM with a message that says
+    why, within the deadline's order of magnitude; the communicator is dead afterwards (every later call fails at once) and
+    the contexts are still good for ordinary calls."""
+    import time
+    dmod = importlib.import_module("bulletproofs-plus_amd.dist")
+    params = bpp.RangeParameters.init(64, 1, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    d = _make(bpp, packed, engine, 1, 90, 4600)
+    world, counts = 3, [30, 30, 30]
+    engs = [bpp.Engine(0) for _ in range(world)]
+    pars = [params.share(e) for e in engs]
+    comms = [dmod.ShardComm(engs[r], r, world, local_group=4646) for r in range(world)]
+    for c in comms:
+        c.set_timeout(400)
+    out, took = [None] * world, [None] * world
+
+    def rank_main(r):
+        sl = slice(30 * r, 30 * r + 30)
+        rb = packed.ResidentBatch(pars[r], d["proofs"][sl], d["commitments"][sl], d["min_values"][sl], d["min_present"][sl], None, LABEL)
+        t0 = time.perf_counter()
+        try:
+            comms[r].verify(rb, counts)
+            out[r] = "ok"
+        except bpp.EngineError as e:
+            out[r] = str(e)
+        took[r] = time.perf_counter() - t0
+        try:  # the communicator is dead: no second wait
+            t1 = time.perf_counter()
+            comms[r].verify(rb, counts)
+            out[r] += " | second call ok"
+        except bpp.EngineError as e:
+            out[r] += " | " + str(e)
+            assert time.perf_counter() - t1 < 0.2
+        rb.verify_only(0)  # the context itself is fine
+        rb.close()
+    ths = [threading.Thread(target=rank_main, args=(r,)) for r in (0, 1)]  # rank 2 never arrives
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in ths), "a surviving rank is stuck in a collective"
+    for r in (0, 1):
+        assert "(-4)" in out[r] and "did not complete within 400 ms" in out[r] and "aborted" in out[r].split("|")[1], out[r]
+        assert 0.3 < took[r] < 5.0, took
+    for c in comms:
+        c.close()
+    for p in pars:
+        p.close()
+    for e in engs:
+        e.close()
+    params.close()
+
+
+def test_eight_ranks_in_process_at_configs3_shape(bpp, packed, engine):
+    """BASELINE configs[3] proper: 4096 proofs as ONE reference batch, 8 x 512, here with eight in-process ranks (threads with a
+    context each on the one GPU; the transport is the in-process stand-in, everything else is the code the RCCL form runs).
+    Four such batches per call through bpp_verify_sharded_groups_wave as two pipelined slots of two groups: the weight chains
+    are shared out over the ranks (rank r replays groups r, r + 8, ...: here ranks 0 and 1) and a third all_gather hands every
+    rank all weights.  Every rank reports, per batch, what the single-call form (chunk = 0 over the 4096 proofs) says; every
+    rank's weights are its 512-proof slices of that call's chain; a tampered proof on rank 5 fails batch 2 only."""
+    dmod = importlib.import_module("bulletproofs-plus_amd.dist")
+    params = bpp.RangeParameters.init(64, 1, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    nb, world, n, S, G = 4, 8, 4096, 2, 2
+    d = _make(bpp, packed, engine, 1, nb * n, 4700)
+    K = bpp.ProofErrorKind
+    counts = [512] * world
+    pr = d["proofs"].copy()
+    pr[2 * n + 5 * 512 + 77, 1 + 32 + 96] ^= 1   # batch 2, a proof on rank 5
+    engs = [[bpp.Engine(0) for _ in range(S)] for _ in range(world)]
+    pars = [[params.share(e) for e in row] for row in engs]
+    comms = [dmod.ShardComm(engs[r][0], r, world, local_group=4747) for r in range(world)]
+    out, weights = [None] * world, [None] * world
+
+    def rank_main(r):
+        rbs = []
+        try:
+            for sl in range(S):  # slot sl holds this rank's shards of batches 2 sl and 2 sl + 1 as ONE resident batch
+                idx = np.concatenate([np.arange(b * n + 512 * r, b * n + 512 * (r + 1)) for b in (G * sl, G * sl + 1)])
+                rbs.append(packed.ResidentBatch(pars[r][sl], pr[idx], d["commitments"][idx], d["min_values"][idx], d["min_present"][idx], None, LABEL))
+            res = comms[r].verify_groups_wave(rbs, G, counts)
+            out[r] = [(x["code"], x["tier"], x["rank"]) for part in res for x in part]
+            weights[r] = [rb.trace(3) for rb in rbs]
+        except BaseException as e:  # noqa: BLE001
+            out[r] = ("exception", repr(e))
+        finally:
+            for rb in rbs:
+                rb.close()
+    ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ths), "a rank is stuck in a collective"
+    assert all(o == out[0] for o in out), out
+    assert out[0] == [(0, 0, -1), (0, 0, -1), (int(K.VerificationFailed), 7, -1), (0, 0, -1)]
+    for b in range(nb):  # against the single-call form on the batch's 4096 proofs
+        sl = slice(b * n, (b + 1) * n)
+        rb = packed.ResidentBatch(params, pr[sl], d["commitments"][sl], d["min_values"][sl], d["min_present"][sl], None, LABEL)
+        try:
+            rb.verify_only(0)
+            want = 0
+        except bpp.ProofError as e:
+            want = int(e.kind)
+        w_all = rb.trace(3)
+        rb.close()
+        assert out[0][b][0] == want
+        for r in range(world):
+            got = weights[r][b // G][32 * 512 * (b % G):32 * 512 * (b % G + 1)]
+            assert got == w_all[32 * 512 * r:32 * 512 * (r + 1)], (b, r)
+    for c in comms:
+        c.close()
+    for row in pars:
+        for p in row:
+            p.close()
+    for row in engs:
+        for e in row:
+            e.close()
+    params.close()
+
+
+def test_missing_rccl_library_is_an_error_code_not_a_crash():
+    """BPP_RCCL_LIB names THE library to load: a missing file makes bpp_comm_create return BPP_ERR_COMM (with the reason where
+    bpp_ctx_last_error finds it) and the single-GPU paths of the same process keep working.  In a child process: the RCCL
+    binding is resolved once per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import ctypes, importlib, sys
+sys.path.insert(0, %r)
+bpp = importlib.import_module("bulletproofs-plus_amd")
+eng = bpp.Engine(0)
+lib = eng.lib
+buf = (ctypes.c_uint8 * 128)()
+assert lib.bpp_comm_unique_id(buf) == -4, "bpp_comm_unique_id"
+comm = ctypes.c_void_p()
+rc = lib.bpp_comm_create(eng.ctx, buf, 0, 1, ctypes.byref(comm))
+msg = lib.bpp_ctx_last_error(eng.ctx).decode()
+assert rc == -4 and "RCCL not loadable" in msg and "/nonexistent/librccl.so" in msg, (rc, msg)
+p = bpp.RangeParameters.init(64, 1, bpp.create_pedersen_gens_with_extension_degree(1), engine=eng)   # the rest still works
+p.close()
+eng.close()
+print("ok")
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BPP_RCCL_LIB="/nonexistent/librccl.so"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
