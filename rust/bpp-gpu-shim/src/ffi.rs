@@ -131,6 +131,23 @@ pub struct bpp_profile {
     pub msm_window_bits: u32,
     pub msm_windows: u32,
     pub msm_groups: u32,
+    pub masks_ms: f32,
+}
+
+/// bpp_runtime_info: what the library sees of its runtime preconditions ("Runtime preconditions")
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct bpp_runtime_info {
+    pub device: c_int,
+    pub contexts: u32,
+    pub contexts_peak: u32,
+    pub hw_queues: u32,
+    pub host_threads: u32,
+    pub small_call_limit: u32,
+    pub small_calls_in_flight: u32,
+    pub small_calls: u64,
+    pub small_calls_queued: u64,
+    pub oversubscribed: u32,
 }
 
 #[repr(C)]
@@ -151,6 +168,9 @@ extern "C" {
     pub fn bpp_ctx_destroy(ctx: *mut bpp_ctx);
     pub fn bpp_ctx_last_error(ctx: *mut bpp_ctx) -> *const c_char;
     pub fn bpp_ctx_set_option(ctx: *mut bpp_ctx, name: *const c_char, value: c_int) -> c_int;
+    // runtime preconditions, the admission gate for small calls
+    pub fn bpp_runtime_info_get(ctx: *mut bpp_ctx, out: *mut bpp_runtime_info) -> c_int;
+    pub fn bpp_small_call_limit(ctx: *mut bpp_ctx, limit: c_int) -> c_int;
     // B1: VartimePrecomputedMultiscalarMul / VartimeMultiscalarMul / MultiscalarMul (src/traits.rs:40-43, src/ristretto.rs:28-64)
     pub fn bpp_precomp_create(ctx: *mut bpp_ctx, points32: *const u8, count: usize, handle: *mut u64) -> c_int;
     pub fn bpp_precomp_destroy(ctx: *mut bpp_ctx, handle: u64) -> c_int;
@@ -197,6 +217,7 @@ extern "C" {
     pub fn bpp_comm_create_local(ctx: *mut bpp_ctx, group_id: u64, rank: c_int, world: c_int, out: *mut *mut bpp_comm) -> c_int;
     pub fn bpp_comm_destroy(comm: *mut bpp_comm);
     pub fn bpp_comm_last_error(comm: *mut bpp_comm) -> *const c_char;
+    pub fn bpp_comm_set_timeout(comm: *mut bpp_comm, timeout_ms: u32) -> c_int;
     pub fn bpp_comm_last_timing(comm: *mut bpp_comm, out: *mut bpp_shard_timing) -> c_int;
     pub fn bpp_verify_sharded(comm: *mut bpp_comm, ctx: *mut bpp_ctx, batch: u64, counts: *const u32, tier_out: *mut c_int,
                               rank_out: *mut c_int, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
@@ -211,6 +232,12 @@ extern "C" {
     pub fn bpp_batcher_create(ctx: *mut bpp_ctx, params: u64, shape: *const bpp_packed_batch, lanes: u32, max_wait_us: u32, max_calls: u32,
                               out: *mut *mut bpp_batcher) -> c_int;
     pub fn bpp_batcher_verify(b: *mut bpp_batcher, input: *const bpp_packed_batch, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    pub fn bpp_verify_resident_groups_actions(ctx: *mut bpp_ctx, batch: u64, group_first: *const u32, n_groups: usize, actions: *const c_int,
+                                              results: *mut bpp_shard_result, masks_out: *mut u8, mask_present: *mut u8) -> c_int;
+    pub fn bpp_batcher_verify_action(b: *mut bpp_batcher, input: *const bpp_packed_batch, action: c_int, masks_out: *mut u8,
+                                     mask_present: *mut u8, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    pub fn bpp_batcher_set_limits(b: *mut bpp_batcher, max_calls: u32, max_proofs: u32) -> c_int;
+    pub fn bpp_batcher_largest_pool(b: *mut bpp_batcher, calls: *mut u32, proofs: *mut u32) -> c_int;
     pub fn bpp_batcher_stats(b: *mut bpp_batcher, pooled_calls: *mut u64, engine_calls: *mut u64, solo_calls: *mut u64) -> c_int;
     pub fn bpp_batcher_destroy(b: *mut bpp_batcher);
     pub fn bpp_shard_local_trailer(defer: *const u8, status: *const u32, rounds_bad: *const u8, n: u32, first_index: u32,

@@ -181,6 +181,82 @@ impl Engine {
         }).collect()).collect())
     }
 
+    /// `RangeProof::verify` with PASS 1 (src/range_proof.rs:811-850) done by the CALLER on its own merlin transcripts
+    /// (bpp_verify_batch_with_challenges, SURVEY 8b option (i)): `challenges[i]` = proof i's y, z, e_0.., e_final as
+    /// (rounds_i + 3) x 32 canonical bytes (:833-842), `rng_out` = n x 32 bytes drawn from each `to_verifier_rng` (:845-848).
+    /// Everything else of verify() runs on the engine; the transcript fields of `items` are ignored.
+    pub fn verify_batch_with_challenges(&self, params: &Params, items: &[VerifyItem<'_>], challenges: &[Vec<u8>], rng_out: &[u8],
+                                        action: Action, chunk: usize) -> Result<Vec<Option<Vec<[u8; 32]>>>, GpuError> {
+        assert!(challenges.len() == items.len() && rng_out.len() == 32 * items.len());
+        let t = params.extension_degree;
+        let present_in: Vec<Vec<u8>> = items.iter().map(|i| i.min_values.iter().map(|v| v.is_some() as u8).collect()).collect();
+        let mins: Vec<Vec<u64>> = items.iter().map(|i| i.min_values.iter().map(|v| v.unwrap_or(0)).collect()).collect();
+        let raw: Vec<ffi::bpp_verify_item> = items.iter().enumerate().map(|(k, i)| ffi::bpp_verify_item {
+            proof: i.proof.as_ptr(),
+            proof_len: i.proof.len(),
+            commitments32: i.commitments.as_ptr(),
+            m: (i.commitments.len() / 32) as u32,
+            min_values: mins[k].as_ptr(),
+            min_present: present_in[k].as_ptr(),
+            seed_nonce32: i.seed_nonce.map_or(ptr::null(), |s| s.as_ptr()),
+            transcript_state: ptr::null(),
+            transcript_label: ptr::null(),
+            label_len: 0,
+        }).collect();
+        let chal_ptrs: Vec<*const u8> = challenges.iter().map(|c| c.as_ptr()).collect();
+        let mut masks = vec![0u8; items.len() * t * 32];
+        let mut present = vec![0u8; items.len()];
+        let mut err = [0 as core::ffi::c_char; 256];
+        let rc = unsafe {
+            ffi::bpp_verify_batch_with_challenges(self.ctx, params.handle, raw.as_ptr(), raw.len(), chal_ptrs.as_ptr(), rng_out.as_ptr(),
+                                                  action as c_int, chunk, masks.as_mut_ptr(), present.as_mut_ptr(), err.as_mut_ptr(), err.len())
+        };
+        let out = map_rc(rc, unsafe { CStr::from_ptr(err.as_ptr()) }.to_string_lossy().into_owned()).map(|_| unpack_masks(&masks, &present, t));
+        masks.iter_mut().for_each(|b| *b = 0); // recovered masks are secrets (src/extended_mask.rs:14)
+        out
+    }
+
+    // ---- seam B1: the three dalek multiscalar traits the reference is generic over (src/traits.rs:40-43, src/ristretto.rs:28-64);
+    // rust/bpp-gpu-ristretto implements them for a point type of its own on top of these three calls
+
+    /// `VartimePrecomputedMultiscalarMul::new(static_points)` (src/generators/bulletproof_gens.rs:103): `points` = count x 32 bytes
+    pub fn precomp(&self, points: &[u8]) -> Result<Precomp, GpuError> {
+        assert!(points.len() % 32 == 0);
+        let mut handle = 0u64;
+        map_rc(unsafe { ffi::bpp_precomp_create(self.ctx, points.as_ptr(), points.len() / 32, &mut handle) }, self.last_error())?;
+        Ok(Precomp { handle, count: points.len() / 32, owner: self.ctx })
+    }
+
+    /// `vartime_mixed_multiscalar_mul(static_scalars, dynamic_scalars, dynamic_points)` (src/range_proof.rs:339-345, :1050-1057):
+    /// scalars 32 canonical bytes each, points 32-byte ristretto255 encodings; static_scalars.len() / 32 <= table size
+    pub fn msm_mixed(&self, table: &Precomp, static_scalars: &[u8], dyn_scalars: &[u8], dyn_points: &[u8]) -> Result<[u8; 32], GpuError> {
+        assert!(static_scalars.len() % 32 == 0 && dyn_scalars.len() == dyn_points.len() && dyn_scalars.len() % 32 == 0);
+        let mut out = [0u8; 32];
+        let rc = unsafe {
+            ffi::bpp_msm_mixed(self.ctx, table.handle, static_scalars.as_ptr(), static_scalars.len() / 32, dyn_scalars.as_ptr(),
+                               dyn_points.as_ptr(), dyn_scalars.len() / 32, out.as_mut_ptr())
+        };
+        map_rc(rc, self.last_error())?;
+        Ok(out)
+    }
+
+    /// `VartimeMultiscalarMul::vartime_multiscalar_mul` / `MultiscalarMul::multiscalar_mul` (src/range_proof.rs:482-495, :512-521,
+    /// src/generators/pedersen_gens.rs:120)
+    pub fn msm_vartime(&self, scalars: &[u8], points: &[u8]) -> Result<[u8; 32], GpuError> {
+        assert!(scalars.len() == points.len() && scalars.len() % 32 == 0);
+        let mut out = [0u8; 32];
+        map_rc(unsafe { ffi::bpp_msm_vartime(self.ctx, scalars.as_ptr(), points.as_ptr(), scalars.len() / 32, out.as_mut_ptr()) }, self.last_error())?;
+        Ok(out)
+    }
+
+    /// what the library sees of its runtime preconditions: hardware queues (GPU_MAX_HW_QUEUES as the HIP runtime read it), live
+    /// contexts, the small-call gate ("Runtime preconditions")
+    pub fn runtime_info(&self) -> ffi::bpp_runtime_info {
+        let mut info = ffi::bpp_runtime_info::default();
+        unsafe { ffi::bpp_runtime_info_get(self.ctx, &mut info) };
+        info
+    }
+
     /// `RangeProof::verify_batch`: every `chunk` consecutive items are one reference batch (256 = MAX_RANGE_PROOF_BATCH_SIZE,
     /// 0 = the whole input).  Returns per item `Some(mask blindings, t x 32 bytes)` or `None`.
     pub fn verify_batch(&self, params: &Params, items: &[VerifyItem<'_>], action: Action, chunk: usize)
@@ -270,9 +346,37 @@ pub struct Params {
 }
 unsafe impl Send for Params {}
 unsafe impl Sync for Params {}
+impl Params {
+    pub fn extension_degree(&self) -> usize {
+        self.extension_degree
+    }
+}
 impl Drop for Params {
     fn drop(&mut self) {
         unsafe { ffi::bpp_params_destroy(self.owner, self.handle) };
+    }
+}
+
+/// A precomputed generator table on the device (bpp_precomp_*): `Precomputation: Send + Sync`, shared through Arc by the
+/// reference (src/traits.rs:42, src/generators/bulletproof_gens.rs:52).  Dropping it drops this holder's reference.
+pub struct Precomp {
+    handle: u64,
+    count: usize,
+    owner: *mut ffi::bpp_ctx, // the context that holds this reference (must outlive it)
+}
+unsafe impl Send for Precomp {}
+unsafe impl Sync for Precomp {}
+impl Precomp {
+    pub fn len(&self) -> usize {
+        self.count
+    }
+    pub fn is_empty(&self) -> bool {
+        self.count == 0
+    }
+}
+impl Drop for Precomp {
+    fn drop(&mut self) {
+        unsafe { ffi::bpp_precomp_destroy(self.owner, self.handle) };
     }
 }
 
@@ -409,8 +513,8 @@ pub fn default_engine() -> &'static Mutex<Engine> {
 
 /// `bpp_batcher`: many threads, each with one reference batch per call; the library pools the calls that are waiting into
 /// grouped engine calls (a small call alone is a chain of latency-bound kernels: separate 256-proof calls stop at about 5 000
-/// per second whatever the number of callers).  `verify` blocks and returns what `Engine::verify_batch_packed(.., VerifyOnly,
-/// 0)` would for that input alone.  Shareable between threads (`&self`).
+/// per second whatever the number of callers).  `verify` / `verify_action` block and return what
+/// `Engine::verify_batch_packed(.., action, 0)` would for that input alone.  Shareable between threads (`&self`).
 pub struct Batcher {
     raw: *mut ffi::bpp_batcher,
     _engine: Option<Engine>,  // the context of the first lane, when the batcher owns it (dropped after the batcher itself)
@@ -419,20 +523,33 @@ unsafe impl Send for Batcher {}
 unsafe impl Sync for Batcher {}
 
 impl Batcher {
-    /// `shape`: any input of the kind to be pooled (proof length, aggregation factor, transcript label)
-    pub fn new(engine: &Engine, params: &Params, shape: &PackedBatch<'_>, lanes: u32, max_wait_us: u32, max_calls: u32) -> Result<Batcher, GpuError> {
-        let raw_shape = shape.raw();
+    /// every shape and every VerifyAction pools (round 4: the `shape` argument of bpp_batcher_create is no longer needed)
+    pub fn new(engine: &Engine, params: &Params, lanes: u32, max_wait_us: u32, max_calls: u32) -> Result<Batcher, GpuError> {
         let mut raw = core::ptr::null_mut();
-        let rc = unsafe { ffi::bpp_batcher_create(engine.ctx, params.handle, &raw_shape, lanes, max_wait_us, max_calls, &mut raw) };
+        let rc = unsafe { ffi::bpp_batcher_create(engine.ctx, params.handle, core::ptr::null(), lanes, max_wait_us, max_calls, &mut raw) };
         map_rc(rc, String::from("bpp_batcher_create"))?;
         Ok(Batcher { raw, _engine: None })
     }
     /// the same, taking ownership of `engine` (a context that exists for this batcher only); `params` is retained on it first
-    pub fn new_owning(engine: Engine, params: &Params, shape: &PackedBatch<'_>, lanes: u32, max_wait_us: u32, max_calls: u32) -> Result<Batcher, GpuError> {
+    pub fn new_owning(engine: Engine, params: &Params, lanes: u32, max_wait_us: u32, max_calls: u32) -> Result<Batcher, GpuError> {
         map_rc(unsafe { ffi::bpp_params_retain(engine.ctx, params.handle) }, String::from("bpp_params_retain"))?;
-        let mut b = Batcher::new(&engine, params, shape, lanes, max_wait_us, max_calls)?;
+        let mut b = Batcher::new(&engine, params, lanes, max_wait_us, max_calls)?;
         b._engine = Some(engine);
         Ok(b)
+    }
+    /// any VerifyAction through the pool (bpp_batcher_verify_action): what `Engine::verify_batch_packed(.., action, 0)` returns for
+    /// this input alone -- its own seed nonces in (`input.seed_nonces`), its own masks out; `t` = the parameters' extension degree
+    pub fn verify_action(&self, input: &PackedBatch<'_>, action: Action, t: usize) -> Result<Vec<Option<Vec<[u8; 32]>>>, GpuError> {
+        let raw_in = input.raw();
+        let mut masks = vec![0u8; input.n_items * t * 32];
+        let mut present = vec![0u8; input.n_items];
+        let mut err = [0 as core::ffi::c_char; 256];
+        let rc = unsafe {
+            ffi::bpp_batcher_verify_action(self.raw, &raw_in, action as c_int, masks.as_mut_ptr(), present.as_mut_ptr(), err.as_mut_ptr(), err.len())
+        };
+        let out = map_rc(rc, unsafe { CStr::from_ptr(err.as_ptr()) }.to_string_lossy().into_owned()).map(|_| unpack_masks(&masks, &present, t));
+        masks.iter_mut().for_each(|b| *b = 0); // recovered masks are secrets (src/extended_mask.rs:14)
+        out
     }
     pub fn verify(&self, input: &PackedBatch<'_>) -> Result<(), GpuError> {
         let raw_in = input.raw();

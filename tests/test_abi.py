@@ -101,3 +101,11 @@ def test_missing_rccl_library_maps_to_the_comm_error_code():
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BPP_RCCL_LIB="/nonexistent/librccl.so"), capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0, (r.stdout, r.stderr[-1000:])
+
+
+def test_rust_ffi_declares_every_symbol_of_the_header():
+    """rust/bpp-gpu-shim/src/ffi.rs cannot be compiled here (no cargo): at least its extern block must name exactly the symbols
+    include/bpp.h declares, so that a new entry point never goes missing on the Rust side unnoticed"""
+    ffi = open(os.path.join(ROOT, "rust", "bpp-gpu-shim", "src", "ffi.rs")).read()
+    rust = sorted(set(re.findall(r"pub fn (bpp_[a-z0-9_]+)\s*\(", ffi)))
+    assert rust == _declared(), (sorted(set(_declared()) - set(rust)), sorted(set(rust) - set(_declared())))
