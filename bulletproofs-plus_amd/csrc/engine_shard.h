@@ -94,7 +94,7 @@ struct CommError {
 
 // sum over ranks of batch i's accumulators -> identity flag.  in: [rank][per_rank bytes], batch i's 128 bytes at i * 128.
 // One lane per batch (a handful of additions: the exchange is latency, not work).
-__global__ void k_sum_accumulators_wave(const uint8_t *__restrict__ in, uint32_t world, uint32_t per_rank, uint32_t k,
+__global__ void __launch_bounds__(64) k_sum_accumulators_wave(const uint8_t *__restrict__ in, uint32_t world, uint32_t per_rank, uint32_t k,
                                         uint32_t *__restrict__ is_identity) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;

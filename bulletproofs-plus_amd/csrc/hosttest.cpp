@@ -75,6 +75,12 @@ void ht_merlin_kat(const uint8_t *label, uint32_t llen, const uint8_t *ml, uint3
   Strobe s; merlin_new(s, label, llen); merlin_append_message(s, ml, mll, msg, mlen); merlin_challenge_bytes(s, cl, cll, out, n); strobe_to_bytes(state_out, s); }
 void ht_merlin_rng(const uint8_t state[203], const uint8_t *wit, uint32_t wlen, const uint8_t rnd[32], uint8_t *out, uint32_t n) {
   Strobe s; strobe_from_bytes(s, state); if (wlen) merlin_rng_rekey(s, (const uint8_t *)"witness", 7, wit, wlen); merlin_rng_finalize(s, rnd); merlin_rng_fill(s, out, n); }
+// nonce() through the word-level BLAKE2b the kernels use (blake2b.h: nonce_hash_words); j, k < 0: absent
+void ht_nonce_words(const uint8_t seed32[32], const char *label, uint32_t llen, int j, int k, uint8_t out[64]) {
+  uint64_t h[8];
+  nonce_hash_words(h, seed32, label, llen, j, k);
+  for (int i = 0; i < 8; i++) for (int b = 0; b < 8; b++) out[8 * i + b] = (uint8_t)(h[i] >> (8 * b));
+}
 void ht_blake2b(const uint8_t *key, uint32_t klen, const uint8_t *persona, uint32_t plen, uint8_t out[64]) { blake2b512_keyed_personal_empty(out, key, klen, persona, plen); }
 // batch-weight chains (chain_host.h): `width` chains of n proofs each in lock-step (1 = the template's scalar instance,
 // 4 = AVX2, 8 = AVX-512); returns 0 when the CPU lacks the instruction set

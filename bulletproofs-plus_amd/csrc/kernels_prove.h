@@ -593,9 +593,16 @@ __global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes,
     }
     for (uint32_t u = lane; u < mn; u += 64) {
       const bool lo = (u & (len - 1)) < nh;
-      sc g = cG[u], h = cH[u];
-      sc_montmul(g, g, lo ? einv : e_yinv);
-      sc_montmul(h, h, lo ? e : einv);
+      sc g = cG[u], h = cH[u], fg, fh;
+      // (word-wise selects: `lo ? einv : e_yinv` as an operand selects between the ADDRESSES of two locals, which then live in
+      // scratch memory)
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        fg.v[q] = lo ? einv.v[q] : e_yinv.v[q];
+        fh.v[q] = lo ? e.v[q] : einv.v[q];
+      }
+      sc_montmul(g, g, fg);
+      sc_montmul(h, h, fh);
       cG[u] = g;
       cH[u] = h;
     }
@@ -622,7 +629,12 @@ __global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes,
       sc_add(cr, cr, u);
     }
     for (int pass = 0; pass < 2; pass++) {
-      red[lane] = pass ? cr : cl;
+      {
+        sc pick;
+#pragma unroll
+        for (int q = 0; q < 8; q++) pick.v[q] = pass ? cr.v[q] : cl.v[q];
+        red[lane] = pick;
+      }
       __syncthreads();
       for (uint32_t off = 32; off >= 1; off >>= 1) {
         if (lane < off) {
@@ -738,11 +750,25 @@ __global__ void __launch_bounds__(64) kp_finish(const ProveDesc *__restrict__ de
   ProveState &st = ps[p];
   const uint32_t mn = desc[p].m * n_bits;
   const sc *a = vec + (size_t)p * (5 * mn + 2), *b = a + mn;
-  Strobe tr = st.tr;
-  bool ok = pv_validate_append(tr, "A1", 2, a1b32 + (size_t)p * 64);
-  ok = pv_validate_append(tr, "B", 1, a1b32 + (size_t)p * 64 + 32) && ok;
+  // the transcript's last three operations on the LDS-resident sponge of PASS 1 (lstrobe.h): merlin.h's byte-wise sponge,
+  // indexed at run-time positions, kept its 200 state bytes in scratch memory (224 bytes per lane, ~800 scratch accesses)
+  __shared__ uint32_t sponge[BPP_LS_WORDS * BPP_LS_STRIDE];
+  LStrobe tr;
+  tr.st = (lds_u32 *)sponge + threadIdx.x;
+#pragma unroll
+  for (uint32_t i = 0; i < 25; i++) {
+    const uint64_t w = st.tr.st[i];
+    tr.st[(2 * i) * BPP_LS_STRIDE] = (uint32_t)w;
+    tr.st[(2 * i + 1) * BPP_LS_STRIDE] = (uint32_t)(w >> 32);
+  }
+  tr.pos = st.tr.pos;
+  tr.pos_begin = st.tr.pos_begin;
+  const uint8_t *pa1 = a1b32 + (size_t)p * 64;
+  bool ok = !bytes32_all_zero(pa1) && !bytes32_all_zero(pa1 + 32);  // validate_and_append_point
+  lm_append_mem(tr, lm_label("A1", 2), 2, pa1, 32);
+  lm_append_mem(tr, lm_label("B", 1), 1, pa1 + 32, 32);
   sc e, esq, r1, s1, u;
-  ok = dev_challenge(tr, (const uint8_t *)"e", 1, e) && ok;
+  ok = lm_challenge_scalar(tr, lm_label("e", 1), 1, e) && ok;
   sc_montsq(esq, e);
   sc_montmul(u, a[0], e);
   sc_add(r1, st.r, u);

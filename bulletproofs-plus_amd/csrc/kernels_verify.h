@@ -383,7 +383,10 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
   sc ym1, acc = one;
   sc_sub(ym1, y, one);
   for (uint32_t j = 0; j < r + 2; j++) {
-    const sc x = (j < r) ? c[2 + j] : (j == r ? y : ym1);
+    sc x;  // (plain copies: `cond ? c[..] : y` selects between ADDRESSES and parks y and ym1 in scratch memory)
+    if (j < r) x = c[2 + j];
+    else if (j == r) x = y;
+    else x = ym1;
     if (j < r) o[SH_EINV(j)] = acc;
     else if (j == r) o[SH_YINV] = acc;
     else o[SH_YNM] = acc;
@@ -392,7 +395,10 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
   sc run, y_1_inverse, y_inverse;
   sc_mont_invert_vartime(run, acc);
   for (int j = (int)r + 1; j >= 0; j--) {
-    const sc x = ((uint32_t)j < r) ? c[2 + j] : ((uint32_t)j == r ? y : ym1);
+    sc x;
+    if ((uint32_t)j < r) x = c[2 + j];
+    else if ((uint32_t)j == r) x = y;
+    else x = ym1;
     const sc pre = ((uint32_t)j < r) ? o[SH_EINV(j)] : ((uint32_t)j == r ? o[SH_YINV] : o[SH_YNM]);
     sc inv_j;
     sc_montmul(inv_j, run, pre);
@@ -898,29 +904,28 @@ __global__ void __launch_bounds__(64) k_reduce_static(const sc *__restrict__ row
 
 // Mask recovery (src/range_proof.rs:941-969) with nonce() (src/utils/generic.rs:30-60), one lane per proof.
 __device__ __forceinline__ void dev_nonce(sc &out, const uint8_t seed32[32], const char *label, uint32_t llen, int j, int k) {
-  uint8_t key[43];
-  uint32_t n = 0;
-  key[n++] = 0;
-  for (int i = 0; i < 32; i++) key[n++] = seed32[i];
-  if (j >= 0) {
-    key[n++] = 'j';
-    u32le(key + n, (uint32_t)j);
-    n += 4;
+  uint64_t h[8];
+  nonce_hash_words(h, seed32, label, llen, j, k);  // (blake2b.h: the key block is put together in registers)
+  uint32_t w[16];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    w[2 * i] = (uint32_t)h[i];
+    w[2 * i + 1] = (uint32_t)(h[i] >> 32);
   }
-  if (k >= 0) {
-    key[n++] = 'k';
-    u32le(key + n, (uint32_t)k);
-    n += 4;
-  }
-  uint8_t h[64];
-  blake2b512_keyed_personal_empty(h, key, n, (const uint8_t *)label, llen);
-  sc_mont_from_wide(out, h);
+  sc_mont_from_wide_words(out, w);
 }
 
+// mask_k = ((d1_k - eta_k - e d_k) e^-2 - alpha_k - sum_j (e_j^2 dL_{j,k} + e_j^-2 dR_{j,k})) (z^2 y^(mn+1))^-1.
+// The r + 2 inverses of a proof (e^2, z^2 y^(mn+1), every round challenge) come out of ONE inversion of their product
+// (the reference inverts each where it needs it, :950,:958; until round 3 this kernel did the same: r + 2 divsteps inversions
+// of ~10 k instructions each were half of its work).  The prefix products wait in LDS, word-major like the PASS-1 sponge: a
+// register array indexed by the round would live in scratch memory.
+#define BPP_MASK_INV (BPP_MAX_ROUNDS + 1)  // e^2, z^2 y^(mn+1), e_0 .. e_{r-1}: r + 2 <= 13 values
 __global__ void __launch_bounds__(64) k_masks(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
                                               const sc *__restrict__ chal, const uint8_t *__restrict__ seeds32,
                                               uint32_t n_bits, uint32_t t, uint32_t cs, uint32_t B,
                                               uint8_t *__restrict__ masks_out /* [B][t][32] */) {
+  __shared__ uint32_t pre[BPP_MASK_INV * 8 * 64];  // word w of entry q of lane l at [(q * 8 + w) * 64 + l]
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B) return;
   const ProofDesc d = desc[p];
@@ -929,15 +934,53 @@ __global__ void __launch_bounds__(64) k_masks(const uint8_t *__restrict__ bytes,
   const uint8_t *seed = seeds32 + (size_t)p * 32;
   const uint8_t *pd1 = bytes + d.proof_off + 1;
   const uint32_t r = d.rounds, mn = d.m * n_bits;
-  if (r + 3 > cs) return;  // more rounds than any statement allows: refused on the host, its challenges were not kept
-  sc y = c[0], z = c[1], ef = c[2 + r];
-  sc e_square, e_square_inv, z_square, y_nm_1, zy_inv, tmp;
+  if (r + 3 > cs || r + 2 > BPP_MASK_INV) return;  // more rounds than any statement allows: refused on the host, its challenges were not kept
+  uint32_t *mine = pre + threadIdx.x;
+  auto park = [&](uint32_t q, const sc &v) {
+#pragma unroll
+    for (int w = 0; w < 8; w++) mine[(q * 8 + w) * 64] = v.v[w];
+  };
+  auto fetch = [&](uint32_t q, sc &v) {
+#pragma unroll
+    for (int w = 0; w < 8; w++) v.v[w] = mine[(q * 8 + w) * 64];
+  };
+  const sc y = c[0], z = c[1], ef = c[2 + r];
+  sc e_square, zy, tmp;
   sc_montsq(e_square, ef);
-  sc_mont_invert_vartime(e_square_inv, e_square);
-  sc_montsq(z_square, z);
-  sc_mont_pow_u32(y_nm_1, y, mn + 1);
-  sc_montmul(tmp, z_square, y_nm_1);
-  sc_mont_invert_vartime(zy_inv, tmp);
+  sc_montsq(tmp, z);
+  sc_mont_pow_u32(zy, y, mn + 1);
+  sc_montmul(zy, zy, tmp);  // z^2 y^(mn+1)
+  // prefix products: pre[q] = x_0 .. x_{q-1} with x = [e^2, z^2 y^(mn+1), e_0, .., e_{r-1}]
+  sc acc;
+  sc_mont_one(acc);
+  for (uint32_t q = 0; q < r + 2; q++) {
+    park(q, acc);
+    sc x;  // (plain copies: a conditional between two locals and a memory operand makes the compiler take the locals' addresses)
+    if (q == 0) x = e_square;
+    else if (q == 1) x = zy;
+    else x = c[q];  // c[2 + j] for q = 2 + j
+    sc_montmul(acc, acc, x);
+  }
+  sc run;
+  sc_mont_invert_vartime(run, acc);
+  // walking back: inverse of x_q = run * pre[q]; the round challenges' inverses are squared and parked where their prefix was
+  sc e_square_inv, zy_inv;
+  for (int q = (int)r + 1; q >= 0; q--) {
+    sc pq, inv;
+    fetch((uint32_t)q, pq);
+    sc_montmul(inv, run, pq);
+    sc x;
+    if (q == 0) x = e_square;
+    else if (q == 1) x = zy;
+    else x = c[q];
+    sc_montmul(run, run, x);
+    if (q == 0) e_square_inv = inv;
+    else if (q == 1) zy_inv = inv;
+    else {
+      sc_montsq(inv, inv);
+      park((uint32_t)q, inv);  // e_j^-2, j = q - 2
+    }
+  }
   for (uint32_t k = 0; k < t; k++) {
     sc mask, n1, n2;
     sc_load_mont(mask, pd1 + 32 * k);
@@ -950,10 +993,9 @@ __global__ void __launch_bounds__(64) k_masks(const uint8_t *__restrict__ bytes,
     dev_nonce(n1, seed, "alpha", 5, -1, (int)k);
     sc_sub(mask, mask, n1);
     for (uint32_t j = 0; j < r; j++) {
-      sc ej = c[2 + j], ej2, ej2inv, ejinv;
-      sc_montsq(ej2, ej);
-      sc_mont_invert_vartime(ejinv, ej);
-      sc_montsq(ej2inv, ejinv);
+      sc ej2, ej2inv;
+      sc_montsq(ej2, c[2 + j]);
+      fetch(2 + j, ej2inv);
       dev_nonce(n1, seed, "dL", 2, (int)j, (int)k);
       sc_montmul(n1, n1, ej2);
       sc_sub(mask, mask, n1);

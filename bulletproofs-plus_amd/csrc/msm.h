@@ -912,7 +912,7 @@ __global__ void k_ge_to_bytes(const ge *__restrict__ R, uint32_t n, uint8_t *__r
 }
 
 // sum of n accumulators (one lane; n = number of ranks) -> identity flag + encoding
-__global__ void k_sum_accumulators(const uint8_t *__restrict__ in128, uint32_t n, uint8_t *__restrict__ comp32,
+__global__ void __launch_bounds__(64) k_sum_accumulators(const uint8_t *__restrict__ in128, uint32_t n, uint8_t *__restrict__ comp32,
                                    uint32_t *__restrict__ is_identity) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   ge acc;

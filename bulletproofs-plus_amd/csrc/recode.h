@@ -152,6 +152,14 @@ inline FbGeom fb_geometry(uint32_t n_gens) {  // host side
 BPP_HD size_t fb_stride(const FbGeom &g) { return (size_t)g.windows * g.entries; }  // entries per generator
 BPP_HD bool fb_top_unsigned(const FbGeom &g) { return g.items < g.windows; }
 
+// word i of a scalar (0 for i >= 8) without indexing its register array at run time
+BPP_HD uint32_t sc_word(const sc &s, uint32_t i) {
+  uint32_t r = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 8; k++) r = (i == k) ? s.v[k] : r;
+  return r;
+}
+
 // digits of a canonical scalar: signed, in [-(2^(w-1) - 1), 2^(w-1)]; the top one in [0, 2^w] when fb_top_unsigned
 BPP_HD void fb_recode(int16_t *dig, const sc &s, const FbGeom &g) {
   uint32_t carry = 0;
@@ -159,7 +167,8 @@ BPP_HD void fb_recode(int16_t *dig, const sc &s, const FbGeom &g) {
     const uint32_t bit = w * g.wbits, wi = bit >> 5, sh = bit & 31u;
     uint32_t raw = 0;
     if (wi < 8) {
-      const uint64_t two = (uint64_t)s.v[wi] | ((wi + 1 < 8) ? ((uint64_t)s.v[wi + 1] << 32) : 0ull);
+      // (sc_word: a select chain over the eight words; s.v[wi] with a run-time wi parks the scalar in scratch memory)
+      const uint64_t two = (uint64_t)sc_word(s, wi) | ((uint64_t)sc_word(s, wi + 1) << 32);
       raw = (uint32_t)(two >> sh) & ((1u << g.wbits) - 1u);
     }
     const uint32_t v = raw + carry;

@@ -149,6 +149,15 @@ def test_merlin_and_blake2b(ht):
         out = _buf(64)
         ht.ht_blake2b(key, len(key), lab.encode(), len(lab), out)
         assert int.from_bytes(out.raw, "little") % L == O.nonce(sn, lab, j, k)
+        # the word-level form the kernels use (blake2b.h: nonce_hash_words -- the key block assembled by shifts, no byte array)
+        out2 = _buf(64)
+        ht.ht_nonce_words(sn.to_bytes(32, "little"), lab.encode(), len(lab), -1 if j is None else j, -1 if k is None else k, out2)
+        assert out2.raw == out.raw
+    for (j, k) in [(None, 0x5eadbeef), (0x01020304, 0x70b0c0d0), (0, None), (0x7fffffff, 0x7fffffff)]:  # every byte lane of the two indices
+        sn = int.from_bytes(bytes(range(101, 133)), "little") % L
+        out2 = _buf(64)
+        ht.ht_nonce_words(sn.to_bytes(32, "little"), b"dR", 2, -1 if j is None else j, -1 if k is None else k, out2)
+        assert int.from_bytes(out2.raw, "little") % L == O.nonce(sn, "dR", j, k)
 
 
 def test_weight_chains_lockstep(ht):
