@@ -1489,7 +1489,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
   // Decompression needs nothing PASS 1 produces (both only OR bits into status[]).  A small input leaves most of the chip
   // idle, so its decompression runs beside PASS 1 and the weight-free scalars on a second stream and joins before the
   // weights are needed (one 256-proof call 0.84 -> 0.79 ms).  Large inputs fill the chip either way: one stream, less
-  // bookkeeping (measured: no gain).  Stage profiling keeps the serial order so that its intervals mean something.
+  // bookkeeping (measured: no gain, HISTORY.md 3).  Stage profiling keeps the serial order so that its intervals mean something.
   const bool side = (ctx->opt.side_decompress >= 0 ? ctx->opt.side_decompress != 0 : b.B <= BPP_SIDE_DECOMPRESS_MAX) && !ctx->profile;
   const uint32_t n_proof_pts = b.total_dyn - b.sum_m;
   auto launch_decompress = [&](hipStream_t st) {
