@@ -26,7 +26,7 @@ replayed weight chain, all_gather of the 128-byte accumulators over RCCL).
 import os
 
 # More than four calls in flight only overlap if the HIP runtime may use more than its default four hardware queues (read
-# once, when the runtime starts: before torch is imported).  The headline (four steps in flight) does not depend on it,
+# once, when the runtime starts: before torch is imported).  The headline (three steps in flight) does not depend on it,
 # the 4096-proof leg does: 5.4 -> 8.5 / 10.8 M proofs/s with eight / twelve calls in flight (sixteen need 24 queues: 11.9 M).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
@@ -56,7 +56,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "4")),
+    # three steps in flight since round 4: with no copy left on a step's chain (the kernels read and write mapped host memory)
+    # three sustain what four did (256 steps: 2.45-2.49 against 2.48-2.54 ms per step, 20 steps: 2.53-2.57 against 2.55-2.62, one
+    # box, alternating: profiles/r04_conc_3_vs_4.txt) at a higher clock and three quarters of the latency per step
+    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "3")),
                     help="steps in flight per GPU (one engine/stream + one host thread each)")
     ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_step", type=int,
                     default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "64")),
@@ -665,7 +668,7 @@ def main():
 
     def recover_only_leg(data, params, steps=32, warmup=6):
         """SURVEY 8(f)2 / src/range_proof.rs:941-969,1040-1043: a wallet scanning outputs.  RecoverOnly over the headline's 65 536
-        resident proofs (seed nonces resident too) in 1024-proof reference batches, 4 steps in flight: PASS 1, decompression,
+        resident proofs (seed nonces resident too) in 1024-proof reference batches, as many steps in flight as the headline: PASS 1, decompression,
         k_masks; no weight chains, no PASS 2, no MSM.  Masks come back as arrays and are checked against the prover's blindings."""
         Rr, Sr = max(1, args.batches_per_step), max(1, args.concurrency)
         legr = Leg(bpp, packed, torch, device, params, data, 1024, Rr, Sr, 1024, action=int(bpp.VerifyAction.RecoverOnly))
