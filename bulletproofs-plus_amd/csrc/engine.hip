@@ -382,6 +382,9 @@ struct Batch {
   DevBuf<uint32_t> idx_commit, idx_proof, status0;  // dynamic slots of the commitments / of the proof points; initial status
   // device work buffers
   DevBuf<sc> chal, rows, scal, shr, tab;
+  DevBuf<uint64_t> parts;      // per-workgroup limb sums of the generator columns (k_scalars_lanes -> k_reduce_parts)
+  bool fused_columns = false;  // this layout sums the generator columns inside k_scalars_lanes (layout_groups decides)
+  uint32_t lanes_ppw = 1;      // proofs per workgroup of k_scalars_lanes for this batch
   DevBuf<uint8_t> rng_out, weights, masks, chal_bytes;
   DevBuf<uint32_t> status, group_first, group_dlo;
   DevBuf<uint32_t> dec_spill;  // k_decompress parks three field elements per proof point here across its squaring chain
@@ -406,7 +409,7 @@ void adopt_buffers(Batch &dst, Batch &src) {
 #define BPP_ADOPT(f) dst.f.swap(src.f)
   BPP_ADOPT(d_ext_status); BPP_ADOPT(bytes); BPP_ADOPT(states); BPP_ADOPT(seeds); BPP_ADOPT(d_desc); BPP_ADOPT(minvals);
   BPP_ADOPT(src_off); BPP_ADOPT(owner); BPP_ADOPT(idx_commit); BPP_ADOPT(idx_proof); BPP_ADOPT(status0); BPP_ADOPT(chal);
-  BPP_ADOPT(rows); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(tab); BPP_ADOPT(rng_out); BPP_ADOPT(weights);
+  BPP_ADOPT(rows); BPP_ADOPT(parts); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(tab); BPP_ADOPT(rng_out); BPP_ADOPT(weights);
   BPP_ADOPT(masks); BPP_ADOPT(chal_bytes); BPP_ADOPT(status); BPP_ADOPT(group_first); BPP_ADOPT(group_dlo); BPP_ADOPT(dynpts); BPP_ADOPT(dyn_hi); BPP_ADOPT(dec_spill);
   BPP_ADOPT(msm.counts); BPP_ADOPT(msm.starts); BPP_ADOPT(msm.sorted); BPP_ADOPT(msm.order); BPP_ADOPT(msm.order_win);
   BPP_ADOPT(msm.cls_hist);
@@ -490,7 +493,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1, msm_split = -1;
+        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -526,6 +529,7 @@ const OptionName kOptions[] = {
     {"fb_threads", "BPP_FB_THREADS", &bpp_ctx::Options::fb_threads},
     {"prove_subs", "BPP_PROVE_SUBS", &bpp_ctx::Options::prove_subs},
     {"msm_split", "BPP_MSM_SPLIT", &bpp_ctx::Options::msm_split},
+    {"fused_columns", "BPP_FUSED_COLUMNS", &bpp_ctx::Options::fused_columns},
 };
 void options_from_env(bpp_ctx *c) {
   for (const OptionName &o : kOptions)
@@ -1333,7 +1337,7 @@ uint64_t upload_device(bpp_ctx *ctx, const std::shared_ptr<Params> &Pp, uint64_t
     B->weights.alloc(n_items * 32);
     B->dynpts.alloc(dyn);
     if (decompress_spill_enabled()) B->dec_spill.alloc((size_t)30 * (dyn - B->sum_m));
-    B->rows.alloc((size_t)n_items * B->cols);
+    // (rows / parts: sized by layout_groups, which knows whether the generator columns are summed inside k_scalars_lanes)
     B->shr.alloc((size_t)n_items * SH_STRIDE);
     B->tab.alloc((size_t)n_items * lanes_tab_stride(B->lanes_nhi_max(P.n_bits)));
     B->masks.alloc(n_items * P.t * 32);
@@ -1733,6 +1737,27 @@ void check_chunk_errors(const Batch &b, uint32_t p0, uint32_t p1) {
   bpp::check_chunk_errors(b.h_status.data(), b.rounds_bad.data(), p0, p1);
 }
 
+// Shape of k_scalars_lanes for the current group layout, and the buffers that go with it (called when a layout is built and
+// again in front of every PASS 2: the option may have changed; nothing is reallocated once the sizes have been seen).
+void plan_lanes(bpp_ctx *ctx, Batch &b) {
+  // proofs per workgroup: enough (proof, generator pair) items for four passes of the 64 lanes.  Large inputs take sixteen
+  // 64-bit proofs per workgroup (the prologue's product jobs, 43 per proof, then fill whole wavefronts); small inputs keep four
+  // (more workgroups, shorter chains: the chip is idle anyway).
+  const uint32_t per_wg = b.B <= BPP_TABLES_WAVE_MAX ? 256u : 1024u;
+  b.lanes_ppw = std::max<uint32_t>(1, std::min<uint32_t>(BPP_LANES_MAX_PPW, per_wg / std::max<uint32_t>(1, b.max_mn)));
+  // Generator columns summed inside k_scalars_lanes (no per-proof rows at all) when a lane can own a generator index across the
+  // workgroup's proofs (max_mn a multiple of 64) and no workgroup straddles a group boundary
+  bool aligned = b.max_mn >= 64 && b.max_mn % 64 == 0;
+  for (uint32_t g = 1; g < b.G && aligned; g++) aligned = b.h_group_first[g] % b.lanes_ppw == 0;
+  b.fused_columns = aligned && ctx->opt.fused_columns != 0;  // (tests force the per-proof rows with fused_columns = 0)
+  if (b.fused_columns) {
+    b.rows.alloc((size_t)b.B * (b.params->t + 1));
+    b.parts.alloc((size_t)cdiv(b.B, b.lanes_ppw) * 2 * b.max_mn * 8);
+  } else {
+    b.rows.alloc((size_t)b.B * b.cols);
+  }
+}
+
 // (re)build the group layout + MSM term lists for `chunk`
 // `bounds` (optional): explicit group boundaries first[0..G] (0 = first[0] < ... < first[G] = B) instead of equal chunks --
 // the reference batches of different callers pooled into one call (bpp_verify_resident_groups)
@@ -1757,6 +1782,7 @@ void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk, const std::vector<uint3
   b.G = G;
   b.group_first.alloc(G + 1);
   b.scal.alloc((size_t)G * b.cols + b.total_dyn);
+  plan_lanes(ctx, b);
   // terms of group g: static columns (first 2*max_mn generators, then g bases, then h) + its proofs' dynamic slots.
   // Only the G + 1 offsets come from the host; the ~1 M term entries are written by k_layout_terms (building them on the
   // host and copying two pageable vectors cost ~20 ms per freshly uploaded batch)
@@ -1801,24 +1827,27 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool weights_residen
   hipStream_t s = ctx->stream;
   // (weights_resident: the grouped sharded form has put them into b.weights device -> device already)
   // otherwise k_scalars_lanes reads them where the chains wrote them: h_weights is mapped, each weight is read once
+  plan_lanes(ctx, b);
   b.weights_on_host = !weights_resident;
   const uint8_t *weights = weights_resident ? b.weights.p : b.h_weights.dev();
   tm.mark(M_WEIGHTS_IN);
   sc *dyn_scal = b.scal.p + (size_t)b.G * b.cols;
   {
     const uint32_t nhi_max = b.lanes_nhi_max(P.n_bits);
-    // proofs per workgroup: enough (proof, generator pair) items for four passes of the 64 lanes.  The weighted part of the
-    // scalar block (dynamic scalars, base columns, w into the low tables) is this kernel's prologue.
-    // Large inputs take sixteen 64-bit proofs per workgroup: the prologue's product jobs (43 per proof) then fill whole
-    // wavefronts; small inputs keep four (more workgroups, shorter chains: the chip is idle anyway).
-    const uint32_t per_wg = b.B <= BPP_TABLES_WAVE_MAX ? 256u : 1024u;
-    const uint32_t ppw = std::max<uint32_t>(1, std::min<uint32_t>(BPP_LANES_MAX_PPW, per_wg / std::max<uint32_t>(1, b.max_mn)));
+    // The weighted part of the scalar block (dynamic scalars, base columns, w into the low tables) is this kernel's prologue;
+    // proofs per workgroup and whether the generator columns are summed in it: layout_groups
+    const uint32_t ppw = b.lanes_ppw;
     hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s, b.d_desc.p, b.tab.p, b.shr.p,
-                       weights, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, b.rows.p, dyn_scal);
+                       weights, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, b.rows.p, dyn_scal,
+                       b.fused_columns ? b.parts.p : (uint64_t *)nullptr);
   }
   tm.mark(M_LANES);
-  hipLaunchKernelGGL(k_reduce_static, dim3(cdiv(b.cols, BPP_REDUCE_TILE), b.G), dim3(64), 0, s, b.rows.p, b.group_first.p, b.cols,
-                     b.scal.p);
+  if (b.fused_columns)
+    hipLaunchKernelGGL(k_reduce_parts, dim3(cdiv(b.cols, BPP_REDUCE_TILE), b.G), dim3(64), 0, s, b.parts.p, b.rows.p, b.group_first.p, b.cols,
+                       b.max_mn, P.t, b.lanes_ppw, b.scal.p);
+  else
+    hipLaunchKernelGGL(k_reduce_static, dim3(cdiv(b.cols, BPP_REDUCE_TILE), b.G), dim3(64), 0, s, b.rows.p, b.group_first.p, b.cols,
+                       b.scal.p);
   tm.mark(M_REDUCE);
   PointTables tabs{P.table.p, b.dynpts.p, P.table_len, P.table_hi.p, b.dyn_hi.p};
   msm_run(ctx, b.msm, b.scal.p, tabs, &tm);

@@ -632,7 +632,8 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
                                                       uint32_t n_bits, uint32_t t, uint32_t max_mn, uint32_t cols, uint32_t B,
                                                       uint32_t nhi_max, uint32_t ppw,
                                                       sc *__restrict__ rows /* weighted, Montgomery */,
-                                                      sc *__restrict__ dyn_out /* canonical */) {
+                                                      sc *__restrict__ dyn_out /* canonical */,
+                                                      uint64_t *__restrict__ parts /* null, or [workgroup][2 max_mn][8] limb sums */) {
   const uint32_t p0 = blockIdx.x * ppw;
   const uint32_t lane = threadIdx.x;
   extern __shared__ uint32_t lanes_lds_raw[];
@@ -690,7 +691,8 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
       const sc *S = shr + p * SH_STRIDE;
       const sc *T = tab + p * ts;
       sc *dyn = dyn_out + s_dyn[sub];
-      sc *row = rows + p * cols;
+      // (with `parts` the generator columns never exist per proof: rows[] holds the t + 1 base columns only, stride t + 1)
+      sc *row_base = parts ? rows + p * (t + 1) : rows + p * cols + 2 * (size_t)max_mn;  // the proof's t + 1 base columns
       uint8_t *base = reinterpret_cast<uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes;
       const sc *src;
       sc *dst = nullptr;
@@ -713,7 +715,7 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
       } else {
         const uint32_t k = job - j_row;  // 0: the h base, 1 + k: g base k
         src = k == 0 ? S + SH_HS : S + SH_D1(k - 1);
-        dst = row + 2 * max_mn + (k == 0 ? t : k - 1);
+        dst = row_base + (k == 0 ? t : k - 1);
         sel = 0;
       }
       sc a = *src, x;
@@ -746,6 +748,47 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     reinterpret_cast<sc9 *>(reinterpret_cast<uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes)[idx] = o9;
   }
   __syncthreads();
+  // ---- generator columns summed over the workgroup's proofs in registers (parts != null: max_mn >= 64, the workgroup lies
+  // inside ONE group): lane = generator index, the proofs in sequence, limb-wise 64-bit sums of the Montgomery values -- the
+  // per-proof rows (272 MB written here and read again by k_reduce_static in a 65 536-proof step) never exist; the group's
+  // column sums are then taken over ppw times fewer addends (k_reduce_parts)
+  if (parts) {
+    for (uint32_t i = lane; i < max_mn; i += 64) {
+      uint64_t ag[8], ah[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) ag[q] = ah[q] = 0;
+      for (uint32_t sub = 0; sub < ppw; sub++) {
+        const uint32_t r = s_r[sub];
+        if (r == ~0u) continue;
+        const uint32_t mn = s_m[sub] * n_bits;
+        if (i >= mn) continue;  // zero padding of a smaller statement
+        const uint32_t nhi = 1u << (r - LB);
+        const sc9 *T = reinterpret_cast<const sc9 *>(reinterpret_cast<const uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes);
+        const sc9 *glo = T, *yn2lo = T + 8, *hlo = T + 16;
+        const sc9 *ghi = T + 24, *y2hi = ghi + nhi_max, *shi = y2hi + nhi_max;
+        const sc e_square_z = *reinterpret_cast<const sc *>(reinterpret_cast<const uint8_t *>(T) + (size_t)n9 * sizeof(sc9));  // w e^2 z
+        const uint32_t lo = i & (nlo - 1), hi_i = (i >> LB) & (nhi - 1);
+        const uint32_t rlo = (~lo) & (nlo - 1), rhi = (~hi_i) & (nhi - 1);
+        sc gi, hi;
+        sc9_montmul(gi, glo[lo], ghi[hi_i]);
+        sc_add(gi, gi, e_square_z);
+        sc9_montmul2(hi, hlo[rlo], shi[rhi], yn2lo[lo], y2hi[hi_i]);  // w (s1e s[mn-1-i] - e^2 d[i] y^(mn-i))
+        sc_sub(hi, hi, e_square_z);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          ag[q] += gi.v[q];
+          ah[q] += hi.v[q];
+        }
+      }
+      uint64_t *o = parts + ((size_t)blockIdx.x * 2 * max_mn + 2 * i) * 8;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        o[q] = ag[q];
+        o[8 + q] = ah[q];
+      }
+    }
+    return;
+  }
   // ---- generator rows
   for (uint32_t it = lane; it < ppw * max_mn; it += 64) {
     const uint32_t sub = it / max_mn, i = it - sub * max_mn;
@@ -884,6 +927,61 @@ __global__ void __launch_bounds__(64) k_reduce_static(const sc *__restrict__ row
     uint64_t carry = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
+      carry += acc[i];
+      wds[i] = (uint32_t)carry;
+      carry >>= 32;
+    }
+    // value = lo + carry * 2^256 (Montgomery form of the true sum): from_mont(lo) + carry * 2^256 * R^-1
+    sc lo, res, hi, p256;
+    sc_const(lo, wds);
+    sc_from_mont(res, lo);
+    sc_0(hi);
+    hi.v[0] = (uint32_t)carry;
+    hi.v[1] = (uint32_t)(carry >> 32);
+    sc_const(p256, SC_P256);
+    sc_montmul(hi, hi, p256);
+    sc_add(res, res, hi);
+    out[(size_t)g * cols + col] = res;
+  }
+}
+
+// The same column sums from k_scalars_lanes' per-workgroup partial sums: column < 2 max_mn: sum over the group's workgroups of
+// parts[wg][col][8] (64-bit limb sums of up to ppw Montgomery values); the t + 1 base columns: sum over the group's proofs of
+// rows[p][t + 1] as before.  group g's proofs are [group_first[g], group_first[g + 1]), its workgroups the ones that hold them
+// (every group boundary is a multiple of ppw: checked on the host).
+__global__ void __launch_bounds__(64) k_reduce_parts(const uint64_t *__restrict__ parts, const sc *__restrict__ rows_base,
+                                                     const uint32_t *__restrict__ group_first, uint32_t cols, uint32_t max_mn, uint32_t t,
+                                                     uint32_t ppw, sc *__restrict__ out /* [G][cols] canonical */) {
+  const uint32_t g = blockIdx.y, lane = threadIdx.x;
+  const uint32_t col = blockIdx.x * BPP_REDUCE_TILE + (lane & (BPP_REDUCE_TILE - 1u)), slot = lane / BPP_REDUCE_TILE;
+  const uint32_t p0 = group_first[g], p1 = group_first[g + 1];
+  const bool live = col < cols;
+  uint64_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc[i] = 0;
+  if (live && col < 2 * max_mn) {
+    const uint32_t w0 = p0 / ppw, w1 = (p1 + ppw - 1) / ppw;
+    for (uint32_t w = w0 + slot; w < w1; w += 64u / BPP_REDUCE_TILE) {
+      const uint64_t *v = parts + ((size_t)w * 2 * max_mn + col) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc[i] += v[i];
+    }
+  } else if (live) {
+    for (uint32_t p = p0 + slot; p < p1; p += 64u / BPP_REDUCE_TILE) {
+      const sc v = rows_base[(size_t)p * (t + 1) + (col - 2 * max_mn)];
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc[i] += v.v[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    for (int off = 32; off >= (int)BPP_REDUCE_TILE; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
+  }
+  if (slot == 0 && live) {
+    uint32_t wds[8];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {  // limb sums are < 2^32 x (proofs of the group) < 2^57: the running carry stays inside 64 bits
       carry += acc[i];
       wds[i] = (uint32_t)carry;
       carry >>= 32;

@@ -434,3 +434,31 @@ print("ok")
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BPP_RCCL_LIB="/nonexistent/librccl.so"), capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("m,count,chunk", [(1, 4096 + 32, 1024), (1, 300, 48), (8, 70, 16), (4, 37, 0), (2, 1000, 250)])
+def test_column_sums_inside_the_lanes_kernel_equal_per_proof_rows(bpp, packed, engine, opt, m, count, chunk):
+    """round 4: k_scalars_lanes sums the generator columns over its workgroup's proofs in registers (k_reduce_parts adds the
+    workgroups' partial sums) whenever no workgroup straddles a group boundary; otherwise -- and with fused_columns = 0 -- the
+    per-proof rows + k_reduce_static of round 3.  Same static scalars (trace 4), same final point per group (trace 6), aligned
+    and unaligned chunk sizes, a tampered group, aggregation 1 / 2 / 4 / 8 (max_mn 64 ... 512)"""
+    params = bpp.RangeParameters.init(64, m, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    import bench
+    d = bench.make_inputs(np, packed, params, count, seed=4800 + m)
+    pr = d["proofs"].copy()
+    pr[count // 2, 1 + 32 + 96] ^= 1
+    got = {}
+    for fused in (1, 0):
+        opt("fused_columns", fused)
+        rb = packed.ResidentBatch(params, pr, d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+        with pytest.raises(bpp.ProofError):
+            rb.verify_only(chunk)
+        got[fused] = (rb.trace(4), rb.trace(5), rb.trace(6))
+        rb.close()
+    opt("fused_columns", -1)
+    assert got[1] == got[0]
+    rb = packed.ResidentBatch(params, d["proofs"], d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+    rb.verify_only(chunk)
+    assert set(rb.trace(6)) == {0}
+    rb.close()
+    params.close()
