@@ -8,6 +8,7 @@
 //   * SHAKE256 / SHA3-512 byte streams for generator derivation (src/generators/generators_chain.rs:23-33,
 //     src/protocols/curve_point_protocol.rs:31-35); the hash-to-group map itself runs on the device
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -486,6 +487,10 @@ struct bpp_ctx {
   DevBuf<uint8_t> prove_arena;
   PinnedBuf<uint8_t> prove_pin_in, prove_pin_out;
   std::vector<hipStream_t> prove_streams;
+  // high-priority twins of the sub-batch streams: the prover's small latency-bound kernels (Fiat-Shamir step, vector fold,
+  // point encoding) run on them so that they are not starved by the other sub-batch's chip-filling fixed-base MSM
+  std::vector<hipStream_t> prove_lane_streams;
+  std::vector<hipEvent_t> prove_sync_events;  // two per sub-batch: lane step done / fixed-base MSM done
   std::vector<hipEvent_t> prove_events;  // pairs around every k_fb_msm launch of the last bpp_prove_batch (profiling only)
   bpp_prove_profile pprof{};
   // knobs (tests, A/B timing).  -1 = the engine's own rule.  The BPP_* environment variables of the same names are read
@@ -493,7 +498,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1;
+        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -530,6 +535,7 @@ const OptionName kOptions[] = {
     {"prove_subs", "BPP_PROVE_SUBS", &bpp_ctx::Options::prove_subs},
     {"msm_split", "BPP_MSM_SPLIT", &bpp_ctx::Options::msm_split},
     {"fused_columns", "BPP_FUSED_COLUMNS", &bpp_ctx::Options::fused_columns},
+    {"prove_prio", "BPP_PROVE_PRIO", &bpp_ctx::Options::prove_prio},
 };
 void options_from_env(bpp_ctx *c) {
   for (const OptionName &o : kOptions)
@@ -840,6 +846,11 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
     (void)hipStreamDestroy(ps);
   }
   for (auto &e : ctx->prove_events) (void)hipEventDestroy(e);
+  for (auto &ps : ctx->prove_lane_streams) {
+    (void)hipStreamSynchronize(ps);
+    (void)hipStreamDestroy(ps);
+  }
+  for (auto &e : ctx->prove_sync_events) (void)hipEventDestroy(e);
   ctx->prove_arena.release();
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   {
@@ -1608,8 +1619,44 @@ class HostPool {
     std::mutex mu;
     std::condition_variable cv;
   };
+  // host threads this process may really run at once: the affinity mask, capped by a cgroup CPU quota when there is one (a
+  // 1-GPU box of the pool reports 256 logical CPUs and schedules 16: sized by hardware_concurrency() the pool had 32 workers
+  // there, and the chain scheduler, which compares the number of chains with the pool, took 64 chains of 4096 proofs for
+  // "few": scalar chains, 10 ms per call instead of 2 ms as eight lock-step bundles)
+  static uint32_t usable_cpus() {
+    uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = std::min<uint32_t>(n, (uint32_t)CPU_COUNT(&set));
+    auto read2 = [](const char *path, long long &a, long long &b, bool &a_is_max) {
+      FILE *f = fopen(path, "r");
+      if (!f) return false;
+      char w[64] = {0};
+      a_is_max = false;
+      bool ok = false;
+      if (fscanf(f, "%63s %lld", w, &b) == 2) {
+        ok = true;
+        if (strcmp(w, "max") == 0) a_is_max = true;
+        else a = atoll(w);
+      }
+      fclose(f);
+      return ok;
+    };
+    long long q = 0, per = 0;
+    bool is_max = false;
+    if (read2("/sys/fs/cgroup/cpu.max", q, per, is_max)) {  // cgroup v2: "<quota|max> <period>"
+      if (!is_max && q > 0 && per > 0) n = std::min<uint32_t>(n, (uint32_t)std::max<long long>(1, (q + per / 2) / per));
+    } else {  // cgroup v1
+      FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+      if (fq && fp && fscanf(fq, "%lld", &q) == 1 && fscanf(fp, "%lld", &per) == 1 && q > 0 && per > 0)
+        n = std::min<uint32_t>(n, (uint32_t)std::max<long long>(1, (q + per / 2) / per));
+      if (fq) fclose(fq);
+      if (fp) fclose(fp);
+    }
+    return std::max(1u, n);
+  }
   HostPool() {
-    uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    uint32_t hw = usable_cpus();
     const char *e = getenv("BPP_HOST_THREADS");
     uint32_t want = e ? (uint32_t)atoi(e) : std::min(hw, 32u);
     want = std::max(1u, std::min(want, 256u));
@@ -2561,6 +2608,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       wipe(ctx->prove_pin_out.p, ctx->prove_pin_out.n);
       if (!arena_clean && ctx->prove_arena.p) {
         for (auto &ps : ctx->prove_streams) (void)hipStreamSynchronize(ps);
+        for (auto &ps : ctx->prove_lane_streams) (void)hipStreamSynchronize(ps);
         (void)hipMemset(ctx->prove_arena.p, 0, ctx->prove_arena.n);
       }
     }};
@@ -2655,6 +2703,39 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
       ctx->prove_streams.push_back(ns);
     }
+    // A round of a sub-batch is [point encoding, Fiat-Shamir step, vector fold] -> [fixed-base MSM]: three latency-bound
+    // kernels of a few wavefronts, then one that fills the chip.  While one sub-batch's MSM runs, the other's small kernels
+    // queue for wave slots behind its 1024 workgroups and take 2-3x their own time (point encoding 70 -> 200 us, fold 45 -> 175:
+    // profiles/r04_prover_launches.txt), the MSMs of the two sub-batches drift into each other, and every period has ~110 us
+    // in which no MSM runs.  With prove_prio the small kernels go to a HIGH-priority stream of their own (the hardware hands
+    // freed wave slots to that queue first), joined to the MSM stream by an event each way per round.
+    const bool prio = ctx->opt.prove_prio > 0;  // (off by default: measured, no gain -- profiles/r04_prover_prio_ab.txt)
+    if (prio) {
+      int least = 0, greatest = 0;
+      HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      while (ctx->prove_lane_streams.size() < n_sub) {
+        hipStream_t ns;
+        HIP_CHECK(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, greatest));
+        ctx->prove_lane_streams.push_back(ns);
+      }
+      while (ctx->prove_sync_events.size() < 2 * (size_t)n_sub) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->prove_sync_events.push_back(e);
+      }
+    }
+    // lane(q): the stream of sub-batch q's small kernels; msm(q): of its fixed-base MSMs (the same stream without prove_prio)
+    auto lane_stream = [&](uint32_t q) { return prio ? ctx->prove_lane_streams[q] : ctx->prove_streams[q]; };
+    auto to_msm = [&](uint32_t q) {  // the MSM stream continues behind everything enqueued on the lane stream so far
+      if (!prio) return;
+      HIP_CHECK(hipEventRecord(ctx->prove_sync_events[2 * q], ctx->prove_lane_streams[q]));
+      HIP_CHECK(hipStreamWaitEvent(ctx->prove_streams[q], ctx->prove_sync_events[2 * q], 0));
+    };
+    auto to_lane = [&](uint32_t q) {  // and back
+      if (!prio) return;
+      HIP_CHECK(hipEventRecord(ctx->prove_sync_events[2 * q + 1], ctx->prove_streams[q]));
+      HIP_CHECK(hipStreamWaitEvent(ctx->prove_lane_streams[q], ctx->prove_sync_events[2 * q + 1], 0));
+    };
     const uint32_t stride = 2 * mn + t + 1;
     struct Sub {
       uint32_t lo, nb;
@@ -2760,7 +2841,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     // alone: its latency-bound Fiat-Shamir kernels with nothing beside them).
     for (uint32_t q = 0; q < n_sub; q++) {
       Sub &u = subs[q];
-      hipStream_t s = ctx->prove_streams[q];
+      hipStream_t s = lane_stream(q), sm = ctx->prove_streams[q];
       const uint32_t nb = u.nb;
       const dim3 lane_grid(cdiv(nb, 64));
       HIP_CHECK(hipMemcpyAsync(u.d_bytes, pin_bytes + u.bytes_lo, u.bytes_len, hipMemcpyHostToDevice, s));
@@ -2772,10 +2853,12 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       // witness check (:275-284): commit(v_j, r_j) for every opening, compared with the statement's commitments
       hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_bytes, u.d_desc, t, n_gen, nb, m, 1 + t, u.d_cts,
                          u.d_ctg, u.d_ctc);
-      fb_mark(s);
-      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(ctx, 1 + t, P.fb_geo)), 0, s, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, P.fb_geo,
+      to_msm(q);
+      fb_mark(sm);
+      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(ctx, 1 + t, P.fb_geo)), 0, sm, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, P.fb_geo,
                          u.d_ge);
-      fb_mark(s);
+      fb_mark(sm);
+      to_lane(q);
       hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_ge, nb * m, u.d_commit32);
       hipLaunchKernelGGL(kp_init, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_states, P.d_hg32.p, n, t, nb, u.d_ps);
       hipLaunchKernelGGL(kp_check_commitments, lane_grid, b64, 0, s, u.d_bytes, u.d_desc, u.d_commit32, nb, u.d_ps);
@@ -2785,22 +2868,24 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     for (uint32_t j = 0; j <= rounds; j++)
       for (uint32_t q = 0; q < n_sub; q++) {
         Sub &u = subs[q];
-        hipStream_t s = ctx->prove_streams[q];
+        hipStream_t s = lane_stream(q), sm = ctx->prove_streams[q];
         const uint32_t nb = u.nb;
         const uint8_t *lr_prev = j ? u.d_lr + (size_t)(j - 1) * nb * 64 : nullptr;
         hipLaunchKernelGGL(kp_lane, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
         hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
                            stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
         uint8_t *out = (j < rounds) ? u.d_lr + (size_t)j * nb * 64 : u.d_a1b;
-        fb_mark(s);
-        hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(fb_threads(ctx, mn + t + 1, P.fb_geo)), 0, s, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, P.fb_geo,
+        to_msm(q);
+        fb_mark(sm);
+        hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(fb_threads(ctx, mn + t + 1, P.fb_geo)), 0, sm, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, P.fb_geo,
                            u.d_ge);
-        fb_mark(s);
+        fb_mark(sm);
+        to_lane(q);
         hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);
       }
     for (uint32_t q = 0; q < n_sub; q++) {
       Sub &u = subs[q];
-      hipStream_t s = ctx->prove_streams[q];
+      hipStream_t s = lane_stream(q);
       const uint32_t nb = u.nb;
       hipLaunchKernelGGL(kp_finish, dim3(cdiv(nb, 64)), b64, 0, s, u.d_desc, n, t, nb, rounds, u.d_a32, u.d_lr, u.d_a1b, u.d_vec, u.d_ps,
                          u.d_proofs, (uint32_t)plen);
@@ -2810,7 +2895,10 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       // zeroize the device copies of witness-derived data (the reference uses Zeroizing<> for these)
       HIP_CHECK(hipMemsetAsync(arena_base + u.arena_lo, 0, u.arena_len, s));
     }
-    for (uint32_t q = 0; q < n_sub; q++) HIP_CHECK(hipStreamSynchronize(ctx->prove_streams[q]));
+    for (uint32_t q = 0; q < n_sub; q++) {
+      HIP_CHECK(hipStreamSynchronize(lane_stream(q)));  // (everything of the MSM stream lies in front of the lane stream's tail)
+      HIP_CHECK(hipStreamSynchronize(ctx->prove_streams[q]));
+    }
     arena_clean = true;  // every sub-batch's arena range was zeroed on its stream
     if (ctx->profile) {
       bpp_prove_profile &pp = ctx->pprof;

@@ -188,6 +188,10 @@ int comm_fail(bpp_comm *c, int code, const std::string &m, char *errbuf = nullpt
 // Waits for everything enqueued on the communicator's stream -- a collective and the copies around it -- with the
 // communicator's deadline.  Polls (the wait must be interruptible: hipStreamSynchronize is not).
 void comm_wait(bpp_comm *c, hipStream_t cs) {
+  if (c->timeout_ms == 0) {  // no deadline asked for: the plain blocking wait
+    HIP_CHECK(hipStreamSynchronize(cs));
+    return;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   for (uint32_t spins = 0;; spins++) {
     const hipError_t q = hipStreamQuery(cs);

@@ -434,7 +434,7 @@ typedef struct {
 int bpp_prove_profile_get(bpp_ctx *ctx, bpp_prove_profile *out);
 
 /* size of the process-wide host worker pool that runs the batch-weight chains and the upload packer
- * (BPP_HOST_THREADS, default min(cores, 32)): the verifier's throughput depends on it */
+ * (BPP_HOST_THREADS, default min(usable cores, 32), usable = affinity mask capped by the cgroup CPU quota): the verifier's throughput depends on it */
 int bpp_host_threads(void);
 
 /* diagnostics: the shader clock the device holds RIGHT NOW, sampled by one napping wavefront on this context's stream for
