@@ -742,8 +742,13 @@ def main():
                              "achieved": fb_bytes / (pp["fb_msm_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": fb_bytes / (pp["fb_msm_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                              "fb_window_bits": pp["fb_window_bits"], "fb_terms": pp["fb_terms"],
+                             "additions_per_s_kernel_events": pp["fb_terms"] * pp["fb_windows"] / (pp["fb_msm_ms"] * 1e-3),
+                             "additions_per_s_call_wall": pp["fb_terms"] * pp["fb_windows"] / (pp["total_ms"] * 1e-3),
+                             "engine_call_ms": pp["total_ms"],
                              "note": "achieved / algorithmic_bytes / kernel_ms are sums over the %d launches of ONE call (both "
-                                     "sub-batch streams); 64 B per term" % pp["fb_launches"]}}
+                                     "sub-batch streams); 64 B per term.  The launches of the two sub-batch streams OVERLAP, so the "
+                                     "summed event time exceeds the wall time they cover: additions_per_s_call_wall divides by the "
+                                     "whole call instead (start-up, Fiat-Shamir steps and the final step included)" % pp["fb_launches"]}}
 
     if args.only in ("cfg3", "prover"):  # a rocprofv3 child pass of measure_traffic(): just the kernels, a short line
         res = cfg3_leg(args.steps, args.warmup, only=True) if args.only == "cfg3" else prover_leg(2)

@@ -491,6 +491,10 @@ struct bpp_ctx {
   // point encoding) run on them so that they are not starved by the other sub-batch's chip-filling fixed-base MSM
   std::vector<hipStream_t> prove_lane_streams;
   std::vector<hipEvent_t> prove_sync_events;  // two per sub-batch: lane step done / fixed-base MSM done
+  // the witness check of a sub-batch (commit(v_j, r_j) against the statement's commitments, :275-284) runs on a stream of its own
+  // beside the call's first steps; two events per sub-batch: inputs resident / check done
+  std::vector<hipStream_t> prove_aux_streams;
+  std::vector<hipEvent_t> prove_aux_events;
   std::vector<hipEvent_t> prove_events;  // pairs around every k_fb_msm launch of the last bpp_prove_batch (profiling only)
   bpp_prove_profile pprof{};
   // knobs (tests, A/B timing).  -1 = the engine's own rule.  The BPP_* environment variables of the same names are read
@@ -498,7 +502,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1;
+        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -536,6 +540,7 @@ const OptionName kOptions[] = {
     {"msm_split", "BPP_MSM_SPLIT", &bpp_ctx::Options::msm_split},
     {"fused_columns", "BPP_FUSED_COLUMNS", &bpp_ctx::Options::fused_columns},
     {"prove_prio", "BPP_PROVE_PRIO", &bpp_ctx::Options::prove_prio},
+    {"prove_fused", "BPP_PROVE_FUSED", &bpp_ctx::Options::prove_fused},
 };
 void options_from_env(bpp_ctx *c) {
   for (const OptionName &o : kOptions)
@@ -851,6 +856,11 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
     (void)hipStreamDestroy(ps);
   }
   for (auto &e : ctx->prove_sync_events) (void)hipEventDestroy(e);
+  for (auto &ps : ctx->prove_aux_streams) {
+    (void)hipStreamSynchronize(ps);
+    (void)hipStreamDestroy(ps);
+  }
+  for (auto &e : ctx->prove_aux_events) (void)hipEventDestroy(e);
   ctx->prove_arena.release();
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   {
@@ -2607,6 +2617,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       wipe(ctx->prove_pin_in.p, ctx->prove_pin_in.n);
       wipe(ctx->prove_pin_out.p, ctx->prove_pin_out.n);
       if (!arena_clean && ctx->prove_arena.p) {
+        for (auto &ps : ctx->prove_aux_streams) (void)hipStreamSynchronize(ps);
         for (auto &ps : ctx->prove_streams) (void)hipStreamSynchronize(ps);
         for (auto &ps : ctx->prove_lane_streams) (void)hipStreamSynchronize(ps);
         (void)hipMemset(ctx->prove_arena.p, 0, ctx->prove_arena.n);
@@ -2642,7 +2653,9 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       if (it.seed_nonce32 && !sc_is_canonical(it.seed_nonce32)) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "seed nonce is not canonical"};
       d.wit_off = (uint32_t)bytes.size();
       for (uint32_t j = 0; j < m; j++) {
-        for (int k = 0; k < 8; k++) bytes.push_back((uint8_t)(it.values[j] >> (8 * k)));
+        uint8_t v8[8];
+        for (int k = 0; k < 8; k++) v8[k] = (uint8_t)(it.values[j] >> (8 * k));
+        bytes.insert(bytes.end(), v8, v8 + 8);
         bytes.insert(bytes.end(), it.blindings32 + (size_t)j * t * 32, it.blindings32 + (size_t)(j + 1) * t * 32);
       }
       d.commit_off = (uint32_t)bytes.size();
@@ -2653,6 +2666,12 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       d.flags = it.seed_nonce32 ? 1u : 0u;
       if (it.seed_nonce32) bytes.insert(bytes.end(), it.seed_nonce32, it.seed_nonce32 + 32);
       else bytes.insert(bytes.end(), 32, 0);
+      // the same transcript source as the previous item (the common case: one label for the whole call): same id, no key, no lookup
+      if (i && items[i - 1].transcript_state == it.transcript_state && items[i - 1].transcript_label == it.transcript_label &&
+          items[i - 1].label_len == it.label_len) {
+        d.state_idx = desc[i - 1].state_idx;
+        continue;
+      }
       std::string key;
       if (it.transcript_state) {
         key.assign((const char *)it.transcript_state, 203);
@@ -2709,6 +2728,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     // profiles/r04_prover_launches.txt), the MSMs of the two sub-batches drift into each other, and every period has ~110 us
     // in which no MSM runs.  With prove_prio the small kernels go to a HIGH-priority stream of their own (the hardware hands
     // freed wave slots to that queue first), joined to the MSM stream by an event each way per round.
+    const bool fused = ctx->opt.prove_fused != 0;  // one launch per round for encoding + Fiat-Shamir step + vector step (tests run both)
     const bool prio = ctx->opt.prove_prio > 0;  // (off by default: measured, no gain -- profiles/r04_prover_prio_ab.txt)
     if (prio) {
       int least = 0, greatest = 0;
@@ -2723,6 +2743,16 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->prove_sync_events.push_back(e);
       }
+    }
+    while (ctx->prove_aux_streams.size() < n_sub) {
+      hipStream_t ns;
+      HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+      ctx->prove_aux_streams.push_back(ns);
+    }
+    while (ctx->prove_aux_events.size() < 2 * (size_t)n_sub) {
+      hipEvent_t e;
+      HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ctx->prove_aux_events.push_back(e);
     }
     // lane(q): the stream of sub-batch q's small kernels; msm(q): of its fixed-base MSMs (the same stream without prove_prio)
     auto lane_stream = [&](uint32_t q) { return prio ? ctx->prove_lane_streams[q] : ctx->prove_streams[q]; };
@@ -2843,25 +2873,28 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       Sub &u = subs[q];
       hipStream_t s = lane_stream(q), sm = ctx->prove_streams[q];
       const uint32_t nb = u.nb;
-      const dim3 lane_grid(cdiv(nb, 64));
       HIP_CHECK(hipMemcpyAsync(u.d_bytes, pin_bytes + u.bytes_lo, u.bytes_len, hipMemcpyHostToDevice, s));
       HIP_CHECK(hipMemcpyAsync(u.d_states, pin_states, states.size(), hipMemcpyHostToDevice, s));
       HIP_CHECK(hipMemcpyAsync(u.d_minpres, pin_minpres + (size_t)u.lo * m, (size_t)nb * m, hipMemcpyHostToDevice, s));
       HIP_CHECK(hipMemcpyAsync(u.d_minvals, pin_minvals + (size_t)u.lo * m * 8, (size_t)nb * m * 8, hipMemcpyHostToDevice, s));
       HIP_CHECK(hipMemcpyAsync(u.d_desc, pin_desc + (size_t)u.lo * sizeof(ProveDesc), (size_t)nb * sizeof(ProveDesc),
                                hipMemcpyHostToDevice, s));
-      // witness check (:275-284): commit(v_j, r_j) for every opening, compared with the statement's commitments
-      hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_bytes, u.d_desc, t, n_gen, nb, m, 1 + t, u.d_cts,
+      // witness check (:275-284): commit(v_j, r_j) for every opening, compared with the statement's commitments.  Nothing of the
+      // proof depends on it (a mismatch is a status bit read after the call), so its three kernels run on a stream of their own
+      // beside kp_init / kp_A / the first round's small kernels (in line they were 0.2 ms of the call's first 0.75 ms, in which no
+      // round's MSM runs yet) and are joined in front of the first round's MSM, which reuses their output buffer
+      hipStream_t sx = ctx->prove_aux_streams[q];
+      HIP_CHECK(hipEventRecord(ctx->prove_aux_events[2 * q], s));
+      HIP_CHECK(hipStreamWaitEvent(sx, ctx->prove_aux_events[2 * q], 0));
+      hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(nb * m, 64)), b64, 0, sx, u.d_bytes, u.d_desc, t, n_gen, nb, m, 1 + t, u.d_cts,
                          u.d_ctg, u.d_ctc);
-      to_msm(q);
-      fb_mark(sm);
-      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(ctx, 1 + t, P.fb_geo)), 0, sm, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, P.fb_geo,
+      fb_mark(sx);
+      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(ctx, 1 + t, P.fb_geo)), 0, sx, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, P.fb_geo,
                          u.d_ge);
-      fb_mark(sm);
-      to_lane(q);
-      hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, s, u.d_ge, nb * m, u.d_commit32);
+      fb_mark(sx);
+      hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, sx, u.d_ge, nb * m, u.d_commit32);
+      HIP_CHECK(hipEventRecord(ctx->prove_aux_events[2 * q + 1], sx));
       hipLaunchKernelGGL(kp_init, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_states, P.d_hg32.p, n, t, nb, u.d_ps);
-      hipLaunchKernelGGL(kp_check_commitments, lane_grid, b64, 0, s, u.d_bytes, u.d_desc, u.d_commit32, nb, u.d_ps);
       hipLaunchKernelGGL(kp_A, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, P.table.p, P.fb_table.p, P.fb_geo, n_gen, n,
                          t, u.d_ps, u.d_a32);
     }
@@ -2870,18 +2903,28 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         Sub &u = subs[q];
         hipStream_t s = lane_stream(q), sm = ctx->prove_streams[q];
         const uint32_t nb = u.nb;
-        const uint8_t *lr_prev = j ? u.d_lr + (size_t)(j - 1) * nb * 64 : nullptr;
-        hipLaunchKernelGGL(kp_lane, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
-        hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
-                           stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
+        uint8_t *lr_prev = j ? u.d_lr + (size_t)(j - 1) * nb * 64 : nullptr;
+        if (fused) {  // the previous round's L / R are encoded by the same launch (kernels_prove.h: kp_round)
+          hipLaunchKernelGGL(kp_round, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, nb, j, rounds, stride,
+                             u.d_a32, j ? u.d_ge : (const ge *)nullptr, lr_prev, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
+        } else {
+          hipLaunchKernelGGL(kp_lane, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
+          hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
+                             stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
+        }
         uint8_t *out = (j < rounds) ? u.d_lr + (size_t)j * nb * 64 : u.d_a1b;
+        if (j == 0) {  // the witness check joins here: its verdict into the proof's status, its buffer free for the round's MSM
+          HIP_CHECK(hipStreamWaitEvent(s, ctx->prove_aux_events[2 * q + 1], 0));
+          hipLaunchKernelGGL(kp_check_commitments, dim3(cdiv(nb, 64)), b64, 0, s, u.d_bytes, u.d_desc, u.d_commit32, nb, u.d_ps);
+        }
         to_msm(q);
         fb_mark(sm);
         hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(fb_threads(ctx, mn + t + 1, P.fb_geo)), 0, sm, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, P.fb_geo,
                            u.d_ge);
         fb_mark(sm);
         to_lane(q);
-        hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);
+        if (!fused || j == rounds)  // (A1 and B of the last launch: kp_finish is a one-lane-per-proof kernel)
+          hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);
       }
     for (uint32_t q = 0; q < n_sub; q++) {
       Sub &u = subs[q];

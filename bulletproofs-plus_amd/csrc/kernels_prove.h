@@ -397,10 +397,10 @@ __global__ void __launch_bounds__(64) kp_A(const uint8_t *__restrict__ bytes, co
 //                 (j < r: d_L, d_R :437-464, y^-n :426-432;  j == r: r, s, d, eta :542-571)
 // The per-round TranscriptRng is a throw-away clone (src/transcripts.rs:185-194): it is only built when something is
 // drawn from it (no seed nonce, or the final round's r and s).
-__global__ void __launch_bounds__(64) kp_lane(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
-                                              uint32_t n_bits, uint32_t t, uint32_t B, uint32_t j, uint32_t rounds,
-                                              const uint8_t *__restrict__ a32, const uint8_t *__restrict__ lr32 /* [B][2][32] of round j-1 */,
-                                              ProveState *__restrict__ ps) {
+__device__ __forceinline__ void kp_lane_body(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
+                                             uint32_t n_bits, uint32_t t, uint32_t B, uint32_t j, uint32_t rounds,
+                                             const uint8_t *__restrict__ a32, const uint8_t *lr32 /* [B][2][32] of round j-1 */,
+                                             ProveState *ps) {
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
   if (p >= B) return;
   __shared__ ProveLds L;
@@ -495,12 +495,12 @@ __global__ void __launch_bounds__(64) kp_lane(const uint8_t *__restrict__ bytes,
 // ---- wave kernel, step j = 0..r (one wavefront per proof): vector prep / fold / inner products / MSM term lists ----
 // vec layout per proof (Montgomery): a[mn] | b[mn] | cG[mn] | cH[mn] | ypow[mn+2]
 // term rows per proof: 2 outputs x stride; gidx uses the table order (2i = G_i, 2i+1 = H_i, n_gen + k = G_k, n_gen + t = H)
-__global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
-                                              const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present,
-                                              uint32_t n_bits, uint32_t t, uint32_t n_gen, uint32_t j, uint32_t rounds,
-                                              uint32_t stride, ProveState *__restrict__ ps, sc *__restrict__ vec,
-                                              sc *__restrict__ term_scal, uint32_t *__restrict__ term_gidx,
-                                              uint32_t *__restrict__ term_count) {
+__device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
+                                             const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present,
+                                             uint32_t n_bits, uint32_t t, uint32_t n_gen, uint32_t j, uint32_t rounds,
+                                             uint32_t stride, ProveState *ps, sc *__restrict__ vec,
+                                             sc *__restrict__ term_scal, uint32_t *__restrict__ term_gidx,
+                                             uint32_t *__restrict__ term_count) {
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
   const ProveDesc d = desc[p];
   ProveState &st = ps[p];
@@ -736,6 +736,47 @@ __global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes,
       term_count[2 * p + 1] = t + 1;
     }
   }
+}
+
+// The two steps as kernels of their own (prove_fused = 0; tests run both forms) ...
+__global__ void __launch_bounds__(64) kp_lane(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc, uint32_t n_bits,
+                                              uint32_t t, uint32_t B, uint32_t j, uint32_t rounds, const uint8_t *__restrict__ a32,
+                                              const uint8_t *lr32, ProveState *ps) {
+  kp_lane_body(bytes, desc, n_bits, t, B, j, rounds, a32, lr32, ps);
+}
+__global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
+                                              const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present, uint32_t n_bits,
+                                              uint32_t t, uint32_t n_gen, uint32_t j, uint32_t rounds, uint32_t stride, ProveState *ps,
+                                              sc *__restrict__ vec, sc *__restrict__ term_scal, uint32_t *__restrict__ term_gidx,
+                                              uint32_t *__restrict__ term_count) {
+  kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count);
+}
+// ... and as ONE launch per round (round 4): the encoding of the previous round's L and R (two lanes, ristretto_compress), the
+// Fiat-Shamir step and the vector step of a proof are consecutive phases of the same 64-lane workgroup.  As three launches per
+// round they were three latency-bound kernels of a few wavefronts each, every one of them queueing for wave slots behind the
+// other sub-batch's chip-filling fixed-base MSM (70 / 135 / 45 us alone, 70-200 / 130-180 / 45-175 us in a call:
+// profiles/r04_prover_launches.txt); whatever a phase writes to memory for the next one is read by the same workgroup behind a
+// barrier.  ge_prev == null: nothing to encode (round 0).
+__global__ void __launch_bounds__(64) kp_round(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
+                                               const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present, uint32_t n_bits,
+                                               uint32_t t, uint32_t n_gen, uint32_t B, uint32_t j, uint32_t rounds, uint32_t stride,
+                                               const uint8_t *__restrict__ a32, const ge *__restrict__ ge_prev, uint8_t *lr_prev,
+                                               ProveState *ps, sc *__restrict__ vec, sc *__restrict__ term_scal,
+                                               uint32_t *__restrict__ term_gidx, uint32_t *__restrict__ term_count) {
+  const uint32_t p = blockIdx.x;
+  if (p >= B) return;
+  if (ge_prev && threadIdx.x < 2) {
+    uint8_t c32[32];
+    ristretto_compress(c32, ge_prev[2 * (size_t)p + threadIdx.x]);
+    uint32_t *o = (uint32_t *)(lr_prev + (size_t)p * 64 + 32 * threadIdx.x);
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      o[k] = (uint32_t)c32[4 * k] | ((uint32_t)c32[4 * k + 1] << 8) | ((uint32_t)c32[4 * k + 2] << 16) | ((uint32_t)c32[4 * k + 3] << 24);
+  }
+  __syncthreads();
+  kp_lane_body(bytes, desc, n_bits, t, B, j, rounds, a32, lr_prev, ps);
+  __syncthreads();
+  kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count);
 }
 
 // ---- final lane kernel: challenge_final_e, responses, wire bytes (:587-607, to_bytes :1120-1150) ----

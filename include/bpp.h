@@ -72,7 +72,8 @@ const char *bpp_ctx_last_error(bpp_ctx *ctx);
 /* per-context knobs for tests and A/B timing; value -1 restores the engine's own rule.  Names: "transcripts_wave",
  * "tables_wave", "side_decompress", "msm_quad", "msm_final_quad" (0 / 1: force the one-lane or the latency form of that stage),
  * "msm_c_bias" (extra MSM window bits of small calls), "msm_c_max" (widest MSM window), "msm_c_add", "msm_rc2" (0: one window per wavefront in the bucket reduction), "msm_split",
- * "fb_threads", "prove_subs", "fused_columns" (0: per-proof generator rows + k_reduce_static instead of the column sums inside
+ * "fb_threads", "prove_subs", "prove_fused" (0: three launches per prover round instead of one), "prove_prio" (1: the prover's small
+ * kernels on a high-priority stream), "fused_columns" (0: per-proof generator rows + k_reduce_static instead of the column sums inside
  * k_scalars_lanes).  The environment variables BPP_<NAME> give
  * the initial values and are read ONCE, when the context is created: no verification path calls getenv. */
 int bpp_ctx_set_option(bpp_ctx *ctx, const char *name, int value);

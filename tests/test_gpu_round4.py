@@ -462,3 +462,28 @@ def test_column_sums_inside_the_lanes_kernel_equal_per_proof_rows(bpp, packed, e
     assert set(rb.trace(6)) == {0}
     rb.close()
     params.close()
+
+
+@pytest.mark.parametrize("m,t,count", [(4, 3, 96), (1, 1, 130), (8, 1, 40)])
+def test_prover_round_as_one_launch_gives_the_same_bytes(bpp, packed, engine, opt, m, t, count):
+    """round 4: point encoding + Fiat-Shamir step + vector step of a round as ONE launch (kp_round) against the three kernels of
+    round 3 (prove_fused = 0), and the small kernels on a high-priority stream (prove_prio = 1): byte-identical proofs for the
+    same witnesses and external randomness (tests/test_gpu_prove.py holds the default form to the oracle's bytes); every proof
+    verifies"""
+    import bench
+    params = bpp.RangeParameters.init(64, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=engine)
+    d = bench.make_inputs(np, packed, params, count, seed=4900 + m)
+    out = {}
+    for name, opts in (("fused", {}), ("three", {"prove_fused": 0}), ("prio", {"prove_prio": 1}), ("prio3", {"prove_prio": 1, "prove_fused": 0})):
+        for k, v in opts.items():
+            opt(k, v)
+        out[name] = packed.prove(params, d["values"], d["blindings"], d["commitments"], d["min_values"], d["min_present"], d["seeds"], LABEL,
+                                 d["ext"])
+        for k in opts:
+            opt(k, -1)
+    assert (out["fused"] == d["proofs"]).all() and (out["three"] == d["proofs"]).all()
+    assert (out["prio"] == d["proofs"]).all() and (out["prio3"] == d["proofs"]).all()
+    rb = packed.ResidentBatch(params, out["fused"], d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+    rb.verify_only(0)
+    rb.close()
+    params.close()

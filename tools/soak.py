@@ -54,13 +54,17 @@ def main():
 
     shared = {}  # the one bpp_batcher all worker threads call into (path "batcher")
 
-    def packed_input(sub):
+    def packed_input(sub, seeds=False):
         n = len(sub)
         proofs = np.frombuffer(b"".join(it["proof"] for it in sub), dtype=np.uint8).reshape(n, -1)
         comm = np.frombuffer(b"".join(it["commitments"][0] for it in sub), dtype=np.uint8).reshape(n, 1, 32)
         mins = np.array([[it["min_values"][0] or 0] for it in sub], dtype=np.uint64)
         pres = np.array([[0 if it["min_values"][0] is None else 1] for it in sub], dtype=np.uint8)
-        return packed.PackedInput(proofs, comm, mins, pres, None, label)
+        sn = sp = None
+        if seeds:  # mask recovery: the statements' seed nonces travel with the call
+            sn = np.frombuffer(b"".join(it["seed_nonce"] or bytes(32) for it in sub), dtype=np.uint8).reshape(n, 32)
+            sp = np.array([1 if it["seed_nonce"] else 0 for it in sub], dtype=np.uint8)
+        return packed.PackedInput(proofs, comm, mins, pres, sn, label, seed_present=sp)
 
     def worker(k):
         rng = random.Random(args.seed + k)
@@ -115,14 +119,20 @@ def main():
                     c = bytearray(sub[j]["commitments"][0])
                     c[rng.randrange(32)] ^= 1 << rng.randrange(8)
                     sub[j]["commitments"] = [bytes(c)]
+            # round 4: the packed and the pooled path take every VerifyAction; the masks are compared as well
+            action = rng.choice([0, 0, 1, 2]) if path in ("packed", "batcher") else 0
+            if action == 0:
+                for it in sub:
+                    it["seed_nonce"] = None
             # expectation: the oracle verifies each chunk like one reference call, first failing chunk wins
-            want = 0
+            want, want_masks = 0, []
             step = chunk if chunk else cnt
             for lo in range(0, cnt, step):
-                rc, _, _ = cp.verify(sub[lo:lo + step], action=0)
+                rc, mk, _ = cp.verify(sub[lo:lo + step], action=action)
                 if rc != 0:
                     want = rc
                     break
+                want_masks += mk
             got = 0
             try:
                 if path == "items":
@@ -131,7 +141,9 @@ def main():
                     trs = [bpp.Transcript.new(label) for _ in sub]
                     bpp.RangeProof.verify_batch(trs, sts, proofs, bpp.VerifyAction.VerifyOnly, chunk=chunk)
                 elif path == "packed":
-                    packed.verify_batch(params, packed_input(sub), bpp.VerifyAction.VerifyOnly, chunk)
+                    mk, pr = packed.verify_batch(params, packed_input(sub, seeds=action != 0), action, chunk)
+                    if action and [[bytes(mk[i, 0])] if pr[i] else None for i in range(cnt)] != want_masks:
+                        got = -2000  # masks differ from the oracle's
                 elif path == "pipeline":
                     ticket = pipe.submit(packed_input(sub), bpp.VerifyAction.VerifyOnly, chunk)  # construction errors raise here
                     pending.append((ticket, want, ("pipeline", cnt, chunk, mutated)))
@@ -139,7 +151,11 @@ def main():
                         collect(pending.pop(rng.randrange(len(pending))))
                     continue
                 elif path == "batcher":  # pooled with whatever the other threads are calling at the moment
-                    shared["bat"].verify(packed_input(sub))
+                    mk, pr = shared["bat"].verify_action(packed_input(sub, seeds=action != 0), action)
+                    if action and [[bytes(mk[i, 0])] if pr[i] else None for i in range(cnt)] != want_masks:
+                        got = -2000
+                    if not action and pr.any():
+                        got = -2001  # masks out of a VerifyOnly call
                 elif path == "groups":
                     n_groups = cnt // chunk
                     if n_groups % 2 == 0 and rng.random() < 0.5:  # two slots of one pipelined call (bpp_verify_sharded_groups_wave)
