@@ -3,9 +3,11 @@
 # benches.  Steps are joined so that a failing GPU step stops the script (no further GPU work after a failure).
 set -e -o pipefail
 TAG=${1:-r03}
+PART=${2:-all}   # a: profile set + bench lines, b: the probes (two gpurun calls: together they exceed one call's time limit)
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
+if [ "$PART" != "b" ]; then
 (cd tools/microbench && (test -x fetch_calib || hipcc -O3 --offload-arch=gfx950 fetch_calib.hip -o fetch_calib))
 timeout -k 10 700 bash tools/profile_round.sh $TAG > $O/${TAG}_profile.log 2>&1
 echo "profile set done"
@@ -14,12 +16,17 @@ echo "full bench done"
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline --no-traffic > $O/${TAG}_bench_steps20.json 2>> $O/${TAG}_bench.err
 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/${TAG}_bench_torchrun1.json 2>> $O/${TAG}_bench.err
 echo "bench lines done"
+fi
+if [ "$PART" = "a" ]; then echo "final_round $TAG part a done"; exit 0; fi
 timeout -k 10 300 python3 tools/wave_probe.py "1x1,1x16,3x12,1g16,1g64,3g32,1p2g64" 20 4096 2>> $O/${TAG}_bench.err | grep "^{" > $O/${TAG}_wave_probe.jsonl
 timeout -k 10 300 python3 tools/wave_probe.py "1x16,1g16,1g64,3g32,1p2g64" 20 512 2>> $O/${TAG}_bench.err | grep "^{" >> $O/${TAG}_wave_probe.jsonl
 timeout -k 10 300 python3 tools/chunk_probe.py "128,256,512,1024,2048,4096" 64 2>> $O/${TAG}_bench.err | grep "^{" > $O/${TAG}_chunk_probe.jsonl
 WIDE_PROBE_N=256 WIDE_PROBE_S=1,4,8,16 timeout -k 10 300 python3 tools/wide_probe.py 2>> $O/${TAG}_bench.err | grep "^{" > $O/${TAG}_calls_in_flight.jsonl
 WIDE_PROBE_HOST=1 WIDE_PROBE_N=256 WIDE_PROBE_S=1,4,8,16,32,64 timeout -k 10 300 python3 tools/wide_probe.py 2>> $O/${TAG}_bench.err | grep "^{" >> $O/${TAG}_calls_in_flight.jsonl
 WIDE_PROBE_HOST=2 WIDE_PROBE_N=256 WIDE_PROBE_S=1,4,8,16,32,64 timeout -k 10 300 python3 tools/wide_probe.py 2>> $O/${TAG}_bench.err | grep "^{" >> $O/${TAG}_calls_in_flight.jsonl
+# the same separate callers with the admission gate switched off (what round 3 measured)
+BPP_SMALL_CALLS_IN_FLIGHT=0 WIDE_PROBE_HOST=1 WIDE_PROBE_N=256 WIDE_PROBE_S=16,32,64 timeout -k 10 300 python3 tools/wide_probe.py 2>> $O/${TAG}_bench.err | grep "^{" | sed 's/"form": "packed"/"form": "packed, gate off"/' >> $O/${TAG}_calls_in_flight.jsonl
+timeout -k 10 120 python3 tools/bench_prover_leg.py > $O/${TAG}_prover_leg.json 2>> $O/${TAG}_bench.err
 timeout -k 10 300 python3 tools/bench_latency.py > $O/${TAG}_bench_latency.jsonl 2>> $O/${TAG}_bench.err
 BPP_MSM_SPLIT=0 timeout -k 10 300 python3 tools/bench_latency.py --no-cpu > $O/${TAG}_bench_latency_nosplit.jsonl 2>> $O/${TAG}_bench.err
 echo "final_round $TAG done"
