@@ -386,6 +386,14 @@ struct Batch {
   DevBuf<uint64_t> parts;      // per-workgroup limb sums of the generator columns (k_scalars_lanes -> k_reduce_parts)
   bool fused_columns = false;  // this layout sums the generator columns inside k_scalars_lanes (layout_groups decides)
   uint32_t lanes_ppw = 1;      // proofs per workgroup of k_scalars_lanes for this batch
+  // generator columns as a matrix product over the proofs of a group (kernels_static_gemm.h): digit tables, anti-diagonal sums
+  DevBuf<int8_t> gemm_lo, gemm_hi;
+  DevBuf<int32_t> gparts;
+  DevBuf<sc> gemm_mult;        // per proof: w, -w e^2 (Montgomery), -w e^2, -w e^2 y^(mn+1) (canonical), the weight as it came
+  bool static_gemm = false;    // this layout takes the generator columns from k_static_gemm (plan_lanes decides)
+  uint32_t gemm_nkc = 1;       // K chunks (256 proofs each) of the largest group
+  int uniform_mn = -1;         // -1 not looked at yet; 0 the proofs differ in shape; else the common m * n_bits
+  bool gemm_hi_ready = false;  // the last k_scalars_shared of this batch wrote the high digit tables
   DevBuf<uint8_t> rng_out, weights, masks, chal_bytes;
   DevBuf<uint32_t> status, group_first, group_dlo;
   DevBuf<uint32_t> dec_spill;  // k_decompress parks three field elements per proof point here across its squaring chain
@@ -410,7 +418,7 @@ void adopt_buffers(Batch &dst, Batch &src) {
 #define BPP_ADOPT(f) dst.f.swap(src.f)
   BPP_ADOPT(d_ext_status); BPP_ADOPT(bytes); BPP_ADOPT(states); BPP_ADOPT(seeds); BPP_ADOPT(d_desc); BPP_ADOPT(minvals);
   BPP_ADOPT(src_off); BPP_ADOPT(owner); BPP_ADOPT(idx_commit); BPP_ADOPT(idx_proof); BPP_ADOPT(status0); BPP_ADOPT(chal);
-  BPP_ADOPT(rows); BPP_ADOPT(parts); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(tab); BPP_ADOPT(rng_out); BPP_ADOPT(weights);
+  BPP_ADOPT(rows); BPP_ADOPT(parts); BPP_ADOPT(gemm_lo); BPP_ADOPT(gemm_hi); BPP_ADOPT(gparts); BPP_ADOPT(gemm_mult); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(tab); BPP_ADOPT(rng_out); BPP_ADOPT(weights);
   BPP_ADOPT(masks); BPP_ADOPT(chal_bytes); BPP_ADOPT(status); BPP_ADOPT(group_first); BPP_ADOPT(group_dlo); BPP_ADOPT(dynpts); BPP_ADOPT(dyn_hi); BPP_ADOPT(dec_spill);
   BPP_ADOPT(msm.counts); BPP_ADOPT(msm.starts); BPP_ADOPT(msm.sorted); BPP_ADOPT(msm.order); BPP_ADOPT(msm.order_win);
   BPP_ADOPT(msm.cls_hist);
@@ -502,7 +510,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1;
+        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -541,6 +549,7 @@ const OptionName kOptions[] = {
     {"fused_columns", "BPP_FUSED_COLUMNS", &bpp_ctx::Options::fused_columns},
     {"prove_prio", "BPP_PROVE_PRIO", &bpp_ctx::Options::prove_prio},
     {"prove_fused", "BPP_PROVE_FUSED", &bpp_ctx::Options::prove_fused},
+    {"static_gemm", "BPP_STATIC_GEMM", &bpp_ctx::Options::static_gemm},
 };
 void options_from_env(bpp_ctx *c) {
   for (const OptionName &o : kOptions)
@@ -1498,11 +1507,13 @@ namespace {
 // still running on the stream (it overlaps the host weight chain).
 // rng_dev_dst != nullptr (the sharded form): the transcript-RNG bytes are copied device -> device right behind PASS 1 and
 // ev_rng is recorded there; nothing comes to the host and the function does not wait
+void plan_lanes(bpp_ctx *ctx, Batch &b, bool for_phase2 = false);
 void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uint8_t *rng_dev_dst = nullptr, size_t rng_row_bytes = 0,
                     size_t rng_dst_pitch = 0) {
   const bool fetch_rng = rng_dev_dst == nullptr;
   Params &P = *b.params;
   hipStream_t s = ctx->stream;
+  if (!pass1_only) plan_lanes(ctx, b);  // (an option may have changed since the layout was built: k_scalars_shared writes what PASS 2 will read)
   if (!ctx->ev_rng_ready) {
     HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_rng, hipEventDisableTiming));
     ctx->ev_rng_ready = true;
@@ -1566,8 +1577,13 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
   if (!pass1_only) {  // the weight-independent part of the PASS-2 scalars; the rest (k_scalars_lanes) takes the weights
     // tables of the generator-row kernel: by the same lane for large inputs, one wavefront per proof for small ones
     const bool tw = ctx->opt.tables_wave >= 0 ? ctx->opt.tables_wave != 0 : b.B <= BPP_TABLES_WAVE_MAX;  // (tests force either form)
-    hipLaunchKernelGGL(k_scalars_shared, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.chal.p,
-                       P.n_bits, P.t, b.cs, b.B, b.shr.p, b.lanes_nhi_max(P.n_bits), tw ? (sc *)nullptr : b.tab.p);
+    b.gemm_hi_ready = b.static_gemm && !tw;
+    if (b.gemm_hi_ready)  // the high tables once more as digit tables (kernels_static_gemm.h)
+      hipLaunchKernelGGL(k_scalars_shared<true>, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.chal.p, P.n_bits,
+                         P.t, b.cs, b.B, b.shr.p, b.lanes_nhi_max(P.n_bits), b.tab.p, b.gemm_hi.p, cdiv(b.B, SGEMM_BLOCK));
+    else
+      hipLaunchKernelGGL(k_scalars_shared<false>, dim3(cdiv(b.B, 64)), dim3(64), 0, s, b.bytes.p, b.d_desc.p, b.minvals.p, b.chal.p, P.n_bits,
+                         P.t, b.cs, b.B, b.shr.p, b.lanes_nhi_max(P.n_bits), tw ? (sc *)nullptr : b.tab.p, (int8_t *)nullptr, 0u);
     if (tw)
       hipLaunchKernelGGL(k_scalars_tables_wave, dim3(b.B), dim3(64), 0, s, b.d_desc.p, b.shr.p, P.n_bits, b.B,
                          b.lanes_nhi_max(P.n_bits), b.tab.p);
@@ -1796,7 +1812,7 @@ void check_chunk_errors(const Batch &b, uint32_t p0, uint32_t p1) {
 
 // Shape of k_scalars_lanes for the current group layout, and the buffers that go with it (called when a layout is built and
 // again in front of every PASS 2: the option may have changed; nothing is reallocated once the sizes have been seen).
-void plan_lanes(bpp_ctx *ctx, Batch &b) {
+void plan_lanes(bpp_ctx *ctx, Batch &b, bool for_phase2) {
   // proofs per workgroup: enough (proof, generator pair) items for four passes of the 64 lanes.  Large inputs take sixteen
   // 64-bit proofs per workgroup (the prologue's product jobs, 43 per proof, then fill whole wavefronts); small inputs keep four
   // (more workgroups, shorter chains: the chip is idle anyway).
@@ -1807,7 +1823,39 @@ void plan_lanes(bpp_ctx *ctx, Batch &b) {
   bool aligned = b.max_mn >= 64 && b.max_mn % 64 == 0;
   for (uint32_t g = 1; g < b.G && aligned; g++) aligned = b.h_group_first[g] % b.lanes_ppw == 0;
   b.fused_columns = aligned && ctx->opt.fused_columns != 0;  // (tests force the per-proof rows with fused_columns = 0)
-  if (b.fused_columns) {
+  // The generator columns as a matrix product over the proofs of each group on the matrix cores (kernels_static_gemm.h) when
+  // every proof has the same shape, the tables are built by k_scalars_shared (large inputs) and every group starts on a block
+  // of the digit tables; otherwise summed in k_scalars_lanes as before (tests run both: static_gemm = 0)
+  if (b.uniform_mn < 0) {
+    uint32_t mn0 = b.B ? b.desc[0].m * b.params->n_bits : 0;
+    for (uint32_t p = 1; p < b.B && mn0; p++)
+      if (b.desc[p].m * b.params->n_bits != mn0 || b.desc[p].rounds != b.desc[0].rounds) mn0 = 0;
+    if (mn0 && (b.any_rounds_bad || (1u << b.desc[0].rounds) != mn0)) mn0 = 0;
+    b.uniform_mn = (int)mn0;
+  }
+  const bool tables_wave = ctx->opt.tables_wave >= 0 ? ctx->opt.tables_wave != 0 : b.B <= BPP_TABLES_WAVE_MAX;
+  const uint32_t lb = lanes_lb(b.params->n_bits);
+  // (by itself from aggregation 8 on: measured with three steps in flight, 64 x 256 proofs per step, the matrix product gains 10 %
+  // at m = 8, nothing at m = 2 and loses 3 - 5 % at m = 1 and 4 -- tools/agg_probe.py, profiles/r04_agg_probe.jsonl)
+  const bool gemm_wanted = ctx->opt.static_gemm >= 0 ? ctx->opt.static_gemm != 0 : b.uniform_mn >= 512;
+  bool gemm = b.fused_columns && gemm_wanted && !tables_wave && b.uniform_mn >= 64 && lb == 3 &&
+              ((uint32_t)b.uniform_mn >> lb) >= SGEMM_HI_PER_WAVE && ((uint32_t)b.uniform_mn >> lb) <= b.lanes_nhi_max(b.params->n_bits);
+  uint32_t max_group = 0;
+  for (uint32_t g = 0; g < b.G && gemm; g++) {
+    gemm = b.h_group_first[g] % SGEMM_BLOCK == 0;
+    max_group = std::max(max_group, b.h_group_first[g + 1] - b.h_group_first[g]);
+  }
+  if (for_phase2 && !b.gemm_hi_ready) gemm = false;  // (PASS 1 of this verification ran under another setting)
+  b.static_gemm = gemm;
+  if (b.static_gemm) {
+    b.gemm_mult.alloc((size_t)b.B * 5);
+    const uint32_t nblk = cdiv(b.B, SGEMM_BLOCK);
+    b.gemm_nkc = std::max<uint32_t>(1, cdiv(cdiv(max_group, SGEMM_BLOCK), SGEMM_KBLOCKS));
+    b.rows.alloc((size_t)b.B * (b.params->t + 2));
+    b.gemm_lo.alloc(3 * sgemm_table_bytes(SGEMM_LO_ENTRIES, nblk));
+    b.gemm_hi.alloc(3 * sgemm_table_bytes(b.lanes_nhi_max(b.params->n_bits), nblk));
+    b.gparts.alloc((size_t)b.G * b.gemm_nkc * b.max_mn * 2 * 64);
+  } else if (b.fused_columns) {
     b.rows.alloc((size_t)b.B * (b.params->t + 1));
     b.parts.alloc((size_t)cdiv(b.B, b.lanes_ppw) * 2 * b.max_mn * 8);
   } else {
@@ -1884,7 +1932,7 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool weights_residen
   hipStream_t s = ctx->stream;
   // (weights_resident: the grouped sharded form has put them into b.weights device -> device already)
   // otherwise k_scalars_lanes reads them where the chains wrote them: h_weights is mapped, each weight is read once
-  plan_lanes(ctx, b);
+  plan_lanes(ctx, b, true);
   b.weights_on_host = !weights_resident;
   const uint8_t *weights = weights_resident ? b.weights.p : b.h_weights.dev();
   tm.mark(M_WEIGHTS_IN);
@@ -1894,12 +1942,26 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool weights_residen
     // The weighted part of the scalar block (dynamic scalars, base columns, w into the low tables) is this kernel's prologue;
     // proofs per workgroup and whether the generator columns are summed in it: layout_groups
     const uint32_t ppw = b.lanes_ppw;
-    hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s, b.d_desc.p, b.tab.p, b.shr.p,
-                       weights, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, b.rows.p, dyn_scal,
-                       b.fused_columns ? b.parts.p : (uint64_t *)nullptr);
+    if (b.static_gemm) {  // the weighted part alone, flat over (proof, job): digit tables of the low entries, dynamic scalars, base columns
+      const uint32_t rounds = b.desc[0].rounds, m0 = b.desc[0].m;
+      const uint32_t n_jobs = 3u * (1u << lanes_lb(P.n_bits)) + 1u + m0 + 3u + 2u * rounds + P.t + 1u, nblk = cdiv(b.B, SGEMM_BLOCK);
+      hipLaunchKernelGGL(k_gemm_mult, dim3(cdiv(4 * b.B, 64)), dim3(64), 0, s, b.shr.p, weights, b.B, b.gemm_mult.p);
+      hipLaunchKernelGGL(k_gemm_jobs, dim3(nblk, cdiv(n_jobs, 4)), dim3(64), 0, s, b.d_desc.p, b.tab.p, b.shr.p, b.gemm_mult.p, P.n_bits, P.t,
+                         b.B, nhi_max, n_jobs, b.rows.p, dyn_scal, b.gemm_lo.p, nblk);
+    } else
+      hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s, b.d_desc.p, b.tab.p, b.shr.p,
+                         weights, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, b.rows.p, dyn_scal,
+                         b.fused_columns ? b.parts.p : (uint64_t *)nullptr);
   }
   tm.mark(M_LANES);
-  if (b.fused_columns)
+  if (b.static_gemm) {
+    const uint32_t lb = lanes_lb(P.n_bits), nhi = (uint32_t)b.uniform_mn >> lb, nblk = cdiv(b.B, SGEMM_BLOCK);
+    const uint32_t nhi_max = b.lanes_nhi_max(P.n_bits);
+    hipLaunchKernelGGL(k_static_gemm, dim3(8 * cdiv(b.G, 8) * SGEMM_LO_ENTRIES * (nhi / SGEMM_HI_PER_WAVE), b.gemm_nkc), dim3(64), 0, s, b.gemm_lo.p,
+                       b.gemm_hi.p, b.group_first.p, nblk, nhi, nhi_max, b.gemm_nkc, b.max_mn, b.G, b.gparts.p);
+    hipLaunchKernelGGL(k_static_finish, dim3(cdiv(2 * b.max_mn, 64) + 1, b.G), dim3(64), 0, s, b.gparts.p, b.rows.p, b.group_first.p, b.cols, b.max_mn,
+                       (uint32_t)b.uniform_mn, P.t, b.gemm_nkc, b.scal.p);
+  } else if (b.fused_columns)
     hipLaunchKernelGGL(k_reduce_parts, dim3(cdiv(b.cols, BPP_REDUCE_TILE), b.G), dim3(64), 0, s, b.parts.p, b.rows.p, b.group_first.p, b.cols,
                        b.max_mn, P.t, b.lanes_ppw, b.scal.p);
   else
@@ -2520,6 +2582,13 @@ int bpp_batch_trace(bpp_ctx *ctx, uint64_t batch, int what, uint8_t *out, size_t
         hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(b.G, 64)), dim3(64), 0, s, b.msm.R.p, b.G, b.msm.comp32.p);
         src = b.msm.comp32.p;
         break;
+      case BPP_TRACE_PLAN: {  // host-side: which form of the scalar stage the last layout / verification chose
+        const uint32_t w[4] = {(b.fused_columns ? 1u : 0u) | (b.static_gemm ? 2u : 0u), b.lanes_ppw, b.gemm_nkc, b.G};
+        if (written) *written = sizeof(w);
+        if (!out || out_len < sizeof(w)) return fail(ctx, BPP_ERR_INVALID_LENGTH, "trace buffer too small");
+        memcpy(out, w, sizeof(w));
+        return BPP_OK;
+      }
       default:
         return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "unknown trace selector");
     }

@@ -18,6 +18,7 @@
 #include "point.h"
 #include "recode.h"
 #include "scalar.h"
+#include "kernels_static_gemm.h"
 
 namespace bpp {
 
@@ -360,11 +361,15 @@ __device__ __forceinline__ void sc_load_mont(sc &r, const uint8_t *p) {
   sc_to_mont(r, a);
 }
 
+template <bool GEMM>  // GEMM: hi_t != null
 __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict__ bytes, const ProofDesc *__restrict__ desc,
                                                        const uint64_t *__restrict__ minvals, const sc *__restrict__ chal,
                                                        uint32_t n_bits, uint32_t t, uint32_t cs, uint32_t B,
                                                        sc *__restrict__ shr, uint32_t nhi_max,
-                                                       sc *tab /* lanes_tab_stride(nhi_max) entries per proof */) {
+                                                       sc *tab /* lanes_tab_stride(nhi_max) entries per proof */,
+                                                       int8_t *__restrict__ hi_t /* null, or the high tables once more as digit
+                                                       tables for k_static_gemm: ghi | shiR | y2hi, nhi_max entries each */,
+                                                       uint32_t nblk) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B) return;
   const ProofDesc d = desc[p];
@@ -533,9 +538,15 @@ __global__ void __launch_bounds__(64) k_scalars_shared(const uint8_t *__restrict
       sc x;
       sc_montmul(x, sv, yh);
       ghi[v] = x;
+      if constexpr (GEMM) {
+        const size_t tb = sgemm_table_bytes(nhi_max, nblk);
+        sgemm_store(hi_t, v, nblk, p, x);
+        sgemm_store(hi_t + tb, (~v) & (nhi - 1u), nblk, p, sv);  // shiR[hi] = shi[~hi]: h[i] pairs s[mn-1-i] with index i
+      }
       sc_mul_pow2(x, yh, lanes_e2k(true, v, nlo, n_bits));
       sc_montmul(x, x, zz);
       y2hi[v] = x;
+      if constexpr (GEMM) sgemm_store(hi_t + 2 * sgemm_table_bytes(nhi_max, nblk), v, nblk, p, x);
       if (v + 1 < nhi) {
         sc_montmul(yh, yh, step);
         if (((v + 1) & (per_party - 1u)) == 0) sc_montmul(zz, zz, z_square);
@@ -816,6 +827,93 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     row[2 * i] = gi;
     row[2 * i + 1] = hi;
   }
+}
+
+// ---- the weighted part of the scalar block when the generator columns are k_static_gemm's (kernels_static_gemm.h) ----
+// Same products on the same operands as k_scalars_lanes' prologue, laid out flat: no per-proof tables go to LDS, so nothing has to
+// wait for a workgroup's sixteen proofs -- k_scalars_lanes' prologue alone took 145 us per 65 536 proofs (one wavefront per
+// workgroup, 15 KB of LDS each: 2.5 wavefronts per SIMD running three dependent phases).
+//   k_gemm_mult : one lane per (proof, multiplier): w (Montgomery), -w e^2 (Montgomery), -w e^2 and -w e^2 y^(mn+1) (canonical),
+//                 the weight as it came -> mult[p][5]
+//   k_gemm_jobs : one lane per (proof, job), sixteen neighbouring lanes = the sixteen proofs of one block of the digit tables,
+//                 a workgroup = four jobs of one block.  Jobs of a proof (uniform shapes: the host checks): 3 * 2^LB low-table
+//                 entries (-> digit tables glo | hloR | yn2lo), w e^2 z (-> rows[p][t + 1]), the m + 3 + 2r dynamic scalars
+//                 (canonical, -> dyn_out), the t + 1 base columns (-> rows[p][0 .. t])
+__global__ void __launch_bounds__(64) k_gemm_mult(const sc *__restrict__ shr, const uint8_t *__restrict__ weights32, uint32_t B,
+                                                  sc *__restrict__ mult) {
+  const uint32_t it = blockIdx.x * 64u + threadIdx.x, p = it >> 2, which = it & 3u;
+  if (p >= B) return;
+  sc wc;
+  {
+    const uint4 *wp = reinterpret_cast<const uint4 *>(weights32 + (size_t)p * 32);  // (mapped host memory: two reads, not thirty-two)
+    const uint4 lo4 = wp[0], hi4 = wp[1];
+    wc.v[0] = lo4.x, wc.v[1] = lo4.y, wc.v[2] = lo4.z, wc.v[3] = lo4.w;
+    wc.v[4] = hi4.x, wc.v[5] = hi4.y, wc.v[6] = hi4.z, wc.v[7] = hi4.w;
+  }
+  const sc *S = shr + (size_t)p * SH_STRIDE;
+  sc *M = mult + (size_t)p * 5;
+  sc x;
+  if (which == 0u) {
+    sc_to_mont(x, wc);
+    M[0] = x;
+    M[4] = wc;
+  } else {
+    const sc a = which == 3u ? S[SH_NEG_E2_YNM1] : S[SH_NEG_E2];
+    sc_montmul(x, a, wc);                 // canonical: a Montgomery value times a canonical one
+    if (which == 1u) sc_to_mont(x, x);    // -w e^2 in Montgomery form (= montmul(-e^2 R, w R))
+    M[which] = x;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_gemm_jobs(const ProofDesc *__restrict__ desc, const sc *__restrict__ tab, const sc *__restrict__ shr,
+                                                  const sc *__restrict__ mult, uint32_t n_bits, uint32_t t, uint32_t B, uint32_t nhi_max,
+                                                  uint32_t n_jobs, sc *__restrict__ rows /* [B][t + 2] */, sc *__restrict__ dyn_out,
+                                                  int8_t *__restrict__ lo_t, uint32_t nblk) {
+  const uint32_t lane = threadIdx.x, p = blockIdx.x * SGEMM_BLOCK + (lane & (SGEMM_BLOCK - 1u)), job = blockIdx.y * 4u + (lane >> 4);
+  if (p >= B || job >= n_jobs) return;
+  const ProofDesc d = desc[p];
+  const uint32_t r = d.rounds, m = d.m, LB = lanes_lb(n_bits), nlo = 1u << LB;
+  const uint32_t j_e2z = 3u * nlo, j_c = j_e2z + 1u, j_a1 = j_c + m, j_lr = j_a1 + 3u, j_row = j_lr + 2u * r;
+  const sc *S = shr + (size_t)p * SH_STRIDE;
+  const sc *T = tab + (size_t)p * lanes_tab_stride(nhi_max);
+  const sc *M = mult + (size_t)p * 5;
+  sc *dyn = dyn_out + d.dyn_off;
+  sc *row_base = rows + (size_t)p * (t + 2);
+  const sc *src;
+  sc *dst = nullptr;
+  uint32_t tsel = ~0u, ent = 0;  // digit table and entry, else `dst`
+  uint32_t sel, zpow = 0;
+  bool neg = false, plain_neg = false;
+  if (job < nlo) src = T + job, tsel = 0, ent = job, sel = 0;                                                // glo
+  else if (job < 2u * nlo) src = T + 16 + (job - nlo), tsel = 1, ent = (~(job - nlo)) & (nlo - 1u), sel = 0;  // hloR[lo] = hlo[~lo]
+  else if (job < 3u * nlo) src = T + 8 + (job - 2u * nlo), tsel = 2, ent = job - 2u * nlo, sel = 1;           // yn2lo
+  else if (job == j_e2z) src = S + SH_E2Z, dst = row_base + (t + 1), sel = 0;                                 // w e^2 z
+  else if (job < j_a1) src = S + SH_Z2, dst = dyn + (job - j_c), sel = 3, zpow = job - j_c;
+  else if (job == j_a1) src = S + SH_E, dst = dyn + m, sel = 4, neg = true;               // A1: -e w
+  else if (job == j_a1 + 1) src = S + SH_E, dst = dyn + m + 1, sel = 4, plain_neg = true;  // B: -w
+  else if (job == j_a1 + 2) src = S + SH_NEG_E2, dst = dyn + m + 2, sel = 4;               // A: -e^2 w
+  else if (job < j_row) {
+    const uint32_t k = job - j_lr;
+    src = k < r ? S + SH_ESQ(k) : S + SH_ESQINV(k - r);
+    dst = dyn + m + 3 + k;
+    sel = 2;
+  } else {
+    const uint32_t k = job - j_row;  // 0: the h base, 1 + k: g base k
+    src = k == 0 ? S + SH_HS : S + SH_D1(k - 1);
+    dst = row_base + (k == 0 ? t : k - 1);
+    sel = 0;
+  }
+  sc a = *src, x;
+  if (zpow) {
+    const sc z2 = a;
+    for (uint32_t i = 0; i < zpow; i++) sc_montmul(a, a, z2);
+  }
+  if (neg) sc_neg(a, a);
+  const sc mu = M[sel];
+  sc_montmul(x, a, mu);
+  if (plain_neg) sc_neg(x, mu);
+  if (tsel == ~0u) *dst = x;
+  else sgemm_store(lo_t + tsel * sgemm_table_bytes(SGEMM_LO_ENTRIES, nblk), ent, nblk, p, x);
 }
 
 // Per proof: byte offsets of its points in dynamic-slot order (C_j.., A1, B, A, L.., R..), their owners (bit 31 = statement

@@ -74,7 +74,9 @@ const char *bpp_ctx_last_error(bpp_ctx *ctx);
  * "msm_c_bias" (extra MSM window bits of small calls), "msm_c_max" (widest MSM window), "msm_c_add", "msm_rc2" (0: one window per wavefront in the bucket reduction), "msm_split",
  * "fb_threads", "prove_subs", "prove_fused" (0: three launches per prover round instead of one), "prove_prio" (1: the prover's small
  * kernels on a high-priority stream), "fused_columns" (0: per-proof generator rows + k_reduce_static instead of the column sums inside
- * k_scalars_lanes).  The environment variables BPP_<NAME> give
+ * k_scalars_lanes), "static_gemm" (1 / 0: those column sums as ONE integer matrix product over the proofs of a group on the
+ * matrix cores, kernels_static_gemm.h, or by Montgomery products per (proof, generator); by itself the engine takes the matrix
+ * product from aggregation 8 on).  The environment variables BPP_<NAME> give
  * the initial values and are read ONCE, when the context is created: no verification path calls getenv. */
 int bpp_ctx_set_option(bpp_ctx *ctx, const char *name, int value);
 
@@ -409,6 +411,8 @@ int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_item *items, 
 #define BPP_TRACE_STATIC_SCALARS 4 /* groups x (2*max_mn + t + 1) x 32: gi0,hi0,gi1,hi1,...,g_0..g_{t-1},h */
 #define BPP_TRACE_DYNAMIC_SCALARS 5 /* total_dyn x 32, proof order: C_j.., A1, B, A, L.., R.. */
 #define BPP_TRACE_MSM_RESULT 6     /* groups x 32 compressed */
+#define BPP_TRACE_PLAN 7           /* four uint32: bit 0 generator columns summed in k_scalars_lanes, bit 1 taken from k_static_gemm;
+                                      proofs per workgroup of k_scalars_lanes; K chunks of k_static_gemm; groups */
 int bpp_batch_trace(bpp_ctx *ctx, uint64_t batch, int what, uint8_t *out, size_t out_len, size_t *written);
 /* shape helpers for the above */
 int bpp_batch_shape(bpp_ctx *ctx, uint64_t batch, uint32_t *n_items, uint32_t *max_rounds, uint32_t *max_mn,

@@ -487,3 +487,45 @@ def test_prover_round_as_one_launch_gives_the_same_bytes(bpp, packed, engine, op
     rb.verify_only(0)
     rb.close()
     params.close()
+
+
+@pytest.mark.parametrize("m,count,chunk", [(1, 4096 + 32, 1024), (1, 300, 48), (8, 70, 16), (4, 37, 0), (2, 1000, 256), (1, 2500, 0),
+                                            (2, 1000, 250)])
+def test_generator_columns_as_a_matrix_product_equal_the_per_proof_form(bpp, packed, engine, opt, m, count, chunk):
+    """round 4: the generator columns of a group as ONE integer matrix product over its proofs on the matrix cores
+    (kernels_static_gemm.h: digit tables, V_MFMA_I32_32X32X32_I8, anti-diagonal sums, one reduction mod l per column) against the
+    per-(proof, generator) Montgomery products of k_scalars_lanes (static_gemm = 0): the same static scalars (trace 4: the oracle's,
+    tests/test_gpu_batch.py), dynamic scalars and final point per group; groups that end inside a 16-proof block of the digit
+    tables, a group of 2500 proofs (ten K chunks), aggregation 1 ... 8, a tampered proof; chunk 250 is not a multiple of 16:
+    the engine must fall back by itself"""
+    import struct
+    params = bpp.RangeParameters.init(64, m, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    import bench
+    d = bench.make_inputs(np, packed, params, count, seed=5200 + m)
+    pr = d["proofs"].copy()
+    pr[count // 2, 1 + 32 + 96] ^= 1
+    got, plan = {}, {}
+    opt("tables_wave", 0)  # the tables from k_scalars_shared whatever the size (small inputs build them one wavefront per proof)
+    for gemm in (1, 0):
+        opt("static_gemm", gemm)
+        rb = packed.ResidentBatch(params, pr, d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+        with pytest.raises(bpp.ProofError):
+            rb.verify_only(chunk)
+        got[gemm] = (rb.trace(4), rb.trace(5), rb.trace(6))
+        plan[gemm] = struct.unpack("<4I", rb.trace(7))
+        rb.close()
+    opt("static_gemm", -1)
+    assert plan[0][0] & 2 == 0
+    assert (plan[1][0] & 2 != 0) == (chunk % 16 == 0), plan
+    if count == 2500:
+        assert plan[1][2] == 10  # 2500 proofs = 157 blocks of 16 = ten K chunks of 16 blocks
+    assert got[1][0] == got[0][0]
+    assert got[1] == got[0]
+    rb = packed.ResidentBatch(params, d["proofs"], d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+    rb.verify_only(chunk)
+    assert set(rb.trace(6)) == {0}
+    # left to itself the engine takes the matrix product from aggregation 8 on (include/bpp.h: "static_gemm")
+    assert (struct.unpack("<4I", rb.trace(7))[0] & 2 != 0) == (chunk % 16 == 0 and m >= 8)
+    rb.close()
+    opt("tables_wave", -1)
+    params.close()

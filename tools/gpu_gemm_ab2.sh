@@ -1,0 +1,11 @@
+#!/bin/bash
+# headline with the matrix-product columns at different workgroup counts per group (BPP_STATIC_GEMM = 0 off, 1 all units side by side, 2 one workgroup per group, 3 two)
+out=${1:-gpurun_out/gemm_ab2.txt}
+: > $out
+for rep in 1 2; do
+for v in 0 1 2 3; do
+  r=$(BPP_STATIC_GEMM=$v python bench.py --steps 256 --warmup 5 --no-extra --no-cpu-baseline --no-traffic 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); s=d['stages_ms']; print('value %.3f M  ms_per_step %.3f  clock %.3f  scalars %.3f reduce %.3f total %.2f' % (d['value']/1e6, d['ms_per_step'], d['shader_clock_ghz'], s['scalars_ms'], s['reduce_ms'], s['total_ms']))")
+  echo "rep=$rep BPP_STATIC_GEMM=$v $r" >> $out
+done
+done
+sort -k2,2 -s $out
