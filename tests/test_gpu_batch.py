@@ -235,6 +235,37 @@ def test_baseline_cfg2_full_size(bpp, engine):
         assert k in (bpp.ProofErrorKind.VerificationFailed, bpp.ProofErrorKind.InvalidArgument)
 
 
+@pytest.mark.parametrize("name,m,chunk", [("bench_cfg3.bin", 8, 0), ("bench_cfg3.bin", 8, 64), ("bench_cfg2.bin", 1, 256), ("bench_cfg2.bin", 1, 1024)])
+def test_matrix_product_columns_against_the_oracle(bpp, engine, opt, name, m, chunk):
+    """round 4: the generator columns of every group taken from the int8 matrix product over its proofs
+    (kernels_static_gemm.h; forced on, with the tables from k_scalars_shared as on large inputs): static scalars, dynamic scalars
+    and the final point of every reference batch equal the C oracle's for that batch alone (configs[2]: 256 x aggregation 8,
+    1024 generator columns; configs[1]: 1024 x aggregation 1)"""
+    import struct
+    data, items, params, sts, pub, proofs, trs = _bench_case(bpp, engine, name)
+    opt("tables_wave", 0)
+    opt("static_gemm", 1)
+    rb = bpp.ResidentBatch(trs(), pub, proofs)
+    assert rb.verify(bpp.VerifyAction.VerifyOnly, chunk=chunk) == [None] * len(items)
+    assert struct.unpack("<4I", rb.trace(7))[0] & 2, "the matrix-product form was not taken"
+    shp = rb.shape()
+    cols = 2 * shp["max_mn"] + data["t"] + 1
+    statics, dyn, acc = rb.trace(4), rb.trace(5), rb.trace(6)
+    size = chunk or len(items)
+    cp = cport.Params(data["bit_length"], data["m"], data["t"])
+    per_proof_dyn = shp["total_dyn"] // len(items)
+    for g in range(shp["groups"]):
+        rc, _, tr = cp.verify(items[g * size:(g + 1) * size], action=0, want_trace=True)
+        assert rc == 0
+        assert statics[g * cols * 32:(g + 1) * cols * 32] == tr["static_scalars"], g
+        assert dyn[g * size * per_proof_dyn * 32:(g + 1) * size * per_proof_dyn * 32] == tr["dynamic_scalars"], g
+        assert acc[32 * g:32 * g + 32] == tr["msm_result"] == bytes(32)
+    rb.close()
+    cp.close()
+    opt("tables_wave", -1)
+    opt("static_gemm", -1)
+
+
 def test_baseline_cfg3_full_size(bpp, engine):
     """BASELINE configs[2]: 256 x aggregation-8 proofs (1024 static generators, 9 rounds)"""
     data, items, params, sts, pub, proofs, trs = _bench_case(bpp, engine, "bench_cfg3.bin")
