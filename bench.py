@@ -850,8 +850,11 @@ def main():
     extra = {}
     # ------------------------------------------------------------------ host buffers in -> verdict out (what verify_batch receives)
     if rank == 0 and world == 1 and not args.no_extra:
-        extra["host_in"] = host_in_leg(bpp, packed, np, local_rank, params2, data2, R, args.host_in_calls, sync)
-        out["pcie_inclusive_value"] = extra["host_in"]["one_context"]["proofs_per_s"]
+        try:
+            extra["host_in"] = host_in_leg(bpp, packed, np, local_rank, params2, data2, R, args.host_in_calls, sync)
+            out["pcie_inclusive_value"] = extra["host_in"]["one_context"]["proofs_per_s"]
+        except Exception as e:  # noqa: BLE001 - a side leg: reported, never allowed to take the line down
+            extra["host_in"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # ------------------------------------------------------------------ N > 1: BASELINE configs[3], one batch over all ranks
     if use_dist:
         # The headline above is complete; this leg must not be able to take it down.  An exception is reported inside the
@@ -873,47 +876,60 @@ def main():
             extra["wide"] = {"error": "%s: %s" % (type(e).__name__, e), "rccl_ranks": world}
         dog.cancel()
 
+    def side_leg(name, fn):
+        """an extra leg: its failure is reported inside its own object, the headline line is printed either way"""
+        try:
+            extra[name] = fn()
+        except Exception as e:  # noqa: BLE001
+            extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        return "error" not in extra[name]
+
     if rank == 0 and world == 1 and not args.no_extra:
         # -------------------------------------------------------------- configs[2]: 256 x aggregation-8
-        extra["cfg3"] = cfg3_leg()
+        side_leg("cfg3", cfg3_leg)
         if profiler_legs and extra["cfg3"].get("roofline"):
             tr = measure_traffic("k_msm_accumulate", "cfg3")
             if tr:
                 extra["cfg3"]["roofline"].update(tr)
         # -------------------------------------------------------------- one 4096-proof reference batch (north_star's sentence)
-        Sw = int(os.environ.get("BPP_BENCH_WIDE_INFLIGHT", "12"))
-        legw = Leg(bpp, packed, torch, device, params2, data2, 4096, 1, Sw, 0, profile=False)
-        nw = 40 * Sw
-        elw, latw, _ = timed(legw, nw, 12 * Sw, sync)  # the rate: no stage events; warm-up long enough for the clock (as the headline's pre-heat)
-        legw.set_profile(True)
-        _, _, prw = timed(legw, 4 * Sw, Sw, sync)  # stage times with the same calls in flight
-        sync()
-        alw = [legw.one_step(0) for _ in range(5)]
-        roofw, stw = kernel_roofline(prw, sum(a[1].get("msm_accumulate_ms", 0.0) for a in alw) / 5)
-        extra["wide4096"] = {"workload": "4096 non-aggregated 64-bit proofs as ONE reference batch (chunk = 0: one weight chain over "
-                                         "4096, one 65 667-term MSM) on one GPU; %d calls in flight, each on another 4096 proofs" % Sw,
-                             "proofs_per_s": 4096 * nw / elw, "ms_per_batch_in_flight": 1e3 * sum(latw) / len(latw),
-                             "ms_per_batch_alone": 1e3 * sum(a[0] for a in alw) / 5, "steps": nw, "roofline": roofw, "stages_ms": stw}
-        legw.close()
+        def wide4096_leg():
+            Sw = int(os.environ.get("BPP_BENCH_WIDE_INFLIGHT", "12"))
+            legw = Leg(bpp, packed, torch, device, params2, data2, 4096, 1, Sw, 0, profile=False)
+            nw = 40 * Sw
+            elw, latw, _ = timed(legw, nw, 12 * Sw, sync)  # the rate: no stage events; warm-up long enough for the clock (as the headline's pre-heat)
+            legw.set_profile(True)
+            _, _, prw = timed(legw, 4 * Sw, Sw, sync)  # stage times with the same calls in flight
+            sync()
+            alw = [legw.one_step(0) for _ in range(5)]
+            roofw, stw = kernel_roofline(prw, sum(a[1].get("msm_accumulate_ms", 0.0) for a in alw) / 5)
+            res = {"workload": "4096 non-aggregated 64-bit proofs as ONE reference batch (chunk = 0: one weight chain over "
+                                             "4096, one 65 667-term MSM) on one GPU; %d calls in flight, each on another 4096 proofs" % Sw,
+                                 "proofs_per_s": 4096 * nw / elw, "ms_per_batch_in_flight": 1e3 * sum(latw) / len(latw),
+                                 "ms_per_batch_alone": 1e3 * sum(a[0] for a in alw) / 5, "steps": nw, "roofline": roofw, "stages_ms": stw}
+            legw.close()
+            return res
+        side_leg("wide4096", wide4096_leg)
         # -------------------------------------------------------------- single-call latency (configs[0]'s shape)
-        lat_out = {}
-        for nb in (1, 64, 256):
-            legl = Leg(bpp, packed, torch, device, params2, data2, nb, 1, 1, 0, profile=False)
-            legl.run_steps(10)
-            ls, _ = legl.run_steps(50)  # the latency: no stage events
-            ls.sort()
-            legl.set_profile(True)
-            legl.run_steps(3)
-            lsp, lp = legl.run_steps(20)  # stage times (the events add ~0.1 ms to the call)
-            lsp.sort()
-            rl, sl = kernel_roofline(lp)
-            lat_out["batch_%d" % nb] = {"ms_per_call_median": 1e3 * ls[len(ls) // 2], "ms_per_call_min": 1e3 * ls[0],
-                                        "ms_per_call_median_with_stage_events": 1e3 * lsp[len(lsp) // 2],
-                                        "proofs_per_s": nb / ls[len(ls) // 2], "roofline": rl, "stages_ms": sl}
-            legl.close()
-        extra["latency"] = dict(lat_out, workload="BASELINE configs[0]'s shape through the engine: ONE call at a time, 1, 64 and 256 "
-                                                  "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input; calls of up to ~1200 proofs "
-                                                  "run the final MSM as a half-scalar plan (s = s_lo + 2^126 s_hi: half the Horner doublings)")
+        def latency_leg():
+            lat_out = {}
+            for nb in (1, 64, 256):
+                legl = Leg(bpp, packed, torch, device, params2, data2, nb, 1, 1, 0, profile=False)
+                legl.run_steps(10)
+                ls, _ = legl.run_steps(50)  # the latency: no stage events
+                ls.sort()
+                legl.set_profile(True)
+                legl.run_steps(3)
+                lsp, lp = legl.run_steps(20)  # stage times (the events add ~0.1 ms to the call)
+                lsp.sort()
+                rl, sl = kernel_roofline(lp)
+                lat_out["batch_%d" % nb] = {"ms_per_call_median": 1e3 * ls[len(ls) // 2], "ms_per_call_min": 1e3 * ls[0],
+                                            "ms_per_call_median_with_stage_events": 1e3 * lsp[len(lsp) // 2],
+                                            "proofs_per_s": nb / ls[len(ls) // 2], "roofline": rl, "stages_ms": sl}
+                legl.close()
+            return dict(lat_out, workload="BASELINE configs[0]'s shape through the engine: ONE call at a time, 1, 64 and 256 "
+                                                      "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input; calls of up to ~1200 proofs "
+                                                      "run the final MSM as a half-scalar plan (s = s_lo + 2^126 s_hi: half the Horner doublings)")
+        side_leg("latency", latency_leg)
         # -------------------------------------------------------------- many callers, one 256-proof verify_batch call each
         try:
             extra["small_calls"] = small_calls_leg(bpp, packed, np, local_rank, params2, data2)
@@ -924,8 +940,7 @@ def main():
             extra["recover_only"] = recover_only_leg(data2, params2)
         except Exception as e:  # noqa: BLE001 - the headline is never held hostage by an extra leg
             extra["recover_only"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        extra["prover"] = prover_leg()
-        if profiler_legs:
+        if side_leg("prover", prover_leg) and profiler_legs:
             tr = measure_traffic("k_fb_msm", "prover")
             if tr:  # the counters are per dispatch: scaled to the launches of one call, like achieved / algorithmic_bytes
                 rp = extra["prover"]["roofline"]
