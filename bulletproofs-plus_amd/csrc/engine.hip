@@ -510,7 +510,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1;
+        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -550,6 +550,7 @@ const OptionName kOptions[] = {
     {"prove_prio", "BPP_PROVE_PRIO", &bpp_ctx::Options::prove_prio},
     {"prove_fused", "BPP_PROVE_FUSED", &bpp_ctx::Options::prove_fused},
     {"static_gemm", "BPP_STATIC_GEMM", &bpp_ctx::Options::static_gemm},
+    {"lazy_columns", "BPP_LAZY_COLUMNS", &bpp_ctx::Options::lazy_columns},
 };
 void options_from_env(bpp_ctx *c) {
   for (const OptionName &o : kOptions)
@@ -1951,7 +1952,7 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool weights_residen
     } else
       hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s, b.d_desc.p, b.tab.p, b.shr.p,
                          weights, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, b.rows.p, dyn_scal,
-                         b.fused_columns ? b.parts.p : (uint64_t *)nullptr);
+                         b.fused_columns ? b.parts.p : (uint64_t *)nullptr, ctx->opt.lazy_columns != 0 ? 1u : 0u);
   }
   tm.mark(M_LANES);
   if (b.static_gemm) {

@@ -644,7 +644,8 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
                                                       uint32_t nhi_max, uint32_t ppw,
                                                       sc *__restrict__ rows /* weighted, Montgomery */,
                                                       sc *__restrict__ dyn_out /* canonical */,
-                                                      uint64_t *__restrict__ parts /* null, or [workgroup][2 max_mn][8] limb sums */) {
+                                                      uint64_t *__restrict__ parts /* null, or [workgroup][2 max_mn][8] limb sums */,
+                                                      uint32_t lazy /* with parts: one reduction per (workgroup, column) */) {
   const uint32_t p0 = blockIdx.x * ppw;
   const uint32_t lane = threadIdx.x;
   extern __shared__ uint32_t lanes_lds_raw[];
@@ -764,6 +765,88 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
   // per-proof rows (272 MB written here and read again by k_reduce_static in a 65 536-proof step) never exist; the group's
   // column sums are then taken over ppw times fewer addends (k_reduce_parts)
   if (parts) {
+    // One reduction per (workgroup, column) instead of two per (proof, column): the products a_p b_p of the workgroup's proofs are
+    // summed as they are (seventeen 64-bit columns of 29-bit limb products, carries pushed up every eight products) and the SUM is
+    // Montgomery-reduced (scalar.h: sc9_mul_acc / sc18_redc) -- 243 multiply-adds per (proof, generator pair) instead of 405 plus
+    // two carry / pack / conditional-subtraction tails.  The same residue as the sum of the reduced products, so the group's
+    // columns come out bit for bit as before.  Needs every proof of the workgroup to have the same shape (then w e^2 z enters as
+    // one sum per workgroup); any other workgroup, and lazy = 0, takes the per-proof products below.
+    __shared__ sc s_E[2];
+    __shared__ uint32_t s_uniform;
+    if (lane == 0) {
+      uint32_t uni = lazy, r0 = ~0u, m0 = 0;
+      sc E;
+      sc_0(E);
+      for (uint32_t sub = 0; sub < ppw && uni; sub++) {
+        if (s_r[sub] == ~0u) continue;
+        if (r0 == ~0u) r0 = s_r[sub], m0 = s_m[sub];
+        else if (s_r[sub] != r0 || s_m[sub] != m0) uni = 0;
+        const sc e2z = *reinterpret_cast<const sc *>(reinterpret_cast<const uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes + (size_t)n9 * sizeof(sc9));
+        sc_add(E, E, e2z);
+      }
+      if (r0 == ~0u) uni = 0;
+      s_uniform = uni;
+      s_E[0] = E;
+      sc_neg(E, E);
+      s_E[1] = E;
+    }
+    __syncthreads();
+    if (s_uniform) {
+      uint32_t first = 0;
+      while (s_r[first] == ~0u) first++;
+      const uint32_t r = s_r[first], mn = s_m[first] * n_bits, nhi = 1u << (r - LB);
+      const sc Ep = s_E[0], Em = s_E[1];
+      for (uint32_t i = lane; i < max_mn; i += 64) {
+        uint64_t *o = parts + ((size_t)blockIdx.x * 2 * max_mn + 2 * i) * 8;
+        if (i >= mn) {  // zero padding of a smaller statement
+#pragma unroll
+          for (int q = 0; q < 16; q++) o[q] = 0;
+          continue;
+        }
+        const uint32_t lo = i & (nlo - 1), hi_i = (i >> LB) & (nhi - 1);
+        const uint32_t rlo = (~lo) & (nlo - 1), rhi = (~hi_i) & (nhi - 1);
+        sc gi, hi;
+        {
+          uint64_t acc[17], top = 0;
+#pragma unroll
+          for (int k = 0; k < 17; k++) acc[k] = 0;
+          uint32_t cnt = 0;
+          for (uint32_t sub = 0; sub < ppw; sub++) {
+            if (s_r[sub] == ~0u) continue;
+            const sc9 *T = reinterpret_cast<const sc9 *>(reinterpret_cast<const uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes);
+            sc9_mul_acc(acc, T[lo], T[24 + hi_i]);  // glo x ghi
+            if (++cnt == 8) {
+              sc18_normalize(acc, top);
+              cnt = 0;
+            }
+          }
+          sc18_redc(gi, acc, top);
+        }
+        {
+          uint64_t acc[17], top = 0;
+#pragma unroll
+          for (int k = 0; k < 17; k++) acc[k] = 0;
+          uint32_t cnt = 0;
+          for (uint32_t sub = 0; sub < ppw; sub++) {
+            if (s_r[sub] == ~0u) continue;
+            const sc9 *T = reinterpret_cast<const sc9 *>(reinterpret_cast<const uint8_t *>(lanes_lds_raw) + (size_t)sub * per_bytes);
+            sc9_mul_acc(acc, T[16 + rlo], T[24 + 2 * nhi_max + rhi]);  // hlo x shi
+            sc9_mul_acc(acc, T[8 + lo], T[24 + nhi_max + hi_i]);       // yn2lo x y2hi
+            if (++cnt == 4) {
+              sc18_normalize(acc, top);
+              cnt = 0;
+            }
+          }
+          sc18_redc(hi, acc, top);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {  // (limb sums: k_reduce_parts adds the workgroups' and reduces)
+          o[q] = (uint64_t)gi.v[q] + Ep.v[q];
+          o[8 + q] = (uint64_t)hi.v[q] + Em.v[q];
+        }
+      }
+      return;
+    }
     for (uint32_t i = lane; i < max_mn; i += 64) {
       uint64_t ag[8], ah[8];
 #pragma unroll

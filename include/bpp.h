@@ -76,7 +76,8 @@ const char *bpp_ctx_last_error(bpp_ctx *ctx);
  * kernels on a high-priority stream), "fused_columns" (0: per-proof generator rows + k_reduce_static instead of the column sums inside
  * k_scalars_lanes), "static_gemm" (1 / 0: those column sums as ONE integer matrix product over the proofs of a group on the
  * matrix cores, kernels_static_gemm.h, or by Montgomery products per (proof, generator); by itself the engine takes the matrix
- * product from aggregation 8 on).  The environment variables BPP_<NAME> give
+ * product from aggregation 8 on), "lazy_columns" (0: every product of the column sums inside k_scalars_lanes reduced by itself
+ * instead of one reduction per workgroup and column).  The environment variables BPP_<NAME> give
  * the initial values and are read ONCE, when the context is created: no verification path calls getenv. */
 int bpp_ctx_set_option(bpp_ctx *ctx, const char *name, int value);
 

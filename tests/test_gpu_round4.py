@@ -448,15 +448,19 @@ def test_column_sums_inside_the_lanes_kernel_equal_per_proof_rows(bpp, packed, e
     pr = d["proofs"].copy()
     pr[count // 2, 1 + 32 + 96] ^= 1
     got = {}
-    for fused in (1, 0):
+    opt("static_gemm", 0)
+    for fused, lazy in ((1, 1), (1, 0), (0, 0)):  # lazy: one reduction per (workgroup, column) for the summed products (scalar.h: sc18_redc)
         opt("fused_columns", fused)
+        opt("lazy_columns", lazy)
         rb = packed.ResidentBatch(params, pr, d["commitments"], d["min_values"], d["min_present"], None, LABEL)
         with pytest.raises(bpp.ProofError):
             rb.verify_only(chunk)
-        got[fused] = (rb.trace(4), rb.trace(5), rb.trace(6))
+        got[(fused, lazy)] = (rb.trace(4), rb.trace(5), rb.trace(6))
         rb.close()
     opt("fused_columns", -1)
-    assert got[1] == got[0]
+    opt("lazy_columns", -1)
+    opt("static_gemm", -1)
+    assert got[(1, 1)] == got[(0, 0)] and got[(1, 0)] == got[(0, 0)]
     rb = packed.ResidentBatch(params, d["proofs"], d["commitments"], d["min_values"], d["min_present"], None, LABEL)
     rb.verify_only(chunk)
     assert set(rb.trace(6)) == {0}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Throughput of the resident verifier against the aggregation factor, with the generator columns per proof (static_gemm 0) and as
-a matrix product over the proofs of a group (1, 2): 64 reference batches of 256 aggregation-m proofs per step, three steps in
-flight.  One JSON line per (m, form).
+"""Throughput of the resident verifier against the aggregation factor, with the generator columns by Montgomery products per
+(proof, generator), by products summed per workgroup under one reduction, and as a matrix product over the proofs of a group on
+the matrix cores: 64 reference batches of 256 aggregation-m proofs per step, three steps in flight.  One JSON line per (m, form).
 
     python tools/agg_probe.py "1,2,4,8" [steps]"""
 import importlib
@@ -30,11 +30,13 @@ def main():
     for m in ms:
         params = bpp.RangeParameters.init(64, m, bpp.create_pedersen_gens_with_extension_degree(1), engine=eng0)
         data = bench.make_inputs(np, packed, params, 256 * 64, seed=8675309 + m)
-        for form in (0, 1, 2):
-            os.environ["BPP_STATIC_GEMM"] = str(form)  # read when the slots' contexts are created
+        for name, env in (("per-proof products", {"BPP_STATIC_GEMM": "0", "BPP_LAZY_COLUMNS": "0"}),
+                          ("one reduction per workgroup", {"BPP_STATIC_GEMM": "0", "BPP_LAZY_COLUMNS": "1"}),
+                          ("matrix product", {"BPP_STATIC_GEMM": "1", "BPP_LAZY_COLUMNS": "1"})):
+            os.environ.update(env)  # read when the slots' contexts are created
             leg = bench.Leg(bpp, packed, torch, device, params, data, 256, 64, 3, 256)
             el, lat, profs = bench.timed(leg, steps, 8, sync)
-            print(json.dumps({"m": m, "static_gemm": form, "proofs_per_s": round(256 * 64 * steps / el), "ms_per_step": round(1e3 * el / steps, 4)}),
+            print(json.dumps({"m": m, "columns": name, "proofs_per_s": round(256 * 64 * steps / el), "ms_per_step": round(1e3 * el / steps, 4)}),
                   flush=True)
             leg.close()
         params.close()
