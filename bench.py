@@ -120,7 +120,7 @@ def make_inputs(np, packed, params, count, seed, chunk=8192):
     n_bits, m, t = params.bit_length(), params.max_aggregation_factor(), int(params.extension_degree())
     rounds = (n_bits * m).bit_length() - 1
     rng = np.random.default_rng(seed)
-    values = rng.integers(0, 1 << 63, size=(count, m), dtype=np.uint64)
+    values = rng.integers(0, 1 << min(63, max(n_bits - 1, 1)), size=(count, m), dtype=np.uint64)  # (2^63 for the 64-bit configs)
     one = rng.integers(0, 256, size=(count, m, 32), dtype=np.uint8)
     one[..., 31] &= 0x0f  # < 2^252 < l: canonical (zero has probability 2^-252)
     one[..., 0] |= 1

@@ -533,3 +533,35 @@ def test_generator_columns_as_a_matrix_product_equal_the_per_proof_form(bpp, pac
     rb.close()
     opt("tables_wave", -1)
     params.close()
+
+
+@pytest.mark.parametrize("n_bits,m,count,chunk", [(8, 8, 100, 32), (16, 4, 75, 0), (32, 2, 130, 64), (64, 16, 40, 16), (64, 32, 20, 0), (8, 32, 48, 16)])
+def test_matrix_product_columns_other_bit_lengths_and_aggregations(bpp, packed, engine, opt, n_bits, m, count, chunk):
+    """the matrix-product form of the generator columns against the per-proof form over the other shapes the index split allows
+    (bit lengths 8 ... 64, aggregation 2 ... 32: 8 ... 256 high-table entries, 64 ... 2048 generator pairs), a tampered proof in
+    the middle; every proof of the untampered input verifies"""
+    import struct
+    import bench
+    params = bpp.RangeParameters.init(n_bits, m, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    d = bench.make_inputs(np, packed, params, count, seed=5300 + n_bits + m)
+    pr = d["proofs"].copy()
+    pr[count // 2, 1 + 32 + 96] ^= 1
+    got = {}
+    opt("tables_wave", 0)
+    for gemm in (1, 0):
+        opt("static_gemm", gemm)
+        rb = packed.ResidentBatch(params, pr, d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+        with pytest.raises(bpp.ProofError):
+            rb.verify_only(chunk)
+        got[gemm] = (rb.trace(4), rb.trace(5), rb.trace(6), struct.unpack("<4I", rb.trace(7))[0] & 2)
+        rb.close()
+    assert got[1][3] and not got[0][3]
+    assert got[1][:3] == got[0][:3]
+    opt("static_gemm", 1)
+    rb = packed.ResidentBatch(params, d["proofs"], d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+    rb.verify_only(chunk)
+    assert set(rb.trace(6)) == {0}
+    rb.close()
+    opt("static_gemm", -1)
+    opt("tables_wave", -1)
+    params.close()
