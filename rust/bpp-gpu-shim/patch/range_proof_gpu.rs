@@ -20,6 +20,7 @@
 //   gpu::prove_with_rng(GpuTranscript, statement, witness, rng)
 pub mod gpu {
     use alloc::vec::Vec;
+    use core::convert::TryInto;  // (the crate is edition 2018: not in its prelude)
     use core::ops::{Add, Mul};
 
     use bpp_gpu_shim::{cached_params, default_engine, Action, Engine, GpuError, PackedBatch, Params, ProveItem, VerifyItem};
@@ -215,10 +216,10 @@ pub mod gpu {
         // seed nonces are secrets (Zeroize for RangeStatement, src/range_statement.rs:76-81)
         let seeds: Zeroizing<Vec<u8>> = Zeroizing::new(statements.iter().flat_map(|s| s.seed_nonce.map_or([0u8; 32], |x| x.to_bytes())).collect());
         let seed_refs: Vec<Option<&[u8; 32]>> = (0..n).map(|i| {
-            if statements[i].seed_nonce.is_some() { Some(seeds[32 * i..32 * i + 32].try_into().unwrap()) } else { None }
+            if statements[i].seed_nonce.is_some() { Some((&seeds[32 * i..32 * i + 32]).try_into().unwrap()) } else { None }
         }).collect();
         let items: Vec<VerifyItem<'_>> = (0..n).map(|i| VerifyItem {
-            proof: &blobs[i], commitments: &comms[i], min_values: &statements[i].minimum_value_promises, seed_nonce: seed_refs[i],
+            proof: &blobs[i][..], commitments: &comms[i][..], min_values: &statements[i].minimum_value_promises[..], seed_nonce: seed_refs[i],
             transcript_label: &[], transcript_state: None }).collect();   // (the transcript fields are ignored by this entry)
         let run = || -> Result<Vec<Option<Vec<[u8; 32]>>>, GpuError> {
             let params = params_for(max_statement)?;
@@ -262,8 +263,8 @@ pub mod gpu {
                 let comms: Vec<u8> = statements.iter().flat_map(|s| s.commitments_compressed.iter().flat_map(|c| *c.as_fixed_bytes())).collect();
                 let mins: Vec<u64> = statements.iter().flat_map(|s| s.minimum_value_promises.iter().map(|v| v.unwrap_or(0))).collect();
                 let present: Vec<u8> = statements.iter().flat_map(|s| s.minimum_value_promises.iter().map(|v| v.is_some() as u8)).collect();
-                let input = PackedBatch { n_items: n, proofs: &flat, proof_len: blobs[0].len(), commitments: &comms, m: m0, min_values: &mins,
-                                          min_present: &present, seed_nonces: Some((&seeds, &seed_present)),
+                let input = PackedBatch { n_items: n, proofs: &flat[..], proof_len: blobs[0].len(), commitments: &comms[..], m: m0, min_values: &mins[..],
+                                          min_present: &present[..], seed_nonces: Some((&seeds[..], &seed_present[..])),
                                           transcript_label: transcripts.label(), transcript_state: transcripts.state() };
                 if n <= MAX_RANGE_PROOF_BATCH_SIZE {
                     // ONE reference batch: a small call.  Separate threads with such calls stop at about 5 000 calls per second
@@ -276,9 +277,9 @@ pub mod gpu {
                 engine.verify_batch_packed(&params, &input, act, MAX_RANGE_PROOF_BATCH_SIZE)
             } else {
                 let comms: Vec<Vec<u8>> = statements.iter().map(|s| s.commitments_compressed.iter().flat_map(|c| *c.as_fixed_bytes()).collect()).collect();
-                let seed_refs: Vec<Option<&[u8; 32]>> = (0..n).map(|i| if seed_present[i] != 0 { Some(seeds[32 * i..32 * i + 32].try_into().unwrap()) } else { None }).collect();
+                let seed_refs: Vec<Option<&[u8; 32]>> = (0..n).map(|i| if seed_present[i] != 0 { Some((&seeds[32 * i..32 * i + 32]).try_into().unwrap()) } else { None }).collect();
                 let items: Vec<VerifyItem<'_>> = (0..n).map(|i| VerifyItem {
-                    proof: &blobs[i], commitments: &comms[i], min_values: &statements[i].minimum_value_promises,
+                    proof: &blobs[i][..], commitments: &comms[i][..], min_values: &statements[i].minimum_value_promises[..],
                     seed_nonce: seed_refs[i], transcript_label: transcripts.label(), transcript_state: transcripts.state() }).collect();
                 let engine = default_engine().lock().unwrap();
                 engine.verify_batch(&params, &items, act, MAX_RANGE_PROOF_BATCH_SIZE)
@@ -310,9 +311,9 @@ pub mod gpu {
         let run = || -> Result<Vec<u8>, GpuError> {
             let params = params_for(statement)?;
             let engine = default_engine().lock().unwrap();
-            let item = ProveItem { values: &values, blindings: &blindings, commitments: &comms, min_values: &statement.minimum_value_promises,
-                                   seed_nonce: seed.as_ref(), transcript_label: transcript.label(), transcript_state: transcript.state(),
-                                   rng_bytes: &rng_bytes };
+            let item = ProveItem { values: &values[..], blindings: &blindings[..], commitments: &comms[..],
+                                   min_values: &statement.minimum_value_promises[..], seed_nonce: (*seed).as_ref(),
+                                   transcript_label: transcript.label(), transcript_state: transcript.state(), rng_bytes: &rng_bytes[..] };
             let mut out = engine.prove_batch(&params, core::slice::from_ref(&item))?;
             Ok(out.remove(0))
         };
