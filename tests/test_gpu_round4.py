@@ -565,3 +565,29 @@ def test_matrix_product_columns_other_bit_lengths_and_aggregations(bpp, packed, 
     opt("static_gemm", -1)
     opt("tables_wave", -1)
     params.close()
+
+
+def test_configs2_at_bench_size_takes_the_matrix_product_by_itself(bpp, packed, engine):
+    """BASELINE configs[2] as bench.py runs it (64 reference batches of 256 aggregation-8 proofs in one call, default options): the
+    engine takes the matrix-product form of the generator columns by itself, every batch's final point is the identity, and one
+    flipped bit in one proof makes exactly that batch fail"""
+    import struct
+    import bench
+    params = bpp.RangeParameters.init(64, 8, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    d = bench.make_inputs(np, packed, params, 64 * 256, seed=5400)
+    rb = packed.ResidentBatch(params, d["proofs"], d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+    rb.verify_only(256)
+    assert struct.unpack("<4I", rb.trace(7))[0] & 2, "aggregation 8, 16 384 proofs: the matrix-product form is the default"
+    acc = rb.trace(6)
+    assert len(acc) == 64 * 32 and set(acc) == {0}
+    rb.close()
+    pr = d["proofs"].copy()
+    pr[37 * 256 + 11, 1 + 32 + 64 + 5] ^= 0x40  # a bit of A1 of proof 11 of batch 37
+    rb = packed.ResidentBatch(params, pr, d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+    with pytest.raises(bpp.ProofError):
+        rb.verify_only(256)
+    acc = rb.trace(6)
+    bad = [g for g in range(64) if acc[32 * g:32 * g + 32] != bytes(32)]
+    assert bad == [37]
+    rb.close()
+    params.close()
