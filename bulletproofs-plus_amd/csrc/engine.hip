@@ -2654,389 +2654,4 @@ int bpp_profile_get(bpp_ctx *ctx, bpp_profile *out) {
 #include "engine_shard.h"
 #include "engine_batcher.h"
 
-// ================================================================= batch prover
-extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_item *items, size_t n_items, uint8_t *proofs_out,
-                               size_t proof_stride, size_t *proof_len, char *errbuf, size_t errbuf_len) {
-  BPP_ENTRY(ctx);
-  try {
-    const std::shared_ptr<Params> Pp = params_registry().get(params);
-    if (!Pp || Pp->device != ctx->device) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown params handle", errbuf, errbuf_len);
-    Params &P = *Pp;
-    if (!items || n_items == 0 || !proofs_out) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument", errbuf, errbuf_len);
-    const uint32_t n = P.n_bits, t = P.t, m = items[0].m, B = (uint32_t)n_items;
-    // RangeStatement::init (src/range_statement.rs:43-62)
-    if (m == 0 || (m & (m - 1))) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Number of commitments must be a power of two"};
-    if (P.m_max < m) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Not enough generators for this statement"};
-    const uint32_t mn = m * n;
-    if (mn < 2) throw ProofErr{BPP_ERR_INVALID_LENGTH, "bit_length * aggregation factor must be at least 2"};
-    uint32_t rounds = 0;
-    while ((1u << rounds) < mn) rounds++;
-    const size_t plen = 1 + 32 * (size_t)(t + 5 + 2 * rounds);
-    if (proof_len) *proof_len = plen;
-    if (proof_stride < plen) return fail(ctx, BPP_ERR_INVALID_LENGTH, "proof_stride too small", errbuf, errbuf_len);
-    const uint32_t wit_len = m * (8 + 32 * t), ext_len = 32 * (rounds + 3);
-
-    std::vector<ProveDesc> desc(B);
-    std::vector<uint8_t> bytes, states;
-    // `bytes` (values, blinding factors, seed nonces), the page-locked staging in both directions (witness bytes in,
-    // ProveState out) and the device arena hold witness-derived data: wiped on EVERY exit path, including the
-    // "Witness opening is invalid!" and HIP-error ones
-    bool arena_clean = true;
-    ScopeExit wipe_secrets{[&] {
-      wipe(bytes.data(), bytes.size());
-      wipe(ctx->prove_pin_in.p, ctx->prove_pin_in.n);
-      wipe(ctx->prove_pin_out.p, ctx->prove_pin_out.n);
-      if (!arena_clean && ctx->prove_arena.p) {
-        for (auto &ps : ctx->prove_aux_streams) (void)hipStreamSynchronize(ps);
-        for (auto &ps : ctx->prove_streams) (void)hipStreamSynchronize(ps);
-        for (auto &ps : ctx->prove_lane_streams) (void)hipStreamSynchronize(ps);
-        (void)hipMemset(ctx->prove_arena.p, 0, ctx->prove_arena.n);
-      }
-    }};
-    std::vector<uint64_t> minvals((size_t)B * m);
-    std::vector<uint8_t> minpres((size_t)B * m);
-    std::map<std::string, uint32_t> state_ids;
-    bytes.reserve((size_t)B * (wit_len + 32 * m + ext_len + 32));
-    for (uint32_t i = 0; i < B; i++) {
-      const bpp_prove_item &it = items[i];
-      ProveDesc &d = desc[i];
-      if (it.m != m) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "all items of one prove batch must share the aggregation factor"};
-      if (!it.values || !it.blindings32 || !it.commitments32 || !it.rng_bytes || (!it.min_values && it.min_present))
-        throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "null witness / statement field"};
-      if (it.seed_nonce32 && m > 1)
-        throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Mask recovery is not supported with an aggregated statement"};
-      if (it.rng_len < ext_len) throw ProofErr{BPP_ERR_INVALID_LENGTH, "not enough external randomness: need (rounds + 3) * 32 bytes"};
-      d.m = m;
-      d.minval_idx = i * m;
-      for (uint32_t j = 0; j < m; j++) {
-        // :264-271
-        if (n < 64 && (it.values[j] >> n) > 0) throw ProofErr{BPP_ERR_INVALID_LENGTH, "Value exceeds bit vector capacity!"};
-        const bool present = it.min_present ? it.min_present[j] != 0 : false;
-        const uint64_t mv = present ? it.min_values[j] : 0;
-        // :308-311
-        if (present && it.values[j] < mv) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Minimum value is larger than value"};
-        minvals[(size_t)i * m + j] = mv;
-        minpres[(size_t)i * m + j] = present ? 1 : 0;
-      }
-      for (uint32_t q = 0; q < m * t; q++)
-        if (!sc_is_canonical(it.blindings32 + 32 * (size_t)q)) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "blinding factor is not canonical"};
-      if (it.seed_nonce32 && !sc_is_canonical(it.seed_nonce32)) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "seed nonce is not canonical"};
-      d.wit_off = (uint32_t)bytes.size();
-      for (uint32_t j = 0; j < m; j++) {
-        uint8_t v8[8];
-        for (int k = 0; k < 8; k++) v8[k] = (uint8_t)(it.values[j] >> (8 * k));
-        bytes.insert(bytes.end(), v8, v8 + 8);
-        bytes.insert(bytes.end(), it.blindings32 + (size_t)j * t * 32, it.blindings32 + (size_t)(j + 1) * t * 32);
-      }
-      d.commit_off = (uint32_t)bytes.size();
-      bytes.insert(bytes.end(), it.commitments32, it.commitments32 + (size_t)m * 32);
-      d.ext_off = (uint32_t)bytes.size();
-      bytes.insert(bytes.end(), it.rng_bytes, it.rng_bytes + ext_len);
-      d.seed_off = (uint32_t)bytes.size();
-      d.flags = it.seed_nonce32 ? 1u : 0u;
-      if (it.seed_nonce32) bytes.insert(bytes.end(), it.seed_nonce32, it.seed_nonce32 + 32);
-      else bytes.insert(bytes.end(), 32, 0);
-      // the same transcript source as the previous item (the common case: one label for the whole call): same id, no key, no lookup
-      if (i && items[i - 1].transcript_state == it.transcript_state && items[i - 1].transcript_label == it.transcript_label &&
-          items[i - 1].label_len == it.label_len) {
-        d.state_idx = desc[i - 1].state_idx;
-        continue;
-      }
-      std::string key;
-      if (it.transcript_state) {
-        key.assign((const char *)it.transcript_state, 203);
-        key.push_back('S');
-      } else {
-        key.assign((const char *)it.transcript_label, it.transcript_label ? it.label_len : 0);
-        key.push_back('L');
-      }
-      auto sit = state_ids.find(key);
-      if (sit == state_ids.end()) {
-        uint32_t id = (uint32_t)(states.size() / 203);
-        states.resize(states.size() + 203);
-        if (it.transcript_state) {
-          memcpy(&states[(size_t)id * 203], it.transcript_state, 203);
-          if (states[(size_t)id * 203 + 200] >= BPP_STROBE_R) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "transcript state has pos >= rate"};
-        } else {
-          Strobe st;
-          merlin_new(st, it.transcript_label, (uint32_t)(it.transcript_label ? it.label_len : 0));
-          strobe_to_bytes(&states[(size_t)id * 203], st);
-        }
-        sit = state_ids.emplace(key, id).first;
-      }
-      d.state_idx = sit->second;
-    }
-
-    hipStream_t s0 = ctx->stream;
-    const uint32_t n_gen = 2 * P.n_bits * P.m_max;
-    {  // fixed-base window tables for every generator of these parameters (one-off; contexts sharing P serialise here)
-     std::lock_guard<std::mutex> fb_lock(P.fb_mu);
-     if (!P.fb_table.p) {
-      P.fb_geo = fb_geometry(P.table_len);
-      P.fb_table.alloc((size_t)P.table_len * fb_stride(P.fb_geo));
-      hipLaunchKernelGGL(k_fb_build, dim3(cdiv(P.table_len * P.fb_geo.windows * cdiv(P.fb_geo.entries, FB_BUILD_BLOCK), 64)),
-                         dim3(64), 0, s0, P.table.p, P.table_len, P.fb_geo, P.fb_table.p);
-      HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipStreamSynchronize(s0));
-     }
-    }
-    // The batch runs as up to PROVE_SUBS sub-batches, each on its own stream: a round is lane step (one lane per proof,
-    // Fiat-Shamir latency, a handful of wavefronts) -> wave step -> fixed-base MSM (fills the chip), so one sub-batch's
-    // lane step overlaps another's MSM.  All device buffers come out of one arena allocation per call.
-    uint32_t PROVE_SUBS = 2;
-    if (ctx->opt.prove_subs > 0) PROVE_SUBS = (uint32_t)std::min(16, ctx->opt.prove_subs);
-    const uint32_t sub_size = std::max<uint32_t>(64, cdiv(B, PROVE_SUBS));
-    const uint32_t n_sub = cdiv(B, sub_size);
-    while (ctx->prove_streams.size() < n_sub) {
-      hipStream_t ns;
-      HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
-      ctx->prove_streams.push_back(ns);
-    }
-    // A round of a sub-batch is [point encoding, Fiat-Shamir step, vector fold] -> [fixed-base MSM]: three latency-bound
-    // kernels of a few wavefronts, then one that fills the chip.  While one sub-batch's MSM runs, the other's small kernels
-    // queue for wave slots behind its 1024 workgroups and take 2-3x their own time (point encoding 70 -> 200 us, fold 45 -> 175:
-    // profiles/r04_prover_launches.txt), the MSMs of the two sub-batches drift into each other, and every period has ~110 us
-    // in which no MSM runs.  With prove_prio the small kernels go to a HIGH-priority stream of their own (the hardware hands
-    // freed wave slots to that queue first), joined to the MSM stream by an event each way per round.
-    const bool fused = ctx->opt.prove_fused != 0;  // one launch per round for encoding + Fiat-Shamir step + vector step (tests run both)
-    const bool prio = ctx->opt.prove_prio > 0;  // (off by default: measured, no gain -- profiles/r04_prover_prio_ab.txt)
-    if (prio) {
-      int least = 0, greatest = 0;
-      HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      while (ctx->prove_lane_streams.size() < n_sub) {
-        hipStream_t ns;
-        HIP_CHECK(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, greatest));
-        ctx->prove_lane_streams.push_back(ns);
-      }
-      while (ctx->prove_sync_events.size() < 2 * (size_t)n_sub) {
-        hipEvent_t e;
-        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ctx->prove_sync_events.push_back(e);
-      }
-    }
-    while (ctx->prove_aux_streams.size() < n_sub) {
-      hipStream_t ns;
-      HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
-      ctx->prove_aux_streams.push_back(ns);
-    }
-    while (ctx->prove_aux_events.size() < 2 * (size_t)n_sub) {
-      hipEvent_t e;
-      HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      ctx->prove_aux_events.push_back(e);
-    }
-    // lane(q): the stream of sub-batch q's small kernels; msm(q): of its fixed-base MSMs (the same stream without prove_prio)
-    auto lane_stream = [&](uint32_t q) { return prio ? ctx->prove_lane_streams[q] : ctx->prove_streams[q]; };
-    auto to_msm = [&](uint32_t q) {  // the MSM stream continues behind everything enqueued on the lane stream so far
-      if (!prio) return;
-      HIP_CHECK(hipEventRecord(ctx->prove_sync_events[2 * q], ctx->prove_lane_streams[q]));
-      HIP_CHECK(hipStreamWaitEvent(ctx->prove_streams[q], ctx->prove_sync_events[2 * q], 0));
-    };
-    auto to_lane = [&](uint32_t q) {  // and back
-      if (!prio) return;
-      HIP_CHECK(hipEventRecord(ctx->prove_sync_events[2 * q + 1], ctx->prove_streams[q]));
-      HIP_CHECK(hipStreamWaitEvent(ctx->prove_lane_streams[q], ctx->prove_sync_events[2 * q + 1], 0));
-    };
-    const uint32_t stride = 2 * mn + t + 1;
-    struct Sub {
-      uint32_t lo, nb;
-      size_t bytes_lo, bytes_len, arena_lo, arena_len;
-      uint8_t *d_bytes, *d_states, *d_minpres, *d_a32, *d_lr, *d_a1b, *d_proofs, *d_commit32;
-      ProveDesc *d_desc;
-      uint64_t *d_minvals;
-      ProveState *d_ps;
-      sc *d_vec, *d_ts, *d_cts;
-      uint32_t *d_tg, *d_tc, *d_ctg, *d_ctc;
-      ge *d_ge;
-    };
-    std::vector<Sub> subs(n_sub);
-    size_t arena_need = 0;
-    uint8_t *arena_base = nullptr;
-    auto take = [&](size_t nbytes) {
-      arena_need = (arena_need + 255) & ~(size_t)255;
-      uint8_t *p = arena_base ? arena_base + arena_need : nullptr;
-      arena_need += nbytes;
-      return p;
-    };
-    auto carve = [&]() {
-      arena_need = 0;
-      for (uint32_t q = 0; q < n_sub; q++) {
-        Sub &u = subs[q];
-        u.lo = q * sub_size;
-        u.nb = std::min(sub_size, B - u.lo);
-        u.bytes_lo = desc[u.lo].wit_off;
-        u.bytes_len = (u.lo + u.nb < B ? desc[u.lo + u.nb].wit_off : bytes.size()) - u.bytes_lo;
-        const size_t nb = u.nb;
-        arena_need = (arena_need + 255) & ~(size_t)255;
-        u.arena_lo = arena_need;
-        u.d_bytes = take(u.bytes_len);
-        u.d_states = take(states.size());
-        u.d_minpres = take(nb * m);
-        u.d_minvals = (uint64_t *)take(nb * m * 8);
-        u.d_desc = (ProveDesc *)take(nb * sizeof(ProveDesc));
-        u.d_ps = (ProveState *)take(nb * sizeof(ProveState));
-        u.d_vec = (sc *)take(nb * (5 * (size_t)mn + 2) * sizeof(sc));
-        u.d_ts = (sc *)take(nb * 2 * stride * sizeof(sc));
-        u.d_tg = (uint32_t *)take(nb * 2 * stride * 4);
-        u.d_tc = (uint32_t *)take(nb * 2 * 4);
-        u.d_a32 = take(nb * 32);
-        u.d_lr = take((size_t)rounds * nb * 64);
-        u.d_a1b = take(nb * 64);
-        u.d_proofs = take(nb * plen);
-        u.d_commit32 = take(nb * m * 32);
-        u.d_cts = (sc *)take(nb * m * (1 + t) * sizeof(sc));
-        u.d_ctg = (uint32_t *)take(nb * m * (1 + t) * 4);
-        u.d_ctc = (uint32_t *)take(nb * m * 4);
-        u.d_ge = (ge *)take(std::max<size_t>(nb * m, 2 * nb) * sizeof(ge));
-        u.arena_len = arena_need - u.arena_lo;
-      }
-    };
-    carve();
-    ctx->prove_arena.alloc(arena_need + 256);
-    arena_base = ctx->prove_arena.p;
-    carve();
-    // descriptors are relative to each sub-batch's own byte block / minimum-value rows
-    for (uint32_t q = 0; q < n_sub; q++)
-      for (uint32_t i = 0; i < subs[q].nb; i++) {
-        ProveDesc &d = desc[subs[q].lo + i];
-        d.wit_off -= (uint32_t)subs[q].bytes_lo;
-        d.commit_off -= (uint32_t)subs[q].bytes_lo;
-        d.ext_off -= (uint32_t)subs[q].bytes_lo;
-        d.seed_off -= (uint32_t)subs[q].bytes_lo;
-        d.minval_idx = i * m;
-      }
-    // page-locked staging so that no copy stalls the enqueue of the next sub-batch
-    const size_t in_need = bytes.size() + states.size() + minpres.size() + minvals.size() * 8 + (size_t)B * sizeof(ProveDesc) + 64;
-    ctx->prove_pin_in.resize(in_need);
-    ctx->prove_pin_out.resize((size_t)B * plen + (size_t)B * sizeof(ProveState) + 64);
-    uint8_t *pin = ctx->prove_pin_in.p;
-    uint8_t *pin_bytes = pin;
-    memcpy(pin_bytes, bytes.data(), bytes.size());
-    uint8_t *pin_states = pin_bytes + bytes.size();
-    memcpy(pin_states, states.data(), states.size());
-    uint8_t *pin_minpres = pin_states + states.size();
-    memcpy(pin_minpres, minpres.data(), minpres.size());
-    uint8_t *pin_minvals = pin_minpres + ((minpres.size() + 7) & ~(size_t)7);
-    memcpy(pin_minvals, minvals.data(), minvals.size() * 8);
-    uint8_t *pin_desc = pin_minvals + minvals.size() * 8;
-    memcpy(pin_desc, desc.data(), (size_t)B * sizeof(ProveDesc));
-    uint8_t *pin_proofs = ctx->prove_pin_out.p;
-    ProveState *pin_ps = (ProveState *)(pin_proofs + (((size_t)B * plen + 15) & ~(size_t)15));
-
-    const dim3 b64(64);
-    // profiling: an event pair around every k_fb_msm launch (the prover's dominant kernel), summed after the call
-    size_t ev_used = 0;
-    auto fb_mark = [&](hipStream_t st) {
-      if (!ctx->profile) return;
-      if (ev_used == ctx->prove_events.size()) {
-        hipEvent_t e;
-        HIP_CHECK(hipEventCreate(&e));
-        ctx->prove_events.push_back(e);
-      }
-      HIP_CHECK(hipEventRecord(ctx->prove_events[ev_used++], st));
-    };
-    const auto t_begin = std::chrono::steady_clock::now();
-    arena_clean = false;
-    // The sub-batches advance together: every phase is enqueued for all of them before the next one (enqueued one
-    // sub-batch after the other, the second stream started ~60 launches late and the call ended with one stream running
-    // alone: its latency-bound Fiat-Shamir kernels with nothing beside them).
-    for (uint32_t q = 0; q < n_sub; q++) {
-      Sub &u = subs[q];
-      hipStream_t s = lane_stream(q), sm = ctx->prove_streams[q];
-      const uint32_t nb = u.nb;
-      HIP_CHECK(hipMemcpyAsync(u.d_bytes, pin_bytes + u.bytes_lo, u.bytes_len, hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(u.d_states, pin_states, states.size(), hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(u.d_minpres, pin_minpres + (size_t)u.lo * m, (size_t)nb * m, hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(u.d_minvals, pin_minvals + (size_t)u.lo * m * 8, (size_t)nb * m * 8, hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(u.d_desc, pin_desc + (size_t)u.lo * sizeof(ProveDesc), (size_t)nb * sizeof(ProveDesc),
-                               hipMemcpyHostToDevice, s));
-      // witness check (:275-284): commit(v_j, r_j) for every opening, compared with the statement's commitments.  Nothing of the
-      // proof depends on it (a mismatch is a status bit read after the call), so its three kernels run on a stream of their own
-      // beside kp_init / kp_A / the first round's small kernels (in line they were 0.2 ms of the call's first 0.75 ms, in which no
-      // round's MSM runs yet) and are joined in front of the first round's MSM, which reuses their output buffer
-      hipStream_t sx = ctx->prove_aux_streams[q];
-      HIP_CHECK(hipEventRecord(ctx->prove_aux_events[2 * q], s));
-      HIP_CHECK(hipStreamWaitEvent(sx, ctx->prove_aux_events[2 * q], 0));
-      hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(nb * m, 64)), b64, 0, sx, u.d_bytes, u.d_desc, t, n_gen, nb, m, 1 + t, u.d_cts,
-                         u.d_ctg, u.d_ctc);
-      fb_mark(sx);
-      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(ctx, 1 + t, P.fb_geo)), 0, sx, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, P.fb_geo,
-                         u.d_ge);
-      fb_mark(sx);
-      hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, sx, u.d_ge, nb * m, u.d_commit32);
-      HIP_CHECK(hipEventRecord(ctx->prove_aux_events[2 * q + 1], sx));
-      hipLaunchKernelGGL(kp_init, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_states, P.d_hg32.p, n, t, nb, u.d_ps);
-      hipLaunchKernelGGL(kp_A, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, P.table.p, P.fb_table.p, P.fb_geo, n_gen, n,
-                         t, u.d_ps, u.d_a32);
-    }
-    for (uint32_t j = 0; j <= rounds; j++)
-      for (uint32_t q = 0; q < n_sub; q++) {
-        Sub &u = subs[q];
-        hipStream_t s = lane_stream(q), sm = ctx->prove_streams[q];
-        const uint32_t nb = u.nb;
-        uint8_t *lr_prev = j ? u.d_lr + (size_t)(j - 1) * nb * 64 : nullptr;
-        if (fused) {  // the previous round's L / R are encoded by the same launch (kernels_prove.h: kp_round)
-          hipLaunchKernelGGL(kp_round, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, nb, j, rounds, stride,
-                             u.d_a32, j ? u.d_ge : (const ge *)nullptr, lr_prev, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
-        } else {
-          hipLaunchKernelGGL(kp_lane, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
-          hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
-                             stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
-        }
-        uint8_t *out = (j < rounds) ? u.d_lr + (size_t)j * nb * 64 : u.d_a1b;
-        if (j == 0) {  // the witness check joins here: its verdict into the proof's status, its buffer free for the round's MSM
-          HIP_CHECK(hipStreamWaitEvent(s, ctx->prove_aux_events[2 * q + 1], 0));
-          hipLaunchKernelGGL(kp_check_commitments, dim3(cdiv(nb, 64)), b64, 0, s, u.d_bytes, u.d_desc, u.d_commit32, nb, u.d_ps);
-        }
-        to_msm(q);
-        fb_mark(sm);
-        hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(fb_threads(ctx, mn + t + 1, P.fb_geo)), 0, sm, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, P.fb_geo,
-                           u.d_ge);
-        fb_mark(sm);
-        to_lane(q);
-        if (!fused || j == rounds)  // (A1 and B of the last launch: kp_finish is a one-lane-per-proof kernel)
-          hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);
-      }
-    for (uint32_t q = 0; q < n_sub; q++) {
-      Sub &u = subs[q];
-      hipStream_t s = lane_stream(q);
-      const uint32_t nb = u.nb;
-      hipLaunchKernelGGL(kp_finish, dim3(cdiv(nb, 64)), b64, 0, s, u.d_desc, n, t, nb, rounds, u.d_a32, u.d_lr, u.d_a1b, u.d_vec, u.d_ps,
-                         u.d_proofs, (uint32_t)plen);
-      HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipMemcpyAsync(pin_proofs + (size_t)u.lo * plen, u.d_proofs, (size_t)nb * plen, hipMemcpyDeviceToHost, s));
-      HIP_CHECK(hipMemcpyAsync(pin_ps + u.lo, u.d_ps, (size_t)nb * sizeof(ProveState), hipMemcpyDeviceToHost, s));
-      // zeroize the device copies of witness-derived data (the reference uses Zeroizing<> for these)
-      HIP_CHECK(hipMemsetAsync(arena_base + u.arena_lo, 0, u.arena_len, s));
-    }
-    for (uint32_t q = 0; q < n_sub; q++) {
-      HIP_CHECK(hipStreamSynchronize(lane_stream(q)));  // (everything of the MSM stream lies in front of the lane stream's tail)
-      HIP_CHECK(hipStreamSynchronize(ctx->prove_streams[q]));
-    }
-    arena_clean = true;  // every sub-batch's arena range was zeroed on its stream
-    if (ctx->profile) {
-      bpp_prove_profile &pp = ctx->pprof;
-      memset(&pp, 0, sizeof(pp));
-      for (size_t k = 0; k + 1 < ev_used; k += 2) {
-        float ms = 0;
-        HIP_CHECK(hipEventElapsedTime(&ms, ctx->prove_events[k], ctx->prove_events[k + 1]));
-        pp.fb_msm_ms += ms;
-      }
-      pp.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-      // terms handed to k_fb_msm: witness check m x (1 + t); per round L and R of mn + t + 1 terms each (every generator
-      // lands in exactly one of the two); the final step's A1 (every generator once more: 2 mn + t + 1 terms) and B (t + 1)
-      pp.fb_terms = (uint64_t)B * ((uint64_t)m * (1 + t) + (uint64_t)rounds * 2 * (mn + t + 1) + 2 * mn + 2 * t + 2);
-      pp.fb_launches = (uint32_t)(ev_used / 2);
-      pp.fb_window_bits = P.fb_geo.wbits;
-      pp.fb_windows = P.fb_geo.items;  // additions per term
-      pp.sub_batches = n_sub;
-    }
-    for (uint32_t i = 0; i < B; i++) {  // only the status word of the (secret-bearing) ProveState is looked at
-      if (pin_ps[i].status & PV_STATUS_COMMIT_MISMATCH) throw ProofErr{BPP_ERR_INVALID_ARGUMENT, "Witness opening is invalid!"};
-      if (pin_ps[i].status & PV_STATUS_TRANSCRIPT)
-        throw ProofErr{BPP_ERR_VERIFICATION_FAILED, "Identity element cannot be added to the transcript / zero challenge"};
-    }
-    for (uint32_t i = 0; i < B; i++) memcpy(proofs_out + (size_t)i * proof_stride, &pin_proofs[(size_t)i * plen], plen);
-    return BPP_OK;
-  }
-  BPP_CATCH(ctx, errbuf, errbuf_len)
-}
+#include "engine_prove.h"
