@@ -591,3 +591,49 @@ def test_configs2_at_bench_size_takes_the_matrix_product_by_itself(bpp, packed, 
     assert bad == [37]
     rb.close()
     params.close()
+
+
+def test_mutated_aggregated_proofs_through_the_matrix_product_end_like_the_oracle(bpp, packed, engine):
+    """nine reference batches of 256 aggregation-8 proofs per call with the engine's default plan (matrix-product columns), one
+    random mutation of one proof per call -- a flipped bit, a zeroed member, a low bit -- : the call's outcome (Ok, or the error
+    kind) is the C oracle's for the batch that holds the mutated proof, and when the final check fails it fails in that batch only"""
+    import struct
+    import bench
+    from oracle import cport
+    from tests.helpers import Prng
+    params = bpp.RangeParameters.init(64, 8, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    n = 9 * 256
+    d = bench.make_inputs(np, packed, params, n, seed=5500)
+    cp = cport.Params(64, 8, 1)
+    rng = Prng(b"gemm-fuzz")
+    plen = d["proofs"].shape[1]
+    for it in range(10):
+        pr = d["proofs"].copy()
+        p = int(rng.next_u64() % n)
+        member = 1 + 32 * int(rng.next_u64() % ((plen - 1) // 32))
+        kind = it % 3
+        if kind == 0:
+            bit = int(rng.next_u64() % (8 * plen))
+            pr[p, bit // 8] ^= 1 << (bit % 8)
+        elif kind == 1:
+            pr[p, member:member + 32] = 0
+        else:
+            pr[p, member] ^= 1
+        g = p // 256
+        items = [{"proof": pr[i].tobytes(), "commitments": [d["commitments"][i, j].tobytes() for j in range(8)],
+                  "min_values": [int(v) for v in d["min_values"][i]], "seed_nonce": None, "label": LABEL} for i in range(256 * g, 256 * g + 256)]
+        want, _, _ = cp.verify(items, action=0)
+        rb = packed.ResidentBatch(params, pr, d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+        try:
+            rb.verify_only(256)
+            got = 0
+        except bpp.ProofError as e:
+            got = int(e.kind)
+        assert got == want, (it, p, kind, got, want)
+        if got == int(bpp.ProofErrorKind.VerificationFailed):
+            assert struct.unpack("<4I", rb.trace(7))[0] & 2
+            acc = rb.trace(6)
+            assert [k for k in range(9) if acc[32 * k:32 * k + 32] != bytes(32)] == [g]
+        rb.close()
+    cp.close()
+    params.close()
