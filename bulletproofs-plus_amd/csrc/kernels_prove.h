@@ -207,7 +207,7 @@ struct ProveDesc {
 struct ProveState {
   Strobe tr;   // the proof's merlin transcript
   Strobe rng;  // current TranscriptRng (src/transcripts.rs:185-194)
-  sc y, z, e, einv, esq, einvsq, yinv_nhalf, yinv_prev, r, s;
+  sc y, z, e, einv, esq, einvsq, yinv_nhalf, yinv_prev, yinv1, r, s;
   sc alpha[6], dl[6], dr[6], dd[6], eta[6];
   uint32_t status;  // nonzero: proving failed (BPP_ERR_*)
 };
@@ -435,22 +435,27 @@ __device__ __forceinline__ void kp_lane_body(const uint8_t *__restrict__ bytes, 
     ok = pw_challenge(tr, L, K, "e", 1, e) && ok;
     y = st.y;
   }
-  // the round's two inversions side by side: even lanes invert e, odd lanes y^(n/2^(j+1))
+  // ONE inversion per round, the same input in every lane: e (rounds >= 1), y in step 0.  y^-(n / 2^(j+1)) is a power of y^-1
+  // (kept from step 0) -- until round 4 it was the inverse of y^(n / 2^(j+1)), taken on the odd lanes beside e's on the even
+  // ones: two different inputs in one wavefront make the variable-time inversion walk both lanes' branches one after the other.
   const uint32_t n_half = mn >> (j + 1);
-  sc yn, inv, einv, yinv;
-  if (j < rounds) sc_mont_pow_u32(yn, y, n_half);
-  else sc_copy(yn, e);
+  sc inv, einv, yinv, yinv1;
   {
     sc x;
 #pragma unroll
-    for (int q = 0; q < 8; q++) x.v[q] = (lane & 1u) ? yn.v[q] : e.v[q];
+    for (int q = 0; q < 8; q++) x.v[q] = j == 0 ? y.v[q] : e.v[q];
     sc_mont_invert_vartime(inv, x);
-    if (lane < 2) L.xch[lane] = inv;
-    __syncthreads();
-    einv = L.xch[0];
-    yinv = L.xch[1];
-    __syncthreads();
   }
+  if (j == 0) {
+    yinv1 = inv;
+    if (lane == 0) st.yinv1 = inv;
+    sc_copy(einv, inv);  // (unused in step 0)
+  } else {
+    yinv1 = st.yinv1;
+    einv = inv;
+  }
+  if (j < rounds) sc_mont_pow_u32(yinv, yinv1, n_half);
+  else sc_copy(yinv, yinv1);  // (unused in the last step)
   if (j > 0) {
     sc esq, einvsq;
     sc_montsq(esq, e);
