@@ -358,20 +358,24 @@ __global__ void __launch_bounds__(64) kp_A(const uint8_t *__restrict__ bytes, co
     niels_cneg(q, !bit);                     // a_R = a_L - 1 = -1 where the bit is 0
     ge_madd(acc, acc, q);
   }
-  if (lane < t) {  // alpha_k * G_k through the fixed-base table
+  // alpha_k * G_k through the fixed-base table: the t scalars' digits go to LDS and the t x windows lookups are spread over the
+  // wavefront (one or two additions per lane; on t lanes they were a chain of 23 additions each with 61 lanes waiting)
+  __shared__ int16_t s_dig[6 * FB_MAX_WINDOWS];
+  if (lane < t) {
     sc s;
     sc_from_mont(s, ps[p].alpha[lane]);
-    const fbent *row = tbl + (size_t)(n_gen + lane) * fb_stride(geo);
-    int16_t dig[FB_MAX_WINDOWS];
-    fb_recode(dig, s, geo);
-    for (uint32_t w = 0; w < geo.items; w++) {
-      const int dgt = dig[w];
-      if (dgt != 0) {
-        const uint32_t mag = (uint32_t)(dgt < 0 ? -dgt : dgt);
-        niels c = row[(size_t)w * geo.entries + (mag - 1)].q;
-        niels_cneg(c, dgt < 0);
-        ge_madd(acc, acc, c);
-      }
+    fb_recode(s_dig + lane * FB_MAX_WINDOWS, s, geo);
+  }
+  __syncthreads();
+  for (uint32_t it = lane; it < t * geo.items; it += 64) {
+    const uint32_t k = it / geo.items, w = it - k * geo.items;
+    const int dgt = s_dig[k * FB_MAX_WINDOWS + w];
+    if (dgt != 0) {
+      const fbent *row = tbl + (size_t)(n_gen + k) * fb_stride(geo);
+      const uint32_t mag = (uint32_t)(dgt < 0 ? -dgt : dgt);
+      niels c = row[(size_t)w * geo.entries + (mag - 1)].q;
+      niels_cneg(c, dgt < 0);
+      ge_madd(acc, acc, c);
     }
   }
   red[lane] = acc;
