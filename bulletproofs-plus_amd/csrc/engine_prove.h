@@ -350,7 +350,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       Sub &u = subs[q];
       hipStream_t s = lane_stream(q);
       const uint32_t nb = u.nb;
-      hipLaunchKernelGGL(kp_finish, dim3(cdiv(nb, 64)), b64, 0, s, u.d_desc, n, t, nb, rounds, u.d_a32, u.d_lr, u.d_a1b, u.d_vec, u.d_ps,
+      hipLaunchKernelGGL(kp_finish, dim3(nb), b64, 0, s, u.d_desc, n, t, nb, rounds, u.d_a32, u.d_lr, u.d_a1b, u.d_vec, u.d_ps,
                          u.d_proofs, (uint32_t)plen);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipMemcpyAsync(pin_proofs + (size_t)u.lo * plen, u.d_proofs, (size_t)nb * plen, hipMemcpyDeviceToHost, s));

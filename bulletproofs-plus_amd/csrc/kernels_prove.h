@@ -795,59 +795,53 @@ __global__ void __launch_bounds__(64) kp_finish(const ProveDesc *__restrict__ de
                                                 const uint8_t *__restrict__ lr_all /* [rounds][B][2][32] */,
                                                 const uint8_t *__restrict__ a1b32 /* [B][2][32] */, const sc *__restrict__ vec,
                                                 ProveState *__restrict__ ps, uint8_t *__restrict__ proofs, uint32_t proof_stride) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wavefront per proof (round 4; before: one lane per proof on the one-lane sponge, three Keccak-f of ~26 us each on the
+  // call's last stretch with nothing beside them): the transcript's last three operations on the cooperative sponge of the
+  // Fiat-Shamir steps, then lane k < t makes d1_k, lanes t and t + 1 make r1 and s1, and the wire bytes are written by all lanes
+  const uint32_t p = blockIdx.x, lane = threadIdx.x;
   if (p >= B) return;
+  __shared__ ProveLds L;
+  const KeccakLanes K = keccak_lanes();
   ProveState &st = ps[p];
   const uint32_t mn = desc[p].m * n_bits;
   const sc *a = vec + (size_t)p * (5 * mn + 2), *b = a + mn;
-  // the transcript's last three operations on the LDS-resident sponge of PASS 1 (lstrobe.h): merlin.h's byte-wise sponge,
-  // indexed at run-time positions, kept its 200 state bytes in scratch memory (224 bytes per lane, ~800 scratch accesses)
-  __shared__ uint32_t sponge[BPP_LS_WORDS * BPP_LS_STRIDE];
-  LStrobe tr;
-  tr.st = (lds_u32 *)sponge + threadIdx.x;
-#pragma unroll
-  for (uint32_t i = 0; i < 25; i++) {
-    const uint64_t w = st.tr.st[i];
-    tr.st[(2 * i) * BPP_LS_STRIDE] = (uint32_t)w;
-    tr.st[(2 * i + 1) * BPP_LS_STRIDE] = (uint32_t)(w >> 32);
-  }
-  tr.pos = st.tr.pos;
-  tr.pos_begin = st.tr.pos_begin;
+  WStrobe tr;
+  ws_load(tr, L.tr, st.tr);
   const uint8_t *pa1 = a1b32 + (size_t)p * 64;
-  bool ok = !bytes32_all_zero(pa1) && !bytes32_all_zero(pa1 + 32);  // validate_and_append_point
-  lm_append_mem(tr, lm_label("A1", 2), 2, pa1, 32);
-  lm_append_mem(tr, lm_label("B", 1), 1, pa1 + 32, 32);
-  sc e, esq, r1, s1, u;
-  ok = lm_challenge_scalar(tr, lm_label("e", 1), 1, e) && ok;
-  sc_montsq(esq, e);
-  sc_montmul(u, a[0], e);
-  sc_add(r1, st.r, u);
-  sc_montmul(u, b[0], e);
-  sc_add(s1, st.s, u);
+  bool ok = pw_validate_append(tr, K, "A1", 2, pa1);
+  ok = pw_validate_append(tr, K, "B", 1, pa1 + 32) && ok;
+  sc e;
+  ok = pw_challenge(tr, L, K, "e", 1, e) && ok;
   uint8_t *o = proofs + (size_t)p * proof_stride;
-  uint8_t tmp[32];
-  *o++ = (uint8_t)t;
-  for (uint32_t k = 0; k < t; k++) {
-    sc d1, v;
-    sc_montmul(v, st.dd[k], e);
-    sc_add(d1, st.eta[k], v);
-    sc_montmul(v, st.alpha[k], esq);
-    sc_add(d1, d1, v);
-    sc_from_mont(d1, d1);
-    sc_store_words(tmp, d1);
-    for (int i = 0; i < 32; i++) *o++ = tmp[i];
+  // wire format (src/range_proof.rs:1120-1150): [t] d1[t] A A1 B r1 s1 (L_j R_j)_j
+  if (lane < t + 2) {
+    sc x, u;
+    if (lane < t) {  // d1_k = eta_k + d_k e + alpha_k e^2
+      sc esq, v;
+      sc_montsq(esq, e);
+      sc_montmul(v, st.dd[lane], e);
+      sc_add(x, st.eta[lane], v);
+      sc_montmul(v, st.alpha[lane], esq);
+      sc_add(x, x, v);
+    } else if (lane == t) {  // r1 = r + a e
+      sc_montmul(u, a[0], e);
+      sc_add(x, st.r, u);
+    } else {  // s1 = s + b e
+      sc_montmul(u, b[0], e);
+      sc_add(x, st.s, u);
+    }
+    sc_from_mont(x, x);
+    uint8_t tmp[32];
+    sc_store_words(tmp, x);
+    uint8_t *dst = o + 1 + (lane < t ? 32 * lane : 32 * t + 96 + 32 * (lane - t));
+    for (int i = 0; i < 32; i++) dst[i] = tmp[i];
   }
-  for (int i = 0; i < 32; i++) *o++ = a32[(size_t)p * 32 + i];
-  for (int i = 0; i < 64; i++) *o++ = a1b32[(size_t)p * 64 + i];
-  sc_from_mont(r1, r1);
-  sc_store_words(tmp, r1);
-  for (int i = 0; i < 32; i++) *o++ = tmp[i];
-  sc_from_mont(s1, s1);
-  sc_store_words(tmp, s1);
-  for (int i = 0; i < 32; i++) *o++ = tmp[i];
-  for (uint32_t j = 0; j < rounds; j++)
-    for (int i = 0; i < 64; i++) *o++ = lr_all[((size_t)j * B + p) * 64 + i];
-  if (!ok) st.status |= PV_STATUS_TRANSCRIPT;
+  if (lane == 0) o[0] = (uint8_t)t;
+  for (uint32_t i = lane; i < 96; i += 64)  // A | A1 | B
+    o[1 + 32 * t + i] = i < 32 ? a32[(size_t)p * 32 + i] : a1b32[(size_t)p * 64 + (i - 32)];
+  uint8_t *olr = o + 1 + 32 * t + 96 + 64;
+  for (uint32_t i = lane; i < 64 * rounds; i += 64) olr[i] = lr_all[((size_t)(i >> 6) * B + p) * 64 + (i & 63u)];
+  if (!ok && lane == 0) st.status |= PV_STATUS_TRANSCRIPT;
 }
 
 // commitment check (:275-284): compare the engine's commit(v_j, r_j) with the statement's commitments
