@@ -117,6 +117,22 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       d.state_idx = sit->second;
     }
 
+    // RangeProofTranscript::new (src/transcripts.rs:59-89) starts every proof's transcript with the same seven appends -- the
+    // domain separator, H, the G bases, N, T, M: parameters of the call, not of the proof.  They are applied HERE, once per distinct
+    // caller transcript; kp_init continues with the proof's own commitments and promises (two Keccak-f fewer per proof on the call's
+    // first stretch, where no fixed-base MSM runs yet).
+    for (size_t id = 0; id < states.size() / 203; id++) {
+      Strobe st;
+      strobe_from_bytes(st, &states[id * 203]);
+      merlin_append_message(st, (const uint8_t *)"dom-sep", 7, (const uint8_t *)"Bulletproofs+ Range Proof", 25);
+      merlin_append_message(st, (const uint8_t *)"H", 1, &P.hg32[0], 32);
+      for (uint32_t k = 0; k < t; k++) merlin_append_message(st, (const uint8_t *)"G", 1, &P.hg32[(size_t)(k + 1) * 32], 32);
+      merlin_append_u64(st, (const uint8_t *)"N", 1, n);
+      merlin_append_u64(st, (const uint8_t *)"T", 1, t);
+      merlin_append_u64(st, (const uint8_t *)"M", 1, m);
+      strobe_to_bytes(&states[id * 203], st);
+    }
+
     hipStream_t s0 = ctx->stream;
     const uint32_t n_gen = 2 * P.n_bits * P.m_max;
     {  // fixed-base window tables for every generator of these parameters (one-off; contexts sharing P serialise here)

@@ -319,12 +319,8 @@ __global__ void __launch_bounds__(64) kp_init(const uint8_t *__restrict__ bytes,
   tr.pos_begin = sb[201];
   tr.cur_flags = sb[202];
   __syncthreads();
-  wm_append_message(tr, K, "dom-sep", 7, BytesAt{(const uint8_t *)"Bulletproofs+ Range Proof"}, 25);
-  wm_append_message(tr, K, "H", 1, BytesAt{hg32}, 32);
-  for (uint32_t k = 0; k < t; k++) wm_append_message(tr, K, "G", 1, BytesAt{hg32 + 32 * (k + 1)}, 32);
-  wm_append_u64(tr, K, "N", 1, n_bits);
-  wm_append_u64(tr, K, "T", 1, t);
-  wm_append_u64(tr, K, "M", 1, d.m);
+  // (the call-wide head of RangeProofTranscript::new -- domain separator, H, G bases, N, T, M -- is already in `states`: the host
+  // applies it once per distinct caller transcript, engine_prove.h)
   for (uint32_t j = 0; j < d.m; j++) wm_append_message(tr, K, "Ci", 2, BytesAt{bytes + d.commit_off + 32 * j}, 32);
   for (uint32_t j = 0; j < d.m; j++) wm_append_u64(tr, K, "vi - minimum_value", 18, minvals[d.minval_idx + j]);
   const uint32_t wit_len = d.m * (8 + 32 * t);
