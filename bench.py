@@ -71,7 +71,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per cpu_baseline leg")
     ap.add_argument("--wide-steps", type=int, default=40)
-    ap.add_argument("--wide-timeout", type=int, default=240, help="seconds after which the sharded leg (N > 1 / torchrun) is abandoned")
+    ap.add_argument("--wide-timeout", type=int, default=150, help="seconds after which the sharded leg (N > 1 / torchrun) is abandoned")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE, SQ_*) that fill roofline.traffic")
     ap.add_argument("--only", choices=("headline", "cfg3", "prover"), default=None,
