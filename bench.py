@@ -235,6 +235,7 @@ class Leg:
         self.bpp, self.chunk, self.slots, self.action = bpp, chunk, [], int(action)
         self.data_idx = []
         self.calls = self.ok_steps = 0
+        self._pool = None
         self.proofs_per_step = batch_proofs * batches
         nb = data["proofs"].shape[0] // batch_proofs
         self.upload_s = self.marshal_s = 0.0
@@ -295,11 +296,12 @@ class Leg:
                 except BaseException as e:  # noqa: BLE001 - re-raised on the calling thread
                     with lock:
                         errors.append(e)
-            ths = [threading.Thread(target=worker, args=(s,)) for s in range(S)]
-            for th in ths:
-                th.start()
-            for th in ths:
-                th.join()
+            # persistent worker threads (created by the warm-up's first use): no thread start-up inside a timed region
+            if getattr(self, "_pool", None) is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=len(self.slots))
+            for fut in [self._pool.submit(worker, s) for s in range(S)]:
+                fut.result()
             if errors:
                 raise errors[0]
             res = [r for part in out for r in part]
@@ -309,6 +311,9 @@ class Leg:
         return [r[0] for r in res], [r[1] for r in res]
 
     def close(self):
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         for _, eng, params, rb in self.slots:
             rb.close()
             params.close()
