@@ -355,9 +355,9 @@ def timed(leg, steps, warmup, sync, clock=None):
     sync()
     ghz = []
     th = threading.Thread(target=lambda: ghz.append(clock())) if clock else None
-    t0 = time.perf_counter()
     if th:
-        th.start()
+        th.start()  # (before t0: the sampling wavefront naps through the region either way, its thread's start-up is not timed work)
+    t0 = time.perf_counter()
     lat, profs = leg.run_steps(steps)
     sync()
     el = time.perf_counter() - t0
