@@ -406,3 +406,15 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
   }
   BPP_CATCH(ctx, errbuf, errbuf_len)
 }
+
+#ifdef BPP_KP_PHASES
+// measurement build only (tools/gpu_kp_phases.sh): the summed shader-clock cycles per phase of kp_round; reset != 0 clears them
+extern "C" int bpp_debug_kp_phases(unsigned long long out[32], int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(bpp::g_kp_phase), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(bpp::g_kp_phase), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -20,6 +20,23 @@
 
 namespace bpp {
 
+// Phase clocks of the prover's round kernel (a measurement build only: -DBPP_KP_PHASES, tools/gpu_kp_phases.sh): lane 0 of every
+// workgroup adds the shader-clock cycles of each phase of kp_round to a device-global table that bpp_debug_kp_phases() reads.
+// The product build compiles none of it.
+#ifdef BPP_KP_PHASES
+__device__ unsigned long long g_kp_phase[32];
+#define KP_T0() unsigned long long kp_t_ = __builtin_readcyclecounter()
+#define KP_MARK(id)                                                      \
+  do {                                                                   \
+    const unsigned long long kp_n_ = __builtin_readcyclecounter();       \
+    if (threadIdx.x == 0) atomicAdd(&g_kp_phase[id], kp_n_ - kp_t_);     \
+    kp_t_ = __builtin_readcyclecounter();                                \
+  } while (0)
+#else
+#define KP_T0()
+#define KP_MARK(id)
+#endif
+
 // ---------------------------------------------------------------- fixed-base tables
 // One table entry = one affine Niels point padded to a full 128-byte line: a lookup is exactly one aligned line
 // (a 160-byte projective entry straddles two), and the mixed addition costs 7 multiplications instead of 8.
@@ -412,6 +429,7 @@ __device__ __forceinline__ void kp_lane_body(const uint8_t *__restrict__ bytes, 
   const uint8_t *seed = bytes + d.seed_off;
   bool ok = true;
   WStrobe tr, rng;
+  KP_T0();
   ws_load(tr, L.tr, st.tr);
   sc e, y;
   // the round's TranscriptRng is cloned after the points are appended and BEFORE the challenge is drawn
@@ -431,9 +449,12 @@ __device__ __forceinline__ void kp_lane_body(const uint8_t *__restrict__ bytes, 
   } else {
     ok = pw_validate_append(tr, K, "L", 1, lr32 + (size_t)p * 64) && ok;
     ok = pw_validate_append(tr, K, "R", 1, lr32 + (size_t)p * 64 + 32) && ok;
+    KP_MARK(1);
     if (need_rng) pw_build_rng(rng, L, K, tr, bytes + d.wit_off, wit_len, bytes + d.ext_off + 32 * (1 + j));
+    KP_MARK(2);
     ok = pw_challenge(tr, L, K, "e", 1, e) && ok;
     y = st.y;
+    KP_MARK(3);
   }
   // ONE inversion per round, the same input in every lane: e (rounds >= 1), y in step 0.  y^-(n / 2^(j+1)) is a power of y^-1
   // (kept from step 0) -- until round 4 it was the inverse of y^(n / 2^(j+1)), taken on the odd lanes beside e's on the even
@@ -446,6 +467,7 @@ __device__ __forceinline__ void kp_lane_body(const uint8_t *__restrict__ bytes, 
     for (int q = 0; q < 8; q++) x.v[q] = j == 0 ? y.v[q] : e.v[q];
     sc_mont_invert_vartime(inv, x);
   }
+  KP_MARK(4);
   if (j == 0) {
     yinv1 = inv;
     if (lane == 0) st.yinv1 = inv;
@@ -476,6 +498,7 @@ __device__ __forceinline__ void kp_lane_body(const uint8_t *__restrict__ bytes, 
     }
     __syncthreads();  // dl / dr are overwritten below
   }
+  KP_MARK(5);
   if (j < rounds) {
     pw_nonces_or_randoms(st.dl, t, rng, L, K, seed, has_seed, "dL", 2, (int)j);
     pw_nonces_or_randoms(st.dr, t, rng, L, K, seed, has_seed, "dR", 2, (int)j);
@@ -493,8 +516,10 @@ __device__ __forceinline__ void kp_lane_body(const uint8_t *__restrict__ bytes, 
     pw_nonces_or_randoms(st.dd, t, rng, L, K, seed, has_seed, "d", 1, -1);
     pw_nonces_or_randoms(st.eta, t, rng, L, K, seed, has_seed, "eta", 3, -1);
   }
+  KP_MARK(6);
   ws_store(st.tr, tr);
   if (!ok && lane == 0) st.status |= PV_STATUS_TRANSCRIPT;
+  KP_MARK(7);
 }
 
 // ---- wave kernel, step j = 0..r (one wavefront per proof): vector prep / fold / inner products / MSM term lists ----
@@ -514,6 +539,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
   sc one;
   sc_mont_one(one);
   __shared__ sc red[64];
+  KP_T0();
 
   if (j == 0) {
     // y powers (:353-359) by lane-strided exponentiation, d (:362-373), a_L - z, a_R + d*y^(mn-i) + z (:376-381)
@@ -569,6 +595,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       }
       st.alpha[lane] = acc;
     }
+    KP_MARK(13);
   } else {
     // fold with e_{j-1} (:511-533): len = mn >> (j-1)
     const uint32_t len = mn >> (j - 1), nh = len >> 1;
@@ -596,6 +623,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
         b[i] = nb;
       }
     }
+    KP_MARK(8);
     for (uint32_t u = lane; u < mn; u += 64) {
       const bool lo = (u & (len - 1)) < nh;
       sc g = cG[u], h = cH[u], fg, fh;
@@ -611,6 +639,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       cG[u] = g;
       cH[u] = h;
     }
+    KP_MARK(9);
   }
   __syncthreads();
 
@@ -653,6 +682,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       else cl = red[0];
       __syncthreads();
     }
+    KP_MARK(10);
     // term lists.  L (:482-488): c_L H, d_L G_k, (a_lo y^-n) on Gf_hi, b_hi on Hf_lo.  R (:489-495) symmetric.
     // output 0 = L, output 1 = R; every original G_u / H_u goes to exactly one of them.
     for (uint32_t u = lane; u < mn; u += 64) {
@@ -700,6 +730,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       term_count[2 * p] = mn + t + 1;
       term_count[2 * p + 1] = mn + t + 1;
     }
+    KP_MARK(11);
   } else {
     // final step (:574-584): A1 = r Gf[0] + s Hf[0] + (r y b + s y a) H + sum d_k G_k ;  B = (r y s) H + sum eta_k G_k
     const sc r = st.r, s = st.s, y = st.y;
@@ -740,6 +771,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       term_count[2 * p] = 2 * mn + t + 1;
       term_count[2 * p + 1] = t + 1;
     }
+    KP_MARK(12);
   }
 }
 
@@ -770,6 +802,7 @@ __global__ void __launch_bounds__(64) kp_round(const uint8_t *__restrict__ bytes
                                                uint32_t *__restrict__ term_gidx, uint32_t *__restrict__ term_count) {
   const uint32_t p = blockIdx.x;
   if (p >= B) return;
+  KP_T0();
   if (ge_prev && threadIdx.x < 2) {
     uint8_t c32[32];
     ristretto_compress(c32, ge_prev[2 * (size_t)p + threadIdx.x]);
@@ -779,6 +812,7 @@ __global__ void __launch_bounds__(64) kp_round(const uint8_t *__restrict__ bytes
       o[k] = (uint32_t)c32[4 * k] | ((uint32_t)c32[4 * k + 1] << 8) | ((uint32_t)c32[4 * k + 2] << 16) | ((uint32_t)c32[4 * k + 3] << 24);
   }
   __syncthreads();
+  KP_MARK(0);
   kp_lane_body(bytes, desc, n_bits, t, B, j, rounds, a32, lr_prev, ps);
   __syncthreads();
   kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count);

@@ -438,6 +438,63 @@ int oracle_verify_timed_mt(const oracle_params *P, const oracle_item *items, siz
   free(th); free(jobs); return rc;
 }
 
+/* bench.py's per-config cpu_baseline legs: `threads` host threads, thread k runs the chunk-sized slice k (mod the number of
+   slices) `iters` times under `action` (0 VerifyOnly, 1 RecoverAndVerify, 2 RecoverOnly: src/range_proof.rs:941-969); wall time.
+   Masks go to a per-thread scratch buffer and are dropped. */
+typedef struct { const oracle_params *P; const oracle_item *items; size_t n; int iters, action, rc; } act_job;
+static void *act_worker(void *arg) { act_job *j = (act_job *)arg; j->rc = 0;
+  uint8_t *masks = (uint8_t *)malloc(32 * (size_t)j->P->t * j->n + 1), *present = (uint8_t *)malloc(j->n + 1);
+  for (int it = 0; it < j->iters && !j->rc; it++) j->rc = oracle_verify(j->P, j->items, j->n, j->action, masks, present, NULL);
+  free(masks); free(present); return NULL; }
+int oracle_verify_action_timed_mt(const oracle_params *P, const oracle_item *items, size_t n_items, size_t chunk, int action, int iters,
+                                  int threads, double *seconds) {
+  if (threads < 1 || threads > 1024 || action < 0 || action > 2) return -1;
+  if (chunk == 0 || chunk > n_items) chunk = n_items;
+  const size_t slices = n_items / chunk; if (slices == 0) return -1;
+  curve_init();
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads); act_job *jobs = (act_job *)malloc(sizeof(act_job) * threads);
+  struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int k = 0; k < threads; k++) { jobs[k] = (act_job){P, items + (k % slices) * chunk, chunk, iters, action, 0}; pthread_create(&th[k], NULL, act_worker, &jobs[k]); }
+  int rc = 0; for (int k = 0; k < threads; k++) { pthread_join(th[k], NULL); if (jobs[k].rc) rc = jobs[k].rc; }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  free(th); free(jobs); return rc;
+}
+
+/* the prover timed the same way (benches/range_proof.rs:43-107): `n_items` witnesses as contiguous arrays (values n x m,
+   blindings n x m x t x 32, minimum values / presence n x m, seed nonces n x 32 or NULL, external randomness n x ext_len), thread k
+   proves items k, k + threads, ... `iters` times each; wall time.  proofs_out (n x proof_stride, may be NULL) receives the last
+   pass's bytes so that the caller can hold them against the engine's. */
+typedef struct { const oracle_params *P; const uint8_t *label; size_t label_len; uint32_t m; const uint64_t *values; const uint8_t *blind;
+                 const uint64_t *minv; const uint8_t *minp; const uint8_t *seeds; const uint8_t *ext; size_t ext_len, n, first, step;
+                 int iters, rc; uint8_t *out; size_t stride; } prove_job;
+static void *prove_worker(void *arg) { prove_job *j = (prove_job *)arg; j->rc = 0; const uint32_t m = j->m, t = j->P->t;
+  uint8_t buf[4096]; size_t len = 0;
+  for (int it = 0; it < j->iters && !j->rc; it++) for (size_t i = j->first; i < j->n && !j->rc; i += j->step) {
+    j->rc = oracle_prove(j->P, j->label, j->label_len, m, j->values + i * m, j->blind + i * (size_t)m * t * 32, j->minv + i * m,
+                         j->minp ? j->minp + i * m : NULL, j->seeds ? j->seeds + 32 * i : NULL, j->ext + i * j->ext_len, j->ext_len, buf, &len, NULL);
+    if (!j->rc && j->out && len <= j->stride) memcpy(j->out + i * j->stride, buf, len);
+  }
+  return NULL; }
+int oracle_prove_timed_mt(const oracle_params *P, const uint8_t *label, size_t label_len, uint32_t m, const uint64_t *values,
+                          const uint8_t *blindings32, const uint64_t *min_values, const uint8_t *min_present, const uint8_t *seed_nonces32,
+                          const uint8_t *ext_rng, size_t ext_len, size_t n_items, int iters, int threads, uint8_t *proofs_out,
+                          size_t proof_stride, double *seconds) {
+  if (threads < 1 || threads > 1024 || n_items == 0) return -1;
+  curve_init();
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads); prove_job *jobs = (prove_job *)malloc(sizeof(prove_job) * threads);
+  struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int k = 0; k < threads; k++) {
+    jobs[k] = (prove_job){P, label, label_len, m, values, blindings32, min_values, min_present, seed_nonces32, ext_rng, ext_len, n_items,
+                          (size_t)k, (size_t)threads, iters, 0, proofs_out, proof_stride};
+    pthread_create(&th[k], NULL, prove_worker, &jobs[k]);
+  }
+  int rc = 0; for (int k = 0; k < threads; k++) { pthread_join(th[k], NULL); if (jobs[k].rc) rc = jobs[k].rc; }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  free(th); free(jobs); return rc;
+}
+
 /* ------------------------------------------------------------------ primitive probes for KAT tests */
 void oracle_from_uniform(const uint8_t in[64], uint8_t out[32]) { curve_init(); ge_p3 p; ristretto_from_uniform(&p, in); ristretto_compress(out, &p); }
 int oracle_decompress_compress(const uint8_t in[32], uint8_t out[32]) { curve_init(); ge_p3 p; if (!ristretto_decompress(&p, in)) return 0; ristretto_compress(out, &p); return 1; }

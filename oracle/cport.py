@@ -46,6 +46,9 @@ def lib():
         L.oracle_verify.argtypes = [c_void_p, POINTER(Item), c_size_t, c_int, c_void_p, c_void_p, POINTER(Trace)]
         L.oracle_verify_timed.argtypes = [c_void_p, POINTER(Item), c_size_t, c_size_t, c_int, POINTER(c_double)]
         L.oracle_verify_timed_mt.argtypes = [c_void_p, POINTER(Item), c_size_t, c_size_t, c_int, c_int, POINTER(c_double)]
+        L.oracle_verify_action_timed_mt.argtypes = [c_void_p, POINTER(Item), c_size_t, c_size_t, c_int, c_int, c_int, POINTER(c_double)]
+        L.oracle_prove_timed_mt.argtypes = [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_size_t, c_size_t, c_int, c_int, c_void_p, c_size_t, POINTER(c_double)]
         L.oracle_keccak_count.restype = c_uint64
         L.oracle_nonce.argtypes = [c_void_p, c_char_p, c_int, c_int, c_void_p]
         L.oracle_msm.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
@@ -154,6 +157,30 @@ class Params:
         sec = c_double()
         rc = lib().oracle_verify_timed_mt(self.h, arr, len(batch), chunk, iters, threads, byref(sec))
         return rc, sec.value
+
+    def verify_action_timed_mt(self, batch, chunk, action, iters, threads):
+        """as verify_timed_mt under any VerifyAction (masks computed and dropped) -> (rc, wall s)"""
+        arr, keep = self.items(batch)
+        sec = c_double()
+        rc = lib().oracle_verify_action_timed_mt(self.h, arr, len(batch), chunk, action, iters, threads, byref(sec))
+        return rc, sec.value
+
+    def prove_timed_mt(self, label, values, blindings, min_values, min_present, seeds, ext, iters, threads, proof_len=0):
+        """numpy arrays in bench.make_inputs' layout (values n x m u64, blindings n x m x t x 32 u8, min_values n x m u64, min_present
+        n x m u8, seeds n x 32 u8 or None, ext n x ext_len u8): thread k proves items k, k + threads, ... `iters` times
+        -> (rc, wall s, proofs n x proof_len u8 array or None)"""
+        import numpy as np
+        n, m = values.shape
+        values, blindings = np.ascontiguousarray(values, dtype=np.uint64), np.ascontiguousarray(blindings, dtype=np.uint8)
+        min_values, min_present = np.ascontiguousarray(min_values, dtype=np.uint64), np.ascontiguousarray(min_present, dtype=np.uint8)
+        ext = np.ascontiguousarray(ext, dtype=np.uint8)
+        seeds = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint8)
+        out = np.zeros((n, proof_len), dtype=np.uint8) if proof_len else None
+        sec = c_double()
+        ptr = lambda a: None if a is None else a.ctypes.data_as(c_void_p)
+        rc = lib().oracle_prove_timed_mt(self.h, _b(label), len(label), m, ptr(values), ptr(blindings), ptr(min_values), ptr(min_present),
+                                         ptr(seeds), ptr(ext), ext.shape[1], n, iters, threads, ptr(out), proof_len, byref(sec))
+        return rc, sec.value, out
 
     def close(self):
         if self.h:
