@@ -69,7 +69,9 @@ def parse_args():
                          "to reach the clock it then sustains (tools/clock_ramp.py), a 20-step timed region lasts 55 ms")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (cfg3, 4096-wide, latency, prover)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU work per part (one thread / all cores) of the headline's cpu_baseline")
+    ap.add_argument("--cpu-leg-seconds", type=float, default=1.5,
+                    help="CPU work per part of every other leg's cpu_baseline (configs[0], [2], [4], the 4096-proof batch, RecoverOnly)")
     ap.add_argument("--wide-steps", type=int, default=40)
     ap.add_argument("--wide-timeout", type=int, default=150, help="seconds after which the sharded leg (N > 1 / torchrun) is abandoned")
     ap.add_argument("--no-traffic", action="store_true",
@@ -225,6 +227,91 @@ def measure_sq(kernels, only="headline"):
         return out
     except (Exception, SystemExit):  # noqa: BLE001
         return {}
+
+
+def _cport():
+    """oracle/c, the CPU port of the reference's algorithms: imported by the cpu_baseline objects ONLY -- there it is the thing
+    timed (kind "port"), never part of a product path"""
+    from oracle import cport
+    return cport
+
+
+def cpu_items(data, idx, with_seeds=False):
+    """the oracle's view of proofs `idx` of a make_inputs() set"""
+    m = data["commitments"].shape[1]
+    return [{"proof": data["proofs"][i].tobytes(), "commitments": [data["commitments"][i, j].tobytes() for j in range(m)],
+             "min_values": [int(v) for v in data["min_values"][i]], "label": LABEL,
+             "seed_nonce": data["seeds"][i].tobytes() if with_seeds and data.get("seeds") is not None else None} for i in idx]
+
+
+def cpu_verify_baseline(shape, data, chunk, action=0, seconds=1.5, all_cores=True):
+    """cpu_baseline object of one leg: RangeProof::verify over reference batches of `chunk` proofs of THIS leg's inputs through the
+    oracle/c port -- one host thread (the reference is single-threaded), then one batch per schedulable core side by side; each
+    part is bounded by `seconds` of wall time (at least one pass)."""
+    cport = _cport()
+    ncpu = usable_cpus()
+    slices = max(1, min(ncpu if all_cores else 1, 4, data["proofs"].shape[0] // chunk))
+    items = cpu_items(data, range(chunk * slices), with_seeds=action != 0)
+    cp = cport.Params(*shape)
+    try:
+        rc, s1 = cp.verify_action_timed_mt(items[:chunk], chunk, action, 1, 1)
+        iters = int(seconds / max(s1, 1e-4))
+        if iters > 1:
+            rc, s1 = cp.verify_action_timed_mt(items[:chunk], chunk, action, iters, 1)
+        iters = max(1, iters)
+        if rc != 0:
+            raise RuntimeError("the CPU port rejected the leg's batch (rc %d)" % rc)
+        verb = ("verify", "recover-and-verify", "recover-only")[action]
+        out = {"value": chunk * iters / s1, "unit": "proofs/s", "cores": 1, "kind": "port", "ms_per_batch": 1e3 * s1 / iters,
+               "sample": "%d x %s of one %d-proof reference batch of this leg's inputs, one thread, oracle/c (dalek's algorithms)"
+                         % (iters, verb, chunk), "nproc": os.cpu_count(), "usable_cpus": ncpu}
+        if all_cores and ncpu > 1:
+            rc, sm = cp.verify_action_timed_mt(items, chunk, action, 1, ncpu)
+            it_mt = int(seconds / max(sm, 1e-4))
+            if it_mt > 1:
+                rc, sm = cp.verify_action_timed_mt(items, chunk, action, it_mt, ncpu)
+            it_mt = max(1, it_mt)
+            if rc != 0:
+                raise RuntimeError("the CPU port rejected the leg's batch on %d threads (rc %d)" % (ncpu, rc))
+            out["all_cores"] = {"value": chunk * it_mt * ncpu / sm, "unit": "proofs/s", "cores": ncpu,
+                                "sample": "%d threads, each %d x %s of a %d-proof reference batch" % (ncpu, it_mt, verb, chunk)}
+        return out
+    finally:
+        cp.close()
+
+
+def cpu_prove_baseline(shape, data, seconds=1.5):
+    """cpu_baseline object of the prover leg: RangeProof::prove_with_rng (src/range_proof.rs:232-608, generator folding as the
+    reference does it) over this leg's witnesses through the oracle/c port, one thread and one thread per schedulable core; the
+    port's proof bytes are held against the engine's on the proofs both made."""
+    import numpy as np
+    cport = _cport()
+    ncpu = usable_cpus()
+    plen = data["proofs"].shape[1]
+    cp = cport.Params(*shape)
+    try:
+        def run(k, threads):
+            sl = slice(0, k)
+            rc, sec, got = cp.prove_timed_mt(LABEL, data["values"][sl], data["blindings"][sl], data["min_values"][sl], data["min_present"][sl],
+                                             None if data.get("seeds") is None else data["seeds"][sl], data["ext"][sl], 1, threads, proof_len=plen)
+            if rc != 0:
+                raise RuntimeError("the CPU port's prover failed (rc %d)" % rc)
+            return sec, bool((got == data["proofs"][sl]).all())
+        s1, eq1 = run(2, 1)
+        k1 = max(2, min(data["proofs"].shape[0], int(seconds / (s1 / 2))))
+        if k1 > 2:
+            s1, eq1 = run(k1, 1)
+        out = {"value": k1 / s1, "unit": "proofs/s", "cores": 1, "kind": "port", "ms_per_proof": 1e3 * s1 / k1,
+               "sample": "%d proofs of this leg's witnesses, one thread, oracle/c (prove_with_rng with generator folding, as the reference)" % k1,
+               "bytes_equal_engine": eq1, "nproc": os.cpu_count(), "usable_cpus": ncpu}
+        if ncpu > 1:
+            km = max(ncpu, min(data["proofs"].shape[0], int(seconds / (s1 / k1)) * ncpu))
+            sm, eqm = run(km, ncpu)
+            out["all_cores"] = {"value": km / sm, "unit": "proofs/s", "cores": ncpu, "bytes_equal_engine": eqm,
+                                "sample": "%d proofs shared out over %d threads" % (km, ncpu)}
+        return out
+    finally:
+        cp.close()
 
 
 class Leg:
@@ -653,6 +740,17 @@ def main():
     eng0.profile(True)
     t_setup = time.perf_counter()
 
+    def cpu_side(obj, fn):
+        """north_star: "the reference's own CPU path timed on the GPU box's host cores ... in the same run" -- every leg's object
+        gets a cpu_baseline from the same inputs (a failure is reported inside it, the leg's own numbers stand)"""
+        if args.no_cpu_baseline or args.only:
+            return obj
+        try:
+            obj["cpu_baseline"] = fn()
+        except Exception as e:  # noqa: BLE001
+            obj["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        return obj
+
     # ------------------------------------------------------------------ legs other than the headline, as functions
     def cfg3_leg(steps=48, warmup=8, only=False):
         p3 = bpp.RangeParameters.init(64, 8, G(1), engine=eng0)
@@ -666,10 +764,12 @@ def main():
         roof3, st3 = kernel_roofline(pr3, sum(al3) / 3 if min(al3) > 0 else None)
         leg3.close()
         p3.close()
-        return {"workload": "BASELINE configs[2]: reference batches of 256 x aggregation-8 64-bit proofs, extension degree 1; "
-                            "one step = %d such batches, %d steps in flight" % (R3, S3),
-                "proofs_per_s": 256 * R3 * steps / el3, "ms_per_step": 1e3 * el3 / steps, "steps": steps, "roofline": roof3,
-                "stages_ms": st3}
+        res = {"workload": "BASELINE configs[2]: reference batches of 256 x aggregation-8 64-bit proofs, extension degree 1; "
+                           "one step = %d such batches, %d steps in flight" % (R3, S3),
+               "proofs_per_s": 256 * R3 * steps / el3, "ms_per_step": 1e3 * el3 / steps, "steps": steps, "roofline": roof3,
+               "stages_ms": st3}
+        # benches/range_proof.rs:206-262 on the host: the same 256 x aggregation-8 batches through the CPU port
+        return cpu_side(res, lambda: cpu_verify_baseline((64, 8, 1), d3, 256, seconds=args.cpu_leg_seconds))
 
     def recover_only_leg(data, params, steps=32, warmup=6):
         """SURVEY 8(f)2 / src/range_proof.rs:941-969,1040-1043: a wallet scanning outputs.  RecoverOnly over the headline's 65 536
@@ -685,7 +785,7 @@ def main():
         n_pts = 1024 * Rr * 15
         dec_ms, msk_ms, tr_ms = avg["decompress_ms"], avg["masks_ms"], avg["transcripts_ms"]
         legr.close()
-        return {"workload": "VerifyAction::RecoverOnly over %d resident 64-bit proofs with seed nonces, as %d reference batches of 1024 per step, "
+        return cpu_side({"workload": "VerifyAction::RecoverOnly over %d resident 64-bit proofs with seed nonces, as %d reference batches of 1024 per step, "
                             "%d steps in flight: PASS 1 + decompression + mask recovery (src/range_proof.rs:941-969), no weight chain, no MSM "
                             "(:1040-1043); masks returned as arrays" % (1024 * Rr, Rr, Sr),
                 "proofs_per_s": 1024 * Rr * steps / elr, "ms_per_step": 1e3 * elr / steps, "steps": steps, "masks_equal_blindings": ok,
@@ -696,7 +796,8 @@ def main():
                              "note": "integer-VALU bound (254 squarings + 25 multiplications per point): see valu",
                              "valu": {"achieved_Tmad_per_s": n_pts * (254 * 55 + 25 * 100) / (dec_ms * 1e-3) / 1e12,
                                       "peak_Tmad_per_s": VALU_PEAK_TMAD,
-                                      "frac": n_pts * (254 * 55 + 25 * 100) / (dec_ms * 1e-3) / (VALU_PEAK_TMAD * 1e12)}}}
+                                      "frac": n_pts * (254 * 55 + 25 * 100) / (dec_ms * 1e-3) / (VALU_PEAK_TMAD * 1e12)}}},
+                        lambda: cpu_verify_baseline((64, 1, 1), data, 256, action=2, seconds=args.cpu_leg_seconds))
 
     def prover_leg(iters5=8):
         p5 = bpp.RangeParameters.init(64, 4, G(3), engine=eng0)
@@ -741,7 +842,7 @@ def main():
             for e in engs:
                 e.close()
         p5.close()
-        return {"workload": "BASELINE configs[4]: bpp_prove_batch over 1024 x aggregation-4 64-bit proofs, extension "
+        return cpu_side({"workload": "BASELINE configs[4]: bpp_prove_batch over 1024 x aggregation-4 64-bit proofs, extension "
                             "degree 3; host witness buffers in, proof bytes out (PCIe-inclusive)",
                 "proofs_per_s": 1024 * iters5 / el5, "ms_per_call": 1e3 * el5 / iters5, "calls": iters5, "four_calls_in_flight": conc,
                 "roofline": {"bound": "hbm", "kernel": "k_fb_msm (fixed-base MSM of every L/R/A1/B and the witness check)",
@@ -755,7 +856,9 @@ def main():
                              "note": "achieved / algorithmic_bytes / kernel_ms are sums over the %d launches of ONE call (both "
                                      "sub-batch streams); 64 B per term.  The launches of the two sub-batch streams OVERLAP, so the "
                                      "summed event time exceeds the wall time they cover: additions_per_s_call_wall divides by the "
-                                     "whole call instead (start-up, Fiat-Shamir steps and the final step included)" % pp["fb_launches"]}}
+                                     "whole call instead (start-up, Fiat-Shamir steps and the final step included)" % pp["fb_launches"]}},
+                        # benches/range_proof.rs:43-107 on the host: the same witnesses through the CPU port's prover
+                        lambda: cpu_prove_baseline((64, 4, 3), d5, seconds=args.cpu_leg_seconds))
 
     if args.only in ("cfg3", "prover"):  # a rocprofv3 child pass of measure_traffic(): just the kernels, a short line
         res = cfg3_leg(args.steps, args.warmup, only=True) if args.only == "cfg3" else prover_leg(2)
@@ -914,7 +1017,7 @@ def main():
                                  "proofs_per_s": 4096 * nw / elw, "ms_per_batch_in_flight": 1e3 * sum(latw) / len(latw),
                                  "ms_per_batch_alone": 1e3 * sum(a[0] for a in alw) / 5, "steps": nw, "roofline": roofw, "stages_ms": stw}
             legw.close()
-            return res
+            return cpu_side(res, lambda: cpu_verify_baseline((64, 1, 1), data2, 4096, seconds=args.cpu_leg_seconds))
         side_leg("wide4096", wide4096_leg)
         # -------------------------------------------------------------- single-call latency (configs[0]'s shape)
         def latency_leg():
@@ -933,6 +1036,15 @@ def main():
                                             "ms_per_call_median_with_stage_events": 1e3 * lsp[len(lsp) // 2],
                                             "proofs_per_s": nb / ls[len(ls) // 2], "roofline": rl, "stages_ms": sl}
                 legl.close()
+                # configs[0] is the reference's own single-call CPU path (benches/range_proof.rs:115-119,199-203): the same call
+                # through the CPU port on one core, beside the engine's
+                cpu_side(lat_out["batch_%d" % nb], lambda: cpu_verify_baseline((64, 1, 1), data2, nb, seconds=args.cpu_leg_seconds / 2,
+                                                                              all_cores=False))
+            cb = {k: {"ms_per_call": v["cpu_baseline"]["ms_per_batch"], "proofs_per_s": v["cpu_baseline"]["value"]}
+                  for k, v in lat_out.items() if "value" in v.get("cpu_baseline", {})}
+            if cb:
+                lat_out["cpu_baseline"] = dict(cb, cores=1, kind="port", unit="ms per call / proofs/s",
+                                               sample="one verify call of 1, 64 and 256 proofs at a time through oracle/c, one thread")
             return dict(lat_out, workload="BASELINE configs[0]'s shape through the engine: ONE call at a time, 1, 64 and 256 "
                                                       "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input; calls of up to ~1200 proofs "
                                                       "run the final MSM as a half-scalar plan (s = s_lo + 2^126 s_hi: half the Horner doublings)")

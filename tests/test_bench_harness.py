@@ -63,3 +63,58 @@ def test_forced_failing_step_makes_bench_exit_nonzero():
     assert ok.returncode == 0, ok.stderr[-800:]
     line = json.loads(ok.stdout.strip().splitlines()[-1])
     assert line["steps_completed"] == 16 and line["all_steps_verified"] is True and line["value"] > 0
+
+
+def _oracle_inputs(np, n_bits, m, t, count, seed_nonces):
+    """a make_inputs()-shaped data set made by the oracle's prover (CPU): what the engine's prover hands the legs on the box"""
+    from oracle import cport
+    rng = np.random.default_rng(11)
+    rounds = (n_bits * m).bit_length() - 1
+    plen = 1 + 32 * (t + 5 + 2 * rounds)
+    values = rng.integers(0, 1 << 63, size=(count, m), dtype=np.uint64)
+    one = rng.integers(0, 256, size=(count, m, 32), dtype=np.uint8)
+    one[..., 31] &= 0x0f
+    one[..., 0] |= 1
+    blindings = np.ascontiguousarray(np.repeat(one[:, :, None, :], t, axis=2))
+    seeds = None
+    if seed_nonces:
+        seeds = rng.integers(0, 256, size=(count, 32), dtype=np.uint8)
+        seeds[:, 31] &= 0x0f
+    ext = rng.integers(0, 256, size=(count, 32 * (rounds + 3)), dtype=np.uint8)
+    min_values, min_present = values // np.uint64(3), np.ones((count, m), dtype=np.uint8)
+    cp = cport.Params(n_bits, m, t)
+    rc, _, proofs = cp.prove_timed_mt(b"BatchedRangeProofTest", values, blindings, min_values, min_present, seeds, ext, 1, 2, proof_len=plen)
+    assert rc == 0
+    commitments = np.zeros((count, m, 32), dtype=np.uint8)
+    for i in range(count):
+        for j in range(m):
+            commitments[i, j] = np.frombuffer(cp.commit(int(values[i, j]), [bytes(blindings[i, j, k]) for k in range(t)]), dtype=np.uint8)
+    cp.close()
+    return {"proofs": proofs, "commitments": commitments, "min_values": min_values, "min_present": min_present, "values": values,
+            "blindings": blindings, "seeds": seeds, "ext": ext}
+
+
+def test_cpu_baseline_objects_of_every_leg():
+    """CPU: the cpu_baseline objects bench.py attaches to every leg (configs[0], [2], [4], the wide batch, RecoverOnly) -- shape of
+    the object (value, unit, cores, kind "port", sample), the all-cores part, and the prover part's byte comparison, on inputs made
+    by the oracle in make_inputs()' layout.  A tampered proof must fail the leg's object loudly, not produce a number."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    d = _oracle_inputs(np, 64, 1, 1, 8, seed_nonces=True)
+    for action in (0, 2):
+        o = bench.cpu_verify_baseline((64, 1, 1), d, 4, action=action, seconds=0.05)
+        assert o["kind"] == "port" and o["cores"] == 1 and o["unit"] == "proofs/s" and o["value"] > 0 and "sample" in o
+        assert o["all_cores"]["cores"] == bench.usable_cpus() and o["all_cores"]["value"] > 0
+    one = bench.cpu_verify_baseline((64, 1, 1), d, 1, seconds=0.02, all_cores=False)
+    assert "all_cores" not in one and one["ms_per_batch"] > 0
+    bad = dict(d, proofs=d["proofs"].copy())
+    bad["proofs"][0, 40] ^= 1
+    with pytest.raises(RuntimeError, match="rejected"):
+        bench.cpu_verify_baseline((64, 1, 1), bad, 4, seconds=0.02)
+    d4 = _oracle_inputs(np, 64, 2, 2, 4, seed_nonces=False)
+    o = bench.cpu_prove_baseline((64, 2, 2), d4, seconds=0.05)
+    assert o["kind"] == "port" and o["cores"] == 1 and o["value"] > 0 and o["bytes_equal_engine"] is True
+    assert o["all_cores"]["bytes_equal_engine"] is True
+    d4["proofs"][1, 100] ^= 1  # "the engine's" bytes differ: reported, not hidden
+    assert bench.cpu_prove_baseline((64, 2, 2), d4, seconds=0.05)["bytes_equal_engine"] is False
