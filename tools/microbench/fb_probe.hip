@@ -182,6 +182,196 @@ __global__ void __launch_bounds__(64) k_fb_sum(const ge *__restrict__ partial, u
   if (lane == 0) out[o] = red[0];
 }
 
+// ---- E: 64-byte table entries.  An entry is the affine point (x, y) as 2 x 8 packed words -- one 64-byte request per lookup
+// instead of a 128-byte line (random 64-byte reads out of <= 2 GB come 1.6x as often: rand_lines.hip) -- and the addition
+// recomputes what the 128-byte entry carried: y+x, y-x by limb additions, 2dxy as two more products (9 instead of 7).
+struct fbxy {
+  uint32_t x[8], y[8];
+};
+static_assert(sizeof(fbxy) == 64, "64-byte entry");
+__global__ void k_fill_xy(fbxy *t, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t a = (uint32_t)i * 2654435761u, b = (uint32_t)(i >> 7) * 40503u;
+  fbxy e;
+  for (int k = 0; k < 8; k++) {
+    e.x[k] = a + k * 40503u + b;
+    e.y[k] = a * 3u + k * 2654435761u;
+  }
+  e.x[7] &= 0x7fffffffu;
+  e.y[7] &= 0x7fffffffu;
+  t[i] = e;
+}
+struct xyw {
+  uint4 q[4];
+};
+BPP_D void fb_fetch_xy(xyw &e, int &d, const FbStage &st, const fbxy *__restrict__ tbl, const FbGeom &geo, uint32_t it) {
+  const uint32_t i = it / geo.items, w = it - i * geo.items;
+  d = st.dig[it];
+  const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+  const uint4 *p = (const uint4 *)&tbl[((size_t)st.gi[i] * geo.windows + w) * geo.entries + (mag ? mag - 1u : 0u)];
+  e.q[0] = p[0];
+  e.q[1] = p[1];
+  e.q[2] = p[2];
+  e.q[3] = p[3];
+}
+BPP_D void ge_madd_xy(ge &r, const ge &p, const xyw &e, bool neg) {
+  const uint32_t wx[8] = {e.q[0].x, e.q[0].y, e.q[0].z, e.q[0].w, e.q[1].x, e.q[1].y, e.q[1].z, e.q[1].w};
+  const uint32_t wy[8] = {e.q[2].x, e.q[2].y, e.q[2].z, e.q[2].w, e.q[3].x, e.q[3].y, e.q[3].z, e.q[3].w};
+  fe x, y, yp, ym, t, a, b, c, ee, f, g, h, u, v, d2;
+  fe_fromwords(x, wx);
+  fe_fromwords(y, wy);
+  fe_add(u, y, x);
+  fe_sub_lazy(v, y, x);
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    yp.v[i] = neg ? v.v[i] : u.v[i];
+    ym.v[i] = neg ? u.v[i] : v.v[i];
+  }
+  fe_mul(t, x, y);
+  fe_const(d2, FE_D2);
+  fe_mul(t, t, d2);
+  fe_add(a, p.Y, p.X);
+  fe_mul(a, a, yp);
+  fe_sub_lazy(b, p.Y, p.X);
+  fe_mul(b, b, ym);
+  fe_mul(c, t, p.T);
+  fe_sub_lazy(ee, a, b);
+  fe_add(h, a, b);
+  fe_dbl_add(u, p.Z, c);
+  fe_dbl_sub_lazy(v, p.Z, c);
+  fe_mul(r.Z, v, u);
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    f.v[i] = neg ? u.v[i] : v.v[i];
+    g.v[i] = neg ? v.v[i] : u.v[i];
+  }
+  fe_mul(r.X, f, ee);
+  fe_mul(r.Y, g, h);
+  fe_mul(r.T, ee, h);
+}
+template <bool TREE>
+__global__ void __launch_bounds__(FB_THREADS) k_fb_msm_xy(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx,
+                                                          const uint32_t *__restrict__ count, uint32_t stride, const fbxy *__restrict__ tbl,
+                                                          FbGeom geo, ge *__restrict__ out) {
+  const uint32_t o = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t n = count[o];
+  __shared__ FbShared sh;
+  ge acc;
+  ge_identity(acc);
+  for (uint32_t base = 0; base < n; base += FB_CHUNK) {
+    const uint32_t cn = n - base < FB_CHUNK ? n - base : FB_CHUNK;
+    __syncthreads();
+    for (uint32_t i = tid; i < cn; i += nthr) {
+      const sc s = scal[(size_t)o * stride + base + i];
+      fb_recode(sh.st.dig + (size_t)i * geo.items, s, geo);
+      sh.st.gi[i] = gidx[(size_t)o * stride + base + i];
+    }
+    __syncthreads();
+    const uint32_t items = cn * geo.items;
+    uint32_t it = tid;
+    xyw nxt;
+    int nd = 0;
+    if (it < items) fb_fetch_xy(nxt, nd, sh.st, tbl, geo, it);
+    while (it < items) {
+      xyw cur = nxt;
+      const int cd = nd;
+      it += nthr;
+      if (it < items) fb_fetch_xy(nxt, nd, sh.st, tbl, geo, it);
+      if (cd != 0) ge_madd_xy(acc, acc, cur, cd < 0);
+    }
+  }
+  if (!TREE) {
+    if (acc.X.v[0] == 0x7fffffffu) out[o] = acc;
+    return;
+  }
+  __syncthreads();
+  sh.red[tid] = acc;
+  __syncthreads();
+  for (uint32_t off = nthr / 2; off >= 1; off >>= 1) {
+    if (tid < off) {
+      ge x = sh.red[tid], y2 = sh.red[tid + off];
+      ge_add(x, x, y2);
+      sh.red[tid] = x;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) out[o] = sh.red[0];
+}
+
+// ---- G: ONE wavefront per output.  The shipped kernel's workgroup is four wavefronts that meet at barriers (staging, an
+// 8-level tree of which the last 6 levels run on one wavefront while three wait) and holds 40 KB of LDS whatever its size, which
+// is what bounds it to four workgroups per CU.  Here an output is 64 lanes: 4x the additions per lane, a 6-level tree inside the
+// wavefront, staging in chunks of GCH terms (LDS per workgroup: GCH x (2 x items + 4) + 64 x 160 bytes).  PF: table lines in flight
+// per lane ahead of the addition.
+template <int GCH, int PF>
+__global__ void __launch_bounds__(64) k_fb_msm_wave(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx,
+                                                    const uint32_t *__restrict__ count, uint32_t stride, const fbent *__restrict__ tbl,
+                                                    FbGeom geo, ge *__restrict__ out) {
+  const uint32_t o = blockIdx.x, lane = threadIdx.x;
+  const uint32_t n = count[o];
+  __shared__ int16_t s_dig[GCH * FB_MAX_WINDOWS];
+  __shared__ uint32_t s_gi[GCH];
+  __shared__ ge red[64];
+  ge acc;
+  ge_identity(acc);
+  auto fetch = [&](niels &q, int &d, uint32_t it) {
+    const uint32_t i = it / geo.items, w = it - i * geo.items;
+    d = s_dig[it];
+    const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+    niels_load_swapped(q, &tbl[((size_t)s_gi[i] * geo.windows + w) * geo.entries + (mag ? mag - 1u : 0u)].q, d < 0);
+  };
+  for (uint32_t base = 0; base < n; base += GCH) {
+    const uint32_t cn = n - base < GCH ? n - base : GCH;
+    __syncthreads();
+    for (uint32_t i = lane; i < cn; i += 64) {
+      const sc s = scal[(size_t)o * stride + base + i];
+      fb_recode(s_dig + (size_t)i * geo.items, s, geo);
+      s_gi[i] = gidx[(size_t)o * stride + base + i];
+    }
+    __syncthreads();
+    const uint32_t items = cn * geo.items;
+    uint32_t it = lane;
+    if constexpr (PF == 1) {
+      niels nxt;
+      int nd = 0;
+      if (it < items) fetch(nxt, nd, it);
+      while (it < items) {
+        niels cur = nxt;
+        const int cd = nd;
+        it += 64;
+        if (it < items) fetch(nxt, nd, it);
+        if (cd != 0) ge_madd_swapped(acc, acc, cur, cd < 0);
+      }
+    } else {
+      niels n0, n1;
+      int d0 = 0, d1 = 0;
+      if (it < items) fetch(n0, d0, it);
+      if (it + 64 < items) fetch(n1, d1, it + 64);
+      while (it < items) {
+        niels cur = n0;
+        const int cd = d0;
+        n0 = n1;
+        d0 = d1;
+        it += 64;
+        if (it + 64 < items) fetch(n1, d1, it + 64);
+        if (cd != 0) ge_madd_swapped(acc, acc, cur, cd < 0);
+      }
+    }
+  }
+  red[lane] = acc;
+  __syncthreads();
+  for (uint32_t off = 32; off >= 1; off >>= 1) {
+    if (lane < off) {
+      ge x = red[lane], y2 = red[lane + off];
+      ge_add(x, x, y2);
+      red[lane] = x;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) out[o] = red[0];
+}
+
 int main(int argc, char **argv) {
   const uint32_t proofs = argc > 1 ? (uint32_t)atoi(argv[1]) : 1024u;
   const uint32_t n_gen = 516, terms = 260, outputs = 2 * proofs, stride = 2 * 256 + 4;
@@ -230,8 +420,10 @@ int main(int argc, char **argv) {
     return best;
   };
   const double adds = (double)outputs * terms * geo.items;
+  float a256 = 0;
   for (uint32_t thr : {256u, 192u, 128u}) {
     const float a = best_of([&] { hipLaunchKernelGGL(k_fb_msm, dim3(outputs), dim3(thr), 0, 0, d_s, d_g, d_c, stride, d_tbl, geo, d_out); });
+    if (thr == 256u) a256 = a;
     printf("A k_fb_msm, %3u lanes per output        : %.3f ms  (%.1f G additions/s)\n", thr, a, adds / a / 1e6);
   }
   std::vector<ge> ref(outputs), got(outputs);
@@ -250,6 +442,38 @@ int main(int argc, char **argv) {
     (void)hipEventElapsedTime(&sum_ms, e2, e1);
     printf("C k_fb_part + k_fb_sum, %u slices (%3u terms): %.3f ms  (%.1f G additions/s; the sum %.3f ms)\n", parts, (terms + parts - 1) / parts, c,
            adds / c / 1e6, sum_ms);
+  }
+  {
+    const float g1 = best_of([&] { hipLaunchKernelGGL((k_fb_msm_wave<128, 1>), dim3(outputs), dim3(64), 0, 0, d_s, d_g, d_c, stride, d_tbl, geo, d_out); });
+    printf("G one wavefront per output, 128-term chunks, 1 line ahead : %.3f ms  (%.1f G additions/s; %.2fx the time of A)\n", g1, adds / g1 / 1e6, g1 / a256);
+    (void)hipMemcpy(got.data(), d_out, (size_t)outputs * sizeof(ge), hipMemcpyDeviceToHost);
+    const float g2 = best_of([&] { hipLaunchKernelGGL((k_fb_msm_wave<128, 2>), dim3(outputs), dim3(64), 0, 0, d_s, d_g, d_c, stride, d_tbl, geo, d_out); });
+    printf("G one wavefront per output, 128-term chunks, 2 lines ahead: %.3f ms  (%.1f G additions/s; %.2fx the time of A)\n", g2, adds / g2 / 1e6, g2 / a256);
+    const float g3 = best_of([&] { hipLaunchKernelGGL((k_fb_msm_wave<64, 1>), dim3(outputs), dim3(64), 0, 0, d_s, d_g, d_c, stride, d_tbl, geo, d_out); });
+    printf("G one wavefront per output,  64-term chunks, 1 line ahead : %.3f ms  (%.1f G additions/s; %.2fx the time of A)\n", g3, adds / g3 / 1e6, g3 / a256);
+    const float g4 = best_of([&] { hipLaunchKernelGGL((k_fb_msm_wave<260, 1>), dim3(outputs), dim3(64), 0, 0, d_s, d_g, d_c, stride, d_tbl, geo, d_out); });
+    printf("G one wavefront per output, 260-term chunks, 1 line ahead : %.3f ms  (%.1f G additions/s; %.2fx the time of A)\n", g4, adds / g4 / 1e6, g4 / a256);
+  }
+  (void)hipFree(d_tbl);
+  for (uint32_t wb : {11u, 12u}) {  // E: 64-byte entries, the same table footprint at one more window bit
+    FbGeom g2;
+    g2.wbits = wb;
+    g2.windows = (254 + wb - 1) / wb;
+    g2.entries = 1u << (wb - 1);
+    g2.items = (253u % wb == 0u) ? 253u / wb : g2.windows;
+    const size_t n2 = (size_t)n_gen * fb_stride(g2);
+    fbxy *d_xy;
+    if (hipMalloc(&d_xy, n2 * sizeof(fbxy)) != hipSuccess) return 1;
+    hipLaunchKernelGGL(k_fill_xy, dim3((uint32_t)((n2 + 255) / 256)), dim3(256), 0, 0, d_xy, n2);
+    const double adds2 = (double)outputs * terms * g2.items;
+    for (uint32_t thr : {256u, 128u}) {
+      const float e = best_of([&] { hipLaunchKernelGGL(k_fb_msm_xy<true>, dim3(outputs), dim3(thr), 0, 0, d_s, d_g, d_c, stride, d_xy, g2, d_out); });
+      printf("E 64-byte entries, %2u-bit windows (%u additions per term, table %.2f GB), %3u lanes: %.3f ms  (%.1f G additions/s; %.2fx the time of A)\n",
+             wb, g2.items, n2 * 64.0 / 1e9, thr, e, adds2 / e / 1e6, e / a256);
+    }
+    const float e2 = best_of([&] { hipLaunchKernelGGL(k_fb_msm_xy<false>, dim3(outputs), dim3(256), 0, 0, d_s, d_g, d_c, stride, d_xy, g2, d_out); });
+    printf("E the same without the tree (256 lanes)   : %.3f ms  (%.1f G additions/s)\n", e2, adds2 / e2 / 1e6);
+    (void)hipFree(d_xy);
   }
   printf("[%s]\n", hipGetErrorString(hipGetLastError()));
   return 0;
