@@ -79,6 +79,12 @@ def parse_args():
     ap.add_argument("--only", choices=("headline", "cfg3", "prover"), default=None,
                     help="run just this leg, no roofline post-processing: what the rocprofv3 child passes of measure_traffic() run")
     ap.add_argument("--host-in-calls", type=int, default=48, help="calls per timed region of the host-buffers-in leg")
+    ap.add_argument("--transport", choices=("rccl", "gloo"), default=os.environ.get("BPP_BENCH_TRANSPORT", "rccl"),
+                    help="N > 1, the sharded leg's all_gathers: RCCL on device buffers, or the caller-supplied transport of the C ABI "
+                         "(bpp_comm_create_callbacks) over torch.distributed's gloo")
+    ap.add_argument("--one-device", action="store_true", default=os.environ.get("BPP_BENCH_ONE_DEVICE", "0") == "1",
+                    help="every local rank on device 0 (a rehearsal of the multi-rank code as PROCESSES on a one-GPU box; RCCL refuses "
+                         "two ranks on one device, so this implies --transport gloo); the line says so")
     return ap.parse_args()
 
 
@@ -551,7 +557,7 @@ def small_calls_leg(bpp, packed, np, local_rank, params2, data2, callers=32, sec
     """The reference's own use: separate callers, each with ONE batch of 256 proofs per verify_batch call (its
     MAX_RANGE_PROOF_BATCH_SIZE), host buffers in.  (a) every caller on a context of its own (bpp_verify_batch_packed): a small
     call is a chain of latency-bound kernels and the chip runs about six of them side by side; the library's admission gate
-    (bpp_small_call_limit, default 8) keeps the other callers waiting on the host instead of on the hardware queues -- the same
+    (bpp_small_call_limit, default 12) keeps the other callers waiting on the host instead of on the hardware queues -- the same
     with the gate switched off is measured next to it; (b) the same callers through ONE bpp_batcher, which pools the calls that
     are waiting into grouped engine calls (bpp_verify_resident_groups_actions); (c) the batcher with RecoverOnly calls (a wallet
     scanning outputs: seed nonces in, masks out, no final check)."""
@@ -649,7 +655,8 @@ def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, para
             rbs.append(packed.ResidentBatch(pars[sl], data2["proofs"][idx], data2["commitments"][idx], data2["min_values"][idx],
                                             data2["min_present"][idx], None, LABEL))
             rbs[-1].prepare(n_local if G > 1 else 0)
-        calls.append((engs, pars, rbs, dmod.ShardComm.from_process_group(engs[0])))
+        calls.append((engs, pars, rbs, dmod.ShardComm.from_process_group_gloo(engs[0]) if args.transport == "gloo"
+                      else dmod.ShardComm.from_process_group(engs[0])))
     errors = []
 
     def worker(w, rounds):
@@ -695,7 +702,8 @@ def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, para
                         "chains replayed (shared out over the ranks and gathered when there are several), RCCL all_gather of the "
                         "128-byte accumulators, sum + identity test on the device; %d calls in flight per rank, each a pipeline of %d "
                         "times %d batches resident as one" % (n_local, W, S, G),
-            "rccl_ranks": world, "proofs_per_s": 4096 * batches / wel, "ms_per_batch": 1e3 * wel / batches,
+            "rccl_ranks": world, "transport": "gloo through bpp_comm_create_callbacks" if args.transport == "gloo" else "rccl",
+            "proofs_per_s": 4096 * batches / wel, "ms_per_batch": 1e3 * wel / batches,
             "batches": batches, "in_flight": W * S * G, "waves": W, "slots_per_call": S, "batches_per_wave": G,
             "last_wave_host_ms": {k: round(v, 3) for k, v in wave_ms.items()}}
 
@@ -718,7 +726,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.one_device:
+        args.transport = "gloo"
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
@@ -881,13 +891,19 @@ def main():
     # runs mostly at the ramp's clock and reads 10-15 % low; `shader_clock_ghz` in the line is what the timed region held.
     sync()  # under torch.distributed the first barrier builds the communicator (100s of ms): not between warm-up and timing
     step_error, elapsed, lat, profs, clock_ghz = None, 0.0, [], [], None
+    pool_cpu0 = proc_cpu0 = 0
     try:
         if args.preheat_ms > 0 and not args.only:
             leg.run_steps(max(1, int(args.preheat_ms / 2.7)))
-        elapsed, lat, profs, clock_ghz = timed(leg, args.steps, args.warmup, sync,
+        leg.run_steps(args.warmup)  # (the warm-up, outside the host-CPU accounting below; timed() then starts at once)
+        pool_cpu0, proc_cpu0 = bpp.host_pool_cpu_ns(), time.process_time()
+        elapsed, lat, profs, clock_ghz = timed(leg, args.steps, 0, sync,
                                                clock=lambda: bpp.shader_clock_ghz(clk_eng, int(1e3 * max(5.0, min(200.0, 0.6 * est_ms)))))
     except Exception as e:  # noqa: BLE001 - a failed step: no number; the other ranks still get their collective
         step_error = e
+    pool_cpu_ms = (bpp.host_pool_cpu_ns() - pool_cpu0) / 1e6 / max(1, args.steps)
+    proc_cpu_ms = (time.process_time() - proc_cpu0) * 1e3 / max(1, args.steps)
+    local_ms = 1e3 * elapsed / max(1, args.steps)
     clk_eng.close()
     # every timed step ran and raised nothing (each step verifies all its batches or raises)
     ok_all = 1 if (step_error is None and len(lat) == args.steps) else 0
@@ -937,7 +953,20 @@ def main():
         "step_latency_ms": 1e3 * sum(lat) / len(lat), "steps_completed": len(lat), "all_steps_verified": bool(ok_all),
         "host_threads": bpp.host_threads(), "nproc": os.cpu_count(), "usable_cpus": usable_cpus(),
         "shader_clock_ghz": clock_ghz,
+        # the one sequential part of a verification stays on the host (the batch weight chains, src/range_proof.rs:849-853,894):
+        # CPU time of the library's host pool per timed step, and of the whole process; cores kept busy = cpu ms / step ms.  With
+        # N ranks on one node, N x host_cores_busy against the node's cores tells a host-bound scaling curve from a GPU-bound one.
+        "host_chain_cpu_ms_per_step": pool_cpu_ms, "host_process_cpu_ms_per_step": proc_cpu_ms,
+        "host_cores_busy": proc_cpu_ms / local_ms if local_ms > 0 else None,
     }
+    if args.one_device:
+        out["config"]["devices"] = "ALL %d ranks on device 0 (--one-device: a rehearsal of the multi-rank code, not a scaling point)" % world
+    if use_dist:
+        mine = {"rank": rank, "device": local_rank, "host_threads": bpp.host_threads(), "usable_cpus": usable_cpus(),
+                "ms_per_step_local": local_ms, "host_chain_cpu_ms_per_step": pool_cpu_ms, "host_process_cpu_ms_per_step": proc_cpu_ms}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        out["per_rank"] = every
     profiler_legs = rank == 0 and world == 1 and not use_dist and not args.no_traffic
     if roof:
         sq = {}

@@ -9,7 +9,7 @@ from . import _build, _lib  # noqa: F401
 from .api import (  # noqa: F401
     CommitmentOpening, EngineError, Engine, ExtendedMask, ExtensionDegree, MAX_RANGE_PROOF_BATCH_SIZE, PedersenGens, Precomputation,
     ProofError, ProofErrorKind, RangeParameters, RangeProof, RangeStatement, RangeWitness, ResidentBatch, Transcript, VerifyAction,
-    accumulators_sum_is_identity, create_pedersen_gens_with_extension_degree, host_threads, shader_clock_ghz, verify_batch_with_challenges, weights_from_chain, weights_from_chains,
+    accumulators_sum_is_identity, create_pedersen_gens_with_extension_degree, host_pool_cpu_ns, host_threads, shader_clock_ghz, verify_batch_with_challenges, weights_from_chain, weights_from_chains,
 )
 
 build = _build.build

@@ -59,6 +59,9 @@ class RuntimeInfo(Structure):
                 ("small_calls", c_uint64), ("small_calls_queued", c_uint64), ("oversubscribed", c_uint32)]
 
 
+# bpp_all_gather_fn: int (*)(void *user, const void *send, void *recv, size_t bytes_per_rank)
+ALL_GATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_size_t)
+
 # every symbol include/bpp.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("bpp_ctx_create", c_int, [POINTER(c_void_p), c_int]),
@@ -100,6 +103,7 @@ SYMBOLS = [
     ("bpp_comm_unique_id", c_int, [c_void_p]),
     ("bpp_comm_create", c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
     ("bpp_comm_adopt", c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    ("bpp_comm_create_callbacks", c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(c_void_p)]),
     ("bpp_comm_create_local", c_int, [c_void_p, c_uint64, c_int, c_int, POINTER(c_void_p)]),
     ("bpp_comm_destroy", None, [c_void_p]),
     ("bpp_comm_last_error", c_char_p, [c_void_p]),
@@ -138,9 +142,11 @@ SYMBOLS = [
     ("bpp_prove_profile_get", c_int, [c_void_p, POINTER(ProveProfile)]),
     ("bpp_batch_prepare", c_int, [c_void_p, c_uint64, c_size_t]),
     ("bpp_host_threads", c_int, []),
+    ("bpp_host_pool_cpu_ns", c_uint64, []),
     ("bpp_shader_clock", c_int, [c_void_p, c_uint32, POINTER(c_double)]),
     ("bpp_transcript_new", c_int, [c_void_p, c_size_t, c_void_p]),
     ("bpp_batch_secret_bytes", c_int, [c_void_p, c_uint64, POINTER(c_uint64)]),
+    ("bpp_prove_secret_bytes", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
 ]
 
 _lib = None

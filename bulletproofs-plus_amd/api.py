@@ -736,6 +736,11 @@ def host_threads():
     return int(_lib.load().bpp_host_threads())
 
 
+def host_pool_cpu_ns():
+    """bpp_host_pool_cpu_ns: CPU time this process has spent in the library's host jobs (weight chains, batch parsing)"""
+    return int(_lib.load().bpp_host_pool_cpu_ns())
+
+
 def weights_from_chain(rng32_all):
     """The batch-weight transcript (src/range_proof.rs:811,849,853,894) over 32-byte transcript-RNG outputs."""
     n = len(rng32_all) // 32

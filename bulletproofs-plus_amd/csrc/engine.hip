@@ -8,6 +8,7 @@
 //   * SHAKE256 / SHA3-512 byte streams for generator derivation (src/generators/generators_chain.rs:23-33,
 //     src/protocols/curve_point_protocol.rs:31-35); the hash-to-group map itself runs on the device
 #include <hip/hip_runtime.h>
+#include <errno.h>
 #include <sched.h>
 #include <stdio.h>
 #include <string.h>
@@ -136,6 +137,19 @@ void set_err(char *errbuf, size_t len, const std::string &m) {
   }
 }
 
+// a whole decimal number in [lo, hi] from an environment variable; false (and *out untouched) for anything else -- a typo must
+// not silently become 0, which for a deadline means "none" and for the small-call gate "off"
+bool parse_env_long(const char *text, long lo, long hi, long *out) {
+  if (!text || !*text) return false;
+  char *end = nullptr;
+  errno = 0;
+  const long v = strtol(text, &end, 10);
+  while (end && (*end == ' ' || *end == '\t')) end++;
+  if (errno || end == text || (end && *end) || v < lo || v > hi) return false;
+  *out = v;
+  return true;
+}
+
 // ------------------------------------------------------------------ host hashing helpers (keccak from merlin.h)
 void keccak_sponge(const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen, uint32_t rate, uint8_t pad) {
   uint64_t st[25];
@@ -165,6 +179,7 @@ void sha3_512(const uint8_t *in, size_t inlen, uint8_t out[64]) { keccak_sponge(
 void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G);
 void host_parallel_for(uint32_t n, const std::function<void(uint32_t)> &fn);  // on the persistent host pool
 uint32_t host_pool_size();
+uint64_t host_pool_cpu_ns();
 
 // weight transcript (src/range_proof.rs:811,849,853,894)
 void weights_from_chain_host(const uint8_t *rng32, size_t n, uint8_t *weights32) {
@@ -269,6 +284,7 @@ struct DeviceState {
   uint64_t small_calls = 0, small_calls_queued = 0;
   uint32_t contexts = 0, contexts_peak = 0;
   bool warned = false;
+  std::string env_note;  // a malformed BPP_SMALL_CALLS_IN_FLIGHT: said once, where bpp_ctx_last_error finds it
 };
 DeviceState &device_state(int dev) {
   static std::mutex mu;
@@ -277,7 +293,11 @@ DeviceState &device_state(int dev) {
   DeviceState *&d = (*all)[dev];
   if (!d) {
     d = new DeviceState();
-    if (const char *e = getenv("BPP_SMALL_CALLS_IN_FLIGHT")) d->limit = (uint32_t)std::max(0, atoi(e));  // 0: no gate
+    if (const char *e = getenv("BPP_SMALL_CALLS_IN_FLIGHT")) {  // 0: no gate
+      long v = 0;
+      if (parse_env_long(e, 0, 1 << 20, &v)) d->limit = (uint32_t)v;
+      else d->env_note = std::string("note: BPP_SMALL_CALLS_IN_FLIGHT=\"") + e + "\" is not a number: the default gate (12 calls) stands";
+    }
   }
   return *d;
 }
@@ -406,6 +426,11 @@ struct Batch {
   std::vector<uint32_t> h_group_first;
   PinnedBuf<uint8_t> h_rng, h_weights, h_masks;  // mapped: written / read by the kernels directly (PinnedBuf)
   PinnedBuf<uint32_t> h_status, h_ident;
+  // k_results_out writes one summary word per BPP_STATUS_BLOCK proofs and a block's words only when there is something in them;
+  // settle_status() makes h_status whole again on the host (a block the kernel skipped is all zero: cleared here if it was not)
+  PinnedBuf<uint32_t> h_status_any;
+  std::vector<uint8_t> h_status_dirty;
+  bool status_settled = true;
   bool have_trace = false, phase1_done = false;
   bool status_clean = false;     // status[] == status0[]: k_results_out resets it behind every verification
   bool weights_on_host = false;  // the last PASS 2 read its weights from h_weights (b.weights holds them only in the sharded forms)
@@ -828,6 +853,7 @@ int bpp_ctx_create_on_stream(bpp_ctx **out, int device_id, void *hip_stream) {
       c->err = note;
       D.warned = true;
     }
+    if (!D.env_note.empty()) c->err = D.env_note;
   }
   *out = c;
   return BPP_OK;
@@ -1468,6 +1494,7 @@ int bpp_batch_upload_packed(bpp_ctx *ctx, uint64_t params, const bpp_packed_batc
 }
 
 int bpp_host_threads(void) { return (int)host_pool_size(); }
+uint64_t bpp_host_pool_cpu_ns(void) { return host_pool_cpu_ns(); }
 
 int bpp_shader_clock(bpp_ctx *ctx, uint32_t window_us, double *ghz) {
   BPP_ENTRY(ctx);
@@ -1616,7 +1643,7 @@ class HostPool {
   void parallel_for(uint32_t n, const std::function<void(uint32_t)> &fn) {
     if (n == 0) return;
     if (n == 1 || workers_.empty()) {
-      for (uint32_t i = 0; i < n; i++) fn(i);
+      for (uint32_t i = 0; i < n; i++) run_item(fn, i);
       return;
     }
     auto job = std::make_shared<Job>();
@@ -1690,11 +1717,30 @@ class HostPool {
     for (uint32_t i = 1; i < want; i++) workers_.emplace_back([this] { loop(); });
     for (auto &t : workers_) t.detach();
   }
+ public:
+  // CPU time spent inside jobs (thread clocks, so a thread that was not scheduled is not counted): what bpp_host_pool_cpu_ns
+  // reports -- with several ranks on one host it tells a host-bound step from a GPU-bound one
+  static uint64_t thread_cpu_ns() {
+    struct timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+  }
+  static std::atomic<uint64_t> &cpu_ns() {
+    static std::atomic<uint64_t> v{0};
+    return v;
+  }
+  static void run_item(const std::function<void(uint32_t)> &fn, uint32_t i) {
+    const uint64_t t0 = thread_cpu_ns();
+    fn(i);
+    cpu_ns().fetch_add(thread_cpu_ns() - t0, std::memory_order_relaxed);
+  }
+
+ private:
   static void work_on(Job &j) {
     for (;;) {
       uint32_t i = j.next.fetch_add(1);
       if (i >= j.n) return;
-      (*j.fn)(i);
+      run_item(*j.fn, i);
       if (j.done.fetch_add(1) + 1 == j.n) {
         std::lock_guard<std::mutex> lk(j.mu);
         j.cv.notify_all();
@@ -1728,6 +1774,7 @@ class HostPool {
 
 void host_parallel_for(uint32_t n, const std::function<void(uint32_t)> &fn) { HostPool::get().parallel_for(n, fn); }
 uint32_t host_pool_size() { return HostPool::get().size(); }
+uint64_t host_pool_cpu_ns() { return HostPool::cpu_ns().load(std::memory_order_relaxed); }
 
 void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G) {
   static const int simd = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") ? 8
@@ -1798,16 +1845,38 @@ void fetch_results(bpp_ctx *ctx, Batch &b, bool ident, bool masks) {
   const uint32_t pieces = masks ? (uint32_t)(((size_t)b.B * b.params->t * 32) / 16) : 0u;
   if (masks) b.h_masks.resize((size_t)pieces * 16);
   const uint32_t items = std::max(b.B, ident ? b.G : 0u);
-  hipLaunchKernelGGL(k_results_out, dim3(cdiv(items, 256)), dim3(256), 0, ctx->stream, b.status.p, b.status0.p, b.h_status.dev(), b.B,
+  b.h_status_any.resize(cdiv(b.B, BPP_STATUS_BLOCK));
+  b.status_settled = false;
+  hipLaunchKernelGGL(k_results_out, dim3(cdiv(items, BPP_STATUS_BLOCK)), dim3(BPP_STATUS_BLOCK), 0, ctx->stream, b.status.p, b.status0.p,
+                     b.h_status.dev(), b.h_status_any.dev(), b.B,
                      ident ? b.msm.is_identity.p : (const uint32_t *)nullptr, ident ? b.h_ident.dev() : (uint32_t *)nullptr, b.G,
                      masks ? (const uint4 *)b.masks.p : (const uint4 *)nullptr, masks ? (uint4 *)b.h_masks.dev() : (uint4 *)nullptr, pieces);
   HIP_CHECK(hipGetLastError());
   b.status_clean = true;  // (in stream order: whatever is enqueued behind this launch finds status0)
 }
 void fetch_status(bpp_ctx *ctx, Batch &b) { fetch_results(ctx, b, false, false); }
+// After the stream has been synchronised behind fetch_results: h_status as every reader expects it.  The kernel wrote the words
+// of the blocks that hold a finding; every other block is zero by its summary word and is cleared here only if an earlier
+// verification left something in it -- on the accept path this touches one word per 256 proofs.
+void settle_status(Batch &b) {
+  if (b.status_settled) return;
+  const uint32_t n_blk = cdiv(b.B, BPP_STATUS_BLOCK);
+  if (b.h_status_dirty.size() != n_blk) b.h_status_dirty.assign(n_blk, 1);  // fresh page-locked memory: contents unknown
+  for (uint32_t k = 0; k < n_blk; k++) {
+    if (b.h_status_any[k]) {
+      b.h_status_dirty[k] = 1;
+    } else if (b.h_status_dirty[k]) {
+      const uint32_t lo = k * BPP_STATUS_BLOCK, hi = std::min(b.B, lo + BPP_STATUS_BLOCK);
+      memset(b.h_status.data() + lo, 0, (size_t)(hi - lo) * 4);
+      b.h_status_dirty[k] = 0;
+    }
+  }
+  b.status_settled = true;
+}
 
 // reference error precedence for proofs [p0, p1) treated as one verify() call (upload_host.h: check_chunk_errors)
-void check_chunk_errors(const Batch &b, uint32_t p0, uint32_t p1) {
+void check_chunk_errors(Batch &b, uint32_t p0, uint32_t p1) {
+  settle_status(b);
   bpp::check_chunk_errors(b.h_status.data(), b.rounds_bad.data(), p0, p1);
 }
 
@@ -2625,6 +2694,31 @@ int bpp_batch_secret_bytes(bpp_ctx *ctx, uint64_t batch, uint64_t *nonzero) {
         wipe(h.data(), h.size());
       }
     }
+    *nonzero = cnt;
+    return BPP_OK;
+  }
+  BPP_CATCH(ctx, nullptr, 0)
+}
+
+int bpp_prove_secret_bytes(bpp_ctx *ctx, uint64_t *examined, uint64_t *nonzero) {
+  BPP_ENTRY(ctx);
+  try {
+    if (!examined || !nonzero) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "null argument");
+    uint64_t seen = 0, cnt = 0;
+    if (ctx->prove_arena.p && ctx->prove_arena.n) {
+      for (auto &ps : ctx->prove_streams) HIP_CHECK(hipStreamSynchronize(ps));
+      std::vector<uint8_t> h(ctx->prove_arena.n);
+      HIP_CHECK(hipMemcpy(h.data(), ctx->prove_arena.p, h.size(), hipMemcpyDeviceToHost));
+      for (uint8_t v : h) cnt += v != 0;
+      seen += h.size();
+      wipe(h.data(), h.size());
+    }
+    for (PinnedBuf<uint8_t> *pb : {&ctx->prove_pin_in, &ctx->prove_pin_out}) {
+      if (!pb->p || !pb->n) continue;
+      for (size_t i = 0; i < pb->n; i++) cnt += pb->p[i] != 0;
+      seen += pb->n;
+    }
+    *examined = seen;
     *nonzero = cnt;
     return BPP_OK;
   }

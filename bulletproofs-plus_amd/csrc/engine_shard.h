@@ -150,6 +150,9 @@ struct LocalGroup {
 struct bpp_comm {
   int device = 0, rank = 0, world = 1;
   std::shared_ptr<LocalGroup> local;  // set: in-process transport instead of RCCL
+  bpp_all_gather_fn cb = nullptr;     // set: the caller's own transport (bpp_comm_create_callbacks), host buffers through cb_send / cb_recv
+  void *cb_user = nullptr;
+  PinnedBuf<uint8_t> cb_send, cb_recv;
   ncclComm_t comm = nullptr;
   bool own_comm = false;
   hipStream_t stream = nullptr;  // collectives and their staging copies
@@ -171,10 +174,14 @@ struct bpp_comm {
   bpp_shard_timing timing{};  // host wall-clock split of the last wave
   // Every wait for a collective has a deadline (bpp_comm_set_timeout; BPP_COMM_TIMEOUT_MS; default 60 s; 0 = none): a peer that
   // died or never called leaves an all_gather kernel spinning on this rank's stream for ever.  When the deadline passes the
-  // communicator is aborted (ncclCommAbort: its kernels exit), marked dead, and the call -- like every later call on it --
-  // returns BPP_ERR_COMM: an RCCL failure maps to a C error code on every surviving rank.
+  // communicator is marked dead and the call -- like every later call on it -- returns BPP_ERR_COMM: an RCCL failure maps to a C
+  // error code on every surviving rank.  A communicator this library CREATED (bpp_comm_create) is aborted as well
+  // (ncclCommAbort: its kernels exit).  One it merely ADOPTED (bpp_comm_adopt: say a framework's process-group communicator) is
+  // NOT: the ncclComm_t belongs to the caller, who may be using it elsewhere and will destroy it himself -- an abort behind his
+  // back would turn that into a use-after-free.  The owner aborts it (which also lets this rank's stream drain).
   uint32_t timeout_ms = 60000;
   bool dead = false;
+  bool stream_stuck = false;  // an adopted communicator's collective is still spinning on `stream`: never wait for it unbounded
 };
 
 namespace {
@@ -203,17 +210,23 @@ void comm_wait(bpp_comm *c, hipStream_t cs) {
     const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
     if (c->timeout_ms && waited >= (long long)c->timeout_ms) {
       c->dead = true;
-      if (!c->local && c->comm) {
+      const bool adopted = !c->local && c->comm && !c->own_comm;
+      if (!c->local && c->comm && c->own_comm) {
         (void)rccl_api().CommAbort(c->comm);  // the collective's kernel exits; the handle is gone with it
         c->comm = nullptr;
         c->own_comm = false;
       }
-      const auto t1 = std::chrono::steady_clock::now();  // let the stream drain (bounded: nothing may hang here either)
-      while (hipStreamQuery(cs) == hipErrorNotReady && std::chrono::steady_clock::now() - t1 < std::chrono::seconds(5))
+      // let the stream drain (bounded: nothing may hang here either).  An adopted communicator's kernel keeps spinning until
+      // its owner aborts it: one short look, then the stream is remembered as stuck.
+      const auto t1 = std::chrono::steady_clock::now();
+      const auto patience = adopted ? std::chrono::milliseconds(50) : std::chrono::milliseconds(5000);
+      while (hipStreamQuery(cs) == hipErrorNotReady && std::chrono::steady_clock::now() - t1 < patience)
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      if (adopted && hipStreamQuery(cs) == hipErrorNotReady) c->stream_stuck = true;
       (void)hipGetLastError();
-      throw CommError{"a collective did not complete within " + std::to_string(c->timeout_ms) +
-                      " ms (a peer is missing or dead); the communicator was aborted and must be destroyed"};
+      throw CommError{"a collective did not complete within " + std::to_string(c->timeout_ms) + " ms (a peer is missing or dead); " +
+                      (adopted ? "this handle is dead and must be destroyed; the adopted ncclComm_t was left alone: its owner aborts it"
+                               : "the communicator was aborted and must be destroyed")};
     }
     if (spins < 2000) std::this_thread::yield();  // the exchanges are tens of microseconds when every rank is there
     else std::this_thread::sleep_for(std::chrono::microseconds(50));
@@ -222,7 +235,12 @@ void comm_wait(bpp_comm *c, hipStream_t cs) {
 
 int comm_new(bpp_ctx *ctx, ncclComm_t nc, bool own, int rank, int world, bpp_comm **out) {
   auto c = std::make_unique<bpp_comm>();
-  if (const char *e = getenv("BPP_COMM_TIMEOUT_MS")) c->timeout_ms = (uint32_t)std::max(0, atoi(e));
+  // (a malformed value keeps the default and says so: `atoi` made a typo a silent "no deadline")
+  if (const char *e = getenv("BPP_COMM_TIMEOUT_MS")) {
+    long v = 0;
+    if (parse_env_long(e, 0, 86400000L, &v)) c->timeout_ms = (uint32_t)v;
+    else ctx->err = std::string("BPP_COMM_TIMEOUT_MS=\"") + e + "\" is not a number of milliseconds: the default deadline (60000 ms) stands";
+  }
   c->device = ctx->device;
   c->rank = rank;
   c->world = world;
@@ -235,26 +253,60 @@ int comm_new(bpp_ctx *ctx, ncclComm_t nc, bool own, int rank, int world, bpp_com
 
 // all_gather of `bytes` per rank on the communicator's stream: RCCL, or the in-process rendezvous
 void comm_allgather(bpp_comm *c, const uint8_t *send, uint8_t *recv, size_t bytes, hipStream_t cs) {
+  if (c->cb) {
+    // the caller's transport moves HOST bytes (the exchanges are 32 bytes per proof and 256 bytes per batch: staging them is
+    // nothing); it blocks until every rank's block is in `recv`, and its own deadline is its own business
+    c->cb_send.resize(bytes);
+    c->cb_recv.resize(bytes * (size_t)c->world);
+    HIP_CHECK(hipMemcpyAsync(c->cb_send.p, send, bytes, hipMemcpyDeviceToHost, cs));
+    HIP_CHECK(hipStreamSynchronize(cs));
+    const int rc = c->cb(c->cb_user, c->cb_send.p, c->cb_recv.p, bytes);
+    if (rc != 0) {
+      c->dead = true;
+      throw CommError{"the caller's all_gather callback failed (" + std::to_string(rc) + "); this communicator is dead and must be destroyed"};
+    }
+    HIP_CHECK(hipMemcpyAsync(recv, c->cb_recv.p, bytes * (size_t)c->world, hipMemcpyHostToDevice, cs));
+    return;
+  }
   if (!c->local) {
     RCCL_CHECK(rccl_api().AllGather(send, recv, bytes, ncclUint8, c->comm, cs));
     return;
   }
-  HIP_CHECK(hipStreamSynchronize(cs));  // everything this rank sends is in place
-  {
+  // Whatever goes wrong on this rank between its first and its second rendezvous -- a deadline, a HIP error -- breaks the GROUP at
+  // once (every peer's wait ends now, with BPP_ERR_COMM, instead of after its own full deadline), and this rank's copies out of the
+  // peers' send buffers have completed or are waited for before it returns: the peers may release those buffers afterwards.  (A
+  // peer that is still copying out of THIS rank's buffer when the buffer is released is covered by hipFree itself, which waits
+  // for the device.)
+  auto break_group = [&] {
     std::lock_guard<std::mutex> lk(c->local->mu);
-    c->local->send[c->rank] = send;
-  }
+    c->local->broken = true;
+    c->local->cv.notify_all();
+  };
   auto rendezvous = [&] {
     if (c->local->barrier(c->timeout_ms)) return;
     c->dead = true;
+    (void)hipStreamSynchronize(cs);
     throw CommError{"a collective did not complete within " + std::to_string(c->timeout_ms) +
                     " ms (a peer is missing or dead); the communicator was aborted and must be destroyed"};
   };
-  rendezvous();
-  for (int r = 0; r < c->world; r++)
-    HIP_CHECK(hipMemcpyAsync(recv + (size_t)r * bytes, c->local->send[r], bytes, hipMemcpyDeviceToDevice, cs));
-  HIP_CHECK(hipStreamSynchronize(cs));
-  rendezvous();  // nobody reuses a send buffer before every rank has read it
+  try {
+    HIP_CHECK(hipStreamSynchronize(cs));  // everything this rank sends is in place
+    {
+      std::lock_guard<std::mutex> lk(c->local->mu);
+      c->local->send[c->rank] = send;
+    }
+    rendezvous();
+    for (int r = 0; r < c->world; r++)
+      HIP_CHECK(hipMemcpyAsync(recv + (size_t)r * bytes, c->local->send[r], bytes, hipMemcpyDeviceToDevice, cs));
+    HIP_CHECK(hipStreamSynchronize(cs));
+    rendezvous();  // nobody reuses a send buffer before every rank has read it
+  } catch (...) {
+    c->dead = true;
+    break_group();
+    (void)hipStreamSynchronize(cs);
+    (void)hipGetLastError();
+    throw;
+  }
 }
 
 std::mutex g_local_groups_mu;
@@ -308,6 +360,18 @@ int bpp_comm_adopt(bpp_ctx *ctx, void *nccl_comm, int rank, int world, bpp_comm 
   return comm_new(ctx, (ncclComm_t)nccl_comm, false, rank, world, out);
 }
 
+int bpp_comm_create_callbacks(bpp_ctx *ctx, int rank, int world, bpp_all_gather_fn all_gather, void *user, bpp_comm **out) {
+  BPP_ENTRY(ctx);
+  if (!out || !all_gather || world < 1 || rank < 0 || rank >= world) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "bad communicator arguments");
+  *out = nullptr;
+  const int rc = comm_new(ctx, nullptr, false, rank, world, out);
+  if (rc == BPP_OK) {
+    (*out)->cb = all_gather;
+    (*out)->cb_user = user;
+  }
+  return rc;
+}
+
 int bpp_comm_create_local(bpp_ctx *ctx, uint64_t group_id, int rank, int world, bpp_comm **out) {
   BPP_ENTRY(ctx);
   if (!out || world < 1 || rank < 0 || rank >= world) return fail(ctx, BPP_ERR_INVALID_ARGUMENT, "bad communicator arguments");
@@ -334,7 +398,20 @@ void bpp_comm_destroy(bpp_comm *c) {
   (void)hipSetDevice(c->device);
   {
     std::lock_guard<std::mutex> lk(c->mu);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream_stuck) {
+      // a timed-out collective of an ADOPTED communicator may still be spinning here (its owner has not aborted it yet): wait a
+      // bounded time; if it is still there, the stream, the exchange buffers and the page-locked staging are deliberately LEFT
+      // ALLOCATED (a few hundred KB) -- releasing memory a running kernel and the copies queued behind it still address would be
+      // worse, and every release call of the runtime would wait for that kernel
+      const auto t0 = std::chrono::steady_clock::now();
+      while (hipStreamQuery(c->stream) == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2))
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      const bool drained = hipStreamQuery(c->stream) != hipErrorNotReady;
+      (void)hipGetLastError();
+      if (!drained) return;  // (the bpp_comm object itself stays too: its destructors would free those buffers)
+    } else {
+      (void)hipStreamSynchronize(c->stream);
+    }
     if (c->own_comm && c->comm) (void)rccl_api().CommDestroy(c->comm);
     (void)hipStreamDestroy(c->stream);
   }
@@ -527,6 +604,7 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
         shard_trailer_encode(tr, BPP_TIER_ENGINE, fault[i], first_index, fault_msg[i].c_str());
       } else {
         Batch &b = *B[i];
+        settle_status(b);
         shard_local_trailer(b.any_defer ? b.defer.data() : nullptr, b.h_status.data(), b.rounds_bad.data(), b.B, first_index, tr);
       }
     }
@@ -750,6 +828,7 @@ int bpp_verify_sharded_groups_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const u
         fault_msg[i] = "a kernel of this rank failed on the device";
       }
       if (fault[i]) (void)hipMemsetAsync(S.send2.p, 0, (size_t)G * 128, cs);
+      else settle_status(*B[i]);
       for (uint32_t g = 0; g < G; g++) {
         uint8_t *tr = S.h_tr.data() + (size_t)g * BPP_SHARD_TRAILER_BYTES;
         if (fault[i]) {

@@ -1338,15 +1338,31 @@ __global__ void __launch_bounds__(256) k_ingest(IngestArgs a) {
 // (src/range_proof.rs:1057-1062) and the recovered masks (:941-969).  status[] is then reset to the batch's initial status
 // (statement commitments that do not decode, caller-side PASS-1 findings), so the next verification of the same resident batch
 // starts clean without a device-to-device copy in front of its first kernel.
-__global__ void __launch_bounds__(256) k_results_out(uint32_t *__restrict__ status, const uint32_t *__restrict__ status0,
-                                                     uint32_t *__restrict__ status_host, uint32_t B,
+//
+// Status words cross the bus only where there is something to say: every workgroup (BPP_STATUS_BLOCK proofs) writes ONE summary
+// word -- the OR of its proofs' words -- and its proofs' words only when that is non-zero.  On the accept path a 65 536-proof
+// step thus stores 256 + 64 words to host memory instead of 65 536 (round 4: 202 us in flight for this launch, at the tail of
+// every step's chain; the host settles the blocks the kernel skipped: settle_status in engine.hip).
+#define BPP_STATUS_BLOCK 256u
+__global__ void __launch_bounds__(BPP_STATUS_BLOCK) k_results_out(uint32_t *__restrict__ status, const uint32_t *__restrict__ status0,
+                                                     uint32_t *__restrict__ status_host, uint32_t *__restrict__ block_any_host, uint32_t B,
                                                      const uint32_t *__restrict__ is_identity, uint32_t *__restrict__ ident_host,
                                                      uint32_t G, const uint4 *__restrict__ masks, uint4 *__restrict__ masks_host,
                                                      uint32_t mask_pieces) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  uint32_t st = 0;
   if (i < B) {
-    status_host[i] = status[i];
+    st = status[i];
     status[i] = status0[i];
+  }
+  if (__ballot(st != 0) != 0 && (threadIdx.x & 63u) == 0) atomicOr(&any, 1u);
+  __syncthreads();
+  if (blockIdx.x * blockDim.x < B) {
+    if (threadIdx.x == 0) block_any_host[blockIdx.x] = any;
+    if (any && i < B) status_host[i] = st;
   }
   if (is_identity && i < G) ident_host[i] = is_identity[i];
   if (masks)

@@ -38,6 +38,41 @@ class ShardComm:
             rc = self.lib.bpp_comm_create(engine.ctx, _lib_buf(unique_id), rank, world, byref(self.handle))
         api._check(rc, engine.ctx)
 
+    @classmethod
+    def from_callbacks(cls, engine, rank, world, all_gather):
+        """bpp_comm_create_callbacks: `all_gather(send: bytes) -> bytes` (the ranks' blocks in rank order) is the transport; it is
+        called on the thread that makes the verify call, in the same order on every rank"""
+        self = cls.__new__(cls)
+        self.engine, self.rank, self.world, self.lib = engine, rank, world, engine.lib
+        self.handle = c_void_p()
+
+        def trampoline(_user, send, recv, nbytes):
+            try:
+                got = all_gather(ctypes.string_at(send, nbytes))
+                if len(got) != nbytes * world:
+                    return 2
+                ctypes.memmove(recv, got, len(got))
+                return 0
+            except Exception:  # noqa: BLE001 - an exception must not unwind through the C caller
+                return 1
+        self._cb = _lib.ALL_GATHER_FN(trampoline)  # kept alive as long as the communicator
+        api._check(self.lib.bpp_comm_create_callbacks(engine.ctx, rank, world, ctypes.cast(self._cb, c_void_p), None, byref(self.handle)),
+                   engine.ctx)
+        return self
+
+    @classmethod
+    def from_process_group_gloo(cls, engine, group=None):
+        """the caller-supplied transport over torch.distributed's CPU backend: what lets several ranks share ONE GPU (RCCL refuses
+        two ranks on a device) and what a caller without RCCL uses"""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def all_gather(send):
+            src = torch.frombuffer(bytearray(send), dtype=torch.uint8)
+            out = torch.empty(world * src.numel(), dtype=torch.uint8)
+            dist.all_gather(list(out.chunk(world)), src, group=group)
+            return out.numpy().tobytes()
+        return cls.from_callbacks(engine, rank, world, all_gather)
+
     @staticmethod
     def unique_id():
         out = (ctypes.c_uint8 * 128)()

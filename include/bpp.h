@@ -267,11 +267,26 @@ int bpp_accumulators_sum_is_identity(bpp_ctx *ctx, const uint8_t *accumulators12
  *
  * Communicators: bpp_comm_unique_id (rank 0) -> the caller ships the 128 bytes to the other ranks over its own channel ->
  * bpp_comm_create on every rank (ncclCommInitRank: collective); or bpp_comm_adopt of an ncclComm_t the caller already
- * has.  A communicator serialises its own calls; use one per thread that verifies concurrently. */
+ * has; or bpp_comm_create_callbacks with the caller's own all_gather.  A communicator serialises its own calls; use one per
+ * thread that verifies concurrently.
+ *
+ * bpp_comm_adopt does NOT take ownership: the ncclComm_t stays the caller's (it may be a framework's process-group communicator
+ * in use elsewhere), bpp_comm_destroy never destroys it, and a collective that misses its deadline (bpp_comm_set_timeout) never
+ * aborts it -- the handle is marked dead and the call returns BPP_ERR_COMM, and it is the OWNER who calls ncclCommAbort (which
+ * also lets the collective still spinning on this rank exit).  Only communicators made by bpp_comm_create are aborted and
+ * destroyed by this library. */
 typedef struct bpp_comm bpp_comm;
 int bpp_comm_unique_id(uint8_t id128[128]);
 int bpp_comm_create(bpp_ctx *ctx, const uint8_t id128[128], int rank, int world, bpp_comm **out);
 int bpp_comm_adopt(bpp_ctx *ctx, void *nccl_comm, int rank, int world, bpp_comm **out);
+/* The caller's own transport instead of RCCL (its MPI / TCP / gloo channel; also how several ranks share ONE GPU, which RCCL
+ * refuses): `all_gather` receives this rank's `bytes_per_rank` bytes in HOST memory and must fill recv[r * bytes_per_rank ...]
+ * with rank r's block for every r (its own included), in the SAME order of calls on every rank; it blocks until that is done and
+ * returns 0, or non-zero on failure (the call then returns BPP_ERR_COMM and the handle is dead).  It is called on the thread
+ * that made the bpp_verify_sharded* call, two or three times per call (32 bytes per proof; weights when the chains are shared
+ * out; 256 bytes per batch).  Any deadline is the transport's own: bpp_comm_set_timeout cannot interrupt a callback. */
+typedef int (*bpp_all_gather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+int bpp_comm_create_callbacks(bpp_ctx *ctx, int rank, int world, bpp_all_gather_fn all_gather, void *user, bpp_comm **out);
 /* In-process stand-in for tests on a single GPU: the `world` ranks are threads of one process, each with its own context on
  * the same device; an all_gather is a rendezvous of the threads plus device-to-device copies.  Everything else of
  * bpp_verify_sharded(_wave) is the code the RCCL form runs.  Ranks of one group pass the same (arbitrary) group_id. */
@@ -279,9 +294,11 @@ int bpp_comm_create_local(bpp_ctx *ctx, uint64_t group_id, int rank, int world, 
 void bpp_comm_destroy(bpp_comm *comm);
 const char *bpp_comm_last_error(bpp_comm *comm);
 /* Deadline of every wait for a collective on this communicator, in ms (default 60 000, or BPP_COMM_TIMEOUT_MS at creation;
- * 0 = wait for ever).  A peer that died or never made the call would leave the all_gather spinning on this rank for ever: when
- * the deadline passes the communicator is aborted (ncclCommAbort), the call returns BPP_ERR_COMM on every surviving rank, and so
- * does every later call on it -- destroy it and build a new one over the ranks that are left. */
+ * 0 = wait for ever; a BPP_COMM_TIMEOUT_MS that is not a number keeps the default and leaves a note in bpp_ctx_last_error).  A
+ * peer that died or never made the call would leave the all_gather spinning on this rank for ever: when the deadline passes
+ * the call returns BPP_ERR_COMM on every surviving rank, and so does every later call on the handle -- destroy it and build a
+ * new one over the ranks that are left.  A communicator made by bpp_comm_create is aborted (ncclCommAbort) at that point; an
+ * ADOPTED one is left alone, see bpp_comm_adopt. */
 int bpp_comm_set_timeout(bpp_comm *comm, uint32_t timeout_ms);
 int bpp_verify_sharded(bpp_comm *comm, bpp_ctx *ctx, uint64_t batch, const uint32_t *counts /* world entries */,
                        int *tier_out, int *rank_out, char *errbuf, size_t errbuf_len);
@@ -442,6 +459,11 @@ int bpp_prove_profile_get(bpp_ctx *ctx, bpp_prove_profile *out);
 /* size of the process-wide host worker pool that runs the batch-weight chains and the upload packer
  * (BPP_HOST_THREADS, default min(usable cores, 32), usable = affinity mask capped by the cgroup CPU quota): the verifier's throughput depends on it */
 int bpp_host_threads(void);
+/* CPU time (ns, thread clocks, summed over the pool and the calling threads) this process has spent in the library's host jobs
+ * so far: the batch weight chains (src/range_proof.rs:849-853,894 -- the one sequential part of a verification, kept on the host)
+ * and the parsing of uploaded batches.  The difference over a run / (steps x step time) = host cores a rank keeps busy: with
+ * several ranks on one node it tells a host-bound scaling curve from a GPU-bound one. */
+uint64_t bpp_host_pool_cpu_ns(void);
 
 /* diagnostics: the shader clock the device holds RIGHT NOW, sampled by one napping wavefront on this context's stream for
  * about `window_us` microseconds (s_memtime against the 100 MHz s_memrealtime) while other contexts' kernels run.  Under the
@@ -454,6 +476,12 @@ int bpp_shader_clock(bpp_ctx *ctx, uint32_t window_us, double *ghz);
  * src/extended_mask.rs:14).  batch == 0 looks at the buffers the context kept from the last destroyed batch, which the
  * next upload will adopt: must read 0. */
 int bpp_batch_secret_bytes(bpp_ctx *ctx, uint64_t batch, uint64_t *nonzero);
+/* the same for the prover (tests/test_gpu_round5.py): the context's prover arena on the device -- witness bytes, bit vectors, nonces,
+ * blinding-factor accumulators, the transcript-RNG states keyed with the witness -- and its page-locked staging in both
+ * directions (witness bytes in; proofs and per-proof states out), which bpp_prove_batch wipes on EVERY exit path (the reference
+ * keeps all of it in Zeroizing<>: src/range_proof.rs:300-301,325,438-464,542-571).  *examined = bytes looked at (0 before the
+ * first prove call), *nonzero = how many of them are not zero: must read 0 between calls. */
+int bpp_prove_secret_bytes(bpp_ctx *ctx, uint64_t *examined, uint64_t *nonzero);
 
 /* Transcript::new(label) -> 203-byte STROBE state (host helper for callers that keep merlin on their side) */
 int bpp_transcript_new(const uint8_t *label, size_t label_len, uint8_t state203[203]);

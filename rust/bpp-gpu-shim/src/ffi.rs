@@ -162,6 +162,9 @@ pub struct bpp_prove_profile {
     pub sub_batches: u32,
 }
 
+/// `int (*bpp_all_gather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank)` (include/bpp.h)
+pub type bpp_all_gather_fn = Option<unsafe extern "C" fn(user: *mut c_void, send: *const c_void, recv: *mut c_void, bytes_per_rank: usize) -> c_int>;
+
 extern "C" {
     pub fn bpp_ctx_create(out: *mut *mut bpp_ctx, device_id: c_int) -> c_int;
     pub fn bpp_ctx_create_on_stream(out: *mut *mut bpp_ctx, device_id: c_int, hip_stream: *mut c_void) -> c_int;
@@ -214,6 +217,9 @@ extern "C" {
     pub fn bpp_comm_unique_id(id128: *mut u8) -> c_int;
     pub fn bpp_comm_create(ctx: *mut bpp_ctx, id128: *const u8, rank: c_int, world: c_int, out: *mut *mut bpp_comm) -> c_int;
     pub fn bpp_comm_adopt(ctx: *mut bpp_ctx, nccl_comm: *mut c_void, rank: c_int, world: c_int, out: *mut *mut bpp_comm) -> c_int;
+    /// The caller's own transport (MPI / TCP / gloo): `all_gather` sees HOST memory, blocks, returns 0 or an error (include/bpp.h).
+    pub fn bpp_comm_create_callbacks(ctx: *mut bpp_ctx, rank: c_int, world: c_int, all_gather: bpp_all_gather_fn, user: *mut c_void,
+                                     out: *mut *mut bpp_comm) -> c_int;
     pub fn bpp_comm_create_local(ctx: *mut bpp_ctx, group_id: u64, rank: c_int, world: c_int, out: *mut *mut bpp_comm) -> c_int;
     pub fn bpp_comm_destroy(comm: *mut bpp_comm);
     pub fn bpp_comm_last_error(comm: *mut bpp_comm) -> *const c_char;
@@ -263,7 +269,9 @@ extern "C" {
     pub fn bpp_profile_get(ctx: *mut bpp_ctx, out: *mut bpp_profile) -> c_int;
     pub fn bpp_prove_profile_get(ctx: *mut bpp_ctx, out: *mut bpp_prove_profile) -> c_int;
     pub fn bpp_host_threads() -> c_int;
+    pub fn bpp_host_pool_cpu_ns() -> u64;
     pub fn bpp_transcript_new(label: *const u8, label_len: usize, state203: *mut u8) -> c_int;
     pub fn bpp_batch_secret_bytes(ctx: *mut bpp_ctx, batch: u64, nonzero: *mut u64) -> c_int;
+    pub fn bpp_prove_secret_bytes(ctx: *mut bpp_ctx, examined: *mut u64, nonzero: *mut u64) -> c_int;
     pub fn bpp_shader_clock(ctx: *mut bpp_ctx, window_us: u32, ghz: *mut f64) -> c_int;
 }
