@@ -1,0 +1,227 @@
+// Uniform-access scalar multiplication for the terms whose scalars are SECRET AND NOTHING ELSE, where the reference itself is
+// constant-time:
+//   PedersenGens::commit            src/generators/pedersen_gens.rs:112-122   P::multiscalar_mul (dalek's constant-time Straus)
+//   the prover's witness check      src/range_proof.rs:275-284                (calls commit)
+//   A1 and B of the final round     src/range_proof.rs:572-584                `&P * Scalar` (constant-time variable-base mult)
+// Everything else on the prover's path is variable-time in the reference as well (A: vartime_mixed_multiscalar_mul :339-345;
+// every L and R: vartime_multiscalar_mul :482-495) and runs through the engine's fixed-base tables, whose ADDRESSES are digits of
+// witness-derived scalars (kernels_prove.h: k_fb_msm, kp_A) -- DESIGN.md, "What is variable-time in secrets".
+//
+// The form (the one dalek uses for those calls, restated): signed radix-16 digits of the scalar, a table of the multiples
+// 0 P .. 8 P per term, and for every digit position four doublings and ONE addition of the entry the digit names -- found by
+// reading ALL nine entries and keeping one under an arithmetic mask, the sign applied by a select.  No branch and no address
+// depends on the scalar: the sequence of table reads is the same for every scalar (tests/test_host_arith.py records it through
+// BPP_CT_TOUCH in a host build and compares two scalars' traces), and so is the instruction stream.
+//
+// On the device one term runs on one QUAD (msm.h: lane q of the quad holds coordinate q of the accumulator, a doubling or an
+// addition is two rounds of four field products), a workgroup of 64 lanes sums up to 16 terms of one output.
+#pragma once
+#include "point.h"
+#include "scalar.h"
+#if defined(__HIPCC__)
+#include "msm.h"  // the quad forms of the point operations
+#endif
+
+namespace bpp {
+
+#define BPP_CT_DIGITS 64
+#define BPP_CT_ENTRIES 9  // 0 P .. 8 P
+
+#ifndef BPP_CT_TOUCH
+#define BPP_CT_TOUCH(entry) \
+  do {                      \
+  } while (0)
+#endif
+
+// signed radix-16 digits of a canonical scalar (< 2^253): 64 digits, d_0 .. d_62 in [-8, 8), d_63 in [0, 2].  Branch-free.
+BPP_HD void ct_recode16(int8_t d[BPP_CT_DIGITS], const sc &s) {
+  int32_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < BPP_CT_DIGITS; i++) {
+    int32_t v = (int32_t)((s.v[i >> 3] >> (4 * (i & 7))) & 15u) + carry;
+    carry = (i + 1 < BPP_CT_DIGITS) ? ((v + 8) >> 4) : 0;
+    v -= carry << 4;
+    d[i] = (int8_t)v;
+  }
+}
+
+// out[0..N) = table[mag][0..N): every entry is read, one is kept.  `table` = BPP_CT_ENTRIES rows of `row_stride` words.
+template <int N>
+BPP_HD void ct_select_words(uint32_t (&out)[N], const uint32_t *table, uint32_t row_stride, uint32_t mag) {
+#pragma unroll
+  for (int k = 0; k < N; k++) out[k] = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < BPP_CT_ENTRIES; j++) {
+    BPP_CT_TOUCH(j);
+    const uint32_t keep = 0u - (((j ^ mag) - 1u) >> 31);  // all ones iff j == mag (j ^ mag < 2^31)
+#pragma unroll
+    for (int k = 0; k < N; k++) out[k] |= table[(size_t)j * row_stride + k] & keep;
+  }
+}
+
+// |d| and the sign of a digit without a branch
+BPP_HD void ct_digit_parts(uint32_t &mag, uint32_t &neg, int32_t d) {
+  const int32_t m = d >> 31;  // 0 or -1
+  mag = (uint32_t)((d ^ m) - m);
+  neg = (uint32_t)m & 1u;
+}
+
+// h = neg ? -f : f by word-wise selects (f reduced)
+BPP_HD void fe_cneg_select(fe &h, const fe &f, uint32_t neg) {
+  fe n;
+  fe_neg(n, f);
+  const uint32_t keep = 0u - neg;
+#pragma unroll
+  for (int i = 0; i < 10; i++) h.v[i] = (n.v[i] & keep) | (f.v[i] & ~keep);
+}
+
+// ---- the whole multiplication on ONE lane: the host probe's form (and the definition the quad form is held to) ----
+BPP_HD void ct_scalarmul(ge &r, const ge &p, const sc &s) {
+  ge tab[BPP_CT_ENTRIES];
+  ge_identity(tab[0]);
+  tab[1] = p;
+  for (int j = 2; j < BPP_CT_ENTRIES; j++) ge_add(tab[j], tab[j - 1], p);
+  // entries with carried limbs: what ct_select_words ORs together must be valid limbs of ONE entry
+  for (int j = 0; j < BPP_CT_ENTRIES; j++) {
+    fe_carry(tab[j].X);
+    fe_carry(tab[j].Y);
+    fe_carry(tab[j].Z);
+    fe_carry(tab[j].T);
+  }
+  int8_t d[BPP_CT_DIGITS];
+  ct_recode16(d, s);
+  ge acc;
+  ge_identity(acc);
+  for (int i = BPP_CT_DIGITS - 1; i >= 0; i--) {
+    if (i != BPP_CT_DIGITS - 1)
+      for (int k = 0; k < 4; k++) ge_dbl(acc, acc);
+    uint32_t mag, neg;
+    ct_digit_parts(mag, neg, d[i]);
+    uint32_t w[40];
+    ct_select_words<40>(w, (const uint32_t *)tab, 40, mag);
+    ge q;
+    for (int k = 0; k < 10; k++) {
+      q.X.v[k] = w[k];
+      q.Y.v[k] = w[10 + k];
+      q.Z.v[k] = w[20 + k];
+      q.T.v[k] = w[30 + k];
+    }
+    fe_cneg_select(q.X, q.X, neg);
+    fe_cneg_select(q.T, q.T, neg);
+    ge_add(acc, acc, q);
+  }
+  r = acc;
+}
+
+#if defined(__HIPCC__)
+#define CT_MAX_TERMS 16
+struct CtShared {
+  uint32_t tab[CT_MAX_TERMS][BPP_CT_ENTRIES][4][10];  // [term][entry][coordinate][limb]
+  int8_t dig[CT_MAX_TERMS][BPP_CT_DIGITS];
+  ge part[CT_MAX_TERMS];
+};
+
+// out[o] = sum_{i < count[o]} scal[o][i] * point(tidx[o][i]),  count[o] <= CT_MAX_TERMS; one workgroup of 64 lanes per output, one
+// quad per term.  point(idx) = dyn[idx & 0x7fffffff] when bit 31 is set (a per-call point in extended coordinates), else the
+// affine-Niels table line bases[idx] (the parameter set's generator table: Pedersen bases at n_gen + k, H at n_gen + t).
+#define BPP_CT_DYN 0x80000000u
+__global__ void __launch_bounds__(64) k_ct_msm(const sc *__restrict__ scal, const uint32_t *__restrict__ tidx,
+                                               const uint32_t *__restrict__ count, uint32_t stride, const niels *__restrict__ bases,
+                                               const ge *__restrict__ dyn, ge *__restrict__ out) {
+  const uint32_t o = blockIdx.x, lane = threadIdx.x, qi = lane & 3u, term = lane >> 2;
+  const QuadMask q = quad_mask(qi);
+  const uint32_t n = count[o] < CT_MAX_TERMS ? count[o] : CT_MAX_TERMS;
+  __shared__ CtShared sh;
+  const bool active = term < n;  // (idle quads run the same instruction stream on the output's first term and write nothing)
+  const uint32_t it = active ? term : 0u;
+  const uint32_t idx = tidx[(size_t)o * stride + it];
+  ge p;
+  if (idx & BPP_CT_DYN) {
+    p = dyn[idx & ~BPP_CT_DYN];
+  } else {
+    const niels b = bases[idx];
+    ge_from_niels(p, b);
+  }
+  fe d2, one;
+  fe_const(d2, FE_D2);
+  fe_1(one);
+  // table 0 P .. 8 P, every entry's coordinate qi written by lane qi with carried limbs
+  auto store_entry = [&](uint32_t j, const fe &m) {
+    fe c = m;
+    fe_carry(c);
+#pragma unroll
+    for (int k = 0; k < 10; k++) sh.tab[term][j][qi][k] = c.v[k];
+  };
+  fe m;
+  {
+    ge id;
+    ge_identity(id);
+    quad_load(m, q, id);
+    store_entry(0, m);
+  }
+  quad_load(m, q, p);
+  store_entry(1, m);
+#pragma unroll 1
+  for (uint32_t j = 2; j < BPP_CT_ENTRIES; j++) {
+    quad_ge_add(m, q, p, d2, one);
+    store_entry(j, m);
+  }
+  if (qi == 0) {
+    const sc s = scal[(size_t)o * stride + it];
+    ct_recode16(sh.dig[term], s);
+  }
+  __syncthreads();
+  {
+    ge id;
+    ge_identity(id);
+    quad_load(m, q, id);
+  }
+#pragma unroll 1
+  for (int i = BPP_CT_DIGITS - 1; i >= 0; i--) {
+    if (i != BPP_CT_DIGITS - 1) {
+#pragma unroll 1
+      for (int k = 0; k < 4; k++) quad_ge_dbl(m, q);
+    }
+    uint32_t mag, neg;
+    ct_digit_parts(mag, neg, (int32_t)sh.dig[term][i]);
+    uint32_t w[10];
+    ct_select_words<10>(w, &sh.tab[term][0][qi][0], 40, mag);  // this lane's coordinate of ALL nine entries
+    fe mine, flipped;
+#pragma unroll
+    for (int k = 0; k < 10; k++) mine.v[k] = w[k];
+    fe_cneg_select(flipped, mine, neg);
+    // -P = (-X, Y, Z, -T): lanes 0 and 3 take the (possibly) negated coordinate; a select on the lane's position, not a branch
+    {
+      const uint32_t xt = 0u - (uint32_t)((qi == 0u) | (qi == 3u));
+#pragma unroll
+      for (int k = 0; k < 10; k++) mine.v[k] = (flipped.v[k] & xt) | (mine.v[k] & ~xt);
+    }
+    ge other;
+    quad_gather(other, mine);
+    quad_ge_add(m, q, other, d2, one);
+  }
+  {
+    ge acc;
+    quad_gather(acc, m);
+    if (qi == 0) sh.part[term] = acc;
+  }
+  __syncthreads();
+  if (term == 0) {  // the output's terms, summed by the first quad (count is public)
+    ge first = sh.part[0];
+    quad_load(m, q, first);
+#pragma unroll 1
+    for (uint32_t j = 1; j < n; j++) {
+      const ge pj = sh.part[j];
+      quad_ge_add(m, q, pj, d2, one);
+    }
+    ge acc;
+    quad_gather(acc, m);
+    if (qi == 0) out[o] = acc;
+  }
+  // the digits and the table of multiples are secret-derived: leave nothing in LDS for the next workgroup on this CU
+  __syncthreads();
+  for (uint32_t k = lane; k < sizeof(CtShared) / 4; k += 64) ((uint32_t *)&sh)[k] = 0;
+}
+#endif
+
+}  // namespace bpp

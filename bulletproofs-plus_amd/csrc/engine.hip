@@ -29,6 +29,7 @@
 
 #include "../../include/bpp.h"
 #include "chain_host.h"
+#include "ct.h"
 #include "kernels_prove.h"
 #include "kernels_verify.h"
 #include "msm.h"
@@ -535,7 +536,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1;
+        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -574,6 +575,7 @@ const OptionName kOptions[] = {
     {"fused_columns", "BPP_FUSED_COLUMNS", &bpp_ctx::Options::fused_columns},
     {"prove_prio", "BPP_PROVE_PRIO", &bpp_ctx::Options::prove_prio},
     {"prove_fused", "BPP_PROVE_FUSED", &bpp_ctx::Options::prove_fused},
+    {"ct", "BPP_CT", &bpp_ctx::Options::ct},
     {"static_gemm", "BPP_STATIC_GEMM", &bpp_ctx::Options::static_gemm},
     {"lazy_columns", "BPP_LAZY_COLUMNS", &bpp_ctx::Options::lazy_columns},
 };
@@ -1204,6 +1206,17 @@ int bpp_pedersen_commit(bpp_ctx *ctx, uint64_t params, const uint64_t *values, c
       gidx[j * per] = P.t;  // H is the last entry of fb_ped
       for (uint32_t k = 0; k < n_blind; k++) gidx[j * per + 1 + k] = k;
     }
+    // value and blinding factors are secrets and nothing else: the reference commits with dalek's CONSTANT-TIME multiscalar_mul
+    // (src/generators/pedersen_gens.rs:112-122).  Default here: the uniform-access form (ct.h: every table entry read, masked
+    // select, no scalar-dependent address or branch).  Option "ct" = 0 takes the fixed-base tables instead, whose addresses are
+    // the scalars' digits (faster by far; for callers whose values are public, e.g. the bench's input generation).
+    const bool ct = ctx->opt.ct != 0;
+    const uint32_t n_gen = 2 * P.n_bits * P.m_max;
+    if (ct)  // indices into the parameter set's generator table: G_k at n_gen + k, H at n_gen + t
+      for (size_t j = 0; j < count; j++) {
+        gidx[j * per] = n_gen + P.t;
+        for (uint32_t k = 0; k < n_blind; k++) gidx[j * per + 1 + k] = n_gen + k;
+      }
     DevBuf<uint32_t> d_g, d_c;
     DevBuf<uint8_t> d_out;
     d_sc.alloc(count * per);
@@ -1216,8 +1229,11 @@ int bpp_pedersen_commit(bpp_ctx *ctx, uint64_t params, const uint64_t *values, c
     HIP_CHECK(hipMemcpyAsync(d_c.p, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, s));
     DevBuf<ge> d_ge;
     d_ge.alloc(count);
-    hipLaunchKernelGGL(k_fb_msm, dim3((uint32_t)count), dim3(fb_threads(ctx, per, P.fb_ped_geo)), 0, s, d_sc.p, d_g.p, d_c.p, per, P.fb_ped.p, P.fb_ped_geo,
-                       d_ge.p);
+    if (ct)
+      hipLaunchKernelGGL(k_ct_msm, dim3((uint32_t)count), dim3(64), 0, s, d_sc.p, d_g.p, d_c.p, per, P.table.p, (const ge *)nullptr, d_ge.p);
+    else
+      hipLaunchKernelGGL(k_fb_msm, dim3((uint32_t)count), dim3(fb_threads(ctx, per, P.fb_ped_geo)), 0, s, d_sc.p, d_g.p, d_c.p, per, P.fb_ped.p,
+                         P.fb_ped_geo, d_ge.p);
     hipLaunchKernelGGL(k_compress_ge, dim3(cdiv((uint32_t)count, 64)), dim3(64), 0, s, d_ge.p, (uint32_t)count, d_out.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(commitments32, d_out.p, count * 32, hipMemcpyDeviceToHost, s));

@@ -164,6 +164,9 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     // profiles/r04_prover_launches.txt), the MSMs of the two sub-batches drift into each other, and every period has ~110 us
     // in which no MSM runs.  With prove_prio the small kernels go to a HIGH-priority stream of their own (the hardware hands
     // freed wave slots to that queue first), joined to the MSM stream by an event each way per round.
+    // secret-only terms -- the witness check's commit(v, r) and A1 / B -- through the uniform-access form (ct.h), as the reference does
+    // them in constant time (src/generators/pedersen_gens.rs:112-122, src/range_proof.rs:572-584); "ct" = 0: through the fixed-base tables
+    const bool ct = ctx->opt.ct != 0;
     const bool fused = ctx->opt.prove_fused != 0;  // one launch per round for encoding + Fiat-Shamir step + vector step (tests run both)
     const bool prio = ctx->opt.prove_prio > 0;  // (off by default: measured, no gain -- profiles/r04_prover_prio_ab.txt)
     if (prio) {
@@ -211,8 +214,9 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       uint64_t *d_minvals;
       ProveState *d_ps;
       sc *d_vec, *d_ts, *d_cts;
-      uint32_t *d_tg, *d_tc, *d_ctg, *d_ctc;
-      ge *d_ge;
+      uint32_t *d_tg, *d_tc, *d_ctg, *d_ctc, *d_ftg, *d_ftc;
+      sc *d_fts;
+      ge *d_ge, *d_ge_ct;
     };
     std::vector<Sub> subs(n_sub);
     size_t arena_need = 0;
@@ -253,11 +257,22 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         u.d_ctg = (uint32_t *)take(nb * m * (1 + t) * 4);
         u.d_ctc = (uint32_t *)take(nb * m * 4);
         u.d_ge = (ge *)take(std::max<size_t>(nb * m, 2 * nb) * sizeof(ge));
+        u.d_fts = (sc *)take(nb * 2 * CT_ROW * sizeof(sc));
+        u.d_ftg = (uint32_t *)take(nb * 2 * CT_ROW * 4);
+        u.d_ftc = (uint32_t *)take(nb * 2 * 4);
+        u.d_ge_ct = (ge *)take(2 * nb * sizeof(ge));
         u.arena_len = arena_need - u.arena_lo;
       }
     };
     carve();
-    ctx->prove_arena.alloc(arena_need + 256);
+    {
+      // a fresh arena starts out zero as a whole: the alignment gaps between the sub-batches' ranges and the slack at its end
+      // are written by nothing and wiped by nothing, and what hipMalloc hands out is not zero -- bpp_prove_secret_bytes (and
+      // anyone reading the arena) must see zeros there, not somebody's left-overs
+      const uint8_t *before = ctx->prove_arena.p;
+      ctx->prove_arena.alloc(arena_need + 256);
+      if (ctx->prove_arena.p != before) HIP_CHECK(hipMemset(ctx->prove_arena.p, 0, ctx->prove_arena.n));
+    }
     arena_base = ctx->prove_arena.p;
     carve();
     // descriptors are relative to each sub-batch's own byte block / minimum-value rows
@@ -324,10 +339,14 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       HIP_CHECK(hipStreamWaitEvent(sx, ctx->prove_aux_events[2 * q], 0));
       hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(nb * m, 64)), b64, 0, sx, u.d_bytes, u.d_desc, t, n_gen, nb, m, 1 + t, u.d_cts,
                          u.d_ctg, u.d_ctc);
-      fb_mark(sx);
-      hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(ctx, 1 + t, P.fb_geo)), 0, sx, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p, P.fb_geo,
-                         u.d_ge);
-      fb_mark(sx);
+      if (ct) {
+        hipLaunchKernelGGL(k_ct_msm, dim3(nb * m), b64, 0, sx, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.table.p, (const ge *)nullptr, u.d_ge);
+      } else {
+        fb_mark(sx);
+        hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(ctx, 1 + t, P.fb_geo)), 0, sx, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p,
+                           P.fb_geo, u.d_ge);
+        fb_mark(sx);
+      }
       hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, sx, u.d_ge, nb * m, u.d_commit32);
       HIP_CHECK(hipEventRecord(ctx->prove_aux_events[2 * q + 1], sx));
       hipLaunchKernelGGL(kp_init, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_states, P.d_hg32.p, n, t, nb, u.d_ps);
@@ -342,11 +361,12 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         uint8_t *lr_prev = j ? u.d_lr + (size_t)(j - 1) * nb * 64 : nullptr;
         if (fused) {  // the previous round's L / R are encoded by the same launch (kernels_prove.h: kp_round)
           hipLaunchKernelGGL(kp_round, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, nb, j, rounds, stride,
-                             u.d_a32, j ? u.d_ge : (const ge *)nullptr, lr_prev, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
+                             u.d_a32, j ? u.d_ge : (const ge *)nullptr, lr_prev, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc, ct ? u.d_fts : (sc *)nullptr,
+                             u.d_ftg, u.d_ftc);
         } else {
           hipLaunchKernelGGL(kp_lane, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
           hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
-                             stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc);
+                             stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc, ct ? u.d_fts : (sc *)nullptr, u.d_ftg, u.d_ftc);
         }
         uint8_t *out = (j < rounds) ? u.d_lr + (size_t)j * nb * 64 : u.d_a1b;
         if (j == 0) {  // the witness check joins here: its verdict into the proof's status, its buffer free for the round's MSM
@@ -359,8 +379,12 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
                            u.d_ge);
         fb_mark(sm);
         to_lane(q);
-        if (!fused || j == rounds)  // (A1 and B of the last launch: kp_finish is a one-lane-per-proof kernel)
+        if (ct && j == rounds) {  // the secret scalars of A1 and B over the two folded generators just made and the Pedersen bases
+          hipLaunchKernelGGL(k_ct_msm, dim3(2 * nb), b64, 0, s, u.d_fts, u.d_ftg, u.d_ftc, CT_ROW, P.table.p, u.d_ge, u.d_ge_ct);
+          hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge_ct, 2 * nb, out);
+        } else if (!fused || j == rounds) {  // (A1 and B of the last launch: kp_finish is a one-lane-per-proof kernel)
           hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);
+        }
       }
     for (uint32_t q = 0; q < n_sub; q++) {
       Sub &u = subs[q];
@@ -390,7 +414,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       pp.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
       // terms handed to k_fb_msm: witness check m x (1 + t); per round L and R of mn + t + 1 terms each (every generator
       // lands in exactly one of the two); the final step's A1 (every generator once more: 2 mn + t + 1 terms) and B (t + 1)
-      pp.fb_terms = (uint64_t)B * ((uint64_t)m * (1 + t) + (uint64_t)rounds * 2 * (mn + t + 1) + 2 * mn + 2 * t + 2);
+      pp.fb_terms = (uint64_t)B * ((ct ? 0ull : (uint64_t)m * (1 + t)) + (uint64_t)rounds * 2 * (mn + t + 1) + 2 * mn + (ct ? 0u : 2 * t + 2));
       pp.fb_launches = (uint32_t)(ev_used / 2);
       pp.fb_window_bits = P.fb_geo.wbits;
       pp.fb_windows = P.fb_geo.items;  // additions per term

@@ -7,8 +7,33 @@
 #include "chain_host.h"
 #include "recode.h"
 #include "upload_host.h"
+// the uniform-access scalar multiplication (ct.h) with its table reads RECORDED: BPP_CT_TOUCH(entry) appends the entry index
+#include <vector>
+static thread_local std::vector<uint8_t> *g_ct_trace = nullptr;
+#define BPP_CT_TOUCH(entry)                                      \
+  do {                                                           \
+    if (g_ct_trace) g_ct_trace->push_back((uint8_t)(entry));     \
+  } while (0)
+#include "ct.h"
 using namespace bpp;
 extern "C" {
+// scalar * P through ct_scalarmul -> compressed result; trace_out (may be null) receives the sequence of table entries read
+// (trace_cap bytes at most), *trace_len their number.  0 if P does not decode.
+int ht_ct_scalarmul(const uint8_t point32[32], const uint8_t scalar32[32], uint8_t out32[32], uint8_t *trace_out, size_t trace_cap,
+                    size_t *trace_len) {
+  niels n; if (!ristretto_decompress(n, point32)) return 0;
+  ge p; ge_from_niels(p, n);
+  sc s; sc_load_words(s, scalar32);
+  std::vector<uint8_t> tr;
+  g_ct_trace = &tr;
+  ge r; ct_scalarmul(r, p, s);
+  g_ct_trace = nullptr;
+  ristretto_compress(out32, r);
+  if (trace_len) *trace_len = tr.size();
+  if (trace_out) memcpy(trace_out, tr.data(), tr.size() < trace_cap ? tr.size() : trace_cap);
+  return 1; }
+// the recoding alone: 64 signed radix-16 digits whose weighted sum is the scalar
+void ht_ct_recode16(const uint8_t scalar32[32], int8_t digits[64]) { sc s; sc_load_words(s, scalar32); ct_recode16(digits, s); }
 void ht_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe x, y, z; fe_frombytes(x, a); fe_frombytes(y, b); fe_mul(z, x, y); fe_tobytes(out, z); }
 void ht_fe_sq(const uint8_t a[32], uint8_t out[32]) { fe x, z; fe_frombytes(x, a); fe_sq(z, x); fe_tobytes(out, z); }
 void ht_fe_addsubmul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {  // (a+b)*(a-b) with lazy limbs

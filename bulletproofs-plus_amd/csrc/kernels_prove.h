@@ -14,6 +14,7 @@
 #pragma once
 #include <stdlib.h>
 
+#include "ct.h"
 #include "kernels_verify.h"
 #include "recode.h"
 #include "wstrobe.h"
@@ -208,6 +209,8 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ sc
   }
   if (tid == 0) out[o] = sh.red[0];
 }
+
+#define CT_ROW 16u  // terms per row of the final round's secret-only term lists (3 + t <= 9 used)
 
 // ---------------------------------------------------------------- per-proof prover state
 struct ProveDesc {
@@ -530,7 +533,8 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
                                              uint32_t n_bits, uint32_t t, uint32_t n_gen, uint32_t j, uint32_t rounds,
                                              uint32_t stride, ProveState *ps, sc *__restrict__ vec,
                                              sc *__restrict__ term_scal, uint32_t *__restrict__ term_gidx,
-                                             uint32_t *__restrict__ term_count) {
+                                             uint32_t *__restrict__ term_count, sc *__restrict__ ct_scal,
+                                             uint32_t *__restrict__ ct_idx, uint32_t *__restrict__ ct_count) {
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
   const ProveDesc d = desc[p];
   ProveState &st = ps[p];
@@ -734,6 +738,62 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
   } else {
     // final step (:574-584): A1 = r Gf[0] + s Hf[0] + (r y b + s y a) H + sum d_k G_k ;  B = (r y s) H + sum eta_k G_k
     const sc r = st.r, s = st.s, y = st.y;
+    if (ct_scal) {
+      // The reference multiplies by r, s, d_k, eta_k and the H scalars in constant time (`&P * Scalar`, :574-584): every scalar of
+      // A1 and B is a secret.  Here the fixed-base MSM gets PUBLIC scalars only -- Gf[0] = sum cG[u] G_u (output 0) and
+      // Hf[0] = sum cH[u] H_u (output 1), the folded generators, functions of the challenges -- and the secret scalars go to the
+      // uniform-access form (ct.h: k_ct_msm) as two short term rows per proof over those two points and the Pedersen bases:
+      //   A1: r Gf[0], s Hf[0], (r y b + s y a) H, d_k G_k      B: (r y s) H, eta_k G_k
+      for (uint32_t u = lane; u < mn; u += 64) {
+        sc sg, sh;
+        sc_from_mont(sg, cG[u]);
+        sc_from_mont(sh, cH[u]);
+        ts[u] = sg;
+        tg[u] = 2 * u;
+        ts[stride + u] = sh;
+        tg[stride + u] = 2 * u + 1;
+      }
+      sc *fs = ct_scal + (size_t)p * 2 * CT_ROW;
+      uint32_t *fi = ct_idx + (size_t)p * 2 * CT_ROW;
+      if (lane <= t) {
+        sc s1v, s2v;
+        if (lane < t) {
+          s1v = st.dd[lane];
+          s2v = st.eta[lane];
+        } else {
+          sc u, v;
+          sc_montmul(u, r, y);
+          sc_montmul(u, u, b[0]);
+          sc_montmul(v, s, y);
+          sc_montmul(v, v, a[0]);
+          sc_add(s1v, u, v);
+          sc_montmul(s2v, r, y);
+          sc_montmul(s2v, s2v, s);
+        }
+        sc_from_mont(s1v, s1v);
+        sc_from_mont(s2v, s2v);
+        // lane t carries the H terms (rows' positions 2 and 0), lanes k < t the G_k terms
+        const uint32_t pa = lane < t ? 3 + lane : 2, pb = lane < t ? 1 + lane : 0;
+        fs[pa] = s1v;
+        fi[pa] = n_gen + lane;
+        fs[CT_ROW + pb] = s2v;
+        fi[CT_ROW + pb] = n_gen + lane;
+      }
+      if (lane < 2) {
+        sc v = lane ? s : r;
+        sc_from_mont(v, v);
+        fs[lane] = v;
+        fi[lane] = BPP_CT_DYN | (2 * p + lane);  // this proof's Gf[0] / Hf[0] among the fixed-base MSM's outputs
+      }
+      if (lane == 0) {
+        term_count[2 * p] = mn;
+        term_count[2 * p + 1] = mn;
+        ct_count[2 * p] = 3 + t;
+        ct_count[2 * p + 1] = 1 + t;
+      }
+      KP_MARK(12);
+      return;
+    }
     for (uint32_t u = lane; u < mn; u += 64) {
       sc sg, sh;
       sc_montmul(sg, r, cG[u]);
@@ -785,8 +845,10 @@ __global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes,
                                               const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present, uint32_t n_bits,
                                               uint32_t t, uint32_t n_gen, uint32_t j, uint32_t rounds, uint32_t stride, ProveState *ps,
                                               sc *__restrict__ vec, sc *__restrict__ term_scal, uint32_t *__restrict__ term_gidx,
-                                              uint32_t *__restrict__ term_count) {
-  kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count);
+                                              uint32_t *__restrict__ term_count, sc *__restrict__ ct_scal, uint32_t *__restrict__ ct_idx,
+                                              uint32_t *__restrict__ ct_count) {
+  kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count, ct_scal,
+               ct_idx, ct_count);
 }
 // ... and as ONE launch per round (round 4): the encoding of the previous round's L and R (two lanes, ristretto_compress), the
 // Fiat-Shamir step and the vector step of a proof are consecutive phases of the same 64-lane workgroup.  As three launches per
@@ -799,7 +861,8 @@ __global__ void __launch_bounds__(64) kp_round(const uint8_t *__restrict__ bytes
                                                uint32_t t, uint32_t n_gen, uint32_t B, uint32_t j, uint32_t rounds, uint32_t stride,
                                                const uint8_t *__restrict__ a32, const ge *__restrict__ ge_prev, uint8_t *lr_prev,
                                                ProveState *ps, sc *__restrict__ vec, sc *__restrict__ term_scal,
-                                               uint32_t *__restrict__ term_gidx, uint32_t *__restrict__ term_count) {
+                                               uint32_t *__restrict__ term_gidx, uint32_t *__restrict__ term_count,
+                                               sc *__restrict__ ct_scal, uint32_t *__restrict__ ct_idx, uint32_t *__restrict__ ct_count) {
   const uint32_t p = blockIdx.x;
   if (p >= B) return;
   KP_T0();
@@ -815,7 +878,8 @@ __global__ void __launch_bounds__(64) kp_round(const uint8_t *__restrict__ bytes
   KP_MARK(0);
   kp_lane_body(bytes, desc, n_bits, t, B, j, rounds, a32, lr_prev, ps);
   __syncthreads();
-  kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count);
+  kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count, ct_scal,
+               ct_idx, ct_count);
 }
 
 // ---- final lane kernel: challenge_final_e, responses, wire bytes (:587-607, to_bytes :1120-1150) ----

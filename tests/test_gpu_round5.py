@@ -277,3 +277,61 @@ def test_prover_secrets_are_wiped(bpp, packed):
     assert secret()[1] == 0
     params.close()
     eng.close()
+
+
+@pytest.mark.parametrize("m,t,seeded", [(1, 1, True), (2, 3, False), (4, 6, False), (1, 2, False)])
+def test_uniform_access_path_gives_the_oracles_bytes(bpp, packed, m, t, seeded):
+    """The secret-only terms through ct.h's uniform-access form (option "ct", default on) -- bpp_pedersen_commit
+    (src/generators/pedersen_gens.rs:112-122), the prover's witness check (src/range_proof.rs:275-284) and A1 / B (:572-584):
+    commitments and whole proofs are the ORACLE's bytes, and the same bytes as with the fixed-base tables ("ct" = 0); edge
+    scalars (0, 1, l - 1, 2^64 - 1) through the commit; a wrong opening is still refused; one launch per round and three."""
+    import bench
+    from oracle import cport
+    from oracle.pyref import curve as C
+    eng = bpp.Engine(0)
+    params = bpp.RangeParameters.init(64, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=eng)
+    cp = cport.Params(64, m, t)
+    # commit: edge scalars and random ones, 1..t blinding factors
+    rng = np.random.default_rng(900 + 10 * m + t)
+    edge = [0, 1, C.L - 1, C.L - 2, 2**252, 8, 7, int("8" * 63, 16) % C.L]
+    for nb in range(1, t + 1):
+        k = 24
+        values = np.array([0, 1, 2**64 - 1, 2**63] + [int(x) for x in rng.integers(0, 2**63, size=k - 4)], dtype=np.uint64)
+        bl = rng.integers(0, 256, size=(k, nb, 32), dtype=np.uint8)
+        bl[..., 31] &= 0x0f
+        for i, e in enumerate(edge):
+            bl[i, i % nb] = np.frombuffer(int(e).to_bytes(32, "little"), dtype=np.uint8)
+        got = {}
+        for ct in (1, 0):
+            eng.set_option("ct", ct)
+            got[ct] = packed.commit(params, values, bl)
+        assert (got[1] == got[0]).all()
+        for i in range(k):
+            assert bytes(got[1][i]) == cp.commit(int(values[i]), [bytes(bl[i, j]) for j in range(nb)]), (nb, i)
+    # whole proofs
+    eng.set_option("ct", 0)
+    d = bench.make_inputs(np, packed, params, 20, seed=7000 + 10 * m + t)
+    if not seeded:
+        d["seeds"] = None
+    args = [params, d["values"], d["blindings"], d["commitments"], d["min_values"], d["min_present"], d["seeds"], LABEL, d["ext"]]
+    out = {}
+    for ct in (0, 1):
+        for fused in (1, 0):
+            eng.set_option("ct", ct)
+            eng.set_option("prove_fused", fused)
+            out[(ct, fused)] = packed.prove(*args)
+    ref = out[(0, 1)]
+    assert all((v == ref).all() for v in out.values())
+    for i in (0, 7, 19):
+        want, _ = cp.prove(LABEL, [int(x) for x in d["values"][i]], [[bytes(d["blindings"][i, j, k]) for k in range(t)] for j in range(m)],
+                           [int(x) for x in d["min_values"][i]], bytes(d["seeds"][i]) if d["seeds"] is not None else None, bytes(d["ext"][i]))
+        assert bytes(ref[i]) == want
+    eng.set_option("ct", 1)
+    eng.set_option("prove_fused", -1)
+    bad = d["commitments"].copy()
+    bad[3, 0] = d["commitments"][4, 0]
+    with pytest.raises(bpp.ProofError, match="Witness opening is invalid"):
+        packed.prove(params, d["values"], d["blindings"], bad, d["min_values"], d["min_present"], d["seeds"], LABEL, d["ext"])
+    cp.close()
+    params.close()
+    eng.close()

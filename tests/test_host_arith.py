@@ -279,3 +279,27 @@ def test_weight_chain_single_forms(ht):
                 t.append_message(b"proof", rng[i * 32:(i + 1) * 32])
             wr = t.build_rng().finalize(O.NullRng())
             assert outs[0] == b"".join(C.scalar_bytes(O.random_not_zero(wr)) for _ in range(n))
+
+
+def test_uniform_access_scalar_multiplication(ht):
+    """csrc/ct.h, host-compiled with its table reads recorded (BPP_CT_TOUCH): the form behind bpp_pedersen_commit, the prover's
+    witness check and A1 / B -- where the reference is constant-time (src/generators/pedersen_gens.rs:112-122,
+    src/range_proof.rs:275-284,572-584).  (1) results equal the oracle's scalar multiplication, edge scalars included;
+    (2) the signed radix-16 digits add up to the scalar and stay in range; (3) the SEQUENCE OF TABLE ENTRIES READ is the same
+    for every scalar and every point: 64 digit positions x all nine entries, in order -- no read depends on a secret."""
+    ht.ht_ct_scalarmul.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
+                                   ctypes.POINTER(ctypes.c_size_t)]
+    scalars = [0, 1, 2, 7, 8, 9, 15, 16, 17, L - 1, L - 2, 2**252, 2**252 - 1, (L - 1) // 2, 0x8888888888888888, 2**128 - 1,
+               int("8" * 63, 16) % L, int("7" * 63, 16) % L] + [int.from_bytes(_r(b"ctk", i), "little") % L for i in range(24)]
+    traces = set()
+    for i, k in enumerate(scalars):
+        pt = C.from_uniform_bytes(_r(b"ctp", i % 5, 64))
+        out, tr, n = _buf(), ctypes.create_string_buffer(4096), ctypes.c_size_t()
+        assert ht.ht_ct_scalarmul(pt.compress(), k.to_bytes(32, "little"), out, tr, 4096, ctypes.byref(n)) == 1
+        assert out.raw == (pt * k).compress(), k
+        traces.add(tr.raw[:n.value])
+        dig = (ctypes.c_int8 * 64)()
+        ht.ht_ct_recode16(k.to_bytes(32, "little"), dig)
+        assert sum(int(d) << (4 * j) for j, d in enumerate(dig)) == k
+        assert all(-8 <= int(d) < 8 for d in dig[:63]) and 0 <= int(dig[63]) <= 2
+    assert traces == {bytes(range(9)) * 64}, "a table read depends on the scalar"
