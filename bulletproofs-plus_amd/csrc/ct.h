@@ -45,15 +45,16 @@ BPP_HD void ct_recode16(int8_t d[BPP_CT_DIGITS], const sc &s) {
   }
 }
 
-// out[0..N) = table[mag][0..N): every entry is read, one is kept.  `table` = BPP_CT_ENTRIES rows of `row_stride` words.
-template <int N>
-BPP_HD void ct_select_words(uint32_t (&out)[N], const uint32_t *table, uint32_t row_stride, uint32_t mag) {
+// out[0..N) = the row that holds multiple `mag`, rows = multiples first, first + 1, .., first + E - 1 (zero when mag is none of
+// them): EVERY row is read, one is kept.  `table` = E rows of `row_stride` words.
+template <int N, int E = BPP_CT_ENTRIES>
+BPP_HD void ct_select_words(uint32_t (&out)[N], const uint32_t *table, uint32_t row_stride, uint32_t mag, uint32_t first = 0) {
 #pragma unroll
   for (int k = 0; k < N; k++) out[k] = 0;
 #pragma unroll
-  for (uint32_t j = 0; j < BPP_CT_ENTRIES; j++) {
+  for (uint32_t j = 0; j < (uint32_t)E; j++) {
     BPP_CT_TOUCH(j);
-    const uint32_t keep = 0u - (((j ^ mag) - 1u) >> 31);  // all ones iff j == mag (j ^ mag < 2^31)
+    const uint32_t keep = 0u - ((((j + first) ^ mag) - 1u) >> 31);  // all ones iff j + first == mag (the xor is < 2^31)
 #pragma unroll
     for (int k = 0; k < N; k++) out[k] |= table[(size_t)j * row_stride + k] & keep;
   }
@@ -113,7 +114,89 @@ BPP_HD void ct_scalarmul(ge &r, const ge &p, const sc &s) {
   r = acc;
 }
 
+// ---- FIXED bases (the Pedersen bases H, G_k of a parameter set): no doublings at all.  Table line [base][position w][j - 1] =
+// j * 16^w * Base as an affine Niels entry, j = 1..8 (64 positions x 8 lines x 128 B = 64 KB per base, built once per parameter
+// set); digit position w of a term contributes the line its digit names -- all eight lines of the position are read, one is kept
+// under a mask, a zero digit keeps none and becomes the neutral entry (1, 1, 0), the sign exchanges y+x / y-x and negates 2dxy by
+// selects -- and the 64 positions are 64 independent mixed additions.
+#define BPP_CTF_ENTRIES 8
+#define BPP_CTF_LINE_WORDS 32  // one 128-byte line
+BPP_HD void ct_fixed_select(niels &q, const niels *position_lines, int32_t digit) {
+  uint32_t mag, neg;
+  ct_digit_parts(mag, neg, digit);
+  uint32_t w[30];
+  ct_select_words<30, BPP_CTF_ENTRIES>(w, (const uint32_t *)position_lines, BPP_CTF_LINE_WORDS, mag, 1);
+  const uint32_t isz = (mag - 1u) >> 31;  // 1 iff the digit is zero: the neutral entry
+  w[0] |= isz;
+  w[10] |= isz;
+  const uint32_t sw = 0u - neg;
+  fe t2d;
+#pragma unroll
+  for (int k = 0; k < 10; k++) {
+    const uint32_t a = w[k], b = w[10 + k];
+    q.yplusx.v[k] = (b & sw) | (a & ~sw);
+    q.yminusx.v[k] = (a & sw) | (b & ~sw);
+    t2d.v[k] = w[20 + k];
+  }
+  fe_cneg_select(q.xy2d, t2d, neg);
+}
+// one lane's model of the whole sum (host probe): acc = sum_w line(w, digit_w)
+BPP_HD void ct_fixed_scalarmul(ge &r, const niels *base_lines /* [64][8] */, const sc &s) {
+  int8_t d[BPP_CT_DIGITS];
+  ct_recode16(d, s);
+  ge acc;
+  ge_identity(acc);
+  for (int w = 0; w < BPP_CT_DIGITS; w++) {
+    niels q;
+    ct_fixed_select(q, base_lines + (size_t)w * BPP_CTF_ENTRIES, d[w]);
+    ge_madd(acc, acc, q);
+  }
+  r = acc;
+}
+
 #if defined(__HIPCC__)
+#define CTF_MAX_TERMS 8
+struct CtFixedShared {
+  int8_t dig[CTF_MAX_TERMS][BPP_CT_DIGITS];
+  ge red[64];
+};
+// out[o] = sum_{i < count[o]} scal[o][i] * Base[bidx[o][i] - idx_off], count[o] <= CTF_MAX_TERMS: one wavefront per output, lane w
+// owns digit position w of every term.  `tbl` = [base][64][8] lines (k_fb_build with 4-bit windows).
+__global__ void __launch_bounds__(64) k_ct_fixed(const sc *__restrict__ scal, const uint32_t *__restrict__ bidx,
+                                                 const uint32_t *__restrict__ count, uint32_t stride, uint32_t idx_off,
+                                                 const niels *__restrict__ tbl, ge *__restrict__ out) {
+  const uint32_t o = blockIdx.x, lane = threadIdx.x;
+  const uint32_t n = count[o] < CTF_MAX_TERMS ? count[o] : CTF_MAX_TERMS;
+  __shared__ CtFixedShared sh;
+  if (lane < CTF_MAX_TERMS) {  // (lanes beyond the output's terms recode its first term again: the same instructions, unused digits)
+    const sc s = scal[(size_t)o * stride + (lane < n ? lane : 0u)];
+    ct_recode16(sh.dig[lane], s);
+  }
+  __syncthreads();
+  ge acc;
+  ge_identity(acc);
+#pragma unroll 1
+  for (uint32_t i = 0; i < n; i++) {  // the number of terms is public
+    const uint32_t b = bidx[(size_t)o * stride + i] - idx_off;
+    niels q;
+    ct_fixed_select(q, tbl + ((size_t)b * BPP_CT_DIGITS + lane) * BPP_CTF_ENTRIES, (int32_t)sh.dig[i][lane]);
+    ge_madd(acc, acc, q);
+  }
+  sh.red[lane] = acc;
+  __syncthreads();
+  for (uint32_t off = 32; off >= 1; off >>= 1) {
+    if (lane < off) {
+      ge x = sh.red[lane], y2 = sh.red[lane + off];
+      ge_add(x, x, y2);
+      sh.red[lane] = x;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) out[o] = sh.red[0];
+  __syncthreads();
+  for (uint32_t k = lane; k < sizeof(CtFixedShared) / 4; k += 64) ((uint32_t *)&sh)[k] = 0;  // digits and partial sums are secret-derived
+}
+
 #define CT_MAX_TERMS 16
 struct CtShared {
   uint32_t tab[CT_MAX_TERMS][BPP_CT_ENTRIES][4][10];  // [term][entry][coordinate][limb]

@@ -206,6 +206,7 @@ struct Params {
   DevBuf<fbent> fb_table;           // prover's fixed-base window table, built on first use (geometry fb_geo)
   FbGeom fb_geo{}, fb_ped_geo{};
   DevBuf<fbent> fb_ped;             // same for the Pedersen bases only [G_0..G_{t-1}, H], always resident (commit)
+  DevBuf<fbent> fb_ct;              // the Pedersen bases' 4-bit lines for the uniform-access form (ct.h: k_ct_fixed), [base][64][8]
 };
 
 struct Precomp {
@@ -1124,6 +1125,15 @@ int bpp_params_create(bpp_ctx *ctx, uint32_t bit_length, uint32_t max_aggregatio
     hipLaunchKernelGGL(k_fb_build,
                        dim3(cdiv((t + 1) * P->fb_ped_geo.windows * cdiv(P->fb_ped_geo.entries, FB_BUILD_BLOCK), 64)), dim3(64), 0,
                        ctx->stream, P->table.p + n_gen, t + 1, P->fb_ped_geo, P->fb_ped.p);
+    {  // j * 16^w * Base, j = 1..8, w = 0..63: the lines k_ct_fixed reads (all eight of a position, every time)
+      FbGeom g4;
+      g4.wbits = 4;
+      g4.windows = BPP_CT_DIGITS;
+      g4.entries = BPP_CTF_ENTRIES;
+      g4.items = BPP_CT_DIGITS;
+      P->fb_ct.alloc((size_t)(t + 1) * fb_stride(g4));
+      hipLaunchKernelGGL(k_fb_build, dim3(cdiv((t + 1) * g4.windows, 64)), dim3(64), 0, ctx->stream, P->table.p + n_gen, t + 1, g4, P->fb_ct.p);
+    }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     P->d_hg32.alloc(P->hg32.size());
@@ -1230,7 +1240,7 @@ int bpp_pedersen_commit(bpp_ctx *ctx, uint64_t params, const uint64_t *values, c
     DevBuf<ge> d_ge;
     d_ge.alloc(count);
     if (ct)
-      hipLaunchKernelGGL(k_ct_msm, dim3((uint32_t)count), dim3(64), 0, s, d_sc.p, d_g.p, d_c.p, per, P.table.p, (const ge *)nullptr, d_ge.p);
+      hipLaunchKernelGGL(k_ct_fixed, dim3((uint32_t)count), dim3(64), 0, s, d_sc.p, d_g.p, d_c.p, per, n_gen, (const niels *)P.fb_ct.p, d_ge.p);
     else
       hipLaunchKernelGGL(k_fb_msm, dim3((uint32_t)count), dim3(fb_threads(ctx, per, P.fb_ped_geo)), 0, s, d_sc.p, d_g.p, d_c.p, per, P.fb_ped.p,
                          P.fb_ped_geo, d_ge.p);

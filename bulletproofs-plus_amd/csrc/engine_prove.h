@@ -164,9 +164,13 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     // profiles/r04_prover_launches.txt), the MSMs of the two sub-batches drift into each other, and every period has ~110 us
     // in which no MSM runs.  With prove_prio the small kernels go to a HIGH-priority stream of their own (the hardware hands
     // freed wave slots to that queue first), joined to the MSM stream by an event each way per round.
-    // secret-only terms -- the witness check's commit(v, r) and A1 / B -- through the uniform-access form (ct.h), as the reference does
-    // them in constant time (src/generators/pedersen_gens.rs:112-122, src/range_proof.rs:572-584); "ct" = 0: through the fixed-base tables
-    const bool ct = ctx->opt.ct != 0;
+    // Secret-only terms through the uniform-access forms of ct.h, where the reference is constant-time:
+    //   "ct" >= 1 (the default): the witness check's commit(v, r) (src/generators/pedersen_gens.rs:112-122, src/range_proof.rs:275-284)
+    //   "ct" == 2: A1 and B as well (:572-584): the fixed-base MSM then sees the PUBLIC folded-generator coefficients only and the
+    //              secret scalars r, s, (r y b + s y a), d_k, (r y s), eta_k multiply by a uniform ladder (k_ct_msm: 256 doublings per
+    //              term on the call's last stretch -- measured cost in DESIGN.md, which is why it is not the default)
+    //   "ct" == 0: everything through the fixed-base tables, whose addresses are the scalars' digits
+    const bool ct_check = ctx->opt.ct != 0, ct = ctx->opt.ct == 2;
     const bool fused = ctx->opt.prove_fused != 0;  // one launch per round for encoding + Fiat-Shamir step + vector step (tests run both)
     const bool prio = ctx->opt.prove_prio > 0;  // (off by default: measured, no gain -- profiles/r04_prover_prio_ab.txt)
     if (prio) {
@@ -339,8 +343,8 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       HIP_CHECK(hipStreamWaitEvent(sx, ctx->prove_aux_events[2 * q], 0));
       hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(nb * m, 64)), b64, 0, sx, u.d_bytes, u.d_desc, t, n_gen, nb, m, 1 + t, u.d_cts,
                          u.d_ctg, u.d_ctc);
-      if (ct) {
-        hipLaunchKernelGGL(k_ct_msm, dim3(nb * m), b64, 0, sx, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.table.p, (const ge *)nullptr, u.d_ge);
+      if (ct_check) {
+        hipLaunchKernelGGL(k_ct_fixed, dim3(nb * m), b64, 0, sx, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, n_gen, (const niels *)P.fb_ct.p, u.d_ge);
       } else {
         fb_mark(sx);
         hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(ctx, 1 + t, P.fb_geo)), 0, sx, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p,
@@ -414,7 +418,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       pp.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
       // terms handed to k_fb_msm: witness check m x (1 + t); per round L and R of mn + t + 1 terms each (every generator
       // lands in exactly one of the two); the final step's A1 (every generator once more: 2 mn + t + 1 terms) and B (t + 1)
-      pp.fb_terms = (uint64_t)B * ((ct ? 0ull : (uint64_t)m * (1 + t)) + (uint64_t)rounds * 2 * (mn + t + 1) + 2 * mn + (ct ? 0u : 2 * t + 2));
+      pp.fb_terms = (uint64_t)B * ((ct_check ? 0ull : (uint64_t)m * (1 + t)) + (uint64_t)rounds * 2 * (mn + t + 1) + 2 * mn + (ct ? 0u : 2 * t + 2));
       pp.fb_launches = (uint32_t)(ev_used / 2);
       pp.fb_window_bits = P.fb_geo.wbits;
       pp.fb_windows = P.fb_geo.items;  // additions per term

@@ -32,6 +32,32 @@ int ht_ct_scalarmul(const uint8_t point32[32], const uint8_t scalar32[32], uint8
   if (trace_len) *trace_len = tr.size();
   if (trace_out) memcpy(trace_out, tr.data(), tr.size() < trace_cap ? tr.size() : trace_cap);
   return 1; }
+// the fixed-base form (k_ct_fixed's per-lane steps, all 64 positions on one lane): lines built here as k_fb_build does (4-bit
+// windows: j * 16^w * P, j = 1..8), then ct_fixed_scalarmul; the trace holds the line index of every read
+int ht_ct_fixed_scalarmul(const uint8_t point32[32], const uint8_t scalar32[32], uint8_t out32[32], uint8_t *trace_out, size_t trace_cap,
+                          size_t *trace_len) {
+  niels n; if (!ristretto_decompress(n, point32)) return 0;
+  std::vector<niels> lines((size_t)BPP_CT_DIGITS * BPP_CTF_ENTRIES);
+  ge base; ge_from_niels(base, n);
+  for (int w = 0; w < BPP_CT_DIGITS; w++) {
+    ge acc = base;
+    for (int j = 0; j < BPP_CTF_ENTRIES; j++) {
+      fe zi, x, y; fe_invert(zi, acc.Z); fe_mul(x, acc.X, zi); fe_mul(y, acc.Y, zi);
+      niels e; niels_from_affine(e, x, y); fe_carry(e.yminusx); fe_carry(e.yplusx);
+      lines[(size_t)w * BPP_CTF_ENTRIES + j] = e;
+      ge_add(acc, acc, base);
+    }
+    for (int k = 0; k < 4; k++) ge_dbl(base, base);
+  }
+  sc s; sc_load_words(s, scalar32);
+  std::vector<uint8_t> tr;
+  g_ct_trace = &tr;
+  ge r; ct_fixed_scalarmul(r, lines.data(), s);
+  g_ct_trace = nullptr;
+  ristretto_compress(out32, r);
+  if (trace_len) *trace_len = tr.size();
+  if (trace_out) memcpy(trace_out, tr.data(), tr.size() < trace_cap ? tr.size() : trace_cap);
+  return 1; }
 // the recoding alone: 64 signed radix-16 digits whose weighted sum is the scalar
 void ht_ct_recode16(const uint8_t scalar32[32], int8_t digits[64]) { sc s; sc_load_words(s, scalar32); ct_recode16(digits, s); }
 void ht_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe x, y, z; fe_frombytes(x, a); fe_frombytes(y, b); fe_mul(z, x, y); fe_tobytes(out, z); }

@@ -77,7 +77,11 @@ const char *bpp_ctx_last_error(bpp_ctx *ctx);
  * k_scalars_lanes), "static_gemm" (1 / 0: those column sums as ONE integer matrix product over the proofs of a group on the
  * matrix cores, kernels_static_gemm.h, or by Montgomery products per (proof, generator); by itself the engine takes the matrix
  * product from aggregation 8 on), "lazy_columns" (0: every product of the column sums inside k_scalars_lanes reduced by itself
- * instead of one reduction per workgroup and column).  The environment variables BPP_<NAME> give
+ * instead of one reduction per workgroup and column), "ct" (which of the SECRET-ONLY terms -- those the reference computes in
+ * constant time -- take the uniform-access forms of csrc/ct.h, where no address and no branch depends on the scalar: 1 = the default:
+ * bpp_pedersen_commit and the prover's witness check (src/generators/pedersen_gens.rs:112-122, src/range_proof.rs:275-284);
+ * 2: A1 and B of the final round as well (:572-584; a 256-doubling ladder on the call's last stretch, see DESIGN.md for its
+ * measured cost); 0: everything through the fixed-base tables, addressed by the scalars' digits).  The environment variables BPP_<NAME> give
  * the initial values and are read ONCE, when the context is created: no verification path calls getenv. */
 int bpp_ctx_set_option(bpp_ctx *ctx, const char *name, int value);
 

@@ -281,7 +281,7 @@ def test_prover_secrets_are_wiped(bpp, packed):
 
 @pytest.mark.parametrize("m,t,seeded", [(1, 1, True), (2, 3, False), (4, 6, False), (1, 2, False)])
 def test_uniform_access_path_gives_the_oracles_bytes(bpp, packed, m, t, seeded):
-    """The secret-only terms through ct.h's uniform-access form (option "ct", default on) -- bpp_pedersen_commit
+    """The secret-only terms through ct.h's uniform-access forms (option "ct": 1 = default, 2 = A1 / B too) -- bpp_pedersen_commit
     (src/generators/pedersen_gens.rs:112-122), the prover's witness check (src/range_proof.rs:275-284) and A1 / B (:572-584):
     commitments and whole proofs are the ORACLE's bytes, and the same bytes as with the fixed-base tables ("ct" = 0); edge
     scalars (0, 1, l - 1, 2^64 - 1) through the commit; a wrong opening is still refused; one launch per round and three."""
@@ -315,7 +315,7 @@ def test_uniform_access_path_gives_the_oracles_bytes(bpp, packed, m, t, seeded):
         d["seeds"] = None
     args = [params, d["values"], d["blindings"], d["commitments"], d["min_values"], d["min_present"], d["seeds"], LABEL, d["ext"]]
     out = {}
-    for ct in (0, 1):
+    for ct in (0, 1, 2):  # 1 (default): the witness check uniform; 2: A1 and B as well (the ladder on the folded generators)
         for fused in (1, 0):
             eng.set_option("ct", ct)
             eng.set_option("prove_fused", fused)

@@ -303,3 +303,13 @@ def test_uniform_access_scalar_multiplication(ht):
         assert sum(int(d) << (4 * j) for j, d in enumerate(dig)) == k
         assert all(-8 <= int(d) < 8 for d in dig[:63]) and 0 <= int(dig[63]) <= 2
     assert traces == {bytes(range(9)) * 64}, "a table read depends on the scalar"
+    # the fixed-base form (the Pedersen bases: bpp_pedersen_commit, the witness check): 64 positions x all eight lines of the position
+    ht.ht_ct_fixed_scalarmul.argtypes = ht.ht_ct_scalarmul.argtypes
+    traces = set()
+    for i, k in enumerate(scalars):
+        pt = C.from_uniform_bytes(_r(b"ctp", i % 3, 64))
+        out, tr, n = _buf(), ctypes.create_string_buffer(4096), ctypes.c_size_t()
+        assert ht.ht_ct_fixed_scalarmul(pt.compress(), k.to_bytes(32, "little"), out, tr, 4096, ctypes.byref(n)) == 1
+        assert out.raw == (pt * k).compress(), k
+        traces.add(tr.raw[:n.value])
+    assert traces == {bytes(range(8)) * 64}, "a table read depends on the scalar"
