@@ -6,7 +6,7 @@
 //! |-------------------------------------------------------------------------------|----------------------------|----------------------|
 //! | `P::Precomputation: VartimePrecomputedMultiscalarMul` (`new`, `optional_mixed_multiscalar_mul`) | `GpuPrecomputation` | `bpp_precomp_create`, `bpp_msm_mixed` |
 //! | `P: VartimeMultiscalarMul` (`optional_multiscalar_mul`; via `CurvePointProtocol`)              | `GpuRistretto`      | `bpp_msm_vartime`    |
-//! | `P: MultiscalarMul` (`multiscalar_mul`; `PedersenGens::commit`, src/generators/pedersen_gens.rs:120) | `GpuRistretto` | `bpp_msm_vartime`    |
+//! | `P: MultiscalarMul` (`multiscalar_mul`; `PedersenGens::commit`, src/generators/pedersen_gens.rs:120) | `GpuRistretto` | none: dalek's CONSTANT-TIME implementation on the host (the scalars are the value and the blinding factors) |
 //!
 //! Everything else a backend owes the crate (src/ristretto.rs:28-64 shows the list for dalek's own point: `Identity`, `Add`,
 //! `AddAssign`, `PartialEq`, `Clone`, `&P * Scalar`, `&P + &P`, `Compressable` / `Decompressable`, `FixedBytesRepr`,
@@ -32,6 +32,7 @@ use curve25519_dalek::{
     traits::{Identity, MultiscalarMul, VartimeMultiscalarMul, VartimePrecomputedMultiscalarMul},
 };
 use subtle::{Choice, ConstantTimeEq};
+use zeroize::Zeroizing;
 use tari_bulletproofs_plus::{
     protocols::curve_point_protocol::CurvePointProtocol,
     traits::{Compressable, Decompressable, FixedBytesRepr, FromUniformBytes, Precomputable},
@@ -121,13 +122,18 @@ impl ConstantTimeEq for GpuCompressedRistretto {
 }
 impl CurvePointProtocol for GpuRistretto {}  // (hash_from_bytes_sha3_512 is provided: SHA3-512 -> from_uniform_bytes)
 
-// ---- the three multiscalar traits: on the device
-fn scalar_bytes<I>(scalars: I) -> Vec<u8>
+// ---- the two VARIABLE-TIME multiscalar traits: on the device.  The constant-time one stays on dalek (below).
+/// The scalars of the variable-time calls are witness-derived in the prover (src/range_proof.rs:482-495: the reference keeps
+/// them in `Zeroizing` vectors): the byte copy made for the C call is wiped when it goes out of scope.  What the engine holds
+/// of them on its side (page-locked staging, device buffers of `bpp_msm_vartime`) is NOT wiped by that entry point -- a caller
+/// who proves with secrets that matter uses seam B2 (`bpp_prove_batch` wipes everything witness-derived), B1 is for
+/// verification and for differential testing.
+fn scalar_bytes<I>(scalars: I) -> Zeroizing<Vec<u8>>
 where I: IntoIterator, I::Item: Borrow<Scalar> {
-    scalars.into_iter().flat_map(|s| {
+    Zeroizing::new(scalars.into_iter().flat_map(|s| {
         let s: &Scalar = s.borrow();
         s.to_bytes()
-    }).collect()
+    }).collect())
 }
 fn decode(out: [u8; 32]) -> GpuRistretto {
     // the engine returns a canonical encoding of the sum it computed
@@ -157,9 +163,11 @@ impl VartimeMultiscalarMul for GpuRistretto {
 impl MultiscalarMul for GpuRistretto {
     type Point = GpuRistretto;
 
-    /// src/generators/pedersen_gens.rs:120 (`PedersenGens::commit`).  The engine's MSM is variable-time; the reference uses the
-    /// constant-time trait there because the scalars are secrets (value, blinding factors).  A caller for whom timing of the
-    /// host <-> device call matters keeps dalek's point type for commitments and uses this one for verification only.
+    /// src/generators/pedersen_gens.rs:120 (`PedersenGens::commit`): the reference calls the CONSTANT-TIME trait here because
+    /// the scalars are secrets and nothing else (the value and its blinding factors).  It therefore stays what it is in the
+    /// reference: dalek's constant-time Straus on the host, on the wrapped `RistrettoPoint`s -- 1 + t terms, microseconds; a
+    /// device round trip would be slower as well as variable-time.  (Many commitments at once, on the device, in the
+    /// uniform-access form: `bpp_gpu_shim::Engine::pedersen_commit` / `bpp_pedersen_commit`, include/bpp.h.)
     fn multiscalar_mul<I, J>(scalars: I, points: J) -> GpuRistretto
     where
         I: IntoIterator,
@@ -167,13 +175,7 @@ impl MultiscalarMul for GpuRistretto {
         J: IntoIterator,
         J::Item: Borrow<GpuRistretto>,
     {
-        let s = scalar_bytes(scalars);
-        let p: Vec<u8> = points.into_iter().flat_map(|q| {
-            let q: &GpuRistretto = q.borrow();
-            q.0.compress().to_bytes()
-        }).collect();
-        assert_eq!(s.len(), p.len(), "scalars and points differ in number");
-        decode(engine().lock().unwrap().msm_vartime(&s, &p).expect("bpp_msm_vartime"))
+        GpuRistretto(RistrettoPoint::multiscalar_mul(scalars, points.into_iter().map(|q| q.borrow().0)))
     }
 }
 
