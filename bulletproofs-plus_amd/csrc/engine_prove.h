@@ -251,7 +251,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         u.d_vec = (sc *)take(nb * (5 * (size_t)mn + 2) * sizeof(sc));
         u.d_ts = (sc *)take(nb * 2 * stride * sizeof(sc));
         u.d_tg = (uint32_t *)take(nb * 2 * stride * 4);
-        u.d_tc = (uint32_t *)take(nb * 2 * 4);
+        u.d_tc = (uint32_t *)take(nb * 3 * 4);  // (three outputs per proof in the last launch)
         u.d_a32 = take(nb * 32);
         u.d_lr = take((size_t)rounds * nb * 64);
         u.d_a1b = take(nb * 64);
@@ -260,7 +260,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         u.d_cts = (sc *)take(nb * m * (1 + t) * sizeof(sc));
         u.d_ctg = (uint32_t *)take(nb * m * (1 + t) * 4);
         u.d_ctc = (uint32_t *)take(nb * m * 4);
-        u.d_ge = (ge *)take(std::max<size_t>(nb * m, 2 * nb) * sizeof(ge));
+        u.d_ge = (ge *)take(std::max<size_t>(nb * m, 3 * nb) * sizeof(ge));
         u.d_fts = (sc *)take(nb * 2 * CT_ROW * sizeof(sc));
         u.d_ftg = (uint32_t *)take(nb * 2 * CT_ROW * 4);
         u.d_ftc = (uint32_t *)take(nb * 2 * 4);
@@ -379,14 +379,18 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         }
         to_msm(q);
         fb_mark(sm);
-        hipLaunchKernelGGL(k_fb_msm, dim3(2 * nb), dim3(fb_threads(ctx, mn + t + 1, P.fb_geo)), 0, sm, u.d_ts, u.d_tg, u.d_tc, stride, P.fb_table.p, P.fb_geo,
-                           u.d_ge);
+        // (the last launch without "ct" = 2: three outputs per proof in rows of mn + t + 1 terms, see kp_wave_body)
+        const bool three = j == rounds && !ct;
+        hipLaunchKernelGGL(k_fb_msm, dim3((three ? 3 : 2) * nb), dim3(fb_threads(ctx, mn + t + 1, P.fb_geo)), 0, sm, u.d_ts, u.d_tg, u.d_tc,
+                           three ? mn + t + 1 : stride, P.fb_table.p, P.fb_geo, u.d_ge);
         fb_mark(sm);
         to_lane(q);
         if (ct && j == rounds) {  // the secret scalars of A1 and B over the two folded generators just made and the Pedersen bases
           hipLaunchKernelGGL(k_ct_msm, dim3(2 * nb), b64, 0, s, u.d_fts, u.d_ftg, u.d_ftc, CT_ROW, P.table.p, u.d_ge, u.d_ge_ct);
           hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge_ct, 2 * nb, out);
-        } else if (!fused || j == rounds) {  // (A1 and B of the last launch: kp_finish is a one-lane-per-proof kernel)
+        } else if (j == rounds) {  // A1 = A1g + A1h and B
+          hipLaunchKernelGGL(kp_final_points, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, nb, out);
+        } else if (!fused) {
           hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);
         }
       }

@@ -794,16 +794,25 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       KP_MARK(12);
       return;
     }
+    // THREE outputs per proof in the last launch: A1 = A1g + A1h with A1g = r Gf[0] (mn terms), A1h = s Hf[0] + the Pedersen-base
+    // terms (mn + t + 1), and B (t + 1).  As ONE 2 mn + t + 1-term output A1 was twice as long as any output of a round and sat
+    // beside a B of four terms: half as many busy workgroups, each twice as long -- the launch took 460-470 us against the
+    // ~300 us of a round with as many additions (profiles/r04_v6_prover_launches.txt), on the call's last stretch.  The rows
+    // (FINAL_ROW(mn, t) = mn + t + 1 terms each) are packed from the start of the term arrays -- 3 (mn + t + 1) <= 2 (2 mn + t + 1)
+    // per proof -- which is safe because no workgroup reads a term row in this step; kp_final_points adds the halves.
+    const uint32_t fstride = mn + t + 1;
+    sc *f_s = term_scal + (size_t)3 * p * fstride;
+    uint32_t *f_g = term_gidx + (size_t)3 * p * fstride;
     for (uint32_t u = lane; u < mn; u += 64) {
       sc sg, sh;
       sc_montmul(sg, r, cG[u]);
       sc_montmul(sh, s, cH[u]);
       sc_from_mont(sg, sg);
       sc_from_mont(sh, sh);
-      ts[2 * u] = sg;
-      tg[2 * u] = 2 * u;
-      ts[2 * u + 1] = sh;
-      tg[2 * u + 1] = 2 * u + 1;
+      f_s[u] = sg;
+      f_g[u] = 2 * u;
+      f_s[fstride + u] = sh;
+      f_g[fstride + u] = 2 * u + 1;
     }
     if (lane <= t) {
       sc s1v, s2v;
@@ -822,14 +831,15 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       }
       sc_from_mont(s1v, s1v);
       sc_from_mont(s2v, s2v);
-      ts[0 * stride + 2 * mn + lane] = s1v;
-      tg[0 * stride + 2 * mn + lane] = n_gen + lane;
-      ts[1 * stride + lane] = s2v;
-      tg[1 * stride + lane] = n_gen + lane;
+      f_s[fstride + mn + lane] = s1v;
+      f_g[fstride + mn + lane] = n_gen + lane;
+      f_s[2 * fstride + lane] = s2v;
+      f_g[2 * fstride + lane] = n_gen + lane;
     }
     if (lane == 0) {
-      term_count[2 * p] = 2 * mn + t + 1;
-      term_count[2 * p + 1] = t + 1;
+      term_count[3 * p] = mn;
+      term_count[3 * p + 1] = mn + t + 1;
+      term_count[3 * p + 2] = t + 1;
     }
     KP_MARK(12);
   }
@@ -936,6 +946,24 @@ __global__ void __launch_bounds__(64) kp_finish(const ProveDesc *__restrict__ de
   uint8_t *olr = o + 1 + 32 * t + 96 + 64;
   for (uint32_t i = lane; i < 64 * rounds; i += 64) olr[i] = lr_all[((size_t)(i >> 6) * B + p) * 64 + (i & 63u)];
   if (!ok && lane == 0) st.status |= PV_STATUS_TRANSCRIPT;
+}
+
+// the last launch's three outputs per proof (kp_wave_body, final step) -> the encodings of A1 = A1g + A1h and of B, a1b32[p][2][32]
+__global__ void __launch_bounds__(64) kp_final_points(const ge *__restrict__ g3, uint32_t B, uint8_t *__restrict__ a1b32) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * B) return;
+  const uint32_t p = i >> 1, which = i & 1u;
+  ge x = g3[3 * (size_t)p + (which ? 2 : 0)];
+  if (!which) {
+    const ge y2 = g3[3 * (size_t)p + 1];
+    ge_add(x, x, y2);
+  }
+  uint8_t c32[32];
+  ristretto_compress(c32, x);
+  uint32_t *o = (uint32_t *)(a1b32 + (size_t)i * 32);
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    o[k] = (uint32_t)c32[4 * k] | ((uint32_t)c32[4 * k + 1] << 8) | ((uint32_t)c32[4 * k + 2] << 16) | ((uint32_t)c32[4 * k + 3] << 24);
 }
 
 // commitment check (:275-284): compare the engine's commit(v_j, r_j) with the statement's commitments

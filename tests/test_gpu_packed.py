@@ -33,8 +33,10 @@ def test_packed_equals_object_api(bpp, engine, n, m, t, count):
     assert [bytes(got[i]) for i in range(count)] == want
     pp = engine.last_prove_profile()
     rounds = (n * m).bit_length() - 1
-    assert pp["fb_terms"] == count * (m * (1 + t) + rounds * 2 * (n * m + t + 1) + 2 * n * m + 2 * t + 2)  # witness check, rounds, A1 + B
-    assert pp["fb_msm_ms"] > 0 and pp["fb_launches"] >= rounds + 2 and pp["total_ms"] >= pp["fb_msm_ms"] / max(pp["sub_batches"], 1)
+    # terms through the fixed-base tables: the rounds' L and R, A1 + B (the witness check's m (1 + t) terms per proof take the
+    # uniform-access form since round 5: option "ct", default 1)
+    assert pp["fb_terms"] == count * (rounds * 2 * (n * m + t + 1) + 2 * n * m + 2 * t + 2)
+    assert pp["fb_msm_ms"] > 0 and pp["fb_launches"] >= rounds + 1 and pp["total_ms"] >= pp["fb_msm_ms"] / max(pp["sub_batches"], 1)
     engine.profile(False)
     # resident batch from arrays: same verdicts and the same intermediates as the object form
     rb = packed.ResidentBatch(params, got, comm, mins, pres, None, LABEL)
