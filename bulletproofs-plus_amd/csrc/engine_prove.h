@@ -171,7 +171,19 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     //              term on the call's last stretch -- measured cost in DESIGN.md, which is why it is not the default)
     //   "ct" == 0: everything through the fixed-base tables, whose addresses are the scalars' digits
     const bool ct_check = ctx->opt.ct != 0, ct = ctx->opt.ct == 2;
-    const bool fused = ctx->opt.prove_fused != 0;  // one launch per round for encoding + Fiat-Shamir step + vector step (tests run both)
+    const bool fused = ctx->opt.prove_fused != 0;
+    // The rounds' fixed-base MSMs as independent one-wavefront slices (k_fb_part) whose partial sums the next round kernel adds
+    // up, instead of one four-wavefront workgroup per output with a reduction tree at its end (k_fb_msm).  `parts` slices per
+    // output: enough workgroups for ~4 wavefronts per SIMD, never more than FBP_MAX_PER terms in a slice.  "prove_parts" = 0 keeps
+    // the workgroup form (tests run both), a positive value fixes the number of slices.
+    uint32_t parts = 0;
+    if (ctx->opt.prove_parts != 0) {
+      const uint32_t outs = 2 * std::max<uint32_t>(64, cdiv(B, ctx->opt.prove_subs > 0 ? (uint32_t)std::min(16, ctx->opt.prove_subs) : 2u));
+      parts = ctx->opt.prove_parts > 0 ? (uint32_t)ctx->opt.prove_parts : cdiv(3072u, outs);
+      parts = std::max(parts, cdiv(mn + t + 1, (uint32_t)FBP_MAX_PER));
+      parts = std::min<uint32_t>(std::max<uint32_t>(parts, 1u), FBP_MAX_PARTS);
+      if (cdiv(mn + t + 1, parts) > FBP_MAX_PER) parts = 0;  // (aggregations whose rounds do not fit the slices: the workgroup form)
+    }  // one launch per round for encoding + Fiat-Shamir step + vector step (tests run both)
     const bool prio = ctx->opt.prove_prio > 0;  // (off by default: measured, no gain -- profiles/r04_prover_prio_ab.txt)
     if (prio) {
       int least = 0, greatest = 0;
@@ -220,7 +232,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       sc *d_vec, *d_ts, *d_cts;
       uint32_t *d_tg, *d_tc, *d_ctg, *d_ctc, *d_ftg, *d_ftc;
       sc *d_fts;
-      ge *d_ge, *d_ge_ct;
+      ge *d_ge, *d_ge_ct, *d_part;
     };
     std::vector<Sub> subs(n_sub);
     size_t arena_need = 0;
@@ -265,6 +277,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         u.d_ftg = (uint32_t *)take(nb * 2 * CT_ROW * 4);
         u.d_ftc = (uint32_t *)take(nb * 2 * 4);
         u.d_ge_ct = (ge *)take(2 * nb * sizeof(ge));
+        u.d_part = (ge *)take(parts ? (size_t)3 * nb * parts * 64 * sizeof(ge) : 16);
         u.arena_len = arena_need - u.arena_lo;
       }
     };
@@ -365,8 +378,8 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         uint8_t *lr_prev = j ? u.d_lr + (size_t)(j - 1) * nb * 64 : nullptr;
         if (fused) {  // the previous round's L / R are encoded by the same launch (kernels_prove.h: kp_round)
           hipLaunchKernelGGL(kp_round, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, nb, j, rounds, stride,
-                             u.d_a32, j ? u.d_ge : (const ge *)nullptr, lr_prev, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc, ct ? u.d_fts : (sc *)nullptr,
-                             u.d_ftg, u.d_ftc);
+                             u.d_a32, j ? (parts ? u.d_part : u.d_ge) : (const ge *)nullptr, parts, lr_prev, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc,
+                             ct ? u.d_fts : (sc *)nullptr, u.d_ftg, u.d_ftc);
         } else {
           hipLaunchKernelGGL(kp_lane, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
           hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
@@ -381,8 +394,15 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         fb_mark(sm);
         // (the last launch without "ct" = 2: three outputs per proof in rows of mn + t + 1 terms, see kp_wave_body)
         const bool three = j == rounds && !ct;
-        hipLaunchKernelGGL(k_fb_msm, dim3((three ? 3 : 2) * nb), dim3(fb_threads(ctx, mn + t + 1, P.fb_geo)), 0, sm, u.d_ts, u.d_tg, u.d_tc,
-                           three ? mn + t + 1 : stride, P.fb_table.p, P.fb_geo, u.d_ge);
+        const uint32_t n_out = (three ? 3 : 2) * nb, row = three ? mn + t + 1 : stride;
+        if (parts) {
+          hipLaunchKernelGGL(k_fb_part, dim3(n_out * parts), b64, 0, sm, u.d_ts, u.d_tg, u.d_tc, row, parts, P.fb_table.p, P.fb_geo, u.d_part);
+          // a plain point per output where the consumer is not the fused round kernel: the last launch, the unfused form
+          if (j == rounds || !fused) hipLaunchKernelGGL(k_fb_sum, dim3(n_out), b64, 0, sm, u.d_part, parts, u.d_ge);
+        } else {
+          hipLaunchKernelGGL(k_fb_msm, dim3(n_out), dim3(fb_threads(ctx, mn + t + 1, P.fb_geo)), 0, sm, u.d_ts, u.d_tg, u.d_tc, row, P.fb_table.p,
+                             P.fb_geo, u.d_ge);
+        }
         fb_mark(sm);
         to_lane(q);
         if (ct && j == rounds) {  // the secret scalars of A1 and B over the two folded generators just made and the Pedersen bases

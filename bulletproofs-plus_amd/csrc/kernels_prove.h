@@ -210,6 +210,113 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ sc
   if (tid == 0) out[o] = sh.red[0];
 }
 
+// ---- The same sum cut into independent WAVEFRONTS (round 5): output o is `parts` slices of <= FBP_MAX_PER terms, one 64-lane
+// workgroup each, and a slice ends with its 64 per-lane partial sums in memory -- no reduction tree, no barrier beyond its own
+// staging, 9 KB of LDS.  The workgroup form above spends 17 % of its time in its 8-level tree (one busy wavefront, three idle
+// ones holding registers and 40 KB of LDS: tools/microbench/fb_probe.hip, B against A); here the tree is gone from the chip-filling
+// kernel and the `parts` x 64 partial sums of an output are added up by the round kernel that consumes the point anyway
+// (kp_round: fb_reduce_pair, both outputs of a proof side by side on the two halves of its wavefront), or by k_fb_sum where a
+// plain point is wanted (the last launch, the unfused form, "ct" = 2).
+#define FBP_MAX_PER 128
+#define FBP_MAX_PARTS 8
+struct FbPartStage {
+  int16_t dig[FBP_MAX_PER * FB_MAX_WINDOWS];
+  uint32_t gi[FBP_MAX_PER];
+};
+__global__ void __launch_bounds__(64) k_fb_part(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx, const uint32_t *__restrict__ count,
+                                                uint32_t stride, uint32_t parts, const fbent *__restrict__ tbl, FbGeom geo,
+                                                ge *__restrict__ partial /* [outputs][parts][64] */) {
+  const uint32_t o = blockIdx.x / parts, part = blockIdx.x - o * parts, lane = threadIdx.x;
+  const uint32_t n = count[o], per = (n + parts - 1) / parts;
+  const uint32_t lo = part * per < n ? part * per : n, hi = lo + per < n ? lo + per : n, cn = hi - lo;
+  __shared__ FbPartStage st;
+  for (uint32_t i = lane; i < cn; i += 64) {
+    const sc s = scal[(size_t)o * stride + lo + i];
+    fb_recode(st.dig + (size_t)i * geo.items, s, geo);
+    st.gi[i] = gidx[(size_t)o * stride + lo + i];
+  }
+  __syncthreads();
+  ge acc;
+  ge_identity(acc);
+  const uint32_t items = cn * geo.items;
+  // item it = (term i, window w), it = lane + 64 k: (i, w) advance without a division
+  const uint32_t di = 64u / geo.items, dw = 64u - di * geo.items;
+  uint32_t it = lane, i = lane / geo.items, w = lane - i * geo.items;
+  auto fetch = [&](niels &q, int &d) {
+    d = st.dig[it];
+    const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+    niels_load_swapped(q, &tbl[((size_t)st.gi[i] * geo.windows + w) * geo.entries + (mag ? mag - 1u : 0u)].q, d < 0);
+  };
+  auto step = [&]() {
+    it += 64u;
+    i += di;
+    w += dw;
+    if (w >= geo.items) {
+      w -= geo.items;
+      i++;
+    }
+  };
+  niels nxt;
+  int nd = 0;
+  if (it < items) fetch(nxt, nd);
+  while (it < items) {
+    niels cur = nxt;
+    const int cd = nd;
+    step();
+    if (it < items) fetch(nxt, nd);
+    if (cd != 0) ge_madd_swapped(acc, acc, cur, cd < 0);
+  }
+  partial[(size_t)blockIdx.x * 64u + lane] = acc;
+}
+// out[o] = sum of output o's parts x 64 partial sums: one wavefront per output
+__global__ void __launch_bounds__(64) k_fb_sum(const ge *__restrict__ partial, uint32_t parts, ge *__restrict__ out) {
+  const uint32_t o = blockIdx.x, lane = threadIdx.x;
+  __shared__ ge red[64];
+  ge acc = partial[((size_t)o * parts) * 64u + lane];
+  for (uint32_t p = 1; p < parts; p++) {
+    const ge x = partial[((size_t)o * parts + p) * 64u + lane];
+    ge_add(acc, acc, x);
+  }
+  red[lane] = acc;
+  __syncthreads();
+  for (uint32_t off = 32; off >= 1; off >>= 1) {
+    if (lane < off) {
+      ge x = red[lane], y2 = red[lane + off];
+      ge_add(x, x, y2);
+      red[lane] = x;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) out[o] = red[0];
+}
+// Outputs 2p and 2p + 1 (a proof's L and R) summed side by side by ONE wavefront: lanes 0..31 take the first, lanes 32..63 the
+// second; a lane adds the 2 x parts partial sums of its two columns, then five levels through LDS inside each half.  The sums end
+// up in red[0] and red[32].  All 64 lanes must call.
+__device__ __forceinline__ void fb_reduce_pair(ge *red /* LDS, 64 */, const ge *__restrict__ partial, uint32_t parts, uint32_t p) {
+  const uint32_t lane = threadIdx.x, half = lane >> 5, h = lane & 31u;
+  const ge *src = partial + ((size_t)(2 * p + half) * parts) * 64u;
+  ge acc = src[h];
+  {
+    const ge x = src[h + 32];
+    ge_add(acc, acc, x);
+  }
+  for (uint32_t q = 1; q < parts; q++) {
+    const ge x = src[(size_t)q * 64u + h], y2 = src[(size_t)q * 64u + h + 32];
+    ge_add(acc, acc, x);
+    ge_add(acc, acc, y2);
+  }
+  red[lane] = acc;
+  __syncthreads();
+  for (uint32_t off = 16; off >= 1; off >>= 1) {
+    if (h < off) {
+      ge x = red[lane], y2 = red[lane + off];
+      ge_add(x, x, y2);
+      red[lane] = x;
+    }
+    __syncthreads();
+  }
+}
+
 #define CT_ROW 16u  // terms per row of the final round's secret-only term lists (3 + t <= 9 used)
 
 // ---------------------------------------------------------------- per-proof prover state
@@ -869,20 +976,31 @@ __global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes,
 __global__ void __launch_bounds__(64) kp_round(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
                                                const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present, uint32_t n_bits,
                                                uint32_t t, uint32_t n_gen, uint32_t B, uint32_t j, uint32_t rounds, uint32_t stride,
-                                               const uint8_t *__restrict__ a32, const ge *__restrict__ ge_prev, uint8_t *lr_prev,
-                                               ProveState *ps, sc *__restrict__ vec, sc *__restrict__ term_scal,
+                                               const uint8_t *__restrict__ a32, const ge *__restrict__ ge_prev, uint32_t prev_parts,
+                                               uint8_t *lr_prev, ProveState *ps, sc *__restrict__ vec, sc *__restrict__ term_scal,
                                                uint32_t *__restrict__ term_gidx, uint32_t *__restrict__ term_count,
                                                sc *__restrict__ ct_scal, uint32_t *__restrict__ ct_idx, uint32_t *__restrict__ ct_count) {
   const uint32_t p = blockIdx.x;
   if (p >= B) return;
   KP_T0();
-  if (ge_prev && threadIdx.x < 2) {
-    uint8_t c32[32];
-    ristretto_compress(c32, ge_prev[2 * (size_t)p + threadIdx.x]);
-    uint32_t *o = (uint32_t *)(lr_prev + (size_t)p * 64 + 32 * threadIdx.x);
+  if (ge_prev) {
+    // prev_parts == 0: ge_prev holds the previous round's L and R as points; otherwise their slices' partial sums (k_fb_part),
+    // summed here first.  Lanes 0 and 32 then encode L and R.
+    __shared__ ge red[64];
+    if (prev_parts) {
+      fb_reduce_pair(red, ge_prev, prev_parts, p);
+      KP_MARK(14);
+    } else if ((threadIdx.x & 31u) == 0) {
+      red[threadIdx.x] = ge_prev[2 * (size_t)p + (threadIdx.x >> 5)];
+    }
+    if ((threadIdx.x & 31u) == 0) {
+      uint8_t c32[32];
+      ristretto_compress(c32, red[threadIdx.x]);
+      uint32_t *o = (uint32_t *)(lr_prev + (size_t)p * 64 + 32 * (threadIdx.x >> 5));
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-      o[k] = (uint32_t)c32[4 * k] | ((uint32_t)c32[4 * k + 1] << 8) | ((uint32_t)c32[4 * k + 2] << 16) | ((uint32_t)c32[4 * k + 3] << 24);
+      for (int k = 0; k < 8; k++)
+        o[k] = (uint32_t)c32[4 * k] | ((uint32_t)c32[4 * k + 1] << 8) | ((uint32_t)c32[4 * k + 2] << 16) | ((uint32_t)c32[4 * k + 3] << 24);
+    }
   }
   __syncthreads();
   KP_MARK(0);

@@ -335,3 +335,33 @@ def test_uniform_access_path_gives_the_oracles_bytes(bpp, packed, m, t, seeded):
     cp.close()
     params.close()
     eng.close()
+
+
+@pytest.mark.parametrize("m,t,count", [(1, 1, 70), (4, 3, 40), (8, 1, 24), (2, 6, 30)])
+def test_prover_slice_form_equals_workgroup_form(bpp, packed, m, t, count):
+    """The rounds' fixed-base MSMs as independent one-wavefront slices whose partial sums the next round kernel adds up
+    (k_fb_part + fb_reduce_pair; option "prove_parts", default) against one workgroup per output with its own reduction tree
+    (k_fb_msm, "prove_parts" = 0): the same proof BYTES for every number of slices, in the fused and the unfused round form and
+    with "ct" = 2 (whose ladder reads the summed points) -- and those bytes are the oracle's (src/range_proof.rs:401-607)."""
+    import bench
+    from oracle import cport
+    eng = bpp.Engine(0)
+    params = bpp.RangeParameters.init(64, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=eng)
+    eng.set_option("prove_parts", 0)
+    d = bench.make_inputs(np, packed, params, count, seed=8100 + 10 * m + t)
+    args = [params, d["values"], d["blindings"], d["commitments"], d["min_values"], d["min_present"], d["seeds"], LABEL, d["ext"]]
+    ref = d["proofs"]
+    cp = cport.Params(64, m, t)
+    for i in (0, count - 1):
+        want, _ = cp.prove(LABEL, [int(x) for x in d["values"][i]], [[bytes(d["blindings"][i, j, k]) for k in range(t)] for j in range(m)],
+                           [int(x) for x in d["min_values"][i]], bytes(d["seeds"][i]) if d["seeds"] is not None else None, bytes(d["ext"][i]))
+        assert bytes(ref[i]) == want
+    cp.close()
+    for parts in (-1, 1, 2, 5, 8):
+        for fused, ct in ((1, 1), (0, 1), (1, 2)):
+            eng.set_option("prove_parts", parts)
+            eng.set_option("prove_fused", fused)
+            eng.set_option("ct", ct)
+            assert (packed.prove(*args) == ref).all(), (parts, fused, ct)
+    params.close()
+    eng.close()
