@@ -1244,7 +1244,7 @@ int bpp_pedersen_commit(bpp_ctx *ctx, uint64_t params, const uint64_t *values, c
       hipLaunchKernelGGL(k_ct_fixed, dim3((uint32_t)count), dim3(64), 0, s, d_sc.p, d_g.p, d_c.p, per, n_gen, (const niels *)P.fb_ct.p, d_ge.p);
     else
       hipLaunchKernelGGL(k_fb_msm, dim3((uint32_t)count), dim3(fb_threads(ctx, per, P.fb_ped_geo)), 0, s, d_sc.p, d_g.p, d_c.p, per, P.fb_ped.p,
-                         P.fb_ped_geo, d_ge.p);
+                         P.fb_ped_geo, d_ge.p, 0u);
     hipLaunchKernelGGL(k_compress_ge, dim3(cdiv((uint32_t)count, 64)), dim3(64), 0, s, d_ge.p, (uint32_t)count, d_out.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(commitments32, d_out.p, count * 32, hipMemcpyDeviceToHost, s));

@@ -361,7 +361,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       } else {
         fb_mark(sx);
         hipLaunchKernelGGL(k_fb_msm, dim3(nb * m), dim3(fb_threads(ctx, 1 + t, P.fb_geo)), 0, sx, u.d_cts, u.d_ctg, u.d_ctc, 1 + t, P.fb_table.p,
-                           P.fb_geo, u.d_ge);
+                           P.fb_geo, u.d_ge, 0u);
         fb_mark(sx);
       }
       hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, sx, u.d_ge, nb * m, u.d_commit32);
@@ -396,12 +396,12 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         const bool three = j == rounds && !ct;
         const uint32_t n_out = (three ? 3 : 2) * nb, row = three ? mn + t + 1 : stride;
         if (parts) {
-          hipLaunchKernelGGL(k_fb_part, dim3(n_out * parts), b64, 0, sm, u.d_ts, u.d_tg, u.d_tc, row, parts, P.fb_table.p, P.fb_geo, u.d_part);
+          hipLaunchKernelGGL(k_fb_part, dim3(n_out * parts), b64, 0, sm, u.d_ts, u.d_tg, u.d_tc, row, parts, P.fb_table.p, P.fb_geo, u.d_part, 1u);
           // a plain point per output where the consumer is not the fused round kernel: the last launch, the unfused form
           if (j == rounds || !fused) hipLaunchKernelGGL(k_fb_sum, dim3(n_out), b64, 0, sm, u.d_part, parts, u.d_ge);
         } else {
           hipLaunchKernelGGL(k_fb_msm, dim3(n_out), dim3(fb_threads(ctx, mn + t + 1, P.fb_geo)), 0, sm, u.d_ts, u.d_tg, u.d_tc, row, P.fb_table.p,
-                             P.fb_geo, u.d_ge);
+                             P.fb_geo, u.d_ge, 1u);
         }
         fb_mark(sm);
         to_lane(q);

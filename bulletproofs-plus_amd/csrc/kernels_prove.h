@@ -147,9 +147,11 @@ BPP_D void fb_fetch(niels &q, int &d, const FbStage &st, const fbent *__restrict
   niels_load_swapped(q, &tbl[((size_t)st.gi[i] * geo.windows + w) * geo.entries + (mag ? mag - 1u : 0u)].q, d < 0);
 }
 
+// mont != 0: the scalars arrive in Montgomery form (the prover's round kernels leave them so: the conversion is one product per
+// term, done here by every lane for its own terms instead of by the round kernel's single wavefront on the call's serial path)
 __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx,
                                                        const uint32_t *__restrict__ count, uint32_t stride,
-                                                       const fbent *__restrict__ tbl, FbGeom geo, ge *__restrict__ out) {
+                                                       const fbent *__restrict__ tbl, FbGeom geo, ge *__restrict__ out, uint32_t mont) {
   // Outputs are dealt to the workgroups even ones first, then the odd ones.  The prover's last launch pairs a long output
   // (A1: 2mn + t + 1 terms) with a short one (B: t + 1 terms) per proof; with o = blockIdx.x every long output sat on an even
   // workgroup index, i.e. (workgroups go round the 8 XCDs) on four of the eight XCDs, and that launch took 1.35 ms against
@@ -165,7 +167,8 @@ __global__ void __launch_bounds__(FB_THREADS) k_fb_msm(const sc *__restrict__ sc
     const uint32_t cn = n - base < FB_CHUNK ? n - base : FB_CHUNK;
     __syncthreads();  // the previous chunk's digits are no longer read
     for (uint32_t i = tid; i < cn; i += nthr) {
-      const sc s = scal[(size_t)o * stride + base + i];
+      sc s = scal[(size_t)o * stride + base + i];
+      if (mont) sc_from_mont(s, s);
       fb_recode(sh.st.dig + (size_t)i * geo.items, s, geo);
       sh.st.gi[i] = gidx[(size_t)o * stride + base + i];
     }
@@ -225,13 +228,14 @@ struct FbPartStage {
 };
 __global__ void __launch_bounds__(64) k_fb_part(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx, const uint32_t *__restrict__ count,
                                                 uint32_t stride, uint32_t parts, const fbent *__restrict__ tbl, FbGeom geo,
-                                                ge *__restrict__ partial /* [outputs][parts][64] */) {
+                                                ge *__restrict__ partial /* [outputs][parts][64] */, uint32_t mont) {
   const uint32_t o = blockIdx.x / parts, part = blockIdx.x - o * parts, lane = threadIdx.x;
   const uint32_t n = count[o], per = (n + parts - 1) / parts;
   const uint32_t lo = part * per < n ? part * per : n, hi = lo + per < n ? lo + per : n, cn = hi - lo;
   __shared__ FbPartStage st;
   for (uint32_t i = lane; i < cn; i += 64) {
-    const sc s = scal[(size_t)o * stride + lo + i];
+    sc s = scal[(size_t)o * stride + lo + i];
+    if (mont) sc_from_mont(s, s);
     fb_recode(st.dig + (size_t)i * geo.items, s, geo);
     st.gi[i] = gidx[(size_t)o * stride + lo + i];
   }
@@ -378,10 +382,13 @@ __device__ __forceinline__ bool pv_validate_append(Strobe &tr, const char *label
 }
 
 // ---- wavefront-cooperative helpers (wstrobe.h): one proof per 64-lane workgroup ----
+#define PW_MAX_DRAWS 14  // r, s, d[6], eta[6]
 struct ProveLds {
   uint64_t tr[25], rng[25];
   uint8_t buf[64];
   sc xch[2];
+  uint64_t rng_bak[25];              // pw_randoms: the generator's state before a batch of draws
+  uint8_t wide[PW_MAX_DRAWS][64];    //             the batch's 64-byte outputs
 };
 // build_rng (src/transcripts.rs:185-194): clone, rekey with the witness bytes, finalize with 32 external bytes
 __device__ __forceinline__ void pw_build_rng(WStrobe &rng, ProveLds &L, const KeccakLanes &K, const WStrobe &tr, const uint8_t *wit,
@@ -407,6 +414,45 @@ __device__ __forceinline__ bool pw_validate_append(WStrobe &tr, const KeccakLane
   const bool nz = __ballot(threadIdx.x < 32 && p32[threadIdx.x & 31u] != 0) != 0;
   wm_append_message(tr, K, label, llen, BytesAt{p32}, 32);
   return nz;
+}
+// n = `counts` scalars in a row from the transcript RNG (Scalar::random_not_zero each, src/protocols/scalar_protocol.rs:23-30),
+// written to dst[0][0..c0), dst[1][0..c1), ...  The generator is sequential -- one forced Keccak-f per draw -- but the wide
+// reduction of a draw's 64 bytes is not: the bytes of all n draws are squeezed first, then lane k reduces draw k (as n
+// reductions in a row, each on every lane, they were ~8 k cycles apiece on the round's serial path).  A zero scalar makes the
+// reference draw again, which shifts every later draw: should any of the n be zero (probability n 2^-252) the generator is put
+// back to where it was and the draws are made one by one as before.
+__device__ __forceinline__ void pw_randoms(WStrobe &rng, ProveLds &L, const KeccakLanes &K, sc *const *dst, const uint32_t *counts,
+                                           uint32_t groups) {
+  uint32_t n = 0;
+  for (uint32_t g = 0; g < groups; g++) n += counts[g];
+  __syncthreads();
+  if (threadIdx.x < 25) L.rng_bak[threadIdx.x] = rng.st[threadIdx.x];
+  const uint32_t pos0 = rng.pos, begin0 = rng.pos_begin, flags0 = rng.cur_flags;
+  for (uint32_t k = 0; k < n; k++) wm_rng_fill(rng, K, L.wide[k], 64);
+  sc v;
+  sc_0(v);
+  if (threadIdx.x < n) sc_mont_from_wide(v, L.wide[threadIdx.x]);
+  const bool zero = threadIdx.x < n && sc_iszero(v);
+  if (__ballot(zero) == 0) {
+    uint32_t k0 = 0;
+    for (uint32_t g = 0; g < groups; g++) {
+      if (threadIdx.x >= k0 && threadIdx.x < k0 + counts[g]) dst[g][threadIdx.x - k0] = v;
+      k0 += counts[g];
+    }
+    return;
+  }
+  __syncthreads();
+  if (threadIdx.x < 25) rng.st[threadIdx.x] = L.rng_bak[threadIdx.x];
+  rng.pos = pos0;
+  rng.pos_begin = begin0;
+  rng.cur_flags = flags0;
+  __syncthreads();
+  for (uint32_t g = 0; g < groups; g++)
+    for (uint32_t k = 0; k < counts[g]; k++) {
+      sc x;
+      pw_random(x, rng, L, K);
+      if (threadIdx.x == 0) dst[g][k] = x;
+    }
 }
 // t scalars "label"[k]: nonces (lane k computes its own BLAKE2b) or sequential draws from the transcript RNG; dst in HBM
 __device__ __forceinline__ void pw_nonces_or_randoms(sc *dst, uint32_t t, WStrobe &rng, ProveLds &L, const KeccakLanes &K,
@@ -452,8 +498,14 @@ __global__ void __launch_bounds__(64) kp_init(const uint8_t *__restrict__ bytes,
   for (uint32_t j = 0; j < d.m; j++) wm_append_u64(tr, K, "vi - minimum_value", 18, minvals[d.minval_idx + j]);
   const uint32_t wit_len = d.m * (8 + 32 * t);
   const bool has_seed = d.flags & 1u;
-  if (!has_seed) pw_build_rng(rng, L, K, tr, bytes + d.wit_off, wit_len, bytes + d.ext_off);
-  pw_nonces_or_randoms(st.alpha, t, rng, L, K, bytes + d.seed_off, has_seed, "alpha", 5, -1);
+  if (!has_seed) {
+    pw_build_rng(rng, L, K, tr, bytes + d.wit_off, wit_len, bytes + d.ext_off);
+    sc *const dst[1] = {st.alpha};
+    const uint32_t cnt[1] = {t};
+    pw_randoms(rng, L, K, dst, cnt, 1);
+  } else {
+    pw_nonces_or_randoms(st.alpha, t, rng, L, K, bytes + d.seed_off, true, "alpha", 5, -1);
+  }
   ws_store(st.tr, tr);
 }
 
@@ -610,21 +662,31 @@ __device__ __forceinline__ void kp_lane_body(const uint8_t *__restrict__ bytes, 
   }
   KP_MARK(5);
   if (j < rounds) {
-    pw_nonces_or_randoms(st.dl, t, rng, L, K, seed, has_seed, "dL", 2, (int)j);
-    pw_nonces_or_randoms(st.dr, t, rng, L, K, seed, has_seed, "dR", 2, (int)j);
+    if (has_seed) {
+      pw_nonces_or_randoms(st.dl, t, rng, L, K, seed, true, "dL", 2, (int)j);
+      pw_nonces_or_randoms(st.dr, t, rng, L, K, seed, true, "dR", 2, (int)j);
+    } else {  // d_L[0..t), d_R[0..t): 2 t draws in a row (:437-464)
+      sc *const dst[2] = {st.dl, st.dr};
+      const uint32_t cnt[2] = {t, t};
+      pw_randoms(rng, L, K, dst, cnt, 2);
+    }
     if (lane == 0) {
       st.yinv_prev = st.yinv_nhalf;  // the fold of step j still needs round j-1's y^-n
       st.yinv_nhalf = yinv;
     }
   } else {
-    sc v;
     if (lane == 0) st.yinv_prev = st.yinv_nhalf;
-    pw_random(v, rng, L, K);
-    if (lane == 0) st.r = v;
-    pw_random(v, rng, L, K);
-    if (lane == 0) st.s = v;
-    pw_nonces_or_randoms(st.dd, t, rng, L, K, seed, has_seed, "d", 1, -1);
-    pw_nonces_or_randoms(st.eta, t, rng, L, K, seed, has_seed, "eta", 3, -1);
+    if (has_seed) {  // r and s are always drawn (:542-546); d and eta are nonces
+      sc *const dst[2] = {&st.r, &st.s};
+      const uint32_t cnt[2] = {1, 1};
+      pw_randoms(rng, L, K, dst, cnt, 2);
+      pw_nonces_or_randoms(st.dd, t, rng, L, K, seed, true, "d", 1, -1);
+      pw_nonces_or_randoms(st.eta, t, rng, L, K, seed, true, "eta", 3, -1);
+    } else {  // r, s, d[0..t), eta[0..t) (:542-571)
+      sc *const dst[4] = {&st.r, &st.s, st.dd, st.eta};
+      const uint32_t cnt[4] = {1, 1, t, t};
+      pw_randoms(rng, L, K, dst, cnt, 4);
+    }
   }
   KP_MARK(6);
   ws_store(st.tr, tr);
@@ -810,8 +872,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
         sc_montmul(sg, sg, cG[u]);
         sc_montmul(sh, b[i], cH[u]);
       }
-      sc_from_mont(sg, sg);
-      sc_from_mont(sh, sh);
+      // (left in Montgomery form: the fixed-base MSM converts while it recodes)
       // position within the output's row: the u-th G term and u-th H term of each half, packed densely
       const uint32_t rank = (u / len) * nh + i;  // index among the mn/2 generators of this kind in this output
       const uint32_t og = lo ? 1u : 0u, oh = lo ? 0u : 1u;
@@ -830,8 +891,6 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
         sl = cl;
         sr = cr;
       }
-      sc_from_mont(sl, sl);
-      sc_from_mont(sr, sr);
       ts[0 * stride + mn + lane] = sl;
       tg[0 * stride + mn + lane] = n_gen + lane;
       ts[1 * stride + mn + lane] = sr;
@@ -852,9 +911,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       // uniform-access form (ct.h: k_ct_msm) as two short term rows per proof over those two points and the Pedersen bases:
       //   A1: r Gf[0], s Hf[0], (r y b + s y a) H, d_k G_k      B: (r y s) H, eta_k G_k
       for (uint32_t u = lane; u < mn; u += 64) {
-        sc sg, sh;
-        sc_from_mont(sg, cG[u]);
-        sc_from_mont(sh, cH[u]);
+        const sc sg = cG[u], sh = cH[u];  // (Montgomery form, as every fixed-base term list)
         ts[u] = sg;
         tg[u] = 2 * u;
         ts[stride + u] = sh;
@@ -914,8 +971,6 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       sc sg, sh;
       sc_montmul(sg, r, cG[u]);
       sc_montmul(sh, s, cH[u]);
-      sc_from_mont(sg, sg);
-      sc_from_mont(sh, sh);
       f_s[u] = sg;
       f_g[u] = 2 * u;
       f_s[fstride + u] = sh;
@@ -936,8 +991,6 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
         sc_montmul(s2v, r, y);
         sc_montmul(s2v, s2v, s);
       }
-      sc_from_mont(s1v, s1v);
-      sc_from_mont(s2v, s2v);
       f_s[fstride + mn + lane] = s1v;
       f_g[fstride + mn + lane] = n_gen + lane;
       f_s[2 * fstride + lane] = s2v;

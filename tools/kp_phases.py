@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 NAMES = {0: "encode L,R (2 lanes)", 1: "load + append L,R", 2: "build_rng", 3: "challenge e", 4: "inversion (step 0: + A, y, z)",
          5: "powers, squares, alpha", 6: "draws dL,dR / r,s,d,eta", 7: "store transcript", 8: "fold a,b", 9: "fold cG,cH",
-         10: "inner products", 11: "term lists", 12: "final-step term lists", 13: "step-0 vector prep"}
+         10: "inner products", 11: "term lists", 12: "final-step term lists", 13: "step-0 vector prep",
+         14: "sum of the slices' partial sums (L, R)"}
 
 
 def main():
@@ -40,7 +41,7 @@ def main():
     per = [buf[i] / (1024.0 * iters) for i in range(32)]
     tot = sum(per)
     out = {"shape": {"m": m, "t": t, "proofs": 1024}, "cycles_per_proof_and_call": round(tot),
-           "phases": {NAMES.get(i, str(i)): {"cycles": round(per[i]), "share": round(per[i] / tot, 4)} for i in range(14) if per[i]}}
+           "phases": {NAMES.get(i, str(i)): {"cycles": round(per[i]), "share": round(per[i] / tot, 4)} for i in range(15) if per[i]}}
     print(json.dumps(out, indent=1))
     p5.close()
     eng.close()

@@ -110,77 +110,7 @@ k_fb_msm_w4(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx, cons
   if (tid == 0) out[o] = sh.red[0];
 }
 
-// ---- C: one wavefront per (output, slice)
-#define FBP_MAX_PER 128
-struct FbPartStage {
-  int16_t dig[FBP_MAX_PER * FB_MAX_WINDOWS];
-  uint32_t gi[FBP_MAX_PER];
-};
-__global__ void __launch_bounds__(64) k_fb_part(const sc *__restrict__ scal, const uint32_t *__restrict__ gidx, const uint32_t *__restrict__ count,
-                                                uint32_t stride, uint32_t parts, const fbent *__restrict__ tbl, FbGeom geo,
-                                                ge *__restrict__ partial /* [outputs][parts][64] */) {
-  const uint32_t o = blockIdx.x / parts, part = blockIdx.x - o * parts, lane = threadIdx.x;
-  const uint32_t n = count[o], per = (n + parts - 1) / parts;
-  const uint32_t lo = part * per < n ? part * per : n, hi = lo + per < n ? lo + per : n, cn = hi - lo;
-  __shared__ FbPartStage st;
-  for (uint32_t i = lane; i < cn; i += 64) {
-    const sc s = scal[(size_t)o * stride + lo + i];
-    fb_recode(st.dig + (size_t)i * geo.items, s, geo);
-    st.gi[i] = gidx[(size_t)o * stride + lo + i];
-  }
-  __syncthreads();
-  ge acc;
-  ge_identity(acc);
-  const uint32_t items = cn * geo.items;
-  // item it = (term i, window w), it = lane + 64 k: (i, w) advance without a division
-  const uint32_t di = 64u / geo.items, dw = 64u - di * geo.items;
-  uint32_t it = lane, i = lane / geo.items, w = lane - i * geo.items;
-  auto fetch = [&](niels &q, int &d) {
-    d = st.dig[it];
-    const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-    niels_load_swapped(q, &tbl[((size_t)st.gi[i] * geo.windows + w) * geo.entries + (mag ? mag - 1u : 0u)].q, d < 0);
-  };
-  auto step = [&]() {
-    it += 64u;
-    i += di;
-    w += dw;
-    if (w >= geo.items) {
-      w -= geo.items;
-      i++;
-    }
-  };
-  niels nxt;
-  int nd = 0;
-  if (it < items) fetch(nxt, nd);
-  while (it < items) {
-    niels cur = nxt;
-    const int cd = nd;
-    step();
-    if (it < items) fetch(nxt, nd);
-    if (cd != 0) ge_madd_swapped(acc, acc, cur, cd < 0);
-  }
-  partial[(size_t)blockIdx.x * 64u + lane] = acc;
-}
-__global__ void __launch_bounds__(64) k_fb_sum(const ge *__restrict__ partial, uint32_t parts, ge *__restrict__ out) {
-  const uint32_t o = blockIdx.x, lane = threadIdx.x;
-  __shared__ ge red[64];
-  ge acc = partial[((size_t)o * parts) * 64u + lane];
-  for (uint32_t p = 1; p < parts; p++) {
-    const ge x = partial[((size_t)o * parts + p) * 64u + lane];
-    ge_add(acc, acc, x);
-  }
-  red[lane] = acc;
-  __syncthreads();
-  for (uint32_t off = 32; off >= 1; off >>= 1) {
-    if (lane < off) {
-      ge x = red[lane], y2 = red[lane + off];
-      ge_add(x, x, y2);
-      red[lane] = x;
-    }
-    __syncthreads();
-  }
-  if (lane == 0) out[o] = red[0];
-}
+// ---- C: one wavefront per (output, slice): k_fb_part + k_fb_sum, since round 5 the product's own kernels (kernels_prove.h)
 
 // ---- E: 64-byte table entries.  An entry is the affine point (x, y) as 2 x 8 packed words -- one 64-byte request per lookup
 // instead of a 128-byte line (random 64-byte reads out of <= 2 GB come 1.6x as often: rand_lines.hip) -- and the addition
@@ -422,7 +352,7 @@ int main(int argc, char **argv) {
   const double adds = (double)outputs * terms * geo.items;
   float a256 = 0;
   for (uint32_t thr : {256u, 192u, 128u}) {
-    const float a = best_of([&] { hipLaunchKernelGGL(k_fb_msm, dim3(outputs), dim3(thr), 0, 0, d_s, d_g, d_c, stride, d_tbl, geo, d_out); });
+    const float a = best_of([&] { hipLaunchKernelGGL(k_fb_msm, dim3(outputs), dim3(thr), 0, 0, d_s, d_g, d_c, stride, d_tbl, geo, d_out, 0u); });
     if (thr == 256u) a256 = a;
     printf("A k_fb_msm, %3u lanes per output        : %.3f ms  (%.1f G additions/s)\n", thr, a, adds / a / 1e6);
   }
@@ -435,7 +365,7 @@ int main(int argc, char **argv) {
   for (uint32_t parts : {3u, 5u}) {
     float sum_ms = 0;
     const float c = best_of([&] {
-      hipLaunchKernelGGL(k_fb_part, dim3(outputs * parts), dim3(64), 0, 0, d_s, d_g, d_c, stride, parts, d_tbl, geo, d_part);
+      hipLaunchKernelGGL(k_fb_part, dim3(outputs * parts), dim3(64), 0, 0, d_s, d_g, d_c, stride, parts, d_tbl, geo, d_part, 0u);
       (void)hipEventRecord(e2);
       hipLaunchKernelGGL(k_fb_sum, dim3(outputs), dim3(64), 0, 0, d_part, parts, d_out);
     });
