@@ -172,6 +172,11 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     //   "ct" == 0: everything through the fixed-base tables, whose addresses are the scalars' digits
     const bool ct_check = ctx->opt.ct != 0, ct = ctx->opt.ct == 2;
     const bool fused = ctx->opt.prove_fused != 0;
+    // wavefronts per proof in the fused round kernel: 1 (the three phases in a row: the default), 2 or 4 (kernels_prove.h: kp_round:
+    // each workgroup's own chain gets 35 % shorter, the call does not -- a round kernel's wavefronts need 174 registers each and
+    // find no room on a SIMD beside three of the other sub-batch's MSM wavefronts, so more of them per proof only wait longer:
+    // profiles/r05_prover_waves_ab.txt)
+    const uint32_t kp_waves = ctx->opt.prove_waves == 2 ? 2u : (ctx->opt.prove_waves == 4 ? 4u : 1u);
     // The rounds' fixed-base MSMs as independent one-wavefront slices (k_fb_part) whose partial sums the next round kernel adds
     // up, instead of one four-wavefront workgroup per output with a reduction tree at its end (k_fb_msm).  `parts` slices per
     // output: enough workgroups for ~4 wavefronts per SIMD, never more than FBP_MAX_PER terms in a slice.  "prove_parts" = 0 keeps
@@ -377,9 +382,14 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         const uint32_t nb = u.nb;
         uint8_t *lr_prev = j ? u.d_lr + (size_t)(j - 1) * nb * 64 : nullptr;
         if (fused) {  // the previous round's L / R are encoded by the same launch (kernels_prove.h: kp_round)
-          hipLaunchKernelGGL(kp_round, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, nb, j, rounds, stride,
-                             u.d_a32, j ? (parts ? u.d_part : u.d_ge) : (const ge *)nullptr, parts, lr_prev, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc,
-                             ct ? u.d_fts : (sc *)nullptr, u.d_ftg, u.d_ftc);
+          auto launch_round = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(nb), dim3(64 * kp_waves), 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, nb, j, rounds,
+                               stride, u.d_a32, j ? (parts ? u.d_part : u.d_ge) : (const ge *)nullptr, parts, lr_prev, u.d_ps, u.d_vec, u.d_ts, u.d_tg,
+                               u.d_tc, ct ? u.d_fts : (sc *)nullptr, u.d_ftg, u.d_ftc);
+          };
+          if (kp_waves == 1) launch_round(kp_round<1>);
+          else if (kp_waves == 2) launch_round(kp_round<2>);
+          else launch_round(kp_round<4>);
         } else {
           hipLaunchKernelGGL(kp_lane, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
           hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,

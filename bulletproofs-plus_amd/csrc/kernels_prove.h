@@ -321,7 +321,31 @@ __device__ __forceinline__ void fb_reduce_pair(ge *red /* LDS, 64 */, const ge *
   }
 }
 
-#define CT_ROW 16u  // terms per row of the final round's secret-only term lists (3 + t <= 9 used)
+// ONE output summed by ONE whole wavefront (kp_round with two or more wavefronts: L on the first, R on the second): lane l adds
+// its column of the `parts` slices, then six levels through this wavefront's 64 entries of LDS.  Wavefront-local synchronisation
+// (wstrobe.h: ws_sync): the other wavefront is doing the same for the other output at its own pace.  Result in red[0].
+__device__ __forceinline__ void fb_reduce_one(ge *red /* LDS, this wavefront's 64 */, const ge *__restrict__ partial, uint32_t parts, uint32_t o) {
+  const uint32_t lane = ws_lane();
+  const ge *src = partial + ((size_t)o * parts) * 64u;
+  ge acc = src[lane];
+  for (uint32_t q = 1; q < parts; q++) {
+    const ge x = src[(size_t)q * 64u + lane];
+    ge_add(acc, acc, x);
+  }
+  red[lane] = acc;
+  ws_sync();
+  for (uint32_t off = 32; off >= 1; off >>= 1) {
+    if (lane < off) {
+      ge x = red[lane], y2 = red[lane + off];
+      ge_add(x, x, y2);
+      red[lane] = x;
+    }
+    ws_sync();
+  }
+}
+
+#define CT_ROW 16u
+#define KP_MAX_THREADS 256u  // the round kernel's workgroup: 1, 2 or 4 wavefronts (option "prove_waves")  // terms per row of the final round's secret-only term lists (3 + t <= 9 used)
 
 // ---------------------------------------------------------------- per-proof prover state
 struct ProveDesc {
@@ -381,11 +405,13 @@ __device__ __forceinline__ bool pv_validate_append(Strobe &tr, const char *label
   return nz != 0;
 }
 
-// ---- wavefront-cooperative helpers (wstrobe.h): one proof per 64-lane workgroup ----
+// ---- wavefront-cooperative helpers (wstrobe.h): one transcript per WAVEFRONT (lanes and synchronisation are the wavefront's) ----
 #define PW_MAX_DRAWS 14  // r, s, d[6], eta[6]
 struct ProveLds {
   uint64_t tr[25], rng[25];
-  uint8_t buf[64];
+  uint8_t buf[64];   // scratch of the wavefront that owns the transcript (challenge bytes)
+  uint8_t buf1[64];  // scratch of the wavefront that owns the round's TranscriptRng when that is another one (kp_lane_body2)
+  uint32_t trmeta[3];  // pos, pos_begin, cur_flags of the transcript, for the wavefront that clones it
   sc xch[2];
   uint64_t rng_bak[25];              // pw_randoms: the generator's state before a batch of draws
   uint8_t wide[PW_MAX_DRAWS][64];    //             the batch's 64-byte outputs
@@ -398,12 +424,13 @@ __device__ __forceinline__ void pw_build_rng(WStrobe &rng, ProveLds &L, const Ke
   wm_rng_finalize(rng, K, BytesAt{ext32});
 }
 // Scalar::random_not_zero(transcript_rng); every lane ends up with the same scalar
-__device__ __forceinline__ void pw_random(sc &out, WStrobe &rng, ProveLds &L, const KeccakLanes &K) {
+__device__ __forceinline__ void pw_random(sc &out, WStrobe &rng, uint8_t *buf64, const KeccakLanes &K) {
   do {
-    wm_rng_fill(rng, K, L.buf, 64);
-    sc_mont_from_wide(out, L.buf);
+    wm_rng_fill(rng, K, buf64, 64);
+    sc_mont_from_wide(out, buf64);
   } while (sc_iszero(out));
 }
+__device__ __forceinline__ void pw_random(sc &out, WStrobe &rng, ProveLds &L, const KeccakLanes &K) { pw_random(out, rng, L.buf, K); }
 __device__ __forceinline__ bool pw_challenge(WStrobe &tr, ProveLds &L, const KeccakLanes &K, const char *label, uint32_t llen, sc &out) {
   wm_challenge_bytes(tr, K, label, llen, L.buf, 64);
   sc_mont_from_wide(out, L.buf);
@@ -411,7 +438,7 @@ __device__ __forceinline__ bool pw_challenge(WStrobe &tr, ProveLds &L, const Kec
 }
 __device__ __forceinline__ bool pw_validate_append(WStrobe &tr, const KeccakLanes &K, const char *label, uint32_t llen,
                                                    const uint8_t *p32) {
-  const bool nz = __ballot(threadIdx.x < 32 && p32[threadIdx.x & 31u] != 0) != 0;
+  const bool nz = __ballot(ws_lane() < 32 && p32[ws_lane() & 31u] != 0) != 0;
   wm_append_message(tr, K, label, llen, BytesAt{p32}, 32);
   return nz;
 }
@@ -422,52 +449,53 @@ __device__ __forceinline__ bool pw_validate_append(WStrobe &tr, const KeccakLane
 // reference draw again, which shifts every later draw: should any of the n be zero (probability n 2^-252) the generator is put
 // back to where it was and the draws are made one by one as before.
 __device__ __forceinline__ void pw_randoms(WStrobe &rng, ProveLds &L, const KeccakLanes &K, sc *const *dst, const uint32_t *counts,
-                                           uint32_t groups) {
+                                           uint32_t groups, uint8_t *buf64 = nullptr) {
+  if (!buf64) buf64 = L.buf;
   uint32_t n = 0;
   for (uint32_t g = 0; g < groups; g++) n += counts[g];
-  __syncthreads();
-  if (threadIdx.x < 25) L.rng_bak[threadIdx.x] = rng.st[threadIdx.x];
+  ws_sync();
+  if (ws_lane() < 25) L.rng_bak[ws_lane()] = rng.st[ws_lane()];
   const uint32_t pos0 = rng.pos, begin0 = rng.pos_begin, flags0 = rng.cur_flags;
   for (uint32_t k = 0; k < n; k++) wm_rng_fill(rng, K, L.wide[k], 64);
   sc v;
   sc_0(v);
-  if (threadIdx.x < n) sc_mont_from_wide(v, L.wide[threadIdx.x]);
-  const bool zero = threadIdx.x < n && sc_iszero(v);
+  if (ws_lane() < n) sc_mont_from_wide(v, L.wide[ws_lane()]);
+  const bool zero = ws_lane() < n && sc_iszero(v);
   if (__ballot(zero) == 0) {
     uint32_t k0 = 0;
     for (uint32_t g = 0; g < groups; g++) {
-      if (threadIdx.x >= k0 && threadIdx.x < k0 + counts[g]) dst[g][threadIdx.x - k0] = v;
+      if (ws_lane() >= k0 && ws_lane() < k0 + counts[g]) dst[g][ws_lane() - k0] = v;
       k0 += counts[g];
     }
     return;
   }
-  __syncthreads();
-  if (threadIdx.x < 25) rng.st[threadIdx.x] = L.rng_bak[threadIdx.x];
+  ws_sync();
+  if (ws_lane() < 25) rng.st[ws_lane()] = L.rng_bak[ws_lane()];
   rng.pos = pos0;
   rng.pos_begin = begin0;
   rng.cur_flags = flags0;
-  __syncthreads();
+  ws_sync();
   for (uint32_t g = 0; g < groups; g++)
     for (uint32_t k = 0; k < counts[g]; k++) {
       sc x;
-      pw_random(x, rng, L, K);
-      if (threadIdx.x == 0) dst[g][k] = x;
+      pw_random(x, rng, buf64, K);
+      if (ws_lane() == 0) dst[g][k] = x;
     }
 }
 // t scalars "label"[k]: nonces (lane k computes its own BLAKE2b) or sequential draws from the transcript RNG; dst in HBM
 __device__ __forceinline__ void pw_nonces_or_randoms(sc *dst, uint32_t t, WStrobe &rng, ProveLds &L, const KeccakLanes &K,
                                                      const uint8_t *seed, bool has_seed, const char *label, uint32_t llen, int j) {
   if (has_seed) {
-    if (threadIdx.x < t) {
+    if (ws_lane() < t) {
       sc v;
-      dev_nonce(v, seed, label, llen, j, (int)threadIdx.x);
-      dst[threadIdx.x] = v;
+      dev_nonce(v, seed, label, llen, j, (int)ws_lane());
+      dst[ws_lane()] = v;
     }
   } else {
     for (uint32_t k = 0; k < t; k++) {
       sc v;
       pw_random(v, rng, L, K);
-      if (threadIdx.x == 0) dst[k] = v;
+      if (ws_lane() == 0) dst[k] = v;
     }
   }
 }
@@ -579,10 +607,9 @@ __global__ void __launch_bounds__(64) kp_A(const uint8_t *__restrict__ bytes, co
 __device__ __forceinline__ void kp_lane_body(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
                                              uint32_t n_bits, uint32_t t, uint32_t B, uint32_t j, uint32_t rounds,
                                              const uint8_t *__restrict__ a32, const uint8_t *lr32 /* [B][2][32] of round j-1 */,
-                                             ProveState *ps) {
+                                             ProveState *ps, ProveLds &L) {
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
   if (p >= B) return;
-  __shared__ ProveLds L;
   const KeccakLanes K = keccak_lanes();
   const ProveDesc d = desc[p];
   ProveState &st = ps[p];
@@ -658,7 +685,7 @@ __device__ __forceinline__ void kp_lane_body(const uint8_t *__restrict__ bytes, 
       sc_add(a, a, v);
       st.alpha[lane] = a;
     }
-    __syncthreads();  // dl / dr are overwritten below
+    ws_sync();  // dl / dr are overwritten below
   }
   KP_MARK(5);
   if (j < rounds) {
@@ -694,6 +721,152 @@ __device__ __forceinline__ void kp_lane_body(const uint8_t *__restrict__ bytes, 
   KP_MARK(7);
 }
 
+// The same step on TWO wavefronts of a larger workgroup (kp_round with prove_waves >= 2).  What a round draws from its
+// TranscriptRng does not depend on the round's challenge -- the generator is a clone of the transcript taken BEFORE the challenge
+// (src/transcripts.rs:142-147) -- so the two halves of the step run side by side:
+//   wavefront 0 (owns the transcript): append the points | challenge, inversion, powers, squares, alpha update, store
+//   wavefront 1 (owns the generator) :                   | clone, rekey with the witness, finalize, the round's draws
+// with workgroup barriers at the three points where one needs what the other made (the appended state to clone; the clone taken
+// before the challenge disturbs the state; the end).  On one wavefront the two halves were 113 k + 151 k cycles in a row
+// (profiles/r05_kp_phases_slices.json).  Every thread of the workgroup must call (wavefronts >= 2 only meet the barriers).
+__device__ __forceinline__ void kp_lane_body2(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
+                                              uint32_t n_bits, uint32_t t, uint32_t B, uint32_t j, uint32_t rounds,
+                                              const uint8_t *__restrict__ a32, const uint8_t *lr32, ProveState *ps, ProveLds &L) {
+  const uint32_t p = blockIdx.x, lane = ws_lane(), wave = threadIdx.x >> 6;
+  const KeccakLanes K = keccak_lanes();
+  const ProveDesc d = desc[p];
+  ProveState &st = ps[p];
+  const uint32_t mn = d.m * n_bits, wit_len = d.m * (8 + 32 * t);
+  const bool has_seed = d.flags & 1u;
+  const uint8_t *seed = bytes + d.seed_off;
+  const bool need_rng = !has_seed || j == rounds;
+  bool ok = true;
+  WStrobe tr;
+  sc old_dl, old_dr;  // d_L, d_R of the round before: the alpha update reads them while the other wavefront writes the new ones
+  sc_0(old_dl);
+  sc_0(old_dr);
+  KP_T0();
+  if (wave == 0) {
+    ws_load(tr, L.tr, st.tr);
+    if (j == 0) {
+      ok = pw_validate_append(tr, K, "A", 1, a32 + (size_t)p * 32) && ok;
+    } else {
+      ok = pw_validate_append(tr, K, "L", 1, lr32 + (size_t)p * 64) && ok;
+      ok = pw_validate_append(tr, K, "R", 1, lr32 + (size_t)p * 64 + 32) && ok;
+      if (lane < t) {
+        old_dl = st.dl[lane];
+        old_dr = st.dr[lane];
+      }
+    }
+    if (lane == 0) {
+      L.trmeta[0] = tr.pos;
+      L.trmeta[1] = tr.pos_begin;
+      L.trmeta[2] = tr.cur_flags;
+    }
+  }
+  KP_MARK(1);
+  __syncthreads();  // the transcript with the round's points in it: what the generator is a clone of
+  WStrobe rng;
+  if (wave == 1 && need_rng) {
+    WStrobe view;
+    view.st = L.tr;
+    view.pos = L.trmeta[0];
+    view.pos_begin = L.trmeta[1];
+    view.cur_flags = L.trmeta[2];
+    ws_clone(rng, L.rng, view);
+  }
+  __syncthreads();  // cloned: the challenge may now disturb the transcript
+  if (wave == 0) {
+    sc e, y;
+    if (j == 0) {
+      sc z;
+      ok = pw_challenge(tr, L, K, "y", 1, y) && ok;
+      ok = pw_challenge(tr, L, K, "z", 1, z) && ok;
+      if (lane == 0) {
+        st.y = y;
+        st.z = z;
+      }
+      sc_copy(e, y);
+    } else {
+      ok = pw_challenge(tr, L, K, "e", 1, e) && ok;
+      y = st.y;
+    }
+    KP_MARK(3);
+    const uint32_t n_half = mn >> (j + 1);
+    sc inv, einv, yinv, yinv1;
+    {
+      sc x;
+#pragma unroll
+      for (int q = 0; q < 8; q++) x.v[q] = j == 0 ? y.v[q] : e.v[q];
+      sc_mont_invert_vartime(inv, x);
+    }
+    KP_MARK(4);
+    if (j == 0) {
+      yinv1 = inv;
+      if (lane == 0) st.yinv1 = inv;
+      sc_copy(einv, inv);
+    } else {
+      yinv1 = st.yinv1;
+      einv = inv;
+    }
+    if (j < rounds) sc_mont_pow_u32(yinv, yinv1, n_half);
+    else sc_copy(yinv, yinv1);
+    if (j > 0) {
+      sc esq, einvsq;
+      sc_montsq(esq, e);
+      sc_montsq(einvsq, einv);
+      if (lane == 0) {
+        st.e = e;
+        st.einv = einv;
+        st.esq = esq;
+        st.einvsq = einvsq;
+      }
+      if (lane < t) {  // alpha_k += d_L,k e^2 + d_R,k e^-2 (:535-537), with the previous round's d_L, d_R
+        sc a = st.alpha[lane], u, v;
+        sc_montmul(u, old_dl, esq);
+        sc_montmul(v, old_dr, einvsq);
+        sc_add(a, a, u);
+        sc_add(a, a, v);
+        st.alpha[lane] = a;
+      }
+    }
+    if (lane == 0) {
+      st.yinv_prev = st.yinv_nhalf;  // the fold of step j still needs round j-1's y^-n
+      if (j < rounds) st.yinv_nhalf = yinv;
+    }
+    KP_MARK(5);
+    ws_store(st.tr, tr);
+    if (!ok && lane == 0) st.status |= PV_STATUS_TRANSCRIPT;
+  } else if (wave == 1) {
+    if (need_rng) {
+      wm_rng_rekey(rng, K, "witness", 7, BytesAt{bytes + d.wit_off}, wit_len);
+      wm_rng_finalize(rng, K, BytesAt{bytes + d.ext_off + 32 * (1 + j)});
+    }
+    if (j < rounds) {
+      if (has_seed) {
+        pw_nonces_or_randoms(st.dl, t, rng, L, K, seed, true, "dL", 2, (int)j);
+        pw_nonces_or_randoms(st.dr, t, rng, L, K, seed, true, "dR", 2, (int)j);
+      } else {
+        sc *const dst[2] = {st.dl, st.dr};
+        const uint32_t cnt[2] = {t, t};
+        pw_randoms(rng, L, K, dst, cnt, 2, L.buf1);
+      }
+    } else if (has_seed) {
+      sc *const dst[2] = {&st.r, &st.s};
+      const uint32_t cnt[2] = {1, 1};
+      pw_randoms(rng, L, K, dst, cnt, 2, L.buf1);
+      pw_nonces_or_randoms(st.dd, t, rng, L, K, seed, true, "d", 1, -1);
+      pw_nonces_or_randoms(st.eta, t, rng, L, K, seed, true, "eta", 3, -1);
+    } else {
+      sc *const dst[4] = {&st.r, &st.s, st.dd, st.eta};
+      const uint32_t cnt[4] = {1, 1, t, t};
+      pw_randoms(rng, L, K, dst, cnt, 4, L.buf1);
+    }
+  }
+  KP_MARK(6);
+  __syncthreads();
+}
+
 // ---- wave kernel, step j = 0..r (one wavefront per proof): vector prep / fold / inner products / MSM term lists ----
 // vec layout per proof (Montgomery): a[mn] | b[mn] | cG[mn] | cH[mn] | ypow[mn+2]
 // term rows per proof: 2 outputs x stride; gidx uses the table order (2i = G_i, 2i+1 = H_i, n_gen + k = G_k, n_gen + t = H)
@@ -703,15 +876,15 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
                                              uint32_t stride, ProveState *ps, sc *__restrict__ vec,
                                              sc *__restrict__ term_scal, uint32_t *__restrict__ term_gidx,
                                              uint32_t *__restrict__ term_count, sc *__restrict__ ct_scal,
-                                             uint32_t *__restrict__ ct_idx, uint32_t *__restrict__ ct_count) {
-  const uint32_t p = blockIdx.x, lane = threadIdx.x;
+                                             uint32_t *__restrict__ ct_idx, uint32_t *__restrict__ ct_count, sc *red /* LDS, blockDim.x */) {
+  // (`lane` = the thread's index in the workgroup, nthr = 64, 128 or 256 threads: every loop below strides by nthr)
+  const uint32_t p = blockIdx.x, lane = threadIdx.x, nthr = blockDim.x;
   const ProveDesc d = desc[p];
   ProveState &st = ps[p];
   const uint32_t mn = d.m * n_bits;
   sc *a = vec + (size_t)p * (5 * mn + 2), *b = a + mn, *cG = b + mn, *cH = cG + mn, *ypow = cH + mn;
   sc one;
   sc_mont_one(one);
-  __shared__ sc red[64];
   KP_T0();
 
   if (j == 0) {
@@ -719,13 +892,13 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
     const sc y = st.y, z = st.z;
     sc z_square;
     sc_montsq(z_square, z);
-    for (uint32_t i = lane; i < mn + 2; i += 64) {
+    for (uint32_t i = lane; i < mn + 2; i += nthr) {
       sc v;
       sc_mont_pow_u32(v, y, i);
       ypow[i] = v;
     }
     __syncthreads();
-    for (uint32_t i = lane; i < mn; i += 64) {
+    for (uint32_t i = lane; i < mn; i += nthr) {
       const uint32_t party = i / n_bits, bit_idx = i % n_bits;
       const uint8_t *w = bytes + d.wit_off + party * (8 + 32 * t);
       uint64_t v = 0;
@@ -777,7 +950,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
     yn = ypow[nh];
     sc_montmul(e_yinv, e, yinv);
     // a' = a_lo*e + (a_hi*y^n)*e^-1 ; b' = b_lo*e^-1 + b_hi*e   (each lane reads both halves before anyone writes)
-    for (uint32_t base = 0; base < nh; base += 64) {
+    for (uint32_t base = 0; base < nh; base += nthr) {
       const uint32_t i = base + lane;
       sc na, nb;
       if (i < nh) {
@@ -797,7 +970,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       }
     }
     KP_MARK(8);
-    for (uint32_t u = lane; u < mn; u += 64) {
+    for (uint32_t u = lane; u < mn; u += nthr) {
       const bool lo = (u & (len - 1)) < nh;
       sc g = cG[u], h = cH[u], fg, fh;
       // (word-wise selects: `lo ? einv : e_yinv` as an operand selects between the ADDRESSES of two locals, which then live in
@@ -826,7 +999,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
     sc cl, cr;
     sc_0(cl);
     sc_0(cr);
-    for (uint32_t i = lane; i < nh; i += 64) {
+    for (uint32_t i = lane; i < nh; i += nthr) {
       sc u;
       sc_montmul(u, a[i], ypow[i + 1]);
       sc_montmul(u, u, b[nh + i]);
@@ -843,7 +1016,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
         red[lane] = pick;
       }
       __syncthreads();
-      for (uint32_t off = 32; off >= 1; off >>= 1) {
+      for (uint32_t off = nthr / 2; off >= 1; off >>= 1) {
         if (lane < off) {
           sc x = red[lane], y2 = red[lane + off];
           sc_add(x, x, y2);
@@ -858,7 +1031,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
     KP_MARK(10);
     // term lists.  L (:482-488): c_L H, d_L G_k, (a_lo y^-n) on Gf_hi, b_hi on Hf_lo.  R (:489-495) symmetric.
     // output 0 = L, output 1 = R; every original G_u / H_u goes to exactly one of them.
-    for (uint32_t u = lane; u < mn; u += 64) {
+    for (uint32_t u = lane; u < mn; u += nthr) {
       const uint32_t fi = u & (len - 1);
       const bool lo = fi < nh;
       const uint32_t i = lo ? fi : fi - nh;
@@ -910,7 +1083,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       // Hf[0] = sum cH[u] H_u (output 1), the folded generators, functions of the challenges -- and the secret scalars go to the
       // uniform-access form (ct.h: k_ct_msm) as two short term rows per proof over those two points and the Pedersen bases:
       //   A1: r Gf[0], s Hf[0], (r y b + s y a) H, d_k G_k      B: (r y s) H, eta_k G_k
-      for (uint32_t u = lane; u < mn; u += 64) {
+      for (uint32_t u = lane; u < mn; u += nthr) {
         const sc sg = cG[u], sh = cH[u];  // (Montgomery form, as every fixed-base term list)
         ts[u] = sg;
         tg[u] = 2 * u;
@@ -967,7 +1140,7 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
     const uint32_t fstride = mn + t + 1;
     sc *f_s = term_scal + (size_t)3 * p * fstride;
     uint32_t *f_g = term_gidx + (size_t)3 * p * fstride;
-    for (uint32_t u = lane; u < mn; u += 64) {
+    for (uint32_t u = lane; u < mn; u += nthr) {
       sc sg, sh;
       sc_montmul(sg, r, cG[u]);
       sc_montmul(sh, s, cH[u]);
@@ -1009,7 +1182,8 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
 __global__ void __launch_bounds__(64) kp_lane(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc, uint32_t n_bits,
                                               uint32_t t, uint32_t B, uint32_t j, uint32_t rounds, const uint8_t *__restrict__ a32,
                                               const uint8_t *lr32, ProveState *ps) {
-  kp_lane_body(bytes, desc, n_bits, t, B, j, rounds, a32, lr32, ps);
+  __shared__ ProveLds L;
+  kp_lane_body(bytes, desc, n_bits, t, B, j, rounds, a32, lr32, ps, L);
 }
 __global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
                                               const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present, uint32_t n_bits,
@@ -1017,8 +1191,9 @@ __global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes,
                                               sc *__restrict__ vec, sc *__restrict__ term_scal, uint32_t *__restrict__ term_gidx,
                                               uint32_t *__restrict__ term_count, sc *__restrict__ ct_scal, uint32_t *__restrict__ ct_idx,
                                               uint32_t *__restrict__ ct_count) {
+  __shared__ sc red[64];
   kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count, ct_scal,
-               ct_idx, ct_count);
+               ct_idx, ct_count, red);
 }
 // ... and as ONE launch per round (round 4): the encoding of the previous round's L and R (two lanes, ristretto_compress), the
 // Fiat-Shamir step and the vector step of a proof are consecutive phases of the same 64-lane workgroup.  As three launches per
@@ -1026,30 +1201,54 @@ __global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes,
 // other sub-batch's chip-filling fixed-base MSM (70 / 135 / 45 us alone, 70-200 / 130-180 / 45-175 us in a call:
 // profiles/r04_prover_launches.txt); whatever a phase writes to memory for the next one is read by the same workgroup behind a
 // barrier.  ge_prev == null: nothing to encode (round 0).
-__global__ void __launch_bounds__(64) kp_round(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
+template <int W>
+__global__ void __launch_bounds__(64 * W) kp_round(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
                                                const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present, uint32_t n_bits,
                                                uint32_t t, uint32_t n_gen, uint32_t B, uint32_t j, uint32_t rounds, uint32_t stride,
                                                const uint8_t *__restrict__ a32, const ge *__restrict__ ge_prev, uint32_t prev_parts,
                                                uint8_t *lr_prev, ProveState *ps, sc *__restrict__ vec, sc *__restrict__ term_scal,
                                                uint32_t *__restrict__ term_gidx, uint32_t *__restrict__ term_count,
                                                sc *__restrict__ ct_scal, uint32_t *__restrict__ ct_idx, uint32_t *__restrict__ ct_count) {
-  const uint32_t p = blockIdx.x;
+  // blockDim.x = 64 x (1, 2 or 4) wavefronts per proof (option "prove_waves").  With two or more: L and R are summed and encoded
+  // on a wavefront each, the Fiat-Shamir step runs its two halves side by side (kp_lane_body2), the vector step strides by the
+  // whole workgroup.  One wavefront: the same three phases in a row (the form of round 4; tests run every form).
+  static_assert(W == 1 || W == 2 || W == 4, "wavefronts per proof");
+  const uint32_t p = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  constexpr bool multi = W >= 2;  // (an instantiation per form: each carries only its own Fiat-Shamir step)
   if (p >= B) return;
+  // The three phases use LDS one after the other -- the points being summed (10 or 20 KB), the sponges of the Fiat-Shamir step,
+  // the vector step's reduction buffer -- and SHARE it: what this workgroup holds decides how many of them fit on a compute unit
+  // beside the other sub-batch's fixed-base MSM (a dozen 9 KB workgroups per CU): at 32 KB it was one, and the 512 workgroups of a
+  // launch ran in two turns.
+  union KpShared {
+    ge red[multi ? 128 : 64];
+    ProveLds L;
+    sc red_sc[64 * W];
+  };
+  __shared__ KpShared sh;
+  ge *red = sh.red;
   KP_T0();
   if (ge_prev) {
     // prev_parts == 0: ge_prev holds the previous round's L and R as points; otherwise their slices' partial sums (k_fb_part),
-    // summed here first.  Lanes 0 and 32 then encode L and R.
-    __shared__ ge red[64];
-    if (prev_parts) {
+    // summed here first.
+    if constexpr (multi) {
+      if (wave < 2) {
+        if (prev_parts) fb_reduce_one(red + 64 * wave, ge_prev, prev_parts, 2 * p + wave);
+        else if (lane == 0) red[64 * wave] = ge_prev[2 * (size_t)p + wave];
+      }
+    } else if (prev_parts) {
       fb_reduce_pair(red, ge_prev, prev_parts, p);
-      KP_MARK(14);
-    } else if ((threadIdx.x & 31u) == 0) {
-      red[threadIdx.x] = ge_prev[2 * (size_t)p + (threadIdx.x >> 5)];
+    } else if ((lane & 31u) == 0) {
+      red[lane] = ge_prev[2 * (size_t)p + (lane >> 5)];
     }
-    if ((threadIdx.x & 31u) == 0) {
+    KP_MARK(14);
+    // the encodings: lane 0 of the first two wavefronts, or lanes 0 and 32 of the only one
+    const bool enc = multi ? (wave < 2 && lane == 0) : ((lane & 31u) == 0);
+    if (enc) {
+      const uint32_t which = multi ? wave : (lane >> 5);
       uint8_t c32[32];
-      ristretto_compress(c32, red[threadIdx.x]);
-      uint32_t *o = (uint32_t *)(lr_prev + (size_t)p * 64 + 32 * (threadIdx.x >> 5));
+      ristretto_compress(c32, red[multi ? 64 * wave : lane]);
+      uint32_t *o = (uint32_t *)(lr_prev + (size_t)p * 64 + 32 * which);
 #pragma unroll
       for (int k = 0; k < 8; k++)
         o[k] = (uint32_t)c32[4 * k] | ((uint32_t)c32[4 * k + 1] << 8) | ((uint32_t)c32[4 * k + 2] << 16) | ((uint32_t)c32[4 * k + 3] << 24);
@@ -1057,10 +1256,14 @@ __global__ void __launch_bounds__(64) kp_round(const uint8_t *__restrict__ bytes
   }
   __syncthreads();
   KP_MARK(0);
-  kp_lane_body(bytes, desc, n_bits, t, B, j, rounds, a32, lr_prev, ps);
-  __syncthreads();
+  if constexpr (multi) {
+    kp_lane_body2(bytes, desc, n_bits, t, B, j, rounds, a32, lr_prev, ps, sh.L);
+  } else {
+    kp_lane_body(bytes, desc, n_bits, t, B, j, rounds, a32, lr_prev, ps, sh.L);
+    __syncthreads();
+  }
   kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count, ct_scal,
-               ct_idx, ct_count);
+               ct_idx, ct_count, sh.red_sc);
 }
 
 // ---- final lane kernel: challenge_final_e, responses, wire bytes (:587-607, to_bytes :1120-1150) ----

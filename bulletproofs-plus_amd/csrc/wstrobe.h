@@ -12,11 +12,24 @@
 //     round is write, reads, write, reads with two waits (the first form took four dependent ds_bpermute steps per
 //     round; PASS 1 of a 256-proof call 0.117 -> 0.106 ms, batch prover 115 -> 119 k proofs/s).
 // pos / pos_begin / cur_flags are wave-uniform registers.  Byte-for-byte the same sponge as merlin.h (tests compare the
-// prover's output with the oracle).  Must be called by all 64 lanes of a one-wavefront workgroup.
+// prover's output with the oracle).  Must be called by all 64 lanes of the wavefront that owns the transcript.
 #pragma once
 #include "merlin.h"
 
 namespace bpp {
+
+// One transcript lives in ONE wavefront, whatever the size of the workgroup around it (the prover's round kernel runs two
+// transcripts side by side in two wavefronts of one workgroup): a lane is its position in the wavefront, and the synchronisation
+// between the steps of a sponge operation is wavefront-local.  The LDS operations of one wavefront execute in issue order, so what
+// such a point has to guarantee is that the COMPILER keeps the accesses in program order and re-reads LDS afterwards: a release /
+// acquire fence pair at workgroup scope (it also waits for the outstanding LDS operations) around a wavefront barrier -- what
+// __syncthreads() is, minus the s_barrier that would tie the workgroup's other wavefronts to this one's step count.
+__device__ __forceinline__ uint32_t ws_lane() { return threadIdx.x & 63u; }
+__device__ __forceinline__ void ws_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 struct WStrobe {
   uint64_t *st;  // 25 words in LDS
@@ -34,7 +47,7 @@ struct KeccakLanes {
 
 __device__ __forceinline__ KeccakLanes keccak_lanes() {
   const uint8_t ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-  const uint32_t l = threadIdx.x;
+  const uint32_t l = ws_lane();
   const int i = l < 25 ? (int)l : 0;  // lanes 25..63 shadow lane 0 and never write back
   const int x = i % 5, y = i / 5;
   KeccakLanes k;
@@ -66,7 +79,7 @@ __device__ __forceinline__ void keccak_f1600_wave(uint64_t *st, const KeccakLane
   // operations in issue order, so a read issued before the next write still sees the previous round's words)
   typedef __attribute__((address_space(3))) uint64_t lds_u64;
   volatile lds_u64 *w = (volatile lds_u64 *)st;  // st points into a __shared__ object
-  const uint32_t self = threadIdx.x < 25 ? threadIdx.x : 0;
+  const uint32_t self = ws_lane() < 25 ? ws_lane() : 0;
   uint64_t a = w[self];  // the caller's barrier made the absorbed bytes visible; the state itself is the first exchange
 #pragma unroll 1
   for (int rnd = 0; rnd < 24; rnd++) {
@@ -86,15 +99,15 @@ __device__ __forceinline__ void keccak_f1600_wave(uint64_t *st, const KeccakLane
 
 __device__ __forceinline__ void ws_run_f(WStrobe &s, const KeccakLanes &K) {
   uint8_t *b = (uint8_t *)s.st;
-  __syncthreads();
-  if (threadIdx.x == 0) {
+  ws_sync();
+  if (ws_lane() == 0) {
     b[s.pos] ^= (uint8_t)s.pos_begin;
     b[s.pos + 1] ^= 0x04;
     b[BPP_STROBE_R + 1] ^= 0x80;
   }
-  __syncthreads();
+  ws_sync();
   keccak_f1600_wave(s.st, K);
-  __syncthreads();
+  ws_sync();
   s.pos = 0;
   s.pos_begin = 0;
 }
@@ -106,7 +119,7 @@ __device__ __forceinline__ void ws_absorb(WStrobe &s, const KeccakLanes &K, F by
   uint32_t off = 0;
   while (off < n) {
     const uint32_t room = BPP_STROBE_R - s.pos, chunk = n - off < room ? n - off : room;
-    for (uint32_t k = threadIdx.x; k < chunk; k += 64) b[s.pos + k] ^= byte_at(off + k);
+    for (uint32_t k = ws_lane(); k < chunk; k += 64) b[s.pos + k] ^= byte_at(off + k);
     s.pos += chunk;
     off += chunk;
     if (s.pos == BPP_STROBE_R) ws_run_f(s, K);
@@ -118,7 +131,7 @@ __device__ __forceinline__ void ws_overwrite(WStrobe &s, const KeccakLanes &K, F
   uint32_t off = 0;
   while (off < n) {
     const uint32_t room = BPP_STROBE_R - s.pos, chunk = n - off < room ? n - off : room;
-    for (uint32_t k = threadIdx.x; k < chunk; k += 64) b[s.pos + k] = byte_at(off + k);
+    for (uint32_t k = ws_lane(); k < chunk; k += 64) b[s.pos + k] = byte_at(off + k);
     s.pos += chunk;
     off += chunk;
     if (s.pos == BPP_STROBE_R) ws_run_f(s, K);
@@ -128,10 +141,10 @@ __device__ __forceinline__ void ws_overwrite(WStrobe &s, const KeccakLanes &K, F
 __device__ __forceinline__ void ws_squeeze(WStrobe &s, const KeccakLanes &K, uint8_t *out, uint32_t n) {
   uint8_t *b = (uint8_t *)s.st;
   uint32_t off = 0;
-  __syncthreads();
+  ws_sync();
   while (off < n) {
     const uint32_t room = BPP_STROBE_R - s.pos, chunk = n - off < room ? n - off : room;
-    for (uint32_t k = threadIdx.x; k < chunk; k += 64) {
+    for (uint32_t k = ws_lane(); k < chunk; k += 64) {
       out[off + k] = b[s.pos + k];
       b[s.pos + k] = 0;
     }
@@ -139,7 +152,7 @@ __device__ __forceinline__ void ws_squeeze(WStrobe &s, const KeccakLanes &K, uin
     off += chunk;
     if (s.pos == BPP_STROBE_R) ws_run_f(s, K);
   }
-  __syncthreads();
+  ws_sync();
 }
 
 __device__ __forceinline__ void ws_begin_op(WStrobe &s, const KeccakLanes &K, uint32_t flags, bool more) {
@@ -208,30 +221,30 @@ __device__ __forceinline__ void wm_rng_fill(WStrobe &rng, const KeccakLanes &K, 
 
 // state <-> the per-proof Strobe kept in HBM between kernels
 __device__ __forceinline__ void ws_load(WStrobe &s, uint64_t *lds25, const Strobe &g) {
-  if (threadIdx.x < 25) lds25[threadIdx.x] = g.st[threadIdx.x];
+  if (ws_lane() < 25) lds25[ws_lane()] = g.st[ws_lane()];
   s.st = lds25;
   s.pos = g.pos;
   s.pos_begin = g.pos_begin;
   s.cur_flags = g.cur_flags;
-  __syncthreads();
+  ws_sync();
 }
 __device__ __forceinline__ void ws_store(Strobe &g, const WStrobe &s) {
-  __syncthreads();
-  if (threadIdx.x < 25) g.st[threadIdx.x] = s.st[threadIdx.x];
-  if (threadIdx.x == 0) {
+  ws_sync();
+  if (ws_lane() < 25) g.st[ws_lane()] = s.st[ws_lane()];
+  if (ws_lane() == 0) {
     g.pos = s.pos;
     g.pos_begin = s.pos_begin;
     g.cur_flags = s.cur_flags;
   }
 }
 __device__ __forceinline__ void ws_clone(WStrobe &dst, uint64_t *lds25, const WStrobe &src) {
-  __syncthreads();
-  if (threadIdx.x < 25) lds25[threadIdx.x] = src.st[threadIdx.x];
+  ws_sync();
+  if (ws_lane() < 25) lds25[ws_lane()] = src.st[ws_lane()];
   dst.st = lds25;
   dst.pos = src.pos;
   dst.pos_begin = src.pos_begin;
   dst.cur_flags = src.cur_flags;
-  __syncthreads();
+  ws_sync();
 }
 
 }  // namespace bpp

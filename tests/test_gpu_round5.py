@@ -363,5 +363,14 @@ def test_prover_slice_form_equals_workgroup_form(bpp, packed, m, t, count):
             eng.set_option("prove_fused", fused)
             eng.set_option("ct", ct)
             assert (packed.prove(*args) == ref).all(), (parts, fused, ct)
+    # the fused round kernel on 1, 2 and 4 wavefronts per proof (two and more: L / R on a wavefront each, the Fiat-Shamir step's
+    # transcript half and generator half side by side, the vector step over the whole workgroup), with and without slices
+    for waves in (1, 2, 4):
+        for parts, ct in ((-1, 1), (0, 1), (3, 2)):
+            eng.set_option("prove_waves", waves)
+            eng.set_option("prove_parts", parts)
+            eng.set_option("prove_fused", 1)
+            eng.set_option("ct", ct)
+            assert (packed.prove(*args) == ref).all(), (waves, parts, ct)
     params.close()
     eng.close()
