@@ -451,8 +451,12 @@ void adopt_buffers(Batch &dst, Batch &src) {
   BPP_ADOPT(msm.cls_hist);
   BPP_ADOPT(msm.buckets); BPP_ADOPT(msm.Q); BPP_ADOPT(msm.W); BPP_ADOPT(msm.R); BPP_ADOPT(msm.comp32);
   BPP_ADOPT(msm.is_identity); BPP_ADOPT(msm.term_sidx); BPP_ADOPT(msm.term_pidx); BPP_ADOPT(msm.group_off);
-  BPP_ADOPT(h_rng); BPP_ADOPT(h_weights); BPP_ADOPT(h_status); BPP_ADOPT(h_ident); BPP_ADOPT(h_masks);
+  BPP_ADOPT(h_rng); BPP_ADOPT(h_weights); BPP_ADOPT(h_status); BPP_ADOPT(h_status_any); BPP_ADOPT(h_ident); BPP_ADOPT(h_masks);
 #undef BPP_ADOPT
+  // what is known about the adopted status words travels with them (settle_status clears only the blocks that may hold something);
+  // a verification whose results were never looked at leaves them unknown
+  dst.h_status_dirty.swap(src.h_status_dirty);
+  if (!src.status_settled) std::fill(dst.h_status_dirty.begin(), dst.h_status_dirty.end(), (uint8_t)1);
 }
 
 void wipe_batch_secrets(Batch &b, hipStream_t s);
@@ -1671,7 +1675,8 @@ class HostPool {
   void parallel_for(uint32_t n, const std::function<void(uint32_t)> &fn) {
     if (n == 0) return;
     if (n == 1 || workers_.empty()) {
-      for (uint32_t i = 0; i < n; i++) run_item(fn, i);
+      CpuSpan span;
+      for (uint32_t i = 0; i < n; i++) fn(i);
       return;
     }
     auto job = std::make_shared<Job>();
@@ -1757,18 +1762,20 @@ class HostPool {
     static std::atomic<uint64_t> v{0};
     return v;
   }
-  static void run_item(const std::function<void(uint32_t)> &fn, uint32_t i) {
-    const uint64_t t0 = thread_cpu_ns();
-    fn(i);
-    cpu_ns().fetch_add(thread_cpu_ns() - t0, std::memory_order_relaxed);
-  }
+  // (the thread clock is a system call, ~1 us: read once per thread and JOB, never per item -- a 256-proof call parses 256 items)
+  struct CpuSpan {
+    uint64_t t0 = thread_cpu_ns();
+    ~CpuSpan() { cpu_ns().fetch_add(thread_cpu_ns() - t0, std::memory_order_relaxed); }
+  };
 
  private:
   static void work_on(Job &j) {
+    if (j.next.load() >= j.n) return;  // nothing left: no clock reads either
+    CpuSpan span;
     for (;;) {
       uint32_t i = j.next.fetch_add(1);
       if (i >= j.n) return;
-      run_item(*j.fn, i);
+      (*j.fn)(i);
       if (j.done.fetch_add(1) + 1 == j.n) {
         std::lock_guard<std::mutex> lk(j.mu);
         j.cv.notify_all();
