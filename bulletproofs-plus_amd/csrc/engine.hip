@@ -432,6 +432,7 @@ struct Batch {
   // settle_status() makes h_status whole again on the host (a block the kernel skipped is all zero: cleared here if it was not)
   PinnedBuf<uint32_t> h_status_any;
   std::vector<uint8_t> h_status_dirty;
+  const uint32_t *h_status_dirty_of = nullptr;  // the allocation those flags describe (a re-allocated h_status holds anything)
   bool status_settled = true;
   bool have_trace = false, phase1_done = false;
   bool status_clean = false;     // status[] == status0[]: k_results_out resets it behind every verification
@@ -456,6 +457,7 @@ void adopt_buffers(Batch &dst, Batch &src) {
   // what is known about the adopted status words travels with them (settle_status clears only the blocks that may hold something);
   // a verification whose results were never looked at leaves them unknown
   dst.h_status_dirty.swap(src.h_status_dirty);
+  std::swap(dst.h_status_dirty_of, src.h_status_dirty_of);
   if (!src.status_settled) std::fill(dst.h_status_dirty.begin(), dst.h_status_dirty.end(), (uint8_t)1);
 }
 
@@ -1896,13 +1898,17 @@ void fetch_status(bpp_ctx *ctx, Batch &b) { fetch_results(ctx, b, false, false);
 void settle_status(Batch &b) {
   if (b.status_settled) return;
   const uint32_t n_blk = cdiv(b.B, BPP_STATUS_BLOCK);
-  if (b.h_status_dirty.size() != n_blk) b.h_status_dirty.assign(n_blk, 1);  // fresh page-locked memory: contents unknown
+  if (b.h_status_dirty.size() != n_blk || b.h_status_dirty_of != b.h_status.data()) {  // fresh page-locked memory: contents unknown
+    b.h_status_dirty.assign(n_blk, 1);
+    b.h_status_dirty_of = b.h_status.data();
+  }
   for (uint32_t k = 0; k < n_blk; k++) {
     if (b.h_status_any[k]) {
       b.h_status_dirty[k] = 1;
     } else if (b.h_status_dirty[k]) {
-      const uint32_t lo = k * BPP_STATUS_BLOCK, hi = std::min(b.B, lo + BPP_STATUS_BLOCK);
-      memset(b.h_status.data() + lo, 0, (size_t)(hi - lo) * 4);
+      // the WHOLE block of the allocation, not just this batch's proofs: the flags travel with the buffer to batches of other sizes
+      const size_t lo = (size_t)k * BPP_STATUS_BLOCK, hi = std::min<size_t>(b.h_status.n, lo + BPP_STATUS_BLOCK);
+      memset(b.h_status.data() + lo, 0, (hi - lo) * 4);
       b.h_status_dirty[k] = 0;
     }
   }

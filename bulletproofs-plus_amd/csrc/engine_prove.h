@@ -40,7 +40,8 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         for (auto &ps : ctx->prove_aux_streams) (void)hipStreamSynchronize(ps);
         for (auto &ps : ctx->prove_streams) (void)hipStreamSynchronize(ps);
         for (auto &ps : ctx->prove_lane_streams) (void)hipStreamSynchronize(ps);
-        (void)hipMemset(ctx->prove_arena.p, 0, ctx->prove_arena.n);
+        (void)hipMemsetAsync(ctx->prove_arena.p, 0, ctx->prove_arena.n, ctx->stream);  // (stream-ordered and waited for: the next
+        (void)hipStreamSynchronize(ctx->stream);                                           // call's streams do not wait for the null stream)
       }
     }};
     std::vector<uint64_t> minvals((size_t)B * m);
@@ -293,7 +294,10 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       // anyone reading the arena) must see zeros there, not somebody's left-overs
       const uint8_t *before = ctx->prove_arena.p;
       ctx->prove_arena.alloc(arena_need + 256);
-      if (ctx->prove_arena.p != before) HIP_CHECK(hipMemset(ctx->prove_arena.p, 0, ctx->prove_arena.n));
+      if (ctx->prove_arena.p != before) {  // (on a stream of ours and waited for: the sub-batch streams do not wait for the null stream)
+        HIP_CHECK(hipMemsetAsync(ctx->prove_arena.p, 0, ctx->prove_arena.n, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      }
     }
     arena_base = ctx->prove_arena.p;
     carve();

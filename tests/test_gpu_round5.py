@@ -374,3 +374,39 @@ def test_prover_slice_form_equals_workgroup_form(bpp, packed, m, t, count):
             assert (packed.prove(*args) == ref).all(), (waves, parts, ct)
     params.close()
     eng.close()
+
+
+def test_status_words_of_an_earlier_batch_never_leak(bpp, packed):
+    """k_results_out writes a block's status words only when the block holds a finding, and the host clears the blocks it skipped
+    (settle_status); the page-locked buffer, and what is known about it, is recycled from batch to batch.  A finding at position 40
+    of a 64-proof call must not resurface in later, clean calls of 2, 16, 40 and 200 proofs on the same context (it did, for one
+    commit of round 5: the block was cleared up to the CURRENT batch's size only), nor after a call that fails before any kernel
+    runs; the finding itself is reported every time it is really there."""
+    import bench
+    eng = bpp.Engine(0)
+    params = bpp.RangeParameters.init(64, 1, bpp.create_pedersen_gens_with_extension_degree(1), engine=eng)
+    d = bench.make_inputs(np, packed, params, 300, seed=5353)
+
+    def call(n, tamper=None, lo=0):
+        pr = d["proofs"][lo:lo + n].copy()
+        if tamper == "identity":
+            pr[min(40, n - 1), 1 + 32:1 + 64] = 0           # A = the identity's encoding: PASS 1 refuses (a status bit)
+        elif tamper == "scalar":
+            pr[0, 1 + 32 + 96:1 + 32 + 128] = 0xff           # r1 >= l: refused while parsing, no kernel runs
+        sl = slice(lo, lo + n)
+        inp = packed.PackedInput(pr, d["commitments"][sl], d["min_values"][sl], d["min_present"][sl], None, LABEL)
+        try:
+            packed.verify_batch(params, inp, bpp.VerifyAction.VerifyOnly, 0)
+            return 0
+        except bpp.ProofError as e:
+            return int(e.kind)
+    K = bpp.ProofErrorKind
+    for rep in range(2):
+        assert call(64, "identity") == int(K.VerificationFailed)
+        assert [call(n, None, lo) for n, lo in ((2, 7), (16, 20), (40, 50), (200, 90), (1, 5), (64, 3))] == [0] * 6
+        assert call(100, "scalar") == int(K.InvalidArgument)
+        assert call(48, None, 100) == 0
+        assert call(300, "identity") == int(K.VerificationFailed)  # block 0 of two
+        assert call(300) == 0 and call(5) == 0
+    params.close()
+    eng.close()
