@@ -2754,10 +2754,10 @@ int bpp_prove_secret_bytes(bpp_ctx *ctx, uint64_t *examined, uint64_t *nonzero) 
       seen += h.size();
       wipe(h.data(), h.size());
     }
-    for (PinnedBuf<uint8_t> *pb : {&ctx->prove_pin_in, &ctx->prove_pin_out}) {
-      if (!pb->p || !pb->n) continue;
-      for (size_t i = 0; i < pb->n; i++) cnt += pb->p[i] != 0;
-      seen += pb->n;
+    // (the staging on the way out holds proofs and status words: nothing secret, not looked at)
+    if (ctx->prove_pin_in.p && ctx->prove_pin_in.n) {
+      for (size_t i = 0; i < ctx->prove_pin_in.n; i++) cnt += ctx->prove_pin_in.p[i] != 0;
+      seen += ctx->prove_pin_in.n;
     }
     *examined = seen;
     *nonzero = cnt;

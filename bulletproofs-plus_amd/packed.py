@@ -83,7 +83,7 @@ def prove(params, values, blindings, commitments, min_values, min_present, seed_
     items["rng_bytes"] = _rows(rng_bytes)
     items["rng_len"] = rng_bytes.shape[1]
     plen = 1 + 32 * (t + 5 + 2 * rounds)
-    out = np.zeros((n, plen), dtype=np.uint8)
+    out = np.empty((n, plen), dtype=np.uint8)  # (every byte is written by the call, or the call raises)
     got = c_size_t()
     err = ctypes.create_string_buffer(256)
     eng = params.engine

@@ -481,8 +481,8 @@ int bpp_shader_clock(bpp_ctx *ctx, uint32_t window_us, double *ghz);
  * next upload will adopt: must read 0. */
 int bpp_batch_secret_bytes(bpp_ctx *ctx, uint64_t batch, uint64_t *nonzero);
 /* the same for the prover (tests/test_gpu_round5.py): the context's prover arena on the device -- witness bytes, bit vectors, nonces,
- * blinding-factor accumulators, the transcript-RNG states keyed with the witness -- and its page-locked staging in both
- * directions (witness bytes in; proofs and per-proof states out), which bpp_prove_batch wipes on EVERY exit path (the reference
+ * blinding-factor accumulators, the transcript-RNG states keyed with the witness -- and its page-locked staging on the way IN
+ * (the witness bytes; on the way out only proofs and status words travel), which bpp_prove_batch wipes on EVERY exit path (the reference
  * keeps all of it in Zeroizing<>: src/range_proof.rs:300-301,325,438-464,542-571).  *examined = bytes looked at (0 before the
  * first prove call), *nonzero = how many of them are not zero: must read 0 between calls. */
 int bpp_prove_secret_bytes(bpp_ctx *ctx, uint64_t *examined, uint64_t *nonzero);

@@ -410,3 +410,37 @@ def test_status_words_of_an_earlier_batch_never_leak(bpp, packed):
         assert call(300) == 0 and call(5) == 0
     params.close()
     eng.close()
+
+
+_ENV_CHILD = r'''
+import ctypes, importlib, json, sys
+sys.path.insert(0, {root!r})
+bpp = importlib.import_module("bulletproofs-plus_amd")
+packed = importlib.import_module("bulletproofs-plus_amd.packed")
+dmod = importlib.import_module("bulletproofs-plus_amd.dist")
+eng = bpp.Engine(0)
+note1 = eng.lib.bpp_ctx_last_error(eng.ctx).decode()
+info = packed.runtime_info(eng)
+c = dmod.ShardComm(eng, 0, 1, local_group=77)
+note2 = eng.lib.bpp_ctx_last_error(eng.ctx).decode()
+c.close()
+print("RESULT " + json.dumps({{"note1": note1, "limit": info["small_call_limit"], "note2": note2}}))
+'''
+
+
+def test_malformed_environment_values_keep_the_defaults_and_say_so(tmp_path):
+    """ADVICE r4: BPP_SMALL_CALLS_IN_FLIGHT and BPP_COMM_TIMEOUT_MS were read with atoi -- a typo became 0, i.e. "no gate" and "no
+    deadline".  Now a value that is not a whole number keeps the default (12 calls; 60 000 ms) and leaves a note where
+    bpp_ctx_last_error finds it; well-formed values still apply (a second child)."""
+    script = tmp_path / "env_child.py"
+    script.write_text(_ENV_CHILD.format(root=ROOT))
+
+    def run(**env):
+        r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([x for x in r.stdout.splitlines() if x.startswith("RESULT ")][0][7:])
+    bad = run(BPP_SMALL_CALLS_IN_FLIGHT="1x", BPP_COMM_TIMEOUT_MS="soon")
+    assert bad["limit"] == 12 and "BPP_SMALL_CALLS_IN_FLIGHT" in bad["note1"] and "default" in bad["note1"], bad
+    assert "BPP_COMM_TIMEOUT_MS" in bad["note2"] and "60000" in bad["note2"], bad
+    good = run(BPP_SMALL_CALLS_IN_FLIGHT="5", BPP_COMM_TIMEOUT_MS="2500")
+    assert good["limit"] == 5 and "BPP_" not in good["note1"] and "BPP_" not in good["note2"], good
