@@ -27,8 +27,8 @@ WIDE_PROBE_HOST=2 WIDE_PROBE_N=256 WIDE_PROBE_S=1,4,8,16,32,64 timeout -k 10 300
 # the same separate callers with the admission gate switched off (what round 3 measured)
 BPP_SMALL_CALLS_IN_FLIGHT=0 WIDE_PROBE_HOST=1 WIDE_PROBE_N=256 WIDE_PROBE_S=16,32,64 timeout -k 10 300 python3 tools/wide_probe.py 2>> $O/${TAG}_bench.err | grep "^{" | sed 's/"form": "packed"/"form": "packed, gate off"/' >> $O/${TAG}_calls_in_flight.jsonl
 timeout -k 10 120 python3 tools/bench_prover_leg.py > $O/${TAG}_prover_leg.json 2>> $O/${TAG}_bench.err
-# the prover: kernel timeline of one call; counters with ONE sub-batch stream (with two, a dispatch's SQ counters include whatever
-# the other stream ran beside it -- round 4's 208 M VALU instructions "of kp_round" were mostly the other sub-batch's MSM); phase clocks
+# the prover on configs[4]: kernel timeline of one call; SQ counters per kernel with ONE sub-batch stream (a dispatch = all 1024
+# proofs; the headline's counter pass only sees the input generation's dispatches: 4096 non-aggregated proofs each); phase clocks
 timeout -k 10 200 bash tools/gpu_prover_trace.sh $O/${TAG}_prover_launches.txt
 rm -rf $O/prov_pmc
 BPP_PROVE_SUBS=1 PROVER_ITERS=3 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/prov_pmc -- python3 tools/bench_prover_leg.py > /dev/null 2>> $O/${TAG}_bench.err

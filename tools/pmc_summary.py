@@ -66,22 +66,28 @@ def counters(d):
                 e["dispatches"] += 1
                 if r.get("Start_Timestamp") and r.get("End_Timestamp"):
                     e["dur_ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                try:  # workgroups of the dispatch: what "per dispatch" has to be divided by to compare launches of different sizes
+                    e["workgroups"] += int(r.get("Grid_Size", 0) or 0) // max(1, int(r.get("Workgroup_Size", 1) or 1))
+                except ValueError:
+                    pass
             e[r["Counter_Name"]] += float(r["Counter_Value"])
     return acc
 
 
 def cmd_counters(d, out):
     acc = counters(d)
-    names = sorted({c for e in acc.values() for c in e if c not in ("dispatches", "dur_ns")})
+    names = sorted({c for e in acc.values() for c in e if c not in ("dispatches", "dur_ns", "workgroups")})
     tot_valu = sum(e.get("SQ_INSTS_VALU", 0.0) for e in acc.values()) or 1.0
     with open(out, "w") as fh:
         w = csv.writer(fh)
-        w.writerow(["kernel", "dispatches", "avg_us"] + names + ["wait_inst_frac", "active_valu_frac", "valu_share", "valu_per_dispatch"])
+        w.writerow(["kernel", "dispatches", "avg_us"] + names + ["wait_inst_frac", "active_valu_frac", "valu_share", "valu_per_dispatch",
+                                                               "workgroups_per_dispatch", "valu_per_workgroup"])
         for k, e in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", kv[1].get("dur_ns", 0))):
             wc = e.get("SQ_WAVE_CYCLES", 0.0)
             w.writerow([k, int(e["dispatches"]), "%.1f" % (e["dur_ns"] / max(e["dispatches"], 1) / 1e3)] + ["%d" % e.get(c, 0) for c in names] +
                        ["%.3f" % (e.get("SQ_WAIT_INST_ANY", 0) / wc) if wc else "", "%.3f" % (e.get("SQ_ACTIVE_INST_VALU", 0) / wc) if wc else "",
-                        "%.4f" % (e.get("SQ_INSTS_VALU", 0) / tot_valu), "%d" % (e.get("SQ_INSTS_VALU", 0) / max(e["dispatches"], 1))])
+                        "%.4f" % (e.get("SQ_INSTS_VALU", 0) / tot_valu), "%d" % (e.get("SQ_INSTS_VALU", 0) / max(e["dispatches"], 1)),
+                        "%d" % (e.get("workgroups", 0) / max(e["dispatches"], 1)), ("%d" % (e.get("SQ_INSTS_VALU", 0) / e["workgroups"])) if e.get("workgroups") else ""])
 
 
 def _per_launch(d, counter, sub):
