@@ -451,9 +451,46 @@ pub struct Ticket {
 pub struct ShardComm {
     raw: *mut ffi::bpp_comm,
     pub rank: i32,
+    /// the caller's transport, kept alive (and at a fixed address) as long as the communicator (`with_transport`)
+    transport: Option<Box<Transport>>,
 }
 unsafe impl Send for ShardComm {}
+
+/// A caller-supplied all_gather: `send` = this rank's block, `recv` = `world` blocks in rank order (this rank's included);
+/// `Err` = the exchange failed (the verify call then returns `GpuError::Comm` and the communicator is dead).
+pub type AllGather = dyn FnMut(&[u8], &mut [u8]) -> Result<(), ()> + Send;
+struct Transport {
+    f: Box<AllGather>,
+    world: usize,
+}
+unsafe extern "C" fn transport_trampoline(user: *mut std::os::raw::c_void, send: *const std::os::raw::c_void, recv: *mut std::os::raw::c_void,
+                                          bytes_per_rank: usize) -> std::os::raw::c_int {
+    // (a panic must not unwind into C)
+    let r = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| {
+        let t = &mut *(user as *mut Transport);
+        let s = std::slice::from_raw_parts(send as *const u8, bytes_per_rank);
+        let d = std::slice::from_raw_parts_mut(recv as *mut u8, bytes_per_rank * t.world);
+        (t.f)(s, d)
+    }));
+    match r {
+        Ok(Ok(())) => 0,
+        Ok(Err(())) => 1,
+        Err(_) => 2,
+    }
+}
+
 impl ShardComm {
+    /// `bpp_comm_create_callbacks`: the sharded entry points over the caller's own channel (MPI, TCP, ...) instead of RCCL --
+    /// the exchanges are 32 bytes per proof and 256 bytes per batch, staged through host memory by the engine.  `all_gather` is
+    /// called on the thread that makes the verify call, in the same order on every rank.
+    pub fn with_transport(engine: &Engine, rank: i32, world: i32, all_gather: Box<AllGather>) -> Result<Self, GpuError> {
+        let mut t = Box::new(Transport { f: all_gather, world: world as usize });
+        let mut raw = ptr::null_mut();
+        map_rc(unsafe {
+            ffi::bpp_comm_create_callbacks(engine.ctx, rank, world, Some(transport_trampoline), &mut *t as *mut Transport as *mut std::os::raw::c_void, &mut raw)
+        }, engine.last_error())?;
+        Ok(ShardComm { raw, rank, transport: Some(t) })
+    }
     pub fn unique_id() -> Result<[u8; 128], GpuError> {
         let mut id = [0u8; 128];
         map_rc(unsafe { ffi::bpp_comm_unique_id(id.as_mut_ptr()) }, "RCCL not loadable".into())?;
@@ -462,12 +499,12 @@ impl ShardComm {
     pub fn create(engine: &Engine, id: &[u8; 128], rank: i32, world: i32) -> Result<Self, GpuError> {
         let mut raw = ptr::null_mut();
         map_rc(unsafe { ffi::bpp_comm_create(engine.ctx, id.as_ptr(), rank, world, &mut raw) }, engine.last_error())?;
-        Ok(ShardComm { raw, rank })
+        Ok(ShardComm { raw, rank, transport: None })
     }
 }
 impl Drop for ShardComm {
     fn drop(&mut self) {
-        unsafe { ffi::bpp_comm_destroy(self.raw) }
+        unsafe { ffi::bpp_comm_destroy(self.raw) }  // (before `transport` goes: no call can be inside the callback any more)
     }
 }
 
