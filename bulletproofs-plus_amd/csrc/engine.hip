@@ -531,6 +531,7 @@ struct bpp_ctx {
   // high-priority twins of the sub-batch streams: the prover's small latency-bound kernels (Fiat-Shamir step, vector fold,
   // point encoding) run on them so that they are not starved by the other sub-batch's chip-filling fixed-base MSM
   std::vector<hipStream_t> prove_lane_streams;
+  hipStream_t prove_msm_stream = nullptr;  // the one stream every sub-batch's fixed-base MSM runs on, first in first out ("prove_fifo")
   std::vector<hipEvent_t> prove_sync_events;  // two per sub-batch: lane step done / fixed-base MSM done
   // the witness check of a sub-batch (commit(v_j, r_j) against the statement's commitments, :275-284) runs on a stream of its own
   // beside the call's first steps; two events per sub-batch: inputs resident / check done
@@ -543,7 +544,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1, prove_parts = -1, prove_waves = -1;
+        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1, prove_parts = -1, prove_waves = -1, prove_fifo = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -585,6 +586,7 @@ const OptionName kOptions[] = {
     {"ct", "BPP_CT", &bpp_ctx::Options::ct},
     {"prove_parts", "BPP_PROVE_PARTS", &bpp_ctx::Options::prove_parts},
     {"prove_waves", "BPP_PROVE_WAVES", &bpp_ctx::Options::prove_waves},
+    {"prove_fifo", "BPP_PROVE_FIFO", &bpp_ctx::Options::prove_fifo},
     {"static_gemm", "BPP_STATIC_GEMM", &bpp_ctx::Options::static_gemm},
     {"lazy_columns", "BPP_LAZY_COLUMNS", &bpp_ctx::Options::lazy_columns},
 };
@@ -903,6 +905,10 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
     (void)hipStreamDestroy(ps);
   }
   for (auto &e : ctx->prove_sync_events) (void)hipEventDestroy(e);
+  if (ctx->prove_msm_stream) {
+    (void)hipStreamSynchronize(ctx->prove_msm_stream);
+    (void)hipStreamDestroy(ctx->prove_msm_stream);
+  }
   for (auto &ps : ctx->prove_aux_streams) {
     (void)hipStreamSynchronize(ps);
     (void)hipStreamDestroy(ps);

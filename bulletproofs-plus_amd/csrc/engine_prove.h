@@ -43,6 +43,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         for (auto &ps : ctx->prove_aux_streams) (void)hipStreamSynchronize(ps);
         for (auto &ps : ctx->prove_streams) (void)hipStreamSynchronize(ps);
         for (auto &ps : ctx->prove_lane_streams) (void)hipStreamSynchronize(ps);
+        if (ctx->prove_msm_stream) (void)hipStreamSynchronize(ctx->prove_msm_stream);
         (void)hipMemsetAsync(ctx->prove_arena.p, 0, ctx->prove_arena.n, ctx->stream);  // (stream-ordered and waited for: the next
         (void)hipStreamSynchronize(ctx->stream);                                           // call's streams do not wait for the null stream)
       }
@@ -194,6 +195,21 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       if (cdiv(mn + t + 1, parts) > FBP_MAX_PER) parts = 0;  // (aggregations whose rounds do not fit the slices: the workgroup form)
     }  // one launch per round for encoding + Fiat-Shamir step + vector step (tests run both)
     const bool prio = ctx->opt.prove_prio > 0;  // (off by default: measured, no gain -- profiles/r04_prover_prio_ab.txt)
+    // The fixed-base MSMs of ALL sub-batches on ONE stream, in the order they are enqueued (round by round, sub-batch by
+    // sub-batch), each behind its own round kernel by an event: first in, first out.  On a stream per sub-batch two MSM launches
+    // that are both ready SHARE the chip: the later one ends when it would have ended anyway, but the earlier one ends later by
+    // the time they overlapped -- and its sub-batch's next round kernel, the chain that bounds the call, starts later by as much.
+    // Measured (profiles/r05_prover_waves_ab.txt, (d)): the MSMs' own event time drops 4 %, the call gets 4 % SLOWER -- two more
+    // cross-stream events per round and sub-batch cost more than the sharing did.  Off unless asked for ("prove_fifo" = 1).
+    const bool fifo = !prio && n_sub > 1 && ctx->opt.prove_fifo > 0;
+    if (fifo && !ctx->prove_msm_stream) HIP_CHECK(hipStreamCreateWithFlags(&ctx->prove_msm_stream, hipStreamNonBlocking));
+    if (prio || fifo) {
+      while (ctx->prove_sync_events.size() < 2 * (size_t)n_sub) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->prove_sync_events.push_back(e);
+      }
+    }
     if (prio) {
       int least = 0, greatest = 0;
       HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -201,11 +217,6 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         hipStream_t ns;
         HIP_CHECK(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, greatest));
         ctx->prove_lane_streams.push_back(ns);
-      }
-      while (ctx->prove_sync_events.size() < 2 * (size_t)n_sub) {
-        hipEvent_t e;
-        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ctx->prove_sync_events.push_back(e);
       }
     }
     while (ctx->prove_aux_streams.size() < n_sub) {
@@ -220,15 +231,16 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     }
     // lane(q): the stream of sub-batch q's small kernels; msm(q): of its fixed-base MSMs (the same stream without prove_prio)
     auto lane_stream = [&](uint32_t q) { return prio ? ctx->prove_lane_streams[q] : ctx->prove_streams[q]; };
+    auto msm_stream = [&](uint32_t q) { return fifo ? ctx->prove_msm_stream : ctx->prove_streams[q]; };
     auto to_msm = [&](uint32_t q) {  // the MSM stream continues behind everything enqueued on the lane stream so far
-      if (!prio) return;
-      HIP_CHECK(hipEventRecord(ctx->prove_sync_events[2 * q], ctx->prove_lane_streams[q]));
-      HIP_CHECK(hipStreamWaitEvent(ctx->prove_streams[q], ctx->prove_sync_events[2 * q], 0));
+      if (!prio && !fifo) return;
+      HIP_CHECK(hipEventRecord(ctx->prove_sync_events[2 * q], lane_stream(q)));
+      HIP_CHECK(hipStreamWaitEvent(msm_stream(q), ctx->prove_sync_events[2 * q], 0));
     };
     auto to_lane = [&](uint32_t q) {  // and back
-      if (!prio) return;
-      HIP_CHECK(hipEventRecord(ctx->prove_sync_events[2 * q + 1], ctx->prove_streams[q]));
-      HIP_CHECK(hipStreamWaitEvent(ctx->prove_lane_streams[q], ctx->prove_sync_events[2 * q + 1], 0));
+      if (!prio && !fifo) return;
+      HIP_CHECK(hipEventRecord(ctx->prove_sync_events[2 * q + 1], msm_stream(q)));
+      HIP_CHECK(hipStreamWaitEvent(lane_stream(q), ctx->prove_sync_events[2 * q + 1], 0));
     };
     const uint32_t stride = 2 * mn + t + 1;
     struct Sub {
@@ -351,7 +363,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     // alone: its latency-bound Fiat-Shamir kernels with nothing beside them).
     for (uint32_t q = 0; q < n_sub; q++) {
       Sub &u = subs[q];
-      hipStream_t s = lane_stream(q), sm = ctx->prove_streams[q];
+      hipStream_t s = lane_stream(q), sm = msm_stream(q);
       const uint32_t nb = u.nb;
       HIP_CHECK(hipMemcpyAsync(u.d_bytes, pin_bytes + u.bytes_lo, u.bytes_len, hipMemcpyHostToDevice, s));
       HIP_CHECK(hipMemcpyAsync(u.d_states, pin_states, states.size(), hipMemcpyHostToDevice, s));
@@ -385,7 +397,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     for (uint32_t j = 0; j <= rounds; j++)
       for (uint32_t q = 0; q < n_sub; q++) {
         Sub &u = subs[q];
-        hipStream_t s = lane_stream(q), sm = ctx->prove_streams[q];
+        hipStream_t s = lane_stream(q), sm = msm_stream(q);
         const uint32_t nb = u.nb;
         uint8_t *lr_prev = j ? u.d_lr + (size_t)(j - 1) * nb * 64 : nullptr;
         if (fused) {  // the previous round's L / R are encoded by the same launch (kernels_prove.h: kp_round)
@@ -456,6 +468,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       HIP_CHECK(hipStreamSynchronize(lane_stream(q)));  // (everything of the MSM stream lies in front of the lane stream's tail)
       HIP_CHECK(hipStreamSynchronize(ctx->prove_streams[q]));
     }
+    if (fifo) HIP_CHECK(hipStreamSynchronize(ctx->prove_msm_stream));
     arena_clean = true;  // every sub-batch's arena range was zeroed on its stream
     if (ctx->profile) {
       bpp_prove_profile &pp = ctx->pprof;
