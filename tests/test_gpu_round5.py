@@ -131,9 +131,13 @@ def test_two_ranks_as_processes_on_one_gpu_through_bench():
     --gpus 2 under torch.distributed.run, both ranks on device 0, the sharded leg's all_gathers through the caller-supplied
     transport over gloo (RCCL refuses two ranks on one device).  The headline AND extra.wide (BASELINE configs[3]: one 4096-proof
     reference batch over the ranks) must complete on both ranks, the line must say what it is, both processes must exit 0."""
+    import socket
     env = dict(os.environ, BPP_BENCH_WAVE_BATCHES="8", BPP_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sk:  # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--batches-per-step", "8",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--batches-per-step", "8",
            "--preheat-ms", "0", "--wide-steps", "4", "--no-cpu-baseline", "--no-traffic"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
