@@ -452,6 +452,7 @@ pub struct ShardComm {
     raw: *mut ffi::bpp_comm,
     pub rank: i32,
     /// the caller's transport, kept alive (and at a fixed address) as long as the communicator (`with_transport`)
+    #[allow(dead_code)]
     transport: Option<Box<Transport>>,
 }
 unsafe impl Send for ShardComm {}
