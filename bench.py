@@ -49,6 +49,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 VALU_PEAK_TMAD = 39.3
 LABEL = b"BatchedRangeProofTest"  # benches/range_proof.rs:49
 FAIL_STEP = int(os.environ.get("BPP_BENCH_FAIL_STEP", "0"))  # harness self-test: the n-th step of a leg raises
+HOST_CORES_PER_RANK = 4.0  # what a rank with host-side weight chains keeps busy at the headline rate, rounded up (RESULTS.md)
+WATCHDOG_EXIT = 4  # exit code of every rank when the sharded leg's watchdog fires (the line is printed first)
 
 
 def parse_args():
@@ -82,6 +84,9 @@ def parse_args():
     ap.add_argument("--transport", choices=("rccl", "gloo"), default=os.environ.get("BPP_BENCH_TRANSPORT", "rccl"),
                     help="N > 1, the sharded leg's all_gathers: RCCL on device buffers, or the caller-supplied transport of the C ABI "
                          "(bpp_comm_create_callbacks) over torch.distributed's gloo")
+    ap.add_argument("--chain", choices=("host", "device", "auto"), default=os.environ.get("BPP_BENCH_CHAIN", "auto"),
+                    help="where the batch-weight chains run (engine option \"chain\"): host cores (csrc/chain_host.h), one wavefront per "
+                         "reference batch on the device (csrc/chain_dev.h), or the harness' rule")
     ap.add_argument("--one-device", action="store_true", default=os.environ.get("BPP_BENCH_ONE_DEVICE", "0") == "1",
                     help="every local rank on device 0 (a rehearsal of the multi-rank code as PROCESSES on a one-GPU box; RCCL refuses "
                          "two ranks on one device, so this implies --transport gloo); the line says so")
@@ -105,6 +110,46 @@ def usable_cpus():
         except (OSError, ValueError):
             pass
     return n
+
+
+def thread_cpu_seconds():
+    """{tid: (comm, user + system CPU seconds)} of every thread of this process (/proc/self/task): who is burning host
+    cores during a timed region -- weight-chain workers, callers waiting on a stream, the runtime's own threads"""
+    out = {}
+    try:
+        tick = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                raw = open("/proc/self/task/%s/stat" % tid).read()
+            except OSError:
+                continue
+            comm = raw[raw.index("(") + 1:raw.rindex(")")]
+            f = raw[raw.rindex(")") + 2:].split()
+            out[int(tid)] = (comm, (int(f[11]) + int(f[12])) / tick)
+    except (OSError, ValueError):
+        pass
+    return out
+
+
+def thread_cpu_delta(before, after, wall_s):
+    """cores kept busy per thread NAME over a region of `wall_s` seconds (threads of one name summed), busiest first"""
+    acc = {}
+    for tid, (comm, sec) in after.items():
+        d = sec - before.get(tid, (comm, 0.0))[1]
+        if d > 0:
+            e = acc.setdefault(comm, [0, 0.0])
+            e[0] += 1
+            e[1] += d
+    rows = sorted(acc.items(), key=lambda kv: -kv[1][1])
+    return [{"thread": k, "threads": v[0], "cores_busy": round(v[1] / wall_s, 3)} for k, v in rows if wall_s > 0][:8]
+
+
+def resolve_chain_mode(args, world):
+    """--chain auto: the host chains (the lowest latency per call) unless the ranks of this node would have to share fewer
+    than HOST_CORES_PER_RANK schedulable cores each -- then the device chains, which leave the host alone"""
+    if args.chain != "auto":
+        return args.chain
+    return "device" if usable_cpus() / max(1, world) < HOST_CORES_PER_RANK else "host"
 
 
 def self_launch(args):
@@ -718,6 +763,9 @@ def main():
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env > 1 and "BPP_HOST_THREADS" not in os.environ:
         os.environ["BPP_HOST_THREADS"] = str(max(4, min(32, usable_cpus() // world_env)))
+    # where the weight chains run: read by the library once per context, when it is created (BPP_CHAIN)
+    chain_mode = resolve_chain_mode(args, world_env)
+    os.environ["BPP_CHAIN"] = "1" if chain_mode == "device" else "0"
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -892,17 +940,20 @@ def main():
     sync()  # under torch.distributed the first barrier builds the communicator (100s of ms): not between warm-up and timing
     step_error, elapsed, lat, profs, clock_ghz = None, 0.0, [], [], None
     pool_cpu0 = proc_cpu0 = 0
+    thr0 = {}
     try:
         if args.preheat_ms > 0 and not args.only:
             leg.run_steps(max(1, int(args.preheat_ms / 2.7)))
         leg.run_steps(args.warmup)  # (the warm-up, outside the host-CPU accounting below; timed() then starts at once)
         pool_cpu0, proc_cpu0 = bpp.host_pool_cpu_ns(), time.process_time()
+        thr0 = thread_cpu_seconds()
         elapsed, lat, profs, clock_ghz = timed(leg, args.steps, 0, sync,
                                                clock=lambda: bpp.shader_clock_ghz(clk_eng, int(1e3 * max(5.0, min(200.0, 0.6 * est_ms)))))
     except Exception as e:  # noqa: BLE001 - a failed step: no number; the other ranks still get their collective
         step_error = e
     pool_cpu_ms = (bpp.host_pool_cpu_ns() - pool_cpu0) / 1e6 / max(1, args.steps)
     proc_cpu_ms = (time.process_time() - proc_cpu0) * 1e3 / max(1, args.steps)
+    thr_busy = thread_cpu_delta(thr0, thread_cpu_seconds(), elapsed) if step_error is None else []
     local_ms = 1e3 * elapsed / max(1, args.steps)
     clk_eng.close()
     # every timed step ran and raised nothing (each step verifies all its batches or raises)
@@ -952,12 +1003,14 @@ def main():
                              "benches/range_proof.rs:206-262), %.1f s" % (1024 * R, gen_s)},
         "step_latency_ms": 1e3 * sum(lat) / len(lat), "steps_completed": len(lat), "all_steps_verified": bool(ok_all),
         "host_threads": bpp.host_threads(), "nproc": os.cpu_count(), "usable_cpus": usable_cpus(),
-        "shader_clock_ghz": clock_ghz,
+        "weight_chains": chain_mode, "shader_clock_ghz": clock_ghz,
         # the one sequential part of a verification stays on the host (the batch weight chains, src/range_proof.rs:849-853,894):
         # CPU time of the library's host pool per timed step, and of the whole process; cores kept busy = cpu ms / step ms.  With
         # N ranks on one node, N x host_cores_busy against the node's cores tells a host-bound scaling curve from a GPU-bound one.
         "host_chain_cpu_ms_per_step": pool_cpu_ms, "host_process_cpu_ms_per_step": proc_cpu_ms,
         "host_cores_busy": proc_cpu_ms / local_ms if local_ms > 0 else None,
+        # the same by thread name (/proc/self/task, 10 ms ticks: meaningful for regions of 0.5 s and more)
+        "host_cores_busy_by_thread": thr_busy,
     }
     if args.one_device:
         out["config"]["devices"] = "ALL %d ranks on device 0 (--one-device: a rehearsal of the multi-rank code, not a scaling point)" % world
@@ -999,13 +1052,16 @@ def main():
         # The headline above is complete; this leg must not be able to take it down.  An exception is reported inside the
         # object; a collective that never returns (this leg cannot be rehearsed on a multi-GPU node by the builder) is cut
         # short by a watchdog: after --wide-timeout seconds every rank gives up at once, rank 0 prints the line it has
-        # (extra.wide = the timeout) and the process ends without waiting for the stuck communicator.
+        # (extra.wide = the timeout) and EVERY rank ends with a non-zero code without waiting for the stuck communicator: a
+        # kernel or collective left hanging behind must never read as success to whoever started the run.
         def give_up():
             if rank == 0:
                 out["extra"] = dict(extra, wide={"error": "the sharded leg did not finish within %d s; headline unaffected" % args.wide_timeout,
                                                  "rccl_ranks": world})
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            sys.stderr.write("bench.py: rank %d: the sharded leg hung; giving up with exit code %d\n" % (rank, WATCHDOG_EXIT))
+            sys.stderr.flush()
+            os._exit(WATCHDOG_EXIT)
         dog = threading.Timer(args.wide_timeout, give_up)
         dog.daemon = True
         dog.start()

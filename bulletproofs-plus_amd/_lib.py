@@ -44,7 +44,7 @@ class Profile(Structure):
     _fields_ = [(n, c_float) for n in ("transcripts_ms", "decompress_ms", "chain_host_ms", "scalars_ms", "reduce_ms",
                                        "msm_digits_ms", "msm_sort_ms", "msm_accumulate_ms", "msm_bucket_reduce_ms",
                                        "msm_final_ms", "total_ms")] + \
-               [(n, c_uint32) for n in ("msm_terms", "msm_window_bits", "msm_windows", "msm_groups")] + [("masks_ms", c_float)]
+               [(n, c_uint32) for n in ("msm_terms", "msm_window_bits", "msm_windows", "msm_groups")] + [("masks_ms", c_float), ("chain_device_ms", c_float)]
 
 
 class ProveProfile(Structure):
@@ -143,6 +143,7 @@ SYMBOLS = [
     ("bpp_batch_prepare", c_int, [c_void_p, c_uint64, c_size_t]),
     ("bpp_host_threads", c_int, []),
     ("bpp_host_pool_cpu_ns", c_uint64, []),
+    ("bpp_device_chain_stats", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     ("bpp_shader_clock", c_int, [c_void_p, c_uint32, POINTER(c_double)]),
     ("bpp_transcript_new", c_int, [c_void_p, c_size_t, c_void_p]),
     ("bpp_batch_secret_bytes", c_int, [c_void_p, c_uint64, POINTER(c_uint64)]),

@@ -145,6 +145,12 @@ class Engine:
         """bpp_ctx_set_option: per-context knob (tests, A/B timing); -1 restores the engine's own rule"""
         _check(self.lib.bpp_ctx_set_option(self.ctx, name.encode(), int(value)), self.ctx)
 
+    def device_chain_stats(self):
+        """bpp_device_chain_stats: (verifications whose weight chains ran on the device, those sent back to the host chains)"""
+        calls, redraws = c_uint64(), c_uint64()
+        _check(self.lib.bpp_device_chain_stats(self.ctx, byref(calls), byref(redraws)), self.ctx)
+        return int(calls.value), int(redraws.value)
+
     def last_profile(self):
         p = _lib.Profile()
         self.lib.bpp_profile_get(self.ctx, byref(p))

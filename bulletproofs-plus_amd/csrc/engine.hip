@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/bpp.h"
+#include "chain_dev.h"
 #include "chain_host.h"
 #include "ct.h"
 #include "kernels_prove.h"
@@ -417,6 +418,7 @@ struct Batch {
   int uniform_mn = -1;         // -1 not looked at yet; 0 the proofs differ in shape; else the common m * n_bits
   bool gemm_hi_ready = false;  // the last k_scalars_shared of this batch wrote the high digit tables
   DevBuf<uint8_t> rng_out, weights, masks, chal_bytes;
+  DevBuf<uint32_t> chain_wide;  // device chain: the 64 PRF bytes per proof as k_weight_chain leaves them (chain_dev.h)
   DevBuf<uint32_t> status, group_first, group_dlo;
   DevBuf<uint32_t> dec_spill;  // k_decompress parks three field elements per proof point here across its squaring chain
   DevBuf<niels> dynpts;
@@ -436,6 +438,7 @@ struct Batch {
   bool status_settled = true;
   bool have_trace = false, phase1_done = false;
   bool status_clean = false;     // status[] == status0[]: k_results_out resets it behind every verification
+  bool dev_chain_pending = false;  // k_weight_chain of this call is on the chain stream: enqueue_phase2 waits for it
   bool weights_on_host = false;  // the last PASS 2 read its weights from h_weights (b.weights holds them only in the sharded forms)
   bool seeds_dirty = false, masks_dirty = false;  // device copies of seed nonces / recovered masks not yet wiped
 };
@@ -446,7 +449,7 @@ void adopt_buffers(Batch &dst, Batch &src) {
 #define BPP_ADOPT(f) dst.f.swap(src.f)
   BPP_ADOPT(d_ext_status); BPP_ADOPT(bytes); BPP_ADOPT(states); BPP_ADOPT(seeds); BPP_ADOPT(d_desc); BPP_ADOPT(minvals);
   BPP_ADOPT(src_off); BPP_ADOPT(owner); BPP_ADOPT(idx_commit); BPP_ADOPT(idx_proof); BPP_ADOPT(status0); BPP_ADOPT(chal);
-  BPP_ADOPT(rows); BPP_ADOPT(parts); BPP_ADOPT(gemm_lo); BPP_ADOPT(gemm_hi); BPP_ADOPT(gparts); BPP_ADOPT(gemm_mult); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(tab); BPP_ADOPT(rng_out); BPP_ADOPT(weights);
+  BPP_ADOPT(rows); BPP_ADOPT(parts); BPP_ADOPT(gemm_lo); BPP_ADOPT(gemm_hi); BPP_ADOPT(gparts); BPP_ADOPT(gemm_mult); BPP_ADOPT(scal); BPP_ADOPT(shr); BPP_ADOPT(tab); BPP_ADOPT(rng_out); BPP_ADOPT(weights); BPP_ADOPT(chain_wide);
   BPP_ADOPT(masks); BPP_ADOPT(chal_bytes); BPP_ADOPT(status); BPP_ADOPT(group_first); BPP_ADOPT(group_dlo); BPP_ADOPT(dynpts); BPP_ADOPT(dyn_hi); BPP_ADOPT(dec_spill);
   BPP_ADOPT(msm.counts); BPP_ADOPT(msm.starts); BPP_ADOPT(msm.sorted); BPP_ADOPT(msm.order); BPP_ADOPT(msm.order_win);
   BPP_ADOPT(msm.cls_hist);
@@ -523,6 +526,14 @@ struct bpp_ctx {
   // small inputs: decompression runs beside PASS 1 on a second stream (enqueue_phase1)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork, ev_join;
+  // the weight chains as a kernel (chain_dev.h): their own stream beside decompression and the weight-free scalars, the
+  // transcript Transcript::new(b"Bulletproofs+ verifier weights") leaves, and the "a weight was zero" word the host looks at
+  // with the results
+  hipStream_t chain_stream = nullptr;
+  hipEvent_t ev_chain_fork, ev_chain_done;
+  DevBuf<Strobe> d_chain_t0;
+  PinnedBuf<uint32_t> h_chain_zero;
+  uint64_t device_chain_calls = 0, device_chain_redraws = 0;
   DevBuf<uint8_t> scratch128;
   // batch prover: one device arena, page-locked staging and the sub-batch streams, all reused across calls
   DevBuf<uint8_t> prove_arena;
@@ -544,7 +555,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1, prove_parts = -1, prove_waves = -1, prove_fifo = -1;
+        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1, prove_parts = -1, prove_waves = -1, prove_fifo = -1, chain = -1, chain_test_zero = 0;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -589,6 +600,10 @@ const OptionName kOptions[] = {
     {"prove_fifo", "BPP_PROVE_FIFO", &bpp_ctx::Options::prove_fifo},
     {"static_gemm", "BPP_STATIC_GEMM", &bpp_ctx::Options::static_gemm},
     {"lazy_columns", "BPP_LAZY_COLUMNS", &bpp_ctx::Options::lazy_columns},
+    // where the batch-weight chains run: 0 host cores (chain_host.h), 1 the device (chain_dev.h), -1 the engine's rule (use_device_chain)
+    {"chain", "BPP_CHAIN", &bpp_ctx::Options::chain},
+    // tests: the device chain reports the weight of proof (value - 1) as zero, so that the redraw fall-back runs
+    {"chain_test_zero", "BPP_CHAIN_TEST_ZERO", &bpp_ctx::Options::chain_test_zero},
 };
 void options_from_env(bpp_ctx *c) {
   for (const OptionName &o : kOptions)
@@ -602,7 +617,7 @@ int fail(bpp_ctx *ctx, int code, const std::string &m, char *errbuf = nullptr, s
 }
 
 enum Mark { M_START = 0, M_TRANSCRIPTS, M_DECOMPRESS, M_SCALARS, M_WEIGHTS_IN, M_LANES, M_REDUCE, M_DIGITS, M_SORT, M_ORDER, M_ACC,
-            M_BUCKET, M_FINAL, M_MASKS0, M_MASKS, M_COUNT };
+            M_BUCKET, M_FINAL, M_MASKS0, M_MASKS, M_CHAIN, M_COUNT };
 
 struct StageTimer {
   bpp_ctx *ctx;
@@ -894,6 +909,12 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
     (void)hipEventDestroy(ctx->ev_fork);
     (void)hipEventDestroy(ctx->ev_join);
   }
+  if (ctx->chain_stream) {
+    (void)hipStreamSynchronize(ctx->chain_stream);
+    (void)hipStreamDestroy(ctx->chain_stream);
+    (void)hipEventDestroy(ctx->ev_chain_fork);
+    (void)hipEventDestroy(ctx->ev_chain_done);
+  }
   ctx->scratch128.release();
   for (auto &ps : ctx->prove_streams) {
     (void)hipStreamSynchronize(ps);
@@ -939,6 +960,14 @@ int bpp_runtime_info_get(bpp_ctx *ctx, bpp_runtime_info *out) {
   out->small_calls = D.small_calls;
   out->small_calls_queued = D.small_calls_queued;
   out->oversubscribed = D.contexts > out->hw_queues ? 1u : 0u;
+  return BPP_OK;
+}
+
+int bpp_device_chain_stats(bpp_ctx *ctx, uint64_t *calls, uint64_t *redraws) {
+  if (!ctx) return BPP_ERR_BAD_HANDLE;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (calls) *calls = ctx->device_chain_calls;
+  if (redraws) *redraws = ctx->device_chain_redraws;
   return BPP_OK;
 }
 
@@ -1576,9 +1605,37 @@ namespace {
 // rng_dev_dst != nullptr (the sharded form): the transcript-RNG bytes are copied device -> device right behind PASS 1 and
 // ev_rng is recorded there; nothing comes to the host and the function does not wait
 void plan_lanes(bpp_ctx *ctx, Batch &b, bool for_phase2 = false);
+
+// Where a call's weight chains run (option "chain" / BPP_CHAIN: 0 host, 1 device, -1 this rule).  The host runs a chain five
+// to eight times faster than a wavefront does (chain_host.h: 0.27 us per proof, chain_dev.h: ~2), so a call that WAITS for its
+// chains -- one call at a time, few groups -- keeps them on the host.  The device form is for callers that keep several
+// calls in flight and want the host left alone (a rank of an 8-GPU node: bench.py): it is chosen explicitly.
+bool use_device_chain(const bpp_ctx *ctx, const Batch &) { return ctx->opt.chain > 0; }
+
+// k_weight_chain + k_chain_finish on `st`: b.rng_out -> b.weights (canonical bytes), one wavefront per group
+void enqueue_device_chain(bpp_ctx *ctx, Batch &b, hipStream_t st) {
+  if (!ctx->d_chain_t0.p) {  // once per context: the weight transcript as Transcript::new leaves it (src/range_proof.rs:811)
+    Strobe t0;
+    const char *lbl = "Bulletproofs+ verifier weights";
+    merlin_new(t0, (const uint8_t *)lbl, (uint32_t)strlen(lbl));
+    ctx->d_chain_t0.alloc(1);
+    HIP_CHECK(hipMemcpy(ctx->d_chain_t0.p, &t0, sizeof(t0), hipMemcpyHostToDevice));
+    ctx->h_chain_zero.resize(1);
+  }
+  b.chain_wide.alloc((size_t)b.B * 16);
+  ctx->h_chain_zero[0] = 0;
+  const uint32_t test_zero = ctx->opt.chain_test_zero > 0 ? (uint32_t)ctx->opt.chain_test_zero : 0u;
+  hipLaunchKernelGGL(k_weight_chain, dim3(b.G), dim3(64), 0, st, b.rng_out.p, b.group_first.p, b.G, ctx->d_chain_t0.p, b.chain_wide.p);
+  hipLaunchKernelGGL(k_chain_finish, dim3(cdiv(b.B, 64)), dim3(64), 0, st, b.chain_wide.p, b.B, b.weights.p, ctx->h_chain_zero.dev(), test_zero);
+  ctx->device_chain_calls++;
+}
+
+// dev_chain: the weight chains follow PASS 1 as kernels (on a stream of their own beside the decompression and the weight-free
+// scalars; enqueue_phase2 joins it): nothing comes to the host and the function does not wait
 void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uint8_t *rng_dev_dst = nullptr, size_t rng_row_bytes = 0,
-                    size_t rng_dst_pitch = 0) {
-  const bool fetch_rng = rng_dev_dst == nullptr;
+                    size_t rng_dst_pitch = 0, bool dev_chain = false) {
+  const bool fetch_rng = rng_dev_dst == nullptr && !dev_chain;
+  b.dev_chain_pending = false;
   Params &P = *b.params;
   hipStream_t s = ctx->stream;
   if (!pass1_only) plan_lanes(ctx, b);  // (an option may have changed since the layout was built: k_scalars_shared writes what PASS 2 will read)
@@ -1633,8 +1690,28 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
                          P.d_hg32.p, P.n_bits, P.t, b.B, b.cs, b.chal.p, b.rng_out.p, b.status.p, rng_host);
   }
   tm.mark(M_TRANSCRIPTS);
-  if (fetch_rng) {
-    // (nothing to copy: PASS 1 wrote the bytes the weight chain reads into h_rng itself; the event below tells the host)
+  if (dev_chain) {
+    if (ctx->profile) {  // stage profiling keeps the serial order so that its intervals mean something
+      enqueue_device_chain(ctx, b, s);
+      tm.mark(M_CHAIN);
+    } else {
+      if (!ctx->chain_stream) {
+        int least = 0, greatest = 0;  // the chains are 64 lone wavefronts on the call's critical path: first in line for a slot
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&ctx->chain_stream, hipStreamNonBlocking, greatest));
+        HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_chain_fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_chain_done, hipEventDisableTiming));
+      }
+      HIP_CHECK(hipEventRecord(ctx->ev_chain_fork, s));
+      HIP_CHECK(hipStreamWaitEvent(ctx->chain_stream, ctx->ev_chain_fork, 0));
+      enqueue_device_chain(ctx, b, ctx->chain_stream);
+      HIP_CHECK(hipEventRecord(ctx->ev_chain_done, ctx->chain_stream));
+      b.dev_chain_pending = true;
+    }
+  }
+  if (fetch_rng || !rng_dev_dst) {
+    // (nothing to copy: PASS 1 wrote the bytes the weight chain reads into h_rng itself -- or the chain runs on the device; the
+    // event below tells the host)
   } else if (rng_dst_pitch && rng_dst_pitch != rng_row_bytes)  // rows of one group each, padded to the widest rank's shard
     HIP_CHECK(hipMemcpy2DAsync(rng_dev_dst, rng_dst_pitch, b.rng_out.p, rng_row_bytes, rng_row_bytes, ((size_t)b.B * 32) / rng_row_bytes,
                                hipMemcpyDeviceToDevice, s));
@@ -1755,7 +1832,11 @@ class HostPool {
     const char *e = getenv("BPP_HOST_THREADS");
     uint32_t want = e ? (uint32_t)atoi(e) : std::min(hw, 32u);
     want = std::max(1u, std::min(want, 256u));
-    for (uint32_t i = 1; i < want; i++) workers_.emplace_back([this] { loop(); });
+    for (uint32_t i = 1; i < want; i++)
+      workers_.emplace_back([this] {
+        pthread_setname_np(pthread_self(), "bpp-chain");  // (who is busy: bench.py's host_cores_busy_by_thread)
+        loop();
+      });
     for (auto &t : workers_) t.detach();
   }
  public:
@@ -2050,6 +2131,10 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool weights_residen
   // (weights_resident: the grouped sharded form has put them into b.weights device -> device already)
   // otherwise k_scalars_lanes reads them where the chains wrote them: h_weights is mapped, each weight is read once
   plan_lanes(ctx, b, true);
+  if (b.dev_chain_pending) {  // the device chain of this call (enqueue_phase1) has written b.weights
+    HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_chain_done, 0));
+    b.dev_chain_pending = false;
+  }
   b.weights_on_host = !weights_resident;
   const uint8_t *weights = weights_resident ? b.weights.p : b.h_weights.dev();
   tm.mark(M_WEIGHTS_IN);
@@ -2095,7 +2180,8 @@ void collect_profile(bpp_ctx *ctx, Batch &b, StageTimer &tm, float chain_ms, flo
   bpp_profile &pf = ctx->prof;
   memset(&pf, 0, sizeof(pf));
   pf.transcripts_ms = tm.between(M_START, M_TRANSCRIPTS);
-  pf.decompress_ms = tm.between(M_TRANSCRIPTS, M_DECOMPRESS);  // includes the 32 B/proof device-to-host copy
+  pf.chain_device_ms = tm.between(M_TRANSCRIPTS, M_CHAIN);  // k_weight_chain + k_chain_finish (0 with the chains on the host)
+  pf.decompress_ms = tm.between(tm.have[M_CHAIN] ? M_CHAIN : M_TRANSCRIPTS, M_DECOMPRESS);  // includes the 32 B/proof device-to-host copy
   pf.scalars_ms = tm.between(M_DECOMPRESS, M_SCALARS) + tm.between(M_WEIGHTS_IN, M_LANES);  // shared + lanes
   pf.chain_host_ms = chain_ms;
   pf.reduce_ms = tm.between(M_LANES, M_REDUCE);
@@ -2140,12 +2226,11 @@ static uint32_t batch_size_peek(bpp_ctx *ctx, uint64_t batch) {
   return it == ctx->batches.end() ? 0u : it->second->B;
 }
 
-int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, uint8_t *masks_out, uint8_t *mask_present,
-                        char *errbuf, size_t errbuf_len) {
-  if (!ctx) return BPP_ERR_BAD_HANDLE;
-  const uint32_t n_peek = batch_size_peek(ctx, batch);
-  GateHold gate(ctx->device, n_peek && n_peek <= BPP_GATE_SMALL_PROOFS);  // small calls queue for the device (DeviceState)
-  BPP_ENTRY(ctx);
+// (the context's lock is held.)  BPP_REDRAW_ON_HOST: the device chain drew a zero weight (probability 2^-252 per proof): the
+// caller runs the call again with the chains on the host, which redraw as the reference does (scalar_protocol.rs:23-30)
+#define BPP_REDRAW_ON_HOST (-0x7fff0001)
+static int verify_resident_locked(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, uint8_t *masks_out, uint8_t *mask_present,
+                                  char *errbuf, size_t errbuf_len, bool allow_dev_chain) {
   try {
     auto it = ctx->batches.find(batch);
     if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle", errbuf, errbuf_len);
@@ -2163,7 +2248,8 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
     // with several groups the earlier groups' MSM verdicts still matter (the kernels tolerate the odd shapes).
     const bool pass1_only = b.any_rounds_bad && b.G == 1;
     const bool want_msm = !pass1_only && action != BPP_RECOVER_ONLY;
-    enqueue_phase1(ctx, b, tm, pass1_only || action == BPP_RECOVER_ONLY);
+    const bool dev_chain = want_msm && allow_dev_chain && use_device_chain(ctx, b);
+    enqueue_phase1(ctx, b, tm, pass1_only || action == BPP_RECOVER_ONLY, nullptr, 0, 0, dev_chain);
 
     float chain_ms = 0;
     // recovered masks on their way to the caller (page-locked, written by k_results_out): wiped on every exit (src/extended_mask.rs:14)
@@ -2178,7 +2264,7 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
     if (!pass1_only) {
       // weight chains: one per chunk (src/range_proof.rs:811,849,853,894); the device keeps working meanwhile
       auto c0 = std::chrono::steady_clock::now();
-      if (want_msm) {
+      if (want_msm && !dev_chain) {
         run_weight_chains(b);
       }
       chain_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c0).count();
@@ -2191,12 +2277,16 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
         have_masks = true;
       }
       if (want_msm) {
-        enqueue_phase2(ctx, b, tm);
+        enqueue_phase2(ctx, b, tm, dev_chain);
         b.have_trace = true;
       }
     }
     fetch_results(ctx, b, want_msm, have_masks);
     HIP_CHECK(hipStreamSynchronize(s));
+    if (dev_chain && ctx->h_chain_zero[0]) {
+      ctx->device_chain_redraws++;
+      return BPP_REDRAW_ON_HOST;
+    }
     if (have_masks) h_masks = b.h_masks.data();
     auto t_end = std::chrono::steady_clock::now();
     collect_profile(ctx, b, tm, chain_ms, std::chrono::duration<float, std::milli>(t_end - t_begin).count());
@@ -2223,6 +2313,17 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
   BPP_CATCH(ctx, errbuf, errbuf_len)
 }
 
+int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, uint8_t *masks_out, uint8_t *mask_present,
+                        char *errbuf, size_t errbuf_len) {
+  if (!ctx) return BPP_ERR_BAD_HANDLE;
+  const uint32_t n_peek = batch_size_peek(ctx, batch);
+  GateHold gate(ctx->device, n_peek && n_peek <= BPP_GATE_SMALL_PROOFS);  // small calls queue for the device (DeviceState)
+  BPP_ENTRY(ctx);
+  int rc = verify_resident_locked(ctx, batch, action, chunk, masks_out, mask_present, errbuf, errbuf_len, true);
+  if (rc == BPP_REDRAW_ON_HOST) rc = verify_resident_locked(ctx, batch, action, chunk, masks_out, mask_present, errbuf, errbuf_len, false);
+  return rc;
+}
+
 // Reference batches of DIFFERENT sizes in one call: group g = proofs [group_first[g], group_first[g + 1]) of the resident
 // batch, every group verified as its own verify() call by the same kernel launches, with its own outcome and its own
 // VerifyAction (src/range_proof.rs:46-54) -- where bpp_verify_resident cuts equal chunks and stops at the first failing one.
@@ -2232,8 +2333,8 @@ int bpp_verify_resident(bpp_ctx *ctx, uint64_t batch, int action, size_t chunk, 
 // looks at the final check (:1040-1043); when EVERY group is RecoverOnly the weight chains and PASS 2 are not run at all.
 }  // extern "C"
 namespace {
-int verify_groups_core(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first, size_t n_groups, const int *actions,
-                       bpp_shard_result *results, uint8_t *masks_out, uint8_t *mask_present) {
+int verify_groups_core_once(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first, size_t n_groups, const int *actions,
+                            bpp_shard_result *results, uint8_t *masks_out, uint8_t *mask_present, bool allow_dev_chain) {
   try {
     auto it = ctx->batches.find(batch);
     if (it == ctx->batches.end()) return fail(ctx, BPP_ERR_BAD_HANDLE, "unknown batch handle");
@@ -2258,14 +2359,15 @@ int verify_groups_core(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first
     layout_groups(ctx, b, 0, &bounds);
     // the kernels tolerate odd shapes and run on every item (as bpp_verify_resident does with several chunks); findings are
     // raised per group afterwards, in the reference's order
-    enqueue_phase1(ctx, b, tm, !want_msm);
+    const bool dev_chain = want_msm && allow_dev_chain && use_device_chain(ctx, b);
+    enqueue_phase1(ctx, b, tm, !want_msm, nullptr, 0, 0, dev_chain);
     b.h_ident.resize(b.G);
     for (uint32_t g = 0; g < b.G; g++) b.h_ident[g] = 1;
     ScopeExit wipe_masks{[&] {
       if (want_masks) wipe(b.h_masks.data(), std::min(b.h_masks.n, (size_t)b.B * P.t * 32));
     }};
     float chain_ms = 0;
-    if (want_msm) {
+    if (want_msm && !dev_chain) {
       auto c0 = std::chrono::steady_clock::now();
       run_weight_chains(b);
       chain_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c0).count();
@@ -2276,11 +2378,15 @@ int verify_groups_core(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first
       b.masks_dirty = true;
     }
     if (want_msm) {
-      enqueue_phase2(ctx, b, tm);
+      enqueue_phase2(ctx, b, tm, dev_chain);
       b.have_trace = true;
     }
     fetch_results(ctx, b, want_msm, want_masks);
     HIP_CHECK(hipStreamSynchronize(s));
+    if (dev_chain && ctx->h_chain_zero[0]) {
+      ctx->device_chain_redraws++;
+      return BPP_REDRAW_ON_HOST;
+    }
     collect_profile(ctx, b, tm, chain_ms, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     for (uint32_t g = 0; g < b.G; g++) {
       bpp_shard_result &r = results[g];
@@ -2311,6 +2417,12 @@ int verify_groups_core(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first
     return BPP_OK;
   }
   BPP_CATCH(ctx, nullptr, 0)
+}
+int verify_groups_core(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_first, size_t n_groups, const int *actions,
+                       bpp_shard_result *results, uint8_t *masks_out, uint8_t *mask_present) {
+  int rc = verify_groups_core_once(ctx, batch, group_first, n_groups, actions, results, masks_out, mask_present, true);
+  if (rc == BPP_REDRAW_ON_HOST) rc = verify_groups_core_once(ctx, batch, group_first, n_groups, actions, results, masks_out, mask_present, false);
+  return rc;
 }
 }  // namespace
 extern "C" {

@@ -82,8 +82,16 @@ const char *bpp_ctx_last_error(bpp_ctx *ctx);
  * bpp_pedersen_commit and the prover's witness check (src/generators/pedersen_gens.rs:112-122, src/range_proof.rs:275-284);
  * 2: A1 and B of the final round as well (:572-584; a 256-doubling ladder on the call's last stretch, see DESIGN.md for its
  * measured cost); 0: everything through the fixed-base tables, addressed by the scalars' digits).  The environment variables BPP_<NAME> give
+ * "chain" (where the batch-weight chains of a verification run -- src/range_proof.rs:811,849,853,894, one strictly sequential
+ * sponge per reference batch: 0 = on host cores (csrc/chain_host.h: lowest latency, 0.04 host-core-ms per 1024 proofs), 1 = on
+ * the device, one wavefront per reference batch behind PASS 1 (csrc/chain_dev.h: the calling thread only enqueues and the
+ * rank needs no host cores in proportion to its throughput; a zero weight, probability 2^-252, sends the call through the host
+ * chains once more, which redraw as the reference does), -1 = the engine's rule: host).  The environment variables BPP_<NAME> give
  * the initial values and are read ONCE, when the context is created: no verification path calls getenv. */
 int bpp_ctx_set_option(bpp_ctx *ctx, const char *name, int value);
+/* verifications of this context whose weight chains ran on the device, and how many of those went back to the host chains
+ * because a weight came out zero */
+int bpp_device_chain_stats(bpp_ctx *ctx, uint64_t *calls, uint64_t *redraws);
 
 /* ---- runtime preconditions and the admission gate for small calls ("Runtime preconditions") ----
  * Separate callers of RangeProof::verify_batch hand over at most MAX_RANGE_PROOF_BATCH_SIZE = 256 proofs per call
@@ -447,6 +455,7 @@ typedef struct {
   float total_ms;
   uint32_t msm_terms, msm_window_bits, msm_windows, msm_groups;
   float masks_ms; /* k_masks (mask recovery, src/range_proof.rs:941-969); 0 for VerifyOnly */
+  float chain_device_ms; /* the weight chains as kernels (option "chain" = 1: k_weight_chain + k_chain_finish); 0 with the chains on the host */
 } bpp_profile;
 int bpp_profile_enable(bpp_ctx *ctx, int on);
 int bpp_profile_get(bpp_ctx *ctx, bpp_profile *out);

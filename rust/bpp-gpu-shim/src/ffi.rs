@@ -132,6 +132,7 @@ pub struct bpp_profile {
     pub msm_windows: u32,
     pub msm_groups: u32,
     pub masks_ms: f32,
+    pub chain_device_ms: f32,
 }
 
 /// bpp_runtime_info: what the library sees of its runtime preconditions ("Runtime preconditions")
@@ -270,6 +271,7 @@ extern "C" {
     pub fn bpp_prove_profile_get(ctx: *mut bpp_ctx, out: *mut bpp_prove_profile) -> c_int;
     pub fn bpp_host_threads() -> c_int;
     pub fn bpp_host_pool_cpu_ns() -> u64;
+    pub fn bpp_device_chain_stats(ctx: *mut bpp_ctx, calls: *mut u64, redraws: *mut u64) -> c_int;
     pub fn bpp_transcript_new(label: *const u8, label_len: usize, state203: *mut u8) -> c_int;
     pub fn bpp_batch_secret_bytes(ctx: *mut bpp_ctx, batch: u64, nonzero: *mut u64) -> c_int;
     pub fn bpp_prove_secret_bytes(ctx: *mut bpp_ctx, examined: *mut u64, nonzero: *mut u64) -> c_int;

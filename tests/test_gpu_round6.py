@@ -1,0 +1,165 @@
+"""GPU tests of round 6: the batch-weight chains as a device kernel (option "chain" = 1, csrc/chain_dev.h + csrc/wkeccak.h).
+
+Reference: the weight transcript of RangeProof::verify (src/range_proof.rs:811 Transcript::new, :849 append_message per proof, :853
+build_rng().finalize(NullRng), :894 one Scalar::random_not_zero per proof; src/protocols/scalar_protocol.rs:23-30 redraws a zero,
+src/utils/nullrng.rs:16-40).  The device form must leave byte for byte the weights of the CPU oracle (oracle/c through
+oracle.cport) and of the host form (csrc/chain_host.h), for whole reference batches of any size and for ragged groups."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import cport
+from tests.helpers import LABEL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def packed():
+    return importlib.import_module("bulletproofs-plus_amd.packed")
+
+
+@pytest.fixture(scope="module")
+def cfg2(bpp, packed, engine):
+    """4096 + 452 non-aggregated 64-bit proofs with bench.py's recipe (benches/range_proof.rs:206-262)"""
+    import bench
+    params = bpp.RangeParameters.init(64, 1, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    d = bench.make_inputs(np, packed, params, 4096 + 452, seed=20261005)
+    yield params, d
+    params.close()
+
+
+def _resident(packed, params, d, lo, hi):
+    return packed.ResidentBatch(params, d["proofs"][lo:hi], d["commitments"][lo:hi], d["min_values"][lo:hi], d["min_present"][lo:hi],
+                                None, LABEL)
+
+
+def _oracle_weights(d, lo, hi):
+    cp = cport.Params(64, 1, 1)
+    items = [{"proof": bytes(d["proofs"][i]), "commitments": [bytes(d["commitments"][i, 0])], "min_values": [int(d["min_values"][i, 0])],
+              "seed_nonce": None, "label": LABEL} for i in range(lo, hi)]
+    rc, _, tr = cp.verify(items, action=0, want_trace=True)
+    cp.close()
+    assert rc == 0
+    return tr["weights"]
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 64, 1024, 4096])
+def test_device_chain_weights_equal_the_oracle(bpp, packed, engine, opt, cfg2, n):
+    """one reference batch of n proofs, chains on the device: accepted, MSM result the identity, and the n weights are the CPU
+    oracle's and the host chain's, byte for byte (n = 3, 4, 5: a record of 45 bytes crosses the sponge's 166-byte block at the
+    fourth proof; 1024 and 4096: the sizes BASELINE's configs quote)"""
+    params, d = cfg2
+    rb = _resident(packed, params, d, 0, n)
+    opt("chain", 1)
+    before = engine.device_chain_stats()
+    rb.verify_only(chunk=0)
+    after = engine.device_chain_stats()
+    assert after[0] == before[0] + 1 and after[1] == before[1]  # the chain kernel ran, nothing was redrawn
+    w_dev = rb.trace(3)
+    assert rb.trace(6) == bytes(32)
+    opt("chain", 0)
+    rb.verify_only(chunk=0)
+    assert engine.device_chain_stats() == after
+    w_host = rb.trace(3)
+    rb.close()
+    assert len(w_dev) == 32 * n and w_dev == w_host
+    assert w_dev == _oracle_weights(d, 0, n)
+
+
+def test_device_chain_per_group_and_ragged(bpp, packed, engine, opt, cfg2):
+    """several reference batches in one call (chunk = 1024 over 4548 proofs: four full groups and one of 452): every group's
+    chain is its own wavefront; the weights are those of the host chains, and a group's weights are those of the same proofs
+    verified alone.  Then ragged groups through bpp_verify_resident_groups (the batcher's form)."""
+    params, d = cfg2
+    n = 4096 + 452
+    rb = _resident(packed, params, d, 0, n)
+    opt("chain", 1)
+    rb.verify_only(chunk=1024)
+    assert rb.shape()["groups"] == 5
+    w_dev = rb.trace(3)
+    assert rb.trace(6) == bytes(32) * 5
+    opt("chain", 0)
+    rb.verify_only(chunk=1024)
+    assert rb.trace(3) == w_dev
+    # ragged groups: 1, 700, 1024, 2823 proofs
+    bounds = [0, 1, 701, 1725, n]
+    opt("chain", 1)
+    res = packed.verify_groups(rb, bounds)
+    assert all(r["code"] == 0 for r in res)
+    w_rag = rb.trace(3)
+    opt("chain", 0)
+    res = packed.verify_groups(rb, bounds)
+    assert all(r["code"] == 0 for r in res)
+    assert rb.trace(3) == w_rag
+    rb.close()
+    assert w_rag[32 * 1:32 * 701] == _oracle_weights(d, 1, 701)
+    one = _resident(packed, params, d, 4096, n)
+    opt("chain", 1)
+    one.verify_only(chunk=0)
+    assert one.trace(3) == w_dev[32 * 4096:]
+    one.close()
+
+
+def test_device_chain_rejects_what_the_host_chain_rejects(bpp, packed, engine, opt, cfg2):
+    """a tampered proof in the third of four 1024-proof batches: the same error kind, the same non-identity point for that batch and
+    the identity for the others, whichever side ran the chains"""
+    params, d = cfg2
+    bad = d["proofs"][:4096].copy()
+    bad[2 * 1024 + 77, 1 + 32 + 96 + 5] ^= 2  # r1
+    out = {}
+    for chain in (1, 0):
+        opt("chain", chain)
+        rb = packed.ResidentBatch(params, bad, d["commitments"][:4096], d["min_values"][:4096], d["min_present"][:4096], None, LABEL)
+        with pytest.raises(bpp.ProofError) as e:
+            rb.verify_only(chunk=1024)
+        out[chain] = (e.value.kind, rb.trace(6), rb.trace(3))
+        rb.close()
+    assert out[0] == out[1]
+    assert out[1][0] == bpp.ProofErrorKind.VerificationFailed
+    pts = out[1][1]
+    assert [pts[32 * g:32 * g + 32] == bytes(32) for g in range(4)] == [True, True, False, True]
+
+
+def test_device_chain_zero_weight_goes_back_to_the_host_chain(bpp, packed, engine, opt, cfg2):
+    """Scalar::random_not_zero redraws a zero weight (src/protocols/scalar_protocol.rs:23-30).  The device chain cannot (the next
+    draw would shift every later weight): it reports the zero and the call runs once more with the chains on the host.  The
+    test hook makes k_chain_finish report proof 700's weight as zero."""
+    params, d = cfg2
+    rb = _resident(packed, params, d, 0, 2048)
+    opt("chain", 1)
+    opt("chain_test_zero", 701)
+    before = engine.device_chain_stats()
+    rb.verify_only(chunk=1024)
+    after = engine.device_chain_stats()
+    assert after == (before[0] + 1, before[1] + 1)
+    w = rb.trace(3)
+    res = packed.verify_groups(rb, [0, 1024, 2048])
+    assert all(r["code"] == 0 for r in res) and engine.device_chain_stats() == (before[0] + 2, before[1] + 2)
+    opt("chain_test_zero", 0)
+    opt("chain", 0)
+    rb.verify_only(chunk=1024)
+    assert rb.trace(3) == w
+    rb.close()
+    engine.set_option("chain_test_zero", 0)  # (the fixture restores options to -1: this one's neutral value is 0)
+
+
+def test_device_chain_stage_profile(bpp, packed, engine, opt, cfg2):
+    """with stage profiling on the chain runs in line on the call's stream and its interval is reported as chain_device_ms; the
+    host chain's wall time stays zero"""
+    params, d = cfg2
+    rb = _resident(packed, params, d, 0, 4096)
+    engine.profile(True)
+    try:
+        opt("chain", 1)
+        rb.verify_only(chunk=1024)
+        pf = engine.last_profile()
+        assert pf["chain_device_ms"] > 0.1 and pf["msm_final_ms"] > 0
+        opt("chain", 0)
+        rb.verify_only(chunk=1024)
+        pf = engine.last_profile()
+        assert pf["chain_device_ms"] == 0 and pf["chain_host_ms"] > 0
+    finally:
+        engine.profile(False)
+        rb.close()
