@@ -84,9 +84,10 @@ def parse_args():
     ap.add_argument("--transport", choices=("rccl", "gloo"), default=os.environ.get("BPP_BENCH_TRANSPORT", "rccl"),
                     help="N > 1, the sharded leg's all_gathers: RCCL on device buffers, or the caller-supplied transport of the C ABI "
                          "(bpp_comm_create_callbacks) over torch.distributed's gloo")
-    ap.add_argument("--chain", choices=("host", "device", "auto"), default=os.environ.get("BPP_BENCH_CHAIN", "auto"),
-                    help="where the batch-weight chains run (engine option \"chain\"): host cores (csrc/chain_host.h), one wavefront per "
-                         "reference batch on the device (csrc/chain_dev.h), or the harness' rule")
+    ap.add_argument("--chain", choices=("host", "host-wide", "device", "auto"), default=os.environ.get("BPP_BENCH_CHAIN", "auto"),
+                    help="where the batch-weight chains run (engine option \"chain\"): host cores, sponge and reduction mod l "
+                         "(csrc/chain_host.h); host-wide: the sponges on host cores, the reduction on the device (the engine's own rule for "
+                         "calls of 4096 proofs and more); device: one wavefront per reference batch (csrc/chain_dev.h); auto: the harness' rule")
     ap.add_argument("--one-device", action="store_true", default=os.environ.get("BPP_BENCH_ONE_DEVICE", "0") == "1",
                     help="every local rank on device 0 (a rehearsal of the multi-rank code as PROCESSES on a one-GPU box; RCCL refuses "
                          "two ranks on one device, so this implies --transport gloo); the line says so")
@@ -149,7 +150,7 @@ def resolve_chain_mode(args, world):
     than HOST_CORES_PER_RANK schedulable cores each -- then the device chains, which leave the host alone"""
     if args.chain != "auto":
         return args.chain
-    return "device" if usable_cpus() / max(1, world) < HOST_CORES_PER_RANK else "host"
+    return "device" if usable_cpus() / max(1, world) < HOST_CORES_PER_RANK else "host-wide"
 
 
 def self_launch(args):
@@ -765,7 +766,7 @@ def main():
         os.environ["BPP_HOST_THREADS"] = str(max(4, min(32, usable_cpus() // world_env)))
     # where the weight chains run: read by the library once per context, when it is created (BPP_CHAIN)
     chain_mode = resolve_chain_mode(args, world_env)
-    os.environ["BPP_CHAIN"] = "1" if chain_mode == "device" else "0"
+    os.environ["BPP_CHAIN"] = {"host": "0", "device": "1", "host-wide": "2"}[chain_mode]
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -190,4 +190,29 @@ __global__ void __launch_bounds__(64) k_chain_finish(const uint32_t *__restrict_
   dst[1] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
 }
 
+// The same for draws that come as plain bytes (the host's sponge with the reduction left to the device: chain_host.h, WIDE):
+// wide64[p] = the 64 PRF bytes of proof p, in mapped host memory
+__global__ void __launch_bounds__(64) k_chain_finish_bytes(const uint8_t *__restrict__ wide64, uint32_t B, uint8_t *__restrict__ weights,
+                                                           uint32_t *__restrict__ zero_flag, uint32_t test_zero) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  uint32_t w[16];
+  const uint4 *src = reinterpret_cast<const uint4 *>(wide64 + (size_t)p * 64);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint4 v = src[q];
+    w[4 * q] = v.x;
+    w[4 * q + 1] = v.y;
+    w[4 * q + 2] = v.z;
+    w[4 * q + 3] = v.w;
+  }
+  sc m, c;
+  sc_mont_from_wide_words(m, w);
+  sc_from_mont(c, m);
+  if (sc_iszero(c) || p + 1 == test_zero) *zero_flag = 1u;
+  uint4 *dst = reinterpret_cast<uint4 *>(weights + (size_t)p * 32);
+  dst[0] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
+  dst[1] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
+}
+
 }  // namespace bpp

@@ -248,8 +248,10 @@ static inline __attribute__((always_inline)) void ms_squeeze(MultiStrobe<W> &s, 
   }
 }
 
-// W chains: rng[w] -> n x 32 transcript-RNG bytes, out[w] -> n x 32 canonical weights
-template <int W>
+// W chains: rng[w] -> n x 32 transcript-RNG bytes, out[w] -> n x 32 canonical weights.
+// WIDE: out[w] -> n x 64 bytes as the sponge leaves them; Scalar::from_bytes_mod_order_wide -- half of a bundle's CPU time, and
+// perfectly parallel -- is then the device's (chain_dev.h: k_chain_finish_bytes), and so is the look for a zero weight.
+template <int W, bool WIDE = false>
 static inline __attribute__((always_inline)) void weights_chain_multi_impl(const uint8_t *const rng[W], size_t n, uint8_t *const out[W]) {
   // Transcript::new(b"Bulletproofs+ verifier weights") is the same for every chain
   Strobe t0;
@@ -288,6 +290,12 @@ static inline __attribute__((always_inline)) void weights_chain_multi_impl(const
     u32le(len4, 64);
     ms_absorb_same<W>(s, len4, 4);
     ms_begin_op<W>(s, BPP_FLAG_I | BPP_FLAG_A | BPP_FLAG_C, false);
+    if (WIDE) {
+      uint8_t *dst[W];
+      for (int w = 0; w < W; w++) dst[w] = out[w] + 64 * i;
+      ms_squeeze<W>(s, dst, 64);
+      continue;
+    }
     ms_squeeze<W>(s, wp, 64);
     // random_not_zero: a zero draw (probability 2^-252) would desynchronise the lockstep; flagged to the caller
     for (int w = 0; w < W; w++) host_wide_reduce(out[w] + 32 * i, wide[w]);
@@ -300,6 +308,13 @@ __attribute__((target("avx512f,avx512vl,avx512bw,avx512dq"))) static void weight
 }
 __attribute__((target("avx2"))) static void weights_chain_x4(const uint8_t *const rng[4], size_t n, uint8_t *const out[4]) {
   weights_chain_multi_impl<4>(rng, n, out);
+}
+__attribute__((target("avx512f,avx512vl,avx512bw,avx512dq"))) static void wide_chain_x8(const uint8_t *const rng[8], size_t n,
+                                                                                       uint8_t *const out[8]) {
+  weights_chain_multi_impl<8, true>(rng, n, out);
+}
+__attribute__((target("avx2"))) static void wide_chain_x4(const uint8_t *const rng[4], size_t n, uint8_t *const out[4]) {
+  weights_chain_multi_impl<4, true>(rng, n, out);
 }
 
 static inline bool weight_is_zero(const uint8_t *w32) {
@@ -431,7 +446,7 @@ static inline __attribute__((always_inline)) void fs_begin_op(FastStrobe &s, uin
   if ((flags & (BPP_FLAG_C | BPP_FLAG_K)) != 0 && s.pos != 0) fs_run_f<PERM>(s);
 }
 // rng: n x 32 transcript-RNG bytes -> out: n x 32 canonical non-zero weights (src/range_proof.rs:811,849,853,894)
-template <void (*PERM)(uint64_t *)>
+template <void (*PERM)(uint64_t *), bool WIDE = false>
 static inline __attribute__((always_inline)) void weights_chain_single_impl(const uint8_t *rng, size_t n, uint8_t *out) {
   Strobe t0;
   const char *lbl = "Bulletproofs+ verifier weights";
@@ -455,6 +470,15 @@ static inline __attribute__((always_inline)) void weights_chain_single_impl(cons
   s.pos = 32;
   static const uint8_t len64[4] = {64, 0, 0, 0};
   for (size_t i = 0; i < n; i++) {
+    if (WIDE) {  // one draw per proof, 64 bytes out as they are (the device reduces them and looks for a zero)
+      fs_begin_op<PERM>(s, BPP_FLAG_M | BPP_FLAG_A);
+      fs_absorb_fixed<PERM, 4>(s, len64);
+      fs_begin_op<PERM>(s, BPP_FLAG_I | BPP_FLAG_A | BPP_FLAG_C);
+      memcpy(out + 64 * i, s.st, 64);
+      for (int j = 0; j < 8; j++) s.st[j] = 0;
+      s.pos = 64;
+      continue;
+    }
     uint8_t *w = out + 32 * i;
     do {  // Scalar::random_not_zero (src/protocols/scalar_protocol.rs:23-30): fill_bytes(64) = meta_ad(u32le(64)) + prf(64)
       fs_begin_op<PERM>(s, BPP_FLAG_M | BPP_FLAG_A);
@@ -478,6 +502,18 @@ static inline void weights_chain_single(const uint8_t *rng, size_t n, uint8_t *o
   static const bool bmi = __builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2");
   if (bmi) weights_chain_single_bmi(rng, n, out);
   else weights_chain_single_plain(rng, n, out);
+}
+static void wide_chain_single_plain(const uint8_t *rng, size_t n, uint8_t *out) {
+  weights_chain_single_impl<keccak_f1600_host_plain, true>(rng, n, out);
+}
+__attribute__((target("bmi,bmi2"))) static void wide_chain_single_bmi(const uint8_t *rng, size_t n, uint8_t *out) {
+  weights_chain_single_impl<keccak_f1600_host_bmi, true>(rng, n, out);
+}
+// rng: n x 32 bytes -> out: n x 64 PRF bytes (one draw per proof, not reduced)
+static inline void wide_chain_single(const uint8_t *rng, size_t n, uint8_t *out) {
+  static const bool bmi = __builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2");
+  if (bmi) wide_chain_single_bmi(rng, n, out);
+  else wide_chain_single_plain(rng, n, out);
 }
 // the same chain on merlin.h's generic byte-wise sponge (the form the device kernels and the oracle tests are written
 // against): kept as the cross-check of the fast form (hosttest.cpp)

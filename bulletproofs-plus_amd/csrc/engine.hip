@@ -12,6 +12,7 @@
 #include <sched.h>
 #include <stdio.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -178,7 +179,7 @@ void keccak_sponge(const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen,
 void shake256(const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen) { keccak_sponge(in, inlen, out, outlen, 136, 0x1f); }
 void sha3_512(const uint8_t *in, size_t inlen, uint8_t out[64]) { keccak_sponge(in, inlen, out, 64, 72, 0x06); }
 
-void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G);
+void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G, bool wide = false);
 void host_parallel_for(uint32_t n, const std::function<void(uint32_t)> &fn);  // on the persistent host pool
 uint32_t host_pool_size();
 uint64_t host_pool_cpu_ns();
@@ -429,6 +430,7 @@ struct Batch {
   uint32_t G = 0;
   std::vector<uint32_t> h_group_first;
   PinnedBuf<uint8_t> h_rng, h_weights, h_masks;  // mapped: written / read by the kernels directly (PinnedBuf)
+  PinnedBuf<uint8_t> h_wide;  // chain mode 2: the host sponges' 64 bytes per proof, reduced on the device
   PinnedBuf<uint32_t> h_status, h_ident;
   // k_results_out writes one summary word per BPP_STATUS_BLOCK proofs and a block's words only when there is something in them;
   // settle_status() makes h_status whole again on the host (a block the kernel skipped is all zero: cleared here if it was not)
@@ -455,7 +457,7 @@ void adopt_buffers(Batch &dst, Batch &src) {
   BPP_ADOPT(msm.cls_hist);
   BPP_ADOPT(msm.buckets); BPP_ADOPT(msm.Q); BPP_ADOPT(msm.W); BPP_ADOPT(msm.R); BPP_ADOPT(msm.comp32);
   BPP_ADOPT(msm.is_identity); BPP_ADOPT(msm.term_sidx); BPP_ADOPT(msm.term_pidx); BPP_ADOPT(msm.group_off);
-  BPP_ADOPT(h_rng); BPP_ADOPT(h_weights); BPP_ADOPT(h_status); BPP_ADOPT(h_status_any); BPP_ADOPT(h_ident); BPP_ADOPT(h_masks);
+  BPP_ADOPT(h_rng); BPP_ADOPT(h_weights); BPP_ADOPT(h_wide); BPP_ADOPT(h_status); BPP_ADOPT(h_status_any); BPP_ADOPT(h_ident); BPP_ADOPT(h_masks);
 #undef BPP_ADOPT
   // what is known about the adopted status words travels with them (settle_status clears only the blocks that may hold something);
   // a verification whose results were never looked at leaves them unknown
@@ -523,6 +525,8 @@ struct bpp_ctx {
   bool ev_ready = false;
   hipEvent_t ev_rng;
   bool ev_rng_ready = false;
+  hipEvent_t ev_wait;  // gpu_wait_stream's marker
+  bool ev_wait_ready = false;
   // small inputs: decompression runs beside PASS 1 on a second stream (enqueue_phase1)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork, ev_join;
@@ -533,7 +537,7 @@ struct bpp_ctx {
   hipEvent_t ev_chain_fork, ev_chain_done;
   DevBuf<Strobe> d_chain_t0;
   PinnedBuf<uint32_t> h_chain_zero;
-  uint64_t device_chain_calls = 0, device_chain_redraws = 0;
+  uint64_t device_chain_calls = 0, device_chain_redraws = 0, wide_chain_calls = 0;
   DevBuf<uint8_t> scratch128;
   // batch prover: one device arena, page-locked staging and the sub-batch streams, all reused across calls
   DevBuf<uint8_t> prove_arena;
@@ -555,7 +559,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1, prove_parts = -1, prove_waves = -1, prove_fifo = -1, chain = -1, chain_test_zero = 0;
+        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1, prove_parts = -1, prove_waves = -1, prove_fifo = -1, chain = -1, chain_test_zero = 0, wait = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -600,10 +604,14 @@ const OptionName kOptions[] = {
     {"prove_fifo", "BPP_PROVE_FIFO", &bpp_ctx::Options::prove_fifo},
     {"static_gemm", "BPP_STATIC_GEMM", &bpp_ctx::Options::static_gemm},
     {"lazy_columns", "BPP_LAZY_COLUMNS", &bpp_ctx::Options::lazy_columns},
-    // where the batch-weight chains run: 0 host cores (chain_host.h), 1 the device (chain_dev.h), -1 the engine's rule (use_device_chain)
+    // where the batch-weight chains run: 0 host cores (chain_host.h), 1 the device (chain_dev.h), 2 the sponges on host cores and the
+    // reduction mod l on the device, -1 the engine's rule (chain_mode)
     {"chain", "BPP_CHAIN", &bpp_ctx::Options::chain},
     // tests: the device chain reports the weight of proof (value - 1) as zero, so that the redraw fall-back runs
     {"chain_test_zero", "BPP_CHAIN_TEST_ZERO", &bpp_ctx::Options::chain_test_zero},
+    // how a calling thread waits for the device: 0 the runtime's wait (spins on a core until the stream is done), 1 naps between
+    // looks at an event (gpu_wait), -1 the engine's rule: naps for calls of BPP_WAIT_NAP_MIN_PROOFS proofs and more
+    {"wait", "BPP_WAIT", &bpp_ctx::Options::wait},
 };
 void options_from_env(bpp_ctx *c) {
   for (const OptionName &o : kOptions)
@@ -642,6 +650,43 @@ struct StageTimer {
 };
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---- how a calling thread waits for the device.  hipStreamSynchronize / hipEventSynchronize spin: measured on the GPU boxes
+// (tools/microbench/wait_modes.hip) a waiting thread burns 100 % of a core with either, whatever flags the event was created
+// with, unless the PROCESS-WIDE device flag hipDeviceScheduleBlockingSync is set (then 25 % / 6 %) -- which is the host
+// application's to set, not a library's.  A verification of tens of thousands of proofs takes milliseconds and several are in
+// flight, so its caller naps instead: hipEventQuery every 50 us costs 1-2 % of a core and wakes up ~70 us late, which such a
+// call does not notice (bench.py: 3.7 -> 0.2 host cores per rank for the three callers of the headline).  Calls of a few
+// hundred proofs (0.5-0.7 ms, one at a time) keep the runtime's spinning wait: there 70 us are 10 %.
+#define BPP_WAIT_NAP_MIN_PROOFS 4096u
+inline bool wait_naps(const bpp_ctx *ctx, size_t proofs) {
+  return ctx->opt.wait >= 0 ? ctx->opt.wait != 0 : proofs >= BPP_WAIT_NAP_MIN_PROOFS;
+}
+inline void gpu_wait_event(hipEvent_t ev, bool nap) {
+  if (!nap) {
+    HIP_CHECK(hipEventSynchronize(ev));
+    return;
+  }
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) HIP_CHECK(e);
+    struct timespec ts = {0, 50000};
+    nanosleep(&ts, nullptr);
+  }
+}
+inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap) {
+  if (!nap) {
+    HIP_CHECK(hipStreamSynchronize(s));
+    return;
+  }
+  if (!ctx->ev_wait_ready) {
+    HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_wait, hipEventDisableTiming));
+    ctx->ev_wait_ready = true;
+  }
+  HIP_CHECK(hipEventRecord(ctx->ev_wait, s));
+  gpu_wait_event(ctx->ev_wait, true);
+}
 
 static bool decompress_spill_enabled() {
   static const bool on = [] {
@@ -903,6 +948,7 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
   if (ctx->ev_ready)
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->ev_rng_ready) (void)hipEventDestroy(ctx->ev_rng);
+  if (ctx->ev_wait_ready) (void)hipEventDestroy(ctx->ev_wait);
   if (ctx->side_stream) {
     (void)hipStreamSynchronize(ctx->side_stream);
     (void)hipStreamDestroy(ctx->side_stream);
@@ -966,7 +1012,7 @@ int bpp_runtime_info_get(bpp_ctx *ctx, bpp_runtime_info *out) {
 int bpp_device_chain_stats(bpp_ctx *ctx, uint64_t *calls, uint64_t *redraws) {
   if (!ctx) return BPP_ERR_BAD_HANDLE;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  if (calls) *calls = ctx->device_chain_calls;
+  if (calls) *calls = ctx->device_chain_calls + ctx->wide_chain_calls;
   if (redraws) *redraws = ctx->device_chain_redraws;
   return BPP_OK;
 }
@@ -1610,7 +1656,23 @@ void plan_lanes(bpp_ctx *ctx, Batch &b, bool for_phase2 = false);
 // to eight times faster than a wavefront does (chain_host.h: 0.27 us per proof, chain_dev.h: ~2), so a call that WAITS for its
 // chains -- one call at a time, few groups -- keeps them on the host.  The device form is for callers that keep several
 // calls in flight and want the host left alone (a rank of an 8-GPU node: bench.py): it is chosen explicitly.
-bool use_device_chain(const bpp_ctx *ctx, const Batch &) { return ctx->opt.chain > 0; }
+enum ChainMode { CHAIN_HOST = 0, CHAIN_DEVICE = 1, CHAIN_HOST_WIDE = 2 };
+// CHAIN_HOST_WIDE: the sponges on host cores, Scalar::from_bytes_mod_order_wide (half of a lock-step bundle's CPU time, and
+// perfectly parallel) on the device: the default for calls of BPP_WAIT_NAP_MIN_PROOFS proofs and more -- their callers keep
+// several calls in flight, and there a host core counts for more than the extra launch.
+ChainMode chain_mode(const bpp_ctx *ctx, const Batch &b, bool allow_device_work) {
+  if (!allow_device_work) return CHAIN_HOST;  // the second run after a zero weight: everything as the reference does it
+  if (ctx->opt.chain >= 0 && ctx->opt.chain <= 2) return (ChainMode)ctx->opt.chain;
+  return b.B >= BPP_WAIT_NAP_MIN_PROOFS ? CHAIN_HOST_WIDE : CHAIN_HOST;
+}
+// the wide bytes of the host sponges (b.h_wide, mapped) -> b.weights
+void enqueue_finish_wide(bpp_ctx *ctx, Batch &b, hipStream_t st) {
+  if (!ctx->h_chain_zero.p) ctx->h_chain_zero.resize(1);
+  ctx->h_chain_zero[0] = 0;
+  const uint32_t test_zero = ctx->opt.chain_test_zero > 0 ? (uint32_t)ctx->opt.chain_test_zero : 0u;
+  hipLaunchKernelGGL(k_chain_finish_bytes, dim3(cdiv(b.B, 64)), dim3(64), 0, st, b.h_wide.dev(), b.B, b.weights.p, ctx->h_chain_zero.dev(), test_zero);
+  ctx->wide_chain_calls++;
+}
 
 // k_weight_chain + k_chain_finish on `st`: b.rng_out -> b.weights (canonical bytes), one wavefront per group
 void enqueue_device_chain(bpp_ctx *ctx, Batch &b, hipStream_t st) {
@@ -1736,13 +1798,17 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
   }
   if (side) HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_join, 0));
   HIP_CHECK(hipGetLastError());
-  if (fetch_rng) HIP_CHECK(hipEventSynchronize(ctx->ev_rng));
+  if (fetch_rng) gpu_wait_event(ctx->ev_rng, wait_naps(ctx, b.B));
 }
 
 // Weight chains of all groups (src/range_proof.rs:811,849,853,894).  Chunks are independent reference batches: groups of
 // equal size run W at a time in lockstep on vector Keccak (chain_host.h), bundles are spread over host threads.
-void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G);
 void run_weight_chains(Batch &b) { run_weight_chains_generic(b.h_rng.data(), b.h_weights.data(), b.h_group_first.data(), b.G); }
+// the sponges alone: 64 PRF bytes per proof into b.h_wide, reduced (and looked at for zeros) by k_chain_finish_bytes
+void run_weight_chains_wide(Batch &b) {
+  b.h_wide.resize((size_t)b.B * 64);
+  run_weight_chains_generic(b.h_rng.data(), b.h_wide.data(), b.h_group_first.data(), b.G, true);
+}
 // Persistent host workers for the weight chains (spawning threads per call costs more than a 1024-proof chain).
 class HostPool {
  public:
@@ -1900,7 +1966,8 @@ void host_parallel_for(uint32_t n, const std::function<void(uint32_t)> &fn) { Ho
 uint32_t host_pool_size() { return HostPool::get().size(); }
 uint64_t host_pool_cpu_ns() { return HostPool::cpu_ns().load(std::memory_order_relaxed); }
 
-void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G) {
+void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const uint32_t *group_first, uint32_t G, bool wide) {
+  const size_t stride = wide ? 64 : 32;  // output bytes per proof
   static const int simd = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") ? 8
                           : (__builtin_cpu_supports("avx2") ? 4 : 1);
   HostPool &pool = HostPool::get();
@@ -1928,7 +1995,8 @@ void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const u
   }
   auto scalar_chain = [&](uint32_t g) {
     const uint32_t p0 = group_first[g], p1 = group_first[g + 1];
-    weights_from_chain_host(h_rng + (size_t)p0 * 32, p1 - p0, h_weights + (size_t)p0 * 32);
+    if (wide) wide_chain_single(h_rng + (size_t)p0 * 32, p1 - p0, h_weights + (size_t)p0 * 64);
+    else weights_from_chain_host(h_rng + (size_t)p0 * 32, p1 - p0, h_weights + (size_t)p0 * 32);
   };
   std::function<void(uint32_t)> run_unit = [&](uint32_t ui) {
     const Unit &u = units[ui];
@@ -1943,7 +2011,14 @@ void run_weight_chains_generic(const uint8_t *h_rng, uint8_t *h_weights, const u
         uint8_t *out[8];
         for (uint32_t k = 0; k < w; k++) {
           in[k] = h_rng + (size_t)group_first[g + k] * 32;
-          out[k] = h_weights + (size_t)group_first[g + k] * 32;
+          out[k] = h_weights + (size_t)group_first[g + k] * stride;
+        }
+        if (wide) {  // (zeros are the device's to find: k_chain_finish_bytes)
+          if (w == 8) wide_chain_x8(in, n, out);
+          else wide_chain_x4(in, n, out);
+          g += w;
+          left -= w;
+          continue;
         }
         if (w == 8) weights_chain_x8(in, n, out);
         else weights_chain_x4(in, n, out);
@@ -2248,7 +2323,8 @@ static int verify_resident_locked(bpp_ctx *ctx, uint64_t batch, int action, size
     // with several groups the earlier groups' MSM verdicts still matter (the kernels tolerate the odd shapes).
     const bool pass1_only = b.any_rounds_bad && b.G == 1;
     const bool want_msm = !pass1_only && action != BPP_RECOVER_ONLY;
-    const bool dev_chain = want_msm && allow_dev_chain && use_device_chain(ctx, b);
+    const ChainMode cmode = want_msm ? chain_mode(ctx, b, allow_dev_chain) : CHAIN_HOST;
+    const bool dev_chain = cmode == CHAIN_DEVICE;
     enqueue_phase1(ctx, b, tm, pass1_only || action == BPP_RECOVER_ONLY, nullptr, 0, 0, dev_chain);
 
     float chain_ms = 0;
@@ -2264,9 +2340,8 @@ static int verify_resident_locked(bpp_ctx *ctx, uint64_t batch, int action, size
     if (!pass1_only) {
       // weight chains: one per chunk (src/range_proof.rs:811,849,853,894); the device keeps working meanwhile
       auto c0 = std::chrono::steady_clock::now();
-      if (want_msm && !dev_chain) {
-        run_weight_chains(b);
-      }
+      if (want_msm && cmode == CHAIN_HOST) run_weight_chains(b);
+      if (want_msm && cmode == CHAIN_HOST_WIDE) run_weight_chains_wide(b);
       chain_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c0).count();
       if (action != BPP_VERIFY_ONLY && b.any_seed) {  // masks (:941-969)
         tm.mark(M_MASKS0);
@@ -2277,13 +2352,14 @@ static int verify_resident_locked(bpp_ctx *ctx, uint64_t batch, int action, size
         have_masks = true;
       }
       if (want_msm) {
-        enqueue_phase2(ctx, b, tm, dev_chain);
+        if (cmode == CHAIN_HOST_WIDE) enqueue_finish_wide(ctx, b, s);
+        enqueue_phase2(ctx, b, tm, cmode != CHAIN_HOST);
         b.have_trace = true;
       }
     }
     fetch_results(ctx, b, want_msm, have_masks);
-    HIP_CHECK(hipStreamSynchronize(s));
-    if (dev_chain && ctx->h_chain_zero[0]) {
+    gpu_wait_stream(ctx, s, wait_naps(ctx, b.B));
+    if (want_msm && cmode != CHAIN_HOST && ctx->h_chain_zero[0]) {
       ctx->device_chain_redraws++;
       return BPP_REDRAW_ON_HOST;
     }
@@ -2359,7 +2435,8 @@ int verify_groups_core_once(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_
     layout_groups(ctx, b, 0, &bounds);
     // the kernels tolerate odd shapes and run on every item (as bpp_verify_resident does with several chunks); findings are
     // raised per group afterwards, in the reference's order
-    const bool dev_chain = want_msm && allow_dev_chain && use_device_chain(ctx, b);
+    const ChainMode cmode = want_msm ? chain_mode(ctx, b, allow_dev_chain) : CHAIN_HOST;
+    const bool dev_chain = cmode == CHAIN_DEVICE;
     enqueue_phase1(ctx, b, tm, !want_msm, nullptr, 0, 0, dev_chain);
     b.h_ident.resize(b.G);
     for (uint32_t g = 0; g < b.G; g++) b.h_ident[g] = 1;
@@ -2369,7 +2446,8 @@ int verify_groups_core_once(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_
     float chain_ms = 0;
     if (want_msm && !dev_chain) {
       auto c0 = std::chrono::steady_clock::now();
-      run_weight_chains(b);
+      if (cmode == CHAIN_HOST_WIDE) run_weight_chains_wide(b);
+      else run_weight_chains(b);
       chain_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c0).count();
     }
     if (want_masks) {
@@ -2378,12 +2456,13 @@ int verify_groups_core_once(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_
       b.masks_dirty = true;
     }
     if (want_msm) {
-      enqueue_phase2(ctx, b, tm, dev_chain);
+      if (cmode == CHAIN_HOST_WIDE) enqueue_finish_wide(ctx, b, s);
+      enqueue_phase2(ctx, b, tm, cmode != CHAIN_HOST);
       b.have_trace = true;
     }
     fetch_results(ctx, b, want_msm, want_masks);
-    HIP_CHECK(hipStreamSynchronize(s));
-    if (dev_chain && ctx->h_chain_zero[0]) {
+    gpu_wait_stream(ctx, s, wait_naps(ctx, b.B));
+    if (want_msm && cmode != CHAIN_HOST && ctx->h_chain_zero[0]) {
       ctx->device_chain_redraws++;
       return BPP_REDRAW_ON_HOST;
     }

@@ -460,15 +460,16 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     // Everything is enqueued and this thread has nothing to do for the call's ~6 ms: the host copies of the witness (the packed
     // bytes and their page-locked staging) are wiped NOW, behind the events that say the staging has been read -- not after the
     // call's last kernel, where three megabytes of explicit_bzero were 0.2 ms on the caller's clock.
-    for (uint32_t q = 0; q < n_sub; q++) HIP_CHECK(hipEventSynchronize(ctx->prove_aux_events[2 * q]));
+    const bool nap = ctx->opt.wait >= 0 ? ctx->opt.wait != 0 : n_items >= 256;  // (a call of a few proofs is a latency chain: the runtime's spinning wait)
+    for (uint32_t q = 0; q < n_sub; q++) gpu_wait_event(ctx->prove_aux_events[2 * q], nap);
     wipe(bytes.data(), bytes.size());
     wipe(ctx->prove_pin_in.p, ctx->prove_pin_in.n);
     staging_clean = true;
     for (uint32_t q = 0; q < n_sub; q++) {
-      HIP_CHECK(hipStreamSynchronize(lane_stream(q)));  // (everything of the MSM stream lies in front of the lane stream's tail)
-      HIP_CHECK(hipStreamSynchronize(ctx->prove_streams[q]));
+      gpu_wait_stream(ctx, lane_stream(q), nap);  // (everything of the MSM stream lies in front of the lane stream's tail)
+      gpu_wait_stream(ctx, ctx->prove_streams[q], nap);
     }
-    if (fifo) HIP_CHECK(hipStreamSynchronize(ctx->prove_msm_stream));
+    if (fifo) gpu_wait_stream(ctx, ctx->prove_msm_stream, nap);
     arena_clean = true;  // every sub-batch's arena range was zeroed on its stream
     if (ctx->profile) {
       bpp_prove_profile &pp = ctx->pprof;

@@ -56,7 +56,13 @@ __global__ void __launch_bounds__(64, BPP_TRANSCRIPTS_WAVES) k_transcripts(const
                                                     uint32_t *__restrict__ status, uint8_t *__restrict__ rng_host) {
   __shared__ uint32_t sponge[BPP_LS_WORDS * BPP_LS_STRIDE];  // word w of lane l at [w * 64 + l] (lstrobe.h)
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= B) return;
+  // The lanes past the end of the input replay the LAST proof once more (the same values to the same places) instead of
+  // leaving: the host's copy at the end is stored by lane q for piece q of the wavefront's rows, so with B % 64 != 0 the
+  // pieces of the last rows belong to lanes that have no proof of their own.  (Round 6: they used to return here; with
+  // B % 64 = L the pieces L .. 2L-1 -- the bytes of the last L / 2 proofs -- never reached the host and the host chain of the
+  // last reference batch ran on stale bytes: verdicts unchanged, weights not the reference's.  tests/test_gpu_round6.py holds
+  // a ragged last batch of an input of more than BPP_TRANSCRIPTS_WAVE_MAX proofs to the oracle.)
+  if (p >= B) p = B - 1;
   const ProofDesc d = desc[p];
   LStrobe s;
   ls_from_bytes(s, (lds_u32 *)sponge + threadIdx.x, states + 203u * d.state_idx);

@@ -9,12 +9,15 @@
 //     50 lanes: a 64-bit rotation is one v_alignbit_b32 per half (by r/2; an odd r swaps the halves, which costs nothing
 //     here: the lane reads the other half's address), xor3 / chi are one v_bitop3_b32;
 //   * a lane stands at a DESTINATION (x', y', h') of pi and does theta + rho for its SOURCE word: one exchange delivers
-//     the source half and the ten halves of the two neighbouring columns (columns are contiguous in LDS: a ds_read_b128
-//     and a ds_read_b32 each), so rho's result is born where pi wants it;
+//     the source half and the parities of the two neighbouring columns, so rho's result is born where pi wants it;
+//   * the column parities are summed by the LDS itself: every lane XORs its half into its column's accumulator with a
+//     ds_xor_b32 (five lanes per accumulator, ten accumulators, a fresh zeroed set per round: six stores per permutation
+//     clear all 24 sets) -- three reads per lane and round instead of eleven, and no XOR tree in the lanes;
 //   * the five lanes of a row (x' = 0..4 of one (y', h')) are neighbours in one 16-lane DPP row, so chi's two operands come
 //     from row_shl / row_shr moves instead of a second exchange.
 // Lane map: group g = 5 h' + y' (ten groups of five lanes, three groups per DPP row): lane = 16 (g / 3) + 5 (g % 3) + x'.
-// LDS image of the state between rounds: dword [(2 x + h) * 8 + y] (column-major, columns padded to 8 dwords).
+// LDS image: dword [2 (x + 5 y) + h] holds a half of the state (64 .. 127: one scratch dword per lane for the 14 idle lanes);
+// dword [128 + 16 r + 2 x + h] is round r's parity accumulator of column x, half h (10 .. 15 of a set: the idle lanes' dump).
 #pragma once
 #include "merlin.h"
 
@@ -53,12 +56,13 @@ BPP_HD constexpr uint64_t wk_word(uint32_t even, uint32_t odd) {
   return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-#define WK_LDS_DWORDS (80 + 64)  // the state image (10 columns x 8) and one scratch dword per lane for the idle lanes
+#define WK_LDS_DWORDS (128 + 24 * 16)  // state halves, the idle lanes' scratch dwords, 24 sets of parity accumulators
 
 struct WkLanes {
-  uint32_t wr, src, cm, cp;  // LDS byte addresses: own half, source half, base of column xs-1 (half hs), of column xs+1 (half 1-hs)
+  uint32_t wr, src, acc, cm, cp;  // LDS byte addresses: own half, source half; in accumulator set 0: own column, column xs-1 (half hs), column xs+1 (half 1-hs)
+  uint32_t zero;             // 4 x lane: the six clearing stores cover dwords 128 + lane + 64 k
   uint32_t cp_sh, rho_sh;    // v_alignbit_b32 shift amounts (rol32(v, n) = alignbit(v, v, (32 - n) & 31))
-  uint32_t wrap1, wrap2;     // all-ones where the row neighbour x'+1 / x'+2 wraps around the group of five
+  uint64_t nowrap1, wrap2;   // wave masks: lanes whose row neighbour x'+1 is the next lane (x' < 4) / whose x'+2 wraps around (x' >= 3)
   uint32_t word, half;       // this lane's state word (x' + 5 y') and half; word = 0xffffffff for the 14 idle lanes
   uint32_t rc_mask;          // all-ones in the two lanes that hold word 0
 };
@@ -82,14 +86,16 @@ __device__ __forceinline__ WkLanes wk_lanes(const uint32_t *lds) {
   const uint32_t odd = r & 1u, hs = h ^ odd, sh = (r >> 1) + (odd & (h ^ 1u));
   const uint32_t base = wk_lds_addr(lds);
   WkLanes L;
-  L.wr = base + 4u * (owner ? (2 * x + h) * 8 + y : 80 + lane);
-  L.src = base + 4u * ((2 * xs + hs) * 8 + ys);
-  L.cm = base + 4u * ((2 * ((xs + 4) % 5) + hs) * 8);
-  L.cp = base + 4u * ((2 * ((xs + 1) % 5) + (hs ^ 1u)) * 8);
+  L.wr = base + 4u * (owner ? 2 * (x + 5 * y) + h : 64 + lane);
+  L.src = base + 4u * (2 * (xs + 5 * ys) + hs);
+  L.acc = base + 4u * (128 + (owner ? 2 * x + h : 10 + (lane & 3u)));
+  L.cm = base + 4u * (128 + 2 * ((xs + 4) % 5) + hs);
+  L.cp = base + 4u * (128 + 2 * ((xs + 1) % 5) + (hs ^ 1u));
+  L.zero = base + 4u * (128 + lane);
   L.cp_sh = hs == 0 ? 31u : 0u;  // D[x] = C[x-1] ^ rol64(C[x+1], 1): even half takes rol32(odd half of C[x+1], 1), odd half the even half as is
   L.rho_sh = (32u - sh) & 31u;
-  L.wrap1 = x >= 4 ? 0xffffffffu : 0u;
-  L.wrap2 = x >= 3 ? 0xffffffffu : 0u;
+  L.nowrap1 = __ballot(x < 4);
+  L.wrap2 = __ballot(x >= 3);
   L.word = owner ? x + 5 * y : 0xffffffffu;
   L.half = h;
   L.rc_mask = (owner && x == 0 && y == 0) ? 0xffffffffu : 0u;
@@ -119,41 +125,64 @@ __device__ __forceinline__ WkRc wk_rc(const WkLanes &L) {
   return R;
 }
 
-typedef uint32_t wk_u32x4 __attribute__((ext_vector_type(4)));
+// Six rounds (R0 is a template parameter: the accumulator sets' offsets are immediates of the LDS instructions).  Written out as
+// instructions: the compiler pads around an asm statement it cannot see into, and v_cndmask_b32 with a DPP operand (one
+// instruction for "the next lane's value, or the lane four below at the end of the group") is not something it emits.  vcc (the
+// lanes with x' < 4) is set once per six rounds.
+#define WK_ROUND_ASM(K)                                                                                               \
+  "ds_write_b32 %[wa], %[a]\n\t"                                                                                      \
+  "ds_xor_b32 %[ca], %[a] offset:%[off" #K "]\n\t"                                                                    \
+  "ds_read_b32 %[s], %[sa]\n\t"                                                                                       \
+  "ds_read_b32 %[cm], %[ma] offset:%[off" #K "]\n\t"                                                                  \
+  "ds_read_b32 %[cp], %[pa] offset:%[off" #K "]\n\t"                                                                  \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                          \
+  "v_alignbit_b32 %[cp], %[cp], %[cp], %[cpsh]\n\t"                                                                   \
+  "v_bitop3_b32 %[s], %[s], %[cm], %[cp] bitop3:0x96\n\t"                  /* theta */                                \
+  "v_alignbit_b32 %[s], %[s], %[s], %[rsh]\n\t"                            /* rho (pi: by position): s = b */         \
+  "s_nop 1\n\t"                                      /* a DPP read of a register needs two wait states after its write */ \
+  "v_mov_b32_dpp %[cm], %[s] row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" /* b[x'+1]: lane + 1 ... */        \
+  "v_mov_b32_dpp %[cp], %[s] row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" /* b[x'+2]: lane + 2 ... */        \
+  "v_mov_b32_dpp %[w2], %[s] row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" /* ... or lane - 3 (x' = 3, 4) */  \
+  "v_cndmask_b32_dpp %[cm], %[s], %[cm], vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" /* or lane - 4 */  \
+  "v_cndmask_b32_e64 %[cp], %[cp], %[w2], %[wr2]\n\t"                                                                 \
+  "v_bitop3_b32 %[s], %[s], %[cm], %[cp] bitop3:0xd2\n\t"                  /* chi */                                  \
+  "v_xor_b32_e32 %[a], %[s], %[rc" #K "]\n\t"                              /* iota */
+
+template <int R0>
+__device__ __forceinline__ uint32_t wk_rounds6(uint32_t a, const WkLanes &L, const WkRc &R) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (gfx950 instructions: nothing for the host pass to parse)
+  uint32_t s, cm, cp, w2;
+  asm volatile("s_mov_b64 vcc, %[nw1]\n\t" WK_ROUND_ASM(0) WK_ROUND_ASM(1) WK_ROUND_ASM(2) WK_ROUND_ASM(3) WK_ROUND_ASM(4) WK_ROUND_ASM(5)
+               : [a] "+&v"(a), [s] "=&v"(s), [cm] "=&v"(cm), [cp] "=&v"(cp), [w2] "=&v"(w2)
+               : [wa] "v"(L.wr), [ca] "v"(L.acc), [sa] "v"(L.src), [ma] "v"(L.cm), [pa] "v"(L.cp), [cpsh] "v"(L.cp_sh), [rsh] "v"(L.rho_sh),
+                 [wr2] "s"(L.wrap2), [nw1] "s"(L.nowrap1), [off0] "n"(64 * R0), [off1] "n"(64 * (R0 + 1)), [off2] "n"(64 * (R0 + 2)),
+                 [off3] "n"(64 * (R0 + 3)), [off4] "n"(64 * (R0 + 4)), [off5] "n"(64 * (R0 + 5)), [rc0] "v"(R.v[R0]), [rc1] "v"(R.v[R0 + 1]),
+                 [rc2] "v"(R.v[R0 + 2]), [rc3] "v"(R.v[R0 + 3]), [rc4] "v"(R.v[R0 + 4]), [rc5] "v"(R.v[R0 + 5])
+               : "memory", "vcc");
+#endif
+  return a;
+}
 
 // `a`: this lane's half of the state (any value in the idle lanes).  All 64 lanes must call it.  Uses lds[0 .. WK_LDS_DWORDS).
 __device__ __forceinline__ uint32_t wk_keccak_f1600(uint32_t a, const WkLanes &L, const WkRc &R) {
-#if defined(__HIP_DEVICE_COMPILE__)  // (gfx950 builtins and instructions: nothing for the host pass to parse)
-#pragma unroll
-  for (int rnd = 0; rnd < 24; rnd++) {
-    uint32_t s, m4, p4;
-    wk_u32x4 m, p;
-    // one wavefront's LDS operations execute in issue order: the reads below see every lane's write of this round, and the next
-    // round's write comes after them
-    asm volatile(
-        "ds_write_b32 %[wa], %[a]\n\t"
-        "ds_read_b32 %[s], %[sa]\n\t"
-        "ds_read_b128 %[m], %[ma]\n\t"
-        "ds_read_b32 %[m4], %[ma] offset:16\n\t"
-        "ds_read_b128 %[p], %[pa]\n\t"
-        "ds_read_b32 %[p4], %[pa] offset:16\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : [s] "=&v"(s), [m] "=&v"(m), [m4] "=&v"(m4), [p] "=&v"(p), [p4] "=&v"(p4)
-        : [wa] "v"(L.wr), [a] "v"(a), [sa] "v"(L.src), [ma] "v"(L.cm), [pa] "v"(L.cp)
-        : "memory");
-    const uint32_t cm = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(m.x, m.y, m.z, 0x96), m.w, m4, 0x96);
-    const uint32_t cp = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(p.x, p.y, p.z, 0x96), p.w, p4, 0x96);
-    const uint32_t in = __builtin_amdgcn_bitop3_b32(s, cm, __builtin_amdgcn_alignbit(cp, cp, L.cp_sh), 0x96);  // theta
-    const uint32_t b = __builtin_amdgcn_alignbit(in, in, L.rho_sh);                                           // rho (pi: by position)
-    // chi: b[x'+1], b[x'+2] of the same row = the next two lanes of the group of five, wrapping around
-    const uint32_t n1 = __builtin_amdgcn_update_dpp(0u, b, 0x101, 0xf, 0xf, true);  // row_shl:1  (lane + 1)
-    const uint32_t w1 = __builtin_amdgcn_update_dpp(0u, b, 0x114, 0xf, 0xf, true);  // row_shr:4  (lane - 4)
-    const uint32_t n2 = __builtin_amdgcn_update_dpp(0u, b, 0x102, 0xf, 0xf, true);  // row_shl:2
-    const uint32_t w2 = __builtin_amdgcn_update_dpp(0u, b, 0x113, 0xf, 0xf, true);  // row_shr:3
-    const uint32_t b1 = L.wrap1 ? w1 : n1, b2 = L.wrap2 ? w2 : n2;
-    a = __builtin_amdgcn_bitop3_b32(b, b1, b2, 0xD2) ^ R.v[rnd];  // chi, iota
-  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // One wavefront's LDS operations execute in issue order: a round's reads see every lane's write and XOR of that round, the
+  // next round's write comes after them, and the clearing stores below come after the previous permutation's last reads.
+  asm volatile(
+      "ds_write_b32 %[z], %[o]\n\t"
+      "ds_write_b32 %[z], %[o] offset:256\n\t"
+      "ds_write_b32 %[z], %[o] offset:512\n\t"
+      "ds_write_b32 %[z], %[o] offset:768\n\t"
+      "ds_write_b32 %[z], %[o] offset:1024\n\t"
+      "ds_write_b32 %[z], %[o] offset:1280"
+      :
+      : [z] "v"(L.zero), [o] "v"(0u)
+      : "memory");
 #endif
+  a = wk_rounds6<0>(a, L, R);
+  a = wk_rounds6<6>(a, L, R);
+  a = wk_rounds6<12>(a, L, R);
+  a = wk_rounds6<18>(a, L, R);
   return a;
 }
 

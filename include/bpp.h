@@ -86,11 +86,14 @@ const char *bpp_ctx_last_error(bpp_ctx *ctx);
  * sponge per reference batch: 0 = on host cores (csrc/chain_host.h: lowest latency, 0.04 host-core-ms per 1024 proofs), 1 = on
  * the device, one wavefront per reference batch behind PASS 1 (csrc/chain_dev.h: the calling thread only enqueues and the
  * rank needs no host cores in proportion to its throughput; a zero weight, probability 2^-252, sends the call through the host
- * chains once more, which redraw as the reference does), -1 = the engine's rule: host).  The environment variables BPP_<NAME> give
+ * chains once more, which redraw as the reference does), 2 = the sponges on host cores, Scalar::from_bytes_mod_order_wide and the
+ * look for a zero weight on the device (half the host time of 0), -1 = the engine's rule: 2 for calls of 4096 proofs and more, else
+ * 0), "wait" (how the calling thread waits for the device: 0 = hipStreamSynchronize, which spins on a core; 1 = naps of 50 us between
+ * looks at an event, 1-2 % of a core; -1 = the engine's rule: naps for calls of 4096 proofs and more).  The environment variables BPP_<NAME> give
  * the initial values and are read ONCE, when the context is created: no verification path calls getenv. */
 int bpp_ctx_set_option(bpp_ctx *ctx, const char *name, int value);
-/* verifications of this context whose weight chains ran on the device, and how many of those went back to the host chains
- * because a weight came out zero */
+/* verifications of this context whose weights were made on the device ("chain" 1 or 2), and how many of those ran once more
+ * with everything on the host because a weight came out zero */
 int bpp_device_chain_stats(bpp_ctx *ctx, uint64_t *calls, uint64_t *redraws);
 
 /* ---- runtime preconditions and the admission gate for small calls ("Runtime preconditions") ----

@@ -2,7 +2,9 @@
 
 Reference: the weight transcript of RangeProof::verify (src/range_proof.rs:811 Transcript::new, :849 append_message per proof, :853
 build_rng().finalize(NullRng), :894 one Scalar::random_not_zero per proof; src/protocols/scalar_protocol.rs:23-30 redraws a zero,
-src/utils/nullrng.rs:16-40).  The device form must leave byte for byte the weights of the CPU oracle (oracle/c through
+src/utils/nullrng.rs:16-40).  Option "chain" = 2 keeps the sponges on host cores and moves only
+Scalar::from_bytes_mod_order_wide and the look for a zero weight to the device (the default for calls of 4096 proofs and more).
+Either form must leave byte for byte the weights of the CPU oracle (oracle/c through
 oracle.cport) and of the host form (csrc/chain_host.h), for whole reference batches of any size and for ragged groups."""
 import importlib
 
@@ -45,14 +47,16 @@ def _oracle_weights(d, lo, hi):
     return tr["weights"]
 
 
+@pytest.mark.parametrize("chain", [1, 2])
 @pytest.mark.parametrize("n", [1, 3, 4, 5, 64, 1024, 4096])
-def test_device_chain_weights_equal_the_oracle(bpp, packed, engine, opt, cfg2, n):
+def test_device_chain_weights_equal_the_oracle(bpp, packed, engine, opt, cfg2, n, chain):
     """one reference batch of n proofs, chains on the device: accepted, MSM result the identity, and the n weights are the CPU
     oracle's and the host chain's, byte for byte (n = 3, 4, 5: a record of 45 bytes crosses the sponge's 166-byte block at the
-    fourth proof; 1024 and 4096: the sizes BASELINE's configs quote)"""
+    fourth proof; 1024 and 4096: the sizes BASELINE's configs quote).  chain = 2: the sponge on a host core, only the reduction
+    mod l and the look for a zero on the device."""
     params, d = cfg2
     rb = _resident(packed, params, d, 0, n)
-    opt("chain", 1)
+    opt("chain", chain)
     before = engine.device_chain_stats()
     rb.verify_only(chunk=0)
     after = engine.device_chain_stats()
@@ -68,14 +72,15 @@ def test_device_chain_weights_equal_the_oracle(bpp, packed, engine, opt, cfg2, n
     assert w_dev == _oracle_weights(d, 0, n)
 
 
-def test_device_chain_per_group_and_ragged(bpp, packed, engine, opt, cfg2):
+@pytest.mark.parametrize("chain", [1, 2])
+def test_device_chain_per_group_and_ragged(bpp, packed, engine, opt, cfg2, chain):
     """several reference batches in one call (chunk = 1024 over 4548 proofs: four full groups and one of 452): every group's
     chain is its own wavefront; the weights are those of the host chains, and a group's weights are those of the same proofs
     verified alone.  Then ragged groups through bpp_verify_resident_groups (the batcher's form)."""
     params, d = cfg2
     n = 4096 + 452
     rb = _resident(packed, params, d, 0, n)
-    opt("chain", 1)
+    opt("chain", chain)
     rb.verify_only(chunk=1024)
     assert rb.shape()["groups"] == 5
     w_dev = rb.trace(3)
@@ -85,7 +90,7 @@ def test_device_chain_per_group_and_ragged(bpp, packed, engine, opt, cfg2):
     assert rb.trace(3) == w_dev
     # ragged groups: 1, 700, 1024, 2823 proofs
     bounds = [0, 1, 701, 1725, n]
-    opt("chain", 1)
+    opt("chain", chain)
     res = packed.verify_groups(rb, bounds)
     assert all(r["code"] == 0 for r in res)
     w_rag = rb.trace(3)
@@ -96,7 +101,7 @@ def test_device_chain_per_group_and_ragged(bpp, packed, engine, opt, cfg2):
     rb.close()
     assert w_rag[32 * 1:32 * 701] == _oracle_weights(d, 1, 701)
     one = _resident(packed, params, d, 4096, n)
-    opt("chain", 1)
+    opt("chain", chain)
     one.verify_only(chunk=0)
     assert one.trace(3) == w_dev[32 * 4096:]
     one.close()
@@ -109,26 +114,27 @@ def test_device_chain_rejects_what_the_host_chain_rejects(bpp, packed, engine, o
     bad = d["proofs"][:4096].copy()
     bad[2 * 1024 + 77, 1 + 32 + 96 + 5] ^= 2  # r1
     out = {}
-    for chain in (1, 0):
+    for chain in (1, 2, 0):
         opt("chain", chain)
         rb = packed.ResidentBatch(params, bad, d["commitments"][:4096], d["min_values"][:4096], d["min_present"][:4096], None, LABEL)
         with pytest.raises(bpp.ProofError) as e:
             rb.verify_only(chunk=1024)
         out[chain] = (e.value.kind, rb.trace(6), rb.trace(3))
         rb.close()
-    assert out[0] == out[1]
+    assert out[0] == out[1] == out[2]
     assert out[1][0] == bpp.ProofErrorKind.VerificationFailed
     pts = out[1][1]
     assert [pts[32 * g:32 * g + 32] == bytes(32) for g in range(4)] == [True, True, False, True]
 
 
-def test_device_chain_zero_weight_goes_back_to_the_host_chain(bpp, packed, engine, opt, cfg2):
+@pytest.mark.parametrize("chain", [1, 2])
+def test_device_chain_zero_weight_goes_back_to_the_host_chain(bpp, packed, engine, opt, cfg2, chain):
     """Scalar::random_not_zero redraws a zero weight (src/protocols/scalar_protocol.rs:23-30).  The device chain cannot (the next
     draw would shift every later weight): it reports the zero and the call runs once more with the chains on the host.  The
     test hook makes k_chain_finish report proof 700's weight as zero."""
     params, d = cfg2
     rb = _resident(packed, params, d, 0, 2048)
-    opt("chain", 1)
+    opt("chain", chain)
     opt("chain_test_zero", 701)
     before = engine.device_chain_stats()
     rb.verify_only(chunk=1024)
