@@ -58,10 +58,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    # three steps in flight since round 4: with no copy left on a step's chain (the kernels read and write mapped host memory)
-    # three sustain what four did (256 steps: 2.45-2.49 against 2.48-2.54 ms per step, 20 steps: 2.53-2.57 against 2.55-2.62, one
-    # box, alternating: profiles/r04_conc_3_vs_4.txt) at a higher clock and three quarters of the latency per step
-    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "3")),
+    # steps in flight per GPU: 0 = the harness' rule (four; five with the weight chains on the device), see main()
+    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "0")),
                     help="steps in flight per GPU (one engine/stream + one host thread each)")
     ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_step", type=int,
                     default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "64")),
@@ -766,7 +764,8 @@ def main():
         os.environ["BPP_HOST_THREADS"] = str(max(4, min(32, usable_cpus() // world_env)))
     # where the weight chains run: read by the library once per context, when it is created (BPP_CHAIN)
     chain_mode = resolve_chain_mode(args, world_env)
-    os.environ["BPP_CHAIN"] = {"host": "0", "device": "1", "host-wide": "2"}[chain_mode]
+    if args.chain != "auto" or chain_mode == "device":  # (auto with cores to spare: the engine's own rule, call by call)
+        os.environ["BPP_CHAIN"] = {"host": "0", "device": "1", "host-wide": "2"}[chain_mode]
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -926,6 +925,10 @@ def main():
         return
 
     # ------------------------------------------------------------------ headline: BASELINE configs[1]
+    # steps in flight: four (round 6: callers nap instead of spinning, a fourth costs nothing and sustains 1-3 % more over long
+    # regions); the device chains put ~2.5 ms of lone-wavefront latency on every step's critical path: five
+    if args.concurrency <= 0:
+        args.concurrency = 5 if chain_mode == "device" else 4
     R, S = max(1, args.batches_per_step), max(1, args.concurrency)
     params2 = bpp.RangeParameters.init(64, 1, G(1), engine=eng0)
     data2 = make_inputs(np, packed, params2, 1024 * R, seed=8675309 + 1000 * rank)
@@ -1013,14 +1016,22 @@ def main():
         # the same by thread name (/proc/self/task, 10 ms ticks: meaningful for regions of 0.5 s and more)
         "host_cores_busy_by_thread": thr_busy,
     }
+    # N ranks of this host want N x host_cores_busy schedulable cores: more than there are = the scaling curve is the host's
+    out["host_bound"] = bool(out["host_cores_busy"] is not None and world * out["host_cores_busy"] > usable_cpus())
     if args.one_device:
         out["config"]["devices"] = "ALL %d ranks on device 0 (--one-device: a rehearsal of the multi-rank code, not a scaling point)" % world
     if use_dist:
         mine = {"rank": rank, "device": local_rank, "host_threads": bpp.host_threads(), "usable_cpus": usable_cpus(),
                 "ms_per_step_local": local_ms, "host_chain_cpu_ms_per_step": pool_cpu_ms, "host_process_cpu_ms_per_step": proc_cpu_ms}
+        mine["host_cores_busy"] = proc_cpu_ms / local_ms if local_ms > 0 else None
+        mine["weight_chains"] = chain_mode
         every = [None] * world
         dist.all_gather_object(every, mine)
         out["per_rank"] = every
+        # ranks of ONE node share its cores (the driver's runs are single-node): all of them together against what is schedulable
+        want = sum(e["host_cores_busy"] or 0.0 for e in every)
+        out["host_cores_busy_all_ranks"] = want
+        out["host_bound"] = bool(want > min(e["usable_cpus"] for e in every))
     profiler_legs = rank == 0 and world == 1 and not use_dist and not args.no_traffic
     if roof:
         sq = {}

@@ -675,6 +675,16 @@ inline void gpu_wait_event(hipEvent_t ev, bool nap) {
     nanosleep(&ts, nullptr);
   }
 }
+inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap);
+inline bool gpu_wait_stream_ok(bpp_ctx *ctx, hipStream_t s, bool nap) {  // false instead of an exception (the sharded forms carry faults along)
+  try {
+    gpu_wait_stream(ctx, s, nap);
+    return true;
+  } catch (const EngineError &) {
+    (void)hipGetLastError();
+    return false;
+  }
+}
 inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap) {
   if (!nap) {
     HIP_CHECK(hipStreamSynchronize(s));
@@ -1621,8 +1631,8 @@ int bpp_shader_clock(bpp_ctx *ctx, uint32_t window_us, double *ghz) {
     const uint32_t naps = std::max<uint32_t>(1, std::min<uint32_t>(window_us, 2000000u) * 2 / 7);
     hipLaunchKernelGGL(k_shader_clock, dim3(1), dim3(64), 0, ctx->stream, d.p, naps);
     uint64_t h[2] = {0, 0};
-    HIP_CHECK(hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    gpu_wait_stream(ctx, ctx->stream, true);  // (naps: a sampling thread that spins for the whole window shows up as a busy host core)
+    HIP_CHECK(hipMemcpy(h, d.p, 16, hipMemcpyDeviceToHost));
     *ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
     return BPP_OK;
   }

@@ -596,7 +596,7 @@ int bpp_verify_sharded_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const uint64_t
     // ---------------------------------------------------------------- findings: one trailer per batch, next to the accumulator
     for (uint32_t i = 0; i < K; i++) {
       uint8_t *tr = comm->h_tr.data() + (size_t)i * BPP_SHARD_TRAILER_BYTES;
-      if (!fault[i] && hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) {
+      if (!fault[i] && !gpu_wait_stream_ok(ctxs[i], ctxs[i]->stream, true)) {
         fault[i] = BPP_ERR_ENGINE;
         fault_msg[i] = "a kernel of this rank failed on the device";
       }
@@ -823,7 +823,7 @@ int bpp_verify_sharded_groups_wave(bpp_comm *comm, bpp_ctx *const *ctxs, const u
     for (uint32_t i = 0; i < K; i++) {
       bpp_comm::GroupSlot &S = *comm->slots[i];
       bpp_ctx *ctx = ctxs[i];
-      if (!fault[i] && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      if (!fault[i] && !gpu_wait_stream_ok(ctx, ctx->stream, true)) {
         fault[i] = BPP_ERR_ENGINE;
         fault_msg[i] = "a kernel of this rank failed on the device";
       }
