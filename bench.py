@@ -495,11 +495,14 @@ def timed(leg, steps, warmup, sync, clock=None):
     if th:
         th.start()  # (before t0: the sampling wavefront naps through the region either way, its thread's start-up is not timed work)
     t0 = time.perf_counter()
-    lat, profs = leg.run_steps(steps)
-    sync()
-    el = time.perf_counter() - t0
+    try:
+        lat, profs = leg.run_steps(steps)
+        sync()
+        el = time.perf_counter() - t0
+    finally:
+        if th:
+            th.join()  # (also when a step raised: the sampler's engine is closed by the caller right after)
     if th:
-        th.join()
         return el, lat, profs, (ghz[0] if ghz else None)
     return el, lat, profs
 
@@ -903,7 +906,9 @@ def main():
         return cpu_side({"workload": "BASELINE configs[4]: bpp_prove_batch over 1024 x aggregation-4 64-bit proofs, extension "
                             "degree 3; host witness buffers in, proof bytes out (PCIe-inclusive)",
                 "proofs_per_s": 1024 * iters5 / el5, "ms_per_call": 1e3 * el5 / iters5, "calls": iters5, "four_calls_in_flight": conc,
-                "roofline": {"bound": "hbm", "kernel": "k_fb_part (fixed-base MSM of every L / R / A1 / B as one-wavefront slices; the witness check runs in the uniform-access form, k_ct_fixed)",
+                "roofline": {"bound": "hbm",
+                             "kernel": "k_fb_part (fixed-base MSM of every L and R -- and of A1's four public points, or of A1 and B with "
+                                       "ct < 2 -- as one-wavefront slices; the secret-only terms run in the uniform-access forms of ct.h)",
                              "kernel_ms": pp["fb_msm_ms"], "launches": pp["fb_launches"], "algorithmic_bytes": fb_bytes,
                              "achieved": fb_bytes / (pp["fb_msm_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": fb_bytes / (pp["fb_msm_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
@@ -1009,7 +1014,8 @@ def main():
         "host_threads": bpp.host_threads(), "nproc": os.cpu_count(), "usable_cpus": usable_cpus(),
         "weight_chains": chain_mode, "shader_clock_ghz": clock_ghz,
         # the one sequential part of a verification stays on the host (the batch weight chains, src/range_proof.rs:849-853,894):
-        # CPU time of the library's host pool per timed step, and of the whole process; cores kept busy = cpu ms / step ms.  With
+        # CPU time of the library's host pool per timed step, and of the whole process (time.process_time: every thread of it, the
+        # callers' naps, the shader-clock sampler and the runtime's own threads included); cores kept busy = cpu ms / step ms.  With
         # N ranks on one node, N x host_cores_busy against the node's cores tells a host-bound scaling curve from a GPU-bound one.
         "host_chain_cpu_ms_per_step": pool_cpu_ms, "host_process_cpu_ms_per_step": proc_cpu_ms,
         "host_cores_busy": proc_cpu_ms / local_ms if local_ms > 0 else None,
@@ -1018,7 +1024,8 @@ def main():
     }
     # N ranks of this host want N x host_cores_busy schedulable cores: more than there are = the scaling curve is the host's
     out["host_bound"] = bool(out["host_cores_busy"] is not None and world * out["host_cores_busy"] > usable_cpus())
-    if args.one_device:
+    if args.one_device:  # every rank on device 0: ONE GPU did all of it -- a rehearsal of the multi-rank code, never a scaling point
+        out.update(n_gpus=1, ranks=world, rehearsal=True, scaling=None)
         out["config"]["devices"] = "ALL %d ranks on device 0 (--one-device: a rehearsal of the multi-rank code, not a scaling point)" % world
     if use_dist:
         mine = {"rank": rank, "device": local_rank, "host_threads": bpp.host_threads(), "usable_cpus": usable_cpus(),
@@ -1143,8 +1150,9 @@ def main():
                 lat_out["cpu_baseline"] = dict(cb, cores=1, kind="port", unit="ms per call / proofs/s",
                                                sample="one verify call of 1, 64 and 256 proofs at a time through oracle/c, one thread")
             return dict(lat_out, workload="BASELINE configs[0]'s shape through the engine: ONE call at a time, 1, 64 and 256 "
-                                                      "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input; calls of up to ~1200 proofs "
-                                                      "run the final MSM as a half-scalar plan (s = s_lo + 2^126 s_hi: half the Horner doublings)")
+                                          "non-aggregated 64-bit proofs (benches/range_proof.rs:115-119,199-203), resident input; calls of "
+                                          "up to ~1200 proofs run the final MSM as a half-scalar plan (s = s_lo + 2^126 s_hi: half the "
+                                          "Horner doublings)")
         side_leg("latency", latency_leg)
         # -------------------------------------------------------------- many callers, one 256-proof verify_batch call each
         try:

@@ -5,6 +5,10 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_siz
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbpp_hip.so")
+# BPP_LIB_PATH: load ANOTHER build of the library instead (measurement builds such as -DBPP_KP_PHASES: tools/gpu_kp_phases.sh).  The
+# product's own .so is never swapped in place for one; whoever sets the variable names the file and gets exactly that file.
+if os.environ.get("BPP_LIB_PATH"):
+    LIB_PATH = os.path.abspath(os.environ["BPP_LIB_PATH"])
 
 u8p = POINTER(c_uint8)
 

@@ -154,6 +154,55 @@ BPP_HD void ct_fixed_scalarmul(ge &r, const niels *base_lines /* [64][8] */, con
   r = acc;
 }
 
+// ---- VARIABLE bases known before their secret scalars (the prover's A1: r Gf[0] + s Hf[0], src/range_proof.rs:574-576): the
+// 63 x 4 doublings of the ladder above are doublings of a PUBLIC point -- they need not wait for the scalar, and they need not be
+// uniform.  With pow[w] = 16^w P made ahead (k_ct_pow16), digit position w contributes d_w * pow[w], d_w in [-8, 8]: the lane of
+// position w walks 1 pow[w], 2 pow[w], .. 8 pow[w] by seven additions and keeps the one its digit names under an arithmetic mask
+// (all eight are computed whatever the digit; zero keeps the neutral element), the sign is a select, and the 64 positions are
+// summed by a tree.  No table, no address and no branch that depends on the scalar; what follows the scalar on the call's
+// critical path is 7 + 1 additions and a 6-level tree instead of 252 doublings and 64 additions.
+BPP_HD void ct_pos_multiple(ge &out, const ge &pw, int32_t digit) {
+  uint32_t mag, neg;
+  ct_digit_parts(mag, neg, digit);
+  ge m = pw, sel;
+  ge_identity(sel);
+#pragma unroll 1
+  for (uint32_t k = 1; k <= 8; k++) {
+    if (k > 1) ge_add(m, m, pw);
+    ge c = m;  // (carried limbs: what the mask keeps must be valid limbs of ONE multiple)
+    fe_carry(c.X);
+    fe_carry(c.Y);
+    fe_carry(c.Z);
+    fe_carry(c.T);
+    const uint32_t keep = 0u - (((k ^ mag) - 1u) >> 31);  // all ones iff k == mag
+#pragma unroll
+    for (int q = 0; q < 10; q++) {
+      sel.X.v[q] = (c.X.v[q] & keep) | (sel.X.v[q] & ~keep);
+      sel.Y.v[q] = (c.Y.v[q] & keep) | (sel.Y.v[q] & ~keep);
+      sel.Z.v[q] = (c.Z.v[q] & keep) | (sel.Z.v[q] & ~keep);
+      sel.T.v[q] = (c.T.v[q] & keep) | (sel.T.v[q] & ~keep);
+    }
+  }
+  fe_cneg_select(sel.X, sel.X, neg);
+  fe_cneg_select(sel.T, sel.T, neg);
+  out = sel;
+}
+// one lane's model of the whole product (host probe): pow[w] by doublings, then the sum over the positions
+BPP_HD void ct_var_scalarmul(ge &r, const ge &p, const sc &s) {
+  int8_t d[BPP_CT_DIGITS];
+  ct_recode16(d, s);
+  ge pw = p, acc;
+  ge_identity(acc);
+  for (int w = 0; w < BPP_CT_DIGITS; w++) {
+    if (w)
+      for (int k = 0; k < 4; k++) ge_dbl(pw, pw);
+    ge q;
+    ct_pos_multiple(q, pw, d[w]);
+    ge_add(acc, acc, q);
+  }
+  r = acc;
+}
+
 #if defined(__HIPCC__)
 #define CTF_MAX_TERMS 8
 struct CtFixedShared {
@@ -195,6 +244,72 @@ __global__ void __launch_bounds__(64) k_ct_fixed(const sc *__restrict__ scal, co
   if (lane == 0) out[o] = sh.red[0];
   __syncthreads();
   for (uint32_t k = lane; k < sizeof(CtFixedShared) / 4; k += 64) ((uint32_t *)&sh)[k] = 0;  // digits and partial sums are secret-derived
+}
+
+// pow[pt][w] = 16^w * pts[pt], w = 0..63: one quad per point (msm.h's quad doubling), 252 dependent doublings of PUBLIC points
+__global__ void __launch_bounds__(64) k_ct_pow16(const ge *__restrict__ pts, uint32_t n_pts, ge *__restrict__ pow) {
+  const uint32_t lane = threadIdx.x, qi = lane & 3u;
+  uint32_t pt = blockIdx.x * 16u + (lane >> 2);
+  const bool live = pt < n_pts;
+  if (!live) pt = n_pts - 1;  // (idle quads walk the last point again and store nothing)
+  const QuadMask q = quad_mask(qi);
+  const ge p = pts[pt];
+  fe m;
+  quad_load(m, q, p);
+#pragma unroll 1
+  for (uint32_t w = 0; w < BPP_CT_DIGITS; w++) {
+    if (w) {
+#pragma unroll 1
+      for (int k = 0; k < 4; k++) quad_ge_dbl(m, q);
+    }
+    fe c = m;
+    fe_carry(c);
+    if (live) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(pow + (size_t)pt * BPP_CT_DIGITS + w) + 10u * qi;  // coordinate qi of the entry
+#pragma unroll
+      for (int k = 0; k < 10; k++) dst[k] = c.v[k];
+    }
+  }
+}
+
+// A1[p] += sum_{v < 4} scal[p][v] * pts[4 p + v], the points given as their multiples pow[4 p + v][w] = 16^w pts[4 p + v]
+// (k_ct_pow16): one workgroup of 256 lanes per proof, wavefront v owns term v, its lane w digit position w (ct_pos_multiple).
+// scal: row p at scal + p * row_stride + row_off, four canonical scalars.  acc[acc_stride * p] is read and written.
+#define CTV_TERMS 4
+struct CtVarShared {
+  int8_t dig[CTV_TERMS][BPP_CT_DIGITS];
+  ge red[CTV_TERMS * 64];
+};
+__global__ void __launch_bounds__(64 * CTV_TERMS) k_ct_var(const ge *__restrict__ pow, const sc *__restrict__ scal, uint32_t row_stride,
+                                                           uint32_t row_off, ge *__restrict__ acc, uint32_t acc_stride) {
+  const uint32_t p = blockIdx.x, tid = threadIdx.x, v = tid >> 6, w = tid & 63u;
+  __shared__ CtVarShared sh;
+  if (w == 0) {
+    const sc s = scal[(size_t)p * row_stride + row_off + v];
+    ct_recode16(sh.dig[v], s);
+  }
+  __syncthreads();
+  const ge pw = pow[((size_t)p * CTV_TERMS + v) * BPP_CT_DIGITS + w];
+  ge mine;
+  ct_pos_multiple(mine, pw, (int32_t)sh.dig[v][w]);
+  sh.red[tid] = mine;
+  __syncthreads();
+  for (uint32_t off = 128; off >= 1; off >>= 1) {  // all 256 partial sums: the four terms add up to one point anyway
+    if (tid < off) {
+      ge x = sh.red[tid], y2 = sh.red[tid + off];
+      ge_add(x, x, y2);
+      sh.red[tid] = x;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    ge x = sh.red[0];
+    const ge y2 = acc[(size_t)acc_stride * p];
+    ge_add(x, x, y2);
+    acc[(size_t)acc_stride * p] = x;
+  }
+  __syncthreads();
+  for (uint32_t k = tid; k < sizeof(CtVarShared) / 4; k += 64 * CTV_TERMS) ((uint32_t *)&sh)[k] = 0;  // digits and partial sums are secret-derived
 }
 
 #define CT_MAX_TERMS 16

@@ -948,6 +948,9 @@ void bpp_ctx_destroy(bpp_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   pipeline_shutdown(ctx);  // waits for the calls in flight on the lanes, joins their threads, destroys their contexts
+  // a call of another thread that is still inside this context (it holds the context's lock while it waits for the device) ends
+  // first: destroying a context under a running call is the caller's bug, but it must not become a use of freed events
+  { std::lock_guard<std::mutex> lk(ctx->mu); }
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &kv : ctx->batches) wipe_batch_secrets(*kv.second, ctx->stream);  // seed nonces / masks of batches never destroyed
   (void)hipStreamSynchronize(ctx->stream);

@@ -157,6 +157,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     uint32_t PROVE_SUBS = 2;
     if (ctx->opt.prove_subs > 0) PROVE_SUBS = (uint32_t)std::min(16, ctx->opt.prove_subs);
     const uint32_t sub_size = std::max<uint32_t>(64, cdiv(B, PROVE_SUBS));
+    constexpr size_t PROVE_PART_BUDGET = (size_t)2 << 30;
     const uint32_t n_sub = cdiv(B, sub_size);
     while (ctx->prove_streams.size() < n_sub) {
       hipStream_t ns;
@@ -171,9 +172,11 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     // freed wave slots to that queue first), joined to the MSM stream by an event each way per round.
     // Secret-only terms through the uniform-access forms of ct.h, where the reference is constant-time:
     //   "ct" >= 1 (the default): the witness check's commit(v, r) (src/generators/pedersen_gens.rs:112-122, src/range_proof.rs:275-284)
-    //   "ct" == 2: A1 and B as well (:572-584): the fixed-base MSM then sees the PUBLIC folded-generator coefficients only and the
-    //              secret scalars r, s, (r y b + s y a), d_k, (r y s), eta_k multiply by a uniform ladder (k_ct_msm: 256 doublings per
-    //              term on the call's last stretch -- measured cost in DESIGN.md, which is why it is not the default)
+    //   "ct" == 2: A1 and B as well (:572-584): no secret scalar of theirs reaches a fixed-base table.  The Pedersen-base terms go
+    //              through the uniform-access lines (k_ct_fixed); the folded generators of the final step are written as
+    //              Gf[0] = e^-1 GE + e y^-1 GO, Hf[0] = e HE + e^-1 HO over four PUBLIC points of the last round, whose fixed-base MSM
+    //              and 16^w multiples (k_ct_pow16: 252 doublings) run on the side stream beside the last round and the final step,
+    //              and the secrets r e^-1, r e y^-1, s e, s e^-1 meet them in k_ct_var: seven additions, a select and a tree (ct.h)
     //   "ct" == 0: everything through the fixed-base tables, whose addresses are the scalars' digits
     const bool ct_check = ctx->opt.ct != 0, ct = ctx->opt.ct == 2;
     const bool fused = ctx->opt.prove_fused != 0;
@@ -188,11 +191,15 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     // the workgroup form (tests run both), a positive value fixes the number of slices.
     uint32_t parts = 0;
     if (ctx->opt.prove_parts != 0) {
-      const uint32_t outs = 2 * std::max<uint32_t>(64, cdiv(B, ctx->opt.prove_subs > 0 ? (uint32_t)std::min(16, ctx->opt.prove_subs) : 2u));
+      const uint32_t outs = 2 * sub_size;  // (a round's outputs per sub-batch as it really is cut)
       parts = ctx->opt.prove_parts > 0 ? (uint32_t)ctx->opt.prove_parts : cdiv(3072u, outs);
       parts = std::max(parts, cdiv(mn + t + 1, (uint32_t)FBP_MAX_PER));
       parts = std::min<uint32_t>(std::max<uint32_t>(parts, 1u), FBP_MAX_PARTS);
       if (cdiv(mn + t + 1, parts) > FBP_MAX_PER) parts = 0;  // (aggregations whose rounds do not fit the slices: the workgroup form)
+      // the slices' partial sums are 3 x proofs x parts x 64 points per sub-batch (30 KB per proof and slice), zeroed with the rest
+      // of the arena after every call: beyond PROVE_PART_BUDGET per sub-batch (a call of more than ~20 000 proofs per sub-batch) the
+      // workgroup form, whose sums stay in LDS, takes over
+      if (parts && (size_t)3 * sub_size * parts * 64 * sizeof(ge) > PROVE_PART_BUDGET) parts = 0;
     }  // one launch per round for encoding + Fiat-Shamir step + vector step (tests run both)
     const bool prio = ctx->opt.prove_prio > 0;  // (off by default: measured, no gain -- profiles/r04_prover_prio_ab.txt)
     // The fixed-base MSMs of ALL sub-batches on ONE stream, in the order they are enqueued (round by round, sub-batch by
@@ -224,7 +231,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
       ctx->prove_aux_streams.push_back(ns);
     }
-    while (ctx->prove_aux_events.size() < 2 * (size_t)n_sub) {
+    while (ctx->prove_aux_events.size() < 4 * (size_t)n_sub) {  // per sub-batch: inputs resident, witness check done; ("ct" = 2) last round's lists written, 16^w multiples made
       hipEvent_t e;
       HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       ctx->prove_aux_events.push_back(e);
@@ -243,6 +250,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       HIP_CHECK(hipStreamWaitEvent(lane_stream(q), ctx->prove_sync_events[2 * q + 1], 0));
     };
     const uint32_t stride = 2 * mn + t + 1;
+    const uint32_t ex_parts = cdiv(mn / 2, 128u);  // slices of <= 128 terms per public point of the last round ("ct" = 2)
     struct Sub {
       uint32_t lo, nb;
       size_t bytes_lo, bytes_len, arena_lo, arena_len;
@@ -254,6 +262,11 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       uint32_t *d_tg, *d_tc, *d_ctg, *d_ctc, *d_ftg, *d_ftc;
       sc *d_fts;
       ge *d_ge, *d_ge_ct, *d_part;
+      // "ct" = 2: the four public points per proof of the last round (GE, GO, HE, HO: kp_wave_body) as term lists, slice sums, points,
+      // and their multiples by 16^w
+      sc *d_exs;
+      uint32_t *d_exg, *d_exc;
+      ge *d_expart, *d_expts, *d_pow;
     };
     std::vector<Sub> subs(n_sub);
     size_t arena_need = 0;
@@ -299,6 +312,12 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         u.d_ftc = (uint32_t *)take(nb * 2 * 4);
         u.d_ge_ct = (ge *)take(2 * nb * sizeof(ge));
         u.d_part = (ge *)take(parts ? (size_t)3 * nb * parts * 64 * sizeof(ge) : 16);
+        u.d_exs = (sc *)take(ct ? nb * 2 * (size_t)mn * sizeof(sc) : 16);
+        u.d_exg = (uint32_t *)take(ct ? nb * 2 * (size_t)mn * 4 : 16);
+        u.d_exc = (uint32_t *)take(nb * 4 * 4);
+        u.d_expart = (ge *)take(ct ? (size_t)4 * nb * ex_parts * 64 * sizeof(ge) : 16);
+        u.d_expts = (ge *)take(ct ? (size_t)4 * nb * sizeof(ge) : 16);
+        u.d_pow = (ge *)take(ct ? (size_t)4 * nb * BPP_CT_DIGITS * sizeof(ge) : 16);
         u.arena_len = arena_need - u.arena_lo;
       }
     };
@@ -376,8 +395,8 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       // beside kp_init / kp_A / the first round's small kernels (in line they were 0.2 ms of the call's first 0.75 ms, in which no
       // round's MSM runs yet) and are joined in front of the first round's MSM, which reuses their output buffer
       hipStream_t sx = ctx->prove_aux_streams[q];
-      HIP_CHECK(hipEventRecord(ctx->prove_aux_events[2 * q], s));
-      HIP_CHECK(hipStreamWaitEvent(sx, ctx->prove_aux_events[2 * q], 0));
+      HIP_CHECK(hipEventRecord(ctx->prove_aux_events[4 * q], s));
+      HIP_CHECK(hipStreamWaitEvent(sx, ctx->prove_aux_events[4 * q], 0));
       hipLaunchKernelGGL(kp_commit_terms, dim3(cdiv(nb * m, 64)), b64, 0, sx, u.d_bytes, u.d_desc, t, n_gen, nb, m, 1 + t, u.d_cts,
                          u.d_ctg, u.d_ctc);
       if (ct_check) {
@@ -389,7 +408,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         fb_mark(sx);
       }
       hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(nb * m, 64)), b64, 0, sx, u.d_ge, nb * m, u.d_commit32);
-      HIP_CHECK(hipEventRecord(ctx->prove_aux_events[2 * q + 1], sx));
+      HIP_CHECK(hipEventRecord(ctx->prove_aux_events[4 * q + 1], sx));
       hipLaunchKernelGGL(kp_init, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_states, P.d_hg32.p, n, t, nb, u.d_ps);
       hipLaunchKernelGGL(kp_A, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, P.table.p, P.fb_table.p, P.fb_geo, n_gen, n,
                          t, u.d_ps, u.d_a32);
@@ -404,7 +423,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
           auto launch_round = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(nb), dim3(64 * kp_waves), 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, nb, j, rounds,
                                stride, u.d_a32, j ? (parts ? u.d_part : u.d_ge) : (const ge *)nullptr, parts, lr_prev, u.d_ps, u.d_vec, u.d_ts, u.d_tg,
-                               u.d_tc, ct ? u.d_fts : (sc *)nullptr, u.d_ftg, u.d_ftc);
+                               u.d_tc, ct ? u.d_fts : (sc *)nullptr, u.d_ftg, u.d_ftc, ct ? u.d_exs : (sc *)nullptr, u.d_exg, u.d_exc);
           };
           if (kp_waves == 1) launch_round(kp_round<1>);
           else if (kp_waves == 2) launch_round(kp_round<2>);
@@ -412,17 +431,42 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         } else {
           hipLaunchKernelGGL(kp_lane, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
           hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
-                             stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc, ct ? u.d_fts : (sc *)nullptr, u.d_ftg, u.d_ftc);
+                             stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc, ct ? u.d_fts : (sc *)nullptr, u.d_ftg, u.d_ftc,
+                             ct ? u.d_exs : (sc *)nullptr, u.d_exg, u.d_exc);
         }
         uint8_t *out = (j < rounds) ? u.d_lr + (size_t)j * nb * 64 : u.d_a1b;
         if (j == 0) {  // the witness check joins here: its verdict into the proof's status, its buffer free for the round's MSM
-          HIP_CHECK(hipStreamWaitEvent(s, ctx->prove_aux_events[2 * q + 1], 0));
+          HIP_CHECK(hipStreamWaitEvent(s, ctx->prove_aux_events[4 * q + 1], 0));
           hipLaunchKernelGGL(kp_check_commitments, dim3(cdiv(nb, 64)), b64, 0, s, u.d_bytes, u.d_desc, u.d_commit32, nb, u.d_ps);
+        }
+        if (ct && j + 1 == rounds) {
+          // "ct" = 2: the last round's four public points per proof -- their fixed-base MSM (as much work as a round's L and R),
+          // the slices' sums and the 252 doublings that make their multiples by 16^w -- on the sub-batch's side stream, beside this
+          // round's L / R and the next step: nothing of it waits for a secret, and nothing secret waits for it before k_ct_var
+          hipStream_t sx = ctx->prove_aux_streams[q];
+          HIP_CHECK(hipEventRecord(ctx->prove_aux_events[4 * q + 2], s));
+          HIP_CHECK(hipStreamWaitEvent(sx, ctx->prove_aux_events[4 * q + 2], 0));
+          fb_mark(sx);
+          hipLaunchKernelGGL(k_fb_part, dim3(4 * nb * ex_parts), b64, 0, sx, u.d_exs, u.d_exg, u.d_exc, mn / 2, ex_parts, P.fb_table.p, P.fb_geo,
+                             u.d_expart, 1u);
+          fb_mark(sx);
+          hipLaunchKernelGGL(k_fb_sum, dim3(4 * nb), b64, 0, sx, u.d_expart, ex_parts, u.d_expts);
+          hipLaunchKernelGGL(k_ct_pow16, dim3(cdiv(4 * nb, 16)), b64, 0, sx, u.d_expts, 4 * nb, u.d_pow);
+          HIP_CHECK(hipEventRecord(ctx->prove_aux_events[4 * q + 3], sx));
+        }
+        if (ct && j == rounds) {
+          // the final step has no fixed-base MSM: the Pedersen-base terms of A1 and B through the uniform-access tables, A1's two
+          // folded generators as four digit-parallel products over the multiples made above (ct.h), the encodings
+          hipLaunchKernelGGL(k_ct_fixed, dim3(2 * nb), b64, 0, s, u.d_fts, u.d_ftg, u.d_ftc, CT_ROW, n_gen, (const niels *)P.fb_ct.p, u.d_ge_ct);
+          HIP_CHECK(hipStreamWaitEvent(s, ctx->prove_aux_events[4 * q + 3], 0));
+          hipLaunchKernelGGL(k_ct_var, dim3(nb), dim3(64 * CTV_TERMS), 0, s, u.d_pow, u.d_fts, 2 * CT_ROW, 8u, u.d_ge_ct, 2u);
+          hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge_ct, 2 * nb, u.d_a1b);
+          continue;
         }
         to_msm(q);
         fb_mark(sm);
-        // (the last launch without "ct" = 2: three outputs per proof in rows of mn + t + 1 terms, see kp_wave_body)
-        const bool three = j == rounds && !ct;
+        // (the last launch: three outputs per proof in rows of mn + t + 1 terms, see kp_wave_body)
+        const bool three = j == rounds;
         const uint32_t n_out = (three ? 3 : 2) * nb, row = three ? mn + t + 1 : stride;
         if (parts) {
           hipLaunchKernelGGL(k_fb_part, dim3(n_out * parts), b64, 0, sm, u.d_ts, u.d_tg, u.d_tc, row, parts, P.fb_table.p, P.fb_geo, u.d_part, 1u);
@@ -434,10 +478,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         }
         fb_mark(sm);
         to_lane(q);
-        if (ct && j == rounds) {  // the secret scalars of A1 and B over the two folded generators just made and the Pedersen bases
-          hipLaunchKernelGGL(k_ct_msm, dim3(2 * nb), b64, 0, s, u.d_fts, u.d_ftg, u.d_ftc, CT_ROW, P.table.p, u.d_ge, u.d_ge_ct);
-          hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge_ct, 2 * nb, out);
-        } else if (j == rounds) {  // A1 = A1g + A1h and B
+        if (j == rounds) {  // A1 = A1g + A1h and B
           hipLaunchKernelGGL(kp_final_points, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, nb, out);
         } else if (!fused) {
           hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, 2 * nb, out);
@@ -461,7 +502,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     // bytes and their page-locked staging) are wiped NOW, behind the events that say the staging has been read -- not after the
     // call's last kernel, where three megabytes of explicit_bzero were 0.2 ms on the caller's clock.
     const bool nap = ctx->opt.wait >= 0 ? ctx->opt.wait != 0 : n_items >= 256;  // (a call of a few proofs is a latency chain: the runtime's spinning wait)
-    for (uint32_t q = 0; q < n_sub; q++) gpu_wait_event(ctx->prove_aux_events[2 * q], nap);
+    for (uint32_t q = 0; q < n_sub; q++) gpu_wait_event(ctx->prove_aux_events[4 * q], nap);
     wipe(bytes.data(), bytes.size());
     wipe(ctx->prove_pin_in.p, ctx->prove_pin_in.n);
     staging_clean = true;

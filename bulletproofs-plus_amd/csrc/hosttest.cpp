@@ -58,6 +58,15 @@ int ht_ct_fixed_scalarmul(const uint8_t point32[32], const uint8_t scalar32[32],
   if (trace_len) *trace_len = tr.size();
   if (trace_out) memcpy(trace_out, tr.data(), tr.size() < trace_cap ? tr.size() : trace_cap);
   return 1; }
+// the digit-parallel form over the multiples 16^w P of a point known ahead of its scalar (k_ct_pow16 + k_ct_var's per-lane steps,
+// all 64 positions on one lane): no table at all -- every position walks 1 .. 8 times its multiple and keeps one under a mask
+int ht_ct_var_scalarmul(const uint8_t point32[32], const uint8_t scalar32[32], uint8_t out32[32]) {
+  niels n; if (!ristretto_decompress(n, point32)) return 0;
+  ge p; ge_from_niels(p, n);
+  sc s; sc_load_words(s, scalar32);
+  ge r; ct_var_scalarmul(r, p, s);
+  ristretto_compress(out32, r);
+  return 1; }
 // the recoding alone: 64 signed radix-16 digits whose weighted sum is the scalar
 void ht_ct_recode16(const uint8_t scalar32[32], int8_t digits[64]) { sc s; sc_load_words(s, scalar32); ct_recode16(digits, s); }
 void ht_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe x, y, z; fe_frombytes(x, a); fe_frombytes(y, b); fe_mul(z, x, y); fe_tobytes(out, z); }

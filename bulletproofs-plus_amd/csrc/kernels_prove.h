@@ -21,6 +21,15 @@
 
 namespace bpp {
 
+// The LDS of a prover kernel holds witness-keyed generator states, raw draws and partial sums: nothing of it is left for the next
+// workgroup on the CU (the reference wraps the same values in Zeroizing<>, src/range_proof.rs:300-301,438-464,542-570).  Called by
+// every thread of the workgroup as the kernel's last statement.
+template <class T>
+__device__ __forceinline__ void lds_wipe(T &obj) {
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < sizeof(T) / 4; k += blockDim.x) ((uint32_t *)&obj)[k] = 0;
+}
+
 // Phase clocks of the prover's round kernel (a measurement build only: -DBPP_KP_PHASES, tools/gpu_kp_phases.sh): lane 0 of every
 // workgroup adds the shader-clock cycles of each phase of kp_round to a device-global table that bpp_debug_kp_phases() reads.
 // The product build compiles none of it.
@@ -271,6 +280,7 @@ __global__ void __launch_bounds__(64) k_fb_part(const sc *__restrict__ scal, con
     if (cd != 0) ge_madd_swapped(acc, acc, cur, cd < 0);
   }
   partial[(size_t)blockIdx.x * 64u + lane] = acc;
+  lds_wipe(st);  // (the digits of witness-derived scalars)
 }
 // out[o] = sum of output o's parts x 64 partial sums: one wavefront per output
 __global__ void __launch_bounds__(64) k_fb_sum(const ge *__restrict__ partial, uint32_t parts, ge *__restrict__ out) {
@@ -292,6 +302,7 @@ __global__ void __launch_bounds__(64) k_fb_sum(const ge *__restrict__ partial, u
     __syncthreads();
   }
   if (lane == 0) out[o] = red[0];
+  lds_wipe(red);
 }
 // Outputs 2p and 2p + 1 (a proof's L and R) summed side by side by ONE wavefront: lanes 0..31 take the first, lanes 32..63 the
 // second; a lane adds the 2 x parts partial sums of its two columns, then five levels through LDS inside each half.  The sums end
@@ -535,6 +546,7 @@ __global__ void __launch_bounds__(64) kp_init(const uint8_t *__restrict__ bytes,
     pw_nonces_or_randoms(st.alpha, t, rng, L, K, bytes + d.seed_off, true, "alpha", 5, -1);
   }
   ws_store(st.tr, tr);
+  lds_wipe(L);
 }
 
 // ---- A = sum_{bit=1} G_i - sum_{bit=0} H_i + sum_k alpha_k G_k  (:300-345), one wavefront per proof ----
@@ -876,7 +888,8 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
                                              uint32_t stride, ProveState *ps, sc *__restrict__ vec,
                                              sc *__restrict__ term_scal, uint32_t *__restrict__ term_gidx,
                                              uint32_t *__restrict__ term_count, sc *__restrict__ ct_scal,
-                                             uint32_t *__restrict__ ct_idx, uint32_t *__restrict__ ct_count, sc *red /* LDS, blockDim.x */) {
+                                             uint32_t *__restrict__ ct_idx, uint32_t *__restrict__ ct_count, sc *__restrict__ ex_scal,
+                                             uint32_t *__restrict__ ex_gidx, uint32_t *__restrict__ ex_count, sc *red /* LDS, blockDim.x */) {
   // (`lane` = the thread's index in the workgroup, nthr = 64, 128 or 256 threads: every loop below strides by nthr)
   const uint32_t p = blockIdx.x, lane = threadIdx.x, nthr = blockDim.x;
   const ProveDesc d = desc[p];
@@ -1073,23 +1086,38 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       term_count[2 * p] = mn + t + 1;
       term_count[2 * p + 1] = mn + t + 1;
     }
+    if (ex_scal && j + 1 == rounds) {
+      // "ct" = 2, last round: the folded generators of the final step are Gf[0] = e^-1 GE + (e y^-1) GO and Hf[0] = e HE + e^-1 HO
+      // with GE / GO (HE / HO) the sums of cG[u] G_u (cH[u] H_u) over the even / odd u as they stand NOW, before this round's
+      // challenge exists: four PUBLIC points per proof, four more outputs of this round's fixed-base MSM (mn / 2 terms each).
+      // Their multiples by 16^w are made while the next step runs (ct.h: k_ct_pow16), so that the secret scalars r e^-1,
+      // r e y^-1, s e, s e^-1 find everything they need when they exist (k_ct_var).
+      const uint32_t hn = mn >> 1;
+      sc *es = ex_scal + (size_t)p * 4 * hn;
+      uint32_t *eg = ex_gidx + (size_t)p * 4 * hn;
+      for (uint32_t u = lane; u < mn; u += nthr) {
+        const uint32_t odd = u & 1u, r2 = u >> 1;
+        es[odd * hn + r2] = cG[u];  // (Montgomery form, as every fixed-base term list)
+        eg[odd * hn + r2] = 2 * u;
+        es[(2 + odd) * hn + r2] = cH[u];
+        eg[(2 + odd) * hn + r2] = 2 * u + 1;
+      }
+      if (lane < 4) ex_count[4 * p + lane] = hn;
+    }
     KP_MARK(11);
   } else {
     // final step (:574-584): A1 = r Gf[0] + s Hf[0] + (r y b + s y a) H + sum d_k G_k ;  B = (r y s) H + sum eta_k G_k
     const sc r = st.r, s = st.s, y = st.y;
     if (ct_scal) {
       // The reference multiplies by r, s, d_k, eta_k and the H scalars in constant time (`&P * Scalar`, :574-584): every scalar of
-      // A1 and B is a secret.  Here the fixed-base MSM gets PUBLIC scalars only -- Gf[0] = sum cG[u] G_u (output 0) and
-      // Hf[0] = sum cH[u] H_u (output 1), the folded generators, functions of the challenges -- and the secret scalars go to the
-      // uniform-access form (ct.h: k_ct_msm) as two short term rows per proof over those two points and the Pedersen bases:
-      //   A1: r Gf[0], s Hf[0], (r y b + s y a) H, d_k G_k      B: (r y s) H, eta_k G_k
-      for (uint32_t u = lane; u < mn; u += nthr) {
-        const sc sg = cG[u], sh = cH[u];  // (Montgomery form, as every fixed-base term list)
-        ts[u] = sg;
-        tg[u] = 2 * u;
-        ts[stride + u] = sh;
-        tg[stride + u] = 2 * u + 1;
-      }
+      // A1 and B is a secret.  None of them reaches a fixed-base table here (whose addresses would be their digits):
+      //   row 2p   (k_ct_fixed):  (r y b + s y a) H, d_k G_k      -> A1's part over the Pedersen bases
+      //   row 2p+1 (k_ct_fixed):  (r y s) H, eta_k G_k            -> B
+      //   row 2p, words 8..11 (k_ct_var): r e^-1, r e y^-1, s e, s e^-1 over GE, GO, HE, HO of the previous step (see there)
+      // and this step has no fixed-base MSM at all.
+      const sc e = st.e, einv = st.einv;
+      sc e_yinv;
+      sc_montmul(e_yinv, e, st.yinv_prev);
       sc *fs = ct_scal + (size_t)p * 2 * CT_ROW;
       uint32_t *fi = ct_idx + (size_t)p * 2 * CT_ROW;
       if (lane <= t) {
@@ -1109,23 +1137,26 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
         }
         sc_from_mont(s1v, s1v);
         sc_from_mont(s2v, s2v);
-        // lane t carries the H terms (rows' positions 2 and 0), lanes k < t the G_k terms
-        const uint32_t pa = lane < t ? 3 + lane : 2, pb = lane < t ? 1 + lane : 0;
-        fs[pa] = s1v;
-        fi[pa] = n_gen + lane;
-        fs[CT_ROW + pb] = s2v;
-        fi[CT_ROW + pb] = n_gen + lane;
+        // lane t carries the H terms (position 0 of either row), lanes k < t the G_k terms
+        const uint32_t pos = lane < t ? 1 + lane : 0;
+        fs[pos] = s1v;
+        fi[pos] = n_gen + lane;
+        fs[CT_ROW + pos] = s2v;
+        fi[CT_ROW + pos] = n_gen + lane;
       }
-      if (lane < 2) {
-        sc v = lane ? s : r;
+      if (lane < 4) {  // (word-wise selects between the operands: a choice between locals' ADDRESSES would put them into scratch memory)
+        sc v, f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          v.v[q] = lane < 2 ? r.v[q] : s.v[q];
+          f.v[q] = lane == 0 ? einv.v[q] : lane == 1 ? e_yinv.v[q] : lane == 2 ? e.v[q] : einv.v[q];
+        }
+        sc_montmul(v, v, f);
         sc_from_mont(v, v);
-        fs[lane] = v;
-        fi[lane] = BPP_CT_DYN | (2 * p + lane);  // this proof's Gf[0] / Hf[0] among the fixed-base MSM's outputs
+        fs[8 + lane] = v;
       }
       if (lane == 0) {
-        term_count[2 * p] = mn;
-        term_count[2 * p + 1] = mn;
-        ct_count[2 * p] = 3 + t;
+        ct_count[2 * p] = 1 + t;
         ct_count[2 * p + 1] = 1 + t;
       }
       KP_MARK(12);
@@ -1184,16 +1215,19 @@ __global__ void __launch_bounds__(64) kp_lane(const uint8_t *__restrict__ bytes,
                                               const uint8_t *lr32, ProveState *ps) {
   __shared__ ProveLds L;
   kp_lane_body(bytes, desc, n_bits, t, B, j, rounds, a32, lr32, ps, L);
+  lds_wipe(L);
 }
 __global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes, const ProveDesc *__restrict__ desc,
                                               const uint64_t *__restrict__ minvals, const uint8_t *__restrict__ min_present, uint32_t n_bits,
                                               uint32_t t, uint32_t n_gen, uint32_t j, uint32_t rounds, uint32_t stride, ProveState *ps,
                                               sc *__restrict__ vec, sc *__restrict__ term_scal, uint32_t *__restrict__ term_gidx,
                                               uint32_t *__restrict__ term_count, sc *__restrict__ ct_scal, uint32_t *__restrict__ ct_idx,
-                                              uint32_t *__restrict__ ct_count) {
+                                              uint32_t *__restrict__ ct_count, sc *__restrict__ ex_scal, uint32_t *__restrict__ ex_gidx,
+                                              uint32_t *__restrict__ ex_count) {
   __shared__ sc red[64];
   kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count, ct_scal,
-               ct_idx, ct_count, red);
+               ct_idx, ct_count, ex_scal, ex_gidx, ex_count, red);
+  lds_wipe(red);
 }
 // ... and as ONE launch per round (round 4): the encoding of the previous round's L and R (two lanes, ristretto_compress), the
 // Fiat-Shamir step and the vector step of a proof are consecutive phases of the same 64-lane workgroup.  As three launches per
@@ -1208,7 +1242,8 @@ __global__ void __launch_bounds__(64 * W) kp_round(const uint8_t *__restrict__ b
                                                const uint8_t *__restrict__ a32, const ge *__restrict__ ge_prev, uint32_t prev_parts,
                                                uint8_t *lr_prev, ProveState *ps, sc *__restrict__ vec, sc *__restrict__ term_scal,
                                                uint32_t *__restrict__ term_gidx, uint32_t *__restrict__ term_count,
-                                               sc *__restrict__ ct_scal, uint32_t *__restrict__ ct_idx, uint32_t *__restrict__ ct_count) {
+                                               sc *__restrict__ ct_scal, uint32_t *__restrict__ ct_idx, uint32_t *__restrict__ ct_count,
+                                               sc *__restrict__ ex_scal, uint32_t *__restrict__ ex_gidx, uint32_t *__restrict__ ex_count) {
   // blockDim.x = 64 x (1, 2 or 4) wavefronts per proof (option "prove_waves").  With two or more: L and R are summed and encoded
   // on a wavefront each, the Fiat-Shamir step runs its two halves side by side (kp_lane_body2), the vector step strides by the
   // whole workgroup.  One wavefront: the same three phases in a row (the form of round 4; tests run every form).
@@ -1263,7 +1298,8 @@ __global__ void __launch_bounds__(64 * W) kp_round(const uint8_t *__restrict__ b
     __syncthreads();
   }
   kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count, ct_scal,
-               ct_idx, ct_count, sh.red_sc);
+               ct_idx, ct_count, ex_scal, ex_gidx, ex_count, sh.red_sc);
+  lds_wipe(sh);
 }
 
 // ---- final lane kernel: challenge_final_e, responses, wire bytes (:587-607, to_bytes :1120-1150) ----
@@ -1320,6 +1356,7 @@ __global__ void __launch_bounds__(64) kp_finish(const ProveDesc *__restrict__ de
   uint8_t *olr = o + 1 + 32 * t + 96 + 64;
   for (uint32_t i = lane; i < 64 * rounds; i += 64) olr[i] = lr_all[((size_t)(i >> 6) * B + p) * 64 + (i & 63u)];
   if (!ok && lane == 0) st.status |= PV_STATUS_TRANSCRIPT;
+  lds_wipe(L);
 }
 
 // the last launch's three outputs per proof (kp_wave_body, final step) -> the encodings of A1 = A1g + A1h and of B, a1b32[p][2][32]

@@ -63,7 +63,12 @@ class ShardComm:
     @classmethod
     def from_process_group_gloo(cls, engine, group=None):
         """the caller-supplied transport over torch.distributed's CPU backend: what lets several ranks share ONE GPU (RCCL refuses
-        two ranks on a device) and what a caller without RCCL uses"""
+        two ranks on a device) and what a caller without RCCL uses.  COLLECTIVE when `group` is None: every communicator gets a
+        process group of its OWN (dist.new_group over all ranks), so that several communicators driven from several threads never
+        share one: their all_gathers have identical shapes, and on a shared group two of them issued in different orders on
+        different ranks would pair up crosswise -- wrong bytes, or a hang -- without any error."""
+        if group is None:
+            group = dist.new_group(backend="gloo")
         rank, world = dist.get_rank(group), dist.get_world_size(group)
 
         def all_gather(send):

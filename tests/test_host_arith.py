@@ -313,3 +313,11 @@ def test_uniform_access_scalar_multiplication(ht):
         assert out.raw == (pt * k).compress(), k
         traces.add(tr.raw[:n.value])
     assert traces == {bytes(range(8)) * 64}, "a table read depends on the scalar"
+    # the digit-parallel form of A1's two folded generators (ct_pos_multiple: no table, all eight multiples of every position
+    # computed, one kept under a mask): the same products
+    ht.ht_ct_var_scalarmul.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    for i, k in enumerate(scalars):
+        pt = C.from_uniform_bytes(_r(b"ctv", i % 4, 64))
+        out = _buf()
+        assert ht.ht_ct_var_scalarmul(pt.compress(), k.to_bytes(32, "little"), out) == 1
+        assert out.raw == (pt * k).compress(), k

@@ -34,9 +34,11 @@ rm -rf $O/prov_pmc
 BPP_PROVE_SUBS=1 PROVER_ITERS=3 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/prov_pmc -- python3 tools/bench_prover_leg.py > /dev/null 2>> $O/${TAG}_bench.err
 python3 tools/pmc_summary.py counters $O/prov_pmc $O/${TAG}_prover_kernels_serial.csv
 rm -rf $O/prov_pmc
-test -f gpurun_in/kp_phases.so && timeout -k 10 200 bash tools/gpu_kp_phases.sh $O/${TAG}_kp_phases.json > /dev/null 2>> $O/${TAG}_bench.err
 # the multi-rank code as two PROCESSES on this one GPU (gloo transport through bpp_comm_create_callbacks)
 BPP_BENCH_ONE_DEVICE=1 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-traffic > $O/${TAG}_bench_two_ranks_one_gpu.json 2>> $O/${TAG}_bench.err
 timeout -k 10 300 python3 tools/bench_latency.py > $O/${TAG}_bench_latency.jsonl 2>> $O/${TAG}_bench.err
 BPP_MSM_SPLIT=0 timeout -k 10 300 python3 tools/bench_latency.py --no-cpu > $O/${TAG}_bench_latency_nosplit.jsonl 2>> $O/${TAG}_bench.err
+# last: the round kernel's phase clocks from a measurement build (its own file, loaded through BPP_LIB_PATH: nothing above or
+# after it can pick it up by accident)
+test -f gpurun_in/kp_phases.so && timeout -k 10 200 bash tools/gpu_kp_phases.sh $O/${TAG}_kp_phases.json > /dev/null 2>> $O/${TAG}_bench.err
 echo "final_round $TAG done"

@@ -1,13 +1,18 @@
 #!/bin/bash
-# phase clocks of the prover's round kernel: gpurun_in/kp_phases.so = engine.hip built with -DBPP_KP_PHASES (built HERE if missing)
+# phase clocks of the prover's round kernel from a MEASUREMENT build of the library: gpurun_in/kp_phases.so = engine.hip with
+# -DBPP_KP_PHASES and the product build's flags, rebuilt HERE whenever it is older than any source.  The product's libbpp_hip.so is
+# never touched: tools/kp_phases.py loads the measurement build through BPP_LIB_PATH (bulletproofs-plus_amd/_lib.py).
 set -e
 out=${1:-gpurun_out/kp_phases.json}
-if [ ! -f gpurun_in/kp_phases.so ]; then
-  mkdir -p gpurun_in
-  (cd bulletproofs-plus_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DBPP_KP_PHASES -o ../../gpurun_in/kp_phases.so engine.hip)
+so=gpurun_in/kp_phases.so
+stale=0
+[ -f $so ] || stale=1
+if [ $stale = 0 ]; then
+  for f in bulletproofs-plus_amd/csrc/* include/bpp.h; do [ "$f" -nt $so ] && stale=1; done
 fi
-cp bulletproofs-plus_amd/libbpp_hip.so /tmp/libbpp_saved.so
-cp gpurun_in/kp_phases.so bulletproofs-plus_amd/libbpp_hip.so; touch bulletproofs-plus_amd/libbpp_hip.so
-python3 tools/kp_phases.py > $out || true
-cp /tmp/libbpp_saved.so bulletproofs-plus_amd/libbpp_hip.so; touch bulletproofs-plus_amd/libbpp_hip.so
+if [ $stale = 1 ]; then
+  mkdir -p gpurun_in
+  (cd bulletproofs-plus_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC $BPP_HIPCC_FLAGS -DBPP_KP_PHASES -o ../../$so engine.hip)
+fi
+BPP_LIB_PATH=$so python3 tools/kp_phases.py > $out
 cat $out

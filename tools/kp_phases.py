@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a prover round's serial kernel spends its cycles: runs configs[4]'s prove call on a library built with -DBPP_KP_PHASES
-(tools/gpu_kp_phases.sh swaps it in) and prints the shader-clock cycles per phase of kp_round, per proof and call."""
+(tools/gpu_kp_phases.sh builds it as gpurun_in/kp_phases.so and names it in BPP_LIB_PATH) and prints the shader-clock cycles per phase of kp_round, per proof and call."""
 import ctypes
 import importlib
 import json
