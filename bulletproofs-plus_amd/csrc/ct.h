@@ -272,44 +272,50 @@ __global__ void __launch_bounds__(64) k_ct_pow16(const ge *__restrict__ pts, uin
   }
 }
 
-// A1[p] += sum_{v < 4} scal[p][v] * pts[4 p + v], the points given as their multiples pow[4 p + v][w] = 16^w pts[4 p + v]
-// (k_ct_pow16): one workgroup of 256 lanes per proof, wavefront v owns term v, its lane w digit position w (ct_pos_multiple).
-// scal: row p at scal + p * row_stride + row_off, four canonical scalars.  acc[acc_stride * p] is read and written.
-#define CTV_TERMS 4
+// prod[p * nt + v] = scal(p, v) * pts[p * nt + v], the points given as their multiples pow[p * nt + v][w] = 16^w pts[..]
+// (k_ct_pow16): one wavefront per term, lane w owns digit position w (ct_pos_multiple), a six-level tree at the end.
+// scal(p, v): rows of `row_stride` scalars per proof, term v at word 8 + (v & 7) of row v >> 3 (the prover's final-step rows).
 struct CtVarShared {
-  int8_t dig[CTV_TERMS][BPP_CT_DIGITS];
-  ge red[CTV_TERMS * 64];
+  int8_t dig[BPP_CT_DIGITS];
+  ge red[64];
 };
-__global__ void __launch_bounds__(64 * CTV_TERMS) k_ct_var(const ge *__restrict__ pow, const sc *__restrict__ scal, uint32_t row_stride,
-                                                           uint32_t row_off, ge *__restrict__ acc, uint32_t acc_stride) {
-  const uint32_t p = blockIdx.x, tid = threadIdx.x, v = tid >> 6, w = tid & 63u;
+__global__ void __launch_bounds__(64) k_ct_var(const ge *__restrict__ pow, const sc *__restrict__ scal, uint32_t row_stride, uint32_t nt,
+                                               ge *__restrict__ prod) {
+  const uint32_t p = blockIdx.x / nt, v = blockIdx.x - p * nt, w = threadIdx.x;
   __shared__ CtVarShared sh;
   if (w == 0) {
-    const sc s = scal[(size_t)p * row_stride + row_off + v];
-    ct_recode16(sh.dig[v], s);
+    const sc s = scal[((size_t)2 * p + (v >> 3)) * row_stride + 8u + (v & 7u)];
+    ct_recode16(sh.dig, s);
   }
   __syncthreads();
-  const ge pw = pow[((size_t)p * CTV_TERMS + v) * BPP_CT_DIGITS + w];
+  const ge pw = pow[((size_t)p * nt + v) * BPP_CT_DIGITS + w];
   ge mine;
-  ct_pos_multiple(mine, pw, (int32_t)sh.dig[v][w]);
-  sh.red[tid] = mine;
+  ct_pos_multiple(mine, pw, (int32_t)sh.dig[w]);
+  sh.red[w] = mine;
   __syncthreads();
-  for (uint32_t off = 128; off >= 1; off >>= 1) {  // all 256 partial sums: the four terms add up to one point anyway
-    if (tid < off) {
-      ge x = sh.red[tid], y2 = sh.red[tid + off];
+  for (uint32_t off = 32; off >= 1; off >>= 1) {
+    if (w < off) {
+      ge x = sh.red[w], y2 = sh.red[w + off];
       ge_add(x, x, y2);
-      sh.red[tid] = x;
+      sh.red[w] = x;
     }
     __syncthreads();
   }
-  if (tid == 0) {
-    ge x = sh.red[0];
-    const ge y2 = acc[(size_t)acc_stride * p];
-    ge_add(x, x, y2);
-    acc[(size_t)acc_stride * p] = x;
-  }
+  if (w == 0) prod[(size_t)p * nt + v] = sh.red[0];
   __syncthreads();
-  for (uint32_t k = tid; k < sizeof(CtVarShared) / 4; k += 64 * CTV_TERMS) ((uint32_t *)&sh)[k] = 0;  // digits and partial sums are secret-derived
+  for (uint32_t k = w; k < sizeof(CtVarShared) / 4; k += 64) ((uint32_t *)&sh)[k] = 0;  // digits and partial sums are secret-derived
+}
+// acc[acc_stride * p] += sum_{v < nt} prod[p * nt + v]: one lane per proof (nt <= 16 additions in a row)
+__global__ void __launch_bounds__(64) k_ct_sum(const ge *__restrict__ prod, uint32_t nt, uint32_t n_proofs, ge *__restrict__ acc,
+                                               uint32_t acc_stride) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_proofs) return;
+  ge x = acc[(size_t)acc_stride * p];
+  for (uint32_t v = 0; v < nt; v++) {
+    const ge y2 = prod[(size_t)p * nt + v];
+    ge_add(x, x, y2);
+  }
+  acc[(size_t)acc_stride * p] = x;
 }
 
 #define CT_MAX_TERMS 16

@@ -559,7 +559,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1, prove_parts = -1, prove_waves = -1, prove_fifo = -1, chain = -1, chain_test_zero = 0, wait = -1;
+        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1, prove_parts = -1, prove_waves = -1, prove_fifo = -1, chain = -1, chain_test_zero = 0, wait = -1, ct_back = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -599,6 +599,8 @@ const OptionName kOptions[] = {
     {"prove_prio", "BPP_PROVE_PRIO", &bpp_ctx::Options::prove_prio},
     {"prove_fused", "BPP_PROVE_FUSED", &bpp_ctx::Options::prove_fused},
     {"ct", "BPP_CT", &bpp_ctx::Options::ct},
+    // "ct" = 2: how many rounds before the end the public points behind A1's folded generators are made (1..3; the engine's rule: 1)
+    {"ct_back", "BPP_CT_BACK", &bpp_ctx::Options::ct_back},
     {"prove_parts", "BPP_PROVE_PARTS", &bpp_ctx::Options::prove_parts},
     {"prove_waves", "BPP_PROVE_WAVES", &bpp_ctx::Options::prove_waves},
     {"prove_fifo", "BPP_PROVE_FIFO", &bpp_ctx::Options::prove_fifo},
@@ -667,10 +669,14 @@ inline void gpu_wait_event(hipEvent_t ev, bool nap) {
     HIP_CHECK(hipEventSynchronize(ev));
     return;
   }
+  // the first ~30 us by looking only: a wait for something that is (nearly) done must not cost a nap -- a nap is 60-100 us with
+  // the kernel's timer slack, and a prover call has six waits in a row at its end (0.6 ms of a 6.5 ms call before this)
+  const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     const hipError_t e = hipEventQuery(ev);
     if (e == hipSuccess) return;
     if (e != hipErrorNotReady) HIP_CHECK(e);
+    if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(30)) continue;
     struct timespec ts = {0, 50000};
     nanosleep(&ts, nullptr);
   }
@@ -689,6 +695,11 @@ inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap) {
   if (!nap) {
     HIP_CHECK(hipStreamSynchronize(s));
     return;
+  }
+  {  // nothing left on the stream: no marker, no nap
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return;
+    if (q != hipErrorNotReady) HIP_CHECK(q);
   }
   if (!ctx->ev_wait_ready) {
     HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_wait, hipEventDisableTiming));

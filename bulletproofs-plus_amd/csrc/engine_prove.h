@@ -250,7 +250,13 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       HIP_CHECK(hipStreamWaitEvent(lane_stream(q), ctx->prove_sync_events[2 * q + 1], 0));
     };
     const uint32_t stride = 2 * mn + t + 1;
-    const uint32_t ex_parts = cdiv(mn / 2, 128u);  // slices of <= 128 terms per public point of the last round ("ct" = 2)
+    // "ct" = 2: the public points behind A1's folded generators are made ex_back rounds before the end (kernels_prove.h): their
+    // fixed-base MSM, the slices' sums and the 252 doublings of their 16^w multiples then have ex_back rounds of time beside the
+    // call's own chain.  2^ex_back points per side and proof; ex_parts slices of <= 128 terms per point.  One round back is the
+    // rule ("ct_back" = 2, 3 for the A/B): earlier, the points' MSM doubles the load of a round whose own MSM the chain waits for,
+    // and the time the final step no longer spends in an MSM is not given back (profiles/r06_ct_back_ab.txt).
+    const uint32_t ex_back = std::min<uint32_t>(rounds, ctx->opt.ct_back > 0 ? std::min(3, ctx->opt.ct_back) : 1u);
+    const uint32_t ex_nc = 1u << ex_back, ex_nt = 2 * ex_nc, ex_terms = mn >> ex_back, ex_parts = cdiv(ex_terms, 128u);
     struct Sub {
       uint32_t lo, nb;
       size_t bytes_lo, bytes_len, arena_lo, arena_len;
@@ -266,7 +272,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       // and their multiples by 16^w
       sc *d_exs;
       uint32_t *d_exg, *d_exc;
-      ge *d_expart, *d_expts, *d_pow;
+      ge *d_expart, *d_expts, *d_pow, *d_ctprod;
     };
     std::vector<Sub> subs(n_sub);
     size_t arena_need = 0;
@@ -294,7 +300,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         u.d_minvals = (uint64_t *)take(nb * m * 8);
         u.d_desc = (ProveDesc *)take(nb * sizeof(ProveDesc));
         u.d_ps = (ProveState *)take(nb * sizeof(ProveState));
-        u.d_vec = (sc *)take(nb * (5 * (size_t)mn + 2) * sizeof(sc));
+        u.d_vec = (sc *)take(nb * (size_t)KP_VEC_LEN(mn) * sizeof(sc));
         u.d_ts = (sc *)take(nb * 2 * stride * sizeof(sc));
         u.d_tg = (uint32_t *)take(nb * 2 * stride * 4);
         u.d_tc = (uint32_t *)take(nb * 3 * 4);  // (three outputs per proof in the last launch)
@@ -314,10 +320,11 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         u.d_part = (ge *)take(parts ? (size_t)3 * nb * parts * 64 * sizeof(ge) : 16);
         u.d_exs = (sc *)take(ct ? nb * 2 * (size_t)mn * sizeof(sc) : 16);
         u.d_exg = (uint32_t *)take(ct ? nb * 2 * (size_t)mn * 4 : 16);
-        u.d_exc = (uint32_t *)take(nb * 4 * 4);
-        u.d_expart = (ge *)take(ct ? (size_t)4 * nb * ex_parts * 64 * sizeof(ge) : 16);
-        u.d_expts = (ge *)take(ct ? (size_t)4 * nb * sizeof(ge) : 16);
-        u.d_pow = (ge *)take(ct ? (size_t)4 * nb * BPP_CT_DIGITS * sizeof(ge) : 16);
+        u.d_exc = (uint32_t *)take(nb * ex_nt * 4);
+        u.d_expart = (ge *)take(ct ? (size_t)ex_nt * nb * ex_parts * 64 * sizeof(ge) : 16);
+        u.d_expts = (ge *)take(ct ? (size_t)ex_nt * nb * sizeof(ge) : 16);
+        u.d_pow = (ge *)take(ct ? (size_t)ex_nt * nb * BPP_CT_DIGITS * sizeof(ge) : 16);
+        u.d_ctprod = (ge *)take(ct ? (size_t)ex_nt * nb * sizeof(ge) : 16);
         u.arena_len = arena_need - u.arena_lo;
       }
     };
@@ -423,7 +430,7 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
           auto launch_round = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(nb), dim3(64 * kp_waves), 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, nb, j, rounds,
                                stride, u.d_a32, j ? (parts ? u.d_part : u.d_ge) : (const ge *)nullptr, parts, lr_prev, u.d_ps, u.d_vec, u.d_ts, u.d_tg,
-                               u.d_tc, ct ? u.d_fts : (sc *)nullptr, u.d_ftg, u.d_ftc, ct ? u.d_exs : (sc *)nullptr, u.d_exg, u.d_exc);
+                               u.d_tc, ct ? u.d_fts : (sc *)nullptr, u.d_ftg, u.d_ftc, ct ? u.d_exs : (sc *)nullptr, u.d_exg, u.d_exc, ex_back);
           };
           if (kp_waves == 1) launch_round(kp_round<1>);
           else if (kp_waves == 2) launch_round(kp_round<2>);
@@ -432,34 +439,20 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
           hipLaunchKernelGGL(kp_lane, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, n, t, nb, j, rounds, u.d_a32, lr_prev, u.d_ps);
           hipLaunchKernelGGL(kp_wave, dim3(nb), b64, 0, s, u.d_bytes, u.d_desc, u.d_minvals, u.d_minpres, n, t, n_gen, j, rounds,
                              stride, u.d_ps, u.d_vec, u.d_ts, u.d_tg, u.d_tc, ct ? u.d_fts : (sc *)nullptr, u.d_ftg, u.d_ftc,
-                             ct ? u.d_exs : (sc *)nullptr, u.d_exg, u.d_exc);
+                             ct ? u.d_exs : (sc *)nullptr, u.d_exg, u.d_exc, ex_back);
         }
         uint8_t *out = (j < rounds) ? u.d_lr + (size_t)j * nb * 64 : u.d_a1b;
         if (j == 0) {  // the witness check joins here: its verdict into the proof's status, its buffer free for the round's MSM
           HIP_CHECK(hipStreamWaitEvent(s, ctx->prove_aux_events[4 * q + 1], 0));
           hipLaunchKernelGGL(kp_check_commitments, dim3(cdiv(nb, 64)), b64, 0, s, u.d_bytes, u.d_desc, u.d_commit32, nb, u.d_ps);
         }
-        if (ct && j + 1 == rounds) {
-          // "ct" = 2: the last round's four public points per proof -- their fixed-base MSM (as much work as a round's L and R),
-          // the slices' sums and the 252 doublings that make their multiples by 16^w -- on the sub-batch's side stream, beside this
-          // round's L / R and the next step: nothing of it waits for a secret, and nothing secret waits for it before k_ct_var
-          hipStream_t sx = ctx->prove_aux_streams[q];
-          HIP_CHECK(hipEventRecord(ctx->prove_aux_events[4 * q + 2], s));
-          HIP_CHECK(hipStreamWaitEvent(sx, ctx->prove_aux_events[4 * q + 2], 0));
-          fb_mark(sx);
-          hipLaunchKernelGGL(k_fb_part, dim3(4 * nb * ex_parts), b64, 0, sx, u.d_exs, u.d_exg, u.d_exc, mn / 2, ex_parts, P.fb_table.p, P.fb_geo,
-                             u.d_expart, 1u);
-          fb_mark(sx);
-          hipLaunchKernelGGL(k_fb_sum, dim3(4 * nb), b64, 0, sx, u.d_expart, ex_parts, u.d_expts);
-          hipLaunchKernelGGL(k_ct_pow16, dim3(cdiv(4 * nb, 16)), b64, 0, sx, u.d_expts, 4 * nb, u.d_pow);
-          HIP_CHECK(hipEventRecord(ctx->prove_aux_events[4 * q + 3], sx));
-        }
         if (ct && j == rounds) {
           // the final step has no fixed-base MSM: the Pedersen-base terms of A1 and B through the uniform-access tables, A1's two
-          // folded generators as four digit-parallel products over the multiples made above (ct.h), the encodings
+          // folded generators as 2 x 2^ex_back digit-parallel products over the multiples made above (ct.h), the encodings
           hipLaunchKernelGGL(k_ct_fixed, dim3(2 * nb), b64, 0, s, u.d_fts, u.d_ftg, u.d_ftc, CT_ROW, n_gen, (const niels *)P.fb_ct.p, u.d_ge_ct);
           HIP_CHECK(hipStreamWaitEvent(s, ctx->prove_aux_events[4 * q + 3], 0));
-          hipLaunchKernelGGL(k_ct_var, dim3(nb), dim3(64 * CTV_TERMS), 0, s, u.d_pow, u.d_fts, 2 * CT_ROW, 8u, u.d_ge_ct, 2u);
+          hipLaunchKernelGGL(k_ct_var, dim3(nb * ex_nt), b64, 0, s, u.d_pow, u.d_fts, CT_ROW, ex_nt, u.d_ctprod);
+          hipLaunchKernelGGL(k_ct_sum, dim3(cdiv(nb, 64)), b64, 0, s, u.d_ctprod, ex_nt, nb, u.d_ge_ct, 2u);
           hipLaunchKernelGGL(k_compress_ge, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge_ct, 2 * nb, u.d_a1b);
           continue;
         }
@@ -478,6 +471,27 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
         }
         fb_mark(sm);
         to_lane(q);
+        if (ct && j + ex_back == rounds) {
+          // "ct" = 2: the public points behind the final step's folded generators -- their fixed-base MSM (as much work as a round's L
+          // and R), the slices' sums and the 252 doublings that make their multiples by 16^w -- on the sub-batch's side stream,
+          // beside the remaining rounds: nothing of it waits for a secret, and nothing secret waits for it before k_ct_var.  Enqueued
+          // BEHIND this round's own MSM (the event is recorded after its launch): side by side, the two would share the chip and the
+          // round's L and R -- which the chain waits for -- would arrive late by as much as the points' MSM takes (measured: + 0.6 ms
+          // per call); behind it, the points' MSM fills the chip while this sub-batch's next step is a lone round kernel, the slot the
+          // final step's MSM has without "ct" = 2
+          hipStream_t sx = ctx->prove_aux_streams[q];  // (no stream of its own: with several calls in flight every further stream per
+                                                       // call is one more tenant of the runtime's hardware queues -- measured: 4 calls x 6
+                                                       // streams fall to half the rate of 4 x 4, profiles/r06_ct_inflight.jsonl)
+          HIP_CHECK(hipEventRecord(ctx->prove_aux_events[4 * q + 2], sm));
+          HIP_CHECK(hipStreamWaitEvent(sx, ctx->prove_aux_events[4 * q + 2], 0));
+          fb_mark(sx);
+          hipLaunchKernelGGL(k_fb_part, dim3(ex_nt * nb * ex_parts), b64, 0, sx, u.d_exs, u.d_exg, u.d_exc, ex_terms, ex_parts, P.fb_table.p,
+                             P.fb_geo, u.d_expart, 1u);
+          fb_mark(sx);
+          hipLaunchKernelGGL(k_fb_sum, dim3(ex_nt * nb), b64, 0, sx, u.d_expart, ex_parts, u.d_expts);
+          hipLaunchKernelGGL(k_ct_pow16, dim3(cdiv(ex_nt * nb, 16)), b64, 0, sx, u.d_expts, ex_nt * nb, u.d_pow);
+          HIP_CHECK(hipEventRecord(ctx->prove_aux_events[4 * q + 3], sx));
+        }
         if (j == rounds) {  // A1 = A1g + A1h and B
           hipLaunchKernelGGL(kp_final_points, dim3(cdiv(2 * nb, 64)), b64, 0, s, u.d_ge, nb, out);
         } else if (!fused) {

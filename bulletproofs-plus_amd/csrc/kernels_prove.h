@@ -356,6 +356,10 @@ __device__ __forceinline__ void fb_reduce_one(ge *red /* LDS, this wavefront's 6
 }
 
 #define CT_ROW 16u
+// scalars per proof in the round kernels' vector buffer: a, b, cG, cH (mn each), y^0 .. y^(mn+1), and ("ct" = 2) the factors the
+// final step's folded generators take over the public points of step rounds - back: fG[c], fH[c], c < 2^back <= KP_EX_CLASSES
+#define KP_EX_CLASSES 8u
+#define KP_VEC_LEN(mn) (5u * (mn) + 2u + 2u * KP_EX_CLASSES)
 #define KP_MAX_THREADS 256u  // the round kernel's workgroup: 1, 2 or 4 wavefronts (option "prove_waves")  // terms per row of the final round's secret-only term lists (3 + t <= 9 used)
 
 // ---------------------------------------------------------------- per-proof prover state
@@ -889,13 +893,15 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
                                              sc *__restrict__ term_scal, uint32_t *__restrict__ term_gidx,
                                              uint32_t *__restrict__ term_count, sc *__restrict__ ct_scal,
                                              uint32_t *__restrict__ ct_idx, uint32_t *__restrict__ ct_count, sc *__restrict__ ex_scal,
-                                             uint32_t *__restrict__ ex_gidx, uint32_t *__restrict__ ex_count, sc *red /* LDS, blockDim.x */) {
+                                             uint32_t *__restrict__ ex_gidx, uint32_t *__restrict__ ex_count, uint32_t ex_back,
+                                             sc *red /* LDS, blockDim.x */) {
   // (`lane` = the thread's index in the workgroup, nthr = 64, 128 or 256 threads: every loop below strides by nthr)
   const uint32_t p = blockIdx.x, lane = threadIdx.x, nthr = blockDim.x;
   const ProveDesc d = desc[p];
   ProveState &st = ps[p];
   const uint32_t mn = d.m * n_bits;
-  sc *a = vec + (size_t)p * (5 * mn + 2), *b = a + mn, *cG = b + mn, *cH = cG + mn, *ypow = cH + mn;
+  sc *a = vec + (size_t)p * KP_VEC_LEN(mn), *b = a + mn, *cG = b + mn, *cH = cG + mn, *ypow = cH + mn;
+  sc *fG = ypow + mn + 2, *fH = fG + KP_EX_CLASSES;  // ("ct" = 2, see below)
   sc one;
   sc_mont_one(one);
   KP_T0();
@@ -997,6 +1003,15 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       sc_montmul(h, h, fh);
       cG[u] = g;
       cH[u] = h;
+      // "ct" = 2: the same factors, from step rounds - ex_back on, for the classes u < 2^ex_back alone: what Gf[0] / Hf[0] take
+      // over the public points made at that step (below)
+      if (ex_scal && j + ex_back > rounds && u < (1u << ex_back)) {
+        sc x = fG[u], y2 = fH[u];
+        sc_montmul(x, x, fg);
+        sc_montmul(y2, y2, fh);
+        fG[u] = x;
+        fH[u] = y2;
+      }
     }
     KP_MARK(9);
   }
@@ -1086,23 +1101,29 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       term_count[2 * p] = mn + t + 1;
       term_count[2 * p + 1] = mn + t + 1;
     }
-    if (ex_scal && j + 1 == rounds) {
-      // "ct" = 2, last round: the folded generators of the final step are Gf[0] = e^-1 GE + (e y^-1) GO and Hf[0] = e HE + e^-1 HO
-      // with GE / GO (HE / HO) the sums of cG[u] G_u (cH[u] H_u) over the even / odd u as they stand NOW, before this round's
-      // challenge exists: four PUBLIC points per proof, four more outputs of this round's fixed-base MSM (mn / 2 terms each).
-      // Their multiples by 16^w are made while the next step runs (ct.h: k_ct_pow16), so that the secret scalars r e^-1,
-      // r e y^-1, s e, s e^-1 find everything they need when they exist (k_ct_var).
-      const uint32_t hn = mn >> 1;
-      sc *es = ex_scal + (size_t)p * 4 * hn;
-      uint32_t *eg = ex_gidx + (size_t)p * 4 * hn;
+    if (ex_scal && j + ex_back == rounds) {
+      // "ct" = 2, ex_back rounds before the end (the vectors have 2^ex_back elements left): the folded generators of the final step
+      // are Gf[0] = sum_c fG[c] GE_c and Hf[0] = sum_c fH[c] HE_c over the classes c = u mod 2^ex_back, with GE_c (HE_c) the sum of
+      // cG[u] G_u (cH[u] H_u) over the class as the coefficients stand NOW -- PUBLIC points, functions of the challenges so far --
+      // and fG[c], fH[c] the products of the remaining rounds' fold factors (updated beside cG / cH above).  The 2 x 2^ex_back
+      // points are more outputs of this round's fixed-base MSM (mn / 2^ex_back terms each: as much work as a round's L and R);
+      // their multiples by 16^w are made while the remaining rounds run (ct.h: k_ct_pow16), so that the secret scalars r fG[c],
+      // s fH[c] find everything they need when they exist (k_ct_var).
+      const uint32_t nc = 1u << ex_back, hn = mn >> ex_back;
+      sc *es = ex_scal + (size_t)p * 2 * mn;
+      uint32_t *eg = ex_gidx + (size_t)p * 2 * mn;
       for (uint32_t u = lane; u < mn; u += nthr) {
-        const uint32_t odd = u & 1u, r2 = u >> 1;
-        es[odd * hn + r2] = cG[u];  // (Montgomery form, as every fixed-base term list)
-        eg[odd * hn + r2] = 2 * u;
-        es[(2 + odd) * hn + r2] = cH[u];
-        eg[(2 + odd) * hn + r2] = 2 * u + 1;
+        const uint32_t c = u & (nc - 1), r2 = u >> ex_back;
+        es[c * hn + r2] = cG[u];  // (Montgomery form, as every fixed-base term list)
+        eg[c * hn + r2] = 2 * u;
+        es[(nc + c) * hn + r2] = cH[u];
+        eg[(nc + c) * hn + r2] = 2 * u + 1;
       }
-      if (lane < 4) ex_count[4 * p + lane] = hn;
+      if (lane < 2 * nc) ex_count[2 * nc * p + lane] = hn;
+      if (lane < nc) {
+        fG[lane] = one;
+        fH[lane] = one;
+      }
     }
     KP_MARK(11);
   } else {
@@ -1113,11 +1134,9 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
       // A1 and B is a secret.  None of them reaches a fixed-base table here (whose addresses would be their digits):
       //   row 2p   (k_ct_fixed):  (r y b + s y a) H, d_k G_k      -> A1's part over the Pedersen bases
       //   row 2p+1 (k_ct_fixed):  (r y s) H, eta_k G_k            -> B
-      //   row 2p, words 8..11 (k_ct_var): r e^-1, r e y^-1, s e, s e^-1 over GE, GO, HE, HO of the previous step (see there)
+      //   words 8..15 of row 2p, then of row 2p+1 (k_ct_var): r fG[c], then s fH[c], over the public points GE_c, HE_c of step
+      //   rounds - ex_back (see there)
       // and this step has no fixed-base MSM at all.
-      const sc e = st.e, einv = st.einv;
-      sc e_yinv;
-      sc_montmul(e_yinv, e, st.yinv_prev);
       sc *fs = ct_scal + (size_t)p * 2 * CT_ROW;
       uint32_t *fi = ct_idx + (size_t)p * 2 * CT_ROW;
       if (lane <= t) {
@@ -1144,16 +1163,17 @@ __device__ __forceinline__ void kp_wave_body(const uint8_t *__restrict__ bytes, 
         fs[CT_ROW + pos] = s2v;
         fi[CT_ROW + pos] = n_gen + lane;
       }
-      if (lane < 4) {  // (word-wise selects between the operands: a choice between locals' ADDRESSES would put them into scratch memory)
-        sc v, f;
+      {  // the secret factors of the public points: r fG[c] and s fH[c], 2^ex_back each, eight slots from word 8 of either row
+        const uint32_t nc = 1u << ex_back;
+        if (lane < 2 * nc) {
+          const bool hside = lane >= nc;
+          sc v, f = hside ? fH[lane - nc] : fG[lane];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          v.v[q] = lane < 2 ? r.v[q] : s.v[q];
-          f.v[q] = lane == 0 ? einv.v[q] : lane == 1 ? e_yinv.v[q] : lane == 2 ? e.v[q] : einv.v[q];
+          for (int q = 0; q < 8; q++) v.v[q] = hside ? s.v[q] : r.v[q];  // (word-wise: no addresses of locals)
+          sc_montmul(v, v, f);
+          sc_from_mont(v, v);
+          fs[(lane >> 3) * CT_ROW + 8 + (lane & 7u)] = v;
         }
-        sc_montmul(v, v, f);
-        sc_from_mont(v, v);
-        fs[8 + lane] = v;
       }
       if (lane == 0) {
         ct_count[2 * p] = 1 + t;
@@ -1223,10 +1243,10 @@ __global__ void __launch_bounds__(64) kp_wave(const uint8_t *__restrict__ bytes,
                                               sc *__restrict__ vec, sc *__restrict__ term_scal, uint32_t *__restrict__ term_gidx,
                                               uint32_t *__restrict__ term_count, sc *__restrict__ ct_scal, uint32_t *__restrict__ ct_idx,
                                               uint32_t *__restrict__ ct_count, sc *__restrict__ ex_scal, uint32_t *__restrict__ ex_gidx,
-                                              uint32_t *__restrict__ ex_count) {
+                                              uint32_t *__restrict__ ex_count, uint32_t ex_back) {
   __shared__ sc red[64];
   kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count, ct_scal,
-               ct_idx, ct_count, ex_scal, ex_gidx, ex_count, red);
+               ct_idx, ct_count, ex_scal, ex_gidx, ex_count, ex_back, red);
   lds_wipe(red);
 }
 // ... and as ONE launch per round (round 4): the encoding of the previous round's L and R (two lanes, ristretto_compress), the
@@ -1243,7 +1263,8 @@ __global__ void __launch_bounds__(64 * W) kp_round(const uint8_t *__restrict__ b
                                                uint8_t *lr_prev, ProveState *ps, sc *__restrict__ vec, sc *__restrict__ term_scal,
                                                uint32_t *__restrict__ term_gidx, uint32_t *__restrict__ term_count,
                                                sc *__restrict__ ct_scal, uint32_t *__restrict__ ct_idx, uint32_t *__restrict__ ct_count,
-                                               sc *__restrict__ ex_scal, uint32_t *__restrict__ ex_gidx, uint32_t *__restrict__ ex_count) {
+                                               sc *__restrict__ ex_scal, uint32_t *__restrict__ ex_gidx, uint32_t *__restrict__ ex_count,
+                                               uint32_t ex_back) {
   // blockDim.x = 64 x (1, 2 or 4) wavefronts per proof (option "prove_waves").  With two or more: L and R are summed and encoded
   // on a wavefront each, the Fiat-Shamir step runs its two halves side by side (kp_lane_body2), the vector step strides by the
   // whole workgroup.  One wavefront: the same three phases in a row (the form of round 4; tests run every form).
@@ -1298,7 +1319,7 @@ __global__ void __launch_bounds__(64 * W) kp_round(const uint8_t *__restrict__ b
     __syncthreads();
   }
   kp_wave_body(bytes, desc, minvals, min_present, n_bits, t, n_gen, j, rounds, stride, ps, vec, term_scal, term_gidx, term_count, ct_scal,
-               ct_idx, ct_count, ex_scal, ex_gidx, ex_count, sh.red_sc);
+               ct_idx, ct_count, ex_scal, ex_gidx, ex_count, ex_back, sh.red_sc);
   lds_wipe(sh);
 }
 
@@ -1318,7 +1339,7 @@ __global__ void __launch_bounds__(64) kp_finish(const ProveDesc *__restrict__ de
   const KeccakLanes K = keccak_lanes();
   ProveState &st = ps[p];
   const uint32_t mn = desc[p].m * n_bits;
-  const sc *a = vec + (size_t)p * (5 * mn + 2), *b = a + mn;
+  const sc *a = vec + (size_t)p * KP_VEC_LEN(mn), *b = a + mn;
   WStrobe tr;
   ws_load(tr, L.tr, st.tr);
   const uint8_t *pa1 = a1b32 + (size_t)p * 64;
