@@ -671,6 +671,48 @@ def small_calls_leg(bpp, packed, np, local_rank, params2, data2, callers=32, sec
     return out
 
 
+def pick_wide_transport(requested, dist, dmod, world):
+    """COLLECTIVE.  The transport of the sharded leg's all_gathers: RCCL (`requested` = "rccl") only if EVERY rank can load it and
+    make an id (bpp_comm_unique_id: dlopen + ncclGetUniqueId, no communication) -- a rank that cannot would leave the others waiting
+    inside ncclCommInitRank; otherwise the caller-supplied transport over torch.distributed's gloo (bpp_comm_create_callbacks), and a
+    note that says which ranks failed and how.  Returns (transport, note or None)."""
+    if requested != "rccl":
+        return "gloo", None
+    ok, why = True, ""
+    try:
+        dmod.ShardComm.unique_id()
+    except Exception as e:  # noqa: BLE001 - reported in the line
+        ok, why = False, "%s: %s" % (type(e).__name__, e)
+    every = [None] * world
+    dist.all_gather_object(every, (ok, why))
+    bad = ["rank %d (%s)" % (r, w) for r, (o, w) in enumerate(every) if not o]
+    if bad:
+        return "gloo", "RCCL is not usable on " + ", ".join(bad) + ": the all_gathers go through the caller-supplied transport over gloo instead"
+    return "rccl", None
+
+
+def make_wide_comm(transport, engine, dist, dmod, world):
+    """COLLECTIVE.  One communicator of the sharded leg: over RCCL when `transport` says so and ncclCommInitRank succeeds on EVERY rank
+    (a rank where it failed tells the others over the control plane; those that succeeded close theirs), else over gloo.
+    Returns (communicator, transport actually used, note or None)."""
+    if transport == "rccl":
+        comm, why = None, ""
+        try:
+            comm = dmod.ShardComm.from_process_group(engine)
+        except Exception as e:  # noqa: BLE001
+            why = "%s: %s" % (type(e).__name__, e)
+        every = [None] * world
+        dist.all_gather_object(every, (comm is not None, why))
+        bad = ["rank %d (%s)" % (r, w) for r, (o, w) in enumerate(every) if not o]
+        if not bad:
+            return comm, "rccl", None
+        if comm is not None:
+            comm.close()
+        note = "bpp_comm_create failed on " + ", ".join(bad) + ": the all_gathers go through the caller-supplied transport over gloo instead"
+        return dmod.ShardComm.from_process_group_gloo(engine), "gloo", note
+    return dmod.ShardComm.from_process_group_gloo(engine), "gloo", None
+
+
 def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, params2, data2, args, sync):
     """BASELINE configs[3]: 4096 proofs as ONE reference batch sharded over the ranks, through the C ABI
     (bpp_verify_sharded_groups_wave: RCCL all_gathers on device buffers).  A rank's shards of G such batches are ONE resident
@@ -691,6 +733,7 @@ def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, para
     counts = [n_local] * world
     nb = data2["proofs"].shape[0] // n_local
     calls = []
+    transport, note = pick_wide_transport(args.transport, dist, dmod, world)
     for w in range(W):  # communicators are built collectively, in the same order on every rank
         engs = [bpp.Engine(local_rank) for _ in range(S)]
         pars = [params2.share(e) for e in engs]
@@ -702,8 +745,9 @@ def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, para
             rbs.append(packed.ResidentBatch(pars[sl], data2["proofs"][idx], data2["commitments"][idx], data2["min_values"][idx],
                                             data2["min_present"][idx], None, LABEL))
             rbs[-1].prepare(n_local if G > 1 else 0)
-        calls.append((engs, pars, rbs, dmod.ShardComm.from_process_group_gloo(engs[0]) if args.transport == "gloo"
-                      else dmod.ShardComm.from_process_group(engs[0])))
+        comm, transport, note2 = make_wide_comm(transport, engs[0], dist, dmod, world)
+        note = note or note2
+        calls.append((engs, pars, rbs, comm))
     errors = []
 
     def worker(w, rounds):
@@ -745,11 +789,13 @@ def wide_leg(bpp, packed, np, torch, dist, device, local_rank, rank, world, para
         for eng in engs:
             eng.close()
     return {"workload": "BASELINE configs[3]: 4096 non-aggregated 64-bit proofs as ONE reference batch, %d per rank, through "
-                        "bpp_verify_sharded_groups_wave: RCCL all_gather of 32 B/proof transcript-RNG bytes (device buffers), weight "
-                        "chains replayed (shared out over the ranks and gathered when there are several), RCCL all_gather of the "
+                        "bpp_verify_sharded_groups_wave: all_gather (%s) of 32 B/proof transcript-RNG bytes, weight "
+                        "chains replayed (shared out over the ranks and gathered when there are several), all_gather of the "
                         "128-byte accumulators, sum + identity test on the device; %d calls in flight per rank, each a pipeline of %d "
-                        "times %d batches resident as one" % (n_local, W, S, G),
-            "rccl_ranks": world, "transport": "gloo through bpp_comm_create_callbacks" if args.transport == "gloo" else "rccl",
+                        "times %d batches resident as one" % (n_local, "RCCL, device buffers" if transport == "rccl" else "gloo, host buffers", W, S, G),
+            "rccl_ranks": world if transport == "rccl" else 0, "ranks": world,
+            "transport": "rccl" if transport == "rccl" else "gloo through bpp_comm_create_callbacks", "transport_requested": args.transport,
+            "transport_note": note,
             "proofs_per_s": 4096 * batches / wel, "ms_per_batch": 1e3 * wel / batches,
             "batches": batches, "in_flight": W * S * G, "waves": W, "slots_per_call": S, "batches_per_wave": G,
             "last_wave_host_ms": {k: round(v, 3) for k, v in wave_ms.items()}}

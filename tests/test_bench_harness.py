@@ -118,3 +118,42 @@ def test_cpu_baseline_objects_of_every_leg():
     assert o["all_cores"]["bytes_equal_engine"] is True
     d4["proofs"][1, 100] ^= 1  # "the engine's" bytes differ: reported, not hidden
     assert bench.cpu_prove_baseline((64, 2, 2), d4, seconds=0.05)["bytes_equal_engine"] is False
+
+
+def _transport_worker(rank, world, port, stub, out_dir):
+    """one rank of test_wide_transport_falls_back_to_gloo (a process of its own: BPP_RCCL_LIB is read once per process)"""
+    import importlib
+    import json
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ["BPP_RCCL_LIB"] = stub if rank == 0 else os.path.join(out_dir, "no-such-librccl.so")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    dmod = importlib.import_module("bulletproofs-plus_amd.dist")
+    res = {"picked": bench.pick_wide_transport("rccl", dist, dmod, world), "asked_gloo": bench.pick_wide_transport("gloo", dist, dmod, world)}
+    with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+def test_wide_transport_falls_back_to_gloo(tmp_path):
+    """bench.py --gpus N, the sharded leg: when RCCL cannot be used on SOME rank (here: rank 1's library does not exist, rank 0 has a
+    stand-in librccl, tests/cpp/rccl_stub.hip) every rank must come to the same answer BEFORE anyone enters ncclCommInitRank -- the
+    caller-supplied transport over gloo -- and the note must name the failing rank.  World size 2 over gloo, no GPU."""
+    import json
+    import shutil
+    import socket
+    import torch.multiprocessing as mp
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    stub = str(tmp_path / "librccl_stub.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-shared", "-fPIC", "-o", stub, os.path.join(ROOT, "tests", "cpp", "rccl_stub.hip")],
+                   check=True, timeout=600)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_transport_worker, args=(2, port, stub, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (json.load(open(tmp_path / ("rank%d.json" % r))) for r in (0, 1))
+    assert r0 == r1  # the same decision on every rank
+    transport, note = r0["picked"]
+    assert transport == "gloo" and "rank 1" in note and "rank 0" not in note and "RCCL" in note
+    assert r0["asked_gloo"] == ["gloo", None]

@@ -150,7 +150,9 @@ def test_two_ranks_as_processes_on_one_gpu_through_bench():
     assert "device 0" in out["config"]["devices"]
     wide = out["extra"]["wide"]
     assert "error" not in wide, wide
-    assert wide["rccl_ranks"] == 2 and wide["proofs_per_s"] > 0 and "gloo" in wide["transport"]
+    # the line names the transport that really carried the all_gathers and how many ranks spoke RCCL (none: one device)
+    assert wide["ranks"] == 2 and wide["rccl_ranks"] == 0 and wide["proofs_per_s"] > 0 and "gloo" in wide["transport"]
+    assert wide["transport_requested"] == "gloo" and wide["transport_note"] is None
     ranks = out["per_rank"]
     assert [x["rank"] for x in ranks] == [0, 1] and all(x["host_threads"] >= 1 and x["host_chain_cpu_ms_per_step"] > 0 for x in ranks)
     assert out["host_chain_cpu_ms_per_step"] > 0 and out["host_cores_busy"] > 0
