@@ -430,6 +430,7 @@ struct ProveLds {
   sc xch[2];
   uint64_t rng_bak[25];              // pw_randoms: the generator's state before a batch of draws
   uint8_t wide[PW_MAX_DRAWS][64];    //             the batch's 64-byte outputs
+  uint32_t wk[2][WK_LDS_DWORDS_RC];  // the permutations' exchange images (wkeccak.h): one per wavefront that runs a sponge (kp_lane_body2: two)
 };
 // build_rng (src/transcripts.rs:185-194): clone, rekey with the witness bytes, finalize with 32 external bytes
 __device__ __forceinline__ void pw_build_rng(WStrobe &rng, ProveLds &L, const KeccakLanes &K, const WStrobe &tr, const uint8_t *wit,
@@ -523,7 +524,7 @@ __global__ void __launch_bounds__(64) kp_init(const uint8_t *__restrict__ bytes,
   const uint32_t p = blockIdx.x;
   if (p >= B) return;
   __shared__ ProveLds L;
-  const KeccakLanes K = keccak_lanes();
+  const KeccakLanes K = keccak_lanes(L.wk[0]);
   const ProveDesc d = desc[p];
   ProveState &st = ps[p];
   if (threadIdx.x == 0) st.status = 0;
@@ -626,7 +627,7 @@ __device__ __forceinline__ void kp_lane_body(const uint8_t *__restrict__ bytes, 
                                              ProveState *ps, ProveLds &L) {
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
   if (p >= B) return;
-  const KeccakLanes K = keccak_lanes();
+  const KeccakLanes K = keccak_lanes(L.wk[0]);
   const ProveDesc d = desc[p];
   ProveState &st = ps[p];
   const uint32_t mn = d.m * n_bits, wit_len = d.m * (8 + 32 * t);
@@ -749,7 +750,7 @@ __device__ __forceinline__ void kp_lane_body2(const uint8_t *__restrict__ bytes,
                                               uint32_t n_bits, uint32_t t, uint32_t B, uint32_t j, uint32_t rounds,
                                               const uint8_t *__restrict__ a32, const uint8_t *lr32, ProveState *ps, ProveLds &L) {
   const uint32_t p = blockIdx.x, lane = ws_lane(), wave = threadIdx.x >> 6;
-  const KeccakLanes K = keccak_lanes();
+  const KeccakLanes K = keccak_lanes(L.wk[wave & 1u]);  // (wavefronts 0 and 1 run the two sponges; 2 and 3 only meet the barriers)
   const ProveDesc d = desc[p];
   ProveState &st = ps[p];
   const uint32_t mn = d.m * n_bits, wit_len = d.m * (8 + 32 * t);
@@ -1336,7 +1337,7 @@ __global__ void __launch_bounds__(64) kp_finish(const ProveDesc *__restrict__ de
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
   if (p >= B) return;
   __shared__ ProveLds L;
-  const KeccakLanes K = keccak_lanes();
+  const KeccakLanes K = keccak_lanes(L.wk[0]);
   ProveState &st = ps[p];
   const uint32_t mn = desc[p].m * n_bits;
   const sc *a = vec + (size_t)p * KP_VEC_LEN(mn), *b = a + mn;

@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(64, BPP_TRANSCRIPTS_WAVES) k_transcripts(const
 struct TranscriptLds {
   uint64_t st[25];
   uint8_t buf[64];
+  uint32_t wk[WK_LDS_DWORDS_RC];  // the permutation's exchange image (wkeccak.h)
 };
 __device__ __forceinline__ bool wave_challenge(WStrobe &s, TranscriptLds &L, const KeccakLanes &K, const char *label, uint32_t llen,
                                                sc &out) {
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(64) k_transcripts_wave(const uint8_t *__restri
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
   if (p >= B) return;
   __shared__ TranscriptLds L;
-  const KeccakLanes K = keccak_lanes();
+  const KeccakLanes K = keccak_lanes(L.wk);
   const ProofDesc d = desc[p];
   const uint8_t *sb = states + 203u * d.state_idx;
   for (uint32_t k = lane; k < 200; k += 64) ((uint8_t *)L.st)[k] = sb[k];

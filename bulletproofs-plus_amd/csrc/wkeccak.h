@@ -57,10 +57,14 @@ BPP_HD constexpr uint64_t wk_word(uint32_t even, uint32_t odd) {
 }
 
 #define WK_LDS_DWORDS (128 + 24 * 16)  // state halves, the idle lanes' scratch dwords, 24 sets of parity accumulators
+// ... and, for callers that cannot spare 24 registers for iota's constants (the sponges of wstrobe.h inside the prover's round
+// kernel), the constants as a table behind the image: [24][2] words for the two lanes of word 0, [24][2] zeros for everybody else
+#define WK_LDS_DWORDS_RC (WK_LDS_DWORDS + 96)
 
 struct WkLanes {
   uint32_t wr, src, acc, cm, cp;  // LDS byte addresses: own half, source half; in accumulator set 0: own column, column xs-1 (half hs), column xs+1 (half 1-hs)
   uint32_t zero;             // 4 x lane: the six clearing stores cover dwords 128 + lane + 64 k
+  uint32_t rc;               // iota from the table behind the image (wk_rc_table_init): this lane's column of it
   uint32_t cp_sh, rho_sh;    // v_alignbit_b32 shift amounts (rol32(v, n) = alignbit(v, v, (32 - n) & 31))
   uint64_t nowrap1, wrap2;   // wave masks: lanes whose row neighbour x'+1 is the next lane (x' < 4) / whose x'+2 wraps around (x' >= 3)
   uint32_t word, half;       // this lane's state word (x' + 5 y') and half; word = 0xffffffff for the 14 idle lanes
@@ -92,6 +96,7 @@ __device__ __forceinline__ WkLanes wk_lanes(const uint32_t *lds) {
   L.cm = base + 4u * (128 + 2 * ((xs + 4) % 5) + hs);
   L.cp = base + 4u * (128 + 2 * ((xs + 1) % 5) + (hs ^ 1u));
   L.zero = base + 4u * (128 + lane);
+  L.rc = base + 4u * (WK_LDS_DWORDS + ((owner && x == 0 && y == 0) ? h : 48u));
   L.cp_sh = hs == 0 ? 31u : 0u;  // D[x] = C[x-1] ^ rol64(C[x+1], 1): even half takes rol32(odd half of C[x+1], 1), odd half the even half as is
   L.rho_sh = (32u - sh) & 31u;
   L.nowrap1 = __ballot(x < 4);
@@ -160,6 +165,69 @@ __device__ __forceinline__ uint32_t wk_rounds6(uint32_t a, const WkLanes &L, con
                  [rc2] "v"(R.v[R0 + 2]), [rc3] "v"(R.v[R0 + 3]), [rc4] "v"(R.v[R0 + 4]), [rc5] "v"(R.v[R0 + 5])
                : "memory", "vcc");
 #endif
+  return a;
+}
+
+// iota's constants into the table behind the image (all 64 lanes; a wavefront barrier before the first permutation)
+__device__ __forceinline__ void wk_rc_table_init(uint32_t *lds) {
+  const uint32_t l = threadIdx.x & 63u;
+  lds[WK_LDS_DWORDS + l] = l < 48 ? WK_RC[l >> 1][l & 1u] : 0u;
+  if (l < 32) lds[WK_LDS_DWORDS + 64 + l] = 0u;
+}
+// the same six rounds with iota's constant read from that table (one more LDS read per round, no constant registers)
+#define WK_ROUND_ASM_T(K)                                                                                             \
+  "ds_write_b32 %[wa], %[a]\n\t"                                                                                      \
+  "ds_xor_b32 %[ca], %[a] offset:%[off" #K "]\n\t"                                                                    \
+  "ds_read_b32 %[s], %[sa]\n\t"                                                                                       \
+  "ds_read_b32 %[cm], %[ma] offset:%[off" #K "]\n\t"                                                                  \
+  "ds_read_b32 %[cp], %[pa] offset:%[off" #K "]\n\t"                                                                  \
+  "ds_read_b32 %[w2], %[ra] offset:%[ro" #K "]\n\t"                                                                   \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                          \
+  "v_alignbit_b32 %[cp], %[cp], %[cp], %[cpsh]\n\t"                                                                   \
+  "v_bitop3_b32 %[s], %[s], %[cm], %[cp] bitop3:0x96\n\t"                                                             \
+  "v_alignbit_b32 %[s], %[s], %[s], %[rsh]\n\t"                                                                       \
+  "v_mov_b32_e32 %[a], %[w2]\n\t"                               /* (iota's word; also one of the two wait states) */   \
+  "s_nop 0\n\t"                                                                                                       \
+  "v_mov_b32_dpp %[cm], %[s] row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                   \
+  "v_mov_b32_dpp %[cp], %[s] row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                   \
+  "v_mov_b32_dpp %[w2], %[s] row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                   \
+  "v_cndmask_b32_dpp %[cm], %[s], %[cm], vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                   \
+  "v_cndmask_b32_e64 %[cp], %[cp], %[w2], %[wr2]\n\t"                                                                 \
+  "v_bitop3_b32 %[s], %[s], %[cm], %[cp] bitop3:0xd2\n\t"                                                             \
+  "v_xor_b32_e32 %[a], %[s], %[a]\n\t"
+
+template <int R0>
+__device__ __forceinline__ uint32_t wk_rounds6_t(uint32_t a, const WkLanes &L) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t s, cm, cp, w2;
+  asm volatile("s_mov_b64 vcc, %[nw1]\n\t" WK_ROUND_ASM_T(0) WK_ROUND_ASM_T(1) WK_ROUND_ASM_T(2) WK_ROUND_ASM_T(3) WK_ROUND_ASM_T(4) WK_ROUND_ASM_T(5)
+               : [a] "+&v"(a), [s] "=&v"(s), [cm] "=&v"(cm), [cp] "=&v"(cp), [w2] "=&v"(w2)
+               : [wa] "v"(L.wr), [ca] "v"(L.acc), [sa] "v"(L.src), [ma] "v"(L.cm), [pa] "v"(L.cp), [ra] "v"(L.rc), [cpsh] "v"(L.cp_sh),
+                 [rsh] "v"(L.rho_sh), [wr2] "s"(L.wrap2), [nw1] "s"(L.nowrap1), [off0] "n"(64 * R0), [off1] "n"(64 * (R0 + 1)),
+                 [off2] "n"(64 * (R0 + 2)), [off3] "n"(64 * (R0 + 3)), [off4] "n"(64 * (R0 + 4)), [off5] "n"(64 * (R0 + 5)), [ro0] "n"(8 * R0),
+                 [ro1] "n"(8 * (R0 + 1)), [ro2] "n"(8 * (R0 + 2)), [ro3] "n"(8 * (R0 + 3)), [ro4] "n"(8 * (R0 + 4)), [ro5] "n"(8 * (R0 + 5))
+               : "memory", "vcc");
+#endif
+  return a;
+}
+// the permutation with iota from the table: uses lds[0 .. WK_LDS_DWORDS_RC), wk_rc_table_init first
+__device__ __forceinline__ uint32_t wk_keccak_f1600_t(uint32_t a, const WkLanes &L) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile(
+      "ds_write_b32 %[z], %[o]\n\t"
+      "ds_write_b32 %[z], %[o] offset:256\n\t"
+      "ds_write_b32 %[z], %[o] offset:512\n\t"
+      "ds_write_b32 %[z], %[o] offset:768\n\t"
+      "ds_write_b32 %[z], %[o] offset:1024\n\t"
+      "ds_write_b32 %[z], %[o] offset:1280"
+      :
+      : [z] "v"(L.zero), [o] "v"(0u)
+      : "memory");
+#endif
+  a = wk_rounds6_t<0>(a, L);
+  a = wk_rounds6_t<6>(a, L);
+  a = wk_rounds6_t<12>(a, L);
+  a = wk_rounds6_t<18>(a, L);
   return a;
 }
 

@@ -5,16 +5,17 @@
 // challenge exists, so per proof it is a pure latency chain of ~15 Keccak-f per round, and one lane needs ~26 us per
 // permutation.  Here the 200-byte state lives in LDS and the wavefront shares the work:
 //   * absorb / overwrite / squeeze touch up to 64 state bytes per step (lane k <-> byte pos + k),
-//   * Keccak-f[1600] keeps one 64-bit state word per lane (25 lanes) and exchanges words through the LDS copy of the
-//     state twice per round: theta reads the ten words of the two neighbouring columns (D[x] = C[x-1] ^ rol(C[x+1], 1)
-//     without a separate parity step), pi and chi read three rotated words at once (own, row neighbours +1 and +2 at
-//     their pre-pi places); rho is a per-lane rotate.  LDS operations of one wavefront execute in issue order, so a
-//     round is write, reads, write, reads with two waits (the first form took four dependent ds_bpermute steps per
-//     round; PASS 1 of a 256-proof call 0.117 -> 0.106 ms, batch prover 115 -> 119 k proofs/s).
+//   * Keccak-f[1600] is wkeccak.h's one-exchange form (round 6): the 25 words are read out of the LDS state as bit-interleaved
+//     32-bit halves, one per lane on 50 lanes, permuted in registers with ONE LDS exchange per round (theta + rho for the source
+//     word of a lane's pi destination, column parities summed by ds_xor_b32, chi's neighbours by DPP), and written back as words.
+//     19 instruction slots per round plus ~80 for the two conversions, against ~60 per round for the form it replaces (a 64-bit
+//     word per lane on 25 lanes, two exchanges per round: kept below as keccak_f1600_wave25 for the microbenchmark): 4.5 -> ~1.7
+//     us per permutation for a lone wavefront, and a third of the instructions.
 // pos / pos_begin / cur_flags are wave-uniform registers.  Byte-for-byte the same sponge as merlin.h (tests compare the
 // prover's output with the oracle).  Must be called by all 64 lanes of the wavefront that owns the transcript.
 #pragma once
 #include "merlin.h"
+#include "wkeccak.h"
 
 namespace bpp {
 
@@ -43,9 +44,13 @@ struct KeccakLanes {
   int pn1, pn2;        // the same for the row neighbours x+1, x+2 (chi)
   uint32_t rot;        // rho offset of this lane's word
   bool lane0, owner;   // owner: lanes 0..24 (the others shadow lane 0 and never write)
+  WkLanes W;           // wkeccak.h's lane constants
+  uint32_t *img;       // its exchange image in LDS: WK_LDS_DWORDS_RC dwords, ONE PER WAVEFRONT that runs a sponge
 };
 
-__device__ __forceinline__ KeccakLanes keccak_lanes() {
+// img: WK_LDS_DWORDS_RC dwords of LDS for this wavefront's permutations (the table of iota's constants behind the image is filled
+// here: all 64 lanes call; the sponge operations that follow start with a wavefront barrier)
+__device__ __forceinline__ KeccakLanes keccak_lanes(uint32_t *img) {
   const uint8_t ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
   const uint32_t l = ws_lane();
   const int i = l < 25 ? (int)l : 0;  // lanes 25..63 shadow lane 0 and never write back
@@ -64,10 +69,13 @@ __device__ __forceinline__ KeccakLanes keccak_lanes() {
   k.rot = r;
   k.lane0 = i == 0;
   k.owner = l < 25;
+  k.W = wk_lanes(img);
+  k.img = img;
+  wk_rc_table_init(img);
   return k;
 }
 
-__device__ __forceinline__ void keccak_f1600_wave(uint64_t *st, const KeccakLanes &K) {
+__device__ __forceinline__ void keccak_f1600_wave25(uint64_t *st, const KeccakLanes &K) {
   const uint64_t RC[24] = {
       0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL,
       0x000000000000808BULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
@@ -95,6 +103,13 @@ __device__ __forceinline__ void keccak_f1600_wave(uint64_t *st, const KeccakLane
     if (K.lane0) a ^= RC[rnd];  // iota
   }
   if (K.owner) w[self] = a;
+}
+
+// the caller's barrier made the absorbed bytes visible; the words are back in st[] (and visible) on return
+__device__ __forceinline__ void keccak_f1600_wave(uint64_t *st, const KeccakLanes &K) {
+  uint32_t a = wk_load(st, K.W);
+  a = wk_keccak_f1600_t(a, K.W);
+  wk_store(st, K.img, a, K.W);
 }
 
 __device__ __forceinline__ void ws_run_f(WStrobe &s, const KeccakLanes &K) {

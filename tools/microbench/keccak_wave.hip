@@ -19,13 +19,16 @@ __global__ void __launch_bounds__(64) k_ref(uint64_t *st, int n) {
   for (int k = 0; k < n; k++) keccak_f1600(a);
   for (int i = 0; i < 25; i++) st[blockIdx.x * 25 + i] = a[i];
 }
+template <int FORM>  // 0: the 25-lane form wstrobe.h had until round 5; 1: the sponge's permutation now (words in LDS -> halves -> words)
 __global__ void __launch_bounds__(64) k_wave64(uint64_t *st, int n) {
   __shared__ uint64_t L[25];
+  __shared__ uint32_t img[WK_LDS_DWORDS_RC];
   if (threadIdx.x < 25) L[threadIdx.x] = st[blockIdx.x * 25 + threadIdx.x];
-  const KeccakLanes K = keccak_lanes();
+  const KeccakLanes K = keccak_lanes(img);
   ws_sync();
   for (int k = 0; k < n; k++) {
-    keccak_f1600_wave(L, K);
+    if (FORM == 0) keccak_f1600_wave25(L, K);
+    else keccak_f1600_wave(L, K);
     ws_sync();
   }
   if (threadIdx.x < 25) st[blockIdx.x * 25 + threadIdx.x] = L[threadIdx.x];
@@ -68,29 +71,33 @@ int main() {
   CK(hipMemcpy(d, h0.data(), h0.size() * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_ref, dim3(blocks), dim3(64), 0, 0, d, n_check);
   CK(hipMemcpy(want.data(), d, h0.size() * 8, hipMemcpyDeviceToHost));
-  for (int v = 0; v < 2; v++) {
+  const char *names[3] = {"25 lanes, a word each, two exchanges per round (wstrobe.h until round 5)",
+                          "wstrobe.h now: LDS words -> halves, one exchange per round, -> words", "wkeccak.h, state kept in registers (the weight chain)"};
+  auto launch = [&](int v, int nb, int n) {
+    if (v == 0) hipLaunchKernelGGL(k_wave64<0>, dim3(nb), dim3(64), 0, 0, d, n);
+    else if (v == 1) hipLaunchKernelGGL(k_wave64<1>, dim3(nb), dim3(64), 0, 0, d, n);
+    else hipLaunchKernelGGL(k_wave50, dim3(nb), dim3(64), 0, 0, d, n);
+  };
+  for (int v = 0; v < 3; v++) {
     CK(hipMemcpy(d, h0.data(), h0.size() * 8, hipMemcpyHostToDevice));
-    if (v == 0) hipLaunchKernelGGL(k_wave64, dim3(blocks), dim3(64), 0, 0, d, n_check);
-    else hipLaunchKernelGGL(k_wave50, dim3(blocks), dim3(64), 0, 0, d, n_check);
+    launch(v, blocks, n_check);
     CK(hipMemcpy(h.data(), d, h0.size() * 8, hipMemcpyDeviceToHost));
-    printf("%s: %s\n", v ? "wkeccak (50 lanes, one exchange)" : "wstrobe (25 lanes, two exchanges)",
-           memcmp(h.data(), want.data(), h0.size() * 8) == 0 ? "equal to the one-lane form" : "DIFFERS");
+    printf("%s: %s\n", names[v], memcmp(h.data(), want.data(), h0.size() * 8) == 0 ? "equal to the one-lane form" : "DIFFERS");
   }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int nb : {1, 64, 1024}) {
-    for (int v = 0; v < 2; v++) {
+  for (int nb : {1, 64}) {
+    for (int v = 0; v < 3; v++) {
       const int n = 4000;
       for (int rep = 0; rep < 3; rep++) {
         CK(hipEventRecord(e0, 0));
-        if (v == 0) hipLaunchKernelGGL(k_wave64, dim3(nb > blocks ? blocks : nb), dim3(64), 0, 0, d, n);
-        else hipLaunchKernelGGL(k_wave50, dim3(nb > blocks ? blocks : nb), dim3(64), 0, 0, d, n);
+        launch(v, nb > blocks ? blocks : nb, n);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
-        if (rep == 2) printf("%-8s wavefronts %4d: %.3f us per permutation\n", v ? "wkeccak" : "wstrobe", nb > blocks ? blocks : nb, 1e3 * ms / n);
+        if (rep == 2) printf("form %d, wavefronts %4d: %.3f us per permutation\n", v, nb > blocks ? blocks : nb, 1e3 * ms / n);
       }
     }
   }
