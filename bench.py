@@ -136,11 +136,13 @@ def thread_cpu_delta(before, after, wall_s):
     for tid, (comm, sec) in after.items():
         d = sec - before.get(tid, (comm, 0.0))[1]
         if d > 0:
-            e = acc.setdefault(comm, [0, 0.0])
+            e = acc.setdefault(comm, [0, 0.0, 0.0])
             e[0] += 1
             e[1] += d
+            e[2] = max(e[2], d)
     rows = sorted(acc.items(), key=lambda kv: -kv[1][1])
-    return [{"thread": k, "threads": v[0], "cores_busy": round(v[1] / wall_s, 3)} for k, v in rows if wall_s > 0][:8]
+    return [{"thread": k, "threads": v[0], "cores_busy": round(v[1] / wall_s, 3), "busiest_one": round(v[2] / wall_s, 3)}
+            for k, v in rows if wall_s > 0][:8]
 
 
 def resolve_chain_mode(args, world):
@@ -367,7 +369,7 @@ def cpu_prove_baseline(shape, data, seconds=1.5):
 class Leg:
     """S slots (engine + stream + resident copy of the input) verifying `chunk`-proof reference batches"""
 
-    def __init__(self, bpp, packed, torch, device, params0, data, batch_proofs, batches, slots, chunk, profile=True, action=0):
+    def __init__(self, bpp, packed, torch, device, params0, data, batch_proofs, batches, slots, chunk, profile=True, action=0, options=None):
         import numpy as np
         self.bpp, self.chunk, self.slots, self.action = bpp, chunk, [], int(action)
         self.data_idx = []
@@ -380,6 +382,8 @@ class Leg:
             stream = None  # the engine's own non-blocking stream (its HIP events time the kernels on it)
             eng = bpp.Engine(device.index)
             eng.profile(profile)  # stage events: nothing next to a 2.5 ms step, 10 % of a 0.8 ms call
+            for name, value in (options or {}).items():  # per-context knobs of this leg (bpp_ctx_set_option)
+                eng.set_option(name, value)
             params = params0.share(eng)  # ONE generator table for every slot (src/traits.rs:42 `Send + Sync`)
             # the same `nb` distinct batches in another order for every slot
             order = [(i * 11 + k) % nb for k in range(batches)]
@@ -948,10 +952,30 @@ def main():
                 q.close()
             for e in engs:
                 e.close()
+        # the same call with A1 and B in the uniform-access form as well ("ct" = 2: the reference's constant-time `&P * Scalar`,
+        # src/range_proof.rs:572-584): what the property costs, in the same run
+        ct2 = {}
+        if iters5 >= 4:
+            eng0.set_option("ct", 2)
+            try:
+                for _ in range(2):
+                    out2 = packed.prove(p5, d5["values"], d5["blindings"], d5["commitments"], d5["min_values"], d5["min_present"], None, LABEL, d5["ext"])
+                t2 = time.perf_counter()
+                for _ in range(iters5):
+                    out2 = packed.prove(p5, d5["values"], d5["blindings"], d5["commitments"], d5["min_values"], d5["min_present"], None, LABEL,
+                                        d5["ext"])
+                el2 = time.perf_counter() - t2
+                ct2 = {"proofs_per_s": 1024 * iters5 / el2, "ms_per_call": 1e3 * el2 / iters5,
+                       "cost_against_default": 1.0 - (1024 * iters5 / el2) / (1024 * iters5 / el5),
+                       "bytes_equal_default": bool((out2 == d5["proofs"]).all()),
+                       "note": "option ct = 2: no secret scalar of A1 / B addresses a table; default ct = 1 (commit and the witness check only)"}
+            finally:
+                eng0.set_option("ct", -1)
         p5.close()
         return cpu_side({"workload": "BASELINE configs[4]: bpp_prove_batch over 1024 x aggregation-4 64-bit proofs, extension "
                             "degree 3; host witness buffers in, proof bytes out (PCIe-inclusive)",
                 "proofs_per_s": 1024 * iters5 / el5, "ms_per_call": 1e3 * el5 / iters5, "calls": iters5, "four_calls_in_flight": conc,
+                "uniform_access_A1_B": ct2,
                 "roofline": {"bound": "hbm",
                              "kernel": "k_fb_part (fixed-base MSM of every L and R -- and of A1's four public points, or of A1 and B with "
                                        "ct < 2 -- as one-wavefront slices; the secret-only terms run in the uniform-access forms of ct.h)",
@@ -1145,6 +1169,28 @@ def main():
         return "error" not in extra[name]
 
     if rank == 0 and world == 1 and not args.no_extra:
+        # -------------------------------------------------------------- the headline's step with the weight chains on the OTHER side
+        def other_chain_leg():
+            """the A/B the line owes: the same resident step with the weight chains on the device (one wavefront per
+            reference batch, five steps in flight) when the headline kept the sponges on host cores -- or the other way round --
+            with what each costs the host"""
+            other = "host-wide" if chain_mode == "device" else "device"
+            So = 5 if other == "device" else 4
+            lego = Leg(bpp, packed, torch, device, params2, data2, 1024, R, So, 1024, profile=False, options={"chain": 1 if other == "device" else 2})
+            steps = max(40, min(args.steps, 120))
+            lego.run_steps(2 * So)
+            sync()
+            pool0, cpu0, t0 = bpp.host_pool_cpu_ns(), time.process_time(), time.perf_counter()
+            lego.run_steps(steps)
+            sync()
+            el = time.perf_counter() - t0
+            cpu_ms, pool_ms = (time.process_time() - cpu0) * 1e3 / steps, (bpp.host_pool_cpu_ns() - pool0) / 1e6 / steps
+            lego.close()
+            return {"workload": "the headline's step (64 reference batches of 1024 proofs, resident) with weight chains = %s, %d steps in flight, "
+                                "%d timed steps" % (other, So, steps), "weight_chains": other, "proofs_per_s": 1024 * R * steps / el,
+                    "ms_per_step": 1e3 * el / steps, "steps": steps, "host_cores_busy": cpu_ms / (1e3 * el / steps),
+                    "host_chain_cpu_ms_per_step": pool_ms, "headline_weight_chains": chain_mode}
+        side_leg("other_chain", other_chain_leg)
         # -------------------------------------------------------------- configs[2]: 256 x aggregation-8
         side_leg("cfg3", cfg3_leg)
         if profiler_legs and extra["cfg3"].get("roofline"):

@@ -527,6 +527,7 @@ struct bpp_ctx {
   bool ev_rng_ready = false;
   hipEvent_t ev_wait;  // gpu_wait_stream's marker
   bool ev_wait_ready = false;
+  uint32_t wait_hint_rng = 0, wait_hint_end = 0, wait_hint_prove = 0;  // how long a verification's two waits / a prover call's wait took lately, us (gpu_wait_event)
   // small inputs: decompression runs beside PASS 1 on a second stream (enqueue_phase1)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork, ev_join;
@@ -658,13 +659,19 @@ inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 // with, unless the PROCESS-WIDE device flag hipDeviceScheduleBlockingSync is set (then 25 % / 6 %) -- which is the host
 // application's to set, not a library's.  A verification of tens of thousands of proofs takes milliseconds and several are in
 // flight, so its caller naps instead: hipEventQuery every 50 us costs 1-2 % of a core and wakes up ~70 us late, which such a
-// call does not notice (bench.py: 3.7 -> 0.2 host cores per rank for the three callers of the headline).  Calls of a few
+// call does not notice (bench.py: 3.7 -> 0.3 host cores per rank for the callers of the headline).  Calls of a few
 // hundred proofs (0.5-0.7 ms, one at a time) keep the runtime's spinning wait: there 70 us are 10 %.
 #define BPP_WAIT_NAP_MIN_PROOFS 4096u
 inline bool wait_naps(const bpp_ctx *ctx, size_t proofs) {
   return ctx->opt.wait >= 0 ? ctx->opt.wait != 0 : proofs >= BPP_WAIT_NAP_MIN_PROOFS;
 }
-inline void gpu_wait_event(hipEvent_t ev, bool nap) {
+// hint (optional): the caller's memory of how long THIS wait took the last times, microseconds (updated here).  A call of a
+// steady stream of calls waits about as long as the one before it: most of that is slept in ONE piece, and the looking starts
+// when the wait is nearly over -- every look is a call into the runtime and every nap two context switches, which on a busy host
+// (measured: the same build 0.3 or 1.2 cores for four waiting callers, box by box) is what a rank's idle callers cost.
+// tail_spin: after the piece slept ahead, look without napping (a call at a time then ends as promptly as under the runtime's
+// spinning wait, for ~30 % of a core instead of all of it; with nothing remembered yet the whole wait is looked through)
+inline void gpu_wait_event(hipEvent_t ev, bool nap, uint32_t *hint = nullptr, bool tail_spin = false) {
   if (!nap) {
     HIP_CHECK(hipEventSynchronize(ev));
     return;
@@ -672,16 +679,33 @@ inline void gpu_wait_event(hipEvent_t ev, bool nap) {
   // the first ~30 us by looking only: a wait for something that is (nearly) done must not cost a nap -- a nap is 60-100 us with
   // the kernel's timer slack, and a prover call has six waits in a row at its end (0.6 ms of a 6.5 ms call before this)
   const auto t0 = std::chrono::steady_clock::now();
+  bool slept_ahead = false;
   for (;;) {
     const hipError_t e = hipEventQuery(ev);
-    if (e == hipSuccess) return;
+    const long waited = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (e == hipSuccess) {
+      if (hint) *hint = (uint32_t)((3ul * *hint + (unsigned long)waited) / 4ul);
+      return;
+    }
     if (e != hipErrorNotReady) HIP_CHECK(e);
-    if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(30)) continue;
-    struct timespec ts = {0, 50000};
+    if (waited < 30) continue;
+    if (tail_spin && (slept_ahead || !hint || *hint <= 600)) continue;
+    long nap_us;
+    if (hint && !slept_ahead && *hint > 600 && waited < (long)*hint / 2) {
+      nap_us = (long)*hint * 7 / 10 - waited;  // the bulk of an expected wait in one piece
+      slept_ahead = true;
+    } else if (slept_ahead && waited < (long)*hint * 5 / 4) {
+      nap_us = 50;  // the expected end is near: short naps (a call at a time wakes up within one of them)
+    } else {
+      // naps grow with the wait: 50 us at first (a wait of a few hundred microseconds ends within a nap of its event), an eighth of
+      // the time waited so far from 0.4 ms on, 400 us at most
+      nap_us = waited < 400 ? 50 : (waited / 8 > 400 ? 400 : waited / 8);
+    }
+    struct timespec ts = {0, nap_us * 1000};
     nanosleep(&ts, nullptr);
   }
 }
-inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap);
+inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap, uint32_t *hint = nullptr, bool tail_spin = false);
 inline bool gpu_wait_stream_ok(bpp_ctx *ctx, hipStream_t s, bool nap) {  // false instead of an exception (the sharded forms carry faults along)
   try {
     gpu_wait_stream(ctx, s, nap);
@@ -691,22 +715,20 @@ inline bool gpu_wait_stream_ok(bpp_ctx *ctx, hipStream_t s, bool nap) {  // fals
     return false;
   }
 }
-inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap) {
+inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap, uint32_t *hint, bool tail_spin) {
   if (!nap) {
     HIP_CHECK(hipStreamSynchronize(s));
     return;
   }
-  {  // nothing left on the stream: no marker, no nap
-    const hipError_t q = hipStreamQuery(s);
-    if (q == hipSuccess) return;
-    if (q != hipErrorNotReady) HIP_CHECK(q);
-  }
+  // (NOT hipStreamQuery as a first look: measured -- tools/microbench/wait_modes.hip -- a stream query on a busy stream leaves a
+  // helper thread of the runtime spinning until that work is done, 70-90 % of a core that no thread of the caller's shows; an
+  // event that is already complete costs the ~30 us look of gpu_wait_event at most)
   if (!ctx->ev_wait_ready) {
     HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_wait, hipEventDisableTiming));
     ctx->ev_wait_ready = true;
   }
   HIP_CHECK(hipEventRecord(ctx->ev_wait, s));
-  gpu_wait_event(ctx->ev_wait, true);
+  gpu_wait_event(ctx->ev_wait, true, hint, tail_spin);
 }
 
 static bool decompress_spill_enabled() {
@@ -1822,7 +1844,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
   }
   if (side) HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_join, 0));
   HIP_CHECK(hipGetLastError());
-  if (fetch_rng) gpu_wait_event(ctx->ev_rng, wait_naps(ctx, b.B));
+  if (fetch_rng) gpu_wait_event(ctx->ev_rng, wait_naps(ctx, b.B), &ctx->wait_hint_rng);
 }
 
 // Weight chains of all groups (src/range_proof.rs:811,849,853,894).  Chunks are independent reference batches: groups of
@@ -2382,7 +2404,7 @@ static int verify_resident_locked(bpp_ctx *ctx, uint64_t batch, int action, size
       }
     }
     fetch_results(ctx, b, want_msm, have_masks);
-    gpu_wait_stream(ctx, s, wait_naps(ctx, b.B));
+    gpu_wait_stream(ctx, s, wait_naps(ctx, b.B), &ctx->wait_hint_end);
     if (want_msm && cmode != CHAIN_HOST && ctx->h_chain_zero[0]) {
       ctx->device_chain_redraws++;
       return BPP_REDRAW_ON_HOST;
@@ -2485,7 +2507,7 @@ int verify_groups_core_once(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_
       b.have_trace = true;
     }
     fetch_results(ctx, b, want_msm, want_masks);
-    gpu_wait_stream(ctx, s, wait_naps(ctx, b.B));
+    gpu_wait_stream(ctx, s, wait_naps(ctx, b.B), &ctx->wait_hint_end);
     if (want_msm && cmode != CHAIN_HOST && ctx->h_chain_zero[0]) {
       ctx->device_chain_redraws++;
       return BPP_REDRAW_ON_HOST;

@@ -521,8 +521,12 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
     wipe(ctx->prove_pin_in.p, ctx->prove_pin_in.n);
     staging_clean = true;
     for (uint32_t q = 0; q < n_sub; q++) {
-      gpu_wait_stream(ctx, lane_stream(q), nap);  // (everything of the MSM stream lies in front of the lane stream's tail)
-      gpu_wait_stream(ctx, ctx->prove_streams[q], nap);
+      // (everything of the MSM stream lies in front of the lane stream's tail; the first of these waits is the call's: it remembers how
+      // long calls of this context take, sleeps 70 % of that in one piece and -- by the engine's own rule -- looks through the rest
+      // without napping: a prover call is something its caller waits FOR (+ 3 % proofs/s one call at a time against naps to the end;
+      // "wait" = 1 naps to the end, 0 leaves the whole wait to the runtime's spinning)
+      gpu_wait_stream(ctx, lane_stream(q), nap, q == 0 ? &ctx->wait_hint_prove : nullptr, ctx->opt.wait < 0);
+      gpu_wait_stream(ctx, ctx->prove_streams[q], nap, nullptr, ctx->opt.wait < 0);
     }
     if (fifo) gpu_wait_stream(ctx, ctx->prove_msm_stream, nap);
     arena_clean = true;  // every sub-batch's arena range was zeroed on its stream

@@ -156,6 +156,8 @@ struct bpp_comm {
   ncclComm_t comm = nullptr;
   bool own_comm = false;
   hipStream_t stream = nullptr;  // collectives and their staging copies
+  hipEvent_t ev_wait = nullptr;  // comm_wait's marker (an EVENT is polled, not the stream: a stream query on a busy stream leaves a
+                                 // helper thread of the runtime spinning, tools/microbench/wait_modes.hip)
   DevBuf<uint8_t> send1, recv1, send2, recv2;
   struct GroupSlot {  // exchange buffers of one batch of bpp_verify_sharded_groups_wave's pipeline
     DevBuf<uint8_t> send1, recv1, send2, recv2, send3, recv3;
@@ -200,8 +202,9 @@ void comm_wait(bpp_comm *c, hipStream_t cs) {
     return;
   }
   const auto t0 = std::chrono::steady_clock::now();
+  HIP_CHECK(hipEventRecord(c->ev_wait, cs));
   for (uint32_t spins = 0;; spins++) {
-    const hipError_t q = hipStreamQuery(cs);
+    const hipError_t q = hipEventQuery(c->ev_wait);
     if (q == hipSuccess) return;
     if (q != hipErrorNotReady) {
       (void)hipGetLastError();
@@ -247,6 +250,7 @@ int comm_new(bpp_ctx *ctx, ncclComm_t nc, bool own, int rank, int world, bpp_com
   c->comm = nc;
   c->own_comm = own;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return BPP_ERR_ENGINE;
+  if (hipEventCreateWithFlags(&c->ev_wait, hipEventDisableTiming) != hipSuccess) return BPP_ERR_ENGINE;
   *out = c.release();
   return BPP_OK;
 }
@@ -415,6 +419,7 @@ void bpp_comm_destroy(bpp_comm *c) {
     if (c->own_comm && c->comm) (void)rccl_api().CommDestroy(c->comm);
     (void)hipStreamDestroy(c->stream);
   }
+  if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
   delete c;
 }
 

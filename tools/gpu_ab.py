@@ -64,7 +64,8 @@ def summarise(leg, out):
         st = d.get("stages_ms") or {}
         return ("%.2f M proofs/s  %.3f ms/step  latency %.2f ms  clock %.2f GHz  host cores %.2f  chains %s | %s"
                 % (d["value"] / 1e6, d["ms_per_step"], d.get("step_latency_ms", 0), d.get("shader_clock_ghz") or 0, d.get("host_cores_busy") or 0,
-                   d.get("weight_chains"), " ".join("%s %.3f" % (k[:-3], v) for k, v in st.items() if v)))
+                   d.get("weight_chains"), " ".join("%s:%.2f(%d threads, busiest %.2f)" % (e["thread"], e["cores_busy"], e["threads"], e.get("busiest_one", 0)) for e in d.get("host_cores_busy_by_thread") or [])
+                   + " | " + " ".join("%s %.3f" % (k[:-3], v) for k, v in st.items() if v)))
     if leg == "prover":
         d = last_json(out)
         if not d:

@@ -20,6 +20,11 @@ static double thread_cpu_ms() {
   clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
   return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
 }
+static double process_cpu_ms() {  // every thread of the process: the runtime's own helpers included
+  timespec ts;
+  clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
+}
 #define CK(x)                                                         \
   do {                                                                \
     hipError_t e = (x);                                               \
@@ -43,12 +48,12 @@ int main() {
       hipError_t e = hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
       printf("hipSetDeviceFlags(hipDeviceScheduleBlockingSync) -> %s\n", hipGetErrorString(e));
     }
-    for (int mode = 0; mode < 4; mode++) {
-      double cpu = 0, wall = 0;
+    for (int mode = 0; mode < 6; mode++) {
+      double cpu = 0, wall = 0, pcpu = 0;
       const int reps = 20;
       for (int r = 0; r < reps; r++) {
         const auto t0 = std::chrono::steady_clock::now();
-        const double c0 = thread_cpu_ms();
+        const double c0 = thread_cpu_ms(), p0 = process_cpu_ms();
         hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, (uint64_t)(kernel_ms * 1e5), d);
         if (mode == 0) CK(hipStreamSynchronize(s));
         else if (mode == 1) {
@@ -57,17 +62,24 @@ int main() {
         } else if (mode == 2) {
           CK(hipEventRecord(ev_block, s));
           CK(hipEventSynchronize(ev_block));
-        } else {
+        } else if (mode == 3) {
+          CK(hipEventRecord(ev_plain, s));
+          while (hipEventQuery(ev_plain) == hipErrorNotReady) usleep(50);
+        } else if (mode == 4) {
+          while (hipStreamQuery(s) == hipErrorNotReady) usleep(50);
+        } else {  // one hipStreamQuery first (as a "nothing left?" look), then the event
+          (void)hipStreamQuery(s);
           CK(hipEventRecord(ev_plain, s));
           while (hipEventQuery(ev_plain) == hipErrorNotReady) usleep(50);
         }
         cpu += thread_cpu_ms() - c0;
+        pcpu += process_cpu_ms() - p0;
         wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       }
-      const char *names[4] = {"hipStreamSynchronize", "hipEventSynchronize (plain event)", "hipEventSynchronize (hipEventBlockingSync)",
-                              "hipEventQuery + usleep(50)"};
-      printf("%-46s kernel %.1f ms: wall %.3f ms, thread CPU %.3f ms per wait (%.0f %% of a core)\n", names[mode], kernel_ms, wall / reps,
-             cpu / reps, 100.0 * cpu / wall);
+      const char *names[6] = {"hipStreamSynchronize", "hipEventSynchronize (plain event)", "hipEventSynchronize (hipEventBlockingSync)",
+                              "hipEventQuery + usleep(50)", "hipStreamQuery + usleep(50)", "hipStreamQuery once, then hipEventQuery + usleep(50)"};
+      printf("%-54s kernel %.1f ms: wall %.3f ms, thread CPU %.3f ms per wait (%.0f %% of a core), PROCESS CPU %.3f ms (%.0f %%)\n", names[mode],
+             kernel_ms, wall / reps, cpu / reps, 100.0 * cpu / wall, pcpu / reps, 100.0 * pcpu / wall);
     }
   }
   return 0;
