@@ -496,7 +496,9 @@ int bpp_batch_secret_bytes(bpp_ctx *ctx, uint64_t batch, uint64_t *nonzero);
  * blinding-factor accumulators, the transcript-RNG states keyed with the witness -- and its page-locked staging on the way IN
  * (the witness bytes; on the way out only proofs and status words travel), which bpp_prove_batch wipes on EVERY exit path (the reference
  * keeps all of it in Zeroizing<>: src/range_proof.rs:300-301,325,438-464,542-571).  *examined = bytes looked at (0 before the
- * first prove call), *nonzero = how many of them are not zero: must read 0 between calls. */
+ * first prove call), *nonzero = how many of them are not zero: must read 0 between calls.  Not reachable from the host and
+ * therefore not counted here: the LDS of the prover's kernels (generator states keyed with the witness, raw draws, digits of
+ * witness-derived scalars) -- every such kernel clears its LDS as its last statement (kernels_prove.h: lds_wipe; ct.h). */
 int bpp_prove_secret_bytes(bpp_ctx *ctx, uint64_t *examined, uint64_t *nonzero);
 
 /* Transcript::new(label) -> 203-byte STROBE state (host helper for callers that keep merlin on their side) */
