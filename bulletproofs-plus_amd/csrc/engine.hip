@@ -506,6 +506,15 @@ struct Pipeline {
 
 void pipeline_shutdown(bpp_ctx *ctx);
 
+// What a waiting site remembers: how long its wait took the last times (microseconds, a running mean) and for WHICH work -- a key the
+// caller makes from the call's size.  A remembered time is only used for a call with the same key: a context that proved 8192
+// proofs per call and then proves 1024 must not sleep through the shorter call on the longer one's memory (it did, for one
+// build: 45 k proofs/s instead of 150 k in bench.py's prover leg, whose context had made the run's inputs before).
+struct WaitHint {
+  uint32_t us = 0;
+  uint64_t key = 0;
+};
+
 struct bpp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -527,7 +536,7 @@ struct bpp_ctx {
   bool ev_rng_ready = false;
   hipEvent_t ev_wait;  // gpu_wait_stream's marker
   bool ev_wait_ready = false;
-  uint32_t wait_hint_rng = 0, wait_hint_end = 0, wait_hint_prove = 0;  // how long a verification's two waits / a prover call's wait took lately, us (gpu_wait_event)
+  WaitHint wait_hint_rng, wait_hint_end, wait_hint_prove;  // a verification's two waits, a prover call's wait (gpu_wait_event)
   // small inputs: decompression runs beside PASS 1 on a second stream (enqueue_phase1)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork, ev_join;
@@ -671,7 +680,12 @@ inline bool wait_naps(const bpp_ctx *ctx, size_t proofs) {
 // (measured: the same build 0.3 or 1.2 cores for four waiting callers, box by box) is what a rank's idle callers cost.
 // tail_spin: after the piece slept ahead, look without napping (a call at a time then ends as promptly as under the runtime's
 // spinning wait, for ~30 % of a core instead of all of it; with nothing remembered yet the whole wait is looked through)
-inline void gpu_wait_event(hipEvent_t ev, bool nap, uint32_t *hint = nullptr, bool tail_spin = false) {
+inline void gpu_wait_event(hipEvent_t ev, bool nap, WaitHint *wh = nullptr, uint64_t key = 0, bool tail_spin = false) {
+  if (wh && wh->key != key) {  // other work than last time: nothing is known about this wait
+    wh->us = 0;
+    wh->key = key;
+  }
+  uint32_t *hint = wh ? &wh->us : nullptr;
   if (!nap) {
     HIP_CHECK(hipEventSynchronize(ev));
     return;
@@ -684,7 +698,7 @@ inline void gpu_wait_event(hipEvent_t ev, bool nap, uint32_t *hint = nullptr, bo
     const hipError_t e = hipEventQuery(ev);
     const long waited = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     if (e == hipSuccess) {
-      if (hint) *hint = (uint32_t)((3ul * *hint + (unsigned long)waited) / 4ul);
+      if (hint) *hint = *hint ? (uint32_t)((3ul * *hint + (unsigned long)waited) / 4ul) : (uint32_t)waited;
       return;
     }
     if (e != hipErrorNotReady) HIP_CHECK(e);
@@ -705,7 +719,7 @@ inline void gpu_wait_event(hipEvent_t ev, bool nap, uint32_t *hint = nullptr, bo
     nanosleep(&ts, nullptr);
   }
 }
-inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap, uint32_t *hint = nullptr, bool tail_spin = false);
+inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap, WaitHint *hint = nullptr, uint64_t key = 0, bool tail_spin = false);
 inline bool gpu_wait_stream_ok(bpp_ctx *ctx, hipStream_t s, bool nap) {  // false instead of an exception (the sharded forms carry faults along)
   try {
     gpu_wait_stream(ctx, s, nap);
@@ -715,7 +729,7 @@ inline bool gpu_wait_stream_ok(bpp_ctx *ctx, hipStream_t s, bool nap) {  // fals
     return false;
   }
 }
-inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap, uint32_t *hint, bool tail_spin) {
+inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap, WaitHint *hint, uint64_t key, bool tail_spin) {
   if (!nap) {
     HIP_CHECK(hipStreamSynchronize(s));
     return;
@@ -728,7 +742,7 @@ inline void gpu_wait_stream(bpp_ctx *ctx, hipStream_t s, bool nap, uint32_t *hin
     ctx->ev_wait_ready = true;
   }
   HIP_CHECK(hipEventRecord(ctx->ev_wait, s));
-  gpu_wait_event(ctx->ev_wait, true, hint, tail_spin);
+  gpu_wait_event(ctx->ev_wait, true, hint, key, tail_spin);
 }
 
 static bool decompress_spill_enabled() {
@@ -1844,7 +1858,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
   }
   if (side) HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_join, 0));
   HIP_CHECK(hipGetLastError());
-  if (fetch_rng) gpu_wait_event(ctx->ev_rng, wait_naps(ctx, b.B), &ctx->wait_hint_rng);
+  if (fetch_rng) gpu_wait_event(ctx->ev_rng, wait_naps(ctx, b.B), &ctx->wait_hint_rng, ((uint64_t)b.B << 32) | b.G);
 }
 
 // Weight chains of all groups (src/range_proof.rs:811,849,853,894).  Chunks are independent reference batches: groups of
@@ -2404,7 +2418,7 @@ static int verify_resident_locked(bpp_ctx *ctx, uint64_t batch, int action, size
       }
     }
     fetch_results(ctx, b, want_msm, have_masks);
-    gpu_wait_stream(ctx, s, wait_naps(ctx, b.B), &ctx->wait_hint_end);
+    gpu_wait_stream(ctx, s, wait_naps(ctx, b.B), &ctx->wait_hint_end, ((uint64_t)b.B << 32) | ((uint64_t)b.G << 2) | (uint64_t)action);
     if (want_msm && cmode != CHAIN_HOST && ctx->h_chain_zero[0]) {
       ctx->device_chain_redraws++;
       return BPP_REDRAW_ON_HOST;
@@ -2507,7 +2521,7 @@ int verify_groups_core_once(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_
       b.have_trace = true;
     }
     fetch_results(ctx, b, want_msm, want_masks);
-    gpu_wait_stream(ctx, s, wait_naps(ctx, b.B), &ctx->wait_hint_end);
+    gpu_wait_stream(ctx, s, wait_naps(ctx, b.B), &ctx->wait_hint_end, ((uint64_t)b.B << 32) | ((uint64_t)b.G << 2) | (uint64_t)((want_msm ? 1 : 0) | (want_masks ? 2 : 0)));
     if (want_msm && cmode != CHAIN_HOST && ctx->h_chain_zero[0]) {
       ctx->device_chain_redraws++;
       return BPP_REDRAW_ON_HOST;

@@ -525,8 +525,8 @@ extern "C" int bpp_prove_batch(bpp_ctx *ctx, uint64_t params, const bpp_prove_it
       // long calls of this context take, sleeps 70 % of that in one piece and -- by the engine's own rule -- looks through the rest
       // without napping: a prover call is something its caller waits FOR (+ 3 % proofs/s one call at a time against naps to the end;
       // "wait" = 1 naps to the end, 0 leaves the whole wait to the runtime's spinning)
-      gpu_wait_stream(ctx, lane_stream(q), nap, q == 0 ? &ctx->wait_hint_prove : nullptr, ctx->opt.wait < 0);
-      gpu_wait_stream(ctx, ctx->prove_streams[q], nap, nullptr, ctx->opt.wait < 0);
+      gpu_wait_stream(ctx, lane_stream(q), nap, q == 0 ? &ctx->wait_hint_prove : nullptr, ((uint64_t)B << 32) | ((uint64_t)m << 8) | t, ctx->opt.wait < 0);
+      gpu_wait_stream(ctx, ctx->prove_streams[q], nap, nullptr, 0, ctx->opt.wait < 0);
     }
     if (fifo) gpu_wait_stream(ctx, ctx->prove_msm_stream, nap);
     arena_clean = true;  // every sub-batch's arena range was zeroed on its stream

@@ -169,3 +169,54 @@ def test_device_chain_stage_profile(bpp, packed, engine, opt, cfg2):
     finally:
         engine.profile(False)
         rb.close()
+
+
+def test_wait_memory_is_per_workload(bpp, packed):
+    """A context remembers how long its calls take and sleeps most of that in one piece (csrc/engine.hip: gpu_wait_event) -- for the SAME
+    work only: one build slept through 1024-proof prover calls on the memory of the 8192-proof calls the context had made before
+    (bench.py's prover leg at a third of its rate).  A small call after large ones must take what it takes on a fresh context."""
+    import time
+    import bench
+    eng = bpp.Engine(0)
+    params = bpp.RangeParameters.init(64, 1, bpp.create_pedersen_gens_with_extension_degree(1), engine=eng)
+    big = bench.make_inputs(np, packed, params, 8192, seed=5)  # one 8192-proof prover call on this context
+    small = {k: (v[:256] if v is not None else None) for k, v in big.items()}
+
+    def prove(p, d):
+        return packed.prove(p, d["values"], d["blindings"], d["commitments"], d["min_values"], d["min_present"], d["seeds"], LABEL, d["ext"])
+
+    def timed_small(p):
+        prove(p, small)
+        t0 = time.perf_counter()
+        for _ in range(4):
+            out = prove(p, small)
+        return (time.perf_counter() - t0) / 4, out
+    for _ in range(3):
+        prove(params, big)
+    after_big, out1 = timed_small(params)
+    eng2 = bpp.Engine(0)
+    params2 = params.share(eng2)
+    fresh, out2 = timed_small(params2)
+    assert (out1 == out2).all() and (out1 == big["proofs"][:256]).all()
+    assert after_big < 2.5 * fresh + 1e-3, (after_big, fresh)
+    # the verifier: one resident 8192-proof batch, then a 64-proof one on the same context
+    rb_big = packed.ResidentBatch(params, big["proofs"], big["commitments"], big["min_values"], big["min_present"], None, LABEL)
+    rb_small = packed.ResidentBatch(params, small["proofs"][:64], small["commitments"][:64], small["min_values"][:64], small["min_present"][:64], None, LABEL)
+    eng.set_option("wait", 1)  # naps (and the remembered sleep) for calls of every size
+    try:
+        for _ in range(4):
+            rb_big.verify_only(chunk=1024)
+        rb_small.verify_only(chunk=0)
+        t0 = time.perf_counter()
+        for _ in range(4):
+            rb_small.verify_only(chunk=0)
+        small_ms = 1e3 * (time.perf_counter() - t0) / 4
+    finally:
+        eng.set_option("wait", -1)
+    assert small_ms < 3.0, small_ms  # (0.5 ms for such a call; the 8192-proof call before it takes ~2 ms)
+    rb_big.close()
+    rb_small.close()
+    params2.close()
+    eng2.close()
+    params.close()
+    eng.close()
