@@ -463,7 +463,7 @@ class Leg:
 
 def kernel_roofline(profs, alone_ms=None):
     """roofline object of k_msm_accumulate from per-step stage profiles (hipEvents on the engine's stream)"""
-    profs = [p for p in profs if p and p.get("msm_final_ms", 0) > 0]
+    profs = [p for p in profs if p and p.get("msm_accumulate_ms", 0) > 0]
     if not profs:
         return None, {}
     avg = {k: sum(p[k] for p in profs) / len(profs) for k in profs[0]}
@@ -1001,13 +1001,18 @@ def main():
 
     # ------------------------------------------------------------------ headline: BASELINE configs[1]
     # steps in flight: four (round 6: callers nap instead of spinning, a fourth costs nothing and sustains 1-3 % more over long
-    # regions); the device chains put ~2.5 ms of lone-wavefront latency on every step's critical path: five
+    # regions); the device chains put ~2.5 ms of lone-wavefront latency on every step's critical path: six
     if args.concurrency <= 0:
-        args.concurrency = 5 if chain_mode == "device" else 4
+        args.concurrency = 6 if chain_mode == "device" else 4
     R, S = max(1, args.batches_per_step), max(1, args.concurrency)
     params2 = bpp.RangeParameters.init(64, 1, G(1), engine=eng0)
     data2 = make_inputs(np, packed, params2, 1024 * R, seed=8675309 + 1000 * rank)
-    leg = Leg(bpp, packed, torch, device, params2, data2, 1024, R, S, 1024)
+    # the timed region carries the roofline kernel's two events per step and no others (profile level 2): an event at every stage
+    # boundary -- thirteen per step -- cost the headline 4 % (profiles/r06_stage_events_ab.txt); the stage table comes from a short
+    # pass with all events on AFTER the timed region, the same steps in flight (BPP_BENCH_STAGE_EVENTS=1: all events in the timed
+    # region, as until round 5; =0: none)
+    ev_level = {"1": 1, "0": 0}.get(os.environ.get("BPP_BENCH_STAGE_EVENTS", ""), 2)
+    leg = Leg(bpp, packed, torch, device, params2, data2, 1024, R, S, 1024, profile=ev_level)
     gen_s = time.perf_counter() - t_setup
     # the shader clock held during the timed region (a light kernel sees 2.4 GHz, this load 2.0-2.2): sampled over the
     # middle of it by one napping wavefront on a context of its own
@@ -1061,7 +1066,15 @@ def main():
     alone = [leg.one_step(0)[1].get("msm_accumulate_ms", 0.0) for _ in range(3)]
     alone_ms = sum(alone) / len(alone) if min(alone) > 0 else None
     sync()
-    roof, stages = kernel_roofline(profs, alone_ms)
+    stage_profs = profs
+    if ev_level == 2:  # the stage intervals: a few steps with every event on, the same steps in flight, outside the timed region
+        leg.set_profile(1)
+        leg.run_steps(len(leg.slots))
+        _, stage_profs = leg.run_steps(max(8, 2 * len(leg.slots)))
+        leg.set_profile(2)
+        sync()
+    roof, _ = kernel_roofline(profs, alone_ms)
+    _, stages = kernel_roofline(stage_profs)
     if roof and clock_ghz:
         # the multiplier's peak at the clock the chip really held: 64 lanes / clock / CU x 256 CUs x clock
         at_clock = 64 * 256 * clock_ghz * 1e9 / 1e12
@@ -1122,6 +1135,9 @@ def main():
                                                      "valu_instr_per_launch": sq["k_msm_accumulate"]["valu_instr_per_launch"]})
         out["roofline"] = roof
         out["stages_ms"] = stages
+        out["stage_events"] = {2: "timed region: the roofline kernel's two events per step only (roofline.kernel_ms); stages_ms: a pass with every "
+                                  "stage event on after the timed region, the same steps in flight",
+                               1: "every stage event in the timed region", 0: "none"}[ev_level]
         # the verifier's other dominant kernel: 15 proof points per non-aggregated 64-bit proof (A, A1, B, 6 L, 6 R)
         out["roofline_decompress"] = decompress_roofline(stages, 15 * 1024 * R, sq, clock_ghz)
     # bpp_batch_upload_packed alone: host proof/statement buffers -> parsed, packed and resident (R batches of 1024); never `value`
@@ -1172,10 +1188,10 @@ def main():
         # -------------------------------------------------------------- the headline's step with the weight chains on the OTHER side
         def other_chain_leg():
             """the A/B the line owes: the same resident step with the weight chains on the device (one wavefront per
-            reference batch, five steps in flight) when the headline kept the sponges on host cores -- or the other way round --
+            reference batch, six steps in flight) when the headline kept the sponges on host cores -- or the other way round --
             with what each costs the host"""
             other = "host-wide" if chain_mode == "device" else "device"
-            So = 5 if other == "device" else 4
+            So = 6 if other == "device" else 4
             lego = Leg(bpp, packed, torch, device, params2, data2, 1024, R, So, 1024, profile=False, options={"chain": 1 if other == "device" else 2})
             steps = max(40, min(args.steps, 120))
             lego.run_steps(2 * So)

@@ -139,7 +139,8 @@ class Engine:
         return Precomputation(self, static_points)
 
     def profile(self, on=True):
-        self.lib.bpp_profile_enable(self.ctx, 1 if on else 0)
+        """bpp_profile_enable: False / 0 off, True / 1 an event at every stage boundary, 2 the roofline kernel's two events only"""
+        self.lib.bpp_profile_enable(self.ctx, int(on))
 
     def set_option(self, name, value):
         """bpp_ctx_set_option: per-context knob (tests, A/B timing); -1 restores the engine's own rule"""

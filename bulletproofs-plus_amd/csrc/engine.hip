@@ -529,6 +529,7 @@ struct bpp_ctx {
   PinnedBuf<uint32_t> pin_small;       // staging for small host->device arrays (a pageable hipMemcpyAsync of a few
                                        // hundred bytes was measured at ~10 ms on this stack)
   bool profile = false;
+  bool profile_light = false;  // bpp_profile_enable(ctx, 2): events around the roofline kernel (k_msm_accumulate) only
   bpp_profile prof{};
   hipEvent_t ev[16];
   bool ev_ready = false;
@@ -569,7 +570,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1, prove_parts = -1, prove_waves = -1, prove_fifo = -1, chain = -1, chain_test_zero = 0, wait = -1, ct_back = -1;
+        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1, prove_parts = -1, prove_waves = -1, prove_fifo = -1, chain = -1, chain_test_zero = 0, wait = -1, ct_back = -1, chain_inline = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -624,6 +625,8 @@ const OptionName kOptions[] = {
     // how a calling thread waits for the device: 0 the runtime's wait (spins on a core until the stream is done), 1 naps between
     // looks at an event (gpu_wait), -1 the engine's rule: naps for calls of BPP_WAIT_NAP_MIN_PROOFS proofs and more
     {"wait", "BPP_WAIT", &bpp_ctx::Options::wait},
+    // the device chains (chain = 1) behind PASS 1 on the call's own stream (1) instead of a stream of their own beside the decompression (0)
+    {"chain_inline", "BPP_CHAIN_INLINE", &bpp_ctx::Options::chain_inline},
 };
 void options_from_env(bpp_ctx *c) {
   for (const OptionName &o : kOptions)
@@ -650,6 +653,9 @@ struct StageTimer {
   }
   void mark(int idx) {
     if (ctx->profile && idx < 16) {
+      // light form: the two events that bracket the roofline kernel and nothing else -- thirteen marks per step cost a step in flight
+      // among four 4 % of its rate (every mark is a barrier packet with a timestamp in the queue), two cost nothing measurable
+      if (ctx->profile_light && idx != M_ORDER && idx != M_ACC) return;
       HIP_CHECK(hipEventRecord(ctx->ev[idx], ctx->stream));
       have[idx] = true;
     }
@@ -1752,8 +1758,8 @@ void enqueue_device_chain(bpp_ctx *ctx, Batch &b, hipStream_t st) {
   ctx->device_chain_calls++;
 }
 
-// dev_chain: the weight chains follow PASS 1 as kernels (on a stream of their own beside the decompression and the weight-free
-// scalars; enqueue_phase2 joins it): nothing comes to the host and the function does not wait
+// dev_chain: the weight chains follow PASS 1 as kernels (option "chain_inline" = 0: on a stream of their own beside the decompression
+// and the weight-free scalars, joined by enqueue_phase2): nothing comes to the host and the function does not wait
 void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uint8_t *rng_dev_dst = nullptr, size_t rng_row_bytes = 0,
                     size_t rng_dst_pitch = 0, bool dev_chain = false) {
   const bool fetch_rng = rng_dev_dst == nullptr && !dev_chain;
@@ -1773,7 +1779,7 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
   // idle, so its decompression runs beside PASS 1 and the weight-free scalars on a second stream and joins before the
   // weights are needed (one 256-proof call 0.84 -> 0.79 ms).  Large inputs fill the chip either way: one stream, less
   // bookkeeping (measured: no gain, HISTORY.md 3).  Stage profiling keeps the serial order so that its intervals mean something.
-  const bool side = (ctx->opt.side_decompress >= 0 ? ctx->opt.side_decompress != 0 : b.B <= BPP_SIDE_DECOMPRESS_MAX) && !ctx->profile;
+  const bool side = (ctx->opt.side_decompress >= 0 ? ctx->opt.side_decompress != 0 : b.B <= BPP_SIDE_DECOMPRESS_MAX) && !(ctx->profile && !ctx->profile_light);
   const uint32_t n_proof_pts = b.total_dyn - b.sum_m;
   auto launch_decompress = [&](hipStream_t st) {
     hipLaunchKernelGGL(k_decompress, dim3(cdiv(n_proof_pts, 64)), dim3(64), 0, st, b.bytes.p, b.src_off.p, b.owner.p,
@@ -1813,7 +1819,10 @@ void enqueue_phase1(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool pass1_only, uin
   }
   tm.mark(M_TRANSCRIPTS);
   if (dev_chain) {
-    if (ctx->profile) {  // stage profiling keeps the serial order so that its intervals mean something
+    // On the call's own stream (the rule): measured against a high-priority stream of their own beside the decompression -- the same
+    // rate once one more step is in flight, and the cross-stream events of that form leave a helper thread of the runtime at 80 %
+    // of a core (profiles/r06_chain_inline_ab.txt); "chain_inline" = 0 brings the side stream back
+    if (ctx->profile || ctx->opt.chain_inline != 0) {
       enqueue_device_chain(ctx, b, s);
       tm.mark(M_CHAIN);
     } else {
@@ -3026,6 +3035,7 @@ int bpp_prove_secret_bytes(bpp_ctx *ctx, uint64_t *examined, uint64_t *nonzero) 
 int bpp_profile_enable(bpp_ctx *ctx, int on) {
   if (!ctx) return BPP_ERR_BAD_HANDLE;
   ctx->profile = on != 0;
+  ctx->profile_light = on == 2;
   return BPP_OK;
 }
 
