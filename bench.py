@@ -1008,9 +1008,10 @@ def main():
     params2 = bpp.RangeParameters.init(64, 1, G(1), engine=eng0)
     data2 = make_inputs(np, packed, params2, 1024 * R, seed=8675309 + 1000 * rank)
     # the timed region carries the roofline kernel's two events per step and no others (profile level 2): an event at every stage
-    # boundary -- thirteen per step -- cost the headline 4 % (profiles/r06_stage_events_ab.txt); the stage table comes from a short
-    # pass with all events on AFTER the timed region, the same steps in flight (BPP_BENCH_STAGE_EVENTS=1: all events in the timed
-    # region, as until round 5; =0: none)
+    # boundary -- thirteen per step -- read 0-4 % lower on one box and no different on another (profiles/r06_stage_events_ab.txt:
+    # inside the +-5 % that identical runs differ by, profiles/r06_run_to_run.txt); the stage table comes from a short pass with
+    # all events on AFTER the timed region, the same steps in flight (BPP_BENCH_STAGE_EVENTS=1: all events in the timed region,
+    # as until round 5; =0: none)
     ev_level = {"1": 1, "0": 0}.get(os.environ.get("BPP_BENCH_STAGE_EVENTS", ""), 2)
     leg = Leg(bpp, packed, torch, device, params2, data2, 1024, R, S, 1024, profile=ev_level)
     gen_s = time.perf_counter() - t_setup

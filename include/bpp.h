@@ -460,8 +460,8 @@ typedef struct {
   float masks_ms; /* k_masks (mask recovery, src/range_proof.rs:941-969); 0 for VerifyOnly */
   float chain_device_ms; /* the weight chains as kernels (option "chain" = 1: k_weight_chain + k_chain_finish); 0 with the chains on the host */
 } bpp_profile;
-/* on = 1: an event at every stage boundary (thirteen per verification: costs a call among several in flight ~4 % of its rate);
- * on = 2: the two events around the roofline kernel only (msm_accumulate_ms; every other interval reads 0): free */
+/* on = 1: an event at every stage boundary (thirteen per verification);
+ * on = 2: the two events around the roofline kernel only (msm_accumulate_ms; every other interval reads 0) */
 int bpp_profile_enable(bpp_ctx *ctx, int on);
 int bpp_profile_get(bpp_ctx *ctx, bpp_profile *out);
 
