@@ -653,8 +653,8 @@ struct StageTimer {
   }
   void mark(int idx) {
     if (ctx->profile && idx < 16) {
-      // light form: the two events that bracket the roofline kernel and nothing else -- thirteen marks per step cost a step in flight
-      // among four 4 % of its rate (every mark is a barrier packet with a timestamp in the queue), two cost nothing measurable
+      // light form: the two events that bracket the roofline kernel and nothing else (every mark is a barrier packet with a
+      // timestamp in the queue; thirteen per step read 0-4 % lower than two, inside the run-to-run spread: profiles/r06_stage_events_ab.txt)
       if (ctx->profile_light && idx != M_ORDER && idx != M_ACC) return;
       HIP_CHECK(hipEventRecord(ctx->ev[idx], ctx->stream));
       have[idx] = true;
