@@ -5,6 +5,7 @@
 #include "merlin.h"
 #include "blake2b.h"
 #include "chain_host.h"
+#include "wkeccak.h"
 #include "recode.h"
 #include "upload_host.h"
 // the uniform-access scalar multiplication (ct.h) with its table reads RECORDED: BPP_CT_TOUCH(entry) appends the entry index
@@ -151,6 +152,19 @@ int ht_weight_chains(const uint8_t *rng /* [width][n][32] */, uint32_t n, uint32
   if (width == 4) { if (!__builtin_cpu_supports("avx2")) return 0; weights_chain_x4(in, n, o); return 1; }
   if (width == 8) { if (!(__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl"))) return 0; weights_chain_x8(in, n, o); return 1; }
   return -1; }
+// the WIDE forms (round 6: the host squeezes 64 bytes per proof, the device reduces them): `width` chains of n proofs each, the 64
+// PRF bytes per proof as the sponge leaves them.  width 1 = wide_chain_single, 4 / 8 = the lock-step bundles (0 when the CPU lacks them)
+int ht_wide_chains(const uint8_t *rng /* [width][n][32] */, uint32_t n, uint32_t width, uint8_t *out /* [width][n][64] */) {
+  const uint8_t *in[8];
+  uint8_t *o[8];
+  for (uint32_t k = 0; k < width && k < 8; k++) { in[k] = rng + (size_t)k * n * 32; o[k] = out + (size_t)k * n * 64; }
+  if (width == 1) { wide_chain_single(in[0], n, o[0]); return 1; }
+  if (width == 4) { if (!__builtin_cpu_supports("avx2")) return 0; wide_chain_x4(in, n, o); return 1; }
+  if (width == 8) { if (!(__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl"))) return 0; wide_chain_x8(in, n, o); return 1; }
+  return -1; }
+// bit interleaving of wkeccak.h (host-evaluable): halves of a word and back
+void ht_wk_halves(uint64_t w, uint32_t out2[2]) { out2[0] = wk_half(w, 0); out2[1] = wk_half(w, 1); }
+uint64_t ht_wk_word(uint32_t even, uint32_t odd) { return wk_word(even, odd); }
 // one chain: form 0 = merlin.h's generic sponge, 1 = fast form without BMI, 2 = fast form compiled for BMI (0 when the CPU lacks it),
 // 3 = whatever the engine picks at run time
 int ht_weight_chain_single(const uint8_t *rng /* [n][32] */, uint32_t n, uint32_t form, uint8_t *out /* [n][32] */) {

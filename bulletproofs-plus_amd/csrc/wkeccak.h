@@ -71,6 +71,7 @@ struct WkLanes {
   uint32_t rc_mask;          // all-ones in the two lanes that hold word 0
 };
 
+#if defined(__HIPCC__)  // (everything below is device code; the interleaving helpers above also serve the host tests)
 __device__ __forceinline__ uint32_t wk_lds_addr(const uint32_t *lds) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)lds;
 }
@@ -277,5 +278,7 @@ __device__ __forceinline__ void wk_store(uint64_t *st25, uint32_t *lds, uint32_t
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+
+#endif  // __HIPCC__
 
 }  // namespace bpp

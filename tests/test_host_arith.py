@@ -183,6 +183,49 @@ def test_weight_chains_lockstep(ht):
                 assert out.raw[k * n * 32:(k + 1) * n * 32] == want, (n, width, k)
 
 
+def test_wide_chains_and_bit_interleaving(ht):
+    """round 6: (1) the WIDE host chains (chain_host.h: the sponge's 64 PRF bytes per proof handed to the device, which reduces them:
+    option chain = 2) -- single and lock-step forms -- reduced mod l here must be the weights of the ordinary forms, i.e. the oracle's;
+    (2) wkeccak.h's bit interleaving: even / odd halves of a word and back, and a rotation by r as two 32-bit rotations (by r / 2; an
+    odd r swaps the halves and rotates the new even half one further) -- the identity the one-wavefront Keccak-f rests on"""
+    import ctypes
+    from oracle.pyref import protocol as O
+    ht.ht_wide_chains.restype = ctypes.c_int
+    for n in (1, 4, 40, 129):
+        for width in (1, 4, 8):
+            rng = b"".join(_r(b"wide%d" % width, 1000 * n + i) for i in range(width * n))
+            out = ctypes.create_string_buffer(64 * width * n)
+            rc = ht.ht_wide_chains(rng, n, width, out)
+            if rc == 0:
+                continue  # (CPU without that vector instruction set)
+            assert rc == 1
+            for k in range(width):
+                t = M.Transcript(b"Bulletproofs+ verifier weights")
+                for i in range(n):
+                    t.append_message(b"proof", rng[(k * n + i) * 32:(k * n + i + 1) * 32])
+                wr = t.build_rng().finalize(O.NullRng())
+                for i in range(n):
+                    wide = out.raw[(k * n + i) * 64:(k * n + i + 1) * 64]
+                    assert wide == wr.fill_bytes(64), (n, width, k, i)
+    ht.ht_wk_halves.argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
+    ht.ht_wk_word.restype = ctypes.c_uint64
+    ht.ht_wk_word.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    rol32 = lambda v, k: ((v << (k % 32)) | (v >> ((32 - k % 32) % 32))) & 0xFFFFFFFF if k % 32 else v
+    words = [0, 1, 2, 1 << 63, 0x0123456789ABCDEF, 0xFFFFFFFF00000000, 0xAAAAAAAAAAAAAAAA] + [int.from_bytes(_r(b"wk", i)[:8], "little") for i in range(20)]
+    for w in words:
+        h = (ctypes.c_uint32 * 2)()
+        ht.ht_wk_halves(w, h)
+        even = sum(((w >> (2 * j)) & 1) << j for j in range(32))
+        odd = sum(((w >> (2 * j + 1)) & 1) << j for j in range(32))
+        assert (h[0], h[1]) == (even, odd)
+        assert ht.ht_wk_word(h[0], h[1]) == w
+        for r in (1, 2, 3, 27, 28, 44, 55, 62, 63):
+            rot = ((w << r) | (w >> (64 - r))) & (2**64 - 1)
+            k = r // 2
+            e2, o2 = (rol32(h[0], k), rol32(h[1], k)) if r % 2 == 0 else (rol32(h[1], k + 1), rol32(h[0], k))
+            assert ht.ht_wk_word(e2, o2) == rot, (hex(w), r)
+
+
 def test_scalar_inversions_agree(ht):
     """divsteps inversion (sc_invert_vartime_plain) and the bit-at-a-time binary GCD it replaced, against pow(a, -1, l):
     random values, small values, values next to l and powers of two (long runs of zero bits stress the divstep batching)"""
