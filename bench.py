@@ -64,9 +64,11 @@ def parse_args():
     ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_step", type=int,
                     default=int(os.environ.get("BPP_BENCH_BATCHES_PER_LAUNCH", "64")),
                     help="independent 1024-proof reference batches verified by one step (one engine call)")
-    ap.add_argument("--preheat-ms", type=float, default=float(os.environ.get("BPP_BENCH_PREHEAT_MS", "150")),
-                    help="untimed run of the headline leg before the --warmup steps: the clock governor needs ~50 ms of full load "
-                         "to reach the clock it then sustains (tools/clock_ramp.py), a 20-step timed region lasts 55 ms")
+    ap.add_argument("--preheat-ms", type=float, default=float(os.environ.get("BPP_BENCH_PREHEAT_MS", "1000")),
+                    help="untimed run of the headline leg before the --warmup steps: the clock governor needs ~50 ms of full load to "
+                         "reach the clock it then sustains (tools/clock_ramp.py), and 0.3-0.4 s after a load starts from idle the chip "
+                         "holds back for ~40 ms (tools/rate_ramp.py: one 100 ms window at 17 M proofs/s and 2.15 GHz among windows at "
+                         "27.5 M and 2.29 GHz) -- the timed region starts behind both; a service under load sees neither")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (cfg3, 4096-wide, latency, prover)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU work per part (one thread / all cores) of the headline's cpu_baseline")
@@ -489,10 +491,20 @@ def kernel_roofline(profs, alone_ms=None):
     return out, {n: round(v, 4) for n, v in avg.items() if n.endswith("_ms")}
 
 
-def timed(leg, steps, warmup, sync, clock=None):
+SIDE_PREHEAT_MS = float(os.environ.get("BPP_BENCH_SIDE_PREHEAT_MS", "600"))  # the extra legs' untimed run (see --preheat-ms)
+
+
+def timed(leg, steps, warmup, sync, clock=None, preheat_ms=0.0):
     """`clock` (optional): callable that samples the shader clock; it runs on its own thread DURING the timed steps (one
-    napping wavefront on its own context: nothing is added to the timed work) and its result is returned as 4th value"""
+    napping wavefront on its own context: nothing is added to the timed work) and its result is returned as 4th value.
+    `preheat_ms`: the untimed run before the region lasts at least this long (more warm-up steps at the rate of the first)."""
+    t_w = time.perf_counter()
     leg.run_steps(warmup)
+    if preheat_ms > 0 and warmup > 0:
+        spent = time.perf_counter() - t_w
+        more = int((preheat_ms * 1e-3 - spent) / max(spent / warmup, 1e-5))
+        if more > 0:
+            leg.run_steps(more)
     sync()
     ghz = []
     th = threading.Thread(target=lambda: ghz.append(clock())) if clock else None
@@ -869,7 +881,7 @@ def main():
         S3 = 1 if only else int(os.environ.get("BPP_BENCH_CFG3_INFLIGHT", "4"))
         d3 = make_inputs(np, packed, p3, 256 * R3, seed=8675309 + 3)
         leg3 = Leg(bpp, packed, torch, device, p3, d3, 256, R3, S3, 256)
-        el3, lat3, pr3 = timed(leg3, steps, warmup, sync)
+        el3, lat3, pr3 = timed(leg3, steps, warmup, sync, preheat_ms=0.0 if only else SIDE_PREHEAT_MS)
         sync()
         al3 = [leg3.one_step(0)[1].get("msm_accumulate_ms", 0.0) for _ in range(3)]
         roof3, st3 = kernel_roofline(pr3, sum(al3) / 3 if min(al3) > 0 else None)
@@ -888,7 +900,7 @@ def main():
         k_masks; no weight chains, no PASS 2, no MSM.  Masks come back as arrays and are checked against the prover's blindings."""
         Rr, Sr = max(1, args.batches_per_step), max(1, args.concurrency)
         legr = Leg(bpp, packed, torch, device, params, data, 1024, Rr, Sr, 1024, action=int(bpp.VerifyAction.RecoverOnly))
-        elr, latr, prr = timed(legr, steps, warmup, sync)
+        elr, latr, prr = timed(legr, steps, warmup, sync, preheat_ms=SIDE_PREHEAT_MS)
         sync()
         masks, present = legr._call(legr.slots[0][3])
         ok = bool(present.all()) and bool((masks[:, 0, :] == data["blindings"][legr.data_idx[0], 0, 0, :]).all())
@@ -1022,6 +1034,13 @@ def main():
     # Untimed pre-heat: right after a load increase the chip runs at 1.9-2.0 GHz and takes ~50 ms of full load to reach the
     # 2.3+ GHz it then sustains (tools/clock_ramp.py); 5 warm-up steps are 15 ms.  Without this a 20-step timed region (55 ms)
     # runs mostly at the ramp's clock and reads 10-15 % low; `shader_clock_ghz` in the line is what the timed region held.
+    # Round 6: the rate per 100 ms window of a leg that starts from idle (tools/rate_ramp.py, profiles/r06_rate_ramp.jsonl) is flat
+    # at 27.5 M proofs/s from the second window on EXCEPT one window 0.3-0.4 s after the start (17 M at 2.15 GHz: the power
+    # controller's answer to the step in load); with 150 ms of pre-heat that window fell inside a 256-step region (0.66 s) and
+    # cost it 6-8 % (profiles/r06_preheat_ab.txt: 25.0-25.4 M against 27.3-27.8 M, whatever the wait policy or the chain form; the
+    # same step as a LATER leg of the same process read 27 M all along, profiles/r06_position_ab.txt).  1000 ms puts the region behind it.
+    if float(os.environ.get("BPP_BENCH_COOL_MS", "0")) > 0:  # (an experiment knob: idle time between input generation and the pre-heat)
+        time.sleep(float(os.environ["BPP_BENCH_COOL_MS"]) / 1e3)
     sync()  # under torch.distributed the first barrier builds the communicator (100s of ms): not between warm-up and timing
     step_error, elapsed, lat, profs, clock_ghz = None, 0.0, [], [], None
     pool_cpu0 = proc_cpu0 = 0
@@ -1177,8 +1196,13 @@ def main():
             extra["wide"] = {"error": "%s: %s" % (type(e).__name__, e), "rccl_ranks": world}
         dog.cancel()
 
+    legs_wanted = [x for x in os.environ.get("BPP_BENCH_EXTRA_LEGS", "").split(",") if x]  # (A/B runs: only these extra legs)
+
     def side_leg(name, fn):
         """an extra leg: its failure is reported inside its own object, the headline line is printed either way"""
+        if legs_wanted and name not in legs_wanted:
+            extra[name] = {"skipped": "BPP_BENCH_EXTRA_LEGS"}
+            return False
         try:
             extra[name] = fn()
         except Exception as e:  # noqa: BLE001
@@ -1192,20 +1216,24 @@ def main():
             reference batch, six steps in flight) when the headline kept the sponges on host cores -- or the other way round --
             with what each costs the host"""
             other = "host-wide" if chain_mode == "device" else "device"
+            if os.environ.get("BPP_BENCH_OTHER_CHAIN") == "same":  # (a position check: the headline's own step once more, later in the run)
+                other = chain_mode
             So = 6 if other == "device" else 4
-            lego = Leg(bpp, packed, torch, device, params2, data2, 1024, R, So, 1024, profile=False, options={"chain": 1 if other == "device" else 2})
+            lego = Leg(bpp, packed, torch, device, params2, data2, 1024, R, So, 1024, profile=False,
+                       options={"chain": {"host": 0, "device": 1, "host-wide": 2}[other]})
             steps = max(40, min(args.steps, 120))
-            lego.run_steps(2 * So)
-            sync()
-            pool0, cpu0, t0 = bpp.host_pool_cpu_ns(), time.process_time(), time.perf_counter()
-            lego.run_steps(steps)
-            sync()
-            el = time.perf_counter() - t0
+            clk = bpp.Engine(local_rank)
+            timed(lego, 1, 2 * So, sync, preheat_ms=SIDE_PREHEAT_MS)
+            pool0, cpu0 = bpp.host_pool_cpu_ns(), time.process_time()
+            try:
+                el, _, _, ghz = timed(lego, steps, 0, sync, clock=lambda: bpp.shader_clock_ghz(clk, int(1e3 * max(5.0, min(200.0, 1.5 * steps)))))
+            finally:
+                clk.close()
             cpu_ms, pool_ms = (time.process_time() - cpu0) * 1e3 / steps, (bpp.host_pool_cpu_ns() - pool0) / 1e6 / steps
             lego.close()
             return {"workload": "the headline's step (64 reference batches of 1024 proofs, resident) with weight chains = %s, %d steps in flight, "
                                 "%d timed steps" % (other, So, steps), "weight_chains": other, "proofs_per_s": 1024 * R * steps / el,
-                    "ms_per_step": 1e3 * el / steps, "steps": steps, "host_cores_busy": cpu_ms / (1e3 * el / steps),
+                    "ms_per_step": 1e3 * el / steps, "steps": steps, "shader_clock_ghz": ghz, "host_cores_busy": cpu_ms / (1e3 * el / steps),
                     "host_chain_cpu_ms_per_step": pool_ms, "headline_weight_chains": chain_mode}
         side_leg("other_chain", other_chain_leg)
         # -------------------------------------------------------------- configs[2]: 256 x aggregation-8
@@ -1219,7 +1247,7 @@ def main():
             Sw = int(os.environ.get("BPP_BENCH_WIDE_INFLIGHT", "12"))
             legw = Leg(bpp, packed, torch, device, params2, data2, 4096, 1, Sw, 0, profile=False)
             nw = 40 * Sw
-            elw, latw, _ = timed(legw, nw, 12 * Sw, sync)  # the rate: no stage events; warm-up long enough for the clock (as the headline's pre-heat)
+            elw, latw, _ = timed(legw, nw, 12 * Sw, sync, preheat_ms=SIDE_PREHEAT_MS)  # the rate: no stage events; untimed run as the headline's pre-heat
             legw.set_profile(True)
             _, _, prw = timed(legw, 4 * Sw, Sw, sync)  # stage times with the same calls in flight
             sync()
@@ -1264,15 +1292,9 @@ def main():
                                           "Horner doublings)")
         side_leg("latency", latency_leg)
         # -------------------------------------------------------------- many callers, one 256-proof verify_batch call each
-        try:
-            extra["small_calls"] = small_calls_leg(bpp, packed, np, local_rank, params2, data2)
-        except Exception as e:  # noqa: BLE001 - a side leg: reported, never allowed to take the line down
-            extra["small_calls"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        side_leg("small_calls", lambda: small_calls_leg(bpp, packed, np, local_rank, params2, data2))
+        side_leg("recover_only", lambda: recover_only_leg(data2, params2))
         # -------------------------------------------------------------- configs[4]: batch prover
-        try:
-            extra["recover_only"] = recover_only_leg(data2, params2)
-        except Exception as e:  # noqa: BLE001 - the headline is never held hostage by an extra leg
-            extra["recover_only"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if side_leg("prover", prover_leg) and profiler_legs:
             tr = measure_traffic("k_fb_part", "prover")
             if tr:  # the counters are per dispatch: scaled to the launches of one call, like achieved / algorithmic_bytes

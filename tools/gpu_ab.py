@@ -11,6 +11,7 @@ differ by several per cent, and so does one box over minutes).  One summary line
 
 Legs (what is run and what the summary shows):
   headline          bench.py --no-extra --no-cpu-baseline --no-traffic         proofs/s, ms per step, clock, host cores, stage times
+  headline-again    the headline, then the SAME step as a later leg of the process  both rates and clocks (does the position matter?)
   prover            tools/bench_prover_leg.py (configs[4], one call at a time)  proofs/s, ms per call, MSM event time
   prover-inflight   tools/bench_prove_concurrent.py (1, 2, 4 calls in flight)   proofs/s per number of calls in flight
   latency           tools/bench_latency.py --no-cpu                             median ms per call and size
@@ -22,6 +23,7 @@ Examples (the A/Bs on record in HISTORY.md, as they would be run today):
   tools/gpu_ab.py --leg prover "BPP_CT=1" "BPP_CT=2 BPP_CT_BACK=1" "BPP_CT=2 BPP_CT_BACK=2"
   tools/gpu_ab.py --leg headline "BPP_STATIC_GEMM=0" "BPP_STATIC_GEMM=1"
   tools/gpu_ab.py --leg prover "BPP_PROVE_SUBS=1" "BPP_PROVE_SUBS=2" "BPP_PROVE_SUBS=3"
+  tools/gpu_ab.py --leg headline-again "--preheat-ms 150" "--preheat-ms 1000" "--preheat-ms 4000"
 """
 import argparse
 import json
@@ -66,6 +68,14 @@ def summarise(leg, out):
                 % (d["value"] / 1e6, d["ms_per_step"], d.get("step_latency_ms", 0), d.get("shader_clock_ghz") or 0, d.get("host_cores_busy") or 0,
                    d.get("weight_chains"), " ".join("%s:%.2f(%d threads, busiest %.2f)" % (e["thread"], e["cores_busy"], e["threads"], e.get("busiest_one", 0)) for e in d.get("host_cores_busy_by_thread") or [])
                    + " | " + " ".join("%s %.3f" % (k[:-3], v) for k, v in st.items() if v)))
+    if leg == "headline-again":
+        d = last_json(out)
+        if not d:
+            return "no line"
+        o = (d.get("extra") or {}).get("other_chain", {})
+        return "headline %.2f M proofs/s at %.3f GHz (%s, %d steps) | as a later leg: %.2f M at %.3f GHz %s" % (
+            d["value"] / 1e6, d.get("shader_clock_ghz") or 0, d.get("weight_chains"), d["steps"], o.get("proofs_per_s", 0) / 1e6,
+            o.get("shader_clock_ghz") or 0, o.get("error", ""))
     if leg == "prover":
         d = last_json(out)
         if not d:
@@ -84,7 +94,7 @@ def summarise(leg, out):
 
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--leg", choices=("headline", "prover", "prover-inflight", "latency", "cmd"), default="headline")
+    ap.add_argument("--leg", choices=("headline", "headline-again", "prover", "prover-inflight", "latency", "cmd"), default="headline")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--out", default=os.path.join("gpurun_out", "ab.txt"))
     ap.add_argument("--args", default="", help="arguments every arm gets (after the leg's own)")
@@ -93,6 +103,7 @@ def main():
     ap.add_argument("arms", nargs="+")
     a = ap.parse_args()
     base = {"headline": [sys.executable, "bench.py", "--no-extra", "--no-cpu-baseline", "--no-traffic"],
+            "headline-again": [sys.executable, "bench.py", "--no-cpu-baseline", "--no-traffic"],
             "prover": [sys.executable, "tools/bench_prover_leg.py"], "prover-inflight": [sys.executable, "tools/bench_prove_concurrent.py"],
             "latency": [sys.executable, "tools/bench_latency.py", "--no-cpu"], "cmd": shlex.split(a.cmd)}[a.leg]
     if not base:
@@ -102,6 +113,8 @@ def main():
         for rep in range(1, a.reps + 1):
             for arm in a.arms:
                 env, args = split_arm(arm)
+                if a.leg == "headline-again":
+                    env = dict({"BPP_BENCH_EXTRA_LEGS": "other_chain", "BPP_BENCH_OTHER_CHAIN": "same"}, **env)
                 cmd = base + shlex.split(a.args) + args
                 try:
                     r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=a.timeout)
