@@ -500,11 +500,14 @@ def timed(leg, steps, warmup, sync, clock=None, preheat_ms=0.0):
     `preheat_ms`: the untimed run before the region lasts at least this long (more warm-up steps at the rate of the first)."""
     t_w = time.perf_counter()
     leg.run_steps(warmup)
-    if preheat_ms > 0 and warmup > 0:
+    done = warmup
+    while preheat_ms > 0 and done > 0:  # (a loop: the first estimate is off when the warm-up did not fill every slot)
         spent = time.perf_counter() - t_w
-        more = int((preheat_ms * 1e-3 - spent) / max(spent / warmup, 1e-5))
-        if more > 0:
-            leg.run_steps(more)
+        more = int((preheat_ms * 1e-3 - spent) / max(spent / done, 1e-5))
+        if more <= 0:
+            break
+        leg.run_steps(max(more, len(leg.slots)))
+        done += max(more, len(leg.slots))
     sync()
     ghz = []
     th = threading.Thread(target=lambda: ghz.append(clock())) if clock else None

@@ -17,6 +17,33 @@ def _leg(bench, slots, one_step):
     return leg
 
 
+def test_timed_region_is_exact_whatever_the_preheat():
+    """CPU: timed() runs the warm-up, stretches it to `preheat_ms` at the warm-up's own rate, then times EXACTLY `steps` steps
+    between two synchronisations; the pre-heat never leaks into the count or the latencies of the region"""
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    lock, stamps, syncs = threading.Lock(), [], []
+
+    def step(slot):
+        time.sleep(0.002)
+        with lock:
+            stamps.append(time.perf_counter())
+        return 0.002, {}
+    for slots, preheat_ms in ((1, 0.0), (4, 0.0), (1, 60.0), (4, 60.0)):
+        del stamps[:], syncs[:]
+        leg = _leg(bench, slots, step)
+        t0 = time.perf_counter()
+        el, lat, profs = bench.timed(leg, 12, 3, lambda: syncs.append(time.perf_counter()), preheat_ms=preheat_ms)
+        assert len(lat) == len(profs) == 12 and len(syncs) == 2
+        inside = [t for t in stamps if syncs[0] <= t <= syncs[1]]
+        assert len(inside) == 12 and len(stamps) >= 15
+        assert syncs[0] - t0 >= preheat_ms * 1e-3 * 0.9  # the region starts behind the pre-heat
+        assert 0 < el <= syncs[1] - syncs[0] + 1e-3
+        if preheat_ms:
+            assert len(stamps) > 15  # more untimed steps than the warm-up alone
+
+
 def test_run_steps_propagates_worker_exceptions_and_counts():
     """CPU: Leg.run_steps with stand-in steps -- every requested step is accounted for, the first exception of any worker
     thread is re-raised on the caller (a thread that dies silently used to leave the step counter handing out its steps)"""
