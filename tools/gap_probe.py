@@ -26,6 +26,16 @@ def main():
     K = int(os.environ.get("GAP_STEPS", "20"))
     leg = bench.Leg(bpp, packed, torch, device, params, data, 1024, 64, S, 1024, profile=False)
     leg.run_steps(400)
+    # GAP_STAGGER_US: worker k of a timed region starts k x this late (do steps that start in phase stay in phase?)
+    stagger = float(os.environ.get("GAP_STAGGER_US", "0")) * 1e-6
+    one, first = leg.one_step, {}
+
+    def staggered(slot):
+        if stagger and first.get(slot):
+            first[slot] = False
+            time.sleep(slot * stagger)
+        return one(slot)
+    leg.one_step = staggered
     for gap_ms in [float(x) for x in os.environ.get("GAP_LIST_MS", "0,0.2,0.5,1,2,5,20,100").split(",")]:
         rates = []
         for _ in range(5):
@@ -33,6 +43,7 @@ def main():
             torch.cuda.synchronize(device)
             if gap_ms:
                 time.sleep(gap_ms * 1e-3)
+            first.update({k: True for k in range(S)})
             t0 = time.perf_counter()
             leg.run_steps(K)
             torch.cuda.synchronize(device)
