@@ -220,3 +220,69 @@ def test_wait_memory_is_per_workload(bpp, packed):
     eng2.close()
     params.close()
     eng.close()
+
+
+@pytest.mark.parametrize("n,m,t", [(16, 2, 4), (8, 1, 5), (64, 1, 6), (8, 4, 6), (64, 2, 6)])
+def test_highest_extension_degrees(bpp, packed, n, m, t):
+    """src/generators/pedersen_gens.rs:42-55: extension degrees up to AddFiveBasePoints (t = 6); the reference's own tests stop at
+    t = 3 (tests/ristretto.rs:25-150).  t distinct blinding factors per commitment; prover bytes == the C oracle's in every `ct`
+    setting, the proofs verify with the weight chains in each of their three forms (weights == the oracle's), the masks come back
+    (m = 1), a flipped bit is VerificationFailed"""
+    count = 9
+    eng = bpp.Engine(0)
+    params = bpp.RangeParameters.init(n, m, bpp.create_pedersen_gens_with_extension_degree(t), engine=eng)
+    cp = cport.Params(n, m, t)
+    rng = np.random.default_rng(4200 + 100 * t + 10 * m + n)
+    rounds = (n * m).bit_length() - 1
+    values = rng.integers(0, 1 << min(63, n - 1), size=(count, m), dtype=np.uint64)
+    values[0, 0] = (1 << n) - 1 if n < 64 else np.uint64(2**64 - 1)  # the largest value of the range
+    bl = rng.integers(0, 256, size=(count, m, t, 32), dtype=np.uint8)
+    bl[..., 31] &= 0x0f
+    bl[..., 0] |= 1
+    min_values = values // np.uint64(3)
+    min_present = (rng.integers(0, 3, size=(count, m)) > 0).astype(np.uint8)
+    min_values[min_present == 0] = 0
+    seeds = None
+    if m == 1:
+        seeds = rng.integers(0, 256, size=(count, 32), dtype=np.uint8)
+        seeds[:, 31] &= 0x0f
+    ext = rng.integers(0, 256, size=(count, 32 * (rounds + 3)), dtype=np.uint8)
+    comm = packed.commit(params, values.reshape(-1), bl.reshape(count * m, t, 32)).reshape(count, m, 32)
+    out = {}
+    for ct in (0, 1, 2):
+        eng.set_option("ct", ct)
+        out[ct] = packed.prove(params, values, bl, comm, min_values, min_present, seeds, LABEL, ext)
+    eng.set_option("ct", -1)
+    proofs = out[1]
+    assert (out[0] == proofs).all() and (out[2] == proofs).all() and proofs.shape[1] == 1 + 32 * (t + 5 + 2 * rounds)
+    mins = [[int(v) if p else None for v, p in zip(min_values[i], min_present[i])] for i in range(count)]
+    for i in (0, 4, 8):
+        want, c = cp.prove(LABEL, [int(x) for x in values[i]], [[bytes(bl[i, j, k]) for k in range(t)] for j in range(m)], mins[i],
+                           bytes(seeds[i]) if seeds is not None else None, bytes(ext[i]))
+        assert bytes(proofs[i]) == want and [bytes(x) for x in comm[i]] == c
+    items = [{"proof": bytes(proofs[i]), "commitments": [bytes(x) for x in comm[i]], "min_values": mins[i],
+              "seed_nonce": bytes(seeds[i]) if seeds is not None else None, "label": LABEL} for i in range(count)]
+    rc, omasks, tr = cp.verify(items, action=int(bpp.VerifyAction.RecoverAndVerify) if seeds is not None else 0, want_trace=True)
+    assert rc == 0
+    for chain in (0, 1, 2):
+        eng.set_option("chain", chain)
+        rb = packed.ResidentBatch(params, proofs, comm, min_values, min_present, seeds, LABEL)
+        if seeds is not None:
+            masks, present = rb.verify_arrays(int(bpp.VerifyAction.RecoverAndVerify), 0)
+            assert bool(present.all()) and (masks == bl[:, 0]).all()
+            assert [[bytes(masks[i, k]) for k in range(t)] for i in range(count)] == omasks
+        else:
+            rb.verify_only(0)
+        assert rb.trace(3) == tr["weights"] and rb.trace(6) == bytes(32)
+        rb.close()
+    eng.set_option("chain", -1)
+    bad = proofs.copy()
+    bad[5, 1 + 32 * t + 32 * 3 + 7] ^= 0x10  # r1 of proof 5
+    rb = packed.ResidentBatch(params, bad, comm, min_values, min_present, seeds, LABEL)
+    with pytest.raises(bpp.ProofError) as e:
+        rb.verify_only(0)
+    assert e.value.kind == bpp.ProofErrorKind.VerificationFailed
+    rb.close()
+    cp.close()
+    params.close()
+    eng.close()
