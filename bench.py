@@ -58,7 +58,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    # steps in flight per GPU: 0 = the harness' rule (four; five with the weight chains on the device), see main()
+    # steps in flight per GPU: 0 = the harness' rule (four; six with the weight chains on the device), see main()
     ap.add_argument("--concurrency", type=int, default=int(os.environ.get("BPP_BENCH_CONCURRENCY", "0")),
                     help="steps in flight per GPU (one engine/stream + one host thread each)")
     ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_step", type=int,
