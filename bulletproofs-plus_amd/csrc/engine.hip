@@ -570,7 +570,7 @@ struct bpp_ctx {
   // would race with it); bpp_ctx_set_option changes them afterwards.
   struct Options {
     int transcripts_wave = -1, tables_wave = -1, side_decompress = -1, msm_c_bias = -1, msm_c_max = -1, msm_c_add = -1, msm_rc2 = -1, msm_quad = -1, msm_final_quad = -1,
-        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1, prove_parts = -1, prove_waves = -1, prove_fifo = -1, chain = -1, chain_test_zero = 0, wait = -1, ct_back = -1, chain_inline = -1;
+        fb_threads = -1, prove_subs = -1, msm_split = -1, fused_columns = -1, prove_prio = -1, prove_fused = -1, static_gemm = -1, lazy_columns = -1, ct = -1, prove_parts = -1, prove_waves = -1, prove_fifo = -1, chain = -1, chain_test_zero = 0, wait = -1, ct_back = -1, chain_inline = -1, wide_in_lanes = -1;
   } opt;
   std::unique_ptr<Pipeline> pipe;  // bpp_verify_submit_packed / bpp_verify_collect: lanes, tickets (built on first submit)
   std::mutex pipe_init_mu;
@@ -627,6 +627,8 @@ const OptionName kOptions[] = {
     {"wait", "BPP_WAIT", &bpp_ctx::Options::wait},
     // the device chains (chain = 1) behind PASS 1 on the call's own stream (1) instead of a stream of their own beside the decompression (0)
     {"chain_inline", "BPP_CHAIN_INLINE", &bpp_ctx::Options::chain_inline},
+    // chain = 2: the reduction mod l of the host sponges' bytes in k_scalars_lanes' prologue (1, the rule) or as a launch of its own (0)
+    {"wide_in_lanes", "BPP_WIDE_IN_LANES", &bpp_ctx::Options::wide_in_lanes},
 };
 void options_from_env(bpp_ctx *c) {
   for (const OptionName &o : kOptions)
@@ -712,7 +714,14 @@ inline void gpu_wait_event(hipEvent_t ev, bool nap, WaitHint *wh = nullptr, uint
     if (tail_spin && (slept_ahead || !hint || *hint <= 600)) continue;
     long nap_us;
     if (hint && !slept_ahead && *hint > 600 && waited < (long)*hint / 2) {
-      nap_us = (long)*hint * 7 / 10 - waited;  // the bulk of an expected wait in one piece
+      // the bulk of an expected wait in one piece: HALF of what the last waits took when naps follow, 70 % when the rest is looked
+      // through.  (70 % for the napping callers too overslept in short runs: between two synchronisations the steps in flight
+      // start together and stay in step, their waits spread from 6 to 13 ms around the remembered 10, a caller that sleeps past
+      // its step's end restarts its slot late and the steps in step with it all shift -- the driver's 20-step form of bench.py
+      // read 25.1 M proofs/s with 70 %, 25.6 with 60 %, 25.8-26.2 with 50 %, 26.0 with 40 %, 25.9-26.0 under the runtime's
+      // spinning wait; 256-step runs and the callers' CPU time do not change: profiles/r06_wait_ahead_ab.txt)
+      nap_us = (long)*hint * (tail_spin ? 7 : 5) / 10 - waited;
+      if (nap_us < 50) nap_us = 50;
       slept_ahead = true;
     } else if (slept_ahead && waited < (long)*hint * 5 / 4) {
       nap_us = 50;  // the expected end is near: short naps (a call at a time wakes up within one of them)
@@ -1731,12 +1740,14 @@ ChainMode chain_mode(const bpp_ctx *ctx, const Batch &b, bool allow_device_work)
   if (ctx->opt.chain >= 0 && ctx->opt.chain <= 2) return (ChainMode)ctx->opt.chain;
   return b.B >= BPP_WAIT_NAP_MIN_PROOFS ? CHAIN_HOST_WIDE : CHAIN_HOST;
 }
-// the wide bytes of the host sponges (b.h_wide, mapped) -> b.weights
-void enqueue_finish_wide(bpp_ctx *ctx, Batch &b, hipStream_t st) {
+// the wide bytes of the host sponges (b.h_wide, mapped) -> b.weights.  launch = false: k_scalars_lanes does it in its prologue
+// (enqueue_phase2), this only arms the zero flag
+void enqueue_finish_wide(bpp_ctx *ctx, Batch &b, hipStream_t st, bool launch = true) {
   if (!ctx->h_chain_zero.p) ctx->h_chain_zero.resize(1);
   ctx->h_chain_zero[0] = 0;
   const uint32_t test_zero = ctx->opt.chain_test_zero > 0 ? (uint32_t)ctx->opt.chain_test_zero : 0u;
-  hipLaunchKernelGGL(k_chain_finish_bytes, dim3(cdiv(b.B, 64)), dim3(64), 0, st, b.h_wide.dev(), b.B, b.weights.p, ctx->h_chain_zero.dev(), test_zero);
+  if (launch)
+    hipLaunchKernelGGL(k_chain_finish_bytes, dim3(cdiv(b.B, 64)), dim3(64), 0, st, b.h_wide.dev(), b.B, b.weights.p, ctx->h_chain_zero.dev(), test_zero);
   ctx->wide_chain_calls++;
 }
 
@@ -2269,12 +2280,19 @@ void layout_groups(bpp_ctx *ctx, Batch &b, size_t chunk, const std::vector<uint3
 
 // Weight-dependent tail: h_weights -> device, the weighted generator rows and dynamic scalars (k_scalars_lanes), the
 // per-group column sums, final MSM.
-void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool weights_resident = false) {
+// wide: chain = 2, the host sponges' 64 bytes per proof stand in b.h_wide (mapped).  When k_scalars_lanes is the kernel that takes
+// the weights it reads and reduces them itself and leaves the canonical weights in b.weights (option "wide_in_lanes", on by
+// rule: one launch fewer on the step's latency chain -- between two synchronisations the steps in flight run in step and every
+// launch of the chain counts: the driver's 20-step form + 1-2 %, profiles/r06_wait_ahead_ab.txt); the matrix-product form of the
+// generator columns keeps k_chain_finish_bytes in front
+void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool weights_resident = false, bool wide = false) {
   Params &P = *b.params;
   hipStream_t s = ctx->stream;
   // (weights_resident: the grouped sharded form has put them into b.weights device -> device already)
   // otherwise k_scalars_lanes reads them where the chains wrote them: h_weights is mapped, each weight is read once
   plan_lanes(ctx, b, true);
+  const bool wide_in_lanes = wide && !b.static_gemm && ctx->opt.wide_in_lanes != 0;
+  if (wide) enqueue_finish_wide(ctx, b, s, !wide_in_lanes);
   if (b.dev_chain_pending) {  // the device chain of this call (enqueue_phase1) has written b.weights
     HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_chain_done, 0));
     b.dev_chain_pending = false;
@@ -2297,7 +2315,9 @@ void enqueue_phase2(bpp_ctx *ctx, Batch &b, StageTimer &tm, bool weights_residen
     } else
       hipLaunchKernelGGL(k_scalars_lanes, dim3(cdiv(b.B, ppw)), dim3(64), ppw * lanes_lds_bytes(nhi_max), s, b.d_desc.p, b.tab.p, b.shr.p,
                          weights, P.n_bits, P.t, b.max_mn, b.cols, b.B, nhi_max, ppw, b.rows.p, dyn_scal,
-                         b.fused_columns ? b.parts.p : (uint64_t *)nullptr, ctx->opt.lazy_columns != 0 ? 1u : 0u);
+                         b.fused_columns ? b.parts.p : (uint64_t *)nullptr, ctx->opt.lazy_columns != 0 ? 1u : 0u,
+                         wide_in_lanes ? b.h_wide.dev() : (const uint8_t *)nullptr, b.weights.p, ctx->h_chain_zero.dev(),
+                         ctx->opt.chain_test_zero > 0 ? (uint32_t)ctx->opt.chain_test_zero : 0u);
   }
   tm.mark(M_LANES);
   if (b.static_gemm) {
@@ -2421,8 +2441,7 @@ static int verify_resident_locked(bpp_ctx *ctx, uint64_t batch, int action, size
         have_masks = true;
       }
       if (want_msm) {
-        if (cmode == CHAIN_HOST_WIDE) enqueue_finish_wide(ctx, b, s);
-        enqueue_phase2(ctx, b, tm, cmode != CHAIN_HOST);
+        enqueue_phase2(ctx, b, tm, cmode != CHAIN_HOST, cmode == CHAIN_HOST_WIDE);
         b.have_trace = true;
       }
     }
@@ -2525,8 +2544,7 @@ int verify_groups_core_once(bpp_ctx *ctx, uint64_t batch, const uint32_t *group_
       b.masks_dirty = true;
     }
     if (want_msm) {
-      if (cmode == CHAIN_HOST_WIDE) enqueue_finish_wide(ctx, b, s);
-      enqueue_phase2(ctx, b, tm, cmode != CHAIN_HOST);
+      enqueue_phase2(ctx, b, tm, cmode != CHAIN_HOST, cmode == CHAIN_HOST_WIDE);
       b.have_trace = true;
     }
     fetch_results(ctx, b, want_msm, want_masks);

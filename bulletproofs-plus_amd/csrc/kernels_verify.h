@@ -652,7 +652,13 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
                                                       sc *__restrict__ rows /* weighted, Montgomery */,
                                                       sc *__restrict__ dyn_out /* canonical */,
                                                       uint64_t *__restrict__ parts /* null, or [workgroup][2 max_mn][8] limb sums */,
-                                                      uint32_t lazy /* with parts: one reduction per (workgroup, column) */) {
+                                                      uint32_t lazy /* with parts: one reduction per (workgroup, column) */,
+                                                      // chain = 2 (host sponges, chain_dev.h): the 64 PRF bytes per proof in mapped host memory instead of
+                                                      // weights32 -- reduced mod l here (Scalar::from_bytes_mod_order_wide, scalar_protocol.rs:23-30), the
+                                                      // canonical weight left in weights_out for traces, a zero weight raises *zero_flag (the call then
+                                                      // runs again with the chains on the host, which redraw): one launch fewer on a step's latency chain
+                                                      const uint8_t *__restrict__ wide64 = nullptr, uint8_t *__restrict__ weights_out = nullptr,
+                                                      uint32_t *__restrict__ zero_flag = nullptr, uint32_t test_zero = 0) {
   const uint32_t p0 = blockIdx.x * ppw;
   const uint32_t lane = threadIdx.x;
   extern __shared__ uint32_t lanes_lds_raw[];
@@ -677,9 +683,29 @@ __global__ void __launch_bounds__(64) k_scalars_lanes(const ProofDesc *__restric
     s_r[lane] = r;  // ~0: nothing to do for this slot (past the end, or a shape rejected on the host before PASS 2)
     s_m[lane] = m;
     s_dyn[lane] = dyn_off;
+    sc wc;
+    if (wide64 && p < B) {  // (every proof of the batch, whatever its shape: what k_chain_finish_bytes does)
+      uint32_t ww[16];
+      const uint4 *src = reinterpret_cast<const uint4 *>(wide64 + (size_t)p * 64);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint4 v = src[q];
+        ww[4 * q] = v.x;
+        ww[4 * q + 1] = v.y;
+        ww[4 * q + 2] = v.z;
+        ww[4 * q + 3] = v.w;
+      }
+      sc wm;
+      sc_mont_from_wide_words(wm, ww);
+      sc_from_mont(wc, wm);
+      if (sc_iszero(wc) || p + 1 == test_zero) *zero_flag = 1u;  // (mapped host memory: every writer writes the same word)
+      uint4 *dst = reinterpret_cast<uint4 *>(weights_out + (size_t)p * 32);
+      dst[0] = make_uint4(wc.v[0], wc.v[1], wc.v[2], wc.v[3]);
+      dst[1] = make_uint4(wc.v[4], wc.v[5], wc.v[6], wc.v[7]);
+    }
     if (r != ~0u) {
-      sc wc, w;
-      sc_load_words(wc, weights32 + (size_t)p * 32);
+      sc w;
+      if (!wide64) sc_load_words(wc, weights32 + (size_t)p * 32);
       sc_to_mont(w, wc);
       s_mult[lane][0] = w;
       s_mult[lane][4] = wc;

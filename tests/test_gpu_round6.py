@@ -151,6 +151,31 @@ def test_device_chain_zero_weight_goes_back_to_the_host_chain(bpp, packed, engin
     engine.set_option("chain_test_zero", 0)  # (the fixture restores options to -1: this one's neutral value is 0)
 
 
+def test_wide_reduction_in_the_lanes_kernel_or_on_its_own(bpp, packed, engine, opt, cfg2):
+    """chain = 2: the reduction mod l of the host sponges' 64 bytes per proof runs in k_scalars_lanes' prologue (option "wide_in_lanes",
+    the rule) or as k_chain_finish_bytes in front of it (0, and whenever the generator columns are a matrix product): the same weights as
+    the oracle's either way, ragged last workgroup included, and a zero weight found in the prologue sends the call back to the host
+    chains just the same"""
+    params, d = cfg2
+    n = 1024 + 452
+    rb = _resident(packed, params, d, 0, n)
+    opt("chain", 2)
+    want = _oracle_weights(d, 0, n)
+    for in_lanes in (1, 0):
+        opt("wide_in_lanes", in_lanes)
+        rb.verify_only(chunk=0)
+        assert rb.trace(6) == bytes(32) and rb.trace(3) == want, in_lanes
+    opt("wide_in_lanes", 1)
+    opt("chain_test_zero", n)  # the last proof, in the partly filled last workgroup
+    before = engine.device_chain_stats()
+    rb.verify_only(chunk=0)
+    assert engine.device_chain_stats() == (before[0] + 1, before[1] + 1)
+    assert rb.trace(6) == bytes(32) and rb.trace(3) == want
+    opt("chain_test_zero", 0)
+    engine.set_option("chain_test_zero", 0)
+    rb.close()
+
+
 def test_device_chain_stage_profile(bpp, packed, engine, opt, cfg2):
     """with stage profiling on the chain runs in line on the call's stream and its interval is reported as chain_device_ms; the
     host chain's wall time stays zero"""
