@@ -3,7 +3,8 @@
 
 usage (GPU box):  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline --no-traffic
                   python3 tools/timeline.py gpurun_out/tl gpurun_out/timeline.txt [steps]
-The timed steps are taken to be the last `steps` (+3 calibration) k_transcripts dispatches of the trace."""
+The timed region is the last burst of exactly `steps` steps between two moments with nothing running (bench.py synchronises on both
+sides of it).  With a fourth argument every kernel of the region is listed as well (start, end, duration, queue, name)."""
 import csv, glob, os, sys, collections
 
 
@@ -21,11 +22,22 @@ def main():
     d, out = sys.argv[1], sys.argv[2]
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
     rows = load(d)
-    tr = [r for r in rows if r[2].startswith("k_transcripts")]
-    first = tr[-(steps + 3)][0]          # first timed step's first kernel
-    last_tr = tr[-4]                     # last timed step's first kernel
-    fin = [r for r in rows if r[2].startswith("k_msm_final")]
-    end = fin[-4][1]
+    # the timed region: bench.py synchronises on both sides of it, so it is a burst of kernels between two moments with nothing
+    # running -- the LAST burst holding exactly `steps` k_transcripts dispatches (the calibration's solo steps and the stage-profile
+    # runs behind it are bursts of their own)
+    bursts, cur, cur_end = [], [], 0
+    for r in rows:
+        if cur and r[0] - cur_end > 100000:  # 0.1 ms of nothing
+            bursts.append(cur)
+            cur, cur_end = [], 0
+        cur.append(r)
+        cur_end = max(cur_end, r[1])
+    if cur:
+        bursts.append(cur)
+    timed = [b for b in bursts if sum(1 for r in b if r[2].startswith("k_transcripts")) == steps]
+    if not timed:
+        raise SystemExit("no burst of %d steps in the trace: %r" % (steps, [sum(1 for r in b if r[2].startswith("k_transcripts")) for b in bursts][-12:]))
+    first, end = timed[-1][0][0], max(r[1] for r in timed[-1])
     win = [r for r in rows if r[0] >= first and r[1] <= end]
     T = end - first
     # union busy time / concurrency histogram by sweeping
@@ -61,7 +73,11 @@ def main():
                 if n.startswith("k_msm_final") and cur is not None:
                     o.write("  q%s %8.3f %8.3f %7.3f\n" % (q, (cur - first) / 1e6, (e - first) / 1e6, (e - cur) / 1e6))
                     cur = None
-    print(open(out).read())
+        if len(sys.argv) > 4:
+            o.write("kernels (start ms, end ms, us, queue, name):\n")
+            for s, e, n, q in win:
+                o.write("  %8.3f %8.3f %8.1f q%s %s\n" % ((s - first) / 1e6, (e - first) / 1e6, (e - s) / 1e3, q, n))
+    print(open(out).read() if len(sys.argv) <= 4 else "written: " + out)
 
 
 if __name__ == "__main__":
