@@ -828,6 +828,9 @@ def main():
     # Several ranks on one host share its cores: each process's pool of weight-chain workers (default: up to 32) is sized to
     # its share before the library is loaded, so that eight ranks do not put 256 runnable threads on the node.
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    # ranks as processes share device memory through dmabuf handles only on this pool (RCCL's P2P setup otherwise fails with
+    # hipIpcGetMemHandle: invalid argument); the GPU boxes export it already -- kept when the launcher's environment does not
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world_env > 1 and "BPP_HOST_THREADS" not in os.environ:
         os.environ["BPP_HOST_THREADS"] = str(max(4, min(32, usable_cpus() // world_env)))
     # where the weight chains run: read by the library once per context, when it is created (BPP_CHAIN)
