@@ -892,11 +892,31 @@ def main():
         al3 = [leg3.one_step(0)[1].get("msm_accumulate_ms", 0.0) for _ in range(3)]
         roof3, st3 = kernel_roofline(pr3, sum(al3) / 3 if min(al3) > 0 else None)
         leg3.close()
-        p3.close()
         res = {"workload": "BASELINE configs[2]: reference batches of 256 x aggregation-8 64-bit proofs, extension degree 1; "
                            "one step = %d such batches, %d steps in flight" % (R3, S3),
                "proofs_per_s": 256 * R3 * steps / el3, "ms_per_step": 1e3 * el3 / steps, "steps": steps, "roofline": roof3,
                "stages_ms": st3}
+        if not only and d3["proofs"].shape[0] >= 4096:
+            # north_star's target sentence, literally: AGGREGATED proofs "on a batch of 4096 on one MI355X" -- 4096 of this leg's
+            # aggregation-8 proofs as ONE reference batch per call (chunk = 0: one weight chain over 4096 proofs, 1024 generator
+            # columns, one 119 809-term MSM; held to the oracle at this size by tests/test_gpu_round6.py), several calls in flight
+            try:
+                Sa = int(os.environ.get("BPP_BENCH_AGG4096_INFLIGHT", "8"))
+                lega = Leg(bpp, packed, torch, device, p3, d3, 4096, 1, Sa, 0, profile=False)
+                na = 10 * Sa
+                ela, lata, _ = timed(lega, na, 3 * Sa, sync, preheat_ms=SIDE_PREHEAT_MS)
+                sync()
+                ala = [lega.one_step(0)[0] for _ in range(5)]
+                lega.close()
+                agg = {"workload": "4096 x aggregation-8 64-bit proofs as ONE reference batch per call (chunk = 0), %d calls in flight, "
+                                   "each on another 4096 proofs" % Sa, "proofs_per_s": 4096 * na / ela,
+                       "values_per_s": 8 * 4096 * na / ela, "ms_per_batch_in_flight": 1e3 * sum(lata) / len(lata),
+                       "ms_per_batch_alone": 1e3 * sum(ala) / len(ala), "calls": na}
+                res["agg4096"] = cpu_side(agg, lambda: cpu_verify_baseline((64, 8, 1), d3, 4096, seconds=args.cpu_leg_seconds / 2,
+                                                                          all_cores=False))
+            except Exception as e:  # noqa: BLE001 - reported inside the object, the leg's own numbers stand
+                res["agg4096"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        p3.close()
         # benches/range_proof.rs:206-262 on the host: the same 256 x aggregation-8 batches through the CPU port
         return cpu_side(res, lambda: cpu_verify_baseline((64, 8, 1), d3, 256, seconds=args.cpu_leg_seconds))
 

@@ -196,6 +196,55 @@ def test_device_chain_stage_profile(bpp, packed, engine, opt, cfg2):
         rb.close()
 
 
+def test_north_star_target_shape_4096_aggregated_proofs_as_one_batch(bpp, packed, engine, opt):
+    """BASELINE.json's target sentence: "aggregated 64-bit range-proof verifications ... on a batch of 4096 on one MI355X, bit-exact vs
+    reference".  4096 aggregation-8 proofs (bench.py's recipe, benches/range_proof.rs:206-262) as ONE reference batch (chunk = 0: one
+    weight chain over 4096 proofs, 1024 generator columns, a 119 809-term MSM; src/range_proof.rs:756-1065): accepted, and the weights,
+    the accumulated generator scalars, every dynamic scalar and the final point are the C oracle's for the same batch -- with the
+    generator columns as the engine's rule takes them (the int8 matrix product) and as per-proof products; a tampered proof leaves the
+    same non-identity point in both forms and the oracle's verdict"""
+    import struct
+    import bench
+    params = bpp.RangeParameters.init(64, 8, bpp.create_pedersen_gens_with_extension_degree(1), engine=engine)
+    n = 4096
+    d = bench.make_inputs(np, packed, params, n, seed=20261006)
+    cp = cport.Params(64, 8, 1)
+    items = bench.cpu_items(d, range(n))
+    rc, _, tr = cp.verify(items, action=0, want_trace=True)
+    assert rc == 0 and tr["msm_result"] == bytes(32)
+    rb = packed.ResidentBatch(params, d["proofs"], d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+    forms = {}
+    for gemm in (-1, 0):
+        opt("static_gemm", gemm)
+        rb.verify_only(chunk=0)
+        shp = rb.shape()
+        assert shp["groups"] == 1 and shp["max_mn"] == 512 and shp["total_dyn"] == n * 29
+        forms[gemm] = struct.unpack("<4I", rb.trace(7))[0] & 2
+        assert rb.trace(3) == tr["weights"], gemm
+        assert rb.trace(4) == tr["static_scalars"], gemm
+        assert rb.trace(5) == tr["dynamic_scalars"], gemm
+        assert rb.trace(6) == tr["msm_result"], gemm
+    assert forms[-1] == 2 and forms[0] == 0  # the rule took the matrix product; the other run did not
+    rb.close()
+    bad = d["proofs"].copy()
+    bad[2999, 1 + 32 + 96 + 3] ^= 0x20  # r1 of one proof: the batch fails in its sum only
+    items[2999] = dict(items[2999], proof=bad[2999].tobytes())
+    rc_bad, _, tr_bad = cp.verify(items, action=0, want_trace=True)
+    cp.close()
+    assert rc_bad == int(bpp.ProofErrorKind.VerificationFailed)
+    points = []
+    rb = packed.ResidentBatch(params, bad, d["commitments"], d["min_values"], d["min_present"], None, LABEL)
+    for gemm in (-1, 0):
+        opt("static_gemm", gemm)
+        with pytest.raises(bpp.ProofError) as e:
+            rb.verify_only(chunk=0)
+        assert e.value.kind == bpp.ProofErrorKind.VerificationFailed
+        points.append(rb.trace(6))
+    rb.close()
+    params.close()
+    assert points[0] == points[1] == tr_bad["msm_result"] != bytes(32)  # (the oracle's sum as well: the same group element)
+
+
 def test_wait_memory_is_per_workload(bpp, packed):
     """A context remembers how long its calls take and sleeps most of that in one piece (csrc/engine.hip: gpu_wait_event) -- for the SAME
     work only: one build slept through 1024-proof prover calls on the memory of the 8192-proof calls the context had made before
